@@ -1,0 +1,153 @@
+/*
+ * include/maple_hip.h -- C ABI of libmaple_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the sample-placement / SPR candidate-scoring path of
+ * MAPLE v0.7.5.4 (reference: MAPLEv0.7.5.4.py, cited as M:<line>).  The
+ * reference has no FFI; its de-facto operator boundary is the set of
+ * top-level pure functions the search loops call.  Each
+ * entry point below is the batched form of one of them and names it.
+ *
+ * Conventions: every function returns 0 on success and a negative code on
+ * error (text via maple_last_error); nothing throws or exits.  All `const T*`
+ * arguments are HOST buffers owned by the caller unless the name ends in
+ * `_dev` (then they are device pointers on the context's GPU and the call is
+ * asynchronous on `stream`).  A context is bound to one GPU and is not
+ * thread-safe.
+ *
+ * Genome lists (M:378-390) live in device memory as a CSR arena:
+ *   word  = { int32 pos ; uint32 meta }            8 bytes per entry
+ *   meta  = type[0:2] | ref[3:4] | hasD0[5] | hasD1[6] | flag[7] | auxoff[8:31]
+ *   aux   = per list, f64 stream: for each entry, in order,
+ *           [d0 if hasD0][d1 if hasD1][vec0..3 if type==6]; auxoff = index of
+ *           the entry's first double inside the list's aux block.
+ * `pos` is the 1-based LAST genome position the entry covers (for the
+ * single-site types 0-3 and 6 that is the site itself); `ref` is the local
+ * reference nucleotide of single-site entries; `flag` is the error-model flag
+ * that exists only when the model uses error rates.  The Python tuple length
+ * of the reference is recovered from hasD0/hasD1 (+1 when the error model is
+ * on and a tail exists).
+ */
+#ifndef MAPLE_HIP_H
+#define MAPLE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAPLE_ABI_VERSION 1
+
+enum {
+    MAPLE_OK = 0,
+    MAPLE_ERR_ARG = -1,      /* bad argument                                   */
+    MAPLE_ERR_HIP = -2,      /* HIP runtime error (message has the call)       */
+    MAPLE_ERR_NOMEM = -3,    /* arena exhausted                                */
+    MAPLE_ERR_STATE = -4,    /* model / lists not set                          */
+    MAPLE_ERR_FATAL = -5     /* a state the reference treats as raise Exception("exit") */
+};
+
+#define MAPLE_META_TYPE(m)   ((m) & 7u)
+#define MAPLE_META_REF(m)    (((m) >> 3) & 3u)
+#define MAPLE_META_HASD0     (1u << 5)
+#define MAPLE_META_HASD1     (1u << 6)
+#define MAPLE_META_FLAG      (1u << 7)
+#define MAPLE_META_AUXOFF(m) ((m) >> 8)
+
+typedef struct maple_ctx maple_ctx;
+
+/* thresholds and derived constants of M:51-62, M:3606-3624 */
+typedef struct {
+    double thresholdProb;              /* --thresholdProb, M:51                 */
+    double minBLenSensitivity;         /* already multiplied by 1/lRef, M:3619  */
+    double thresholdDiffForUpdate;     /* M:61                                  */
+    double thresholdFoldChangeUpdate;  /* M:62                                  */
+    double defaultBLen;                /* M:77 (evaluatePlacement fallback)     */
+} maple_params;
+
+/* ---- life cycle ----------------------------------------------------------- */
+int maple_abi_version(void);
+/* refIdx = refIndeces (M:3681-3686), rootFreqs (M:3677-3680 / JC M:3687-3689).
+ * arena_bytes = device memory reserved for genome lists (0 = default 1 GiB). */
+int maple_create(maple_ctx **out, int device, int32_t lRef, const uint8_t *refIdx,
+                 const double *rootFreqs4, const maple_params *params, uint64_t arena_bytes);
+int maple_destroy(maple_ctx *ctx);
+const char *maple_last_error(maple_ctx *ctx);
+
+/* Model tables: replaces the *Passed / *Global keyword arguments of the
+ * reference's functions (M:4446, 5040, 6505, 6817) and derives
+ * cumulativeRate / cumulativeErrorRate / totError on the way exactly as
+ * updateMutMatrices (M:6350-6370) and updateErrorRates (M:6373-6390) do.
+ * siteRates != NULL <=> useRateVariation; errorRates != NULL <=> errorRateSiteSpecific. */
+int maple_set_model(maple_ctx *ctx, const double *Q16, const double *siteRates, int usingErrorRate,
+                    double errorRateGlobal, const double *errorRates);
+/* read back derived tables (for parity checks): any pointer may be NULL */
+int maple_get_model(maple_ctx *ctx, double *cumulativeRate /*[lRef+1]*/, double *cumulativeErrorRate /*[lRef+1]*/,
+                    double *totError);
+
+/* ---- genome-list arena ------------------------------------------------------ */
+/* Upload n_lists packed lists; ids first_id .. first_id+n_lists-1 are assigned.
+ * ent_off / aux_off are CSR offsets with n_lists+1 elements. */
+int maple_lists_upload(maple_ctx *ctx, int32_t n_lists, const int64_t *ent_off, const int32_t *pos,
+                       const uint32_t *meta, const int64_t *aux_off, const double *aux, int32_t *first_id);
+int maple_lists_sizes(maple_ctx *ctx, int32_t n, const int32_t *ids, int32_t *n_ent, int32_t *n_aux);
+/* Download into caller buffers sized from maple_lists_sizes (CSR, same layout as upload). */
+int maple_lists_download(maple_ctx *ctx, int32_t n, const int32_t *ids, const int64_t *ent_off, int32_t *pos,
+                         uint32_t *meta, const int64_t *aux_off, double *aux);
+/* Stack discipline for temporaries: everything created after `mark` is dropped. */
+int maple_arena_mark(maple_ctx *ctx, int64_t *mark);
+int maple_arena_release(maple_ctx *ctx, int64_t mark);
+int maple_arena_stats(maple_ctx *ctx, int64_t *n_lists, int64_t *n_entries, int64_t *n_aux, int64_t *cap_entries);
+
+/* MAT branch mutation lists (tree.mutations[node], M:336): triples (pos, from, to). CSR upload. */
+int maple_mutations_upload(maple_ctx *ctx, int32_t n_lists, const int64_t *off, const int32_t *mut3,
+                           int32_t *first_id);
+
+/* ---- batched operators (host index arrays in, host results out) -------------- */
+/* appendProbNode(probVectP, probVectC, isTipC, bLen), M:6505-6785 -> log-LK (may be -inf) */
+int maple_append_batch(maple_ctx *ctx, int32_t n, const int32_t *parentList, const int32_t *childList,
+                       const uint8_t *isTipC, const double *bLen, double *outLK);
+/* mergeVectors(pv1,bLen1,fromTip1,pv2,bLen2,fromTip2,isUpDown=...), M:4446-4859.
+ * outList[i] = new list id, or -1 where the reference returns None.
+ * outLK may be NULL; when given, the returnLK=True value (M:4856) is also produced
+ * (numMinor1/2 may be NULL = 0). */
+int maple_merge_batch(maple_ctx *ctx, int32_t n, const int32_t *list1, const double *bLen1, const uint8_t *fromTip1,
+                      const int32_t *list2, const double *bLen2, const uint8_t *fromTip2, const uint8_t *isUpDown,
+                      const int32_t *numMinor1, const int32_t *numMinor2, int32_t *outList, double *outLK);
+/* estimateBranchLengthWithDerivative(P, C, fromTipC), M:5040-5358; isFalse[i]=1 where it returns False */
+int maple_blen_batch(maple_ctx *ctx, int32_t n, const int32_t *parentList, const int32_t *childList,
+                     const uint8_t *fromTipC, double *t, uint8_t *isFalse);
+/* areVectorsDifferent(pv1, pv2), M:5419-5472; list2 == -1 means None -> different */
+int maple_differ_batch(maple_ctx *ctx, int32_t n, const int32_t *list1, const int32_t *list2, uint8_t *out);
+/* passGenomeListThroughBranch(probVect, mutations, dirIsUp), M:3749-3877 */
+int maple_pass_branch_batch(maple_ctx *ctx, int32_t n, const int32_t *list, const int32_t *mutList,
+                            const uint8_t *dirIsUp, int32_t *outList);
+/* shorten(vec), M:3721-3745 (produces a new list; the input is left untouched) */
+int maple_shorten_batch(maple_ctx *ctx, int32_t n, const int32_t *list, int32_t *outList);
+/* rootVector(probVect, bLen, isFromTip, tree, node), M:4916-4996.  The walk to the root
+ * (M:4930-4940, 4988-4993) is given as a CSR of mutation-list ids per call, node first, root last. */
+int maple_root_vector_batch(maple_ctx *ctx, int32_t n, const int32_t *list, const double *bLen,
+                            const uint8_t *isFromTip, const int64_t *pathOff, const int32_t *pathMutLists,
+                            int32_t *outList);
+/* evaluatePlacement(midTot, downVect, upVect, distance, removedPartials, isRemovedTip, ..., fromTip1), M:6790-6806
+ * out4[i*4..] = appendingCost, bestBottomLength, bestTopLength, bestAppendingLength (False -> 0.0) */
+int maple_evaluate_placement_batch(maple_ctx *ctx, int32_t n, const int32_t *midTot, const int32_t *downVect,
+                                   const int32_t *upVect, const double *distance, const int32_t *removedPartials,
+                                   const uint8_t *isRemovedTip, const uint8_t *fromTip1, double *out4);
+
+/* ---- device-resident forms (inputs already in HBM; asynchronous on `stream`) --- */
+int maple_append_batch_dev(maple_ctx *ctx, int32_t n, const int32_t *parentList_dev, const int32_t *childList_dev,
+                           const uint8_t *isTipC_dev, const double *bLen_dev, double *outLK_dev, void *stream);
+/* One query against many candidates (the placement loop, M:8050): the child list is staged
+ * once per workgroup in LDS.  cand_dev holds n parent-side list ids. */
+int maple_append_query_dev(maple_ctx *ctx, int32_t n, int32_t childList, int isTipC, double bLen,
+                           const int32_t *cand_dev, double *outLK_dev, void *stream);
+/* Time the most recent *_dev launch with HIP events on its own stream (milliseconds). */
+int maple_last_kernel_ms(maple_ctx *ctx, float *ms);
+/* algorithmic bytes (8*E + 8*B + 32*O + 8 per candidate, child list once per query) */
+int maple_append_algorithmic_bytes(maple_ctx *ctx, int32_t n, const int32_t *parentList, const int32_t *childList,
+                                   int child_once, uint64_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,757 @@
+// maple_amd/csrc/genome_dev.h -- gfx950 device functions for MAPLE genome lists.
+//
+// Packed CSR genome lists (see include/maple_hip.h) are walked by ONE LANE per
+// (parent, child) pair; 64 independent walks per wavefront.  The arithmetic
+// follows MAPLE v0.7.5.4 (reference MAPLEv0.7.5.4.py, cited as M:<line>) in
+// operand order so that fp64 results are reproducible; compile with
+// -ffp-contract=off.  The 4x4 rate matrix and root frequencies live in LDS
+// (dynamic per-lane indexing), per-site rate / error vectors are gathered
+// through L2 only at non-reference sites.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace maple {
+
+// ---- model ---------------------------------------------------------------------
+struct DevModel {                      // kernel argument (uniform -> SGPRs)
+    int32_t lRef;
+    int32_t useRateVariation, usingErrorRate, errorRateSiteSpecific;
+    const double *siteRates;           // [lRef] or null
+    const double *errorRates;          // [lRef] or null
+    const double *cumulativeRate;      // [lRef+1]
+    const double *cumulativeErrorRate; // [lRef+1] or null
+    double Q[16];
+    double rootFreqs[4];
+    double errorRate, totError, globalTotRate, minimumCarryOver;
+    double thresholdProb, thresholdProb4, minBLenSensitivity, thresholdDiffForUpdate, thresholdFoldChangeUpdate;
+    double defaultBLen;
+};
+
+struct Lds {                           // per-workgroup staging of the tiny tables
+    double Q[16];
+    double rf[4];
+};
+
+__device__ inline void stage_model(const DevModel &m, Lds &s)
+{
+    if (threadIdx.x < 16) s.Q[threadIdx.x] = m.Q[threadIdx.x];
+    if (threadIdx.x < 4) s.rf[threadIdx.x] = m.rootFreqs[threadIdx.x];
+    __syncthreads();
+}
+
+template <bool RV, bool U, bool SS> struct Ctx {
+    const DevModel &m;
+    const double *Q;                   // LDS
+    const double *rf;                  // LDS
+    __device__ Ctx(const DevModel &m_, const Lds &s) : m(m_), Q(s.Q), rf(s.rf) {}
+    // site rate multiplier of mutMatrices[pos] = Q * siteRates[pos]  (M:6361-6366)
+    __device__ inline double rate(int pos) const { return RV ? m.siteRates[pos] : 1.0; }
+    __device__ inline double q(double r, int i, int j) const { return RV ? Q[i * 4 + j] * r : Q[i * 4 + j]; }
+    // errorRate resolved like "if usingErrorRate and errorRateSiteSpecific: errorRate=errorRates[pos]"
+    __device__ inline double err(int pos) const { return (U && SS) ? m.errorRates[pos] : m.errorRate; }
+};
+
+// ---- packed lists -----------------------------------------------------------------
+struct ListRef {
+    const uint2 *w;                    // entry words {pos, meta}
+    const double *aux;                 // this list's aux block
+};
+
+struct Ent {                           // decoded view of one entry
+    int pos;                           // last covered position (1-based)
+    int type;                          // 0-3 nuc, 4 R, 5 N, 6 O
+    int ref;                           // local reference nucleotide (single-site entries)
+    bool hasD0, hasD1, flag;
+    double d0, d1;
+    const double *vec;                 // type 6
+    __device__ inline bool single() const { return type < 4 || type == 6; }
+};
+
+struct Cursor {
+    ListRef l;
+    int idx;
+    Ent e;
+    __device__ inline void load()
+    {
+        uint2 w = l.w[idx];
+        e.pos = (int)w.x;
+        uint32_t meta = w.y;
+        e.type = meta & 7u;
+        e.ref = (meta >> 3) & 3u;
+        e.hasD0 = meta & (1u << 5);
+        e.hasD1 = meta & (1u << 6);
+        e.flag = meta & (1u << 7);
+        const double *a = l.aux + (meta >> 8);
+        e.d0 = 0.0; e.d1 = 0.0;
+        if (e.hasD0) { e.d0 = *a++; }
+        if (e.hasD1) { e.d1 = *a++; }
+        e.vec = a;
+    }
+    __device__ inline void init(ListRef r) { l = r; idx = 0; load(); }
+    __device__ inline void next() { ++idx; load(); }
+    // common tail of every two-list walk (e.g. M:4841-4854): step past single-site entries
+    // and past runs that end at `pos`
+    __device__ inline void step(int pos) { if (e.single() || e.pos == pos) next(); }
+};
+
+struct Writer {                        // builds one packed list
+    uint2 *w;
+    double *aux;
+    int n, na;
+    __device__ inline void init(uint2 *w_, double *a_) { w = w_; aux = a_; n = 0; na = 0; }
+    __device__ inline void put(int type, int pos, int ref, bool hasD0, double d0, bool hasD1, double d1, bool flag,
+                               const double *vec)
+    {
+        uint32_t meta = (uint32_t)type | ((uint32_t)ref << 3) | (hasD0 ? 1u << 5 : 0u) | (hasD1 ? 1u << 6 : 0u)
+                        | (flag ? 1u << 7 : 0u) | ((uint32_t)na << 8);
+        w[n++] = make_uint2((uint32_t)pos, meta);
+        if (hasD0) aux[na++] = d0;
+        if (hasD1) aux[na++] = d1;
+        if (type == 6) { aux[na] = vec[0]; aux[na + 1] = vec[1]; aux[na + 2] = vec[2]; aux[na + 3] = vec[3]; na += 4; }
+    }
+    __device__ inline void bare(int type, int pos, int ref) { put(type, pos, ref, false, 0, false, 0, false, nullptr); }
+    __device__ inline void copy(const Ent &e, int type, int pos, int ref)
+    {
+        put(type, pos, ref, e.hasD0, e.d0, e.hasD1, e.d1, e.flag, e.vec);
+    }
+};
+
+// ---- getPartialVec (M:4073-4141) -----------------------------------------------------
+// O vector moved along a branch: v + t*(Q v) going down, v + t*(Q^T v) going up
+template <class C> __device__ inline void gpv_vec(const C &c, double r, const double *v, double t, bool up, double *out)
+{
+    if (t == 0.0) { out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3]; return; }
+    double nv[4];
+    bool neg = false;
+    for (int i = 0; i < 4; i++) {
+        double tot = 0.0;
+        for (int j = 0; j < 4; j++) tot += (up ? c.q(r, j, i) : c.q(r, i, j)) * v[j];
+        tot *= t;
+        tot += v[i];
+        if (tot < 0) neg = true;
+        nv[i] = tot;
+    }
+    for (int i = 0; i < 4; i++) out[i] = neg ? 0.25 : nv[i];
+}
+// one-hot nucleotide (optionally error-smeared, M:4109-4125) moved along a branch
+template <class C, bool U>
+__device__ inline void gpv_nuc(const C &c, double r, int nuc, double t, double errorRate, bool up, bool flag, double *out)
+{
+    if (U && flag) {
+        double nv[4];
+        double off = errorRate * 0.33333;
+        for (int i = 0; i < 4; i++) nv[i] = (i == nuc) ? 1.0 - errorRate : off;
+        if (t == 0.0) { for (int i = 0; i < 4; i++) out[i] = nv[i]; return; }
+        double mv[4];
+        bool neg = false;
+        for (int j = 0; j < 4; j++) {
+            double tot = 0.0;
+            for (int i = 0; i < 4; i++) tot += c.q(r, j, i) * nv[i];
+            tot *= t;
+            tot += nv[j];
+            if (tot < 0) neg = true;
+            mv[j] = tot;
+        }
+        for (int i = 0; i < 4; i++) out[i] = neg ? 0.25 : mv[i];
+    } else {
+        if (t == 0.0) { for (int i = 0; i < 4; i++) out[i] = (i == nuc) ? 1.0 : 0.0; return; }
+        double nv[4];
+        for (int i = 0; i < 4; i++) nv[i] = (up ? c.q(r, nuc, i) : c.q(r, i, nuc)) * t;
+        double d = 0.0;
+        for (int i = 0; i < 4; i++) if (i == nuc) { nv[i] += 1.0; d = nv[i]; }
+        bool neg = d < 0;
+        for (int i = 0; i < 4; i++) out[i] = neg ? 0.25 : nv[i];
+    }
+}
+
+// NOTE on the early "return [0.25]*4" of the reference: it leaves the loop at the FIRST negative
+// component; every later component is then irrelevant, so testing after the loop is equivalent.
+
+// ---- simplify (M:3697-3717): 4 = R, 0-3 = nucleotide, 6 = keep O, -1 = fatal ------------
+template <class C> __device__ inline int simplify(const C &c, const double *v, int refNuc)
+{
+    double maxP = 0.0; int maxI = 0, numA = 0;
+    for (int i = 0; i < 4; i++) {
+        if (v[i] > maxP) { maxP = v[i]; maxI = i; }
+        if (v[i] > c.m.thresholdProb) numA++;
+    }
+    if (maxP < c.m.thresholdProb4) return -1;
+    if (numA == 1) return maxI == refNuc ? 4 : maxI;
+    return 6;
+}
+
+__device__ inline double fmin_py(double a, double b) { return (b < a) ? b : a; }   // Python min(a, b)
+// v[i] for a register-resident 4-vector without forcing it into scratch memory
+__device__ inline double sel4(const double *v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
+
+// ---- appendProbNode (M:6505-6785) -----------------------------------------------------
+template <bool RV, bool U, bool SS>
+__device__ double append_walk(const Ctx<RV, U, SS> &c, ListRef P, ListRef Cl, bool isTipC, double bLen)
+{
+    typedef Ctx<RV, U, SS> CT;
+    const int lRef = c.m.lRef;
+    const double *rf = c.rf;
+    Cursor a, b;                       // a = parent side, b = child side
+    a.init(P); b.init(Cl);
+    int pos = 0;
+    double totalFactor = 1.0;
+    double Lk = bLen * c.m.globalTotRate;
+    if (U && isTipC) Lk += c.m.totError;
+    for (;;) {
+        const Ent &e1 = a.e, &e2 = b.e;
+        double f = 1.0;                // multiplicative contribution of this step
+        bool mult = false;
+        if (e2.type == 5 || e1.type == 5) {
+            // N on either side contributes nothing (M:6545-6582)
+            bool run1 = (e1.type == 4 || e1.type == 5), run2 = (e2.type == 4 || e2.type == 5);
+            pos = (run1 && run2) ? min(e1.pos, e2.pos) : pos + 1;
+        } else if (e1.type == 4 && e2.type == 4) {
+            pos = min(e1.pos, e2.pos);                                  // M:6602-6608
+        } else {
+            const int site = pos;      // 0-based index of the site being scored
+            pos += 1;
+            if (e1.type != e2.type || e1.type == 6) {
+                double cl = bLen;                                       // M:6586-6599
+                if (e1.type < 5) { if (e1.hasD1) cl += e1.d1; else if (e1.hasD0) cl += e1.d0; }
+                else if (e1.hasD0) cl += e1.d0;
+                if (e2.type < 5) { if (e2.hasD0 && !e2.hasD1) cl += e2.d0; }
+                else if (e2.hasD0) cl += e2.d0;
+                const double r = c.rate(site);
+                const bool flag1 = U && e1.type < 5 && e1.hasD0 && e1.flag;
+                const bool flag2 = U && e2.type < 5 && (isTipC || (e2.hasD0 && e2.flag));
+                mult = true;
+                if (e1.type == 6 && e2.type == 6) {                     // M:6677-6686
+                    double t3[4];
+                    gpv_vec(c, r, e2.vec, cl, false, t3);
+                    double tot = 0.0;
+                    for (int j = 0; j < 4; j++) tot += e1.vec[j] * t3[j];
+                    f = tot;
+                } else if (e1.type == 6) {                              // O over nucleotide/R, M:6687-6703
+                    int i2 = (e2.type == 4) ? e1.ref : e2.type;
+                    double p = e1.vec[i2];
+                    if (p > 0.02) f = p;
+                    else {
+                        double t3[4];
+                        gpv_nuc<CT, U>(c, r, i2, cl, flag2 ? c.err(site) : 0.0, false, flag2, t3);
+                        double tot = 0.0;
+                        for (int j = 0; j < 4; j++) tot += e1.vec[j] * t3[j];
+                        f = tot;
+                    }
+                } else if (e2.type == 6) {                              // nucleotide/R over O, M:6611-6633, 6744-6761
+                    int i1 = (e1.type == 4) ? e2.ref : e1.type;
+                    double p = e2.vec[i1];
+                    if (p > 0.02) f = p;
+                    else if (e1.hasD1) {
+                        double t2[4], t3[4];
+                        gpv_vec(c, r, e2.vec, cl, false, t3);
+                        gpv_nuc<CT, U>(c, r, i1, e1.d0, c.err(site), false, flag1, t2);
+                        double tot = 0.0;
+                        if (e1.type == 4) { for (int i = 0; i < 4; i++) tot += t3[i] * t2[i] * rf[i]; }
+                        else { for (int i = 0; i < 4; i++) tot += t2[i] * t3[i] * rf[i]; }
+                        f = tot / rf[i1];
+                    } else if (cl != 0.0) {
+                        double t3[4];
+                        gpv_vec(c, r, e2.vec, cl, false, t3);
+                        f = sel4(t3, i1);
+                    } else f = p;
+                } else {                                                // two different nucleotides (R counts as the reference one)
+                    int i1 = (e1.type == 4) ? e2.ref : e1.type;         // M:6640-6668, 6713-6742
+                    int i2 = (e2.type == 4) ? e1.ref : e2.type;
+                    if (e1.hasD1) {
+                        double t2[4], t3[4];
+                        double er = c.err(site);
+                        gpv_nuc<CT, U>(c, r, i2, cl, er, false, flag2, t3);
+                        gpv_nuc<CT, U>(c, r, i1, e1.d0, er, false, flag1, t2);
+                        double tot = 0.0;
+                        if (e1.type == 4) { for (int i = 0; i < 4; i++) tot += t3[i] * t2[i] * rf[i]; }
+                        else { for (int j = 0; j < 4; j++) tot += rf[j] * t3[j] * t2[j]; }
+                        f = tot / rf[i1];
+                    } else {
+                        double qv = c.q(r, i1, i2);
+                        if (e1.type == 4) {
+                            if (flag2) f = fmin_py(0.25, qv * cl) + c.err(site) * 0.33333;
+                            else if (cl != 0.0) f = fmin_py(0.25, qv * cl);
+                            else return -INFINITY;
+                        } else {
+                            if (flag1 || flag2)
+                                f = fmin_py(0.25, qv * cl) + (double)((int)flag1 + (int)flag2) * 0.33333 * c.err(site);
+                            else if (cl != 0.0) f = fmin_py(0.25, qv * cl);
+                            else return -INFINITY;
+                        }
+                    }
+                }
+            }
+        }
+        if (mult) totalFactor *= f;
+        if (pos == lRef) break;
+        if (totalFactor <= c.m.minimumCarryOver) {                      // M:6772-6783
+            if (totalFactor < 2.2250738585072014e-308) return -INFINITY;
+            Lk += log(totalFactor);
+            totalFactor = 1.0;
+        }
+        a.step(pos);
+        b.step(pos);
+    }
+    return (totalFactor > 0.0) ? Lk + log(totalFactor) : -INFINITY;
+}
+
+// ---- mergeVectors (M:4446-4859) -----------------------------------------------------------
+// returns number of entries written, -1 for the reference's None, -2 for a fatal state
+template <bool RV, bool U, bool SS>
+__device__ int merge_walk(const Ctx<RV, U, SS> &c, ListRef L1, double bLen1, bool tip1, ListRef L2, double bLen2,
+                          bool tip2, bool upDown, bool wantLK, int numMinor1, int numMinor2, Writer &o, double *outLK)
+{
+    typedef Ctx<RV, U, SS> CT;
+    const int lRef = c.m.lRef;
+    const double *rf = c.rf;
+    const double *cr = c.m.cumulativeRate, *cer = c.m.cumulativeErrorRate;
+    Cursor a, b;
+    a.init(L1); b.init(L2);
+    int pos = 0;
+    double totalFactor = 1.0, lk = 0.0;
+    if (wantLK) {                                                       // M:4486-4494
+        lk = (bLen1 + bLen2) * c.m.globalTotRate;
+        if (U) {
+            if (tip1 || numMinor1) lk += c.m.totError * (1 + numMinor1);
+            if (tip2 || numMinor2) lk += c.m.totError * (1 + numMinor2);
+        }
+    }
+    for (;;) {
+        const Ent &e1 = a.e, &e2 = b.e;
+        int newPos;
+        if (e1.type == 5 || e2.type == 5) {
+            // one side carries no information: the other side is copied with its distance extended
+            const bool oneIsN = (e1.type == 5);
+            if (e1.type == 5 && e2.type == 5) {
+                newPos = min(e1.pos, e2.pos);
+                o.bare(5, newPos, 0);                                   // M:4498-4500
+            } else {
+                const Ent &e = oneIsN ? e2 : e1;
+                const double bl = oneIsN ? bLen2 : bLen1;
+                const bool tip = oneIsN ? tip2 : tip1;
+                if (e.type < 5) {
+                    newPos = (e.type < 4) ? pos + 1 : min(e1.pos, e2.pos);
+                    if (upDown && !oneIsN) {                            // upper list kept, M:4597-4619
+                        if (e.hasD1) o.put(e.type, newPos, e.ref, true, e.d0, true, e.d1 + bl, U && e.flag, nullptr);
+                        else if (e.hasD0) o.put(e.type, newPos, e.ref, true, e.d0 + bl, false, 0, U && e.flag, nullptr);
+                        else if (bl != 0.0) o.put(e.type, newPos, e.ref, true, bl, false, 0, false, nullptr);
+                        else o.bare(e.type, newPos, e.ref);
+                    } else if (upDown) {                                // lower list seen from above, M:4508-4526
+                        if (e.hasD0) o.put(e.type, newPos, e.ref, true, e.d0 + bl, true, 0.0, U && e.flag, nullptr);
+                        else if (bl != 0.0 || (U && tip)) o.put(e.type, newPos, e.ref, true, bl, true, 0.0, U && tip, nullptr);
+                        else o.bare(e.type, newPos, e.ref);
+                    } else {                                            // two lower lists, M:4527-4548, 4621-4643
+                        if (e.hasD0) o.put(e.type, newPos, e.ref, true, e.d0 + bl, false, 0, U && e.flag, nullptr);
+                        else if (bl != 0.0 || (U && tip)) o.put(e.type, newPos, e.ref, true, bl, false, 0, U && tip, nullptr);
+                        else o.bare(e.type, newPos, e.ref);
+                    }
+                } else {                                                // O against N
+                    newPos = pos + 1;
+                    bool propagate = upDown && (oneIsN || (e.hasD0 && e.d0 > 0) || bl != 0.0);
+                    if (propagate) {                                    // M:4552-4566, 4647-4660
+                        double nv[4];
+                        double tb = bl;
+                        if (e.hasD0) tb += e.d0;
+                        gpv_vec(c, c.rate(pos), e.vec, tb, !oneIsN, nv);
+                        if (oneIsN) for (int i = 0; i < 4; i++) nv[i] *= rf[i];
+                        double s = 0.0;
+                        for (int i = 0; i < 4; i++) s += nv[i];
+                        for (int i = 0; i < 4; i++) nv[i] /= s;
+                        o.put(6, newPos, e.ref, false, 0, false, 0, false, nv);
+                    } else {                                            // M:4568-4576, 4661-4668
+                        if (e.hasD0) o.put(6, newPos, e.ref, true, e.d0 + bl, false, 0, false, e.vec);
+                        else if (bl != 0.0) o.put(6, newPos, e.ref, true, bl, false, 0, false, e.vec);
+                        else o.put(6, newPos, e.ref, false, 0, false, 0, false, e.vec);
+                    }
+                }
+            }
+            if (wantLK) {                                               // M:4578-4587, 4670-4679
+                lk += (bLen1 + bLen2) * (cr[pos] - cr[newPos]);
+                if (U) {
+                    double ce = 0.0;
+                    if (tip1 || tip2) ce = SS ? cer[newPos] - cer[pos] : c.m.errorRate * (newPos - pos);
+                    if (tip1) lk += ce;
+                    if (tip2) lk += ce;
+                }
+            }
+        } else {
+            double totLen1 = bLen1, totLen2 = bLen2;                    // M:4683-4693
+            if (e1.hasD0) { totLen1 += e1.d0; if (e1.type != 6 && e1.hasD1) totLen1 += e1.d1; }
+            if (e2.hasD0) totLen2 += e2.d0;
+            const bool flag1 = U && e1.type != 6 && ((e1.hasD0 && e1.flag) || tip1);
+            const bool flag2 = U && e2.type != 6 && ((e2.hasD0 && e2.flag) || tip2);
+            const bool bothR = (e1.type == 4 && e2.type == 4);
+            newPos = bothR ? min(e1.pos, e2.pos) : pos + 1;
+            if (wantLK) {                                               // M:4703-4732
+                if (bothR) {
+                    if (totLen2 > bLen2 || totLen1 > bLen1) {
+                        lk += (totLen2 - bLen2 + totLen1 - bLen1) * (cr[newPos] - cr[pos]);
+                        if (U && ((!tip1 && flag1) || (!tip2 && flag2))) {
+                            double ce = SS ? cer[pos] - cer[newPos] : c.m.errorRate * (pos - newPos);
+                            if (!tip1 && flag1) lk += ce;
+                            if (!tip2 && flag2) lk += ce;
+                        }
+                    }
+                } else {
+                    int rn = (e1.type != 4) ? e1.ref : e2.ref;
+                    lk -= c.q(c.rate(pos), rn, rn) * (bLen2 + bLen1);
+                    if (U && ((e1.type != e2.type) || e1.type == 6) && (tip1 || tip2)) {
+                        double ce = c.err(pos);
+                        if (tip1) lk += ce;
+                        if (tip2) lk += ce;
+                    }
+                }
+            }
+            if (e1.type == e2.type && e1.type < 5) {                    // same state, M:4734-4755
+                if (e1.type == 4) o.bare(4, newPos, 0);
+                else {
+                    o.bare(e1.type, newPos, e1.ref);
+                    if (wantLK) {
+                        lk += c.q(c.rate(pos), e1.type, e1.type) * (totLen1 + totLen2);
+                        if (U && ((!tip1 && flag1) || (!tip2 && flag2))) {
+                            double ce = c.err(pos);
+                            if (!tip1 && flag1) lk -= ce;
+                            if (!tip2 && flag2) lk -= ce;
+                        }
+                    }
+                }
+            } else if (totLen1 == 0.0 && totLen2 == 0.0 && e1.type < 5 && e2.type < 5 && !flag1 && !flag2) {
+                return wantLK ? -2 : -1;                                // M:4757-4762
+            } else {                                                    // M:4763-4826
+                const double r = c.rate(pos);
+                const double er = c.err(pos);
+                const int refNuc = (e1.type == 4) ? e2.ref : e1.ref;
+                double v1[4], v2[4];
+                if (e1.type != 6) {
+                    int i1 = (e1.type == 4) ? refNuc : e1.type;
+                    if (totLen1 != 0.0 || flag1) {
+                        if (upDown && e1.hasD1) {                       // observation beyond the root, M:4777-4782
+                            gpv_nuc<CT, U>(c, r, i1, e1.d0, er, false, flag1, v1);
+                            for (int i = 0; i < 4; i++) v1[i] *= rf[i];
+                            double t = e1.d1 + bLen1;
+                            if (t != 0.0) { double tmp[4]; gpv_vec(c, r, v1, t, true, tmp); for (int i = 0; i < 4; i++) v1[i] = tmp[i]; }
+                        } else gpv_nuc<CT, U>(c, r, i1, totLen1, er, upDown, flag1, v1);
+                    } else for (int i = 0; i < 4; i++) v1[i] = (i == i1) ? 1.0 : 0.0;
+                } else gpv_vec(c, r, e1.vec, totLen1, upDown, v1);
+                if (e2.type == 6) gpv_vec(c, r, e2.vec, totLen2, false, v2);
+                else {
+                    int i2 = (e2.type == 4) ? refNuc : e2.type;
+                    if (totLen2 != 0.0 || flag2) gpv_nuc<CT, U>(c, r, i2, totLen2, er, false, flag2, v2);
+                    else for (int i = 0; i < 4; i++) v2[i] = (i == i2) ? 1.0 : 0.0;
+                }
+                for (int j = 0; j < 4; j++) v1[j] *= v2[j];
+                double s = 0.0;
+                for (int i = 0; i < 4; i++) s += v1[i];
+                if (s == 0.0) return wantLK ? -2 : -1;
+                for (int i = 0; i < 4; i++) v1[i] /= s;
+                int st = simplify(c, v1, refNuc);
+                if (st < 0) return -2;
+                if (st == 6) o.put(6, newPos, refNuc, false, 0, false, 0, false, v1);
+                else if (st == 4) o.bare(4, newPos, 0);
+                else o.bare(st, newPos, refNuc);
+                if (wantLK) totalFactor *= s;
+            }
+        }
+        pos = newPos;
+        if (wantLK && totalFactor <= c.m.minimumCarryOver) {            // M:4830-4839
+            if (totalFactor < 2.2250738585072014e-308) return -2;
+            lk += log(totalFactor);
+            totalFactor = 1.0;
+        }
+        if (pos == lRef) break;
+        a.step(pos);
+        b.step(pos);
+    }
+    if (wantLK && outLK) *outLK = lk + log(totalFactor);
+    return o.n;
+}
+
+// ---- estimateBranchLengthWithDerivative (M:5040-5358) ---------------------------------------
+// `ais` = per-lane scratch of at least (entries of P + entries of C) doubles, strided by `stride`
+template <bool RV, bool U, bool SS>
+__device__ double blen_walk(const Ctx<RV, U, SS> &c, ListRef P, ListRef Cl, bool fromTipC, double *ais, int stride,
+                            bool *isFalse)
+{
+    const int lRef = c.m.lRef;
+    const double *rf = c.rf;
+    const double *cr = c.m.cumulativeRate;
+    Cursor a, b;
+    a.init(P); b.init(Cl);
+    int pos = 0, nA = 0, nZeros = 0;
+    double c1 = c.m.globalTotRate;
+    *isFalse = false;
+    for (;;) {
+        const Ent &e1 = a.e, &e2 = b.e;
+        if (e1.type == 5 || e2.type == 5) {                             // M:5077-5092
+            bool run1 = (e1.type == 4 || e1.type == 5), run2 = (e2.type == 4 || e2.type == 5);
+            int end = (run1 && run2) ? min(e1.pos, e2.pos) : pos + 1;
+            c1 += (cr[pos] - cr[end]);
+            pos = end;
+        } else if (e1.type == 4 && e2.type == 4) {
+            pos = min(e1.pos, e2.pos);
+        } else {
+            const double r = c.rate(pos);
+            const int rn = (e1.type == 4) ? e2.ref : e1.ref;
+            c1 -= c.q(r, rn, rn);                                       // M:5101-5104
+            const bool flag1 = U && e1.type != 6 && e1.hasD0 && e1.flag;
+            const bool flag2 = U && e2.type != 6 && (fromTipC || (e2.hasD0 && e2.flag));
+            const double er = c.err(pos);
+            double cl = 0.0;                                            // M:5109-5124
+            if (e1.type < 5) { if (e1.hasD1) cl = e1.d1; else if (e1.hasD0) cl = e1.d0; }
+            else if (e1.hasD0) cl = e1.d0;
+            if (e2.hasD0) cl += e2.d0;
+            double coeff0 = 0.0, coeff1 = 0.0;
+            int kind;   // 0: (coeff0, coeff1) pair rule ; 1: plain a_i rule ; 2: nothing
+            if (e1.type == 6) {                                         // M:5188-5212
+                if (e2.type == 6) {
+                    coeff0 = e1.vec[0] * e2.vec[0] + e1.vec[1] * e2.vec[1] + e1.vec[2] * e2.vec[2] + e1.vec[3] * e2.vec[3];
+                    for (int i = 0; i < 4; i++)
+                        for (int j = 0; j < 4; j++) coeff1 += e1.vec[i] * e2.vec[j] * c.q(r, i, j);
+                    if (cl != 0.0) coeff0 += coeff1 * cl;
+                } else {
+                    int i2 = (e2.type == 4) ? e1.ref : e2.type;
+                    coeff0 = e1.vec[i2];
+                    for (int i = 0; i < 4; i++) coeff1 += e1.vec[i] * c.q(r, i, i2);
+                    if (cl != 0.0) coeff0 += coeff1 * cl;
+                    if (flag2) coeff0 += er * 0.33333;
+                }
+                kind = 0;
+            } else if (e2.type == 6) {                                  // M:5128-5155, 5252-5276
+                int i1 = (e1.type == 4) ? e2.ref : e1.type;
+                if (e1.hasD1) {
+                    coeff0 = rf[i1] * e2.vec[i1];
+                    for (int i = 0; i < 4; i++) {
+                        coeff0 += rf[i] * c.q(r, i, i1) * e1.d0 * e2.vec[i];
+                        coeff1 += c.q(r, i1, i) * e2.vec[i];
+                    }
+                    coeff1 *= rf[i1];
+                    if (cl != 0.0) coeff0 += coeff1 * cl;
+                    if (flag1) {
+                        coeff0 -= 1.33333 * er * rf[i1] * e2.vec[i1];
+                        for (int i = 0; i < 4; i++) coeff0 += rf[i] * e2.vec[i] * 0.33333 * er;
+                    }
+                } else {
+                    coeff0 = e2.vec[i1];
+                    for (int j = 0; j < 4; j++) coeff1 += c.q(r, i1, j) * e2.vec[j];
+                    if (cl != 0.0) coeff0 += coeff1 * cl;
+                }
+                kind = 0;
+            } else if (e1.type == e2.type) {                            // same non-reference nucleotide, M:5217-5218
+                c1 += c.q(r, e1.type, e1.type);
+                kind = 2;
+            } else {                                                    // M:5157-5185, 5219-5250
+                int i1 = (e1.type == 4) ? e2.ref : e1.type;
+                int i2 = (e2.type == 4) ? e1.ref : e2.type;
+                kind = 1;
+                if (e1.hasD1) {
+                    coeff0 = rf[i2] * c.q(r, i2, i1) * e1.d0;
+                    if (cl != 0.0) coeff0 += rf[i1] * c.q(r, i1, i2) * cl;
+                    if (flag2) coeff0 += rf[i1] * 0.33333 * er;
+                    if (flag1) coeff0 += rf[i2] * 0.33333 * er;
+                    coeff1 = rf[i1] * c.q(r, i1, i2);
+                    if (coeff1 != 0.0) coeff0 = coeff0 / coeff1;
+                    else kind = 2;
+                } else {
+                    coeff0 = cl;
+                    if (flag2) {
+                        double qv = c.q(r, i1, i2);
+                        if (e1.type == 4 && qv == 0.0) kind = 2;        // M:5176-5180 guards only the R case
+                        else coeff0 += er * 0.33333 / qv;
+                    }
+                }
+            }
+            if (kind == 0) {
+                if (coeff1 < 0.0) c1 += coeff1 / coeff0;
+                else if (coeff1 != 0.0) { ais[(size_t)nA * stride] = coeff0 / coeff1; nA++; }
+            } else if (kind == 1) {
+                if (coeff0 != 0.0) { ais[(size_t)nA * stride] = coeff0; nA++; }
+                else nZeros++;
+            }
+            pos += 1;
+        }
+        if (pos == lRef) break;
+        a.step(pos);
+        b.step(pos);
+    }
+    // bracket and bisect  sum 1/(a_i+t) + nZeros/t = c1   (M:5298-5358)
+    const double sens = c.m.minBLenSensitivity;
+    c1 = -c1;
+    const int n = nA + nZeros;
+    if (n == 0) { *isFalse = true; return 0.0; }
+    double minA = 0.0, maxA = 0.0;
+    if (nA) {
+        minA = maxA = ais[0];
+        for (int i = 1; i < nA; i++) { double v = ais[(size_t)i * stride]; if (v < minA) minA = v; if (v > maxA) maxA = v; }
+    }
+    if (nZeros) minA = fmin_py(0.0, minA);
+    if (minA < 0.0) return 0.1;
+    double tDown = fmin_py(0.1, n / c1 - minA);
+    if (tDown <= 0.0) { *isFalse = true; return 0.0; }
+    double vDown = nZeros ? nZeros / tDown : 0.0;
+    for (int i = 0; i < nA; i++) vDown += 1.0 / (ais[(size_t)i * stride] + tDown);
+    double tUp = fmin_py(0.1, n / c1 - maxA);
+    if (tUp >= 0.1) return 0.1;
+    if (tUp <= sens) tUp = (minA != 0.0) ? 0.0 : sens;
+    double vUp = nZeros ? nZeros / tUp : 0.0;
+    for (int i = 0; i < nA; i++) vUp += 1.0 / (ais[(size_t)i * stride] + tUp);
+    if (vDown > c1 + sens || vUp < c1 - sens) {
+        if (vUp < c1 - sens && tUp == 0.0) { *isFalse = true; return 0.0; }
+        if (vDown > c1 + sens && tDown >= 0.1) return 0.1;
+    }
+    while (tDown - tUp > sens) {
+        double tM = (tUp + tDown) / 2;
+        double vM = nZeros ? nZeros / tM : 0.0;
+        for (int i = 0; i < nA; i++) vM += 1.0 / (ais[(size_t)i * stride] + tM);
+        if (vM > c1) tUp = tM; else tDown = tM;
+    }
+    return tUp;
+}
+
+// ---- areVectorsDifferent (M:5419-5472) -------------------------------------------------------
+template <class C> __device__ bool differ_walk(const C &c, ListRef L1, ListRef L2)
+{
+    const int lRef = c.m.lRef;
+    const double thr = c.m.thresholdProb;
+    Cursor a, b;
+    a.init(L1); b.init(L2);
+    int pos = 0;
+    for (;;) {
+        const Ent &e1 = a.e, &e2 = b.e;
+        if (e1.type != e2.type) return true;
+        if (e1.hasD0 != e2.hasD0 || e1.hasD1 != e2.hasD1) return true;     // tuple lengths
+        if (e1.type < 5) {
+            if (e1.hasD0) {
+                if (fabs(e1.d0 - e2.d0) > thr) return true;
+                if (e1.hasD1 && fabs(e1.d1 - e2.d1) > thr) return true;
+                if (e1.flag != e2.flag) return true;                        // |True-False| = 1 > thr
+            }
+            pos = (e1.type < 4) ? pos + 1 : min(e1.pos, e2.pos);
+        } else if (e1.type == 6) {
+            if (e1.hasD0 && fabs(e1.d0 - e2.d0) > thr) return true;
+            for (int i = 0; i < 4; i++) {
+                double x = e1.vec[i], y = e2.vec[i];
+                double d = fabs(x - y);
+                if (d != 0.0) {
+                    if (x == 0.0 || y == 0.0) return true;
+                    if (d > c.m.thresholdDiffForUpdate
+                        || (d > thr && ((d / x > c.m.thresholdFoldChangeUpdate) || (d / y > c.m.thresholdFoldChangeUpdate))))
+                        return true;
+                }
+            }
+            pos += 1;
+        } else pos = min(e1.pos, e2.pos);
+        if (pos == lRef) break;
+        a.step(pos);
+        b.step(pos);
+    }
+    return false;
+}
+
+// ---- passGenomeListThroughBranch (M:3749-3877) -----------------------------------------------
+// mutations: int32 triples (pos, from, to) sorted by pos
+__device__ inline int pass_walk(int lRef, ListRef L, const int32_t *mut, int nMut, bool dirIsUp, Writer &o)
+{
+    Cursor a;
+    a.init(L);
+    int iM = 0, lastPos = 0;
+    for (;;) {
+        const Ent &e = a.e;
+        if (e.type == 5) {
+            o.bare(5, e.pos, 0);
+            lastPos = e.pos;
+            while (iM < nMut && mut[iM * 3] <= lastPos) iM++;
+        } else if (e.type == 4) {
+            // split the reference run around mutated sites; each mutated site becomes an explicit nucleotide
+            while (iM < nMut && mut[iM * 3] <= e.pos) {
+                int mp = mut[iM * 3];
+                if (mp > lastPos + 1) { lastPos = mp - 1; o.copy(e, 4, lastPos, 0); }
+                lastPos += 1;
+                int from = mut[iM * 3 + 1], to = mut[iM * 3 + 2];
+                o.copy(e, dirIsUp ? to : from, lastPos, dirIsUp ? from : to);
+                iM++;
+            }
+            if (lastPos < e.pos) { lastPos = e.pos; o.copy(e, 4, lastPos, 0); }
+        } else {
+            lastPos += 1;
+            if (iM < nMut && mut[iM * 3] <= lastPos) {
+                int newRef = dirIsUp ? mut[iM * 3 + 1] : mut[iM * 3 + 2];
+                iM++;
+                if (e.type == 6) o.copy(e, 6, lastPos, newRef);
+                else if (e.type == newRef) o.copy(e, 4, lastPos, 0);        // equals the new reference -> R
+                else o.copy(e, e.type, lastPos, newRef);
+            } else o.copy(e, e.type, lastPos, e.ref);
+        }
+        if (lastPos == lRef) break;
+        a.next();
+    }
+    return o.n;
+}
+
+// ---- shorten (M:3721-3745) -------------------------------------------------------------------
+// Adjacent R entries with matching tails collapse into the later one.  The reference compares
+// every candidate with the FIRST entry of the current group (it never refreshes `entryOld` after
+// a pop), which is reproduced by keeping `head`.
+template <class C> __device__ int shorten_walk(const C &c, ListRef L, int nEnt, Writer &o)
+{
+    const double thr = c.m.thresholdProb;
+    Cursor a;
+    a.init(L);
+    Ent head = a.e;                    // entryOld
+    Ent last = a.e;                    // entry currently at vec[index]
+    for (int k = 1; k < nEnt; k++) {
+        a.next();
+        const Ent &nw = a.e;
+        bool absorb = false;
+        if (nw.type == 4 && head.type == 4 && nw.hasD0 == head.hasD0 && nw.hasD1 == head.hasD1) {
+            if (!nw.hasD0) absorb = true;
+            else if (fabs(nw.d0 - head.d0) > thr) absorb = false;
+            else if (nw.hasD1 && fabs(nw.d1 - head.d1) > thr) absorb = false;
+            else absorb = (nw.flag == head.flag);
+        }
+        if (!absorb) {
+            o.copy(last, last.type, last.pos, last.ref);
+            head = nw;
+        }
+        last = nw;
+    }
+    o.copy(last, last.type, last.pos, last.ref);
+    return o.n;
+}
+
+// ---- rootVector body (M:4941-4986): lower list (already in the root frame) -> upper list ------
+template <bool RV, bool U, bool SS>
+__device__ int root_walk(const Ctx<RV, U, SS> &c, ListRef L, double bLen, bool isFromTip, Writer &o)
+{
+    const int lRef = c.m.lRef;
+    const double *rf = c.rf;
+    Cursor a;
+    a.init(L);
+    int prev = 0;                      // positions consumed so far
+    for (;;) {
+        const Ent &e = a.e;
+        if (e.type == 5) o.bare(5, e.pos, 0);
+        else if (e.type == 6) {
+            double nv[4];
+            double tb = bLen;
+            if (e.hasD0) tb += e.d0;
+            if (tb != 0.0) { gpv_vec(c, c.rate(prev), e.vec, tb, false, nv); for (int i = 0; i < 4; i++) nv[i] *= rf[i]; }
+            else for (int i = 0; i < 4; i++) nv[i] = e.vec[i] * rf[i];
+            double s = 0.0;
+            for (int i = 0; i < 4; i++) s += nv[i];
+            for (int i = 0; i < 4; i++) nv[i] /= s;
+            o.put(6, e.pos, e.ref, false, 0, false, 0, false, nv);
+        } else {
+            bool fl = U && ((e.hasD0 && e.flag) || isFromTip);
+            if (e.hasD0) o.put(e.type, e.pos, e.ref, true, e.d0 + bLen, true, 0.0, fl, nullptr);
+            else if (bLen != 0.0 || fl) o.put(e.type, e.pos, e.ref, true, bLen, true, 0.0, fl, nullptr);
+            else o.bare(e.type, e.pos, e.ref);
+        }
+        prev = e.pos;
+        if (prev == lRef) break;
+        a.next();
+    }
+    return o.n;
+}
+
+} // namespace maple

@@ -1,0 +1,1038 @@
+// maple_amd/csrc/maple_hip.hip -- libmaple_hip.so: kernels + C ABI (include/maple_hip.h).
+// gfx950 only.  One lane walks one (parent list, child list) pair; see genome_dev.h.
+#include "../../include/maple_hip.h"
+#include "genome_dev.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace maple;
+
+// =================================================================================================
+// context
+// =================================================================================================
+struct ArenaView {
+    const uint2 *words;
+    const double *aux;
+    const int64_t *ent_off;            // per list
+    const int64_t *aux_off;            // per list
+    const int32_t *n_ent;              // per list
+};
+
+struct MutView {
+    const int32_t *mut3;
+    const int64_t *off;                // per mutation list (n+1 style: off[id], cnt[id])
+    const int32_t *cnt;
+};
+
+template <class T> struct DevBuf {     // grow-only device scratch
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        size_t want = n + n / 2 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        cap = (e == hipSuccess) ? want : 0;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct maple_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::string err;
+    maple_params params{};
+    int32_t lRef = 0;
+    std::vector<uint8_t> refIdx;
+    DevModel dm{};                     // device pointers inside
+    bool model_set = false;
+    double *d_siteRates = nullptr, *d_errorRates = nullptr, *d_cumRate = nullptr, *d_cumErr = nullptr;
+    std::vector<double> h_cumRate, h_cumErr;
+    // list arena
+    uint2 *d_words = nullptr;
+    double *d_aux = nullptr;
+    int64_t cap_ent = 0, cap_aux = 0, cap_lists = 0;
+    int64_t used_ent = 0, used_aux = 0;
+    int64_t *d_ent_off = nullptr, *d_aux_off = nullptr;
+    int32_t *d_n_ent = nullptr;
+    std::vector<int64_t> h_ent_off, h_aux_off;
+    std::vector<int32_t> h_n_ent, h_n_aux;
+    // mutation lists
+    int32_t *d_mut3 = nullptr;
+    int64_t *d_mut_off = nullptr;
+    int32_t *d_mut_cnt = nullptr;
+    int64_t cap_mut = 0, used_mut = 0, cap_mut_lists = 0;
+    std::vector<int64_t> h_mut_off;
+    std::vector<int32_t> h_mut_cnt;
+    // staging / scratch
+    DevBuf<int32_t> s_i32[8];
+    DevBuf<double> s_f64[4];
+    DevBuf<uint8_t> s_u8[4];
+    DevBuf<int64_t> s_i64[6];
+    DevBuf<uint2> s_words;
+    DevBuf<double> s_aux;
+    DevBuf<double> s_ais;
+};
+
+static int fail(maple_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+#define HIPCK(c, call)                                                                       \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail((c), MAPLE_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
+    } while (0)
+
+static ArenaView view(const maple_ctx *c) { return ArenaView{c->d_words, c->d_aux, c->d_ent_off, c->d_aux_off, c->d_n_ent}; }
+static MutView mview(const maple_ctx *c) { return MutView{c->d_mut3, c->d_mut_off, c->d_mut_cnt}; }
+
+__device__ inline ListRef list_ref(const ArenaView &a, int id)
+{
+    return ListRef{a.words + a.ent_off[id], a.aux + a.aux_off[id]};
+}
+
+// =================================================================================================
+// kernels
+// =================================================================================================
+#define MAPLE_BLOCK 256
+
+// appendProbNode over arbitrary pairs ----------------------------------------------------------
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_append(DevModel m, ArenaView av, int n, const int32_t *pl,
+                                                        const int32_t *cl, const uint8_t *tip, const double *bl,
+                                                        double *out)
+{
+    __shared__ Lds lds;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = append_walk(c, list_ref(av, pl[i]), list_ref(av, cl[i]), tip[i] != 0, bl[i]);
+}
+
+// one query (child list) against many candidates: the child list is staged in LDS once per workgroup
+#define MAPLE_QLDS_WORDS 1024
+#define MAPLE_QLDS_AUX 2048
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_append_query(DevModel m, ArenaView av, int n, int childList,
+                                                              int isTip, double bLen, const int32_t *cand, double *out)
+{
+    __shared__ Lds lds;
+    __shared__ uint2 qw[MAPLE_QLDS_WORDS];
+    __shared__ double qa[MAPLE_QLDS_AUX];
+    const int ne = av.n_ent[childList];
+    const int64_t eo = av.ent_off[childList], ao = av.aux_off[childList];
+    // aux length of the child list = offset of the entry after the last one
+    bool fits = ne <= MAPLE_QLDS_WORDS;
+    int na = 0;
+    if (fits) {
+        uint2 lw = av.words[eo + ne - 1];
+        na = (int)(lw.y >> 8) + ((lw.y & (1u << 5)) ? 1 : 0) + ((lw.y & (1u << 6)) ? 1 : 0) + (((lw.y & 7u) == 6) ? 4 : 0);
+        fits = na <= MAPLE_QLDS_AUX;
+    }
+    if (fits) {
+        for (int k = threadIdx.x; k < ne; k += blockDim.x) qw[k] = av.words[eo + k];
+        for (int k = threadIdx.x; k < na; k += blockDim.x) qa[k] = av.aux[ao + k];
+    }
+    stage_model(m, lds);               // contains the __syncthreads()
+    Ctx<RV, U, SS> c(m, lds);
+    ListRef q = fits ? ListRef{qw, qa} : list_ref(av, childList);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = append_walk(c, list_ref(av, cand[i]), q, isTip != 0, bLen);
+}
+
+// per-item scratch placement for list-producing kernels
+struct OutSpec {
+    uint2 *words;                      // scratch words
+    double *aux;                       // scratch aux
+    const int64_t *woff;               // per item offset into words
+    const int64_t *aoff;               // per item offset into aux
+    int32_t *n_ent;                    // per item result: entries (or <0 status)
+    int32_t *n_aux;
+};
+
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_merge(DevModel m, ArenaView av, int n, const int32_t *l1,
+                                                       const double *b1, const uint8_t *t1, const int32_t *l2,
+                                                       const double *b2, const uint8_t *t2, const uint8_t *ud,
+                                                       const int32_t *nm1, const int32_t *nm2, OutSpec o, double *outLK)
+{
+    __shared__ Lds lds;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Writer w;
+        w.init(o.words + o.woff[i], o.aux + o.aoff[i]);
+        double lk = 0.0;
+        int r = merge_walk(c, list_ref(av, l1[i]), b1[i], t1[i] != 0, list_ref(av, l2[i]), b2[i], t2[i] != 0,
+                           ud[i] != 0, outLK != nullptr, nm1 ? nm1[i] : 0, nm2 ? nm2[i] : 0, w, &lk);
+        o.n_ent[i] = r;
+        o.n_aux[i] = w.na;
+        if (outLK) outLK[i] = lk;
+    }
+}
+
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_blen(DevModel m, ArenaView av, int n, const int32_t *pl,
+                                                      const int32_t *cl, const uint8_t *tip, double *ais,
+                                                      const int64_t *aisOff, double *t, uint8_t *isFalse)
+{
+    __shared__ Lds lds;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        bool f;
+        t[i] = blen_walk(c, list_ref(av, pl[i]), list_ref(av, cl[i]), tip[i] != 0, ais + aisOff[i], 1, &f);
+        isFalse[i] = f ? 1 : 0;
+    }
+}
+
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_differ(DevModel m, ArenaView av, int n, const int32_t *l1,
+                                                        const int32_t *l2, uint8_t *out)
+{
+    __shared__ Lds lds;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = (l2[i] < 0) ? 1 : (differ_walk(c, list_ref(av, l1[i]), list_ref(av, l2[i])) ? 1 : 0);
+}
+
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_pass(int lRef, ArenaView av, MutView mv, int n, const int32_t *l,
+                                                      const int32_t *ml, const uint8_t *up, OutSpec o)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Writer w;
+        w.init(o.words + o.woff[i], o.aux + o.aoff[i]);
+        int id = ml[i];
+        int r = pass_walk(lRef, list_ref(av, l[i]), mv.mut3 + 3 * mv.off[id], mv.cnt[id], up[i] != 0, w);
+        o.n_ent[i] = r;
+        o.n_aux[i] = w.na;
+    }
+}
+
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_shorten(DevModel m, ArenaView av, int n, const int32_t *l, OutSpec o)
+{
+    __shared__ Lds lds;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Writer w;
+        w.init(o.words + o.woff[i], o.aux + o.aoff[i]);
+        o.n_ent[i] = shorten_walk(c, list_ref(av, l[i]), av.n_ent[l[i]], w);
+        o.n_aux[i] = w.na;
+    }
+}
+
+// rootVector: frames up (node..root), root_walk, frames down (root..node), shorten.
+// Each item owns 3 scratch lists of `cap` entries: A, B (ping-pong) and the final output slot.
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_root_vector(DevModel m, ArenaView av, MutView mv, int n,
+                                                             const int32_t *l, const double *bl, const uint8_t *tip,
+                                                             const int64_t *pathOff, const int32_t *pathMut,
+                                                             const int64_t *capOff, OutSpec o)
+{
+    __shared__ Lds lds;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int64_t cap = capOff[i + 1] - capOff[i];
+        // o.woff[i] addresses 3*cap words; o.aoff[i] addresses 3*5*cap doubles
+        uint2 *W[3] = {o.words + o.woff[i], o.words + o.woff[i] + cap, o.words + o.woff[i] + 2 * cap};
+        double *A[3] = {o.aux + o.aoff[i], o.aux + o.aoff[i] + 5 * cap, o.aux + o.aoff[i] + 10 * cap};
+        ListRef cur = list_ref(av, l[i]);
+        int curN = av.n_ent[l[i]];
+        int slot = 1;                  // next buffer to write (1 or 2); slot 0 is reserved for the result
+        Writer w;
+        for (int64_t k = pathOff[i]; k < pathOff[i + 1]; k++) {
+            int id = pathMut[k];
+            if (id < 0 || mv.cnt[id] == 0) continue;
+            w.init(W[slot], A[slot]);
+            curN = pass_walk(m.lRef, cur, mv.mut3 + 3 * mv.off[id], mv.cnt[id], true, w);
+            cur = ListRef{W[slot], A[slot]};
+            slot = 3 - slot;
+        }
+        w.init(W[slot], A[slot]);
+        curN = root_walk(c, cur, bl[i], tip[i] != 0, w);
+        cur = ListRef{W[slot], A[slot]};
+        slot = 3 - slot;
+        for (int64_t k = pathOff[i + 1] - 1; k >= pathOff[i]; k--) {
+            int id = pathMut[k];
+            if (id < 0 || mv.cnt[id] == 0) continue;
+            w.init(W[slot], A[slot]);
+            curN = pass_walk(m.lRef, cur, mv.mut3 + 3 * mv.off[id], mv.cnt[id], false, w);
+            cur = ListRef{W[slot], A[slot]};
+            slot = 3 - slot;
+        }
+        w.init(W[0], A[0]);
+        o.n_ent[i] = shorten_walk(c, cur, curN, w);
+        o.n_aux[i] = w.na;
+    }
+}
+
+// evaluatePlacement (M:6790-6806): three branch-length solves around three merges, then one append.
+// Each item owns 3 scratch lists (capacities capA/capB/capC packed back to back) and an `ais` strip.
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_evalplace(DevModel m, ArenaView av, int n, const int32_t *midTot,
+                                                           const int32_t *down, const int32_t *up, const double *dist,
+                                                           const int32_t *rem, const uint8_t *remTip,
+                                                           const uint8_t *fromTip1, uint2 *sw, double *sa,
+                                                           const int64_t *capOff, double *ais, const int64_t *aisOff,
+                                                           double *out4, int32_t *status)
+{
+    __shared__ Lds lds;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        ListRef Lmid = list_ref(av, midTot[i]), Ldown = list_ref(av, down[i]), Lup = list_ref(av, up[i]),
+                Lrem = list_ref(av, rem[i]);
+        const int nDown = av.n_ent[down[i]], nUp = av.n_ent[up[i]], nRem = av.n_ent[rem[i]];
+        const int64_t base = capOff[i];
+        uint2 *wA = sw + base, *wB = wA + (nDown + nRem), *wC = wB + (nUp + nRem);
+        double *aA = sa + 5 * base, *aB = aA + 5 * (int64_t)(nDown + nRem), *aC = aB + 5 * (int64_t)(nUp + nRem);
+        double *myAis = ais + aisOff[i];
+        const bool rt = remTip[i] != 0, ft = fromTip1[i] != 0;
+        bool f;
+        Writer w;
+        status[i] = 0;
+        double bestApp = blen_walk(c, Lmid, Lrem, rt, myAis, 1, &f);
+        w.init(wA, aA);
+        int r = merge_walk(c, Ldown, dist[i] / 2, ft, Lrem, bestApp, rt, false, false, 0, 0, w, nullptr);
+        if (r < 0) { status[i] = -1; continue; }
+        ListRef midLower{wA, aA};
+        double bestTop = blen_walk(c, Lup, midLower, false, myAis, 1, &f);
+        w.init(wB, aB);
+        r = merge_walk(c, Lup, bestTop, false, Lrem, bestApp, rt, true, false, 0, 0, w, nullptr);
+        if (r == -1) {
+            bestTop = m.defaultBLen * 0.1;
+            w.init(wB, aB);
+            r = merge_walk(c, Lup, bestTop, false, Lrem, bestApp, rt, true, false, 0, 0, w, nullptr);
+        }
+        if (r < 0) { status[i] = -1; continue; }
+        ListRef midTop{wB, aB};
+        double bestBottom = blen_walk(c, midTop, Ldown, ft, myAis, 1, &f);
+        w.init(wC, aC);
+        r = merge_walk(c, Lup, bestTop, false, Ldown, bestBottom, ft, true, false, 0, 0, w, nullptr);
+        if (r < 0) { status[i] = -1; continue; }
+        ListRef newMid{wC, aC};
+        out4[i * 4 + 0] = append_walk(c, newMid, Lrem, rt, bestApp);
+        out4[i * 4 + 1] = bestBottom;
+        out4[i * 4 + 2] = bestTop;
+        out4[i * 4 + 3] = bestApp;
+    }
+}
+
+// compaction of scratch lists into the arena: one wavefront per list, coalesced copies
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_commit(int n, const uint2 *sw, const double *sa, const int64_t *swoff,
+                                                        const int64_t *saoff, const int32_t *n_ent, const int32_t *n_aux,
+                                                        const int64_t *dst_w, const int64_t *dst_a, uint2 *words,
+                                                        double *aux)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < n; i += nwaves) {
+        if (n_ent[i] < 0) continue;
+        const uint2 *s = sw + swoff[i];
+        uint2 *d = words + dst_w[i];
+        for (int k = lane; k < n_ent[i]; k += 64) d[k] = s[k];
+        const double *s2 = sa + saoff[i];
+        double *d2 = aux + dst_a[i];
+        for (int k = lane; k < n_aux[i]; k += 64) d2[k] = s2[k];
+    }
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+static int grid_for(int n)
+{
+    int g = (n + MAPLE_BLOCK - 1) / MAPLE_BLOCK;
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;      // 256 CUs x 8 workgroups, grid-stride beyond
+    return g;
+}
+
+#define DISPATCH3(c, KERNEL, ...)                                                                          \
+    do {                                                                                                  \
+        const bool rv_ = (c)->dm.useRateVariation, u_ = (c)->dm.usingErrorRate, ss_ = (c)->dm.errorRateSiteSpecific; \
+        if (!rv_ && !u_) KERNEL<false, false, false> __VA_ARGS__;                                          \
+        else if (rv_ && !u_) KERNEL<true, false, false> __VA_ARGS__;                                       \
+        else if (!rv_ && u_ && !ss_) KERNEL<false, true, false> __VA_ARGS__;                               \
+        else if (!rv_ && u_ && ss_) KERNEL<false, true, true> __VA_ARGS__;                                 \
+        else if (rv_ && u_ && !ss_) KERNEL<true, true, false> __VA_ARGS__;                                 \
+        else KERNEL<true, true, true> __VA_ARGS__;                                                         \
+    } while (0)
+
+extern "C" int maple_abi_version(void) { return MAPLE_ABI_VERSION; }
+
+extern "C" const char *maple_last_error(maple_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int maple_create(maple_ctx **out, int device, int32_t lRef, const uint8_t *refIdx, const double *rootFreqs4,
+                            const maple_params *params, uint64_t arena_bytes)
+{
+    if (!out || !refIdx || !rootFreqs4 || !params || lRef <= 0) return MAPLE_ERR_ARG;
+    *out = nullptr;
+    maple_ctx *c = new maple_ctx();
+    c->device = device;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0 || device >= ndev) {
+        delete c;
+        return MAPLE_ERR_HIP;          // no GPU: the product path fails loudly, there is no CPU fallback
+    }
+    if (hipSetDevice(device) != hipSuccess) { delete c; return MAPLE_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MAPLE_ERR_HIP; }
+    (void)hipEventCreate(&c->ev0);
+    (void)hipEventCreate(&c->ev1);
+    c->lRef = lRef;
+    c->refIdx.assign(refIdx, refIdx + lRef);
+    c->params = *params;
+    DevModel &m = c->dm;
+    memset(&m, 0, sizeof m);
+    m.lRef = lRef;
+    for (int i = 0; i < 4; i++) m.rootFreqs[i] = rootFreqs4[i];
+    m.globalTotRate = -(double)lRef;                                   // M:3607
+    m.minimumCarryOver = DBL_MIN * (1e50);                             // M:3623
+    m.thresholdProb = params->thresholdProb;
+    double t2 = params->thresholdProb * params->thresholdProb;         // M:3692-3693
+    m.thresholdProb4 = t2 * t2;
+    m.minBLenSensitivity = params->minBLenSensitivity;
+    m.thresholdDiffForUpdate = params->thresholdDiffForUpdate;
+    m.thresholdFoldChangeUpdate = params->thresholdFoldChangeUpdate;
+    m.defaultBLen = params->defaultBLen;
+    if (arena_bytes == 0) arena_bytes = 1ull << 30;
+    c->cap_ent = (int64_t)(arena_bytes / 24);
+    c->cap_aux = 2 * c->cap_ent;
+    c->cap_lists = c->cap_ent / 4 + 1024;
+    c->cap_mut = c->cap_ent / 16 + 4096;
+    c->cap_mut_lists = c->cap_lists / 4 + 1024;
+    bool ok = hipMalloc((void **)&c->d_words, c->cap_ent * sizeof(uint2)) == hipSuccess
+              && hipMalloc((void **)&c->d_aux, c->cap_aux * sizeof(double)) == hipSuccess
+              && hipMalloc((void **)&c->d_ent_off, c->cap_lists * sizeof(int64_t)) == hipSuccess
+              && hipMalloc((void **)&c->d_aux_off, c->cap_lists * sizeof(int64_t)) == hipSuccess
+              && hipMalloc((void **)&c->d_n_ent, c->cap_lists * sizeof(int32_t)) == hipSuccess
+              && hipMalloc((void **)&c->d_mut3, c->cap_mut * 3 * sizeof(int32_t)) == hipSuccess
+              && hipMalloc((void **)&c->d_mut_off, c->cap_mut_lists * sizeof(int64_t)) == hipSuccess
+              && hipMalloc((void **)&c->d_mut_cnt, c->cap_mut_lists * sizeof(int32_t)) == hipSuccess
+              && hipMalloc((void **)&c->d_cumRate, (lRef + 1) * sizeof(double)) == hipSuccess;
+    if (!ok) { maple_destroy(c); return MAPLE_ERR_NOMEM; }
+    *out = c;
+    return MAPLE_OK;
+}
+
+extern "C" int maple_destroy(maple_ctx *c)
+{
+    if (!c) return MAPLE_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->d_words, c->d_aux, c->d_ent_off, c->d_aux_off, c->d_n_ent, c->d_mut3, c->d_mut_off,
+                    c->d_mut_cnt, c->d_cumRate, c->d_cumErr, c->d_siteRates, c->d_errorRates};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &b : c->s_i32) b.release();
+    for (auto &b : c->s_f64) b.release();
+    for (auto &b : c->s_u8) b.release();
+    for (auto &b : c->s_i64) b.release();
+    c->s_words.release(); c->s_aux.release(); c->s_ais.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return MAPLE_OK;
+}
+
+extern "C" int maple_set_model(maple_ctx *c, const double *Q16, const double *siteRates, int usingErrorRate,
+                               double errorRateGlobal, const double *errorRates)
+{
+    if (!c || !Q16) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    DevModel &m = c->dm;
+    const int lRef = c->lRef;
+    for (int i = 0; i < 16; i++) m.Q[i] = Q16[i];
+    m.useRateVariation = siteRates ? 1 : 0;
+    m.usingErrorRate = usingErrorRate ? 1 : 0;
+    m.errorRateSiteSpecific = (usingErrorRate && errorRates) ? 1 : 0;
+    m.errorRate = errorRateGlobal;
+    // cumulativeRate, M:6350-6370
+    c->h_cumRate.assign(lRef + 1, 0.0);
+    for (int i = 0; i < lRef; i++) {
+        double nm = Q16[c->refIdx[i] * 5];
+        c->h_cumRate[i + 1] = siteRates ? c->h_cumRate[i] + nm * siteRates[i] : c->h_cumRate[i] + nm;
+    }
+    HIPCK(c, hipMemcpyAsync(c->d_cumRate, c->h_cumRate.data(), (lRef + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    m.cumulativeRate = c->d_cumRate;
+    if (siteRates) {
+        if (!c->d_siteRates) HIPCK(c, hipMalloc((void **)&c->d_siteRates, lRef * sizeof(double)));
+        HIPCK(c, hipMemcpyAsync(c->d_siteRates, siteRates, lRef * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        m.siteRates = c->d_siteRates;
+    } else m.siteRates = nullptr;
+    // cumulativeErrorRate / totError, M:6373-6390
+    c->h_cumErr.clear();
+    m.cumulativeErrorRate = nullptr;
+    m.errorRates = nullptr;
+    m.totError = 0.0;
+    if (usingErrorRate) {
+        if (errorRates) {
+            c->h_cumErr.assign(lRef + 1, 0.0);
+            for (int i = 0; i < lRef; i++) c->h_cumErr[i + 1] = c->h_cumErr[i] + errorRates[i];
+            m.totError = -c->h_cumErr[lRef];
+            if (!c->d_errorRates) HIPCK(c, hipMalloc((void **)&c->d_errorRates, lRef * sizeof(double)));
+            if (!c->d_cumErr) HIPCK(c, hipMalloc((void **)&c->d_cumErr, (lRef + 1) * sizeof(double)));
+            HIPCK(c, hipMemcpyAsync(c->d_errorRates, errorRates, lRef * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPCK(c, hipMemcpyAsync(c->d_cumErr, c->h_cumErr.data(), (lRef + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            m.errorRates = c->d_errorRates;
+            m.cumulativeErrorRate = c->d_cumErr;
+        } else m.totError = -errorRateGlobal * lRef;
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->model_set = true;
+    return MAPLE_OK;
+}
+
+extern "C" int maple_get_model(maple_ctx *c, double *cumulativeRate, double *cumulativeErrorRate, double *totError)
+{
+    if (!c) return MAPLE_ERR_ARG;
+    if (!c->model_set) return fail(c, MAPLE_ERR_STATE, "model not set");
+    if (cumulativeRate) memcpy(cumulativeRate, c->h_cumRate.data(), c->h_cumRate.size() * sizeof(double));
+    if (cumulativeErrorRate && !c->h_cumErr.empty())
+        memcpy(cumulativeErrorRate, c->h_cumErr.data(), c->h_cumErr.size() * sizeof(double));
+    if (totError) *totError = c->dm.totError;
+    return MAPLE_OK;
+}
+
+// ---- arena --------------------------------------------------------------------------------------
+static int push_list_rows(maple_ctx *c, int32_t n, const int64_t *ent_off_abs, const int64_t *aux_off_abs,
+                          const int32_t *n_ent, const int32_t *n_aux)
+{
+    int64_t first = (int64_t)c->h_n_ent.size();
+    if (first + n > c->cap_lists) return fail(c, MAPLE_ERR_NOMEM, "list table full (%lld)", (long long)c->cap_lists);
+    c->h_ent_off.insert(c->h_ent_off.end(), ent_off_abs, ent_off_abs + n);
+    c->h_aux_off.insert(c->h_aux_off.end(), aux_off_abs, aux_off_abs + n);
+    c->h_n_ent.insert(c->h_n_ent.end(), n_ent, n_ent + n);
+    c->h_n_aux.insert(c->h_n_aux.end(), n_aux, n_aux + n);
+    HIPCK(c, hipMemcpyAsync(c->d_ent_off + first, ent_off_abs, n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->d_aux_off + first, aux_off_abs, n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->d_n_ent + first, n_ent, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));   // source vectors are caller temporaries
+    return MAPLE_OK;
+}
+
+extern "C" int maple_lists_upload(maple_ctx *c, int32_t n, const int64_t *ent_off, const int32_t *pos,
+                                  const uint32_t *meta, const int64_t *aux_off, const double *aux, int32_t *first_id)
+{
+    if (!c || n < 0 || !ent_off || !aux_off || !first_id) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    *first_id = (int32_t)c->h_n_ent.size();
+    if (n == 0) return MAPLE_OK;
+    const int64_t ne = ent_off[n] - ent_off[0], na = aux_off[n] - aux_off[0];
+    if (c->used_ent + ne > c->cap_ent || c->used_aux + na > c->cap_aux)
+        return fail(c, MAPLE_ERR_NOMEM, "arena full: need %lld entries / %lld aux", (long long)ne, (long long)na);
+    std::vector<uint2> w((size_t)ne);
+    for (int64_t k = 0; k < ne; k++) w[k] = make_uint2((uint32_t)pos[ent_off[0] + k], meta[ent_off[0] + k]);
+    HIPCK(c, hipMemcpyAsync(c->d_words + c->used_ent, w.data(), ne * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+    if (na) HIPCK(c, hipMemcpyAsync(c->d_aux + c->used_aux, aux + aux_off[0], na * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    std::vector<int64_t> eo(n), ao(n);
+    std::vector<int32_t> cnt(n), cna(n);
+    for (int i = 0; i < n; i++) {
+        eo[i] = c->used_ent + (ent_off[i] - ent_off[0]);
+        ao[i] = c->used_aux + (aux_off[i] - aux_off[0]);
+        cnt[i] = (int32_t)(ent_off[i + 1] - ent_off[i]);
+        cna[i] = (int32_t)(aux_off[i + 1] - aux_off[i]);
+        if (cnt[i] <= 0) return fail(c, MAPLE_ERR_ARG, "list %d is empty", i);
+    }
+    int rc = push_list_rows(c, n, eo.data(), ao.data(), cnt.data(), cna.data());
+    if (rc) return rc;
+    c->used_ent += ne;
+    c->used_aux += na;
+    return MAPLE_OK;
+}
+
+static int check_ids(maple_ctx *c, int32_t n, const int32_t *ids, bool allowNeg, const char *what)
+{
+    const int32_t nl = (int32_t)c->h_n_ent.size();
+    for (int i = 0; i < n; i++)
+        if (ids[i] >= nl || (ids[i] < 0 && !allowNeg))
+            return fail(c, MAPLE_ERR_ARG, "%s[%d] = %d is not a list id (have %d)", what, i, ids[i], nl);
+    return MAPLE_OK;
+}
+
+extern "C" int maple_lists_sizes(maple_ctx *c, int32_t n, const int32_t *ids, int32_t *n_ent, int32_t *n_aux)
+{
+    if (!c || n < 0 || !ids) return MAPLE_ERR_ARG;
+    int rc = check_ids(c, n, ids, false, "ids");
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) {
+        if (n_ent) n_ent[i] = c->h_n_ent[ids[i]];
+        if (n_aux) n_aux[i] = c->h_n_aux[ids[i]];
+    }
+    return MAPLE_OK;
+}
+
+extern "C" int maple_lists_download(maple_ctx *c, int32_t n, const int32_t *ids, const int64_t *ent_off, int32_t *pos,
+                                    uint32_t *meta, const int64_t *aux_off, double *aux)
+{
+    if (!c || n < 0 || !ids || !ent_off || !aux_off) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = check_ids(c, n, ids, false, "ids");
+    if (rc) return rc;
+    std::vector<uint2> w;
+    for (int i = 0; i < n; i++) {
+        int id = ids[i];
+        int ne = c->h_n_ent[id], na = c->h_n_aux[id];
+        w.resize(ne);
+        HIPCK(c, hipMemcpyAsync(w.data(), c->d_words + c->h_ent_off[id], ne * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+        if (na) HIPCK(c, hipMemcpyAsync(aux + aux_off[i], c->d_aux + c->h_aux_off[id], na * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < ne; k++) { pos[ent_off[i] + k] = (int32_t)w[k].x; meta[ent_off[i] + k] = w[k].y; }
+    }
+    return MAPLE_OK;
+}
+
+extern "C" int maple_arena_mark(maple_ctx *c, int64_t *mark)
+{
+    if (!c || !mark) return MAPLE_ERR_ARG;
+    *mark = (int64_t)c->h_n_ent.size();
+    return MAPLE_OK;
+}
+
+extern "C" int maple_arena_release(maple_ctx *c, int64_t mark)
+{
+    if (!c || mark < 0 || mark > (int64_t)c->h_n_ent.size()) return MAPLE_ERR_ARG;
+    if (mark == (int64_t)c->h_n_ent.size()) return MAPLE_OK;
+    c->used_ent = c->h_ent_off[mark];
+    c->used_aux = c->h_aux_off[mark];
+    c->h_ent_off.resize(mark); c->h_aux_off.resize(mark); c->h_n_ent.resize(mark); c->h_n_aux.resize(mark);
+    return MAPLE_OK;
+}
+
+extern "C" int maple_arena_stats(maple_ctx *c, int64_t *n_lists, int64_t *n_entries, int64_t *n_aux, int64_t *cap_entries)
+{
+    if (!c) return MAPLE_ERR_ARG;
+    if (n_lists) *n_lists = (int64_t)c->h_n_ent.size();
+    if (n_entries) *n_entries = c->used_ent;
+    if (n_aux) *n_aux = c->used_aux;
+    if (cap_entries) *cap_entries = c->cap_ent;
+    return MAPLE_OK;
+}
+
+extern "C" int maple_mutations_upload(maple_ctx *c, int32_t n, const int64_t *off, const int32_t *mut3, int32_t *first_id)
+{
+    if (!c || n < 0 || !off || !first_id) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    *first_id = (int32_t)c->h_mut_cnt.size();
+    if (n == 0) return MAPLE_OK;
+    const int64_t nm = off[n] - off[0];
+    if (c->used_mut + nm > c->cap_mut || (int64_t)c->h_mut_cnt.size() + n > c->cap_mut_lists)
+        return fail(c, MAPLE_ERR_NOMEM, "mutation arena full");
+    if (nm) HIPCK(c, hipMemcpyAsync(c->d_mut3 + 3 * c->used_mut, mut3 + 3 * off[0], nm * 3 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    std::vector<int64_t> o(n);
+    std::vector<int32_t> cnt(n);
+    for (int i = 0; i < n; i++) { o[i] = c->used_mut + (off[i] - off[0]); cnt[i] = (int32_t)(off[i + 1] - off[i]); }
+    int64_t first = *first_id;
+    HIPCK(c, hipMemcpyAsync(c->d_mut_off + first, o.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->d_mut_cnt + first, cnt.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->h_mut_off.insert(c->h_mut_off.end(), o.begin(), o.end());
+    c->h_mut_cnt.insert(c->h_mut_cnt.end(), cnt.begin(), cnt.end());
+    c->used_mut += nm;
+    return MAPLE_OK;
+}
+
+// ---- helpers for batch calls -----------------------------------------------------------------------
+template <class T> static int h2d(maple_ctx *c, DevBuf<T> &b, const T *src, size_t n)
+{
+    HIPCK(c, b.reserve(n ? n : 1));
+    if (n) HIPCK(c, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return MAPLE_OK;
+}
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+static int need_model(maple_ctx *c)
+{
+    if (!c->model_set) return fail(c, MAPLE_ERR_STATE, "maple_set_model has not been called");
+    return MAPLE_OK;
+}
+
+// Move freshly produced scratch lists into the arena and hand out ids (or -1 for None).
+static int commit_lists(maple_ctx *c, int32_t n, const std::vector<int64_t> &woff, const std::vector<int64_t> &aoff,
+                        int32_t *d_n_ent, int32_t *d_n_aux, int32_t *outList)
+{
+    std::vector<int32_t> ne(n), na(n);
+    HIPCK(c, hipMemcpyAsync(ne.data(), d_n_ent, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(na.data(), d_n_aux, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    std::vector<int64_t> dw(n, -1), da(n, -1), rows_eo, rows_ao;
+    std::vector<int32_t> rows_ne, rows_na;
+    int64_t ue = c->used_ent, ua = c->used_aux;
+    int32_t next_id = (int32_t)c->h_n_ent.size();
+    for (int i = 0; i < n; i++) {
+        if (ne[i] == -1) { outList[i] = -1; continue; }
+        if (ne[i] < 0) return fail(c, MAPLE_ERR_FATAL, "item %d hit a state the reference treats as fatal (%d)", i, ne[i]);
+        dw[i] = ue; da[i] = ua;
+        rows_eo.push_back(ue); rows_ao.push_back(ua); rows_ne.push_back(ne[i]); rows_na.push_back(na[i]);
+        ue += ne[i]; ua += na[i];
+        outList[i] = next_id++;
+    }
+    if (ue > c->cap_ent || ua > c->cap_aux) return fail(c, MAPLE_ERR_NOMEM, "arena full while committing %d lists", n);
+    TRY(h2d(c, c->s_i64[2], dw.data(), (size_t)n));
+    TRY(h2d(c, c->s_i64[3], da.data(), (size_t)n));
+    TRY(h2d(c, c->s_i64[4], woff.data(), (size_t)n));
+    TRY(h2d(c, c->s_i64[5], aoff.data(), (size_t)n));
+    int waves_per_block = MAPLE_BLOCK / 64;
+    int g = (n + waves_per_block - 1) / waves_per_block;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_commit, dim3(g), dim3(MAPLE_BLOCK), 0, c->stream, n, c->s_words.p, c->s_aux.p, c->s_i64[4].p,
+                       c->s_i64[5].p, d_n_ent, d_n_aux, c->s_i64[2].p, c->s_i64[3].p, c->d_words, c->d_aux);
+    HIPCK(c, hipGetLastError());
+    if (!rows_ne.empty())
+        TRY(push_list_rows(c, (int32_t)rows_ne.size(), rows_eo.data(), rows_ao.data(), rows_ne.data(), rows_na.data()));
+    else HIPCK(c, hipStreamSynchronize(c->stream));
+    c->used_ent = ue;
+    c->used_aux = ua;
+    return MAPLE_OK;
+}
+
+// ---- batched operators -----------------------------------------------------------------------------
+extern "C" int maple_append_batch(maple_ctx *c, int32_t n, const int32_t *pl, const int32_t *cl, const uint8_t *tip,
+                                  const double *bl, double *out)
+{
+    if (!c || n < 0 || !pl || !cl || !tip || !bl || !out) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    TRY(check_ids(c, n, pl, false, "parentList"));
+    TRY(check_ids(c, n, cl, false, "childList"));
+    TRY(h2d(c, c->s_i32[0], pl, (size_t)n));
+    TRY(h2d(c, c->s_i32[1], cl, (size_t)n));
+    TRY(h2d(c, c->s_u8[0], tip, (size_t)n));
+    TRY(h2d(c, c->s_f64[0], bl, (size_t)n));
+    HIPCK(c, c->s_f64[1].reserve(n));
+    DISPATCH3(c, k_append, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
+                                                                          c->s_u8[0].p, c->s_f64[0].p, c->s_f64[1].p));
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(out, c->s_f64[1].p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MAPLE_OK;
+}
+
+extern "C" int maple_merge_batch(maple_ctx *c, int32_t n, const int32_t *l1, const double *b1, const uint8_t *t1,
+                                 const int32_t *l2, const double *b2, const uint8_t *t2, const uint8_t *ud,
+                                 const int32_t *nm1, const int32_t *nm2, int32_t *outList, double *outLK)
+{
+    if (!c || n < 0 || !l1 || !b1 || !t1 || !l2 || !b2 || !t2 || !ud || !outList) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    TRY(check_ids(c, n, l1, false, "list1"));
+    TRY(check_ids(c, n, l2, false, "list2"));
+    std::vector<int64_t> woff(n), aoff(n);
+    int64_t tot = 0;
+    for (int i = 0; i < n; i++) {
+        woff[i] = tot; aoff[i] = 5 * tot;
+        tot += (int64_t)c->h_n_ent[l1[i]] + c->h_n_ent[l2[i]];
+    }
+    HIPCK(c, c->s_words.reserve((size_t)tot));
+    HIPCK(c, c->s_aux.reserve((size_t)(5 * tot)));
+    TRY(h2d(c, c->s_i32[0], l1, (size_t)n));
+    TRY(h2d(c, c->s_i32[1], l2, (size_t)n));
+    TRY(h2d(c, c->s_f64[0], b1, (size_t)n));
+    TRY(h2d(c, c->s_f64[1], b2, (size_t)n));
+    TRY(h2d(c, c->s_u8[0], t1, (size_t)n));
+    TRY(h2d(c, c->s_u8[1], t2, (size_t)n));
+    TRY(h2d(c, c->s_u8[2], ud, (size_t)n));
+    const int32_t *dnm1 = nullptr, *dnm2 = nullptr;
+    if (nm1) { TRY(h2d(c, c->s_i32[4], nm1, (size_t)n)); dnm1 = c->s_i32[4].p; }
+    if (nm2) { TRY(h2d(c, c->s_i32[5], nm2, (size_t)n)); dnm2 = c->s_i32[5].p; }
+    TRY(h2d(c, c->s_i64[0], woff.data(), (size_t)n));
+    TRY(h2d(c, c->s_i64[1], aoff.data(), (size_t)n));
+    HIPCK(c, c->s_i32[2].reserve(n));
+    HIPCK(c, c->s_i32[3].reserve(n));
+    double *dlk = nullptr;
+    if (outLK) { HIPCK(c, c->s_f64[2].reserve(n)); dlk = c->s_f64[2].p; }
+    OutSpec o{c->s_words.p, c->s_aux.p, c->s_i64[0].p, c->s_i64[1].p, c->s_i32[2].p, c->s_i32[3].p};
+    DISPATCH3(c, k_merge, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), n, c->s_i32[0].p, c->s_f64[0].p,
+                                                                         c->s_u8[0].p, c->s_i32[1].p, c->s_f64[1].p,
+                                                                         c->s_u8[1].p, c->s_u8[2].p, dnm1, dnm2, o, dlk));
+    HIPCK(c, hipGetLastError());
+    if (outLK) HIPCK(c, hipMemcpyAsync(outLK, dlk, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outList);
+}
+
+extern "C" int maple_blen_batch(maple_ctx *c, int32_t n, const int32_t *pl, const int32_t *cl, const uint8_t *tip,
+                                double *t, uint8_t *isFalse)
+{
+    if (!c || n < 0 || !pl || !cl || !tip || !t || !isFalse) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    TRY(check_ids(c, n, pl, false, "parentList"));
+    TRY(check_ids(c, n, cl, false, "childList"));
+    std::vector<int64_t> aoff(n);
+    int64_t tot = 0;
+    for (int i = 0; i < n; i++) { aoff[i] = tot; tot += (int64_t)c->h_n_ent[pl[i]] + c->h_n_ent[cl[i]]; }
+    HIPCK(c, c->s_ais.reserve((size_t)tot));
+    TRY(h2d(c, c->s_i32[0], pl, (size_t)n));
+    TRY(h2d(c, c->s_i32[1], cl, (size_t)n));
+    TRY(h2d(c, c->s_u8[0], tip, (size_t)n));
+    TRY(h2d(c, c->s_i64[0], aoff.data(), (size_t)n));
+    HIPCK(c, c->s_f64[0].reserve(n));
+    HIPCK(c, c->s_u8[1].reserve(n));
+    DISPATCH3(c, k_blen, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
+                                                                        c->s_u8[0].p, c->s_ais.p, c->s_i64[0].p,
+                                                                        c->s_f64[0].p, c->s_u8[1].p));
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(t, c->s_f64[0].p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(isFalse, c->s_u8[1].p, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MAPLE_OK;
+}
+
+extern "C" int maple_differ_batch(maple_ctx *c, int32_t n, const int32_t *l1, const int32_t *l2, uint8_t *out)
+{
+    if (!c || n < 0 || !l1 || !l2 || !out) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    TRY(check_ids(c, n, l1, false, "list1"));
+    TRY(check_ids(c, n, l2, true, "list2"));
+    TRY(h2d(c, c->s_i32[0], l1, (size_t)n));
+    TRY(h2d(c, c->s_i32[1], l2, (size_t)n));
+    HIPCK(c, c->s_u8[0].reserve(n));
+    DISPATCH3(c, k_differ, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
+                                                                          c->s_u8[0].p));
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(out, c->s_u8[0].p, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MAPLE_OK;
+}
+
+extern "C" int maple_pass_branch_batch(maple_ctx *c, int32_t n, const int32_t *l, const int32_t *ml, const uint8_t *up,
+                                       int32_t *outList)
+{
+    if (!c || n < 0 || !l || !ml || !up || !outList) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(check_ids(c, n, l, false, "list"));
+    const int32_t nml = (int32_t)c->h_mut_cnt.size();
+    std::vector<int64_t> woff(n), aoff(n);
+    int64_t tot = 0;
+    for (int i = 0; i < n; i++) {
+        if (ml[i] < 0 || ml[i] >= nml) return fail(c, MAPLE_ERR_ARG, "mutList[%d] = %d is not a mutation-list id", i, ml[i]);
+        woff[i] = tot; aoff[i] = 5 * tot;
+        tot += (int64_t)c->h_n_ent[l[i]] + 2 * (int64_t)c->h_mut_cnt[ml[i]];
+    }
+    HIPCK(c, c->s_words.reserve((size_t)tot));
+    HIPCK(c, c->s_aux.reserve((size_t)(5 * tot)));
+    TRY(h2d(c, c->s_i32[0], l, (size_t)n));
+    TRY(h2d(c, c->s_i32[1], ml, (size_t)n));
+    TRY(h2d(c, c->s_u8[0], up, (size_t)n));
+    TRY(h2d(c, c->s_i64[0], woff.data(), (size_t)n));
+    TRY(h2d(c, c->s_i64[1], aoff.data(), (size_t)n));
+    HIPCK(c, c->s_i32[2].reserve(n));
+    HIPCK(c, c->s_i32[3].reserve(n));
+    OutSpec o{c->s_words.p, c->s_aux.p, c->s_i64[0].p, c->s_i64[1].p, c->s_i32[2].p, c->s_i32[3].p};
+    hipLaunchKernelGGL(k_pass, dim3(grid_for(n)), dim3(MAPLE_BLOCK), 0, c->stream, c->lRef, view(c), mview(c), n,
+                       c->s_i32[0].p, c->s_i32[1].p, c->s_u8[0].p, o);
+    HIPCK(c, hipGetLastError());
+    return commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outList);
+}
+
+extern "C" int maple_shorten_batch(maple_ctx *c, int32_t n, const int32_t *l, int32_t *outList)
+{
+    if (!c || n < 0 || !l || !outList) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    TRY(check_ids(c, n, l, false, "list"));
+    std::vector<int64_t> woff(n), aoff(n);
+    int64_t tot = 0;
+    for (int i = 0; i < n; i++) { woff[i] = tot; aoff[i] = 5 * tot; tot += c->h_n_ent[l[i]]; }
+    HIPCK(c, c->s_words.reserve((size_t)tot));
+    HIPCK(c, c->s_aux.reserve((size_t)(5 * tot)));
+    TRY(h2d(c, c->s_i32[0], l, (size_t)n));
+    TRY(h2d(c, c->s_i64[0], woff.data(), (size_t)n));
+    TRY(h2d(c, c->s_i64[1], aoff.data(), (size_t)n));
+    HIPCK(c, c->s_i32[2].reserve(n));
+    HIPCK(c, c->s_i32[3].reserve(n));
+    OutSpec o{c->s_words.p, c->s_aux.p, c->s_i64[0].p, c->s_i64[1].p, c->s_i32[2].p, c->s_i32[3].p};
+    DISPATCH3(c, k_shorten, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), n, c->s_i32[0].p, o));
+    HIPCK(c, hipGetLastError());
+    return commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outList);
+}
+
+extern "C" int maple_root_vector_batch(maple_ctx *c, int32_t n, const int32_t *l, const double *bl, const uint8_t *tip,
+                                       const int64_t *pathOff, const int32_t *pathMut, int32_t *outList)
+{
+    if (!c || n < 0 || !l || !bl || !tip || !pathOff || !outList) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    TRY(check_ids(c, n, l, false, "list"));
+    const int32_t nml = (int32_t)c->h_mut_cnt.size();
+    std::vector<int64_t> capOff(n + 1), woff(n), aoff(n);
+    int64_t tot = 0;
+    for (int i = 0; i < n; i++) {
+        int64_t cap = c->h_n_ent[l[i]];
+        for (int64_t k = pathOff[i]; k < pathOff[i + 1]; k++) {
+            if (pathMut[k] >= nml) return fail(c, MAPLE_ERR_ARG, "pathMutLists[%lld] is not a mutation-list id", (long long)k);
+            if (pathMut[k] >= 0) cap += 4 * (int64_t)c->h_mut_cnt[pathMut[k]];
+        }
+        capOff[i] = tot; woff[i] = 3 * tot; aoff[i] = 15 * tot;
+        tot += cap;
+    }
+    capOff[n] = tot;
+    HIPCK(c, c->s_words.reserve((size_t)(3 * tot)));
+    HIPCK(c, c->s_aux.reserve((size_t)(15 * tot)));
+    const int64_t np = pathOff[n];
+    TRY(h2d(c, c->s_i32[0], l, (size_t)n));
+    TRY(h2d(c, c->s_f64[0], bl, (size_t)n));
+    TRY(h2d(c, c->s_u8[0], tip, (size_t)n));
+    TRY(h2d(c, c->s_i64[0], woff.data(), (size_t)n));
+    TRY(h2d(c, c->s_i64[1], aoff.data(), (size_t)n));
+    TRY(h2d(c, c->s_i64[2], pathOff, (size_t)n + 1));
+    TRY(h2d(c, c->s_i32[1], pathMut, (size_t)np));
+    TRY(h2d(c, c->s_i64[3], capOff.data(), (size_t)n + 1));
+    HIPCK(c, c->s_i32[2].reserve(n));
+    HIPCK(c, c->s_i32[3].reserve(n));
+    OutSpec o{c->s_words.p, c->s_aux.p, c->s_i64[0].p, c->s_i64[1].p, c->s_i32[2].p, c->s_i32[3].p};
+    DISPATCH3(c, k_root_vector, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), mview(c), n, c->s_i32[0].p,
+                                                                               c->s_f64[0].p, c->s_u8[0].p, c->s_i64[2].p,
+                                                                               c->s_i32[1].p, c->s_i64[3].p, o));
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipStreamSynchronize(c->stream));   // commit_lists reuses s_i64[2..5]
+    return commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outList);
+}
+
+extern "C" int maple_evaluate_placement_batch(maple_ctx *c, int32_t n, const int32_t *midTot, const int32_t *down,
+                                              const int32_t *up, const double *dist, const int32_t *rem,
+                                              const uint8_t *remTip, const uint8_t *fromTip1, double *out4)
+{
+    if (!c || n < 0 || !midTot || !down || !up || !dist || !rem || !remTip || !fromTip1 || !out4) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    TRY(check_ids(c, n, midTot, false, "midTot"));
+    TRY(check_ids(c, n, down, false, "downVect"));
+    TRY(check_ids(c, n, up, false, "upVect"));
+    TRY(check_ids(c, n, rem, false, "removedPartials"));
+    std::vector<int64_t> capOff(n), aisOff(n);
+    int64_t tot = 0, totA = 0;
+    for (int i = 0; i < n; i++) {
+        int64_t nd = c->h_n_ent[down[i]], nu = c->h_n_ent[up[i]], nr = c->h_n_ent[rem[i]], nm = c->h_n_ent[midTot[i]];
+        capOff[i] = tot;
+        tot += (nd + nr) + (nu + nr) + (nu + nd);
+        aisOff[i] = totA;
+        int64_t mx = nm + nr;
+        if (nu + nd + nr > mx) mx = nu + nd + nr;
+        if (nu + nr + nd > mx) mx = nu + nr + nd;
+        totA += mx;
+    }
+    HIPCK(c, c->s_words.reserve((size_t)tot));
+    HIPCK(c, c->s_aux.reserve((size_t)(5 * tot)));
+    HIPCK(c, c->s_ais.reserve((size_t)totA));
+    TRY(h2d(c, c->s_i32[0], midTot, (size_t)n));
+    TRY(h2d(c, c->s_i32[1], down, (size_t)n));
+    TRY(h2d(c, c->s_i32[2], up, (size_t)n));
+    TRY(h2d(c, c->s_i32[3], rem, (size_t)n));
+    TRY(h2d(c, c->s_f64[0], dist, (size_t)n));
+    TRY(h2d(c, c->s_u8[0], remTip, (size_t)n));
+    TRY(h2d(c, c->s_u8[1], fromTip1, (size_t)n));
+    TRY(h2d(c, c->s_i64[0], capOff.data(), (size_t)n));
+    TRY(h2d(c, c->s_i64[1], aisOff.data(), (size_t)n));
+    HIPCK(c, c->s_f64[1].reserve((size_t)4 * n));
+    HIPCK(c, c->s_i32[4].reserve(n));
+    DISPATCH3(c, k_evalplace, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
+                                                                             c->s_i32[2].p, c->s_f64[0].p, c->s_i32[3].p,
+                                                                             c->s_u8[0].p, c->s_u8[1].p, c->s_words.p,
+                                                                             c->s_aux.p, c->s_i64[0].p, c->s_ais.p,
+                                                                             c->s_i64[1].p, c->s_f64[1].p, c->s_i32[4].p));
+    HIPCK(c, hipGetLastError());
+    std::vector<int32_t> st(n);
+    HIPCK(c, hipMemcpyAsync(out4, c->s_f64[1].p, (size_t)4 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(st.data(), c->s_i32[4].p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++)
+        if (st[i]) return fail(c, MAPLE_ERR_FATAL, "evaluatePlacement item %d: a merge returned None", i);
+    return MAPLE_OK;
+}
+
+// ---- device-resident forms ---------------------------------------------------------------------------
+extern "C" int maple_append_batch_dev(maple_ctx *c, int32_t n, const int32_t *pl, const int32_t *cl, const uint8_t *tip,
+                                      const double *bl, double *out, void *stream)
+{
+    if (!c || n < 0 || !pl || !cl || !tip || !bl || !out) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    HIPCK(c, hipEventRecord(c->ev0, s));
+    DISPATCH3(c, k_append, <<<grid_for(n), MAPLE_BLOCK, 0, s>>>(c->dm, view(c), n, pl, cl, tip, bl, out));
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipEventRecord(c->ev1, s));
+    c->timed = true;
+    return MAPLE_OK;
+}
+
+extern "C" int maple_append_query_dev(maple_ctx *c, int32_t n, int32_t childList, int isTipC, double bLen,
+                                      const int32_t *cand, double *out, void *stream)
+{
+    if (!c || n < 0 || !cand || !out) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    TRY(check_ids(c, 1, &childList, false, "childList"));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    HIPCK(c, hipEventRecord(c->ev0, s));
+    DISPATCH3(c, k_append_query, <<<grid_for(n), MAPLE_BLOCK, 0, s>>>(c->dm, view(c), n, childList, isTipC, bLen, cand, out));
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipEventRecord(c->ev1, s));
+    c->timed = true;
+    return MAPLE_OK;
+}
+
+extern "C" int maple_last_kernel_ms(maple_ctx *c, float *ms)
+{
+    if (!c || !ms) return MAPLE_ERR_ARG;
+    if (!c->timed) return fail(c, MAPLE_ERR_STATE, "no timed launch yet");
+    HIPCK(c, hipEventSynchronize(c->ev1));
+    HIPCK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return MAPLE_OK;
+}
+
+extern "C" int maple_append_algorithmic_bytes(maple_ctx *c, int32_t n, const int32_t *pl, const int32_t *cl,
+                                              int child_once, uint64_t *bytes)
+{
+    if (!c || n < 0 || !pl || !bytes) return MAPLE_ERR_ARG;
+    TRY(check_ids(c, n, pl, false, "parentList"));
+    uint64_t b = 0;
+    // 8 B per entry word + 8 B per aux double (d0/d1 scalars, 4 per O vector) + 8 B result   
+    for (int i = 0; i < n; i++) b += 8ull * c->h_n_ent[pl[i]] + 8ull * c->h_n_aux[pl[i]] + 8ull;
+    if (cl) {
+        if (child_once) b += 8ull * c->h_n_ent[cl[0]] + 8ull * c->h_n_aux[cl[0]];
+        else {
+            TRY(check_ids(c, n, cl, false, "childList"));
+            for (int i = 0; i < n; i++) b += 8ull * c->h_n_ent[cl[i]] + 8ull * c->h_n_aux[cl[i]];
+        }
+    }
+    *bytes = b;
+    return MAPLE_OK;
+}

@@ -1,0 +1,293 @@
+"""ctypes binding of oracle/libmaple_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module.  The product (``maple_amd``) never does.
+Lists are exchanged in the reference's tuple form (M:378-390).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libmaple_oracle.so")
+
+OENTRY = np.dtype(
+    [("type", np.int32), ("x", np.int32), ("len", np.int32), ("flag", np.int32),
+     ("d0", np.float64), ("d1", np.float64), ("vec", np.float64, (4,))], align=True)
+assert OENTRY.itemsize == 64
+
+
+class OModel(C.Structure):
+    _fields_ = [
+        ("lRef", C.c_int), ("useRateVariation", C.c_int), ("usingErrorRate", C.c_int),
+        ("errorRateSiteSpecific", C.c_int),
+        ("refIdx", C.c_void_p), ("siteRates", C.c_void_p), ("errorRates", C.c_void_p),
+        ("cumulativeRate", C.c_void_p), ("cumulativeErrorRate", C.c_void_p),
+        ("Q", C.c_double * 16), ("rootFreqs", C.c_double * 4),
+        ("errorRate", C.c_double), ("totError", C.c_double), ("globalTotRate", C.c_double),
+        ("minimumCarryOver", C.c_double), ("thresholdProb", C.c_double), ("minBLenSensitivity", C.c_double),
+        ("thresholdDiffForUpdate", C.c_double), ("thresholdFoldChangeUpdate", C.c_double),
+    ]
+
+
+def build(force=False):
+    src = os.path.join(HERE, "maple_oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-s"])
+    return LIB
+
+
+def to_entries(gl, u):
+    """Reference tuple list -> OENTRY array."""
+    arr = np.zeros(len(gl), dtype=OENTRY)
+    for k, e in enumerate(gl):
+        r = arr[k]
+        t = e[0]
+        r["type"] = t
+        r["x"] = e[1]
+        r["len"] = len(e)
+        if t == 6:
+            if len(e) == 4:
+                r["d0"] = e[2]
+            r["vec"] = e[-1]
+        elif t < 5 and len(e) > 2:
+            if u:
+                if len(e) == 3:
+                    raise ValueError("length-3 tuple with the error model on")
+                r["d0"] = e[2]
+                if len(e) == 5:
+                    r["d1"] = e[3]
+                r["flag"] = 1 if e[-1] else 0
+            else:
+                r["d0"] = e[2]
+                if len(e) == 4:
+                    r["d1"] = e[3]
+    return arr
+
+
+def from_entries(arr, n, u):
+    out = []
+    for k in range(n):
+        r = arr[k]
+        t, x, ln = int(r["type"]), int(r["x"]), int(r["len"])
+        if t == 5:
+            out.append((5, x))
+        elif t == 6:
+            vec = [float(v) for v in r["vec"]]
+            out.append((6, x, vec) if ln == 3 else (6, x, float(r["d0"]), vec))
+        elif ln == 2:
+            out.append((t, x))
+        elif u:
+            fl = bool(r["flag"])
+            out.append((t, x, float(r["d0"]), fl) if ln == 4 else (t, x, float(r["d0"]), float(r["d1"]), fl))
+        else:
+            out.append((t, x, float(r["d0"])) if ln == 3 else (t, x, float(r["d0"]), float(r["d1"])))
+    return out
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Oracle:
+    """The reference's functions, by name, evaluated by the C restatement."""
+
+    def __init__(self, ref_idx, root_freqs, thresholdProb=1e-8, minBLenSensitivity=None,
+                 thresholdDiffForUpdate=1e-5, thresholdFoldChangeUpdate=1.01, defaultBLen=0.000033):
+        build()
+        self.lib = C.CDLL(LIB)
+        self.lib.omo_simplify.restype = C.c_int
+        self.ref_idx = np.ascontiguousarray(ref_idx, dtype=np.uint8)
+        self.lRef = len(self.ref_idx)
+        self.m = OModel()
+        m = self.m
+        m.lRef = self.lRef
+        m.refIdx = _p(self.ref_idx)
+        for i in range(4):
+            m.rootFreqs[i] = root_freqs[i]
+        m.globalTotRate = -float(self.lRef)
+        import sys
+        m.minimumCarryOver = sys.float_info.min * 1e50
+        m.thresholdProb = thresholdProb
+        m.minBLenSensitivity = minBLenSensitivity if minBLenSensitivity is not None else 0.001 / self.lRef
+        m.thresholdDiffForUpdate = thresholdDiffForUpdate
+        m.thresholdFoldChangeUpdate = thresholdFoldChangeUpdate
+        self.defaultBLen = defaultBLen
+        self._keep = []
+        self.u = False
+
+    def set_model(self, Q, siteRates=None, usingErrorRate=False, errorRateGlobal=0.0, errorRates=None):
+        m = self.m
+        Qf = np.asarray(Q, dtype=np.float64).reshape(16)
+        for i in range(16):
+            m.Q[i] = Qf[i]
+        self.sr = None if siteRates is None else np.ascontiguousarray(siteRates, dtype=np.float64)
+        self.er = None if errorRates is None else np.ascontiguousarray(errorRates, dtype=np.float64)
+        m.useRateVariation = 1 if self.sr is not None else 0
+        m.usingErrorRate = 1 if usingErrorRate else 0
+        m.errorRateSiteSpecific = 1 if (usingErrorRate and self.er is not None) else 0
+        m.errorRate = errorRateGlobal if errorRateGlobal is not None else 0.0
+        self.u = bool(usingErrorRate)
+        # cumulativeRate (M:6350-6370) / cumulativeErrorRate, totError (M:6373-6390), plain Python floats
+        lRef = self.lRef
+        cr = [0.0] * (lRef + 1)
+        nm = [Qf[0], Qf[5], Qf[10], Qf[15]]
+        ri = self.ref_idx.tolist()
+        if self.sr is not None:
+            srl = self.sr.tolist()
+            for i in range(lRef):
+                cr[i + 1] = cr[i] + nm[ri[i]] * srl[i]
+        else:
+            for i in range(lRef):
+                cr[i + 1] = cr[i] + nm[ri[i]]
+        self.cr = np.asarray(cr, dtype=np.float64)
+        self.cer = None
+        m.totError = 0.0
+        if usingErrorRate:
+            if self.er is not None:
+                ce = [0.0] * (lRef + 1)
+                erl = self.er.tolist()
+                for i in range(lRef):
+                    ce[i + 1] = ce[i] + erl[i]
+                self.cer = np.asarray(ce, dtype=np.float64)
+                m.totError = -ce[-1]
+            else:
+                m.totError = -m.errorRate * lRef
+        m.siteRates = _p(self.sr)
+        m.errorRates = _p(self.er)
+        m.cumulativeRate = _p(self.cr)
+        m.cumulativeErrorRate = _p(self.cer)
+
+    # ---- the reference's functions -------------------------------------------------------
+    def appendProbNode(self, P, Cl, isTipC, bLen):
+        a, b = to_entries(P, self.u), to_entries(Cl, self.u)
+        out = C.c_double()
+        rc = self.lib.omo_appendProbNode(C.byref(self.m), _p(a), len(a), _p(b), len(b), int(bool(isTipC)),
+                                         C.c_double(bLen), C.byref(out))
+        assert rc == 0
+        return out.value
+
+    def mergeVectors(self, pv1, b1, tip1, pv2, b2, tip2, returnLK=False, isUpDown=False, numMinor1=0, numMinor2=0):
+        a, b = to_entries(pv1, self.u), to_entries(pv2, self.u)
+        out = np.zeros(len(a) + len(b) + 2, dtype=OENTRY)
+        lk = C.c_double()
+        n = self.lib.omo_mergeVectors(C.byref(self.m), _p(a), len(a), C.c_double(b1), int(bool(tip1)), _p(b), len(b),
+                                      C.c_double(b2), int(bool(tip2)), int(bool(returnLK)), int(bool(isUpDown)),
+                                      int(numMinor1), int(numMinor2), _p(out), C.byref(lk))
+        if n == -1:
+            return None
+        if n < 0:
+            raise RuntimeError(f"mergeVectors fatal {n}")
+        res = from_entries(out, n, self.u)
+        return (res, lk.value) if returnLK else res
+
+    def estimateBranchLengthWithDerivative(self, P, Cl, fromTipC=False):
+        a, b = to_entries(P, self.u), to_entries(Cl, self.u)
+        t = C.c_double()
+        f = C.c_int()
+        scratch = np.zeros(len(a) + len(b) + 2)
+        self.lib.omo_estimateBranchLength(C.byref(self.m), _p(a), len(a), _p(b), len(b), int(bool(fromTipC)),
+                                          C.byref(t), C.byref(f), _p(scratch))
+        return False if f.value else t.value
+
+    def areVectorsDifferent(self, pv1, pv2):
+        if pv2 is None:
+            return True
+        a, b = to_entries(pv1, self.u), to_entries(pv2, self.u)
+        return bool(self.lib.omo_areVectorsDifferent(C.byref(self.m), _p(a), len(a), _p(b), len(b)))
+
+    def passGenomeListThroughBranch(self, pv, mutations, dirIsUp=False):
+        a = to_entries(pv, self.u)
+        mut = np.ascontiguousarray(np.asarray(mutations, dtype=np.int32).reshape(-1, 3))
+        out = np.zeros(len(a) + 2 * len(mut) + 2, dtype=OENTRY)
+        n = self.lib.omo_passGenomeListThroughBranch(C.byref(self.m), _p(a), len(a), _p(mut), len(mut),
+                                                     int(bool(dirIsUp)), _p(out))
+        return from_entries(out, n, self.u)
+
+    def shorten(self, vec):
+        a = to_entries(vec, self.u)
+        n = self.lib.omo_shorten(C.byref(self.m), _p(a), len(a))
+        return from_entries(a, n, self.u)
+
+    @staticmethod
+    def _path(pathMutations):
+        off = [0]
+        flat = []
+        for ml in pathMutations:
+            flat.extend(ml)
+            off.append(len(flat))
+        mut = np.ascontiguousarray(np.asarray(flat, dtype=np.int32).reshape(-1, 3))
+        return mut, np.asarray(off, dtype=np.int32)
+
+    def rootVector(self, pv, bLen, isFromTip, pathMutations):
+        a = to_entries(pv, self.u)
+        mut, off = self._path(pathMutations)
+        cap = len(a) + 4 * len(mut) + 4
+        out = np.zeros(cap, dtype=OENTRY)
+        tmp = np.zeros(cap, dtype=OENTRY)
+        n = self.lib.omo_rootVector(C.byref(self.m), _p(a), len(a), C.c_double(bLen), int(bool(isFromTip)), _p(mut),
+                                    _p(off), len(off) - 1, _p(out), _p(tmp), cap)
+        return from_entries(out, n, self.u)
+
+    def getPartialVec(self, i12, totLen, mutMatrix, errorRate, vect=None, upNode=False, flag=False):
+        M = np.ascontiguousarray(np.asarray(mutMatrix, dtype=np.float64).reshape(16))
+        v = None if vect is None else np.ascontiguousarray(vect, dtype=np.float64)
+        out = np.zeros(4)
+        self.lib.omo_getPartialVec(C.byref(self.m), int(i12), C.c_double(totLen if totLen else 0.0), _p(M),
+                                   C.c_double(errorRate if errorRate else 0.0), _p(v), int(bool(upNode)),
+                                   int(bool(flag)), _p(out))
+        return out.tolist()
+
+    def simplify(self, vec, refA):
+        v = np.ascontiguousarray(vec, dtype=np.float64)
+        st = C.c_int()
+        rc = self.lib.omo_simplify(C.byref(self.m), _p(v), int(refA), C.byref(st))
+        if rc < 0:
+            raise RuntimeError("simplify fatal")
+        return st.value
+
+    def evaluatePlacement(self, midTot, downVect, upVect, distance, removedPartials, isRemovedTip, fromTip1):
+        a, d, u_, r = (to_entries(x, self.u) for x in (midTot, downVect, upVect, removedPartials))
+        cap = len(d) + len(u_) + len(r) + 4
+        tmp = np.zeros(3 * cap, dtype=OENTRY)
+        scratch = np.zeros(len(a) + cap + 4)
+        out = np.zeros(4)
+        rc = self.lib.omo_evaluatePlacement(C.byref(self.m), _p(a), len(a), _p(d), len(d), _p(u_), len(u_),
+                                            C.c_double(distance), _p(r), len(r), int(bool(isRemovedTip)),
+                                            int(bool(fromTip1)), C.c_double(self.defaultBLen), _p(out), _p(tmp), cap,
+                                            _p(scratch))
+        if rc < 0:
+            raise RuntimeError("evaluatePlacement fatal")
+        return out.tolist()
+
+    def findProbRoot(self, pv, pathMutations, rootFreqsLogErrorCumulative=None):
+        a = to_entries(pv, self.u)
+        mut, off = self._path(pathMutations)
+        cap = len(a) + 4 * len(mut) + 4
+        t1 = np.zeros(cap, dtype=OENTRY)
+        t2 = np.zeros(cap, dtype=OENTRY)
+        if not hasattr(self, "_cb"):
+            cb = np.zeros((self.lRef + 1, 4), dtype=np.int32)
+            ri = self.ref_idx
+            oh = np.zeros((self.lRef, 4), dtype=np.int32)
+            oh[np.arange(self.lRef), ri] = 1
+            cb[1:] = np.cumsum(oh, axis=0)
+            self._cb = np.ascontiguousarray(cb)
+        rl = None
+        if self.u:
+            rf = [self.m.rootFreqs[i] for i in range(4)]
+            acc = [0.0] * (self.lRef + 1)
+            ri = self.ref_idx.tolist()
+            erl = self.er.tolist() if self.er is not None else [self.m.errorRate] * self.lRef
+            for i in range(self.lRef):
+                acc[i + 1] = acc[i] + math.log(rf[ri[i]] * (1.0 - 1.33333 * erl[i]) + 0.333333 * erl[i])
+            rl = np.asarray(acc)
+        out = C.c_double()
+        self.lib.omo_findProbRoot(C.byref(self.m), _p(a), len(a), _p(mut), _p(off), len(off) - 1, _p(self._cb), _p(rl),
+                                  _p(t1), _p(t2), cap, C.byref(out))
+        return out.value
