@@ -1,0 +1,291 @@
+"""ctypes binding of libmaple_hip.so (the C ABI in include/maple_hip.h).
+
+This is the only way the host reaches the GPU kernels.  There is no CPU
+fallback: if the shared library is missing or no MI355X is visible,
+construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .genome_list import PackedLists, pack_lists, pack_mutations, unpack_list
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmaple_hip.so")
+
+EXPORTS = [
+    "maple_abi_version", "maple_create", "maple_destroy", "maple_last_error", "maple_set_model", "maple_get_model",
+    "maple_lists_upload", "maple_lists_sizes", "maple_lists_download", "maple_arena_mark", "maple_arena_release",
+    "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
+    "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
+    "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_query_dev", "maple_last_kernel_ms",
+    "maple_append_algorithmic_bytes",
+]
+
+
+class MapleParams(C.Structure):
+    _fields_ = [("thresholdProb", C.c_double), ("minBLenSensitivity", C.c_double),
+                ("thresholdDiffForUpdate", C.c_double), ("thresholdFoldChangeUpdate", C.c_double),
+                ("defaultBLen", C.c_double)]
+
+
+class MapleError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Load libmaple_hip.so; raises if it has not been built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MapleError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                             "there is no CPU fallback for the placement path")
+        lib = C.CDLL(LIB_PATH)
+        lib.maple_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            getattr(lib, name)       # fail early if a declared symbol is not exported
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _i32(x):
+    return np.ascontiguousarray(x, dtype=np.int32)
+
+
+def _u8(x):
+    return np.ascontiguousarray(x, dtype=np.uint8)
+
+
+def _f64(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+class Device:
+    """One GPU context: model tables, the genome-list arena and the batched operators."""
+
+    def __init__(self, ref_idx, root_freqs, *, device=0, thresholdProb=1e-8, minBLenSensitivity=None,
+                 thresholdDiffForUpdate=1e-5, thresholdFoldChangeUpdate=1.01, defaultBLen=0.000033,
+                 arena_bytes=0):
+        self.lib = load_library()
+        self.ref_idx = _u8(ref_idx)
+        self.lRef = int(len(self.ref_idx))
+        if minBLenSensitivity is None:
+            minBLenSensitivity = 0.001 / self.lRef
+        p = MapleParams(thresholdProb, minBLenSensitivity, thresholdDiffForUpdate, thresholdFoldChangeUpdate, defaultBLen)
+        rf = _f64(root_freqs)
+        h = C.c_void_p()
+        rc = self.lib.maple_create(C.byref(h), int(device), self.lRef, _ptr(self.ref_idx), _ptr(rf), C.byref(p),
+                                   C.c_uint64(arena_bytes))
+        if rc != 0:
+            raise MapleError(f"maple_create failed ({rc}): no usable MI355X / HIP runtime; the placement path has no "
+                             "CPU fallback")
+        self.h = h
+        self.device = int(device)
+        self.u = False
+
+    # -- plumbing --------------------------------------------------------------------------
+    def _ck(self, rc):
+        if rc != 0:
+            msg = self.lib.maple_last_error(self.h)
+            raise MapleError(f"libmaple_hip error {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.maple_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- model -------------------------------------------------------------------------------
+    def set_model(self, Q, siteRates=None, usingErrorRate=False, errorRateGlobal=0.0, errorRates=None):
+        Qf = _f64(np.asarray(Q, dtype=np.float64).reshape(16))
+        sr = None if siteRates is None else _f64(siteRates)
+        er = None if (errorRates is None or not usingErrorRate) else _f64(errorRates)
+        self._ck(self.lib.maple_set_model(self.h, _ptr(Qf), _ptr(sr), int(bool(usingErrorRate)),
+                                          C.c_double(errorRateGlobal or 0.0), _ptr(er)))
+        self.u = bool(usingErrorRate)
+
+    def get_model(self):
+        cr = np.zeros(self.lRef + 1)
+        ce = np.zeros(self.lRef + 1)
+        te = C.c_double()
+        self._ck(self.lib.maple_get_model(self.h, _ptr(cr), _ptr(ce), C.byref(te)))
+        return cr, ce, te.value
+
+    # -- lists -------------------------------------------------------------------------------
+    def upload_packed(self, pl: PackedLists):
+        first = C.c_int32()
+        self._ck(self.lib.maple_lists_upload(self.h, len(pl), _ptr(pl.ent_off), _ptr(pl.pos), _ptr(pl.meta),
+                                             _ptr(pl.aux_off), _ptr(pl.aux), C.byref(first)))
+        return np.arange(first.value, first.value + len(pl), dtype=np.int32)
+
+    def upload(self, lists):
+        """Upload genome lists given in the reference's tuple form; returns their ids."""
+        return self.upload_packed(pack_lists(lists, self.u))
+
+    def sizes(self, ids):
+        ids = _i32(ids)
+        ne = np.zeros(len(ids), dtype=np.int32)
+        na = np.zeros(len(ids), dtype=np.int32)
+        self._ck(self.lib.maple_lists_sizes(self.h, len(ids), _ptr(ids), _ptr(ne), _ptr(na)))
+        return ne, na
+
+    def download(self, ids):
+        """Download lists by id into the reference's tuple form (None for id -1)."""
+        ids = _i32(ids)
+        good = ids[ids >= 0]
+        ne, na = self.sizes(good)
+        eo = np.zeros(len(good) + 1, dtype=np.int64)
+        ao = np.zeros(len(good) + 1, dtype=np.int64)
+        np.cumsum(ne, out=eo[1:])
+        np.cumsum(na, out=ao[1:])
+        pos = np.zeros(max(1, eo[-1]), dtype=np.int32)
+        meta = np.zeros(max(1, eo[-1]), dtype=np.uint32)
+        aux = np.zeros(max(1, ao[-1]), dtype=np.float64)
+        if len(good):
+            self._ck(self.lib.maple_lists_download(self.h, len(good), _ptr(good), _ptr(eo), _ptr(pos), _ptr(meta),
+                                                   _ptr(ao), _ptr(aux)))
+        out, k = [], 0
+        for i in ids:
+            if i < 0:
+                out.append(None)
+            else:
+                out.append(unpack_list(pos[eo[k]:eo[k + 1]], meta[eo[k]:eo[k + 1]], aux[ao[k]:ao[k + 1]], self.u))
+                k += 1
+        return out
+
+    def mark(self):
+        m = C.c_int64()
+        self._ck(self.lib.maple_arena_mark(self.h, C.byref(m)))
+        return m.value
+
+    def release(self, mark):
+        self._ck(self.lib.maple_arena_release(self.h, C.c_int64(mark)))
+
+    def stats(self):
+        a, b, c_, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.lib.maple_arena_stats(self.h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d)))
+        return dict(n_lists=a.value, n_entries=b.value, n_aux=c_.value, cap_entries=d.value)
+
+    def upload_mutations(self, mut_lists):
+        off, mut3 = pack_mutations(mut_lists)
+        first = C.c_int32()
+        self._ck(self.lib.maple_mutations_upload(self.h, len(off) - 1, _ptr(off), _ptr(mut3), C.byref(first)))
+        return np.arange(first.value, first.value + len(off) - 1, dtype=np.int32)
+
+    # -- batched operators ----------------------------------------------------------------------
+    def append_batch(self, parent, child, isTipC, bLen):
+        parent, child = _i32(parent), _i32(child)
+        n = len(parent)
+        tip = _u8(np.broadcast_to(isTipC, n))
+        bl = _f64(np.broadcast_to(bLen, n))
+        out = np.zeros(n)
+        self._ck(self.lib.maple_append_batch(self.h, n, _ptr(parent), _ptr(child), _ptr(tip), _ptr(bl), _ptr(out)))
+        return out
+
+    def merge_batch(self, l1, b1, tip1, l2, b2, tip2, isUpDown, returnLK=False, numMinor1=None, numMinor2=None):
+        l1, l2 = _i32(l1), _i32(l2)
+        n = len(l1)
+        b1, b2 = _f64(np.broadcast_to(b1, n)), _f64(np.broadcast_to(b2, n))
+        t1, t2 = _u8(np.broadcast_to(tip1, n)), _u8(np.broadcast_to(tip2, n))
+        ud = _u8(np.broadcast_to(isUpDown, n))
+        nm1 = None if numMinor1 is None else _i32(np.broadcast_to(numMinor1, n))
+        nm2 = None if numMinor2 is None else _i32(np.broadcast_to(numMinor2, n))
+        out = np.zeros(n, dtype=np.int32)
+        lk = np.zeros(n) if returnLK else None
+        self._ck(self.lib.maple_merge_batch(self.h, n, _ptr(l1), _ptr(b1), _ptr(t1), _ptr(l2), _ptr(b2), _ptr(t2),
+                                            _ptr(ud), _ptr(nm1), _ptr(nm2), _ptr(out), _ptr(lk)))
+        return (out, lk) if returnLK else out
+
+    def blen_batch(self, parent, child, fromTipC):
+        parent, child = _i32(parent), _i32(child)
+        n = len(parent)
+        tip = _u8(np.broadcast_to(fromTipC, n))
+        t = np.zeros(n)
+        f = np.zeros(n, dtype=np.uint8)
+        self._ck(self.lib.maple_blen_batch(self.h, n, _ptr(parent), _ptr(child), _ptr(tip), _ptr(t), _ptr(f)))
+        return t, f.astype(bool)
+
+    def differ_batch(self, l1, l2):
+        l1, l2 = _i32(l1), _i32(l2)
+        out = np.zeros(len(l1), dtype=np.uint8)
+        self._ck(self.lib.maple_differ_batch(self.h, len(l1), _ptr(l1), _ptr(l2), _ptr(out)))
+        return out.astype(bool)
+
+    def pass_branch_batch(self, lists, mutLists, dirIsUp):
+        lists, mutLists = _i32(lists), _i32(mutLists)
+        n = len(lists)
+        up = _u8(np.broadcast_to(dirIsUp, n))
+        out = np.zeros(n, dtype=np.int32)
+        self._ck(self.lib.maple_pass_branch_batch(self.h, n, _ptr(lists), _ptr(mutLists), _ptr(up), _ptr(out)))
+        return out
+
+    def shorten_batch(self, lists):
+        lists = _i32(lists)
+        out = np.zeros(len(lists), dtype=np.int32)
+        self._ck(self.lib.maple_shorten_batch(self.h, len(lists), _ptr(lists), _ptr(out)))
+        return out
+
+    def root_vector_batch(self, lists, bLen, isFromTip, paths):
+        """paths[i] = mutation-list ids on the walk node -> root (node first)."""
+        lists = _i32(lists)
+        n = len(lists)
+        bl = _f64(np.broadcast_to(bLen, n))
+        tip = _u8(np.broadcast_to(isFromTip, n))
+        off = np.zeros(n + 1, dtype=np.int64)
+        flat = []
+        for i, p in enumerate(paths):
+            flat.extend(int(x) for x in p)
+            off[i + 1] = len(flat)
+        pm = _i32(flat if flat else [0])
+        out = np.zeros(n, dtype=np.int32)
+        self._ck(self.lib.maple_root_vector_batch(self.h, n, _ptr(lists), _ptr(bl), _ptr(tip), _ptr(off), _ptr(pm),
+                                                  _ptr(out)))
+        return out
+
+    def evaluate_placement_batch(self, midTot, down, up, distance, removed, isRemovedTip, fromTip1):
+        midTot, down, up, removed = _i32(midTot), _i32(down), _i32(up), _i32(removed)
+        n = len(midTot)
+        dist = _f64(np.broadcast_to(distance, n))
+        rt, ft = _u8(np.broadcast_to(isRemovedTip, n)), _u8(np.broadcast_to(fromTip1, n))
+        out = np.zeros((n, 4))
+        self._ck(self.lib.maple_evaluate_placement_batch(self.h, n, _ptr(midTot), _ptr(down), _ptr(up), _ptr(dist),
+                                                         _ptr(removed), _ptr(rt), _ptr(ft), _ptr(out)))
+        return out
+
+    # -- device-resident forms (pointers into HBM, e.g. torch tensors' data_ptr()) ------------------
+    def append_batch_dev(self, n, parent_ptr, child_ptr, tip_ptr, blen_ptr, out_ptr, stream=0):
+        self._ck(self.lib.maple_append_batch_dev(self.h, int(n), C.c_void_p(parent_ptr), C.c_void_p(child_ptr),
+                                                 C.c_void_p(tip_ptr), C.c_void_p(blen_ptr), C.c_void_p(out_ptr),
+                                                 C.c_void_p(stream)))
+
+    def append_query_dev(self, n, child_list, isTipC, bLen, cand_ptr, out_ptr, stream=0):
+        self._ck(self.lib.maple_append_query_dev(self.h, int(n), int(child_list), int(bool(isTipC)), C.c_double(bLen),
+                                                 C.c_void_p(cand_ptr), C.c_void_p(out_ptr), C.c_void_p(stream)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._ck(self.lib.maple_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def append_algorithmic_bytes(self, parent, child=None, child_once=False):
+        parent = _i32(parent)
+        ch = None if child is None else _i32(child)
+        b = C.c_uint64()
+        self._ck(self.lib.maple_append_algorithmic_bytes(self.h, len(parent), _ptr(parent), _ptr(ch),
+                                                         int(bool(child_once)), C.byref(b)))
+        return b.value

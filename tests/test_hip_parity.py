@@ -1,0 +1,219 @@
+"""GPU parity: the HIP kernels (through the C ABI) against the reference's recorded answers
+(tests/golden) and against the C oracle on the same inputs.
+
+Bar: integer structure (entry types, positions, reference nucleotides, tuple lengths, flags,
+None / False / -inf outcomes) bit-exact; log-likelihoods, branch lengths and partial vectors
+within 1e-9 relative of the reference (north_star allows 1e-6).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from golden_util import close, fixture_names, lists_match, load, model_args, ref_indices, tup
+
+pytestmark = pytest.mark.gpu
+REL = 1e-9
+FIXTURES = fixture_names()
+
+
+def make_device(f):
+    from maple_amd.runtime import Device
+    ctx = f["context"]
+    return Device(ref_indices(ctx), ctx["rootFreqs"], thresholdProb=ctx["thresholdProb"],
+                  minBLenSensitivity=ctx["minBLenSensitivity"], thresholdDiffForUpdate=ctx["thresholdDiffForUpdate"],
+                  thresholdFoldChangeUpdate=ctx["thresholdFoldChangeUpdate"], defaultBLen=ctx["defaultBLen"],
+                  arena_bytes=256 << 20)
+
+
+def make_oracle(f):
+    from oracle.oracle_py import Oracle
+    ctx = f["context"]
+    return Oracle(ref_indices(ctx), ctx["rootFreqs"], thresholdProb=ctx["thresholdProb"],
+                  minBLenSensitivity=ctx["minBLenSensitivity"], thresholdDiffForUpdate=ctx["thresholdDiffForUpdate"],
+                  thresholdFoldChangeUpdate=ctx["thresholdFoldChangeUpdate"], defaultBLen=ctx["defaultBLen"])
+
+
+def by_model(f, fn):
+    groups = {}
+    for rec in f["calls"][fn]:
+        if rec.get("raised"):
+            continue
+        groups.setdefault(rec["model"], []).append(rec)
+    return groups
+
+
+@pytest.fixture(scope="module", params=FIXTURES)
+def env(request):
+    f = load(request.param)
+    dev = make_device(f)
+    yield f, dev, make_oracle(f)
+    dev.close()
+
+
+def test_model_tables(env):
+    f, dev, o = env
+    for mod in f["models"]:
+        dev.set_model(**model_args(mod))
+        o.set_model(**model_args(mod))
+        cr, ce, te = dev.get_model()
+        assert np.array_equal(cr, o.cr)
+        lRef = dev.lRef
+        probe = mod.get("cumulativeRate_probe")
+        if probe:
+            assert [cr[1], cr[lRef // 2], cr[lRef]] == probe
+        if mod["usingErrorRate"]:
+            assert te == mod["totError"]
+
+
+def test_appendProbNode(env):
+    f, dev, o = env
+    total = 0
+    for mid, recs in by_model(f, "appendProbNode").items():
+        dev.set_model(**model_args(f["models"][mid]))
+        o.set_model(**model_args(f["models"][mid]))
+        mark = dev.mark()
+        ids = dev.upload([tup(r["P"]) for r in recs] + [tup(r["C"]) for r in recs])
+        n = len(recs)
+        got = dev.append_batch(ids[:n], ids[n:], [r["isTipC"] for r in recs], [r["bLen"] for r in recs])
+        dev.release(mark)
+        for g, r in zip(got, recs):
+            assert close(float(g), r["ret"], REL), (g, r["ret"])
+            assert close(float(g), o.appendProbNode(tup(r["P"]), tup(r["C"]), r["isTipC"], r["bLen"]), REL)
+        total += n
+    assert total > 100
+
+
+def test_mergeVectors(env):
+    f, dev, o = env
+    total = 0
+    for mid, recs in by_model(f, "mergeVectors").items():
+        dev.set_model(**model_args(f["models"][mid]))
+        for want_lk in (False, True):
+            sub = [r for r in recs if r["returnLK"] == want_lk]
+            if not sub:
+                continue
+            mark = dev.mark()
+            ids = dev.upload([tup(r["pv1"]) for r in sub] + [tup(r["pv2"]) for r in sub])
+            n = len(sub)
+            res = dev.merge_batch(ids[:n], [r["b1"] or 0.0 for r in sub], [r["tip1"] for r in sub], ids[n:],
+                                  [r["b2"] or 0.0 for r in sub], [r["tip2"] for r in sub],
+                                  [r["isUpDown"] for r in sub], returnLK=want_lk,
+                                  numMinor1=[r["numMinor1"] for r in sub], numMinor2=[r["numMinor2"] for r in sub])
+            out, lk = res if want_lk else (res, None)
+            lists = dev.download(out)
+            dev.release(mark)
+            for k, r in enumerate(sub):
+                want = r["ret"]
+                if want_lk:
+                    assert lists_match(lists[k], tup(want[0]), REL)
+                    assert close(float(lk[k]), want[1], REL), (lk[k], want[1])
+                else:
+                    assert lists_match(lists[k], tup(want), REL), (lists[k], want)
+            total += n
+    assert total > 100
+
+
+def test_estimateBranchLength(env):
+    f, dev, o = env
+    for mid, recs in by_model(f, "estimateBranchLengthWithDerivative").items():
+        dev.set_model(**model_args(f["models"][mid]))
+        mark = dev.mark()
+        ids = dev.upload([tup(r["P"]) for r in recs] + [tup(r["C"]) for r in recs])
+        n = len(recs)
+        t, isf = dev.blen_batch(ids[:n], ids[n:], [r["fromTipC"] for r in recs])
+        dev.release(mark)
+        for k, r in enumerate(recs):
+            if r["ret"] is False:
+                assert isf[k]
+            else:
+                assert not isf[k] and close(float(t[k]), r["ret"], REL), (t[k], r["ret"])
+
+
+def test_evaluatePlacement(env):
+    f, dev, o = env
+    for mid, recs in by_model(f, "evaluatePlacement").items():
+        dev.set_model(**model_args(f["models"][mid]))
+        mark = dev.mark()
+        n = len(recs)
+        ids = dev.upload([tup(r[k]) for k in ("midTot", "downVect", "upVect", "removedPartials") for r in recs])
+        out = dev.evaluate_placement_batch(ids[:n], ids[n:2 * n], ids[2 * n:3 * n], [r["distance"] for r in recs],
+                                           ids[3 * n:], [r["isRemovedTip"] for r in recs],
+                                           [r["fromTip1"] for r in recs])
+        dev.release(mark)
+        for k, r in enumerate(recs):
+            want = [0.0 if w is False else w for w in r["ret"]]
+            assert all(close(float(g), w, 1e-8) for g, w in zip(out[k], want)), (out[k], want)
+
+
+def test_rootVector(env):
+    f, dev, o = env
+    for mid, recs in by_model(f, "rootVector").items():
+        dev.set_model(**model_args(f["models"][mid]))
+        mark = dev.mark()
+        ids = dev.upload([tup(r["pv"]) for r in recs])
+        paths = [dev.upload_mutations(r["pathMutations"]) for r in recs]
+        out = dev.root_vector_batch(ids, [r["bLen"] or 0.0 for r in recs], [r["isFromTip"] for r in recs], paths)
+        lists = dev.download(out)
+        dev.release(mark)
+        for k, r in enumerate(recs):
+            assert lists_match(lists[k], tup(r["ret"]), REL), (lists[k], r["ret"])
+
+
+def _u_groups(f, fn):
+    g = {}
+    for rec in f["calls"][fn]:
+        g.setdefault(bool(rec["usingErrorRate"]), []).append(rec)
+    return g
+
+
+def test_structural_functions(env):
+    f, dev, o = env
+    Q = f["models"][0]["Q"]
+    for u, recs in _u_groups(f, "passGenomeListThroughBranch").items():
+        dev.set_model(Q, usingErrorRate=u, errorRateGlobal=1e-4)
+        mark = dev.mark()
+        ids = dev.upload([tup(r["pv"]) for r in recs])
+        mids = dev.upload_mutations([r["mutations"] for r in recs])
+        lists = dev.download(dev.pass_branch_batch(ids, mids, [r["dirIsUp"] for r in recs]))
+        dev.release(mark)
+        for k, r in enumerate(recs):
+            assert lists_match(lists[k], tup(r["ret"]), 0.0), (lists[k], r["ret"])
+    for u, recs in _u_groups(f, "shorten").items():
+        dev.set_model(Q, usingErrorRate=u, errorRateGlobal=1e-4)
+        mark = dev.mark()
+        lists = dev.download(dev.shorten_batch(dev.upload([tup(r["vec"]) for r in recs])))
+        dev.release(mark)
+        for k, r in enumerate(recs):
+            assert lists_match(lists[k], tup(r["ret"]), 0.0)
+    for u, recs in _u_groups(f, "areVectorsDifferent").items():
+        recs = [r for r in recs if r["pv2"] is not None]
+        dev.set_model(Q, usingErrorRate=u, errorRateGlobal=1e-4)
+        mark = dev.mark()
+        n = len(recs)
+        ids = dev.upload([tup(r["pv1"]) for r in recs] + [tup(r["pv2"]) for r in recs])
+        got = dev.differ_batch(ids[:n], ids[n:])
+        dev.release(mark)
+        assert [bool(g) for g in got] == [r["ret"] for r in recs]
+
+
+def test_ops_mirror_reads_like_the_reference(env):
+    """The same-name host functions (maple_amd.ops) on a few records per function."""
+    from maple_amd.ops import GenomeOps
+    f, dev, o = env
+    ops = GenomeOps(dev)
+    for mid, recs in list(by_model(f, "appendProbNode").items())[:2]:
+        dev.set_model(**model_args(f["models"][mid]))
+        for r in recs[:5]:
+            assert close(ops.appendProbNode(tup(r["P"]), tup(r["C"]), r["isTipC"], r["bLen"]), r["ret"], REL)
+    for mid, recs in list(by_model(f, "mergeVectors").items())[:2]:
+        dev.set_model(**model_args(f["models"][mid]))
+        for r in [x for x in recs if not x["returnLK"]][:5]:
+            got = ops.mergeVectors(tup(r["pv1"]), r["b1"], r["tip1"], tup(r["pv2"]), r["b2"], r["tip2"],
+                                   isUpDown=r["isUpDown"])
+            assert lists_match(got, tup(r["ret"]), REL)
+    for mid, recs in list(by_model(f, "estimateBranchLengthWithDerivative").items())[:2]:
+        dev.set_model(**model_args(f["models"][mid]))
+        for r in recs[:5]:
+            got = ops.estimateBranchLengthWithDerivative(tup(r["P"]), tup(r["C"]), r["fromTipC"])
+            assert (got is False) if r["ret"] is False else close(got, r["ret"], REL)
