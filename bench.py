@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- candidate SPR placements / second on MI355X (BASELINE.json metric).
+
+A *step* is one pass of the hot path over one batch of synthetic input: every query genome list of
+this rank is scored with appendProbNode (M:6505-6785) against every candidate branch of a
+synthetic SARS-CoV-2-like tree (the mid-branch ``probVectTotUp`` lists, M:8050), followed by the
+per-query arg-max and -- for N>1 -- one RCCL all-gather of the (score, branch) proposals, the
+analogue of the reference's gather-and-sort of proposed moves (M:12306-12312).  Queries are sharded
+round-robin over ranks exactly like ``assignCoreNumbers`` (M:12164-12195); the tree mirror is
+replicated; per-GPU work is fixed (weak scaling).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  Inputs (tree mirror, query lists, pair index arrays) are resident
+in HBM before the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+UNREST_Q = [[-0.5524, 0.0602, 0.3655, 0.1267],
+            [0.1666, -2.6077, 0.0405, 2.4006],
+            [0.8421, 0.1305, -2.4012, 1.4286],
+            [0.0688, 0.4849, 0.0502, -0.6039]]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=10000, help="tips of the synthetic tree (BASELINE configs[1]: 10k)")
+    ap.add_argument("--queries", type=int, default=256, help="query genome lists per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate host time spent on cpu_baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the placement path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    distd = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        distd = dist
+
+    from maple_amd.host import reference_tables, tip_genome_list
+    from maple_amd.runtime import Device
+    from maple_amd.synth import make_dataset
+    from maple_amd.tree_mirror import TreeMirror
+
+    t_setup = time.time()
+    data = make_dataset(n_samples=args.samples, l_ref=29903, seed=1, mean_diffs=30.0)
+    ref_idx, root_freqs = reference_tables(data.ref)
+    dev = Device(ref_idx, root_freqs, device=local_rank, arena_bytes=4 << 30)
+    dev.set_model(UNREST_Q)
+    tip_lists = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
+    mirror = TreeMirror(dev, data.parent, data.blen, tip_lists).build()
+    l_ref = dev.lRef
+    cand_nodes = mirror.candidate_nodes(1.0 / (10 * l_ref))
+    cand_lists = mirror.tot_up[cand_nodes]
+    # queries of this rank: samples rank, rank+world, ... (round-robin like coreNum, M:12164-12195)
+    q_nodes = np.asarray(data.tip_node[rank::world][: args.queries], dtype=np.int64)
+    q_lists = mirror.lower[q_nodes]
+    Q, Cn = len(q_lists), len(cand_lists)
+    n_pairs = Q * Cn
+    parent_ids = np.tile(cand_lists.astype(np.int32), Q)
+    child_ids = np.repeat(q_lists.astype(np.int32), Cn)
+    # 8 B per entry word + 8 B per stored scalar (4 per O vector) + 8 B result per candidate;
+    # the query list is counted once per query per launch
+    q_ne, q_na = dev.sizes(q_lists)
+    alg_bytes = dev.append_algorithmic_bytes(parent_ids) + 8 * int(q_ne.sum() + q_na.sum())
+    cu = torch.device("cuda", local_rank)
+    t_parent = torch.from_numpy(parent_ids).to(cu)
+    t_child = torch.from_numpy(child_ids).to(cu)
+    t_tip = torch.ones(n_pairs, dtype=torch.uint8, device=cu)
+    t_blen = torch.full((n_pairs,), 1.0 / l_ref, dtype=torch.float64, device=cu)
+    t_out = torch.empty(n_pairs, dtype=torch.float64, device=cu)
+    t_cand_nodes = torch.from_numpy(cand_nodes.astype(np.int64)).to(cu)
+    stream = torch.cuda.current_stream().cuda_stream
+    setup_s = time.time() - t_setup
+
+    def step():
+        dev.append_batch_dev(n_pairs, t_parent.data_ptr(), t_child.data_ptr(), t_tip.data_ptr(), t_blen.data_ptr(),
+                             t_out.data_ptr(), stream)
+        best_score, best_idx = t_out.view(Q, Cn).max(dim=1)
+        rec = torch.stack([best_score, t_cand_nodes[best_idx].to(torch.float64)], dim=1)
+        if distd is not None:
+            gathered = [torch.empty_like(rec) for _ in range(world)]
+            distd.all_gather(gathered, rec)
+            rec = torch.cat(gathered, dim=0)
+        return rec
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distd is not None:
+        distd.barrier()
+    torch.cuda.synchronize()
+    dev.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = step()
+    torch.cuda.synchronize()
+    if distd is not None:
+        distd.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_launch, kernel_ms = dev.timing_read()
+    if distd is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=cu)
+        distd.all_reduce(te, op=distd.ReduceOp.MAX)
+        elapsed = float(te.item())
+        tp = torch.tensor([float(n_pairs)], dtype=torch.float64, device=cu)
+        distd.all_reduce(tp, op=distd.ReduceOp.SUM)
+        total_pairs = float(tp.item())
+    else:
+        total_pairs = float(n_pairs)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = total_pairs * args.steps / elapsed
+        k_ms = kernel_ms / max(1, n_launch)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "candidate SPR placements/sec", "value": value, "unit": "placements/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.samples} synthetic SARS-CoV-2 diff-lists (lRef 29903, ~30 diffs/sample), "
+                                   "UNREST, appendProbNode over queries x all candidate branches",
+                       "samples": args.samples, "queries_per_gpu": Q, "candidate_branches": int(Cn),
+                       "pairs_per_step_per_gpu": int(n_pairs), "tree_nodes": int(mirror.n_nodes),
+                       "parallelism": f"queries sharded round-robin over {world} GPU(s), tree mirror replicated",
+                       "setup_s": round(setup_s, 1)},
+            "roofline": {"bound": "hbm", "kernel": "k_append", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": k_ms, "launches_timed": n_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs,
+                                               args.cpu_seconds, t_out)
+        print(json.dumps(out), flush=True)
+    if distd is not None:
+        distd.destroy_process_group()
+    dev.close()
+
+
+def cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs, cpu_seconds, t_out):
+    """The C oracle (a port of the reference's appendProbNode) timed on ONE host core on a bounded
+    sample of the same (query, candidate) pairs; also cross-checks the GPU scores."""
+    from oracle.oracle_py import Oracle
+    orc = Oracle(ref_idx, root_freqs)
+    orc.set_model(UNREST_Q)
+    Cn = len(cand_lists)
+    lists = dev.download(np.concatenate([cand_lists, q_lists]))
+    packed = orc.pack_many(lists)
+    # calibrate on one query, then time as many queries as fit the budget
+    pl1 = np.arange(Cn, dtype=np.int32)
+    t0 = time.perf_counter()
+    orc.appendProbNode_batch(packed, pl1, np.full(Cn, Cn, dtype=np.int32), True, 1.0 / dev.lRef)
+    per_query = max(1e-6, time.perf_counter() - t0)
+    nq = int(max(1, min(len(q_lists), cpu_seconds / per_query)))
+    reps = int(max(1, round(cpu_seconds / (per_query * nq))))
+    pl = np.tile(pl1, nq)
+    cl = np.repeat(np.arange(Cn, Cn + nq, dtype=np.int32), Cn)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ref = orc.appendProbNode_batch(packed, pl, cl, True, 1.0 / dev.lRef)
+    dt = time.perf_counter() - t0
+    gpu = t_out[: nq * Cn].cpu().numpy()
+    both_inf = np.isinf(ref) & np.isinf(gpu)
+    err = np.abs(ref - gpu) / np.maximum(1.0, np.abs(ref))
+    err[both_inf] = 0.0
+    return {"value": reps * nq * Cn / dt, "unit": "placements/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} pass(es) over {nq} queries x {Cn} candidate branches = {reps * nq * Cn} pairs of the "
+                      f"same workload, C oracle (oracle/maple_oracle.c), {dt:.1f} s",
+            "max_rel_diff_vs_gpu": float(err.max())}
+
+
+if __name__ == "__main__":
+    main()

@@ -141,8 +141,10 @@ int maple_append_batch_dev(maple_ctx *ctx, int32_t n, const int32_t *parentList_
  * once per workgroup in LDS.  cand_dev holds n parent-side list ids. */
 int maple_append_query_dev(maple_ctx *ctx, int32_t n, int32_t childList, int isTipC, double bLen,
                            const int32_t *cand_dev, double *outLK_dev, void *stream);
-/* Time the most recent *_dev launch with HIP events on its own stream (milliseconds). */
-int maple_last_kernel_ms(maple_ctx *ctx, float *ms);
+/* Every *_dev launch is bracketed by a pair of HIP events recorded on the launch's own stream.
+ * maple_timing_read sums the elapsed time of all launches since the last maple_timing_reset. */
+int maple_timing_reset(maple_ctx *ctx);
+int maple_timing_read(maple_ctx *ctx, int32_t *n_launches, double *total_ms);
 /* algorithmic bytes (8*E + 8*B + 32*O + 8 per candidate, child list once per query) */
 int maple_append_algorithmic_bytes(maple_ctx *ctx, int32_t n, const int32_t *parentList, const int32_t *childList,
                                    int child_once, uint64_t *bytes);

@@ -49,8 +49,8 @@ template <class T> struct DevBuf {     // grow-only device scratch
 struct maple_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    std::vector<hipEvent_t> evs;       // pairs (start, stop) of timed *_dev launches since the last reset
+    size_t ev_used = 0;
     std::string err;
     maple_params params{};
     int32_t lRef = 0;
@@ -402,8 +402,6 @@ extern "C" int maple_create(maple_ctx **out, int device, int32_t lRef, const uin
     }
     if (hipSetDevice(device) != hipSuccess) { delete c; return MAPLE_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MAPLE_ERR_HIP; }
-    (void)hipEventCreate(&c->ev0);
-    (void)hipEventCreate(&c->ev1);
     c->lRef = lRef;
     c->refIdx.assign(refIdx, refIdx + lRef);
     c->params = *params;
@@ -453,8 +451,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     for (auto &b : c->s_u8) b.release();
     for (auto &b : c->s_i64) b.release();
     c->s_words.release(); c->s_aux.release(); c->s_ais.release();
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return MAPLE_OK;
@@ -976,6 +973,20 @@ extern "C" int maple_evaluate_placement_batch(maple_ctx *c, int32_t n, const int
 }
 
 // ---- device-resident forms ---------------------------------------------------------------------------
+static int ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b)
+{
+    if (c->ev_used + 2 > c->evs.size()) {
+        hipEvent_t e0, e1;
+        HIPCK(c, hipEventCreate(&e0));
+        HIPCK(c, hipEventCreate(&e1));
+        c->evs.push_back(e0);
+        c->evs.push_back(e1);
+    }
+    *a = c->evs[c->ev_used];
+    *b = c->evs[c->ev_used + 1];
+    c->ev_used += 2;
+    return MAPLE_OK;
+}
 extern "C" int maple_append_batch_dev(maple_ctx *c, int32_t n, const int32_t *pl, const int32_t *cl, const uint8_t *tip,
                                       const double *bl, double *out, void *stream)
 {
@@ -984,11 +995,12 @@ extern "C" int maple_append_batch_dev(maple_ctx *c, int32_t n, const int32_t *pl
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    HIPCK(c, hipEventRecord(c->ev0, s));
+    hipEvent_t e0, e1;
+    TRY(ev_pair(c, &e0, &e1));
+    HIPCK(c, hipEventRecord(e0, s));
     DISPATCH3(c, k_append, <<<grid_for(n), MAPLE_BLOCK, 0, s>>>(c->dm, view(c), n, pl, cl, tip, bl, out));
     HIPCK(c, hipGetLastError());
-    HIPCK(c, hipEventRecord(c->ev1, s));
-    c->timed = true;
+    HIPCK(c, hipEventRecord(e1, s));
     return MAPLE_OK;
 }
 
@@ -1001,20 +1013,34 @@ extern "C" int maple_append_query_dev(maple_ctx *c, int32_t n, int32_t childList
     TRY(need_model(c));
     TRY(check_ids(c, 1, &childList, false, "childList"));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    HIPCK(c, hipEventRecord(c->ev0, s));
+    hipEvent_t e0, e1;
+    TRY(ev_pair(c, &e0, &e1));
+    HIPCK(c, hipEventRecord(e0, s));
     DISPATCH3(c, k_append_query, <<<grid_for(n), MAPLE_BLOCK, 0, s>>>(c->dm, view(c), n, childList, isTipC, bLen, cand, out));
     HIPCK(c, hipGetLastError());
-    HIPCK(c, hipEventRecord(c->ev1, s));
-    c->timed = true;
+    HIPCK(c, hipEventRecord(e1, s));
     return MAPLE_OK;
 }
 
-extern "C" int maple_last_kernel_ms(maple_ctx *c, float *ms)
+extern "C" int maple_timing_reset(maple_ctx *c)
 {
-    if (!c || !ms) return MAPLE_ERR_ARG;
-    if (!c->timed) return fail(c, MAPLE_ERR_STATE, "no timed launch yet");
-    HIPCK(c, hipEventSynchronize(c->ev1));
-    HIPCK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    if (!c) return MAPLE_ERR_ARG;
+    c->ev_used = 0;
+    return MAPLE_OK;
+}
+
+extern "C" int maple_timing_read(maple_ctx *c, int32_t *n_launches, double *total_ms)
+{
+    if (!c || !n_launches || !total_ms) return MAPLE_ERR_ARG;
+    double tot = 0.0;
+    for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
+        float ms = 0.f;
+        HIPCK(c, hipEventSynchronize(c->evs[k + 1]));
+        HIPCK(c, hipEventElapsedTime(&ms, c->evs[k], c->evs[k + 1]));
+        tot += ms;
+    }
+    *n_launches = (int32_t)(c->ev_used / 2);
+    *total_ms = tot;
     return MAPLE_OK;
 }
 

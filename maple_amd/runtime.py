@@ -21,7 +21,7 @@ EXPORTS = [
     "maple_lists_upload", "maple_lists_sizes", "maple_lists_download", "maple_arena_mark", "maple_arena_release",
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
-    "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_query_dev", "maple_last_kernel_ms",
+    "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_query_dev", "maple_timing_reset", "maple_timing_read",
     "maple_append_algorithmic_bytes",
 ]
 
@@ -277,10 +277,14 @@ class Device:
         self._ck(self.lib.maple_append_query_dev(self.h, int(n), int(child_list), int(bool(isTipC)), C.c_double(bLen),
                                                  C.c_void_p(cand_ptr), C.c_void_p(out_ptr), C.c_void_p(stream)))
 
-    def last_kernel_ms(self):
-        ms = C.c_float()
-        self._ck(self.lib.maple_last_kernel_ms(self.h, C.byref(ms)))
-        return ms.value
+    def timing_reset(self):
+        self._ck(self.lib.maple_timing_reset(self.h))
+
+    def timing_read(self):
+        """(number of timed *_dev launches since the last reset, their summed HIP-event time in ms)."""
+        n, ms = C.c_int32(), C.c_double()
+        self._ck(self.lib.maple_timing_read(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
 
     def append_algorithmic_bytes(self, parent, child=None, child_once=False):
         parent = _i32(parent)

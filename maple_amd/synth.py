@@ -102,7 +102,7 @@ def make_dataset(
     for v in range(1, n_nodes):
         depth[v] = depth[parent[v]] + 1
     mean_depth = max(1.0, float(depth[is_tip].mean()))
-    per_branch = mean_diffs / mean_depth
+    per_branch = mean_diffs / mean_depth / max(1e-9, 1.0 - zero_branch_frac)
     site_rates = None
     if rate_variation:
         site_rates = np.clip(rng.gamma(0.5, 2.0, size=l_ref), 0.001, 0.005 * l_ref)

@@ -1,0 +1,105 @@
+"""Device mirror of a tree's genome lists, built level-synchronously on the GPU.
+
+Given a rooted binary topology with branch lengths and the tip genome lists, compute for every
+node the four lists MAPLE keeps (M:331-376): ``probVect`` (lower), ``probVectUpRight`` /
+``probVectUpLeft`` (upper, seen by child 0 / child 1) and ``probVectTotUp`` (mid-branch total) --
+the two passes of reCalculateAllGenomeLists (M:6013-6347) -- as batches of mergeVectors /
+rootVector / shorten launches, one batch per tree level.  No list ever leaves HBM.
+
+This mirror is for trees without MAT local references (``tree.mutations`` all empty, the
+reference's ``--noLocalRef`` layout); it is what ``bench.py`` scores candidates against.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .runtime import Device
+
+
+class TreeMirror:
+    def __init__(self, dev: Device, parent, blen, tip_lists):
+        """parent[n] (-1 root, parents precede children), blen[n], tip_lists: {node: tuple-form list}."""
+        self.dev = dev
+        self.parent = np.asarray(parent, dtype=np.int64)
+        self.dist = np.asarray(blen, dtype=np.float64)
+        n = len(self.parent)
+        self.n_nodes = n
+        self.children = -np.ones((n, 2), dtype=np.int64)
+        for v in range(n):
+            p = self.parent[v]
+            if p >= 0:
+                k = 0 if self.children[p, 0] < 0 else 1
+                self.children[p, k] = v
+        self.is_tip = self.children[:, 0] < 0
+        self.root = int(np.nonzero(self.parent < 0)[0][0])
+        depth = np.zeros(n, dtype=np.int64)
+        for v in range(n):
+            if self.parent[v] >= 0:
+                depth[v] = depth[self.parent[v]] + 1
+        self.depth = depth
+        self.lower = -np.ones(n, dtype=np.int32)
+        self.up_right = -np.ones(n, dtype=np.int32)
+        self.up_left = -np.ones(n, dtype=np.int32)
+        self.tot_up = -np.ones(n, dtype=np.int32)
+        tips = sorted(tip_lists)
+        ids = dev.upload([tip_lists[t] for t in tips])
+        self.lower[np.asarray(tips, dtype=np.int64)] = ids
+        self.launches = 0
+
+    def build(self):
+        dev, ch, dist = self.dev, self.children, self.dist
+        internal = np.nonzero(~self.is_tip)[0]
+        maxd = int(self.depth.max())
+        # pass 1 (M:6031-6200): lower lists, deepest level first
+        for d in range(maxd, -1, -1):
+            nodes = internal[self.depth[internal] == d]
+            if len(nodes) == 0:
+                continue
+            c0, c1 = ch[nodes, 0], ch[nodes, 1]
+            out = dev.merge_batch(self.lower[c0], dist[c0], self.is_tip[c0], self.lower[c1], dist[c1], self.is_tip[c1],
+                                  False)
+            if (out < 0).any():
+                raise RuntimeError("inconsistent zero-length branches while building lower lists")
+            self.lower[nodes] = dev.shorten_batch(out)
+            self.launches += 2
+        # pass 2 (M:6226-6345): upper lists from the root down
+        r = self.root
+        if not self.is_tip[r]:
+            c0, c1 = ch[r]
+            rv = dev.root_vector_batch([self.lower[c1], self.lower[c0]], [dist[c1], dist[c0]],
+                                       [self.is_tip[c1], self.is_tip[c0]], [[], []])
+            self.up_right[r], self.up_left[r] = rv[0], rv[1]
+            self.launches += 1
+        for d in range(1, maxd + 1):
+            nodes = np.nonzero(self.depth == d)[0]
+            if len(nodes) == 0:
+                continue
+            p = self.parent[nodes]
+            first = ch[p, 0] == nodes
+            vect_up = np.where(first, self.up_right[p], self.up_left[p]).astype(np.int32)
+            nz = dist[nodes] != 0.0
+            if nz.any():
+                nn = nodes[nz]
+                tu = dev.merge_batch(vect_up[nz], dist[nn] / 2, False, self.lower[nn], dist[nn] / 2, self.is_tip[nn], True)
+                ok = tu >= 0
+                sh = dev.shorten_batch(tu[ok])
+                self.tot_up[nn[ok]] = sh
+                self.launches += 2
+            inner = ~self.is_tip[nodes]
+            if inner.any():
+                nn = nodes[inner]
+                vu = vect_up[inner]
+                c0, c1 = ch[nn, 0], ch[nn, 1]
+                ur = dev.merge_batch(vu, dist[nn], False, self.lower[c1], dist[c1], self.is_tip[c1], True)
+                ul = dev.merge_batch(vu, dist[nn], False, self.lower[c0], dist[c0], self.is_tip[c0], True)
+                if (ur < 0).any() or (ul < 0).any():
+                    raise RuntimeError("inconsistent zero-length branches while building upper lists")
+                self.up_right[nn] = dev.shorten_batch(ur)
+                self.up_left[nn] = dev.shorten_batch(ul)
+                self.launches += 4
+        return self
+
+    def candidate_nodes(self, min_blen):
+        """Nodes whose mid-branch total list is a placement candidate (dist > effectivelyNon0BLen, M:8012)."""
+        ok = (self.tot_up >= 0) & (self.dist > min_blen) & (self.parent >= 0)
+        return np.nonzero(ok)[0]

@@ -1043,3 +1043,15 @@ int omo_evaluatePlacement(const OModel *m, const OEntry *midTot, int nMid, const
     out4[0] = cost; out4[1] = bestBottom; out4[2] = bestTop; out4[3] = bestApp;
     return 0;
 }
+
+/* ---- batch driver for timing the CPU baseline (bench.py cpu_baseline leg only) --------------------- */
+int omo_appendProbNode_batch(const OModel *m, const OEntry *all, const long long *off, int n, const int *pl,
+                             const int *cl, const unsigned char *tip, const double *bl, double *out)
+{
+    for (int i = 0; i < n; i++) {
+        const OEntry *P = all + off[pl[i]], *C = all + off[cl[i]];
+        omo_appendProbNode(m, P, (int)(off[pl[i] + 1] - off[pl[i]]), C, (int)(off[cl[i] + 1] - off[cl[i]]), tip[i],
+                           bl[i], &out[i]);
+    }
+    return 0;
+}

@@ -90,6 +90,10 @@ int   omo_evaluatePlacement(const OModel *m, const OEntry *midTot, int nMid, con
                             int isRemovedTip, int fromTip1, double defaultBLen, double *out4,
                             OEntry *tmp /* 3*cap */, int cap, double *scratch);
 
+/* batch driver (lists concatenated, off[] = CSR offsets by list index) used to time the CPU baseline */
+int   omo_appendProbNode_batch(const OModel *m, const OEntry *all, const long long *off, int n, const int *pl,
+                               const int *cl, const unsigned char *tip, const double *bl, double *out);
+
 #ifdef __cplusplus
 }
 #endif

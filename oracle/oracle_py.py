@@ -291,3 +291,21 @@ class Oracle:
         self.lib.omo_findProbRoot(C.byref(self.m), _p(a), len(a), _p(mut), _p(off), len(off) - 1, _p(self._cb), _p(rl),
                                   _p(t1), _p(t2), cap, C.byref(out))
         return out.value
+
+    # ---- batch driver for bench.py's cpu_baseline leg -------------------------------------------
+    def pack_many(self, lists):
+        arrs = [to_entries(gl, self.u) for gl in lists]
+        off = np.zeros(len(arrs) + 1, dtype=np.int64)
+        np.cumsum([len(a) for a in arrs], out=off[1:])
+        return np.concatenate(arrs), off
+
+    def appendProbNode_batch(self, packed, parent_idx, child_idx, isTipC, bLen):
+        allent, off = packed
+        pl = np.ascontiguousarray(parent_idx, dtype=np.int32)
+        cl = np.ascontiguousarray(child_idx, dtype=np.int32)
+        n = len(pl)
+        tip = np.ascontiguousarray(np.broadcast_to(isTipC, n), dtype=np.uint8)
+        bl = np.ascontiguousarray(np.broadcast_to(bLen, n), dtype=np.float64)
+        out = np.zeros(n)
+        self.lib.omo_appendProbNode_batch(C.byref(self.m), _p(allent), _p(off), n, _p(pl), _p(cl), _p(tip), _p(bl), _p(out))
+        return out
