@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Golden vectors for the SEARCH rows of SURVEY.md section 8a (a11-a13) -- BUILD CONTAINER ONLY.
+
+Runs the unmodified reference to completion on tests/golden/synth_small.maple.txt, then -- on the
+frozen final tree, with the model the run ended with -- calls the reference's own
+``startTopologyUpdatesParallel`` (M:9580-9716; it calls ``findBestParentTopology`` M:6817 for every
+node) and ``findBestParentForNewSample`` (M:7912) and records inputs and outputs, plus ONE snapshot
+of the tree (topology, branch lengths, MAT mutations and the four genome lists of every node).
+
+Data only is written: tests/golden/search_<name>.json.gz.
+"""
+import contextlib
+import copy
+import gzip
+import io
+import json
+import os
+import random
+import runpy
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+from make_golden import REF, ser_list  # noqa: E402
+
+RUNS = {
+    "synth_unrest": ["--model", "UNREST", "--maxNumDescendantsForMATClade", "12"],
+    "synth_siteerr": ["--model", "UNREST", "--rateVariation", "--estimateSiteSpecificErrorRate",
+                      "--maxNumDescendantsForMATClade", "12"],
+}
+
+
+def snapshot_tree(tree, root):
+    n = len(tree.up)
+    return dict(
+        root=root, up=list(tree.up), children=[list(c) for c in tree.children], dist=list(tree.dist),
+        mutations=[[list(m) for m in ml] for ml in tree.mutations],
+        nMinor=[len(m) for m in tree.minorSequences],
+        probVect=[ser_list(x) for x in tree.probVect],
+        probVectUpRight=[ser_list(x) for x in tree.probVectUpRight],
+        probVectUpLeft=[ser_list(x) for x in tree.probVectUpLeft],
+        probVectTotUp=[ser_list(x) for x in tree.probVectTotUp],
+        n=n)
+
+
+def perturb(diffs, ref, rng):
+    """A new sample close to an existing one: drop / add a substitution, maybe an N run."""
+    out = [tuple(e) for e in diffs]
+    if out and rng.random() < 0.5:
+        out.pop(rng.randrange(len(out)))
+    for _ in range(rng.randrange(0, 3)):
+        p = rng.randrange(1, len(ref) + 1)
+        if any((e[1] <= p <= e[1] + (e[2] - 1 if len(e) > 2 else 0)) for e in out):
+            continue
+        ch = rng.choice([c for c in "acgt" if c != ref[p - 1]])
+        out.append((ch, p))
+    if rng.random() < 0.3:
+        p = rng.randrange(1, len(ref) - 40)
+        ln = rng.randrange(3, 30)
+        out = [e for e in out if not (p <= e[1] < p + ln) and not (len(e) > 2 and e[1] <= p + ln and p <= e[1] + e[2] - 1)]
+        out.append(("n", p, ln))
+    out.sort(key=lambda e: e[1])
+    return out
+
+
+def run(name, flags):
+    inp = os.path.join(HERE, "synth_small.maple.txt")
+    out_dir = tempfile.mkdtemp(prefix="maple_golden_search_")
+    argv = ["MAPLE", "--input", inp, "--output", os.path.join(out_dir, "out"), "--overwrite"] + flags
+    holder = {}
+
+    def grab(frame, event, arg):
+        if "g" not in holder and frame.f_code.co_filename.endswith("MAPLEv0.7.5.4.py"):
+            holder["g"] = frame.f_globals
+        return None
+
+    old = sys.argv
+    sys.argv = argv
+    log = io.StringIO()
+    sys.setprofile(grab)
+    try:
+        with contextlib.redirect_stdout(log):
+            runpy.run_path(REF, run_name="__main__")
+    except SystemExit:
+        pass
+    finally:
+        sys.setprofile(None)
+        sys.argv = old
+    g = holder["g"]
+    tree, t1 = g["tree"], g["t1"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        g["setAllDirty"](tree, t1)
+        g["reCalculateAllGenomeLists"](tree, t1)
+        g["assignCoreNumbers"](tree, t1, 1)
+    for i in range(len(tree.replacements)):
+        tree.replacements[i] = 0
+    snap = snapshot_tree(tree, t1)
+    lRef = g["lRef"]
+    model = dict(useRateVariation=bool(g["useRateVariation"]), usingErrorRate=bool(g["usingErrorRate"]),
+                 errorRateSiteSpecific=bool(g["errorRateSiteSpecific"]), Q=[list(r) for r in g["mutMatrixGlobal"]],
+                 siteRates=list(g["siteRates"]) if g["useRateVariation"] else None,
+                 errorRateGlobal=g["errorRateGlobal"], totError=g["totError"],
+                 errorRates=list(g["errorRates"]) if (g["usingErrorRate"] and g["errorRateSiteSpecific"]) else None)
+    keys = ["lRef", "thresholdProb", "minBLenSensitivity", "thresholdDiffForUpdate", "thresholdFoldChangeUpdate",
+            "oneMutBLen", "effectivelyNon0BLen", "thresholdLogLK", "thresholdLogLKoptimization",
+            "thresholdLogLKoptimizationTopology", "thresholdLogLKtopology", "thresholdLogLKconsecutivePlacement",
+            "allowedFails", "allowedFailsTopology", "defaultBLen", "maxReplacements", "strictStopRules",
+            "thresholdTopologyPlacement", "thresholdLogLKtopologyInitial", "allowedFailsTopologyInitial"]
+    ctx = {k: g[k] for k in keys}
+    ctx["rootFreqs"] = list(g["rootFreqs"])
+    ctx["ref"] = g["ref"]
+
+    # ---- a11 / a13: SPR searches on the frozen tree, two parameter sets (fast initial round, deep round) ----
+    param_sets = [
+        dict(strict=True, fails=g["allowedFailsTopologyInitial"], thr=g["thresholdLogLKtopologyInitial"], place=-0.1),
+        dict(strict=bool(g["strictTopologyStopRules"]), fails=g["allowedFailsTopology"], thr=g["thresholdLogLKtopology"],
+             place=g["thresholdTopologyPlacement"]),
+    ]
+    spr = []
+    for ps in param_sets:
+        tcopy = copy.deepcopy(tree)
+        calls = []
+        state = {"cur": None, "n_append": 0}
+
+        def prof(frame, event, arg):
+            co = frame.f_code
+            if not co.co_filename.endswith("MAPLEv0.7.5.4.py"):
+                return
+            if co.co_name == "findBestParentTopology":
+                if event == "call":
+                    L = frame.f_locals
+                    state["cur"] = dict(node=L["node"], child=L["child"], bestLKdiff=L["bestLKdiff"],
+                                        removedBLen=L["removedBLen"])
+                    state["n_append"] = 0
+                elif event == "return" and state["cur"] is not None:
+                    r = state["cur"]
+                    if arg is not None:
+                        r["ret"] = dict(bestNode=arg[0], bestScore=arg[1], bestBranchLengths=list(arg[2]),
+                                        bestRemovedPartials=ser_list(arg[5]))
+                    else:
+                        r["ret"] = None
+                    r["n_append"] = state["n_append"]
+                    calls.append(r)
+                    state["cur"] = None
+            elif co.co_name == "appendProbNode" and event == "call" and state["cur"] is not None:
+                state["n_append"] += 1
+
+        tup = (tcopy, t1, 0, ps["strict"], ps["fails"], ps["thr"], ps["place"], None, g["errorRateGlobal"],
+               g["mutMatrixGlobal"], g["errorRates"], g["mutMatrices"], g["cumulativeRate"], g["cumulativeErrorRate"])
+        sys.setprofile(prof)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                moves = g["startTopologyUpdatesParallel"](tup)
+        finally:
+            sys.setprofile(None)
+        spr.append(dict(params=ps, calls=calls, proposedMoves=[list(m) for m in moves]))
+        print(f"[{name}] SPR params {ps}: {len(calls)} searches, {len(moves)} proposed moves, "
+              f"{sum(c['n_append'] for c in calls)} appendProbNode calls", flush=True)
+
+    # ---- a12: placement searches for new samples on the frozen tree ----
+    rng = random.Random(123)
+    data = g["data"] if "data" in g else None
+    if data is None:
+        data = g["readConciseAlignment"](inp, extractReference=False, ref=g["ref"])
+    names = sorted(data)
+    placements = []
+    for k in range(60):
+        base = data[names[rng.randrange(len(names))]]
+        diffs = perturb(base, g["ref"], rng)
+        tcopy = copy.deepcopy(tree)
+        state = {"n_append": 0}
+
+        def prof2(frame, event, arg):
+            if event == "call" and frame.f_code.co_name == "appendProbNode":
+                state["n_append"] += 1
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            q = g["probVectTerminalNode"](diffs, None, None)
+            q_ser = ser_list(q)
+            sys.setprofile(prof2)
+            try:
+                ret = g["findBestParentForNewSample"](tcopy, t1, q, f"new{k}", False)
+            finally:
+                sys.setprofile(None)
+        placements.append(dict(diffs=[list(e) for e in diffs], query=q_ser, n_append=state["n_append"],
+                               ret=dict(bestNode=ret[0], bestScore=ret[1],
+                                        bestBranchLengths=None if ret[2] is None else list(ret[2]),
+                                        bestDiffs=ser_list(ret[3]))))
+    print(f"[{name}] {len(placements)} placement searches, "
+          f"{sum(p['n_append'] for p in placements)} appendProbNode calls", flush=True)
+
+    fixture = dict(name=name, flags=flags, context=ctx, model=model, tree=snap, spr=spr, placements=placements)
+    path = os.path.join(HERE, f"search_{name}.json.gz")
+    with gzip.open(path, "wt") as fh:
+        json.dump(fixture, fh)
+    print(f"[{name}] -> {path} {os.path.getsize(path)/1e6:.2f} MB", flush=True)
+
+
+if __name__ == "__main__":
+    for nm in (sys.argv[1:] or list(RUNS)):
+        run(nm, RUNS[nm])
