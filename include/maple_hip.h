@@ -118,6 +118,9 @@ int maple_blen_batch(maple_ctx *ctx, int32_t n, const int32_t *parentList, const
                      const uint8_t *fromTipC, double *t, uint8_t *isFalse);
 /* areVectorsDifferent(pv1, pv2), M:5419-5472; list2 == -1 means None -> different */
 int maple_differ_batch(maple_ctx *ctx, int32_t n, const int32_t *list1, const int32_t *list2, uint8_t *out);
+/* isMinorSequence(probVect1, probVect2, onlyFindIdentical), M:5919-6004 -> 0 / 1 / 2 */
+int maple_minor_batch(maple_ctx *ctx, int32_t n, const int32_t *list1, const int32_t *list2, int onlyFindIdentical,
+                      uint8_t *out);
 /* passGenomeListThroughBranch(probVect, mutations, dirIsUp), M:3749-3877 */
 int maple_pass_branch_batch(maple_ctx *ctx, int32_t n, const int32_t *list, const int32_t *mutList,
                             const uint8_t *dirIsUp, int32_t *outList);
@@ -133,6 +136,39 @@ int maple_root_vector_batch(maple_ctx *ctx, int32_t n, const int32_t *list, cons
 int maple_evaluate_placement_batch(maple_ctx *ctx, int32_t n, const int32_t *midTot, const int32_t *downVect,
                                    const int32_t *upVect, const double *distance, const int32_t *removedPartials,
                                    const uint8_t *isRemovedTip, const uint8_t *fromTip1, double *out4);
+
+/* ---- tree mirror and the device-resident SPR search ------------------------------- */
+/* Topology of the tree whose genome lists are in the arena (struct-of-arrays Tree, M:331-376):
+ * up / child0 / child1 use -1 for None; isTip[n] = leaf with no minor sequences (the `isTip` tests of
+ * M:6986, 7129, 9645); lower/upRight/upLeft/totUp are list ids (probVect, probVectUpRight,
+ * probVectUpLeft, probVectTotUp; -1 = None); mutList[n] = mutation-list id of tree.mutations[n], -1 if empty. */
+int maple_tree_upload(maple_ctx *ctx, int32_t n, int32_t root, const int32_t *up, const int32_t *child0,
+                      const int32_t *child1, const double *dist, const uint8_t *isTip, const int32_t *lower,
+                      const int32_t *upRight, const int32_t *upLeft, const int32_t *totUp, const int32_t *mutList);
+
+typedef struct {
+    int32_t strictTopologyStopRules;            /* M:57  */
+    int32_t allowedFailsTopology;               /* M:54  */
+    double thresholdLogLKtopology;              /* M:53, already multiplied by log(lRef) (M:3612) */
+    double thresholdTopologyPlacement;          /* M:56  */
+    double thresholdLogLKoptimizationTopology;  /* M:66, x log(lRef) (M:3609), data-adaptive M:11770 */
+    double thresholdLogLKconsecutivePlacement;  /* M:63  */
+    double effectivelyNon0BLen;                 /* M:3614 */
+} maple_search_params;
+
+/* The worker body of startTopologyUpdatesParallel (M:9615-9711) for n pruned nodes, each running
+ * findBestParentTopology (M:6817-7724) entirely on the GPU (one lane per query).  Per query:
+ *   bestNode/bestScore/blen3 = findBestParentTopology's (bestNode, bestScore, bestBranchLengths);
+ *   placement (-1 = None) / improvement = the proposed move after the accept rule and vetoes (M:9681-9700);
+ *   currentLK = bestCurrentLK (M:9646); nAppend = appendProbNode evaluations issued by the search
+ *   (the "candidate placements" of the metric); status: 0 searched, 1 root, 2 not searched (M:9674),
+ *   -1 the reference would have raised inside the search (its worker swallows it, M:9703),
+ *   -3 per-lane workspace exhausted (retry with a larger ws_entries_per_lane).
+ * outRprList (may be NULL): new list ids of bestRemovedPartials.  ws_entries_per_lane: 0 = default. */
+int maple_spr_search_batch(maple_ctx *ctx, int32_t n, const int32_t *nodes, const maple_search_params *params,
+                           int32_t ws_entries_per_lane, int32_t *bestNode, double *bestScore, double *blen3,
+                           int32_t *placement, double *improvement, double *currentLK, int32_t *nAppend,
+                           int32_t *status, int32_t *outRprList);
 
 /* ---- device-resident forms (inputs already in HBM; asynchronous on `stream`) --- */
 int maple_append_batch_dev(maple_ctx *ctx, int32_t n, const int32_t *parentList_dev, const int32_t *childList_dev,

@@ -648,6 +648,45 @@ template <class C> __device__ bool differ_walk(const C &c, ListRef L1, ListRef L
     return false;
 }
 
+// ---- isMinorSequence (M:5919-6004): 1 = list2 is at most as informative as list1, 2 = the opposite, 0 = neither ----
+__device__ inline int minor_walk(int lRef, ListRef L1, ListRef L2, bool onlyFindIdentical)
+{
+    Cursor a, b;
+    a.init(L1); b.init(L2);
+    int pos = 0;
+    bool big1 = false, big2 = false;
+    for (;;) {
+        const Ent &e1 = a.e, &e2 = b.e;
+        if (e1.type != e2.type) {
+            if (onlyFindIdentical) return 0;
+            if (e1.type == 5) { pos = (e2.type == 4) ? min(e1.pos, e2.pos) : pos + 1; big2 = true; }
+            else if (e2.type == 5) { pos = (e1.type == 4) ? min(e1.pos, e2.pos) : pos + 1; big1 = true; }
+            else if (e1.type == 6) {
+                int i2 = (e2.type == 4) ? e1.ref : e2.type;
+                if (e1.vec[i2] > 0.1) big2 = true; else return 0;
+                pos += 1;
+            } else if (e2.type == 6) {
+                int i1 = (e1.type == 4) ? e2.ref : e1.type;
+                if (e2.vec[i1] > 0.1) big1 = true; else return 0;
+                pos += 1;
+            } else return 0;
+        } else if (e1.type == 6) {
+            for (int j = 0; j < 4; j++) {
+                if (onlyFindIdentical) { if (e2.vec[j] != e1.vec[j]) return 0; }
+                else if (e2.vec[j] > 0.1 && e1.vec[j] < 0.1) big1 = true;
+                else if (e1.vec[j] > 0.1 && e2.vec[j] < 0.1) big2 = true;
+            }
+            pos += 1;
+        } else pos = (e1.type < 4) ? pos + 1 : min(e1.pos, e2.pos);
+        if (big1 && big2) return 0;
+        if (pos == lRef) break;
+        a.step(pos);
+        b.step(pos);
+    }
+    if (big1) return 1;
+    return big2 ? 2 : 1;
+}
+
 // ---- passGenomeListThroughBranch (M:3749-3877) -----------------------------------------------
 // mutations: int32 triples (pos, from, to) sorted by pos
 __device__ inline int pass_walk(int lRef, ListRef L, const int32_t *mut, int nMut, bool dirIsUp, Writer &o)

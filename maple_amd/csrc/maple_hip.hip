@@ -2,6 +2,7 @@
 // gfx950 only.  One lane walks one (parent list, child list) pair; see genome_dev.h.
 #include "../../include/maple_hip.h"
 #include "genome_dev.h"
+#include "search_dev.h"
 
 #include <cfloat>
 #include <cmath>
@@ -16,19 +17,8 @@ using namespace maple;
 // =================================================================================================
 // context
 // =================================================================================================
-struct ArenaView {
-    const uint2 *words;
-    const double *aux;
-    const int64_t *ent_off;            // per list
-    const int64_t *aux_off;            // per list
-    const int32_t *n_ent;              // per list
-};
-
-struct MutView {
-    const int32_t *mut3;
-    const int64_t *off;                // per mutation list (n+1 style: off[id], cnt[id])
-    const int32_t *cnt;
-};
+typedef maple::ArenaViewS ArenaView;   // {words, aux, ent_off[], aux_off[], n_ent[], n_aux[]} per list
+typedef maple::MutViewS MutView;       // {mut3, off[], cnt[]} per mutation list
 
 template <class T> struct DevBuf {     // grow-only device scratch
     T *p = nullptr;
@@ -65,7 +55,7 @@ struct maple_ctx {
     int64_t cap_ent = 0, cap_aux = 0, cap_lists = 0;
     int64_t used_ent = 0, used_aux = 0;
     int64_t *d_ent_off = nullptr, *d_aux_off = nullptr;
-    int32_t *d_n_ent = nullptr;
+    int32_t *d_n_ent = nullptr, *d_n_aux = nullptr;
     std::vector<int64_t> h_ent_off, h_aux_off;
     std::vector<int32_t> h_n_ent, h_n_aux;
     // mutation lists
@@ -83,6 +73,17 @@ struct maple_ctx {
     DevBuf<uint2> s_words;
     DevBuf<double> s_aux;
     DevBuf<double> s_ais;
+    // tree mirror (topology + list ids), maple_tree_upload
+    DevTree dtree{};
+    bool tree_set = false;
+    DevBuf<int32_t> t_i32[9];
+    DevBuf<double> t_dist;
+    DevBuf<uint8_t> t_tip;
+    std::vector<int32_t> h_tree_up, h_tree_lower;
+    // SPR search workspace
+    DevBuf<uint8_t> s_search_ws;
+    DevBuf<uint8_t> s_search_out;
+    DevBuf<int32_t> s_counter;
 };
 
 static int fail(maple_ctx *c, int code, const char *fmt, ...)
@@ -102,7 +103,7 @@ static int fail(maple_ctx *c, int code, const char *fmt, ...)
             return fail((c), MAPLE_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
     } while (0)
 
-static ArenaView view(const maple_ctx *c) { return ArenaView{c->d_words, c->d_aux, c->d_ent_off, c->d_aux_off, c->d_n_ent}; }
+static ArenaView view(const maple_ctx *c) { return ArenaView{c->d_words, c->d_aux, c->d_ent_off, c->d_aux_off, c->d_n_ent, c->d_n_aux}; }
 static MutView mview(const maple_ctx *c) { return MutView{c->d_mut3, c->d_mut_off, c->d_mut_cnt}; }
 
 __device__ inline ListRef list_ref(const ArenaView &a, int id)
@@ -214,6 +215,13 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_differ(DevModel m, ArenaView av
     Ctx<RV, U, SS> c(m, lds);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         out[i] = (l2[i] < 0) ? 1 : (differ_walk(c, list_ref(av, l1[i]), list_ref(av, l2[i])) ? 1 : 0);
+}
+
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_minor(int lRef, ArenaView av, int n, const int32_t *l1, const int32_t *l2,
+                                                       int onlyIdentical, uint8_t *out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = (uint8_t)minor_walk(lRef, list_ref(av, l1[i]), list_ref(av, l2[i]), onlyIdentical != 0);
 }
 
 __global__ __launch_bounds__(MAPLE_BLOCK) void k_pass(int lRef, ArenaView av, MutView mv, int n, const int32_t *l,
@@ -341,6 +349,116 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_evalplace(DevModel m, ArenaView
     }
 }
 
+
+// SPR regraft search: one lane = one query (state machine in search_dev.h) ---------------------------
+struct LaneBytes { size_t w, aux, h, st, best, ais, total; };
+static LaneBytes lane_bytes(const WsLayout &L)
+{
+    auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    LaneBytes b;
+    b.w = al((size_t)L.capW * sizeof(uint2));
+    b.aux = al((size_t)L.capA * sizeof(double));
+    b.h = al((size_t)L.capH * sizeof(TList));
+    b.st = al((size_t)L.capS * sizeof(StackItem));
+    b.best = al((size_t)L.capB * sizeof(BestRec));
+    b.ais = al((size_t)L.capAis * sizeof(double));
+    b.total = b.w + b.aux + b.h + b.st + b.best + b.ais;
+    return b;
+}
+
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(64) void k_spr_search(DevModel m, ArenaView av, MutView mv, DevTree T, SearchParams P, int n,
+                                                   const int32_t *nodes, WsLayout L, LaneBytes LB, uint8_t *wsBase,
+                                                   int32_t *counter, SearchOut *out, uint2 *poolW, double *poolA,
+                                                   unsigned long long *poolUsed, long long poolCapW, long long poolCapA)
+{
+    __shared__ Lds lds;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint8_t *base = wsBase + lane * LB.total;
+    LaneWs ws;
+    ws.w = (uint2 *)base;
+    ws.aux = (double *)(base + LB.w);
+    ws.h = (TList *)(base + LB.w + LB.aux);
+    ws.st = (StackItem *)(base + LB.w + LB.aux + LB.h);
+    ws.best = (BestRec *)(base + LB.w + LB.aux + LB.h + LB.st);
+    ws.ais = (double *)(base + LB.w + LB.aux + LB.h + LB.st + LB.best);
+    ws.L = L;
+    Search<RV, U, SS> S(c, av, mv, T, P, ws);
+    bool active = false;
+    int q = -1, node = -1;
+    double curLK = 0.0;
+    for (;;) {
+        if (!active) {
+            q = atomicAdd(counter, 1);
+            if (q >= n) break;
+            node = nodes[q];
+            ws.usedW = ws.usedA = ws.nH = ws.sp = ws.nB = 0;
+            ws.overflow = false;
+            S.nAppend = 0;
+            SearchOut &o = out[q];
+            o.bestNode = -1; o.placement = -1; o.status = 0; o.nAppend = 0;
+            o.bestScore = 0.0; o.improvement = 0.0; o.currentLK = 0.0;
+            o.blen[0] = o.blen[1] = o.blen[2] = 0.0;
+            o.rprWoff = o.rprAoff = -1; o.rprN = o.rprNA = 0;
+            const int parent = T.up[node];
+            if (parent < 0) { o.status = 1; continue; }               // the root cannot be re-placed (M:9626)
+            // current placement cost, M:9629-9646
+            const int childIdx = (T.c0[parent] == node) ? 0 : 1;
+            int vectUp = S.opPass(S.treeList(childIdx == 0 ? T.upRight[parent] : T.upLeft[parent]), T.mutId[node], false);
+            if (!S.valid(vectUp)) { o.status = ws.overflow ? -3 : -1; continue; }
+            curLK = append_walk(c, S.ref(vectUp), S.ref(S.treeList(T.lower[node])), T.isTip[node] != 0, T.dist[node]);
+            o.currentLK = curLK;
+            if (!(curLK < P.thrPlacement || T.dist[node] != 0.0)) { o.status = 2; continue; }   // M:9674
+            ws.usedW = ws.usedA = ws.nH = 0;
+            S.begin(parent, childIdx, curLK, T.dist[node]);
+            active = true;
+        } else if (ws.overflow) {
+            out[q].status = -3;                                       // workspace exhausted: the host retries with more
+            active = false;
+        } else if (ws.sp > 0) {
+            S.step();
+        } else if (S.refineIdx < ws.nB) {
+            int r = S.refine(ws.best[S.refineIdx++]);
+            if (r < 0 && !ws.overflow) {                              // the reference raises here; its worker swallows it (M:9703)
+                SearchOut &o = out[q];
+                o.status = -1; o.nAppend = S.nAppend;
+                active = false;
+            }
+        } else {
+            SearchOut &o = out[q];
+            o.bestNode = S.bestNode; o.bestScore = S.bestScore;
+            o.blen[0] = S.bl0; o.blen[1] = S.bl1; o.blen[2] = S.bl2;
+            o.nAppend = S.nAppend;
+            if (poolW) {                                             // hand bestRemovedPartials out through the pool
+                TList rp = S.L(S.hBestRpr);
+                long long ow = (long long)atomicAdd(&poolUsed[0], (unsigned long long)rp.n);
+                long long oa = (long long)atomicAdd(&poolUsed[1], (unsigned long long)rp.na);
+                if (ow + rp.n <= poolCapW && oa + rp.na <= poolCapA) {
+                    for (int k = 0; k < rp.n; k++) poolW[ow + k] = rp.w[k];
+                    for (int k = 0; k < rp.na; k++) poolA[oa + k] = rp.aux[k];
+                    o.rprWoff = ow; o.rprAoff = oa; o.rprN = rp.n; o.rprNA = rp.na;
+                } else o.status = -4;
+            }
+            // accept rule and the four "same place" vetoes, M:9681-9700
+            if (S.bestScore + P.thrPlacement > curLK) {
+                bool updated = true;
+                int topNode = T.up[node];
+                if (S.bestNode == topNode) updated = false;
+                while (T.dist[topNode] == 0.0 && T.up[topNode] >= 0) topNode = T.up[topNode];
+                if (S.bestNode == topNode && S.bl1 == 0.0) updated = false;
+                const int par = T.up[node];
+                const int sib = (T.c0[par] == node) ? T.c1[par] : T.c0[par];
+                if (S.bestNode == sib) updated = false;
+                if (T.up[S.bestNode] == sib && S.bl0 == 0.0) updated = false;
+                if (updated) { o.improvement = S.bestScore - curLK; o.placement = S.bestNode; }
+            }
+            active = false;
+        }
+    }
+}
+
 // compaction of scratch lists into the arena: one wavefront per list, coalesced copies
 __global__ __launch_bounds__(MAPLE_BLOCK) void k_commit(int n, const uint2 *sw, const double *sa, const int64_t *swoff,
                                                         const int64_t *saoff, const int32_t *n_ent, const int32_t *n_aux,
@@ -429,6 +547,7 @@ extern "C" int maple_create(maple_ctx **out, int device, int32_t lRef, const uin
               && hipMalloc((void **)&c->d_ent_off, c->cap_lists * sizeof(int64_t)) == hipSuccess
               && hipMalloc((void **)&c->d_aux_off, c->cap_lists * sizeof(int64_t)) == hipSuccess
               && hipMalloc((void **)&c->d_n_ent, c->cap_lists * sizeof(int32_t)) == hipSuccess
+              && hipMalloc((void **)&c->d_n_aux, c->cap_lists * sizeof(int32_t)) == hipSuccess
               && hipMalloc((void **)&c->d_mut3, c->cap_mut * 3 * sizeof(int32_t)) == hipSuccess
               && hipMalloc((void **)&c->d_mut_off, c->cap_mut_lists * sizeof(int64_t)) == hipSuccess
               && hipMalloc((void **)&c->d_mut_cnt, c->cap_mut_lists * sizeof(int32_t)) == hipSuccess
@@ -443,7 +562,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     if (!c) return MAPLE_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_words, c->d_aux, c->d_ent_off, c->d_aux_off, c->d_n_ent, c->d_mut3, c->d_mut_off,
+    void *ptrs[] = {c->d_words, c->d_aux, c->d_ent_off, c->d_aux_off, c->d_n_ent, c->d_n_aux, c->d_mut3, c->d_mut_off,
                     c->d_mut_cnt, c->d_cumRate, c->d_cumErr, c->d_siteRates, c->d_errorRates};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &b : c->s_i32) b.release();
@@ -451,6 +570,9 @@ extern "C" int maple_destroy(maple_ctx *c)
     for (auto &b : c->s_u8) b.release();
     for (auto &b : c->s_i64) b.release();
     c->s_words.release(); c->s_aux.release(); c->s_ais.release();
+    for (auto &b : c->t_i32) b.release();
+    c->t_dist.release(); c->t_tip.release();
+    c->s_search_ws.release(); c->s_search_out.release(); c->s_counter.release();
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -529,6 +651,7 @@ static int push_list_rows(maple_ctx *c, int32_t n, const int64_t *ent_off_abs, c
     HIPCK(c, hipMemcpyAsync(c->d_ent_off + first, ent_off_abs, n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(c->d_aux_off + first, aux_off_abs, n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(c->d_n_ent + first, n_ent, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->d_n_aux + first, n_aux, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));   // source vectors are caller temporaries
     return MAPLE_OK;
 }
@@ -822,6 +945,25 @@ extern "C" int maple_differ_batch(maple_ctx *c, int32_t n, const int32_t *l1, co
     return MAPLE_OK;
 }
 
+extern "C" int maple_minor_batch(maple_ctx *c, int32_t n, const int32_t *l1, const int32_t *l2, int onlyFindIdentical,
+                                 uint8_t *out)
+{
+    if (!c || n < 0 || !l1 || !l2 || !out) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(check_ids(c, n, l1, false, "list1"));
+    TRY(check_ids(c, n, l2, false, "list2"));
+    TRY(h2d(c, c->s_i32[0], l1, (size_t)n));
+    TRY(h2d(c, c->s_i32[1], l2, (size_t)n));
+    HIPCK(c, c->s_u8[0].reserve(n));
+    hipLaunchKernelGGL(k_minor, dim3(grid_for(n)), dim3(MAPLE_BLOCK), 0, c->stream, c->lRef, view(c), n, c->s_i32[0].p,
+                       c->s_i32[1].p, onlyFindIdentical, c->s_u8[0].p);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(out, c->s_u8[0].p, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MAPLE_OK;
+}
+
 extern "C" int maple_pass_branch_batch(maple_ctx *c, int32_t n, const int32_t *l, const int32_t *ml, const uint8_t *up,
                                        int32_t *outList)
 {
@@ -1019,6 +1161,137 @@ extern "C" int maple_append_query_dev(maple_ctx *c, int32_t n, int32_t childList
     DISPATCH3(c, k_append_query, <<<grid_for(n), MAPLE_BLOCK, 0, s>>>(c->dm, view(c), n, childList, isTipC, bLen, cand, out));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipEventRecord(e1, s));
+    return MAPLE_OK;
+}
+
+
+// ---- tree mirror + SPR search ------------------------------------------------------------------------
+extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const int32_t *up, const int32_t *child0,
+                                 const int32_t *child1, const double *dist, const uint8_t *isTip, const int32_t *lower,
+                                 const int32_t *upRight, const int32_t *upLeft, const int32_t *totUp, const int32_t *mutList)
+{
+    if (!c || n <= 0 || !up || !child0 || !child1 || !dist || !isTip || !lower || !upRight || !upLeft || !totUp || !mutList)
+        return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(check_ids(c, n, lower, true, "lower"));
+    TRY(check_ids(c, n, upRight, true, "upRight"));
+    TRY(check_ids(c, n, upLeft, true, "upLeft"));
+    TRY(check_ids(c, n, totUp, true, "totUp"));
+    const int32_t nml = (int32_t)c->h_mut_cnt.size();
+    for (int i = 0; i < n; i++)
+        if (mutList[i] >= nml) return fail(c, MAPLE_ERR_ARG, "mutList[%d] is not a mutation-list id", i);
+    const int32_t *src[9] = {up, child0, child1, lower, upRight, upLeft, totUp, mutList, nullptr};
+    for (int k = 0; k < 8; k++) TRY(h2d(c, c->t_i32[k], src[k], (size_t)n));
+    TRY(h2d(c, c->t_dist, dist, (size_t)n));
+    TRY(h2d(c, c->t_tip, isTip, (size_t)n));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    DevTree &T = c->dtree;
+    T.n = n; T.root = root;
+    T.up = c->t_i32[0].p; T.c0 = c->t_i32[1].p; T.c1 = c->t_i32[2].p;
+    T.lower = c->t_i32[3].p; T.upRight = c->t_i32[4].p; T.upLeft = c->t_i32[5].p; T.totUp = c->t_i32[6].p;
+    T.mutId = c->t_i32[7].p;
+    T.dist = c->t_dist.p; T.isTip = c->t_tip.p;
+    c->h_tree_up.assign(up, up + n);
+    c->h_tree_lower.assign(lower, lower + n);
+    c->tree_set = true;
+    return MAPLE_OK;
+}
+
+extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *nodes, const maple_search_params *sp,
+                                      int32_t ws_entries_per_lane, int32_t *bestNode, double *bestScore, double *blen3,
+                                      int32_t *placement, double *improvement, double *currentLK, int32_t *nAppend,
+                                      int32_t *status, int32_t *outRprList)
+{
+    if (!c || n < 0 || !nodes || !sp || !bestNode || !bestScore || !blen3 || !placement || !improvement || !currentLK
+        || !nAppend || !status)
+        return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    if (!c->tree_set) return fail(c, MAPLE_ERR_STATE, "maple_tree_upload has not been called");
+    for (int i = 0; i < n; i++)
+        if (nodes[i] < 0 || nodes[i] >= c->dtree.n) return fail(c, MAPLE_ERR_ARG, "nodes[%d] = %d is not a node", i, nodes[i]);
+    SearchParams P;
+    P.strict = sp->strictTopologyStopRules; P.allowedFails = sp->allowedFailsTopology;
+    P.thrLKtopology = sp->thresholdLogLKtopology; P.thrPlacement = sp->thresholdTopologyPlacement;
+    P.thrOptTopo = sp->thresholdLogLKoptimizationTopology; P.thrConsec = sp->thresholdLogLKconsecutivePlacement;
+    P.effNon0 = sp->effectivelyNon0BLen;
+    HIPCK(c, c->s_search_out.reserve((size_t)n * sizeof(SearchOut)));
+    HIPCK(c, c->s_counter.reserve(8));
+    std::vector<SearchOut> ho(n);
+    std::vector<int32_t> todo(nodes, nodes + n), slot(n);
+    for (int i = 0; i < n; i++) slot[i] = i;
+    // output pool for bestRemovedPartials: a list re-expressed in another frame stays close to its original size
+    long long poolCapW = 0, poolCapA = 0;
+    uint2 *poolW = nullptr;
+    double *poolA = nullptr;
+    if (outRprList) {
+        for (int i = 0; i < n; i++) {
+            int lid = c->h_tree_lower[nodes[i]];
+            long long ne = lid >= 0 ? c->h_n_ent[lid] : 0, na = lid >= 0 ? c->h_n_aux[lid] : 0;
+            poolCapW += 3 * ne + 64; poolCapA += 3 * na + 5 * ne + 64;
+        }
+        HIPCK(c, c->s_words.reserve((size_t)poolCapW));
+        HIPCK(c, c->s_aux.reserve((size_t)poolCapA));
+        poolW = c->s_words.p; poolA = c->s_aux.p;
+    }
+    HIPCK(c, hipMemsetAsync(c->s_counter.p, 0, 8 * sizeof(int32_t), c->stream));
+    unsigned long long *poolUsed = (unsigned long long *)(c->s_counter.p + 2);
+    int capW = ws_entries_per_lane > 0 ? ws_entries_per_lane : 16384;
+    // queries whose per-lane workspace overflowed (status -3) are re-run with 8x the workspace, twice at most
+    for (int attempt = 0; attempt < 3 && !todo.empty(); attempt++, capW *= 8) {
+        const int m = (int)todo.size();
+        WsLayout L;
+        L.capW = capW;
+        L.capA = 3 * L.capW;
+        L.capH = L.capW / 8 + 256;
+        L.capS = 1024 * (attempt + 1);
+        L.capB = 1024 * (attempt + 1);
+        L.capAis = 8192 * (attempt + 1);
+        LaneBytes LB = lane_bytes(L);
+        int maxLanes = 16384 >> (3 * attempt);                         // keeps the workspace footprint bounded
+        int lanes = m < maxLanes ? ((m + 63) / 64) * 64 : maxLanes;
+        HIPCK(c, c->s_search_ws.reserve((size_t)lanes * LB.total));
+        HIPCK(c, hipMemsetAsync(c->s_counter.p, 0, sizeof(int32_t), c->stream));
+        TRY(h2d(c, c->s_i32[0], todo.data(), (size_t)m));
+        SearchOut *dout = (SearchOut *)c->s_search_out.p;
+        hipEvent_t e0, e1;
+        TRY(ev_pair(c, &e0, &e1));
+        HIPCK(c, hipEventRecord(e0, c->stream));
+        DISPATCH3(c, k_spr_search, <<<lanes / 64, 64, 0, c->stream>>>(c->dm, view(c), mview(c), c->dtree, P, m, c->s_i32[0].p,
+                                                                     L, LB, c->s_search_ws.p, c->s_counter.p, dout, poolW,
+                                                                     poolA, poolUsed, poolCapW, poolCapA));
+        HIPCK(c, hipGetLastError());
+        HIPCK(c, hipEventRecord(e1, c->stream));
+        std::vector<SearchOut> part(m);
+        HIPCK(c, hipMemcpyAsync(part.data(), dout, (size_t)m * sizeof(SearchOut), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        std::vector<int32_t> todo2, slot2;
+        for (int k = 0; k < m; k++) {
+            ho[slot[k]] = part[k];
+            if (part[k].status == -3 && attempt < 2) { todo2.push_back(todo[k]); slot2.push_back(slot[k]); }
+        }
+        todo.swap(todo2);
+        slot.swap(slot2);
+    }
+    for (int i = 0; i < n; i++) {
+        bestNode[i] = ho[i].bestNode; bestScore[i] = ho[i].bestScore;
+        blen3[3 * i] = ho[i].blen[0]; blen3[3 * i + 1] = ho[i].blen[1]; blen3[3 * i + 2] = ho[i].blen[2];
+        placement[i] = ho[i].placement; improvement[i] = ho[i].improvement; currentLK[i] = ho[i].currentLK;
+        nAppend[i] = ho[i].nAppend; status[i] = ho[i].status;
+    }
+    if (outRprList) {                                                  // bestRemovedPartials become arena lists
+        std::vector<int64_t> woff(n, 0), aoff(n, 0);
+        std::vector<int32_t> ne(n, -1), na(n, 0);
+        for (int i = 0; i < n; i++)
+            if (ho[i].status == 0 && ho[i].rprWoff >= 0) { woff[i] = ho[i].rprWoff; aoff[i] = ho[i].rprAoff; ne[i] = ho[i].rprN; na[i] = ho[i].rprNA; }
+        HIPCK(c, c->s_i32[2].reserve(n));
+        HIPCK(c, c->s_i32[3].reserve(n));
+        HIPCK(c, hipMemcpyAsync(c->s_i32[2].p, ne.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->s_i32[3].p, na.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        TRY(commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outRprList));
+    }
     return MAPLE_OK;
 }
 

@@ -1,0 +1,418 @@
+// maple_amd/csrc/search_dev.h -- device-resident SPR regraft search.
+//
+// One lane runs one findBestParentTopology (M:6817-7724) as a state machine: every loop iteration pops one
+// item of the reference's LIFO stack `nodesToVisit`, so the order-dependent pruning (bestLKdiff, failedPasses)
+// is reproduced exactly.  The "as-if-removed" genome lists live in a per-lane bump arena in HBM; list handles
+// are indirect so that the reference's in-place shorten() (M:7087) is seen by every holder of the list.
+// The wrapper around it is the worker body of startTopologyUpdatesParallel (M:9615-9711).
+// Not implemented (flags that are off by default and outside BASELINE's configs): HnZ, time trees, SPRTA,
+// --deeperSearchForLongBranches.
+#pragma once
+#include "genome_dev.h"
+
+namespace maple {
+
+struct ArenaViewS {                    // same fields as ArenaView in maple_hip.hip (kept POD for kernel args)
+    const uint2 *words;
+    const double *aux;
+    const int64_t *ent_off;
+    const int64_t *aux_off;
+    const int32_t *n_ent;
+    const int32_t *n_aux;
+};
+
+struct MutViewS {
+    const int32_t *mut3;
+    const int64_t *off;
+    const int32_t *cnt;
+};
+
+struct DevTree {
+    int32_t n, root;
+    const int32_t *up, *c0, *c1;       // -1 = none
+    const double *dist;
+    const uint8_t *isTip;              // leaf without minor sequences
+    const int32_t *lower, *upRight, *upLeft, *totUp;   // list ids, -1 = None
+    const int32_t *mutId;              // mutation-list id of the branch above the node, -1 = empty
+};
+
+struct SearchParams {
+    int32_t strict;                    // strictTopologyStopRules
+    int32_t allowedFails;              // allowedFailsTopology
+    double thrLKtopology;              // thresholdLogLKtopology (already x log lRef)
+    double thrPlacement;               // thresholdTopologyPlacement
+    double thrOptTopo;                 // thresholdLogLKoptimizationTopology
+    double thrConsec;                  // thresholdLogLKconsecutivePlacement
+    double effNon0;                    // effectivelyNon0BLen
+};
+
+struct TList { const uint2 *w; const double *aux; int32_t n, na; };
+
+struct StackItem {
+    int32_t t1;
+    int8_t dir, upd;
+    int16_t fails;
+    int32_t hPassed, hRpr;
+    double distance, lastLK;
+};
+
+struct BestRec { int32_t t1, hUp, hDown, hMid, hRpr; double score, distance; };
+
+struct SearchOut {                     // per query
+    int32_t bestNode, placement, status, nAppend;
+    double bestScore, improvement, currentLK;
+    double blen[3];
+    int64_t rprWoff, rprAoff;          // bestRemovedPartials inside the output pool (-1 = not stored)
+    int32_t rprN, rprNA;
+};
+
+struct WsLayout {                      // per-lane workspace capacities
+    int32_t capW, capA, capH, capS, capB, capAis;
+};
+
+struct LaneWs {
+    uint2 *w; double *aux; TList *h; StackItem *st; BestRec *best; double *ais;
+    int32_t usedW, usedA, nH, sp, nB;
+    WsLayout L;
+    bool overflow;
+    __device__ inline int newHandle(const uint2 *w_, const double *a_, int n, int na)
+    {
+        if (nH >= L.capH) { overflow = true; return -2; }
+        h[nH] = TList{w_, a_, n, na};
+        return nH++;
+    }
+    __device__ inline bool reserve(int nw) { if (usedW + nw > L.capW || usedA + 5 * nw > L.capA) { overflow = true; return false; } return true; }
+    __device__ inline int commit(const Writer &wr)
+    {
+        int hid = newHandle(w + usedW, aux + usedA, wr.n, wr.na);
+        usedW += wr.n; usedA += wr.na;
+        return hid;
+    }
+};
+
+template <bool RV, bool U, bool SS> struct Search {
+    typedef Ctx<RV, U, SS> CT;
+    const CT &c;
+    const ArenaViewS &av;
+    const MutViewS &mv;
+    const DevTree &T;
+    const SearchParams &P;
+    LaneWs &ws;
+    int nAppend;
+
+    __device__ Search(const CT &c_, const ArenaViewS &av_, const MutViewS &mv_, const DevTree &T_, const SearchParams &P_, LaneWs &ws_)
+        : c(c_), av(av_), mv(mv_), T(T_), P(P_), ws(ws_), nAppend(0) {}
+
+    // ---- list helpers (every op returns a handle; -1 = the reference's None; -2 = out of workspace) ----
+    // handles >= 0 index the lane's handle table; handles <= -10 name a list of the tree arena directly
+    // (read-only, never shortened in place)
+    __device__ inline int treeList(int listId) const { return listId < 0 ? -1 : -(listId + 10); }
+    __device__ inline TList L(int hid) const
+    {
+        if (hid >= 0) return ws.h[hid];
+        int id = -hid - 10;
+        return TList{av.words + av.ent_off[id], av.aux + av.aux_off[id], av.n_ent[id], av.n_aux[id]};
+    }
+    __device__ inline ListRef ref(int hid) const { TList t = L(hid); return ListRef{t.w, t.aux}; }
+    __device__ inline int len(int hid) const { return hid >= 0 ? ws.h[hid].n : av.n_ent[-hid - 10]; }
+    __device__ inline bool valid(int hid) const { return hid >= 0 || hid <= -10; }
+    // a real (repointable) handle for a tree list: needed for the list that shorten() may edit in place
+    __device__ inline int ownHandle(int listId)
+    {
+        if (listId < 0) return -1;
+        return ws.newHandle(av.words + av.ent_off[listId], av.aux + av.aux_off[listId], av.n_ent[listId], av.n_aux[listId]);
+    }
+    __device__ __noinline__ int opPass(int hid, int mutId, bool dirUp)
+    {
+        if (!valid(hid) || mutId < 0) return hid;
+        int cnt = mv.cnt[mutId];
+        if (cnt == 0) return hid;
+        if (!ws.reserve(len(hid) + 2 * cnt)) return -2;
+        Writer wr;
+        wr.init(ws.w + ws.usedW, ws.aux + ws.usedA);
+        pass_walk(c.m.lRef, ref(hid), mv.mut3 + 3 * mv.off[mutId], cnt, dirUp, wr);
+        return ws.commit(wr);
+    }
+    __device__ __noinline__ int opMerge(int h1, double b1, bool t1, int h2, double b2, bool t2, bool upDown)
+    {
+        if (!valid(h1) || !valid(h2)) return -2;
+        if (!ws.reserve(len(h1) + len(h2))) return -2;
+        Writer wr;
+        wr.init(ws.w + ws.usedW, ws.aux + ws.usedA);
+        int r = merge_walk(c, ref(h1), b1, t1, ref(h2), b2, t2, upDown, false, 0, 0, wr, nullptr);
+        if (r == -1) return -1;
+        if (r < 0) return -2;
+        return ws.commit(wr);
+    }
+    __device__ __noinline__ void opShortenInPlace(int hid)
+    {
+        if (hid < 0) return;                                          // only real handles can be repointed
+        int n = ws.h[hid].n;
+        if (!ws.reserve(n)) return;
+        Writer wr;
+        wr.init(ws.w + ws.usedW, ws.aux + ws.usedA);
+        shorten_walk(c, ref(hid), n, wr);
+        if (wr.n == n) return;                                        // nothing merged: keep the old storage
+        ws.h[hid] = TList{ws.w + ws.usedW, ws.aux + ws.usedA, wr.n, wr.na};
+        ws.usedW += wr.n; ws.usedA += wr.na;
+    }
+    __device__ __noinline__ double opAppend(int hP, int hC, bool isTipC, double bLen)
+    {
+        nAppend++;
+        return append_walk(c, ref(hP), ref(hC), isTipC, bLen);
+    }
+    __device__ __noinline__ double opBlen(int hP, int hC, bool fromTipC)
+    {
+        bool f;
+        if (len(hP) + len(hC) > ws.L.capAis) { ws.overflow = true; return 0.0; }
+        return blen_walk(c, ref(hP), ref(hC), fromTipC, ws.ais, 1, &f);
+    }
+    __device__ __noinline__ bool opDiffer(int h1, int h2)
+    {
+        if (!valid(h2)) return true;
+        return differ_walk(c, ref(h1), ref(h2));
+    }
+    // rootVector(probVect, bLen, isFromTip, tree, node), M:4916-4996
+    __device__ __noinline__ int opRootVector(int hid, double bLen, bool isFromTip, int node)
+    {
+        int cur = hid;
+        if (!valid(cur)) return -2;
+        for (int v = node; v >= 0; v = T.up[v]) { cur = opPass(cur, T.mutId[v], true); if (!valid(cur)) return -2; }
+        if (!ws.reserve(len(cur))) return -2;
+        Writer wr;
+        wr.init(ws.w + ws.usedW, ws.aux + ws.usedA);
+        root_walk(c, ref(cur), bLen, isFromTip, wr);
+        cur = ws.commit(wr);
+        if (cur < 0) return -2;
+        // back down: root first ... node last (M:4988-4993); walk the path again from the top
+        int depth = 0;
+        for (int v = node; v >= 0; v = T.up[v]) depth++;
+        for (int k = depth - 1; k >= 0; k--) {
+            int v = node;
+            for (int s = 0; s < k; s++) v = T.up[v];
+            cur = opPass(cur, T.mutId[v], false);
+            if (cur < 0) return -2;                                  // always a real handle after root_walk
+        }
+        opShortenInPlace(cur);
+        return cur;
+    }
+
+    __device__ inline void push(int t1, int dir, bool upd, int hPassed, double distance, double lastLK, int fails, int hRpr)
+    {
+        if (ws.sp >= ws.L.capS) { ws.overflow = true; return; }
+        StackItem &s = ws.st[ws.sp++];
+        s.t1 = t1; s.dir = (int8_t)dir; s.upd = upd ? 1 : 0; s.fails = (int16_t)fails;
+        s.hPassed = hPassed; s.hRpr = hRpr; s.distance = distance; s.lastLK = lastLK;
+    }
+    __device__ inline void record(int t1, double score, int hUp, int hDown, double distance, int hMid, int hRpr)
+    {
+        if (ws.nB >= ws.L.capB) { ws.overflow = true; return; }
+        ws.best[ws.nB++] = BestRec{t1, hUp, hDown, hMid, hRpr, score, distance};
+    }
+    __device__ inline int child(int v, int k) const { return k == 0 ? T.c0[v] : T.c1[v]; }
+    __device__ inline int upVectOf(int t1) const { return (T.c0[T.up[t1]] == t1) ? T.upRight[T.up[t1]] : T.upLeft[T.up[t1]]; }
+
+    // search state
+    int node, removed, sibling;
+    bool isRemovedTip;
+    double removedBLen, bestLKdiff, originalLK;
+    int hBestRpr, bestNode;
+    double bestScore, bl0, bl1, bl2;
+    int refineIdx;
+
+    // seeding of nodesToVisit, M:6855-6962
+    __device__ __noinline__ void begin(int node_, int childIdx, double bestLK, double remBLen)
+    {
+        node = node_;
+        removed = child(node, childIdx);
+        sibling = child(node, 1 - childIdx);
+        removedBLen = remBLen;
+        bestLKdiff = originalLK = bestLK;
+        bestNode = sibling;
+        refineIdx = 0;
+        int rpr = opPass(ownHandle(T.lower[removed]), T.mutId[removed], true);
+        hBestRpr = opPass(rpr, T.mutId[sibling], false);
+        isRemovedTip = T.isTip[removed];
+        if (T.up[node] >= 0) {
+            int parent = T.up[node];
+            bool first = T.c0[parent] == node;
+            int vectUpUp = treeList(first ? T.upRight[parent] : T.upLeft[parent]);
+            int pv1 = opPass(treeList(T.lower[sibling]), T.mutId[sibling], true);
+            int rpr1 = rpr;
+            if (T.mutId[node] >= 0) { pv1 = opPass(pv1, T.mutId[node], true); rpr1 = opPass(rpr, T.mutId[node], true); }
+            double d = T.dist[sibling] + T.dist[node];
+            push(parent, first ? 1 : 2, true, pv1, d, bestLK, 0, rpr1);
+            vectUpUp = opPass(vectUpUp, T.mutId[node], false);
+            rpr1 = rpr;
+            if (T.mutId[sibling] >= 0) { vectUpUp = opPass(vectUpUp, T.mutId[sibling], false); rpr1 = opPass(rpr, T.mutId[sibling], false); }
+            push(sibling, 0, true, vectUpUp, d, bestLK, 0, rpr1);
+            bl0 = T.dist[node]; bl1 = T.dist[sibling]; bl2 = remBLen;
+        } else {
+            if (T.c0[sibling] >= 0) {                                // M:6916-6960, node is the root
+                int ch1 = T.c0[sibling], ch2 = T.c1[sibling];
+                int v1 = opPass(treeList(T.lower[ch2]), T.mutId[ch2], true);
+                v1 = opRootVector(v1, T.dist[ch2], T.isTip[ch2], node);
+                int r1 = hBestRpr;
+                if (T.mutId[ch1] >= 0) { r1 = opPass(hBestRpr, T.mutId[ch1], false); v1 = opPass(v1, T.mutId[ch1], false); }
+                push(ch1, 0, true, v1, T.dist[ch1], bestLK, 0, r1);
+                int v2 = opPass(treeList(T.lower[ch1]), T.mutId[ch1], true);
+                v2 = opRootVector(v2, T.dist[ch1], T.isTip[ch1], node);
+                int r2 = hBestRpr;
+                if (T.mutId[ch2] >= 0) { r2 = opPass(hBestRpr, T.mutId[ch2], false); v2 = opPass(v2, T.mutId[ch2], false); }
+                push(ch2, 0, true, v2, T.dist[ch2], bestLK, 0, r2);
+            }
+            bl0 = 0.0; bl1 = T.dist[sibling]; bl2 = remBLen;
+        }
+        bestScore = originalLK;
+    }
+
+    // one iteration of "while nodesToVisit", M:6964-7434
+    __device__ __noinline__ void step()
+    {
+        StackItem it = ws.st[--ws.sp];
+        const int t1 = it.t1;
+        bool upd = it.upd;
+        int fails = it.fails;
+        const int hPassed = it.hPassed, hRpr = it.hRpr;
+        double distance = it.distance;
+        double midProb;
+        if (it.dir == 0) {                                           // moving from a parent to its child
+            const int upT = T.up[t1];
+            if (!(upT == node || upT < 0) && (T.dist[t1] > P.effNon0 || T.up[upT] < 0)) {
+                int midTot;
+                if (upd) {
+                    midTot = opMerge(hPassed, distance / 2, false, treeList(T.lower[t1]), distance / 2, T.isTip[t1], true);
+                    if (midTot < 0) return;
+                    if (!opDiffer(midTot, treeList(T.totUp[t1]))) upd = false;
+                } else {
+                    midTot = treeList(T.totUp[t1]);
+                    distance = T.dist[t1];
+                }
+                if (!valid(midTot)) return;
+                midProb = opAppend(midTot, hRpr, isRemovedTip, removedBLen);
+                if (midProb > bestLKdiff - P.thrOptTopo) {            // M:7071-7082
+                    if (upd) record(t1, midProb, hPassed, treeList(T.lower[t1]), distance, midTot, hRpr);
+                    else record(t1, midProb, -1, -1, 0.0, -1, hRpr);
+                }
+                if (midProb > bestLKdiff) { bestLKdiff = midProb; fails = 0; opShortenInPlace(hRpr); }
+                else if (midProb < (it.lastLK - P.thrConsec)) fails++;
+            } else midProb = it.lastLK;
+            bool go;
+            if (P.strict) go = fails <= P.allowedFails && midProb > (bestLKdiff - P.thrLKtopology) && T.c0[t1] >= 0;
+            else go = (fails <= P.allowedFails || midProb > (bestLKdiff - P.thrLKtopology)) && T.c0[t1] >= 0;
+            if (go) {
+                for (int k = 0; k < 2; k++) {                         // child 0 uses vectUpRight, child 1 vectUpLeft
+                    const int ch = child(t1, k), other = child(t1, 1 - k);
+                    int vUp;
+                    if (upd) {
+                        int opv = opPass(treeList(T.lower[other]), T.mutId[other], true);
+                        vUp = opMerge(hPassed, distance, false, opv, T.dist[other], T.isTip[other], true);
+                        if (vUp == -2) { ws.overflow = true; return; }
+                    } else vUp = treeList(k == 0 ? T.upRight[t1] : T.upLeft[t1]);
+                    if (valid(vUp)) {
+                        int r1 = opPass(hRpr, T.mutId[ch], false);
+                        if (upd) { vUp = opPass(vUp, T.mutId[ch], false); push(ch, 0, true, vUp, T.dist[ch], midProb, fails, r1); }
+                        else push(ch, 0, false, -1, 0.0, midProb, fails, r1);
+                    }
+                }
+            }
+        } else {                                                     // crawling up from child (dir-1) to its parent t1
+            const int other = child(t1, 2 - it.dir);
+            const int upT = T.up[t1];
+            int midBottom = -1, vectUp = -1;
+            if (upT >= 0 && (T.dist[t1] > P.effNon0 || T.up[upT] < 0)) {
+                int midTot;
+                if (upd) {
+                    int opv = opPass(treeList(T.lower[other]), T.mutId[other], true);
+                    midBottom = opMerge(hPassed, distance, false, opv, T.dist[other], T.isTip[other], false);
+                    if (midBottom < 0) return;
+                    vectUp = opPass(treeList(upVectOf(t1)), T.mutId[t1], false);
+                    midTot = opMerge(vectUp, T.dist[t1] / 2, false, midBottom, T.dist[t1] / 2, false, true);
+                    if (midTot < 0) return;
+                    if (!opDiffer(midTot, treeList(T.totUp[t1]))) upd = false;
+                } else midTot = treeList(T.totUp[t1]);
+                if (!valid(midTot)) return;
+                midProb = opAppend(midTot, hRpr, isRemovedTip, removedBLen);
+                if (midProb >= (bestLKdiff - P.thrOptTopo)) {         // M:7293-7304 (>= here, > on the way down)
+                    if (upd) record(t1, midProb, vectUp, midBottom, T.dist[t1], midTot, hRpr);
+                    else record(t1, midProb, -1, -1, 0.0, -1, hRpr);
+                }
+                if (midProb > bestLKdiff) { bestLKdiff = midProb; fails = 0; }
+                else if (midProb < (it.lastLK - P.thrConsec)) fails++;
+            } else midProb = it.lastLK;
+            bool go;
+            if (P.strict) go = fails <= P.allowedFails && midProb > (bestLKdiff - P.thrLKtopology);
+            else go = fails <= P.allowedFails || midProb > (bestLKdiff - P.thrLKtopology);
+            if (!go) return;
+            if (upT >= 0) {
+                const int upChild = (T.c0[upT] == t1) ? 0 : 1;
+                int vUp;
+                if (upd) {
+                    int vUpUp = opPass(treeList(upVectOf(t1)), T.mutId[t1], false);
+                    vUp = opMerge(vUpUp, T.dist[t1], false, hPassed, distance, false, true);
+                    if (vUp == -2) { ws.overflow = true; return; }
+                } else vUp = treeList(it.dir == 1 ? T.upLeft[t1] : T.upRight[t1]);
+                if (!valid(vUp)) return;
+                int r1 = opPass(hRpr, T.mutId[other], false);
+                if (upd) { vUp = opPass(vUp, T.mutId[other], false); push(other, 0, true, vUp, T.dist[other], midProb, fails, r1); }
+                else push(other, 0, false, -1, 0.0, midProb, fails, r1);
+                if (upd && midBottom < 0) {                           // M:7376-7384
+                    int opv = opPass(treeList(T.lower[other]), T.mutId[other], true);
+                    midBottom = opMerge(hPassed, distance, false, opv, T.dist[other], T.isTip[other], false);
+                    if (midBottom < 0) return;
+                }
+                r1 = opPass(hRpr, T.mutId[t1], true);
+                if (upd) { midBottom = opPass(midBottom, T.mutId[t1], true); push(upT, upChild + 1, true, midBottom, T.dist[t1], midProb, fails, r1); }
+                else push(upT, upChild + 1, false, -1, 0.0, midProb, fails, r1);
+            } else {                                                  // t1 is the root, M:7406-7432
+                int r1 = opPass(hRpr, T.mutId[other], false);
+                if (upd) {
+                    int vUp = opRootVector(hPassed, distance, false, t1);
+                    vUp = opPass(vUp, T.mutId[other], false);
+                    if (!valid(vUp)) { ws.overflow = true; return; }
+                    push(other, 0, true, vUp, T.dist[other], midProb, fails, r1);
+                } else push(other, 0, false, -1, 0.0, midProb, fails, r1);
+            }
+        }
+    }
+
+    // refinement of one short-listed branch, M:7460-7639 (evaluatePlacement M:6790-6806 inlined)
+    __device__ __noinline__ int refine(const BestRec &r)
+    {
+        if (!(r.score >= originalLK - P.thrOptTopo)) return 0;
+        const int t1 = r.t1;
+        int upV, downV, midTot;
+        double distance;
+        if (r.hUp == -1) {
+            upV = opPass(treeList(upVectOf(t1)), T.mutId[t1], false);
+            downV = treeList(T.lower[t1]);
+            distance = T.dist[t1];
+            midTot = treeList(T.totUp[t1]);
+        } else { upV = r.hUp; downV = r.hDown; distance = r.distance; midTot = r.hMid; }
+        if (!valid(upV) || !valid(downV) || !valid(midTot)) return -1;
+        const int rem = r.hRpr;
+        const bool ft = T.isTip[t1];
+        const int saveW = ws.usedW, saveA = ws.usedA, saveH = ws.nH;
+        double app = opBlen(midTot, rem, isRemovedTip);
+        int midLower = opMerge(downV, distance / 2, ft, rem, app, isRemovedTip, false);
+        if (midLower < 0) return -1;                                  // the reference fails here (caught by the worker)
+        double top = opBlen(upV, midLower, false);
+        int midTop = opMerge(upV, top, false, rem, app, isRemovedTip, true);
+        if (midTop == -1) { top = c.m.defaultBLen * 0.1; midTop = opMerge(upV, top, false, rem, app, isRemovedTip, true); }
+        if (midTop < 0) return -1;
+        double bottom = opBlen(midTop, downV, ft);
+        int newMid = opMerge(upV, top, false, downV, bottom, ft, true);
+        if (newMid < 0) return -1;
+        double cost = opAppend(newMid, rem, isRemovedTip, app);
+        double initialCost = opAppend(upV, downV, ft, distance);
+        double newPartialCost = opAppend(upV, downV, ft, bottom + top);
+        double optimized = cost + newPartialCost - initialCost;
+        ws.usedW = saveW; ws.usedA = saveA; ws.nH = saveH;            // temporaries of this record are dead
+        if (optimized >= bestScore) {
+            bestNode = t1; bestScore = optimized; bl0 = top; bl1 = bottom; bl2 = app; hBestRpr = rem;
+        }
+        return 0;
+    }
+};
+
+} // namespace maple

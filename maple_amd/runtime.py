@@ -22,7 +22,7 @@ EXPORTS = [
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
     "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_query_dev", "maple_timing_reset", "maple_timing_read",
-    "maple_append_algorithmic_bytes",
+    "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch",
 ]
 
 
@@ -30,6 +30,13 @@ class MapleParams(C.Structure):
     _fields_ = [("thresholdProb", C.c_double), ("minBLenSensitivity", C.c_double),
                 ("thresholdDiffForUpdate", C.c_double), ("thresholdFoldChangeUpdate", C.c_double),
                 ("defaultBLen", C.c_double)]
+
+
+class MapleSearchParams(C.Structure):
+    _fields_ = [("strictTopologyStopRules", C.c_int32), ("allowedFailsTopology", C.c_int32),
+                ("thresholdLogLKtopology", C.c_double), ("thresholdTopologyPlacement", C.c_double),
+                ("thresholdLogLKoptimizationTopology", C.c_double), ("thresholdLogLKconsecutivePlacement", C.c_double),
+                ("effectivelyNon0BLen", C.c_double)]
 
 
 class MapleError(RuntimeError):
@@ -226,6 +233,12 @@ class Device:
         self._ck(self.lib.maple_differ_batch(self.h, len(l1), _ptr(l1), _ptr(l2), _ptr(out)))
         return out.astype(bool)
 
+    def minor_batch(self, l1, l2, onlyFindIdentical=False):
+        l1, l2 = _i32(l1), _i32(l2)
+        out = np.zeros(len(l1), dtype=np.uint8)
+        self._ck(self.lib.maple_minor_batch(self.h, len(l1), _ptr(l1), _ptr(l2), int(bool(onlyFindIdentical)), _ptr(out)))
+        return out
+
     def pass_branch_batch(self, lists, mutLists, dirIsUp):
         lists, mutLists = _i32(lists), _i32(mutLists)
         n = len(lists)
@@ -265,6 +278,38 @@ class Device:
         out = np.zeros((n, 4))
         self._ck(self.lib.maple_evaluate_placement_batch(self.h, n, _ptr(midTot), _ptr(down), _ptr(up), _ptr(dist),
                                                          _ptr(removed), _ptr(rt), _ptr(ft), _ptr(out)))
+        return out
+
+    # -- tree mirror + device-resident SPR search ------------------------------------------------------
+    def upload_tree(self, root, up, child0, child1, dist, isTip, lower, upRight, upLeft, totUp, mutList):
+        n = len(up)
+        arrs = [_i32(x) for x in (up, child0, child1)]
+        d, tip = _f64(dist), _u8(isTip)
+        ls = [_i32(x) for x in (lower, upRight, upLeft, totUp, mutList)]
+        self._ck(self.lib.maple_tree_upload(self.h, n, int(root), _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(d),
+                                            _ptr(tip), _ptr(ls[0]), _ptr(ls[1]), _ptr(ls[2]), _ptr(ls[3]), _ptr(ls[4])))
+        self.n_nodes = n
+
+    def spr_search_batch(self, nodes, *, strict, allowedFails, thresholdLogLKtopology, thresholdTopologyPlacement,
+                         thresholdLogLKoptimizationTopology, thresholdLogLKconsecutivePlacement, effectivelyNon0BLen,
+                         ws_entries_per_lane=0, want_removed_partials=False):
+        """startTopologyUpdatesParallel's worker body (M:9615-9711) for `nodes`, searches run on the GPU."""
+        nodes = _i32(nodes)
+        n = len(nodes)
+        sp = MapleSearchParams(int(bool(strict)), int(allowedFails), thresholdLogLKtopology, thresholdTopologyPlacement,
+                               thresholdLogLKoptimizationTopology, thresholdLogLKconsecutivePlacement,
+                               effectivelyNon0BLen)
+        out = dict(bestNode=np.zeros(n, np.int32), bestScore=np.zeros(n), blen=np.zeros((n, 3)),
+                   placement=np.zeros(n, np.int32), improvement=np.zeros(n), currentLK=np.zeros(n),
+                   nAppend=np.zeros(n, np.int32), status=np.zeros(n, np.int32))
+        rpr = np.zeros(n, np.int32) if want_removed_partials else None
+        self._ck(self.lib.maple_spr_search_batch(self.h, n, _ptr(nodes), C.byref(sp), int(ws_entries_per_lane),
+                                                 _ptr(out["bestNode"]), _ptr(out["bestScore"]), _ptr(out["blen"]),
+                                                 _ptr(out["placement"]), _ptr(out["improvement"]),
+                                                 _ptr(out["currentLK"]), _ptr(out["nAppend"]), _ptr(out["status"]),
+                                                 _ptr(rpr)))
+        if want_removed_partials:
+            out["removedPartials"] = rpr
         return out
 
     # -- device-resident forms (pointers into HBM, e.g. torch tensors' data_ptr()) ------------------

@@ -1,0 +1,219 @@
+"""Placement search for a new sample -- the host counterpart of findBestParentForNewSample
+(MAPLEv0.7.5.4.py:7912-8292) with every genome-list evaluation done on the GPU.
+
+One query is searched at a time (the tree changes between samples), so the parallel axis is the
+candidate set: the query is scored against EVERY branch of the tree in one launch (a superset of
+what the reference's depth-first search visits), then the reference's LIFO traversal, stop rules,
+tie-breaks and short-list refinement are replayed over the cached scores.  Results (node,
+score, branch lengths, bestDiffs) are those of the reference; the number of appendProbNode
+evaluations the *reference* would have issued is reported as ``n_append``.
+
+Not implemented (off by default, outside BASELINE's configs): HnZ, time trees,
+--deeperSearchForLongBranches, computePlacementSupportOnly.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from .runtime import Device
+from .tree_host import HostTree
+
+
+@dataclass
+class PlacementParams:
+    oneMutBLen: float
+    effectivelyNon0BLen: float
+    thresholdLogLK: float                       # already x log(lRef), M:3613
+    thresholdLogLKoptimization: float           # already x log(lRef), M:3610
+    thresholdLogLKconsecutivePlacement: float   # M:63
+    allowedFails: int = 5
+    strictStopRules: bool = True
+    onlyFindIdentical: bool = False             # M:7931 / 7976: any error-model flag, supportFor0Branches or HnZ
+
+
+class _Diffs:
+    """A query genome list as the reference sees it: one mutable object per (frame, creation)."""
+    __slots__ = ("lid", "frame", "shortened")
+
+    def __init__(self, lid, frame):
+        self.lid, self.frame, self.shortened = int(lid), frame, False
+
+
+class PlacementSearcher:
+    def __init__(self, dev: Device, tree: HostTree, params: PlacementParams):
+        self.dev, self.tree, self.p = dev, tree, params
+        t = tree
+        n = t.n
+        self.has_mut = np.asarray([bool(m) for m in t.mutations])
+        # frame of a node = nearest ancestor-or-self carrying MAT mutations (-1 = the root frame)
+        order = []
+        stack = [t.root]
+        while stack:
+            v = stack.pop()
+            order.append(v)
+            stack.extend(t.children[v])
+        self.frame = -np.ones(n, dtype=np.int64)
+        self.frame_depth = {}
+        for v in order:
+            u = t.up[v]
+            pf = -1 if u is None else self.frame[u]
+            if self.has_mut[v]:
+                self.frame[v] = v
+                self.frame_depth[v] = 0 if pf < 0 else self.frame_depth[pf] + 1
+            else:
+                self.frame[v] = pf
+        self.frame_parent = {f: (-1 if t.up[f] is None else int(self.frame[t.up[f]])) for f in self.frame_depth}
+        levels = {}
+        for f, d in self.frame_depth.items():
+            levels.setdefault(d, []).append(f)
+        self.frame_levels = [levels[d] for d in sorted(levels)]
+        up = np.asarray([-1 if u is None else u for u in t.up])
+        dist = np.asarray(t.dist)
+        self.cand = np.nonzero((up >= 0) & (dist > params.effectivelyNon0BLen) & (t.id_totUp >= 0))[0]
+        self.leaves = np.asarray([v for v in range(n) if not t.children[v]], dtype=np.int64)
+        # rootVector(probVect[root], False, False, tree, root) does not depend on the query (M:7958)
+        path = [t.id_mut[t.root]] if t.id_mut[t.root] >= 0 else []
+        self.root_vect = int(dev.root_vector_batch([t.id_lower[t.root]], [0.0], [False], [path])[0])
+        self.is_tip = np.asarray([(not c) and (m == 0) for c, m in zip(t.children, t.n_minor)])
+
+    # ---------------------------------------------------------------------------------------------
+    def _frame_lists(self, q_id):
+        """Query list in every frame (U), its shortened form (S) -- all on the device."""
+        dev, t = self.dev, self.tree
+        U = {-1: int(q_id)}
+        for fl in self.frame_levels:
+            src = [U[self.frame_parent[f]] for f in fl]
+            out = dev.pass_branch_batch(src, [t.id_mut[f] for f in fl], False)
+            for f, o in zip(fl, out):
+                U[f] = int(o)
+        keys = list(U)
+        s_ids = dev.shorten_batch([U[k] for k in keys])
+        ne_u, _ = dev.sizes([U[k] for k in keys])
+        ne_s, _ = dev.sizes(s_ids)
+        S = {k: (int(s) if a != b else U[k]) for k, s, a, b in zip(keys, s_ids, ne_u, ne_s)}
+        return U, S
+
+    def find_best_parent_for_new_sample(self, diffs, sample=None):
+        """Returns (bestNode, bestScore, bestBranchLengths, bestDiffs, info); the first four as the reference."""
+        dev, t, p = self.dev, self.tree, self.p
+        mark = dev.mark()
+        try:
+            return self._search(diffs, sample)
+        finally:
+            dev.release(mark)
+
+    def _search(self, diffs, sample):
+        dev, t, p = self.dev, self.tree, self.p
+        q_id = dev.upload([diffs])[0]
+        U, S = self._frame_lists(q_id)
+        fr = self.frame
+        # one launch: the query against every candidate branch (+ the root), one launch: minor test on every leaf
+        cand = self.cand
+        child_ids = np.asarray([U[int(fr[v])] for v in cand] + [U[int(fr[t.root])]], dtype=np.int32)
+        parent_ids = np.concatenate([t.id_totUp[cand], [self.root_vect]]).astype(np.int32)
+        sc = dev.append_batch(parent_ids, child_ids, True, p.oneMutBLen)
+        score = dict(zip(cand.tolist(), sc[:-1].tolist()))
+        minor = {}
+        if len(self.leaves):
+            mres = dev.minor_batch(t.id_lower[self.leaves], [U[int(fr[v])] for v in self.leaves], p.onlyFindIdentical)
+            minor = dict(zip(self.leaves.tolist(), mres.tolist()))
+        n_append = 1
+
+        def shorten(obj):
+            if obj.shortened:
+                return
+            if obj.lid == U[obj.frame]:
+                obj.lid = S[obj.frame]
+            else:
+                obj.lid = int(dev.shorten_batch([obj.lid])[0])
+            obj.shortened = True
+
+        def pass_to(obj, c):
+            if not self.has_mut[c]:
+                return obj
+            if obj.lid == U[obj.frame]:
+                return _Diffs(U[c], c)
+            return _Diffs(dev.pass_branch_batch([obj.lid], [t.id_mut[c]], False)[0], c)
+
+        root = t.root
+        d0 = _Diffs(U[int(fr[root])], int(fr[root]))
+        best_nodes = []
+        best_node = root
+        best_blens = (False, False, p.oneMutBLen)
+        best_diffs = d0
+        missed = 0
+        if not t.children[root]:
+            if minor.get(root) == 1:
+                return root, 1.0, None, dev.download([d0.lid])[0], dict(n_append=0, minor=True)
+        best_lk = float(sc[-1])
+        original_lk = best_lk
+        stack = [(c, best_lk, 0, pass_to(d0, c)) for c in t.children[root]]
+        while stack:                                                     # M:7972-8100
+            t1, parent_lk, fails, dobj = stack.pop()
+            if not t.children[t1]:
+                cmpv = minor[t1]
+                if cmpv == 1:
+                    return t1, 1.0, None, dev.download([dobj.lid])[0], dict(n_append=n_append, minor=True)
+                if cmpv == 2:
+                    missed += 1
+            if t1 in score:                                              # dist > effectivelyNon0BLen and up != None
+                lk = score[t1]
+                n_append += 1
+                half = t.dist[t1] / 2
+                if lk >= best_lk:                                        # M:8065-8073
+                    shorten(dobj)
+                    best_lk = lk
+                    best_node = t1
+                    fails = 0
+                    best_nodes.append((t1, lk, dobj))
+                    best_diffs = dobj
+                    best_blens = (half, half / 2, p.oneMutBLen)
+                elif lk > best_lk - p.thresholdLogLKoptimization:
+                    best_nodes.append((t1, lk, dobj))
+                if lk < (parent_lk - p.thresholdLogLKconsecutivePlacement):
+                    fails += 1
+            else:
+                lk = parent_lk
+            if p.strictStopRules:
+                go = fails <= p.allowedFails and lk > (best_lk - p.thresholdLogLK)
+            else:
+                go = fails <= p.allowedFails or lk > (best_lk - p.thresholdLogLK)
+            if go:
+                for c in t.children[t1]:
+                    stack.append((c, lk, fails, pass_to(dobj, c)))
+        # short-list refinement, M:8101-8187
+        best_score = best_lk
+        todo = [(nd, s, d) for nd, s, d in best_nodes if s >= best_lk - p.thresholdLogLKoptimization]
+        if todo:
+            nodes = [nd for nd, _, _ in todo]
+            up_ids = []
+            for nd in nodes:
+                u = t.up[nd]
+                uid = t.id_upRight[u] if t.children[u][0] == nd else t.id_upLeft[u]
+                up_ids.append(int(uid))
+            need = [i for i, nd in enumerate(nodes) if self.has_mut[nd]]
+            if need:
+                passed = dev.pass_branch_batch([up_ids[i] for i in need], [t.id_mut[nodes[i]] for i in need], False)
+                for i, pid in zip(need, passed):
+                    up_ids[i] = int(pid)
+            q_ids = [d.lid for _, _, d in todo]
+            tips = [bool(self.is_tip[nd]) for nd in nodes]
+            dists = [t.dist[nd] for nd in nodes]
+            ev = dev.evaluate_placement_batch(t.id_totUp[nodes], t.id_lower[nodes], up_ids, dists, q_ids, True, tips)
+            k = len(nodes)
+            comp = dev.append_batch(up_ids + up_ids, list(t.id_lower[nodes]) * 2, tips + tips,
+                                    dists + [float(ev[i, 1] + ev[i, 2]) for i in range(k)])
+            n_append += 3 * k
+            for i, (nd, _, dobj) in enumerate(todo):
+                cost, bottom, top, app = (float(x) for x in ev[i])
+                optimized = cost + float(comp[k + i]) - float(comp[i])
+                if optimized >= best_score:
+                    best_node, best_score = nd, optimized
+                    best_blens = (top, bottom, app)
+                    best_diffs = dobj
+        if best_score == float("-inf"):
+            best_score = original_lk
+        return (best_node, best_score, best_blens, dev.download([best_diffs.lid])[0],
+                dict(n_append=n_append, minor=False, missed_minors=missed, candidates_scored=len(cand) + 1))

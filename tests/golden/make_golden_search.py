@@ -27,7 +27,9 @@ sys.path.insert(0, HERE)
 from make_golden import REF, ser_list  # noqa: E402
 
 RUNS = {
-    "synth_unrest": ["--model", "UNREST", "--maxNumDescendantsForMATClade", "12"],
+    # no SPR rounds in the reference run itself, so the frozen tree still has improvable placements
+    "synth_unrest": ["--model", "UNREST", "--maxNumDescendantsForMATClade", "12", "--numTopologyImprovements", "0",
+                     "--noFastTopologyInitialSearch"],
     "synth_siteerr": ["--model", "UNREST", "--rateVariation", "--estimateSiteSpecificErrorRate",
                       "--maxNumDescendantsForMATClade", "12"],
 }
@@ -121,8 +123,8 @@ def run(name, flags):
     ]
     spr = []
     for ps in param_sets:
-        tcopy = copy.deepcopy(tree)
         calls = []
+        moves = []
         state = {"cur": None, "n_append": 0}
 
         def prof(frame, event, arg):
@@ -148,23 +150,30 @@ def run(name, flags):
             elif co.co_name == "appendProbNode" and event == "call" and state["cur"] is not None:
                 state["n_append"] += 1
 
-        tup = (tcopy, t1, 0, ps["strict"], ps["fails"], ps["thr"], ps["place"], None, g["errorRateGlobal"],
-               g["mutMatrixGlobal"], g["errorRates"], g["mutMatrices"], g["cumulativeRate"], g["cumulativeErrorRate"])
-        sys.setprofile(prof)
-        try:
-            with contextlib.redirect_stdout(io.StringIO()):
-                moves = g["startTopologyUpdatesParallel"](tup)
-        finally:
-            sys.setprofile(None)
+        # The reference shortens genome lists of the tree in place while it searches (M:7087), which makes a
+        # query's float results depend (at the 1e-9 level, enough to flip exact ties) on the queries before it.
+        # Frozen-tree semantics: every pruned node is searched on its own pristine copy of the tree.
+        for v in range(len(tree.up)):
+            tcopy = copy.deepcopy(tree)
+            for i in range(len(tcopy.dirty)):
+                tcopy.dirty[i] = (i == v)
+            tup = (tcopy, t1, 0, ps["strict"], ps["fails"], ps["thr"], ps["place"], None, g["errorRateGlobal"],
+                   g["mutMatrixGlobal"], g["errorRates"], g["mutMatrices"], g["cumulativeRate"],
+                   g["cumulativeErrorRate"])
+            sys.setprofile(prof)
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    moves.extend(g["startTopologyUpdatesParallel"](tup))
+            finally:
+                sys.setprofile(None)
         spr.append(dict(params=ps, calls=calls, proposedMoves=[list(m) for m in moves]))
         print(f"[{name}] SPR params {ps}: {len(calls)} searches, {len(moves)} proposed moves, "
               f"{sum(c['n_append'] for c in calls)} appendProbNode calls", flush=True)
 
     # ---- a12: placement searches for new samples on the frozen tree ----
     rng = random.Random(123)
-    data = g["data"] if "data" in g else None
-    if data is None:
-        data = g["readConciseAlignment"](inp, extractReference=False, ref=g["ref"])
+    from maple_amd.host import read_maple_file
+    _, data = read_maple_file(inp)
     names = sorted(data)
     placements = []
     for k in range(60):

@@ -1,0 +1,135 @@
+"""CPU-side checks: the C ABI library loads and exports every symbol include/maple_hip.h declares, fails
+loudly without a GPU, and the host logic (packing, MAPLE-format reader, tip lists, sharding) is right."""
+import ctypes as C
+import gzip
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN, fixture_names, load, tup
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "maple_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(maple_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from maple_amd import runtime
+    lib = runtime.load_library()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/maple_hip.h but not exported"
+    assert set(runtime.EXPORTS) <= set(names)
+    assert lib.maple_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from maple_amd.runtime import Device, MapleError
+    with pytest.raises(MapleError):
+        Device(np.zeros(100, dtype=np.uint8), [0.25] * 4)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "maple_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("C oracle", ""), os.path.join(dirpath, f)
+
+
+@pytest.mark.parametrize("name", fixture_names())
+def test_pack_unpack_roundtrip(name):
+    from maple_amd.genome_list import pack_lists, unpack_lists
+    f = load(name)
+    for u in (False, True):
+        lists = []
+        for rec in f["calls"]["appendProbNode"]:
+            if f["models"][rec["model"]]["usingErrorRate"] == u:
+                lists += [tup(rec["P"]), tup(rec["C"])]
+        for rec in f["calls"]["mergeVectors"]:
+            if f["models"][rec["model"]]["usingErrorRate"] == u and not rec.get("raised"):
+                r = rec["ret"][0] if rec["returnLK"] else rec["ret"]
+                if r is not None:
+                    lists.append(tup(r))
+        if not lists:
+            continue
+        pl = pack_lists(lists, u)
+        back = unpack_lists(pl, u)
+        assert len(back) == len(lists)
+        for a, b in zip(back, lists):
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                assert len(x) == len(y) and x[0] == y[0] and x[1] == y[1]
+                assert list(x[2:-1]) == list(y[2:-1]) if x[0] == 6 else tuple(x[2:]) == tuple(y[2:])
+                if x[0] == 6:
+                    assert list(x[-1]) == list(y[-1])
+        # positions are explicit and increasing inside every list
+        for i in range(len(pl)):
+            p = pl.pos[pl.ent_off[i]:pl.ent_off[i + 1]]
+            assert (np.diff(p) > 0).all() and p[-1] == len(f["context"]["ref"])
+
+
+def _search_fixtures():
+    return sorted(f for f in os.listdir(GOLDEN) if f.startswith("search_"))
+
+
+@pytest.mark.parametrize("fname", _search_fixtures())
+def test_tip_lists_and_reader_match_reference(fname):
+    from maple_amd.host import read_maple_file, reference_tables, tip_genome_list
+    with gzip.open(os.path.join(GOLDEN, fname), "rt") as fh:
+        f = json.load(fh)
+    ref, data = read_maple_file(os.path.join(GOLDEN, "synth_small.maple.txt"))
+    assert ref == f["context"]["ref"] and len(data) == 160
+    ref_idx, root_freqs = reference_tables(ref)
+    assert root_freqs == f["context"]["rootFreqs"]
+    m = f["model"]
+    for rec in f["placements"]:
+        diffs = [tuple(e) for e in rec["diffs"]]
+        kw = {}
+        if m["usingErrorRate"]:
+            kw = dict(error_rates=m["errorRates"]) if m["errorRateSiteSpecific"] else dict(error_rate=m["errorRateGlobal"])
+        got = tip_genome_list(diffs, ref_idx, **kw)
+        want = tup(rec["query"])
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert a[0] == b[0] and a[1] == b[1] and len(a) == len(b)
+            if a[0] == 6 and not m["usingErrorRate"]:
+                # With the error model on, the reference's ambiguity vectors depend on hidden mutable state:
+                # updateProbVectTerminalNode (M:3966-4008) edits the shared `ambiguities` table in place, so what
+                # probVectTerminalNode returns afterwards depends on the last site it was called for.
+                assert list(a[-1]) == list(b[-1])
+
+
+@pytest.mark.parametrize("fname", _search_fixtures())
+def test_sharding_covers_every_node_once(fname):
+    from maple_amd.parallel import shard_nodes
+    from maple_amd.tree_host import HostTree
+    with gzip.open(os.path.join(GOLDEN, fname), "rt") as fh:
+        t = json.load(fh)["tree"]
+    tree = HostTree(t["root"], t["up"], t["children"], t["dist"], t["mutations"], t["nMinor"], t["probVect"],
+                    t["probVectUpRight"], t["probVectUpLeft"], t["probVectTotUp"])
+    reachable = sorted(tree.preorder())       # tree surgery leaves unused node slots behind
+    for world in (1, 2, 8):
+        shards = [shard_nodes(tree, r, world) for r in range(world)]
+        flat = sorted(v for s in shards for v in s)
+        assert flat == reachable
+        assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    # pre-order with child 0 first (assignCoreNumbers) vs the worker's pop order (child 1 first)
+    core = tree.assign_core_numbers(tree.n + 5)
+    assert core[tree.root] == 0 and sorted(c for c in core if c is not None) == list(range(len(reachable)))
+    if tree.children[tree.root]:
+        assert core[tree.children[tree.root][0]] == 1
+        assert tree.preorder()[1] == tree.children[tree.root][1]
