@@ -170,6 +170,11 @@ int maple_spr_search_batch(maple_ctx *ctx, int32_t n, const int32_t *nodes, cons
                            int32_t *placement, double *improvement, double *currentLK, int32_t *nAppend,
                            int32_t *status, int32_t *outRprList);
 
+/* Debugging aid: record the visit sequence of query index `query` of the next maple_spr_search_batch
+ * (per visited item: t1, direction, needsUpdating, failedPasses | lastLK, midProb); -1 switches it off. */
+int maple_debug_trace_query(maple_ctx *ctx, int32_t query);
+int maple_debug_trace_read(maple_ctx *ctx, int32_t *n, int32_t *items4 /*[4*4096]*/, double *vals2 /*[2*4096]*/);
+
 /* ---- device-resident forms (inputs already in HBM; asynchronous on `stream`) --- */
 int maple_append_batch_dev(maple_ctx *ctx, int32_t n, const int32_t *parentList_dev, const int32_t *childList_dev,
                            const uint8_t *isTipC_dev, const double *bLen_dev, double *outLK_dev, void *stream);

@@ -84,6 +84,9 @@ struct maple_ctx {
     DevBuf<uint8_t> s_search_ws;
     DevBuf<uint8_t> s_search_out;
     DevBuf<int32_t> s_counter;
+    int trace_query = -1;
+    DevBuf<int32_t> s_trace_i;
+    DevBuf<double> s_trace_d;
 };
 
 static int fail(maple_ctx *c, int code, const char *fmt, ...)
@@ -370,7 +373,8 @@ template <bool RV, bool U, bool SS>
 __global__ __launch_bounds__(64) void k_spr_search(DevModel m, ArenaView av, MutView mv, DevTree T, SearchParams P, int n,
                                                    const int32_t *nodes, WsLayout L, LaneBytes LB, uint8_t *wsBase,
                                                    int32_t *counter, SearchOut *out, uint2 *poolW, double *poolA,
-                                                   unsigned long long *poolUsed, long long poolCapW, long long poolCapA)
+                                                   unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
+                                                   int traceQuery, int32_t *trI, double *trD, int trCap, int32_t *trN)
 {
     __shared__ Lds lds;
     stage_model(m, lds);
@@ -412,6 +416,8 @@ __global__ __launch_bounds__(64) void k_spr_search(DevModel m, ArenaView av, Mut
             o.currentLK = curLK;
             if (!(curLK < P.thrPlacement || T.dist[node] != 0.0)) { o.status = 2; continue; }   // M:9674
             ws.usedW = ws.usedA = ws.nH = 0;
+            S.trI = nullptr;
+            if (q == traceQuery && trI) { S.trI = trI; S.trD = trD; S.trCap = trCap; S.trN = 0; }
             S.begin(parent, childIdx, curLK, T.dist[node]);
             active = true;
         } else if (ws.overflow) {
@@ -431,6 +437,7 @@ __global__ __launch_bounds__(64) void k_spr_search(DevModel m, ArenaView av, Mut
             o.bestNode = S.bestNode; o.bestScore = S.bestScore;
             o.blen[0] = S.bl0; o.blen[1] = S.bl1; o.blen[2] = S.bl2;
             o.nAppend = S.nAppend;
+            if (S.trI) *trN = S.trN;
             if (poolW) {                                             // hand bestRemovedPartials out through the pool
                 TList rp = S.L(S.hBestRpr);
                 long long ow = (long long)atomicAdd(&poolUsed[0], (unsigned long long)rp.n);
@@ -1260,7 +1267,9 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         HIPCK(c, hipEventRecord(e0, c->stream));
         DISPATCH3(c, k_spr_search, <<<lanes / 64, 64, 0, c->stream>>>(c->dm, view(c), mview(c), c->dtree, P, m, c->s_i32[0].p,
                                                                      L, LB, c->s_search_ws.p, c->s_counter.p, dout, poolW,
-                                                                     poolA, poolUsed, poolCapW, poolCapA));
+                                                                     poolA, poolUsed, poolCapW, poolCapA,
+                                                                     attempt == 0 ? c->trace_query : -1, c->s_trace_i.p,
+                                                                     c->s_trace_d.p, 4096, c->s_trace_i.p ? c->s_trace_i.p + 4 * 4096 : nullptr));
         HIPCK(c, hipGetLastError());
         HIPCK(c, hipEventRecord(e1, c->stream));
         std::vector<SearchOut> part(m);
@@ -1292,6 +1301,28 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         HIPCK(c, hipStreamSynchronize(c->stream));
         TRY(commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outRprList));
     }
+    return MAPLE_OK;
+}
+
+// debugging aid: record the visit sequence (t1, direction, needsUpdating, failedPasses, lastLK, midProb) of one query
+extern "C" int maple_debug_trace_query(maple_ctx *c, int32_t query)
+{
+    if (!c) return MAPLE_ERR_ARG;
+    c->trace_query = query;
+    if (query >= 0) {
+        HIPCK(c, c->s_trace_i.reserve(4 * 4096 + 4));
+        HIPCK(c, c->s_trace_d.reserve(2 * 4096));
+        HIPCK(c, hipMemset(c->s_trace_i.p, 0, (4 * 4096 + 4) * sizeof(int32_t)));
+    }
+    return MAPLE_OK;
+}
+
+extern "C" int maple_debug_trace_read(maple_ctx *c, int32_t *n, int32_t *items4, double *vals2)
+{
+    if (!c || !n || !items4 || !vals2 || !c->s_trace_i.p) return MAPLE_ERR_ARG;
+    HIPCK(c, hipMemcpy(n, c->s_trace_i.p + 4 * 4096, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(items4, c->s_trace_i.p, 4 * 4096 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(vals2, c->s_trace_d.p, 2 * 4096 * sizeof(double), hipMemcpyDeviceToHost));
     return MAPLE_OK;
 }
 

@@ -99,6 +99,15 @@ template <bool RV, bool U, bool SS> struct Search {
     const SearchParams &P;
     LaneWs &ws;
     int nAppend;
+    // optional visit trace of ONE query (debugging / parity of the visit sequence)
+    int32_t *trI = nullptr; double *trD = nullptr; int trN = 0, trCap = 0;
+    __device__ inline void trace(int t1, int dir, int upd, int fails, double lastLK, double midProb)
+    {
+        if (!trI || trN >= trCap) return;
+        trI[4 * trN] = t1; trI[4 * trN + 1] = dir; trI[4 * trN + 2] = upd; trI[4 * trN + 3] = fails;
+        trD[2 * trN] = lastLK; trD[2 * trN + 1] = midProb;
+        trN++;
+    }
 
     __device__ Search(const CT &c_, const ArenaViewS &av_, const MutViewS &mv_, const DevTree &T_, const SearchParams &P_, LaneWs &ws_)
         : c(c_), av(av_), mv(mv_), T(T_), P(P_), ws(ws_), nAppend(0) {}
@@ -297,6 +306,7 @@ template <bool RV, bool U, bool SS> struct Search {
                 if (midProb > bestLKdiff) { bestLKdiff = midProb; fails = 0; opShortenInPlace(hRpr); }
                 else if (midProb < (it.lastLK - P.thrConsec)) fails++;
             } else midProb = it.lastLK;
+            trace(t1, 0, upd, fails, it.lastLK, midProb);
             bool go;
             if (P.strict) go = fails <= P.allowedFails && midProb > (bestLKdiff - P.thrLKtopology) && T.c0[t1] >= 0;
             else go = (fails <= P.allowedFails || midProb > (bestLKdiff - P.thrLKtopology)) && T.c0[t1] >= 0;
@@ -329,7 +339,10 @@ template <bool RV, bool U, bool SS> struct Search {
                     vectUp = opPass(treeList(upVectOf(t1)), T.mutId[t1], false);
                     midTot = opMerge(vectUp, T.dist[t1] / 2, false, midBottom, T.dist[t1] / 2, false, true);
                     if (midTot < 0) return;
-                    if (!opDiffer(midTot, treeList(T.totUp[t1]))) upd = false;
+                    int cached = treeList(T.totUp[t1]);
+                    if (!valid(cached))                               // "Node has no probVectTotUp ... calculating new one", M:7198-7200
+                        cached = opMerge(vectUp, T.dist[t1] / 2, false, treeList(T.lower[t1]), T.dist[t1] / 2, false, true);
+                    if (!opDiffer(midTot, cached)) upd = false;
                 } else midTot = treeList(T.totUp[t1]);
                 if (!valid(midTot)) return;
                 midProb = opAppend(midTot, hRpr, isRemovedTip, removedBLen);
@@ -340,6 +353,7 @@ template <bool RV, bool U, bool SS> struct Search {
                 if (midProb > bestLKdiff) { bestLKdiff = midProb; fails = 0; }
                 else if (midProb < (it.lastLK - P.thrConsec)) fails++;
             } else midProb = it.lastLK;
+            trace(t1, it.dir, upd, fails, it.lastLK, midProb);
             bool go;
             if (P.strict) go = fails <= P.allowedFails && midProb > (bestLKdiff - P.thrLKtopology);
             else go = fails <= P.allowedFails || midProb > (bestLKdiff - P.thrLKtopology);

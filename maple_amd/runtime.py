@@ -22,7 +22,7 @@ EXPORTS = [
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
     "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_query_dev", "maple_timing_reset", "maple_timing_read",
-    "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch",
+    "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_debug_trace_query", "maple_debug_trace_read",
 ]
 
 
@@ -311,6 +311,17 @@ class Device:
         if want_removed_partials:
             out["removedPartials"] = rpr
         return out
+
+    def debug_trace_query(self, q):
+        self._ck(self.lib.maple_debug_trace_query(self.h, int(q)))
+
+    def debug_trace_read(self):
+        n = C.c_int32()
+        it = np.zeros(4 * 4096, dtype=np.int32)
+        va = np.zeros(2 * 4096, dtype=np.float64)
+        self._ck(self.lib.maple_debug_trace_read(self.h, C.byref(n), _ptr(it), _ptr(va)))
+        k = min(n.value, 4096)
+        return it[: 4 * k].reshape(k, 4), va[: 2 * k].reshape(k, 2)
 
     # -- device-resident forms (pointers into HBM, e.g. torch tensors' data_ptr()) ------------------
     def append_batch_dev(self, n, parent_ptr, child_ptr, tip_ptr, blen_ptr, out_ptr, stream=0):
