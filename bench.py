@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--queries", type=int, default=256, help="query genome lists per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate host time spent on cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-spr", action="store_true", help="skip the secondary SPR-search-round measurement")
+    ap.add_argument("--pairs", action="store_true", help="experiment: explicit (parent, child) index arrays, untiled kernel")
+    ap.add_argument("--sort", action="store_true", help="experiment: order candidates by list length")
     args = ap.parse_args()
 
     import torch
@@ -75,7 +78,7 @@ def main():
     tip_lists = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
     mirror = TreeMirror(dev, data.parent, data.blen, tip_lists).build()
     l_ref = dev.lRef
-    cand_nodes = mirror.candidate_nodes(1.0 / (10 * l_ref))
+    cand_nodes = mirror.candidates_by_length(1.0 / (10 * l_ref)) if args.sort else mirror.candidate_nodes(1.0 / (10 * l_ref))
     cand_lists = mirror.tot_up[cand_nodes]
     # queries of this rank: samples rank, rank+world, ... (round-robin like coreNum, M:12164-12195)
     q_nodes = np.asarray(data.tip_node[rank::world][: args.queries], dtype=np.int64)
@@ -89,18 +92,25 @@ def main():
     q_ne, q_na = dev.sizes(q_lists)
     alg_bytes = dev.append_algorithmic_bytes(parent_ids) + 8 * int(q_ne.sum() + q_na.sum())
     cu = torch.device("cuda", local_rank)
-    t_parent = torch.from_numpy(parent_ids).to(cu)
-    t_child = torch.from_numpy(child_ids).to(cu)
-    t_tip = torch.ones(n_pairs, dtype=torch.uint8, device=cu)
-    t_blen = torch.full((n_pairs,), 1.0 / l_ref, dtype=torch.float64, device=cu)
+    t_q = torch.from_numpy(q_lists.astype(np.int32)).to(cu)
+    t_c = torch.from_numpy(cand_lists.astype(np.int32)).to(cu)
     t_out = torch.empty(n_pairs, dtype=torch.float64, device=cu)
     t_cand_nodes = torch.from_numpy(cand_nodes.astype(np.int64)).to(cu)
     stream = torch.cuda.current_stream().cuda_stream
     setup_s = time.time() - t_setup
 
+    if args.pairs:
+        t_parent = torch.from_numpy(parent_ids).to(cu)
+        t_child = torch.from_numpy(child_ids).to(cu)
+        t_tip = torch.ones(n_pairs, dtype=torch.uint8, device=cu)
+        t_blen = torch.full((n_pairs,), 1.0 / l_ref, dtype=torch.float64, device=cu)
+
     def step():
-        dev.append_batch_dev(n_pairs, t_parent.data_ptr(), t_child.data_ptr(), t_tip.data_ptr(), t_blen.data_ptr(),
-                             t_out.data_ptr(), stream)
+        if args.pairs:
+            dev.append_batch_dev(n_pairs, t_parent.data_ptr(), t_child.data_ptr(), t_tip.data_ptr(), t_blen.data_ptr(),
+                                 t_out.data_ptr(), stream)
+        else:
+            dev.append_queries_dev(Q, t_q.data_ptr(), Cn, t_c.data_ptr(), True, 1.0 / l_ref, t_out.data_ptr(), stream)
         best_score, best_idx = t_out.view(Q, Cn).max(dim=1)
         rec = torch.stack([best_score, t_cand_nodes[best_idx].to(torch.float64)], dim=1)
         if distd is not None:
@@ -135,6 +145,35 @@ def main():
     else:
         total_pairs = float(n_pairs)
 
+    # ---- secondary measurement: one device-resident SPR search round (findBestParentTopology for every node
+    # of this rank's shard, M:9580-9716), reported next to the headline, never mixed into it ----
+    spr = None
+    if not args.no_spr:
+        import math
+        log_lref = math.log(l_ref)
+        nodes_all = np.arange(mirror.n_nodes)
+        my_nodes = nodes_all[rank::world]
+        dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist,
+                        mirror.is_tip, mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up,
+                        -np.ones(mirror.n_nodes, dtype=np.int32))
+        kw = dict(strict=False, allowedFails=4, thresholdLogLKtopology=14.0 * log_lref, thresholdTopologyPlacement=-0.1,
+                  thresholdLogLKoptimizationTopology=1.0 * log_lref, thresholdLogLKconsecutivePlacement=1.0,
+                  effectivelyNon0BLen=1.0 / (10 * l_ref))
+        dev.spr_search_batch(my_nodes[:256], **kw)                      # warm-up
+        dev.timing_reset()
+        t0 = time.perf_counter()
+        res = dev.spr_search_batch(my_nodes, **kw)
+        wall = time.perf_counter() - t0
+        n_l, k_ms_spr = dev.timing_read()
+        st = res["status"]
+        spr = {"queries": int(len(my_nodes)), "searched": int((st == 0).sum()), "not_searched": int((st > 0).sum()),
+               "failed_or_overflow": int((st < 0).sum()), "candidate_placements": int(res["nAppend"].sum()),
+               "proposed_moves": int((res["placement"] >= 0).sum()), "kernel_ms": k_ms_spr, "launches": n_l,
+               "wall_ms": 1e3 * wall,
+               "placements_per_s_kernel": float(res["nAppend"].sum() / (k_ms_spr * 1e-3)) if k_ms_spr else None,
+               "placements_per_s_wall": float(res["nAppend"].sum() / wall),
+               "params": "deep round: non-strict, allowedFailsTopology 4, thresholdLogLKtopology 14 log(lRef)"}
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_pairs * args.steps / elapsed
@@ -150,10 +189,12 @@ def main():
                        "pairs_per_step_per_gpu": int(n_pairs), "tree_nodes": int(mirror.n_nodes),
                        "parallelism": f"queries sharded round-robin over {world} GPU(s), tree mirror replicated",
                        "setup_s": round(setup_s, 1)},
-            "roofline": {"bound": "hbm", "kernel": "k_append", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_append_queries", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": k_ms, "launches_timed": n_launch},
         }
+        if spr is not None:
+            out["spr_search"] = spr
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs,
                                                args.cpu_seconds, t_out)

@@ -178,10 +178,10 @@ int maple_debug_trace_read(maple_ctx *ctx, int32_t *n, int32_t *items4 /*[4*4096
 /* ---- device-resident forms (inputs already in HBM; asynchronous on `stream`) --- */
 int maple_append_batch_dev(maple_ctx *ctx, int32_t n, const int32_t *parentList_dev, const int32_t *childList_dev,
                            const uint8_t *isTipC_dev, const double *bLen_dev, double *outLK_dev, void *stream);
-/* One query against many candidates (the placement loop, M:8050): the child list is staged
- * once per workgroup in LDS.  cand_dev holds n parent-side list ids. */
-int maple_append_query_dev(maple_ctx *ctx, int32_t n, int32_t childList, int isTipC, double bLen,
-                           const int32_t *cand_dev, double *outLK_dev, void *stream);
+/* Q queries x C candidates (the placement loop, M:8050, and the cached regime of the SPR search, M:6993-7011):
+ * out_dev[q*C + k] = appendProbNode(list cand[k], list qList[q], isTipC, bLen); one lane per pair, no index arrays. */
+int maple_append_queries_dev(maple_ctx *ctx, int32_t nQ, const int32_t *qList_dev, int32_t nC, const int32_t *cand_dev,
+                             int isTipC, double bLen, double *out_dev, void *stream);
 /* Every *_dev launch is bracketed by a pair of HIP events recorded on the launch's own stream.
  * maple_timing_read sums the elapsed time of all launches since the last maple_timing_reset. */
 int maple_timing_reset(maple_ctx *ctx);

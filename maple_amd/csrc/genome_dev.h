@@ -186,114 +186,186 @@ __device__ inline double fmin_py(double a, double b) { return (b < a) ? b : a; }
 __device__ inline double sel4(const double *v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
 
 // ---- appendProbNode (M:6505-6785) -----------------------------------------------------
+// decode one packed word (+ its aux doubles) into the Ent view
+__device__ __forceinline__ void decode_word(unsigned long long w, const double *aux, Ent &e)
+{
+    const uint32_t meta = (uint32_t)(w >> 32);
+    e.pos = (int)(uint32_t)w;
+    e.type = meta & 7u;
+    e.ref = (meta >> 3) & 3u;
+    e.hasD0 = meta & (1u << 5);
+    e.hasD1 = meta & (1u << 6);
+    e.flag = meta & (1u << 7);
+    const double *a = aux + (meta >> 8);
+    e.d0 = 0.0; e.d1 = 0.0;
+    if (e.hasD0) { e.d0 = *a++; }
+    if (e.hasD1) { e.d1 = *a++; }
+    e.vec = a;
+}
+
+// Contribution of ONE site whose entries involve an O vector or an observation beyond the root (e1 = parent side,
+// e2 = child side; neither is N, they are not both R).  Returns 0 and the factor in *f, or 1 when the reference
+// returns -inf (zero-length mismatch).  Always inlined: a call would force the entry views through scratch memory.
 template <bool RV, bool U, bool SS>
-__device__ double append_walk(const Ctx<RV, U, SS> &c, ListRef P, ListRef Cl, bool isTipC, double bLen)
+__device__ __forceinline__ int site_factor(const Ctx<RV, U, SS> &c, const Ent &e1, const Ent &e2, int site, bool isTipC,
+                                           double bLen, double *fOut)
 {
     typedef Ctx<RV, U, SS> CT;
-    const int lRef = c.m.lRef;
     const double *rf = c.rf;
-    Cursor a, b;                       // a = parent side, b = child side
-    a.init(P); b.init(Cl);
-    int pos = 0;
-    double totalFactor = 1.0;
-    double Lk = bLen * c.m.globalTotRate;
-    if (U && isTipC) Lk += c.m.totError;
-    for (;;) {
-        const Ent &e1 = a.e, &e2 = b.e;
-        double f = 1.0;                // multiplicative contribution of this step
-        bool mult = false;
-        if (e2.type == 5 || e1.type == 5) {
-            // N on either side contributes nothing (M:6545-6582)
-            bool run1 = (e1.type == 4 || e1.type == 5), run2 = (e2.type == 4 || e2.type == 5);
-            pos = (run1 && run2) ? min(e1.pos, e2.pos) : pos + 1;
-        } else if (e1.type == 4 && e2.type == 4) {
-            pos = min(e1.pos, e2.pos);                                  // M:6602-6608
-        } else {
-            const int site = pos;      // 0-based index of the site being scored
-            pos += 1;
-            if (e1.type != e2.type || e1.type == 6) {
-                double cl = bLen;                                       // M:6586-6599
-                if (e1.type < 5) { if (e1.hasD1) cl += e1.d1; else if (e1.hasD0) cl += e1.d0; }
-                else if (e1.hasD0) cl += e1.d0;
-                if (e2.type < 5) { if (e2.hasD0 && !e2.hasD1) cl += e2.d0; }
-                else if (e2.hasD0) cl += e2.d0;
-                const double r = c.rate(site);
-                const bool flag1 = U && e1.type < 5 && e1.hasD0 && e1.flag;
-                const bool flag2 = U && e2.type < 5 && (isTipC || (e2.hasD0 && e2.flag));
-                mult = true;
-                if (e1.type == 6 && e2.type == 6) {                     // M:6677-6686
-                    double t3[4];
-                    gpv_vec(c, r, e2.vec, cl, false, t3);
-                    double tot = 0.0;
-                    for (int j = 0; j < 4; j++) tot += e1.vec[j] * t3[j];
-                    f = tot;
-                } else if (e1.type == 6) {                              // O over nucleotide/R, M:6687-6703
-                    int i2 = (e2.type == 4) ? e1.ref : e2.type;
-                    double p = e1.vec[i2];
-                    if (p > 0.02) f = p;
-                    else {
-                        double t3[4];
-                        gpv_nuc<CT, U>(c, r, i2, cl, flag2 ? c.err(site) : 0.0, false, flag2, t3);
-                        double tot = 0.0;
-                        for (int j = 0; j < 4; j++) tot += e1.vec[j] * t3[j];
-                        f = tot;
-                    }
-                } else if (e2.type == 6) {                              // nucleotide/R over O, M:6611-6633, 6744-6761
-                    int i1 = (e1.type == 4) ? e2.ref : e1.type;
-                    double p = e2.vec[i1];
-                    if (p > 0.02) f = p;
-                    else if (e1.hasD1) {
-                        double t2[4], t3[4];
-                        gpv_vec(c, r, e2.vec, cl, false, t3);
-                        gpv_nuc<CT, U>(c, r, i1, e1.d0, c.err(site), false, flag1, t2);
-                        double tot = 0.0;
-                        if (e1.type == 4) { for (int i = 0; i < 4; i++) tot += t3[i] * t2[i] * rf[i]; }
-                        else { for (int i = 0; i < 4; i++) tot += t2[i] * t3[i] * rf[i]; }
-                        f = tot / rf[i1];
-                    } else if (cl != 0.0) {
-                        double t3[4];
-                        gpv_vec(c, r, e2.vec, cl, false, t3);
-                        f = sel4(t3, i1);
-                    } else f = p;
-                } else {                                                // two different nucleotides (R counts as the reference one)
-                    int i1 = (e1.type == 4) ? e2.ref : e1.type;         // M:6640-6668, 6713-6742
-                    int i2 = (e2.type == 4) ? e1.ref : e2.type;
-                    if (e1.hasD1) {
-                        double t2[4], t3[4];
-                        double er = c.err(site);
-                        gpv_nuc<CT, U>(c, r, i2, cl, er, false, flag2, t3);
-                        gpv_nuc<CT, U>(c, r, i1, e1.d0, er, false, flag1, t2);
-                        double tot = 0.0;
-                        if (e1.type == 4) { for (int i = 0; i < 4; i++) tot += t3[i] * t2[i] * rf[i]; }
-                        else { for (int j = 0; j < 4; j++) tot += rf[j] * t3[j] * t2[j]; }
-                        f = tot / rf[i1];
-                    } else {
-                        double qv = c.q(r, i1, i2);
-                        if (e1.type == 4) {
-                            if (flag2) f = fmin_py(0.25, qv * cl) + c.err(site) * 0.33333;
-                            else if (cl != 0.0) f = fmin_py(0.25, qv * cl);
-                            else return -INFINITY;
-                        } else {
-                            if (flag1 || flag2)
-                                f = fmin_py(0.25, qv * cl) + (double)((int)flag1 + (int)flag2) * 0.33333 * c.err(site);
-                            else if (cl != 0.0) f = fmin_py(0.25, qv * cl);
-                            else return -INFINITY;
-                        }
-                    }
-                }
+    double cl = bLen;                                                   // M:6586-6599
+    if (e1.type < 5) { if (e1.hasD1) cl += e1.d1; else if (e1.hasD0) cl += e1.d0; }
+    else if (e1.hasD0) cl += e1.d0;
+    if (e2.type < 5) { if (e2.hasD0 && !e2.hasD1) cl += e2.d0; }
+    else if (e2.hasD0) cl += e2.d0;
+    const double r = c.rate(site);
+    const bool flag1 = U && e1.type < 5 && e1.hasD0 && e1.flag;
+    const bool flag2 = U && e2.type < 5 && (isTipC || (e2.hasD0 && e2.flag));
+    double f;
+    if (e1.type == 6 && e2.type == 6) {                                 // M:6677-6686
+        double t3[4];
+        gpv_vec(c, r, e2.vec, cl, false, t3);
+        double tot = 0.0;
+        for (int j = 0; j < 4; j++) tot += e1.vec[j] * t3[j];
+        f = tot;
+    } else if (e1.type == 6) {                                          // O over nucleotide/R, M:6687-6703
+        int i2 = (e2.type == 4) ? e1.ref : e2.type;
+        double p = e1.vec[i2];
+        if (p > 0.02) f = p;
+        else {
+            double t3[4];
+            gpv_nuc<CT, U>(c, r, i2, cl, flag2 ? c.err(site) : 0.0, false, flag2, t3);
+            double tot = 0.0;
+            for (int j = 0; j < 4; j++) tot += e1.vec[j] * t3[j];
+            f = tot;
+        }
+    } else if (e2.type == 6) {                                          // nucleotide/R over O, M:6611-6633, 6744-6761
+        int i1 = (e1.type == 4) ? e2.ref : e1.type;
+        double p = e2.vec[i1];
+        if (p > 0.02) f = p;
+        else if (e1.hasD1) {
+            double t2[4], t3[4];
+            gpv_vec(c, r, e2.vec, cl, false, t3);
+            gpv_nuc<CT, U>(c, r, i1, e1.d0, c.err(site), false, flag1, t2);
+            double tot = 0.0;
+            if (e1.type == 4) { for (int i = 0; i < 4; i++) tot += t3[i] * t2[i] * rf[i]; }
+            else { for (int i = 0; i < 4; i++) tot += t2[i] * t3[i] * rf[i]; }
+            f = tot / rf[i1];
+        } else if (cl != 0.0) {
+            double t3[4];
+            gpv_vec(c, r, e2.vec, cl, false, t3);
+            f = sel4(t3, i1);
+        } else f = p;
+    } else {                                                            // two nucleotides, observation beyond the root on the
+        int i1 = (e1.type == 4) ? e2.ref : e1.type;                     // parent side (M:6644-6654, 6726-6733)
+        int i2 = (e2.type == 4) ? e1.ref : e2.type;
+        double t2[4], t3[4];
+        double er = c.err(site);
+        gpv_nuc<CT, U>(c, r, i2, cl, er, false, flag2, t3);
+        gpv_nuc<CT, U>(c, r, i1, e1.d0, er, false, flag1, t2);
+        double tot = 0.0;
+        if (e1.type == 4) { for (int i = 0; i < 4; i++) tot += t3[i] * t2[i] * rf[i]; }
+        else { for (int j = 0; j < 4; j++) tot += rf[j] * t3[j] * t2[j]; }
+        f = tot / rf[i1];
+    }
+    *fOut = f;
+    return 0;
+}
+
+// The walk is a small state machine (start / step / finish): one lane, factors multiplied in genome order exactly
+// like the reference, so the result is bit-for-bit that of the CPU restatement (apart from log()).
+// Every entry carries its last position, so the end of the current segment is min(end1, end2) for every type pair,
+// and "advance the cursor whose entry ends here" is the reference's stepping rule (M:6545-6770) in one line.
+template <bool RV, bool U, bool SS> struct PairWalk {
+    typedef Ctx<RV, U, SS> CT;
+    const CT &c;
+    ListRef Cl;                        // child list
+    const unsigned long long *cw;
+    bool isTipC; double bLen;
+    ListRef P;                         // parent list
+    const unsigned long long *pw;
+    unsigned long long wa, wb;         // current words: low half = pos, high half = meta
+    int ia, ib;
+    double tf, Lk;
+    bool dead;
+    int lRef; double carry;            // hot scalars of the model kept in registers
+
+    __device__ PairWalk(const CT &c_, ListRef Cl_, bool isTipC_, double bLen_)
+        : c(c_), Cl(Cl_), cw((const unsigned long long *)Cl_.w), isTipC(isTipC_), bLen(bLen_), lRef(c_.m.lRef),
+          carry(c_.m.minimumCarryOver) {}
+
+    __device__ inline void start(ListRef P_)
+    {
+        P = P_;
+        pw = (const unsigned long long *)P.w;
+        wa = pw[0]; wb = cw[0];
+        ia = ib = 0;
+        tf = 1.0;
+        Lk = bLen * c.m.globalTotRate;                                   // M:6541
+        if (U && isTipC) Lk += c.m.totError;                             // M:6542-6543
+        dead = false;
+    }
+
+    // one segment of the two-list walk; returns true when the end of the genome (or a dead end) is reached
+    __device__ inline bool step()
+    {
+        const int pa = (int)(uint32_t)wa, pb = (int)(uint32_t)wb;
+        const uint32_t m1 = (uint32_t)(wa >> 32), m2 = (uint32_t)(wb >> 32);
+        const int t1 = m1 & 7u, t2 = m2 & 7u;
+        const int pos = min(pa, pb);
+        // a site needs work unless N is involved, both sides are reference runs, or both show the same nucleotide
+        const bool work = (t1 != 5) & (t2 != 5) & !((t1 == 4) & (t2 == 4)) & !((t1 == t2) & (t1 < 4));
+        if (work) {
+            const int site = pos - 1;
+            if (t1 == 6 || t2 == 6 || (m1 & (1u << 6))) {               // O vector or observation beyond the root
+                Ent e1, e2;
+                decode_word(wa, P.aux, e1);
+                decode_word(wb, Cl.aux, e2);
+                double f;
+                if (site_factor(c, e1, e2, site, isTipC, bLen, &f) == 1) dead = true;
+                else tf *= f;
+            } else {                                                     // two different nucleotides (R = the reference one)
+                double cl = bLen;                                        // M:6640-6668, 6713-6742
+                if (m1 & (1u << 5)) cl += P.aux[m1 >> 8];
+                if ((m2 & (1u << 5)) && !(m2 & (1u << 6))) cl += Cl.aux[m2 >> 8];
+                const int i1 = (t1 == 4) ? (int)((m2 >> 3) & 3u) : t1;
+                const int i2 = (t2 == 4) ? (int)((m1 >> 3) & 3u) : t2;
+                const double qv = c.q(c.rate(site), i1, i2);
+                double f = fmin_py(0.25, qv * cl);
+                if (U) {
+                    const bool flag1 = (t1 != 4) && (m1 & (1u << 5)) && (m1 & (1u << 7));
+                    const bool flag2 = isTipC || ((m2 & (1u << 5)) && (m2 & (1u << 7)));
+                    if (t1 == 4) { if (flag2) f += c.err(site) * 0.33333; else if (cl == 0.0) dead = true; }
+                    else if (flag1 || flag2) f += (double)((int)flag1 + (int)flag2) * 0.33333 * c.err(site);
+                    else if (cl == 0.0) dead = true;
+                } else if (cl == 0.0) dead = true;                       // zero-length mismatch: -inf (M:6663, 6742)
+                tf *= f;
             }
         }
-        if (mult) totalFactor *= f;
-        if (pos == lRef) break;
-        if (totalFactor <= c.m.minimumCarryOver) {                      // M:6772-6783
-            if (totalFactor < 2.2250738585072014e-308) return -INFINITY;
-            Lk += log(totalFactor);
-            totalFactor = 1.0;
+        if (pos == lRef || dead) return true;
+        if (tf <= carry) {                                               // M:6772-6783
+            if (tf < 2.2250738585072014e-308) { dead = true; return true; }
+            Lk += log(tf);
+            tf = 1.0;
         }
-        a.step(pos);
-        b.step(pos);
+        if (pa == pos) { ++ia; wa = pw[ia]; }
+        if (pb == pos) { ++ib; wb = cw[ib]; }
+        return false;
     }
-    return (totalFactor > 0.0) ? Lk + log(totalFactor) : -INFINITY;
+
+    __device__ inline double finish() const
+    {
+        if (dead) return -INFINITY;
+        return (tf > 0.0) ? Lk + log(tf) : -INFINITY;
+    }
+};
+
+template <bool RV, bool U, bool SS>
+__device__ inline double append_walk(const Ctx<RV, U, SS> &c, ListRef P, ListRef Cl, bool isTipC, double bLen)
+{
+    PairWalk<RV, U, SS> w(c, Cl, isTipC, bLen);
+    w.start(P);
+    while (!w.step()) {}
+    return w.finish();
 }
 
 // ---- mergeVectors (M:4446-4859) -----------------------------------------------------------

@@ -46,6 +46,7 @@ struct maple_ctx {
     int32_t lRef = 0;
     std::vector<uint8_t> refIdx;
     DevModel dm{};                     // device pointers inside
+    DevModel *d_model = nullptr;       // the same struct in device memory: what the kernels read
     bool model_set = false;
     double *d_siteRates = nullptr, *d_errorRates = nullptr, *d_cumRate = nullptr, *d_cumErr = nullptr;
     std::vector<double> h_cumRate, h_cumErr;
@@ -120,47 +121,42 @@ __device__ inline ListRef list_ref(const ArenaView &a, int id)
 #define MAPLE_BLOCK 256
 
 // appendProbNode over arbitrary pairs ----------------------------------------------------------
+// 120 VGPRs / no scratch at 4 waves per SIMD measured fastest (5 waves spills, 3 waves loses latency hiding).
+#define MAPLE_APPEND_ATTR __launch_bounds__(MAPLE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(MAPLE_BLOCK) void k_append(DevModel m, ArenaView av, int n, const int32_t *pl,
-                                                        const int32_t *cl, const uint8_t *tip, const double *bl,
-                                                        double *out)
+__global__ MAPLE_APPEND_ATTR void k_append(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *pl,
+                                           const int32_t *cl, const uint8_t *tip, const double *bl, double *out)
 {
     __shared__ Lds lds;
+    const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         out[i] = append_walk(c, list_ref(av, pl[i]), list_ref(av, cl[i]), tip[i] != 0, bl[i]);
 }
 
-// one query (child list) against many candidates: the child list is staged in LDS once per workgroup
-#define MAPLE_QLDS_WORDS 1024
-#define MAPLE_QLDS_AUX 2048
+// Q queries x C candidates, query-major output out[q*C + k]: pair (q, k) is handled by one lane, a workgroup takes
+// 256 consecutive candidates of one query (so its 4 wavefronts read the same child list through L1) and there is
+// NO barrier anywhere: wavefronts of very different list lengths never wait for each other.  (Measured: staging the
+// query in LDS behind __syncthreads() was 1.4x slower; dealing candidate chunks to XCDs for L2 affinity made no
+// difference -- the lists that miss L2 are served by the 256 MiB Infinity Cache.)
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(MAPLE_BLOCK) void k_append_query(DevModel m, ArenaView av, int n, int childList,
-                                                              int isTip, double bLen, const int32_t *cand, double *out)
+__global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ mp, ArenaView av, int nQ,
+                                                   const int32_t *qList, int nC, const int32_t *cand, int isTip,
+                                                   double bLen, double *out)
 {
     __shared__ Lds lds;
-    __shared__ uint2 qw[MAPLE_QLDS_WORDS];
-    __shared__ double qa[MAPLE_QLDS_AUX];
-    const int ne = av.n_ent[childList];
-    const int64_t eo = av.ent_off[childList], ao = av.aux_off[childList];
-    // aux length of the child list = offset of the entry after the last one
-    bool fits = ne <= MAPLE_QLDS_WORDS;
-    int na = 0;
-    if (fits) {
-        uint2 lw = av.words[eo + ne - 1];
-        na = (int)(lw.y >> 8) + ((lw.y & (1u << 5)) ? 1 : 0) + ((lw.y & (1u << 6)) ? 1 : 0) + (((lw.y & 7u) == 6) ? 4 : 0);
-        fits = na <= MAPLE_QLDS_AUX;
-    }
-    if (fits) {
-        for (int k = threadIdx.x; k < ne; k += blockDim.x) qw[k] = av.words[eo + k];
-        for (int k = threadIdx.x; k < na; k += blockDim.x) qa[k] = av.aux[ao + k];
-    }
-    stage_model(m, lds);               // contains the __syncthreads()
+    const DevModel &m = *mp;
+    stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
-    ListRef q = fits ? ListRef{qw, qa} : list_ref(av, childList);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        out[i] = append_walk(c, list_ref(av, cand[i]), q, isTip != 0, bLen);
+    const int nChunks = (nC + MAPLE_BLOCK - 1) / MAPLE_BLOCK;
+    const int tiles = nQ * nChunks;
+    for (int j = blockIdx.x; j < tiles; j += gridDim.x) {
+        const int q = j / nChunks;
+        const int ci = (j - q * nChunks) * MAPLE_BLOCK + threadIdx.x;
+        if (ci < nC)
+            out[(long long)q * nC + ci] = append_walk(c, list_ref(av, cand[ci]), list_ref(av, qList[q]), isTip != 0, bLen);
+    }
 }
 
 // per-item scratch placement for list-producing kernels
@@ -174,12 +170,13 @@ struct OutSpec {
 };
 
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(MAPLE_BLOCK) void k_merge(DevModel m, ArenaView av, int n, const int32_t *l1,
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_merge(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *l1,
                                                        const double *b1, const uint8_t *t1, const int32_t *l2,
                                                        const double *b2, const uint8_t *t2, const uint8_t *ud,
                                                        const int32_t *nm1, const int32_t *nm2, OutSpec o, double *outLK)
 {
     __shared__ Lds lds;
+    const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -195,11 +192,12 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_merge(DevModel m, ArenaView av,
 }
 
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(MAPLE_BLOCK) void k_blen(DevModel m, ArenaView av, int n, const int32_t *pl,
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_blen(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *pl,
                                                       const int32_t *cl, const uint8_t *tip, double *ais,
                                                       const int64_t *aisOff, double *t, uint8_t *isFalse)
 {
     __shared__ Lds lds;
+    const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -210,10 +208,11 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_blen(DevModel m, ArenaView av, 
 }
 
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(MAPLE_BLOCK) void k_differ(DevModel m, ArenaView av, int n, const int32_t *l1,
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_differ(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *l1,
                                                         const int32_t *l2, uint8_t *out)
 {
     __shared__ Lds lds;
+    const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -241,9 +240,10 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_pass(int lRef, ArenaView av, Mu
 }
 
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(MAPLE_BLOCK) void k_shorten(DevModel m, ArenaView av, int n, const int32_t *l, OutSpec o)
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_shorten(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *l, OutSpec o)
 {
     __shared__ Lds lds;
+    const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -257,12 +257,13 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_shorten(DevModel m, ArenaView a
 // rootVector: frames up (node..root), root_walk, frames down (root..node), shorten.
 // Each item owns 3 scratch lists of `cap` entries: A, B (ping-pong) and the final output slot.
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(MAPLE_BLOCK) void k_root_vector(DevModel m, ArenaView av, MutView mv, int n,
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_root_vector(const DevModel *__restrict__ mp, ArenaView av, MutView mv, int n,
                                                              const int32_t *l, const double *bl, const uint8_t *tip,
                                                              const int64_t *pathOff, const int32_t *pathMut,
                                                              const int64_t *capOff, OutSpec o)
 {
     __shared__ Lds lds;
+    const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_root_vector(DevModel m, ArenaVi
 // evaluatePlacement (M:6790-6806): three branch-length solves around three merges, then one append.
 // Each item owns 3 scratch lists (capacities capA/capB/capC packed back to back) and an `ais` strip.
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(MAPLE_BLOCK) void k_evalplace(DevModel m, ArenaView av, int n, const int32_t *midTot,
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_evalplace(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *midTot,
                                                            const int32_t *down, const int32_t *up, const double *dist,
                                                            const int32_t *rem, const uint8_t *remTip,
                                                            const uint8_t *fromTip1, uint2 *sw, double *sa,
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_evalplace(DevModel m, ArenaView
                                                            double *out4, int32_t *status)
 {
     __shared__ Lds lds;
+    const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -370,13 +372,14 @@ static LaneBytes lane_bytes(const WsLayout &L)
 }
 
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(64) void k_spr_search(DevModel m, ArenaView av, MutView mv, DevTree T, SearchParams P, int n,
+__global__ __launch_bounds__(64) void k_spr_search(const DevModel *__restrict__ mp, ArenaView av, MutView mv, DevTree T, SearchParams P, int n,
                                                    const int32_t *nodes, WsLayout L, LaneBytes LB, uint8_t *wsBase,
                                                    int32_t *counter, SearchOut *out, uint2 *poolW, double *poolA,
                                                    unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
                                                    int traceQuery, int32_t *trI, double *trD, int trCap, int32_t *trN)
 {
     __shared__ Lds lds;
+    const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -549,7 +552,7 @@ extern "C" int maple_create(maple_ctx **out, int device, int32_t lRef, const uin
     c->cap_lists = c->cap_ent / 4 + 1024;
     c->cap_mut = c->cap_ent / 16 + 4096;
     c->cap_mut_lists = c->cap_lists / 4 + 1024;
-    bool ok = hipMalloc((void **)&c->d_words, c->cap_ent * sizeof(uint2)) == hipSuccess
+    bool ok = hipMalloc((void **)&c->d_words, (c->cap_ent + 64) * sizeof(uint2)) == hipSuccess
               && hipMalloc((void **)&c->d_aux, c->cap_aux * sizeof(double)) == hipSuccess
               && hipMalloc((void **)&c->d_ent_off, c->cap_lists * sizeof(int64_t)) == hipSuccess
               && hipMalloc((void **)&c->d_aux_off, c->cap_lists * sizeof(int64_t)) == hipSuccess
@@ -558,7 +561,8 @@ extern "C" int maple_create(maple_ctx **out, int device, int32_t lRef, const uin
               && hipMalloc((void **)&c->d_mut3, c->cap_mut * 3 * sizeof(int32_t)) == hipSuccess
               && hipMalloc((void **)&c->d_mut_off, c->cap_mut_lists * sizeof(int64_t)) == hipSuccess
               && hipMalloc((void **)&c->d_mut_cnt, c->cap_mut_lists * sizeof(int32_t)) == hipSuccess
-              && hipMalloc((void **)&c->d_cumRate, (lRef + 1) * sizeof(double)) == hipSuccess;
+              && hipMalloc((void **)&c->d_cumRate, (lRef + 1) * sizeof(double)) == hipSuccess
+              && hipMalloc((void **)&c->d_model, sizeof(DevModel)) == hipSuccess;
     if (!ok) { maple_destroy(c); return MAPLE_ERR_NOMEM; }
     *out = c;
     return MAPLE_OK;
@@ -569,7 +573,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     if (!c) return MAPLE_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_words, c->d_aux, c->d_ent_off, c->d_aux_off, c->d_n_ent, c->d_n_aux, c->d_mut3, c->d_mut_off,
+    void *ptrs[] = {c->d_model, c->d_words, c->d_aux, c->d_ent_off, c->d_aux_off, c->d_n_ent, c->d_n_aux, c->d_mut3, c->d_mut_off,
                     c->d_mut_cnt, c->d_cumRate, c->d_cumErr, c->d_siteRates, c->d_errorRates};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &b : c->s_i32) b.release();
@@ -629,6 +633,7 @@ extern "C" int maple_set_model(maple_ctx *c, const double *Q16, const double *si
             m.cumulativeErrorRate = c->d_cumErr;
         } else m.totError = -errorRateGlobal * lRef;
     }
+    HIPCK(c, hipMemcpyAsync(c->d_model, &c->dm, sizeof(DevModel), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     c->model_set = true;
     return MAPLE_OK;
@@ -853,7 +858,7 @@ extern "C" int maple_append_batch(maple_ctx *c, int32_t n, const int32_t *pl, co
     TRY(h2d(c, c->s_u8[0], tip, (size_t)n));
     TRY(h2d(c, c->s_f64[0], bl, (size_t)n));
     HIPCK(c, c->s_f64[1].reserve(n));
-    DISPATCH3(c, k_append, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
+    DISPATCH3(c, k_append, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
                                                                           c->s_u8[0].p, c->s_f64[0].p, c->s_f64[1].p));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(out, c->s_f64[1].p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -896,7 +901,7 @@ extern "C" int maple_merge_batch(maple_ctx *c, int32_t n, const int32_t *l1, con
     double *dlk = nullptr;
     if (outLK) { HIPCK(c, c->s_f64[2].reserve(n)); dlk = c->s_f64[2].p; }
     OutSpec o{c->s_words.p, c->s_aux.p, c->s_i64[0].p, c->s_i64[1].p, c->s_i32[2].p, c->s_i32[3].p};
-    DISPATCH3(c, k_merge, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), n, c->s_i32[0].p, c->s_f64[0].p,
+    DISPATCH3(c, k_merge, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, c->s_i32[0].p, c->s_f64[0].p,
                                                                          c->s_u8[0].p, c->s_i32[1].p, c->s_f64[1].p,
                                                                          c->s_u8[1].p, c->s_u8[2].p, dnm1, dnm2, o, dlk));
     HIPCK(c, hipGetLastError());
@@ -923,7 +928,7 @@ extern "C" int maple_blen_batch(maple_ctx *c, int32_t n, const int32_t *pl, cons
     TRY(h2d(c, c->s_i64[0], aoff.data(), (size_t)n));
     HIPCK(c, c->s_f64[0].reserve(n));
     HIPCK(c, c->s_u8[1].reserve(n));
-    DISPATCH3(c, k_blen, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
+    DISPATCH3(c, k_blen, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
                                                                         c->s_u8[0].p, c->s_ais.p, c->s_i64[0].p,
                                                                         c->s_f64[0].p, c->s_u8[1].p));
     HIPCK(c, hipGetLastError());
@@ -944,7 +949,7 @@ extern "C" int maple_differ_batch(maple_ctx *c, int32_t n, const int32_t *l1, co
     TRY(h2d(c, c->s_i32[0], l1, (size_t)n));
     TRY(h2d(c, c->s_i32[1], l2, (size_t)n));
     HIPCK(c, c->s_u8[0].reserve(n));
-    DISPATCH3(c, k_differ, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
+    DISPATCH3(c, k_differ, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
                                                                           c->s_u8[0].p));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(out, c->s_u8[0].p, n, hipMemcpyDeviceToHost, c->stream));
@@ -1020,7 +1025,7 @@ extern "C" int maple_shorten_batch(maple_ctx *c, int32_t n, const int32_t *l, in
     HIPCK(c, c->s_i32[2].reserve(n));
     HIPCK(c, c->s_i32[3].reserve(n));
     OutSpec o{c->s_words.p, c->s_aux.p, c->s_i64[0].p, c->s_i64[1].p, c->s_i32[2].p, c->s_i32[3].p};
-    DISPATCH3(c, k_shorten, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), n, c->s_i32[0].p, o));
+    DISPATCH3(c, k_shorten, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, c->s_i32[0].p, o));
     HIPCK(c, hipGetLastError());
     return commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outList);
 }
@@ -1060,7 +1065,7 @@ extern "C" int maple_root_vector_batch(maple_ctx *c, int32_t n, const int32_t *l
     HIPCK(c, c->s_i32[2].reserve(n));
     HIPCK(c, c->s_i32[3].reserve(n));
     OutSpec o{c->s_words.p, c->s_aux.p, c->s_i64[0].p, c->s_i64[1].p, c->s_i32[2].p, c->s_i32[3].p};
-    DISPATCH3(c, k_root_vector, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), mview(c), n, c->s_i32[0].p,
+    DISPATCH3(c, k_root_vector, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), mview(c), n, c->s_i32[0].p,
                                                                                c->s_f64[0].p, c->s_u8[0].p, c->s_i64[2].p,
                                                                                c->s_i32[1].p, c->s_i64[3].p, o));
     HIPCK(c, hipGetLastError());
@@ -1106,7 +1111,7 @@ extern "C" int maple_evaluate_placement_batch(maple_ctx *c, int32_t n, const int
     TRY(h2d(c, c->s_i64[1], aisOff.data(), (size_t)n));
     HIPCK(c, c->s_f64[1].reserve((size_t)4 * n));
     HIPCK(c, c->s_i32[4].reserve(n));
-    DISPATCH3(c, k_evalplace, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->dm, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
+    DISPATCH3(c, k_evalplace, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
                                                                              c->s_i32[2].p, c->s_f64[0].p, c->s_i32[3].p,
                                                                              c->s_u8[0].p, c->s_u8[1].p, c->s_words.p,
                                                                              c->s_aux.p, c->s_i64[0].p, c->s_ais.p,
@@ -1147,30 +1152,31 @@ extern "C" int maple_append_batch_dev(maple_ctx *c, int32_t n, const int32_t *pl
     hipEvent_t e0, e1;
     TRY(ev_pair(c, &e0, &e1));
     HIPCK(c, hipEventRecord(e0, s));
-    DISPATCH3(c, k_append, <<<grid_for(n), MAPLE_BLOCK, 0, s>>>(c->dm, view(c), n, pl, cl, tip, bl, out));
+    DISPATCH3(c, k_append, <<<grid_for(n), MAPLE_BLOCK, 0, s>>>(c->d_model, view(c), n, pl, cl, tip, bl, out));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipEventRecord(e1, s));
     return MAPLE_OK;
 }
 
-extern "C" int maple_append_query_dev(maple_ctx *c, int32_t n, int32_t childList, int isTipC, double bLen,
-                                      const int32_t *cand, double *out, void *stream)
+extern "C" int maple_append_queries_dev(maple_ctx *c, int32_t nQ, const int32_t *qList_dev, int32_t nC,
+                                        const int32_t *cand_dev, int isTipC, double bLen, double *out_dev, void *stream)
 {
-    if (!c || n < 0 || !cand || !out) return MAPLE_ERR_ARG;
-    if (n == 0) return MAPLE_OK;
+    if (!c || nQ < 0 || nC < 0 || !qList_dev || !cand_dev || !out_dev) return MAPLE_ERR_ARG;
+    if (nQ == 0 || nC == 0) return MAPLE_OK;
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
-    TRY(check_ids(c, 1, &childList, false, "childList"));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const long long tiles = (long long)nQ * ((nC + MAPLE_BLOCK - 1) / MAPLE_BLOCK);
+    if (tiles > 0x7fffffffLL) return fail(c, MAPLE_ERR_ARG, "nQ x nC too large for one launch");
+    const int grid = tiles < 256 * 8 ? (int)tiles : 256 * 8;
     hipEvent_t e0, e1;
     TRY(ev_pair(c, &e0, &e1));
     HIPCK(c, hipEventRecord(e0, s));
-    DISPATCH3(c, k_append_query, <<<grid_for(n), MAPLE_BLOCK, 0, s>>>(c->dm, view(c), n, childList, isTipC, bLen, cand, out));
+    DISPATCH3(c, k_append_queries, <<<grid, MAPLE_BLOCK, 0, s>>>(c->d_model, view(c), nQ, qList_dev, nC, cand_dev, isTipC, bLen, out_dev));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipEventRecord(e1, s));
     return MAPLE_OK;
 }
-
 
 // ---- tree mirror + SPR search ------------------------------------------------------------------------
 extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const int32_t *up, const int32_t *child0,
@@ -1265,7 +1271,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         hipEvent_t e0, e1;
         TRY(ev_pair(c, &e0, &e1));
         HIPCK(c, hipEventRecord(e0, c->stream));
-        DISPATCH3(c, k_spr_search, <<<lanes / 64, 64, 0, c->stream>>>(c->dm, view(c), mview(c), c->dtree, P, m, c->s_i32[0].p,
+        DISPATCH3(c, k_spr_search, <<<lanes / 64, 64, 0, c->stream>>>(c->d_model, view(c), mview(c), c->dtree, P, m, c->s_i32[0].p,
                                                                      L, LB, c->s_search_ws.p, c->s_counter.p, dout, poolW,
                                                                      poolA, poolUsed, poolCapW, poolCapA,
                                                                      attempt == 0 ? c->trace_query : -1, c->s_trace_i.p,

@@ -21,7 +21,7 @@ EXPORTS = [
     "maple_lists_upload", "maple_lists_sizes", "maple_lists_download", "maple_arena_mark", "maple_arena_release",
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
-    "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_query_dev", "maple_timing_reset", "maple_timing_read",
+    "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_debug_trace_query", "maple_debug_trace_read",
 ]
 
@@ -329,9 +329,10 @@ class Device:
                                                  C.c_void_p(tip_ptr), C.c_void_p(blen_ptr), C.c_void_p(out_ptr),
                                                  C.c_void_p(stream)))
 
-    def append_query_dev(self, n, child_list, isTipC, bLen, cand_ptr, out_ptr, stream=0):
-        self._ck(self.lib.maple_append_query_dev(self.h, int(n), int(child_list), int(bool(isTipC)), C.c_double(bLen),
-                                                 C.c_void_p(cand_ptr), C.c_void_p(out_ptr), C.c_void_p(stream)))
+    def append_queries_dev(self, nQ, qlist_ptr, nC, cand_ptr, isTipC, bLen, out_ptr, stream=0):
+        self._ck(self.lib.maple_append_queries_dev(self.h, int(nQ), C.c_void_p(qlist_ptr), int(nC), C.c_void_p(cand_ptr),
+                                                   int(bool(isTipC)), C.c_double(bLen), C.c_void_p(out_ptr),
+                                                   C.c_void_p(stream)))
 
     def timing_reset(self):
         self._ck(self.lib.maple_timing_reset(self.h))

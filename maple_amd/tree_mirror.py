@@ -103,3 +103,10 @@ class TreeMirror:
         """Nodes whose mid-branch total list is a placement candidate (dist > effectivelyNon0BLen, M:8012)."""
         ok = (self.tot_up >= 0) & (self.dist > min_blen) & (self.parent >= 0)
         return np.nonzero(ok)[0]
+
+    def candidates_by_length(self, min_blen):
+        """Candidate nodes ordered by the length of their mid-branch list (longest first).  A wavefront walks 64
+        lists in lock-step and takes as long as its longest one, so neighbours should have similar lengths."""
+        cand = self.candidate_nodes(min_blen)
+        ne, _ = self.dev.sizes(self.tot_up[cand])
+        return cand[np.argsort(-ne, kind="stable")]

@@ -217,3 +217,36 @@ def test_ops_mirror_reads_like_the_reference(env):
         for r in recs[:5]:
             got = ops.estimateBranchLengthWithDerivative(tup(r["P"]), tup(r["C"]), r["fromTipC"])
             assert (got is False) if r["ret"] is False else close(got, r["ret"], REL)
+
+
+def test_append_queries_dev_matches_pair_batches(env):
+    """The query-major tiled kernel (the bench's headline kernel) against the reference's recorded values:
+    every recorded (P, C) pair is scored as query C against the candidate set of ALL recorded P lists."""
+    import torch
+    f, dev, o = env
+    for mid, recs in list(by_model(f, "appendProbNode").items())[:3]:
+        mod = f["models"][mid]
+        dev.set_model(**model_args(mod))
+        recs = [r for r in recs if r["isTipC"]][:40]
+        if len(recs) < 4:
+            continue
+        bl = recs[0]["bLen"]
+        mark = dev.mark()
+        n = len(recs)
+        ids = dev.upload([tup(r["P"]) for r in recs] + [tup(r["C"]) for r in recs])
+        cu = torch.device("cuda", 0)
+        t_q = torch.from_numpy(ids[n:].astype(np.int32)).to(cu)
+        t_c = torch.from_numpy(ids[:n].astype(np.int32)).to(cu)
+        t_out = torch.empty(n * n, dtype=torch.float64, device=cu)
+        torch.cuda.synchronize()
+        dev.append_queries_dev(n, t_q.data_ptr(), n, t_c.data_ptr(), True, bl, t_out.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = t_out.cpu().numpy().reshape(n, n)
+        want = dev.append_batch(np.tile(ids[:n], n), np.repeat(ids[n:], n), True, bl).reshape(n, n)
+        dev.release(mark)
+        for q in range(n):
+            for k in range(n):
+                assert close(float(got[q, k]), float(want[q, k]), 1e-12), (q, k, got[q, k], want[q, k])
+            if recs[q]["bLen"] == bl:
+                assert close(float(got[q, q]), recs[q]["ret"], REL)
