@@ -174,6 +174,18 @@ def main():
                "placements_per_s_wall": float(res["nAppend"].sum() / wall),
                "params": "deep round: non-strict, allowedFailsTopology 4, thresholdLogLKtopology 14 log(lRef)"}
 
+    # HBM-side bytes per launch come from separate rocprofv3 PMC passes over this same command (a running process
+    # cannot read its own PMCs); they are recorded, with the FETCH_SIZE calibration for this access pattern, in
+    # profiles/pmc_k_append_queries.json and only reported when the workload is the one they were measured on.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_append_queries.json")))
+        w = pmc["workload"]
+        if (w["samples"], w["queries_per_gpu"], w["candidate_branches"]) == (args.samples, Q, int(Cn)) and not args.pairs:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_pairs * args.steps / elapsed
@@ -190,7 +202,7 @@ def main():
                        "parallelism": f"queries sharded round-robin over {world} GPU(s), tree mirror replicated",
                        "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_append_queries", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": k_ms, "launches_timed": n_launch},
         }
         if spr is not None:

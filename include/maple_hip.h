@@ -173,6 +173,9 @@ int maple_spr_search_batch(maple_ctx *ctx, int32_t n, const int32_t *nodes, cons
 /* Debugging aid: record the visit sequence of query index `query` of the next maple_spr_search_batch
  * (per visited item: t1, direction, needsUpdating, failedPasses | lastLK, midProb); -1 switches it off. */
 int maple_debug_trace_query(maple_ctx *ctx, int32_t query);
+/* PMC calibration: `repeats` launches of a kernel that reads `bytes` bytes with this library's access pattern
+ * (one lane = one contiguous 512-byte list, dependent 8-byte loads); returns the total time. */
+int maple_debug_calib_walk(maple_ctx *ctx, uint64_t bytes, int32_t repeats, float *ms);
 int maple_debug_trace_read(maple_ctx *ctx, int32_t *n, int32_t *items4 /*[4*4096]*/, double *vals2 /*[2*4096]*/);
 
 /* ---- device-resident forms (inputs already in HBM; asynchronous on `stream`) --- */

@@ -1310,6 +1310,48 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     return MAPLE_OK;
 }
 
+// Calibration of the FETCH_SIZE counter for THIS library's access pattern (MI355X_MICROARCH.md, HBM section: the
+// counter is only calibrated for 16 B/lane coalesced streams).  Every lane walks its own contiguous 512-byte "list"
+// with dependent 8-byte loads, exactly like a genome-list walk, over a buffer far larger than the 256 MiB Infinity
+// Cache; the byte count is known, so FETCH_SIZE / bytes is the correction factor for k_append*.
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_calib_walk(const unsigned long long *buf, long long nLists, unsigned long long *sink)
+{
+    unsigned long long acc = 0;
+    for (long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x; l < nLists; l += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long *p = buf + l * 64;
+        unsigned idx = 0;
+        for (int k = 0; k < 64; k++) {
+            unsigned long long w = p[idx];
+            acc += w;
+            idx = (idx + 1 + (unsigned)(w & 0)) & 63;                    // data-dependent next index, like a cursor
+        }
+    }
+    if (acc == 0x123456789abcdefull) *sink = acc;
+}
+
+extern "C" int maple_debug_calib_walk(maple_ctx *c, uint64_t bytes, int32_t repeats, float *ms)
+{
+    if (!c || bytes < 512 || repeats <= 0) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    unsigned long long *buf = nullptr, *sink = nullptr;
+    HIPCK(c, hipMalloc((void **)&buf, bytes));
+    HIPCK(c, hipMalloc((void **)&sink, 8));
+    HIPCK(c, hipMemset(buf, 1, bytes));
+    HIPCK(c, hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    HIPCK(c, hipEventCreate(&e0));
+    HIPCK(c, hipEventCreate(&e1));
+    HIPCK(c, hipEventRecord(e0, c->stream));
+    for (int r = 0; r < repeats; r++)
+        hipLaunchKernelGGL(k_calib_walk, dim3(2048), dim3(MAPLE_BLOCK), 0, c->stream, buf, (long long)(bytes / 512), sink);
+    HIPCK(c, hipEventRecord(e1, c->stream));
+    HIPCK(c, hipEventSynchronize(e1));
+    if (ms) HIPCK(c, hipEventElapsedTime(ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(buf); (void)hipFree(sink);
+    return MAPLE_OK;
+}
+
 // debugging aid: record the visit sequence (t1, direction, needsUpdating, failedPasses, lastLK, midProb) of one query
 extern "C" int maple_debug_trace_query(maple_ctx *c, int32_t query)
 {

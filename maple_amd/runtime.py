@@ -22,7 +22,7 @@ EXPORTS = [
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
     "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read",
-    "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_debug_trace_query", "maple_debug_trace_read",
+    "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
 ]
 
 
@@ -311,6 +311,11 @@ class Device:
         if want_removed_partials:
             out["removedPartials"] = rpr
         return out
+
+    def debug_calib_walk(self, nbytes, repeats=1):
+        ms = C.c_float()
+        self._ck(self.lib.maple_debug_calib_walk(self.h, C.c_uint64(nbytes), int(repeats), C.byref(ms)))
+        return ms.value
 
     def debug_trace_query(self, q):
         self._ck(self.lib.maple_debug_trace_query(self.h, int(q)))
