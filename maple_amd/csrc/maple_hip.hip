@@ -376,13 +376,17 @@ __global__ __launch_bounds__(64) void k_spr_search(const DevModel *__restrict__ 
                                                    const int32_t *nodes, WsLayout L, LaneBytes LB, uint8_t *wsBase,
                                                    int32_t *counter, SearchOut *out, uint2 *poolW, double *poolA,
                                                    unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
-                                                   int traceQuery, int32_t *trI, double *trD, int trCap, int32_t *trN)
+                                                   int traceQuery, int32_t *trI, double *trD, int trCap, int32_t *trN,
+                                                   int activeLanes)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
-    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // only the first `activeLanes` lanes of every wavefront search: with few queries it is better to spread them
+    // over many wavefronts (a wavefront executes the union of its lanes' control paths) than to fill 64-wide waves
+    if ((int)threadIdx.x >= activeLanes) return;
+    const size_t lane = (size_t)blockIdx.x * activeLanes + threadIdx.x;
     uint8_t *base = wsBase + lane * LB.total;
     LaneWs ws;
     ws.w = (uint2 *)base;
@@ -1262,8 +1266,18 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         L.capB = 1024 * (attempt + 1);
         L.capAis = 8192 * (attempt + 1);
         LaneBytes LB = lane_bytes(L);
-        int maxLanes = 16384 >> (3 * attempt);                         // keeps the workspace footprint bounded
-        int lanes = m < maxLanes ? ((m + 63) / 64) * 64 : maxLanes;
+        // lanes: one query per lane while they last; at most 2 wavefronts per SIMD (the kernel's occupancy) and a
+        // workspace footprint bounded to ~48 GB of the 288 GB
+        const long long wsBudget = 48ll << 30;
+        long long maxLanes = wsBudget / (long long)LB.total;
+        if (maxLanes > 2048 * 64) maxLanes = 2048 * 64;
+        if (maxLanes < 64) maxLanes = 64;
+        const int lanesWanted = (int)(m < maxLanes ? m : maxLanes);
+        int activeLanes = (lanesWanted + 2047) / 2048;                 // per wavefront
+        if (activeLanes < 4) activeLanes = 4;
+        if (activeLanes > 64) activeLanes = 64;
+        const int nWaves = (lanesWanted + activeLanes - 1) / activeLanes;
+        const int lanes = nWaves * activeLanes;
         HIPCK(c, c->s_search_ws.reserve((size_t)lanes * LB.total));
         HIPCK(c, hipMemsetAsync(c->s_counter.p, 0, sizeof(int32_t), c->stream));
         TRY(h2d(c, c->s_i32[0], todo.data(), (size_t)m));
@@ -1271,11 +1285,12 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         hipEvent_t e0, e1;
         TRY(ev_pair(c, &e0, &e1));
         HIPCK(c, hipEventRecord(e0, c->stream));
-        DISPATCH3(c, k_spr_search, <<<lanes / 64, 64, 0, c->stream>>>(c->d_model, view(c), mview(c), c->dtree, P, m, c->s_i32[0].p,
+        DISPATCH3(c, k_spr_search, <<<nWaves, 64, 0, c->stream>>>(c->d_model, view(c), mview(c), c->dtree, P, m, c->s_i32[0].p,
                                                                      L, LB, c->s_search_ws.p, c->s_counter.p, dout, poolW,
                                                                      poolA, poolUsed, poolCapW, poolCapA,
                                                                      attempt == 0 ? c->trace_query : -1, c->s_trace_i.p,
-                                                                     c->s_trace_d.p, 4096, c->s_trace_i.p ? c->s_trace_i.p + 4 * 4096 : nullptr));
+                                                                     c->s_trace_d.p, 4096, c->s_trace_i.p ? c->s_trace_i.p + 4 * 4096 : nullptr,
+                                                                     activeLanes));
         HIPCK(c, hipGetLastError());
         HIPCK(c, hipEventRecord(e1, c->stream));
         std::vector<SearchOut> part(m);
