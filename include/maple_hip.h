@@ -118,6 +118,8 @@ int maple_blen_batch(maple_ctx *ctx, int32_t n, const int32_t *parentList, const
                      const uint8_t *fromTipC, double *t, uint8_t *isFalse);
 /* areVectorsDifferent(pv1, pv2), M:5419-5472; list2 == -1 means None -> different */
 int maple_differ_batch(maple_ctx *ctx, int32_t n, const int32_t *list1, const int32_t *list2, uint8_t *out);
+/* findProbRoot(probVect) for lists already expressed in the root frame, M:4865-4912 */
+int maple_root_prob_batch(maple_ctx *ctx, int32_t n, const int32_t *list, double *outLK);
 /* isMinorSequence(probVect1, probVect2, onlyFindIdentical), M:5919-6004 -> 0 / 1 / 2 */
 int maple_minor_batch(maple_ctx *ctx, int32_t n, const int32_t *list1, const int32_t *list2, int onlyFindIdentical,
                       uint8_t *out);
@@ -154,6 +156,8 @@ typedef struct {
     double thresholdLogLKoptimizationTopology;  /* M:66, x log(lRef) (M:3609), data-adaptive M:11770 */
     double thresholdLogLKconsecutivePlacement;  /* M:63  */
     double effectivelyNon0BLen;                 /* M:3614 */
+    int32_t wideSearchBudget;                   /* searches scoring more branches than this are batch-scored first
+                                                   (0 = default 512, < 0 = never); results do not depend on it */
 } maple_search_params;
 
 /* The worker body of startTopologyUpdatesParallel (M:9615-9711) for n pruned nodes, each running

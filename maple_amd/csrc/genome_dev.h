@@ -26,6 +26,10 @@ struct DevModel {                      // kernel argument (uniform -> SGPRs)
     double errorRate, totError, globalTotRate, minimumCarryOver;
     double thresholdProb, thresholdProb4, minBLenSensitivity, thresholdDiffForUpdate, thresholdFoldChangeUpdate;
     double defaultBLen;
+    // tables of findProbRoot (M:4865-4912)
+    double rootFreqsLog[4];
+    const int32_t *cumulativeBases;    // [(lRef+1)*4], M:3669-3674
+    const double *rootFreqsLogErrorCumulative;   // [lRef+1] when usingErrorRate, M:6373-6390
 };
 
 struct Lds {                           // per-workgroup staging of the tiny tables
@@ -718,6 +722,47 @@ template <class C> __device__ bool differ_walk(const C &c, ListRef L1, ListRef L
         b.step(pos);
     }
     return false;
+}
+
+// ---- findProbRoot (M:4865-4912): log-likelihood of a lower list (already in the root frame) at the root ----
+template <bool RV, bool U, bool SS> __device__ double root_prob_walk(const Ctx<RV, U, SS> &c, ListRef L)
+{
+    const int lRef = c.m.lRef;
+    const double *rf = c.rf;
+    const int32_t *cb = c.m.cumulativeBases;
+    Cursor a;
+    a.init(L);
+    double logLK = 0.0, logFactor = 1.0;
+    int pos = 0;
+    for (;;) {
+        const Ent &e = a.e;
+        if (U && e.type < 5 && e.hasD0 && e.flag) {
+            if (e.type == 4) { logLK += c.m.rootFreqsLogErrorCumulative[e.pos] - c.m.rootFreqsLogErrorCumulative[pos]; pos = e.pos; }
+            else {
+                double er = c.err(pos);
+                logFactor *= (sel4(rf, e.type) * (1.0 - 1.33333 * er) + 0.33333 * er);
+                pos += 1;
+            }
+        } else if (e.type == 4) {
+            for (int i = 0; i < 4; i++) logLK += c.m.rootFreqsLog[i] * (cb[e.pos * 4 + i] - cb[pos * 4 + i]);
+            pos = e.pos;
+        } else if (e.type < 4) { logLK += c.m.rootFreqsLog[e.type]; pos += 1; }
+        else if (e.type == 6) {
+            double tot = 0.0;
+            for (int i = 0; i < 4; i++) tot += rf[i] * e.vec[i];
+            logFactor *= tot;
+            pos += 1;
+        } else pos = e.pos;
+        if (logFactor <= c.m.minimumCarryOver) {
+            if (logFactor < 2.2250738585072014e-308) return -INFINITY;
+            logLK += log(logFactor);
+            logFactor = 1.0;
+        }
+        if (pos == lRef) break;
+        a.next();
+    }
+    logLK += log(logFactor);
+    return logLK;
 }
 
 // ---- isMinorSequence (M:5919-6004): 1 = list2 is at most as informative as list1, 2 = the opposite, 0 = neither ----

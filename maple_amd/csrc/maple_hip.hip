@@ -49,6 +49,8 @@ struct maple_ctx {
     DevModel *d_model = nullptr;       // the same struct in device memory: what the kernels read
     bool model_set = false;
     double *d_siteRates = nullptr, *d_errorRates = nullptr, *d_cumRate = nullptr, *d_cumErr = nullptr;
+    int32_t *d_cumBases = nullptr;
+    double *d_rflec = nullptr;
     std::vector<double> h_cumRate, h_cumErr;
     // list arena
     uint2 *d_words = nullptr;
@@ -81,10 +83,14 @@ struct maple_ctx {
     DevBuf<double> t_dist;
     DevBuf<uint8_t> t_tip;
     std::vector<int32_t> h_tree_up, h_tree_lower;
+    std::vector<double> h_tree_dist;
+    std::vector<uint8_t> h_tree_tip;
+    bool tree_has_mut = false;
     // SPR search workspace
     DevBuf<uint8_t> s_search_ws;
     DevBuf<uint8_t> s_search_out;
     DevBuf<int32_t> s_counter;
+    DevBuf<double> s_cache;            // cached (query x node) scores of wide searches
     int trace_query = -1;
     DevBuf<int32_t> s_trace_i;
     DevBuf<double> s_trace_d;
@@ -143,7 +149,7 @@ __global__ MAPLE_APPEND_ATTR void k_append(const DevModel *__restrict__ mp, Aren
 template <bool RV, bool U, bool SS>
 __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ mp, ArenaView av, int nQ,
                                                    const int32_t *qList, int nC, const int32_t *cand, int isTip,
-                                                   double bLen, double *out)
+                                                   double bLen, double *out, const uint8_t *qTip, const double *qBLen)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
@@ -154,8 +160,12 @@ __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ 
     for (int j = blockIdx.x; j < tiles; j += gridDim.x) {
         const int q = j / nChunks;
         const int ci = (j - q * nChunks) * MAPLE_BLOCK + threadIdx.x;
-        if (ci < nC)
-            out[(long long)q * nC + ci] = append_walk(c, list_ref(av, cand[ci]), list_ref(av, qList[q]), isTip != 0, bLen);
+        if (ci < nC) {
+            const int cl = cand[ci];                                     // -1: this column has no list (score unused)
+            if (cl >= 0)
+                out[(long long)q * nC + ci] = append_walk(c, list_ref(av, cl), list_ref(av, qList[q]),
+                                                          qTip ? qTip[q] != 0 : isTip != 0, qBLen ? qBLen[q] : bLen);
+        }
     }
 }
 
@@ -217,6 +227,18 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_differ(const DevModel *__restri
     Ctx<RV, U, SS> c(m, lds);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         out[i] = (l2[i] < 0) ? 1 : (differ_walk(c, list_ref(av, l1[i]), list_ref(av, l2[i])) ? 1 : 0);
+}
+
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_root_prob(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *l,
+                                                           double *out)
+{
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = root_prob_walk(c, list_ref(av, l[i]));
 }
 
 __global__ __launch_bounds__(MAPLE_BLOCK) void k_minor(int lRef, ArenaView av, int n, const int32_t *l1, const int32_t *l2,
@@ -377,7 +399,7 @@ __global__ __launch_bounds__(64) void k_spr_search(const DevModel *__restrict__ 
                                                    int32_t *counter, SearchOut *out, uint2 *poolW, double *poolA,
                                                    unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
                                                    int traceQuery, int32_t *trI, double *trD, int trCap, int32_t *trN,
-                                                   int activeLanes)
+                                                   int activeLanes, const double *cacheS, int budget)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
@@ -423,12 +445,18 @@ __global__ __launch_bounds__(64) void k_spr_search(const DevModel *__restrict__ 
             o.currentLK = curLK;
             if (!(curLK < P.thrPlacement || T.dist[node] != 0.0)) { o.status = 2; continue; }   // M:9674
             ws.usedW = ws.usedA = ws.nH = 0;
+            S.cached = cacheS ? cacheS + (size_t)q * T.n : nullptr;       // row q of the (queries x nodes) score table
+            S.budget = budget;
+            S.overBudget = false;
             S.trI = nullptr;
             if (q == traceQuery && trI) { S.trI = trI; S.trD = trD; S.trCap = trCap; S.trN = 0; }
             S.begin(parent, childIdx, curLK, T.dist[node]);
             active = true;
         } else if (ws.overflow) {
             out[q].status = -3;                                       // workspace exhausted: the host retries with more
+            active = false;
+        } else if (S.overBudget) {
+            out[q].status = -5;                                       // a wide search: the host batch-scores it and re-runs it
             active = false;
         } else if (ws.sp > 0) {
             S.step();
@@ -541,6 +569,7 @@ extern "C" int maple_create(maple_ctx **out, int device, int32_t lRef, const uin
     memset(&m, 0, sizeof m);
     m.lRef = lRef;
     for (int i = 0; i < 4; i++) m.rootFreqs[i] = rootFreqs4[i];
+    for (int i = 0; i < 4; i++) m.rootFreqsLog[i] = log(rootFreqs4[i]);  // M:3679
     m.globalTotRate = -(double)lRef;                                   // M:3607
     m.minimumCarryOver = DBL_MIN * (1e50);                             // M:3623
     m.thresholdProb = params->thresholdProb;
@@ -567,7 +596,20 @@ extern "C" int maple_create(maple_ctx **out, int device, int32_t lRef, const uin
               && hipMalloc((void **)&c->d_mut_cnt, c->cap_mut_lists * sizeof(int32_t)) == hipSuccess
               && hipMalloc((void **)&c->d_cumRate, (lRef + 1) * sizeof(double)) == hipSuccess
               && hipMalloc((void **)&c->d_model, sizeof(DevModel)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_cumBases, (size_t)(lRef + 1) * 4 * sizeof(int32_t)) == hipSuccess;
     if (!ok) { maple_destroy(c); return MAPLE_ERR_NOMEM; }
+    {                                                                  // cumulativeBases, M:3669-3674
+        std::vector<int32_t> cb((size_t)(lRef + 1) * 4, 0);
+        for (int i = 0; i < lRef; i++) {
+            for (int k = 0; k < 4; k++) cb[(size_t)(i + 1) * 4 + k] = cb[(size_t)i * 4 + k];
+            cb[(size_t)(i + 1) * 4 + refIdx[i]] += 1;
+        }
+        if (hipMemcpy(c->d_cumBases, cb.data(), cb.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            maple_destroy(c);
+            return MAPLE_ERR_HIP;
+        }
+        m.cumulativeBases = c->d_cumBases;
+    }
     *out = c;
     return MAPLE_OK;
 }
@@ -577,7 +619,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     if (!c) return MAPLE_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->d_model, c->d_words, c->d_aux, c->d_ent_off, c->d_aux_off, c->d_n_ent, c->d_n_aux, c->d_mut3, c->d_mut_off,
+    void *ptrs[] = {c->d_cumBases, c->d_rflec, c->d_model, c->d_words, c->d_aux, c->d_ent_off, c->d_aux_off, c->d_n_ent, c->d_n_aux, c->d_mut3, c->d_mut_off,
                     c->d_mut_cnt, c->d_cumRate, c->d_cumErr, c->d_siteRates, c->d_errorRates};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &b : c->s_i32) b.release();
@@ -587,7 +629,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     c->s_words.release(); c->s_aux.release(); c->s_ais.release();
     for (auto &b : c->t_i32) b.release();
     c->t_dist.release(); c->t_tip.release();
-    c->s_search_ws.release(); c->s_search_out.release(); c->s_counter.release();
+    c->s_search_ws.release(); c->s_search_out.release(); c->s_counter.release(); c->s_cache.release();
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -636,6 +678,17 @@ extern "C" int maple_set_model(maple_ctx *c, const double *Q16, const double *si
             m.errorRates = c->d_errorRates;
             m.cumulativeErrorRate = c->d_cumErr;
         } else m.totError = -errorRateGlobal * lRef;
+    }
+    m.rootFreqsLogErrorCumulative = nullptr;
+    if (usingErrorRate) {                                              // M:6380-6389 (note the 0.333333 of the table)
+        std::vector<double> acc(lRef + 1, 0.0);
+        for (int i = 0; i < lRef; i++) {
+            double e = errorRates ? errorRates[i] : errorRateGlobal;
+            acc[i + 1] = acc[i] + log(m.rootFreqs[c->refIdx[i]] * (1.0 - 1.33333 * e) + 0.333333 * e);
+        }
+        if (!c->d_rflec) HIPCK(c, hipMalloc((void **)&c->d_rflec, (lRef + 1) * sizeof(double)));
+        HIPCK(c, hipMemcpy(c->d_rflec, acc.data(), (lRef + 1) * sizeof(double), hipMemcpyHostToDevice));
+        m.rootFreqsLogErrorCumulative = c->d_rflec;
     }
     HIPCK(c, hipMemcpyAsync(c->d_model, &c->dm, sizeof(DevModel), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -961,6 +1014,22 @@ extern "C" int maple_differ_batch(maple_ctx *c, int32_t n, const int32_t *l1, co
     return MAPLE_OK;
 }
 
+extern "C" int maple_root_prob_batch(maple_ctx *c, int32_t n, const int32_t *l, double *out)
+{
+    if (!c || n < 0 || !l || !out) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    TRY(check_ids(c, n, l, false, "list"));
+    TRY(h2d(c, c->s_i32[0], l, (size_t)n));
+    HIPCK(c, c->s_f64[0].reserve(n));
+    DISPATCH3(c, k_root_prob, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, c->s_i32[0].p, c->s_f64[0].p));
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(out, c->s_f64[0].p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MAPLE_OK;
+}
+
 extern "C" int maple_minor_batch(maple_ctx *c, int32_t n, const int32_t *l1, const int32_t *l2, int onlyFindIdentical,
                                  uint8_t *out)
 {
@@ -1176,7 +1245,7 @@ extern "C" int maple_append_queries_dev(maple_ctx *c, int32_t nQ, const int32_t 
     hipEvent_t e0, e1;
     TRY(ev_pair(c, &e0, &e1));
     HIPCK(c, hipEventRecord(e0, s));
-    DISPATCH3(c, k_append_queries, <<<grid, MAPLE_BLOCK, 0, s>>>(c->d_model, view(c), nQ, qList_dev, nC, cand_dev, isTipC, bLen, out_dev));
+    DISPATCH3(c, k_append_queries, <<<grid, MAPLE_BLOCK, 0, s>>>(c->d_model, view(c), nQ, qList_dev, nC, cand_dev, isTipC, bLen, out_dev, nullptr, nullptr));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipEventRecord(e1, s));
     return MAPLE_OK;
@@ -1210,6 +1279,10 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     T.dist = c->t_dist.p; T.isTip = c->t_tip.p;
     c->h_tree_up.assign(up, up + n);
     c->h_tree_lower.assign(lower, lower + n);
+    c->h_tree_dist.assign(dist, dist + n);
+    c->h_tree_tip.assign(isTip, isTip + n);
+    c->tree_has_mut = false;
+    for (int i = 0; i < n; i++) if (mutList[i] >= 0) c->tree_has_mut = true;
     c->tree_set = true;
     return MAPLE_OK;
 }
@@ -1254,55 +1327,106 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     }
     HIPCK(c, hipMemsetAsync(c->s_counter.p, 0, 8 * sizeof(int32_t), c->stream));
     unsigned long long *poolUsed = (unsigned long long *)(c->s_counter.p + 2);
-    int capW = ws_entries_per_lane > 0 ? ws_entries_per_lane : 16384;
-    // queries whose per-lane workspace overflowed (status -3) are re-run with 8x the workspace, twice at most
-    for (int attempt = 0; attempt < 3 && !todo.empty(); attempt++, capW *= 8) {
-        const int m = (int)todo.size();
-        WsLayout L;
-        L.capW = capW;
-        L.capA = 3 * L.capW;
-        L.capH = L.capW / 8 + 256;
-        L.capS = 1024 * (attempt + 1);
-        L.capB = 1024 * (attempt + 1);
-        L.capAis = 8192 * (attempt + 1);
-        LaneBytes LB = lane_bytes(L);
-        // lanes: one query per lane while they last; at most 2 wavefronts per SIMD (the kernel's occupancy) and a
-        // workspace footprint bounded to ~48 GB of the 288 GB
-        const long long wsBudget = 48ll << 30;
-        long long maxLanes = wsBudget / (long long)LB.total;
-        if (maxLanes > 2048 * 64) maxLanes = 2048 * 64;
-        if (maxLanes < 64) maxLanes = 64;
-        const int lanesWanted = (int)(m < maxLanes ? m : maxLanes);
-        int activeLanes = (lanesWanted + 2047) / 2048;                 // per wavefront
-        if (activeLanes < 4) activeLanes = 4;
-        if (activeLanes > 64) activeLanes = 64;
-        const int nWaves = (lanesWanted + activeLanes - 1) / activeLanes;
-        const int lanes = nWaves * activeLanes;
-        HIPCK(c, c->s_search_ws.reserve((size_t)lanes * LB.total));
-        HIPCK(c, hipMemsetAsync(c->s_counter.p, 0, sizeof(int32_t), c->stream));
-        TRY(h2d(c, c->s_i32[0], todo.data(), (size_t)m));
-        SearchOut *dout = (SearchOut *)c->s_search_out.p;
-        hipEvent_t e0, e1;
-        TRY(ev_pair(c, &e0, &e1));
-        HIPCK(c, hipEventRecord(e0, c->stream));
-        DISPATCH3(c, k_spr_search, <<<nWaves, 64, 0, c->stream>>>(c->d_model, view(c), mview(c), c->dtree, P, m, c->s_i32[0].p,
-                                                                     L, LB, c->s_search_ws.p, c->s_counter.p, dout, poolW,
-                                                                     poolA, poolUsed, poolCapW, poolCapA,
-                                                                     attempt == 0 ? c->trace_query : -1, c->s_trace_i.p,
-                                                                     c->s_trace_d.p, 4096, c->s_trace_i.p ? c->s_trace_i.p + 4 * 4096 : nullptr,
-                                                                     activeLanes));
-        HIPCK(c, hipGetLastError());
-        HIPCK(c, hipEventRecord(e1, c->stream));
-        std::vector<SearchOut> part(m);
-        HIPCK(c, hipMemcpyAsync(part.data(), dout, (size_t)m * sizeof(SearchOut), hipMemcpyDeviceToHost, c->stream));
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        std::vector<int32_t> todo2, slot2;
-        for (int k = 0; k < m; k++) {
-            ho[slot[k]] = part[k];
-            if (part[k].status == -3 && attempt < 2) { todo2.push_back(todo[k]); slot2.push_back(slot[k]); }
+    const int capW0 = ws_entries_per_lane > 0 ? ws_entries_per_lane : 16384;
+    // Runs the searches `todo` (results into ho[slot[]]).  Queries whose per-lane workspace overflowed (status -3) are
+    // re-run with 8x the workspace, twice at most.  cacheS (optional) = row-major (|todo| x T.n) cached scores.
+    auto run_queries = [&](std::vector<int32_t> todo, std::vector<int32_t> slot, const double *cacheS, int budgetNow) -> int {
+        int capW = capW0;
+        for (int attempt = 0; attempt < 3 && !todo.empty(); attempt++, capW *= 8) {
+            const int m = (int)todo.size();
+            WsLayout L;
+            L.capW = capW;
+            L.capA = 3 * L.capW;
+            L.capH = L.capW / 8 + 256;
+            L.capS = 1024 * (attempt + 1);
+            L.capB = 1024 * (attempt + 1);
+            L.capAis = 8192 * (attempt + 1);
+            LaneBytes LB = lane_bytes(L);
+            // lanes: one query per lane while they last; at most 2 wavefronts per SIMD (the kernel's occupancy) and a
+            // workspace footprint bounded to ~48 GB of the 288 GB
+            const long long wsBudget = 48ll << 30;
+            long long maxLanes = wsBudget / (long long)LB.total;
+            if (maxLanes > 2048 * 64) maxLanes = 2048 * 64;
+            if (maxLanes < 64) maxLanes = 64;
+            const int lanesWanted = (int)(m < maxLanes ? m : maxLanes);
+            int activeLanes = (lanesWanted + 2047) / 2048;             // per wavefront
+            if (activeLanes < 4) activeLanes = 4;
+            if (activeLanes > 64) activeLanes = 64;
+            const int nWaves = (lanesWanted + activeLanes - 1) / activeLanes;
+            const int lanes = nWaves * activeLanes;
+            HIPCK(c, c->s_search_ws.reserve((size_t)lanes * LB.total));
+            HIPCK(c, hipMemsetAsync(c->s_counter.p, 0, sizeof(int32_t), c->stream));
+            TRY(h2d(c, c->s_i32[0], todo.data(), (size_t)m));
+            HIPCK(c, c->s_search_out.reserve((size_t)m * sizeof(SearchOut)));
+            SearchOut *dout = (SearchOut *)c->s_search_out.p;
+            hipEvent_t e0, e1;
+            TRY(ev_pair(c, &e0, &e1));
+            HIPCK(c, hipEventRecord(e0, c->stream));
+            DISPATCH3(c, k_spr_search, <<<nWaves, 64, 0, c->stream>>>(c->d_model, view(c), mview(c), c->dtree, P, m, c->s_i32[0].p,
+                                                                         L, LB, c->s_search_ws.p, c->s_counter.p, dout, poolW,
+                                                                         poolA, poolUsed, poolCapW, poolCapA,
+                                                                         attempt == 0 ? c->trace_query : -1, c->s_trace_i.p,
+                                                                         c->s_trace_d.p, 4096, c->s_trace_i.p ? c->s_trace_i.p + 4 * 4096 : nullptr,
+                                                                         activeLanes, cacheS, budgetNow));
+            HIPCK(c, hipGetLastError());
+            HIPCK(c, hipEventRecord(e1, c->stream));
+            std::vector<SearchOut> part(m);
+            HIPCK(c, hipMemcpyAsync(part.data(), dout, (size_t)m * sizeof(SearchOut), hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            std::vector<int32_t> todo2, slot2;
+            for (int k = 0; k < m; k++) {
+                ho[slot[k]] = part[k];
+                if (part[k].status == -3 && attempt < 2) { todo2.push_back(todo[k]); slot2.push_back(slot[k]); }
+            }
+            todo.swap(todo2);
+            slot.swap(slot2);
+            cacheS = nullptr;                                          // rows no longer line up: retries run uncached
+            budgetNow = 0;
         }
-        todo.swap(todo2);
-        slot.swap(slot2);
+        return MAPLE_OK;
+    };
+    // Wide searches (the non-strict rounds let ~1 query in 5 walk the whole tree): in the cached regime the score of a
+    // branch is a pure function of (query, branch), so those queries are scored against every branch by the batch
+    // kernel (k_append_queries) and the state machine then only replays the traversal over the cached scores.
+    // Only for trees without MAT local references for now (one frame: the removed list is the same everywhere).
+    int wideBudget = sp->wideSearchBudget == 0 ? 512 : sp->wideSearchBudget;
+    const bool hybrid = wideBudget > 0 && !c->tree_has_mut;
+    TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0));
+    if (hybrid) {
+        std::vector<int32_t> wide;
+        for (int i = 0; i < n; i++) if (ho[i].status == -5) wide.push_back(i);
+        const int nT = c->dtree.n;
+        const size_t rowBytes = (size_t)nT * sizeof(double);
+        size_t chunk = (size_t)(4ull << 30) / rowBytes;
+        if (chunk < 1) chunk = 1;
+        for (size_t w0 = 0; w0 < wide.size(); w0 += chunk) {
+            const int m = (int)std::min(chunk, wide.size() - w0);
+            std::vector<int32_t> qn(m), ql(m), sl(m);
+            std::vector<uint8_t> qt(m);
+            std::vector<double> qb(m);
+            for (int k = 0; k < m; k++) {
+                const int node = nodes[wide[w0 + k]];
+                qn[k] = node; sl[k] = wide[w0 + k];
+                ql[k] = c->h_tree_lower[node];                         // the removed subtree's lower list (M:6838)
+                qt[k] = c->h_tree_tip[node];                           // isRemovedTip (M:6846)
+                qb[k] = c->h_tree_dist[node];                          // removedBLen = dist[node] (M:9644)
+            }
+            HIPCK(c, c->s_cache.reserve((size_t)m * nT));
+            TRY(h2d(c, c->s_i32[6], ql.data(), (size_t)m));
+            TRY(h2d(c, c->s_u8[3], qt.data(), (size_t)m));
+            TRY(h2d(c, c->s_f64[3], qb.data(), (size_t)m));
+            const long long tiles = (long long)m * ((nT + MAPLE_BLOCK - 1) / MAPLE_BLOCK);
+            const int grid = tiles < 256 * 8 ? (int)tiles : 256 * 8;
+            hipEvent_t e0, e1;
+            TRY(ev_pair(c, &e0, &e1));
+            HIPCK(c, hipEventRecord(e0, c->stream));
+            DISPATCH3(c, k_append_queries, <<<grid, MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), m, c->s_i32[6].p, nT,
+                                                                               c->dtree.totUp, 0, 0.0, c->s_cache.p,
+                                                                               c->s_u8[3].p, c->s_f64[3].p));
+            HIPCK(c, hipGetLastError());
+            HIPCK(c, hipEventRecord(e1, c->stream));
+            TRY(run_queries(qn, sl, c->s_cache.p, 0));
+        }
     }
     for (int i = 0; i < n; i++) {
         bestNode[i] = ho[i].bestNode; bestScore[i] = ho[i].bestScore;

@@ -99,6 +99,12 @@ template <bool RV, bool U, bool SS> struct Search {
     const SearchParams &P;
     LaneWs &ws;
     int nAppend;
+    // Cached regime: when the search has stopped updating partials (needsUpdating False) the score of a branch is
+    // appendProbNode(probVectTotUp[t1], removed list, ...) -- a pure function of (query, branch) that a batch kernel
+    // computes ~50x faster per placement.  `cached` (if set) is this query's row of such scores, indexed by node.
+    const double *cached = nullptr;
+    int budget = 0;                    // > 0: give up (status -5) after this many traversal placements without a cache
+    bool overBudget = false;
     // optional visit trace of ONE query (debugging / parity of the visit sequence)
     int32_t *trI = nullptr; double *trD = nullptr; int trN = 0, trCap = 0;
     __device__ inline void trace(int t1, int dir, int upd, int fails, double lastLK, double midProb)
@@ -298,7 +304,9 @@ template <bool RV, bool U, bool SS> struct Search {
                     distance = T.dist[t1];
                 }
                 if (!valid(midTot)) return;
-                midProb = opAppend(midTot, hRpr, isRemovedTip, removedBLen);
+                if (cached && !it.upd) { midProb = cached[t1]; nAppend++; }   // only items that ARRIVED in the cached regime
+                else midProb = opAppend(midTot, hRpr, isRemovedTip, removedBLen);
+                if (budget > 0 && !cached && nAppend > budget) { overBudget = true; return; }
                 if (midProb > bestLKdiff - P.thrOptTopo) {            // M:7071-7082
                     if (upd) record(t1, midProb, hPassed, treeList(T.lower[t1]), distance, midTot, hRpr);
                     else record(t1, midProb, -1, -1, 0.0, -1, hRpr);
@@ -345,7 +353,9 @@ template <bool RV, bool U, bool SS> struct Search {
                     if (!opDiffer(midTot, cached)) upd = false;
                 } else midTot = treeList(T.totUp[t1]);
                 if (!valid(midTot)) return;
-                midProb = opAppend(midTot, hRpr, isRemovedTip, removedBLen);
+                if (cached && !it.upd) { midProb = cached[t1]; nAppend++; }   // only items that ARRIVED in the cached regime
+                else midProb = opAppend(midTot, hRpr, isRemovedTip, removedBLen);
+                if (budget > 0 && !cached && nAppend > budget) { overBudget = true; return; }
                 if (midProb >= (bestLKdiff - P.thrOptTopo)) {         // M:7293-7304 (>= here, > on the way down)
                     if (upd) record(t1, midProb, vectUp, midBottom, T.dist[t1], midTot, hRpr);
                     else record(t1, midProb, -1, -1, 0.0, -1, hRpr);

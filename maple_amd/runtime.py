@@ -22,7 +22,7 @@ EXPORTS = [
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
     "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read",
-    "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
+    "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
 ]
 
 
@@ -36,7 +36,7 @@ class MapleSearchParams(C.Structure):
     _fields_ = [("strictTopologyStopRules", C.c_int32), ("allowedFailsTopology", C.c_int32),
                 ("thresholdLogLKtopology", C.c_double), ("thresholdTopologyPlacement", C.c_double),
                 ("thresholdLogLKoptimizationTopology", C.c_double), ("thresholdLogLKconsecutivePlacement", C.c_double),
-                ("effectivelyNon0BLen", C.c_double)]
+                ("effectivelyNon0BLen", C.c_double), ("wideSearchBudget", C.c_int32)]
 
 
 class MapleError(RuntimeError):
@@ -233,6 +233,12 @@ class Device:
         self._ck(self.lib.maple_differ_batch(self.h, len(l1), _ptr(l1), _ptr(l2), _ptr(out)))
         return out.astype(bool)
 
+    def root_prob_batch(self, lists):
+        lists = _i32(lists)
+        out = np.zeros(len(lists))
+        self._ck(self.lib.maple_root_prob_batch(self.h, len(lists), _ptr(lists), _ptr(out)))
+        return out
+
     def minor_batch(self, l1, l2, onlyFindIdentical=False):
         l1, l2 = _i32(l1), _i32(l2)
         out = np.zeros(len(l1), dtype=np.uint8)
@@ -292,13 +298,13 @@ class Device:
 
     def spr_search_batch(self, nodes, *, strict, allowedFails, thresholdLogLKtopology, thresholdTopologyPlacement,
                          thresholdLogLKoptimizationTopology, thresholdLogLKconsecutivePlacement, effectivelyNon0BLen,
-                         ws_entries_per_lane=0, want_removed_partials=False):
+                         ws_entries_per_lane=0, want_removed_partials=False, wide_search_budget=0):
         """startTopologyUpdatesParallel's worker body (M:9615-9711) for `nodes`, searches run on the GPU."""
         nodes = _i32(nodes)
         n = len(nodes)
         sp = MapleSearchParams(int(bool(strict)), int(allowedFails), thresholdLogLKtopology, thresholdTopologyPlacement,
                                thresholdLogLKoptimizationTopology, thresholdLogLKconsecutivePlacement,
-                               effectivelyNon0BLen)
+                               effectivelyNon0BLen, int(wide_search_budget))
         out = dict(bestNode=np.zeros(n, np.int32), bestScore=np.zeros(n), blen=np.zeros((n, 3)),
                    placement=np.zeros(n, np.int32), improvement=np.zeros(n), currentLK=np.zeros(n),
                    nAppend=np.zeros(n, np.int32), status=np.zeros(n, np.int32))

@@ -70,3 +70,46 @@ class HostTree:
         dev.upload_tree(self.root, up, c0, c1, self.dist, is_tip, self.id_lower, self.id_upRight, self.id_upLeft,
                         self.id_totUp, self.id_mut)
         return self
+
+
+def tree_log_likelihood(dev: Device, tree: HostTree):
+    """calculateTreeLikelihood (M:9721-9779) on the uploaded tree: one merge launch (returnLK) over every internal
+    node's two stored lower lists, one findProbRoot launch, summed in the reference's post-order."""
+    order = []                                   # internal nodes in the order the reference adds their contribution
+    stack = [(tree.root, False)]
+    while stack:
+        v, done = stack.pop()
+        if not tree.children[v]:
+            continue
+        if done:
+            order.append(v)
+        else:
+            stack.append((v, True))
+            stack.append((tree.children[v][1], False))
+            stack.append((tree.children[v][0], False))
+    mark = dev.mark()
+    try:
+        c0 = np.asarray([tree.children[v][0] for v in order])
+        c1 = np.asarray([tree.children[v][1] for v in order])
+        l0, l1 = tree.id_lower[c0].copy(), tree.id_lower[c1].copy()
+        for arr, ch in ((l0, c0), (l1, c1)):
+            need = np.nonzero(tree.id_mut[ch] >= 0)[0]
+            if len(need):
+                arr[need] = dev.pass_branch_batch(arr[need], tree.id_mut[ch[need]], True)
+        dist = np.asarray(tree.dist)
+        tip = np.asarray([(not c) and (m == 0) for c, m in zip(tree.children, tree.n_minor)])
+        nminor = np.asarray(tree.n_minor, dtype=np.int32)
+        out, lk = dev.merge_batch(l0, dist[c0], tip[c0], l1, dist[c1], tip[c1], False, returnLK=True,
+                                  numMinor1=nminor[c0], numMinor2=nminor[c1])
+        if (out < 0).any():
+            raise RuntimeError("inconsistent lower genome lists (the reference raises here, M:9761)")
+        total = 0.0
+        for x in lk.tolist():
+            total += x
+        root_list = tree.id_lower[tree.root]
+        if tree.id_mut[tree.root] >= 0:
+            root_list = dev.pass_branch_batch([root_list], [tree.id_mut[tree.root]], True)[0]
+        root_lk = float(dev.root_prob_batch([root_list])[0])
+        return total + root_lk, root_lk
+    finally:
+        dev.release(mark)

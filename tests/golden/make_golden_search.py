@@ -100,6 +100,12 @@ def run(name, flags):
     for i in range(len(tree.replacements)):
         tree.replacements[i] = 0
     snap = snapshot_tree(tree, t1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tree_lk = g["calculateTreeLikelihood"](tree, t1)          # the parity metric "tree log-LK" (M:9721-9779)
+        root_pv = tree.probVect[t1]
+        if tree.mutations[t1]:
+            root_pv = g["passGenomeListThroughBranch"](root_pv, tree.mutations[t1], dirIsUp=True)
+        root_lk = g["findProbRoot"](root_pv)
     lRef = g["lRef"]
     model = dict(useRateVariation=bool(g["useRateVariation"]), usingErrorRate=bool(g["usingErrorRate"]),
                  errorRateSiteSpecific=bool(g["errorRateSiteSpecific"]), Q=[list(r) for r in g["mutMatrixGlobal"]],
@@ -201,7 +207,8 @@ def run(name, flags):
     print(f"[{name}] {len(placements)} placement searches, "
           f"{sum(p['n_append'] for p in placements)} appendProbNode calls", flush=True)
 
-    fixture = dict(name=name, flags=flags, context=ctx, model=model, tree=snap, spr=spr, placements=placements)
+    fixture = dict(name=name, flags=flags, context=ctx, model=model, tree=snap, spr=spr, placements=placements,
+                   treeLK=tree_lk, rootLK=root_lk)
     path = os.path.join(HERE, f"search_{name}.json.gz")
     with gzip.open(path, "wt") as fh:
         json.dump(fixture, fh)

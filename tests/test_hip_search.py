@@ -127,3 +127,49 @@ def test_placement_search_matches_reference(env):
             n_real += 1
         assert lists_match(best_diffs, tup(want["bestDiffs"]), 0.0), (best_diffs, want["bestDiffs"])
     assert n_real > 20
+
+
+def test_tree_log_likelihood_matches_reference(env):
+    """The parity metric of BASELINE.json: tree log-LK (calculateTreeLikelihood, M:9721) within 1e-6 relative
+    (observed ~1e-14) on the reference's own final tree."""
+    from maple_amd.tree_host import tree_log_likelihood
+    f, dev, tree = env
+    if "treeLK" not in f:
+        pytest.skip("fixture predates the tree-LK record")
+    got, got_root = tree_log_likelihood(dev, tree)
+    assert close(got_root, f["rootLK"], 1e-12), (got_root, f["rootLK"])
+    assert close(got, f["treeLK"], 1e-11), (got, f["treeLK"])
+    assert abs(got - f["treeLK"]) / abs(f["treeLK"]) < 1e-6
+
+
+def test_wide_searches_batch_scored_identically():
+    """Deep-round searches that walk most of the tree are batch-scored (k_append_queries) and replayed over the cached
+    scores; every output must be bit-identical to the plain lane-sequential search (a size-independent property,
+    checked on a synthetic 1500-tip tree built on the GPU)."""
+    import math
+    from maple_amd.host import reference_tables, tip_genome_list
+    from maple_amd.runtime import Device
+    from maple_amd.synth import make_dataset
+    from maple_amd.tree_mirror import TreeMirror
+    data = make_dataset(n_samples=1500, l_ref=29903, seed=3, mean_diffs=30.0)
+    ref_idx, rf = reference_tables(data.ref)
+    dev = Device(ref_idx, rf, arena_bytes=1 << 30)
+    dev.set_model([[-0.55, 0.06, 0.37, 0.12], [0.17, -2.6, 0.04, 2.39], [0.84, 0.13, -2.4, 1.43], [0.07, 0.48, 0.05, -0.6]])
+    tips = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
+    m = TreeMirror(dev, data.parent, data.blen, tips).build()
+    dev.upload_tree(m.root, m.parent, m.children[:, 0], m.children[:, 1], m.dist, m.is_tip, m.lower, m.up_right, m.up_left,
+                    m.tot_up, -np.ones(m.n_nodes, dtype=np.int32))
+    ll = math.log(dev.lRef)
+    kw = dict(strict=False, allowedFails=4, thresholdLogLKtopology=14.0 * ll, thresholdTopologyPlacement=-0.1,
+              thresholdLogLKoptimizationTopology=ll, thresholdLogLKconsecutivePlacement=1.0,
+              effectivelyNon0BLen=1.0 / (10 * dev.lRef))
+    nodes = np.arange(m.n_nodes)
+    plain = dev.spr_search_batch(nodes, wide_search_budget=-1, **kw)
+    hybrid = dev.spr_search_batch(nodes, wide_search_budget=64, **kw)
+    assert (plain["status"] >= 0).all() and (plain["nAppend"] > 64).sum() > 50
+    for k in ("status", "bestNode", "placement", "nAppend", "bestScore", "blen", "improvement", "currentLK"):
+        assert np.array_equal(plain[k], hybrid[k]), k
+    # and a sanity property of every proposed move: it improves on the current placement by the accept margin
+    mv = plain["placement"] >= 0
+    assert (plain["bestScore"][mv] - 0.1 > plain["currentLK"][mv]).all()
+    dev.close()
