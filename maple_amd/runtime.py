@@ -53,6 +53,12 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise MapleError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`; "
                              "there is no CPU fallback for the placement path")
+        # PyTorch-ROCm ships its own HIP runtime; whichever copy of libamdhip64 is loaded first serves the whole
+        # process, and torch cannot see the GPU if the system copy got there before it.  Load torch's first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         lib.maple_last_error.restype = C.c_char_p
         for name in EXPORTS:

@@ -1,0 +1,159 @@
+"""GPU checks at BASELINE-like sizes through properties that do not depend on the size (the reference cannot be run
+at these sizes in minutes; the C oracle, itself pinned to the reference's golden calls, is the checker on samples):
+
+* model modes of configs[2] and configs[3]: UNREST + per-site rates, + per-site error rates;
+* the query-major kernel against the oracle on a seeded sample of (query, candidate) pairs of a 10 000-tip tree;
+* tree log-likelihood of the whole GPU-built mirror against the oracle's post-order sum;
+* passGenomeListThroughBranch up then down restores the list (after shorten);
+* shorten is idempotent; a list is never "different" from itself; merging is symmetric in the likelihood it returns.
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+Q = [[-0.5524, 0.0602, 0.3655, 0.1267], [0.1666, -2.6077, 0.0405, 2.4006],
+     [0.8421, 0.1305, -2.4012, 1.4286], [0.0688, 0.4849, 0.0502, -0.6039]]
+
+
+def build(n_tips, mode, seed=2):
+    from maple_amd.host import reference_tables, tip_genome_list
+    from maple_amd.runtime import Device
+    from maple_amd.synth import make_dataset
+    from maple_amd.tree_mirror import TreeMirror
+    from oracle.oracle_py import Oracle
+    data = make_dataset(n_samples=n_tips, l_ref=29903, seed=seed, mean_diffs=30.0, rate_variation=(mode != "unrest"),
+                        frac_with_n=0.05, frac_ambig=0.05)
+    ref_idx, rf = reference_tables(data.ref)
+    rng = np.random.default_rng(seed + 100)
+    kw = dict(Q=Q)
+    if mode != "unrest":
+        kw["siteRates"] = np.clip(rng.gamma(0.5, 2.0, size=len(ref_idx)), 0.001, 0.005 * len(ref_idx))
+    if mode == "siteerr":
+        er = np.exp(rng.uniform(math.log(1e-10), math.log(1e-3), size=len(ref_idx)))
+        kw.update(usingErrorRate=True, errorRates=er, errorRateGlobal=float(er.mean()))
+    dev = Device(ref_idx, rf, arena_bytes=3 << 30)
+    dev.set_model(**kw)
+    orc = Oracle(ref_idx, rf)
+    orc.set_model(**kw)
+    tip_kw = dict(error_rates=kw["errorRates"]) if mode == "siteerr" else {}
+    tips = {int(v): tip_genome_list(dl, ref_idx, **tip_kw) for v, dl in zip(data.tip_node, data.diffs)}
+    mirror = TreeMirror(dev, data.parent, data.blen, tips).build()
+    return data, dev, orc, mirror
+
+
+@pytest.fixture(scope="module", params=["unrest", "ratevar", "siteerr"])
+def world(request):
+    n = 10000 if request.param == "unrest" else 3000
+    data, dev, orc, mirror = build(n, request.param)
+    yield request.param, data, dev, orc, mirror
+    dev.close()
+
+
+def rel(a, b):
+    if a == b:
+        return 0.0
+    return abs(a - b) / max(1.0, abs(a), abs(b))
+
+
+def test_query_major_kernel_vs_oracle_sample(world):
+    import torch
+    mode, data, dev, orc, mirror = world
+    l_ref = dev.lRef
+    cand = mirror.candidate_nodes(1.0 / (10 * l_ref))
+    q_nodes = np.asarray(data.tip_node[:64])
+    cu = torch.device("cuda", 0)
+    t_q = torch.from_numpy(mirror.lower[q_nodes].astype(np.int32)).to(cu)
+    t_c = torch.from_numpy(mirror.tot_up[cand].astype(np.int32)).to(cu)
+    out = torch.empty(len(q_nodes) * len(cand), dtype=torch.float64, device=cu)
+    torch.cuda.synchronize()
+    dev.append_queries_dev(len(q_nodes), t_q.data_ptr(), len(cand), t_c.data_ptr(), True, 1.0 / l_ref, out.data_ptr(),
+                           torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(len(q_nodes), len(cand))
+    assert np.isfinite(got).mean() > 0.99
+    rng = np.random.default_rng(5)
+    qi = rng.integers(len(q_nodes), size=400)
+    ci = rng.integers(len(cand), size=400)
+    q_lists = dev.download(mirror.lower[q_nodes])
+    keys = sorted(set(ci.tolist()))
+    c_lists = dict(zip(keys, dev.download(mirror.tot_up[cand[keys]])))
+    worst = 0.0
+    for a, b in zip(qi, ci):
+        want = orc.appendProbNode(c_lists[int(b)], q_lists[int(a)], True, 1.0 / l_ref)
+        g = float(got[a, b])
+        if math.isinf(want):
+            assert math.isinf(g)
+        else:
+            worst = max(worst, rel(g, want))
+    assert worst < 1e-12, worst
+    # each query scored against its own branch must be (one of) its best placements: the tree was built from the truth
+    own = np.asarray([np.nonzero(cand == v)[0][0] if (cand == v).any() else -1 for v in q_nodes])
+    ok = own >= 0
+    best = got.max(axis=1)
+    assert (got[np.arange(len(q_nodes))[ok], own[ok]] >= best[ok] - 25.0).mean() > 0.9
+
+
+def test_tree_log_likelihood_vs_oracle(world):
+    mode, data, dev, orc, mirror = world
+    n = mirror.n_nodes
+    ch = mirror.children
+    internal = [v for v in range(n) if ch[v, 0] >= 0]
+    c0, c1 = ch[internal, 0], ch[internal, 1]
+    out, lk = dev.merge_batch(mirror.lower[c0], mirror.dist[c0], mirror.is_tip[c0], mirror.lower[c1], mirror.dist[c1],
+                              mirror.is_tip[c1], False, returnLK=True)
+    assert (out >= 0).all()
+    root_lk = float(dev.root_prob_batch([mirror.lower[mirror.root]])[0])
+    total = float(lk.sum()) + root_lk
+    # oracle on a seeded sample of internal nodes + the root
+    rng = np.random.default_rng(9)
+    pick = rng.choice(len(internal), size=150, replace=False)
+    lists0 = dev.download(mirror.lower[c0[pick]])
+    lists1 = dev.download(mirror.lower[c1[pick]])
+    merged = dev.download(out[pick])
+    for k, i in enumerate(pick):
+        res, want = orc.mergeVectors(lists0[k], mirror.dist[c0[i]], bool(mirror.is_tip[c0[i]]), lists1[k],
+                                     mirror.dist[c1[i]], bool(mirror.is_tip[c1[i]]), returnLK=True)
+        assert rel(float(lk[i]), want) < 1e-12
+        assert len(res) == len(merged[k]) and all(x[0] == y[0] and x[1] == y[1] for x, y in zip(res, merged[k]))
+    want_root = orc.findProbRoot(dev.download([mirror.lower[mirror.root]])[0], [[]])
+    assert rel(root_lk, want_root) < 1e-12
+    assert math.isfinite(total) and total < 0
+    # symmetry: swapping the two children gives the same likelihood contribution
+    out2, lk2 = dev.merge_batch(mirror.lower[c1[pick]], mirror.dist[c1[pick]], mirror.is_tip[c1[pick]],
+                                mirror.lower[c0[pick]], mirror.dist[c0[pick]], mirror.is_tip[c0[pick]], False, returnLK=True)
+    assert np.allclose(lk2, lk[pick], rtol=1e-12, atol=0)
+
+
+def test_structural_properties(world):
+    mode, data, dev, orc, mirror = world
+    rng = np.random.default_rng(3)
+    ids = mirror.tot_up[mirror.candidate_nodes(0.0)][:2000]
+    mark = dev.mark()
+    # shorten is idempotent and a list never differs from itself or from its shortened form
+    s1 = dev.shorten_batch(ids)
+    s2 = dev.shorten_batch(s1)
+    n1, _ = dev.sizes(s1)
+    n2, _ = dev.sizes(s2)
+    assert np.array_equal(n1, n2)
+    assert not dev.differ_batch(ids, ids).any()
+    assert not dev.differ_batch(ids, s1).any()
+    # a change of reference frame and back restores the list
+    muts = []
+    nuc = {"a": 0, "c": 1, "g": 2, "t": 3}
+    for _ in range(len(ids)):
+        pos = sorted(rng.choice(dev.lRef, size=5, replace=False) + 1)
+        ml = []
+        for p in pos:
+            r = nuc[data.ref[p - 1]]
+            ml.append((int(p), r, int((r + 1 + rng.integers(3)) % 4)))
+        muts.append(ml)
+    mids = dev.upload_mutations(muts)
+    down = dev.pass_branch_batch(ids, mids, False)
+    back = dev.shorten_batch(dev.pass_branch_batch(down, mids, True))
+    a = dev.download(s1[:300])
+    b = dev.download(back[:300])
+    assert a == b
+    dev.release(mark)
