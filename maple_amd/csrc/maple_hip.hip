@@ -82,6 +82,7 @@ struct maple_ctx {
     DevBuf<int32_t> t_i32[9];
     DevBuf<double> t_dist;
     DevBuf<uint8_t> t_tip;
+    DevBuf<uint8_t> t_nodes;           // NodeRec[n], 64-byte aligned
     std::vector<int32_t> h_tree_up, h_tree_lower;
     std::vector<double> h_tree_dist;
     std::vector<uint8_t> h_tree_tip;
@@ -435,22 +436,22 @@ __global__ __launch_bounds__(64) void k_spr_search(const DevModel *__restrict__ 
             o.bestScore = 0.0; o.improvement = 0.0; o.currentLK = 0.0;
             o.blen[0] = o.blen[1] = o.blen[2] = 0.0;
             o.rprWoff = o.rprAoff = -1; o.rprN = o.rprNA = 0;
-            const int parent = T.up[node];
+            const int parent = T.nd[node].up;
             if (parent < 0) { o.status = 1; continue; }               // the root cannot be re-placed (M:9626)
             // current placement cost, M:9629-9646
-            const int childIdx = (T.c0[parent] == node) ? 0 : 1;
-            int vectUp = S.opPass(S.treeList(childIdx == 0 ? T.upRight[parent] : T.upLeft[parent]), T.mutId[node], false);
+            const int childIdx = (T.nd[parent].c0 == node) ? 0 : 1;
+            int vectUp = S.opPass(S.treeList(childIdx == 0 ? T.nd[parent].upRight : T.nd[parent].upLeft), T.nd[node].mutId, false);
             if (!S.valid(vectUp)) { o.status = ws.overflow ? -3 : -1; continue; }
-            curLK = append_walk(c, S.ref(vectUp), S.ref(S.treeList(T.lower[node])), T.isTip[node] != 0, T.dist[node]);
+            curLK = append_walk(c, S.ref(vectUp), S.ref(S.treeList(T.nd[node].lower)), T.nd[node].isTip != 0, T.nd[node].dist);
             o.currentLK = curLK;
-            if (!(curLK < P.thrPlacement || T.dist[node] != 0.0)) { o.status = 2; continue; }   // M:9674
+            if (!(curLK < P.thrPlacement || T.nd[node].dist != 0.0)) { o.status = 2; continue; }   // M:9674
             ws.usedW = ws.usedA = ws.nH = 0;
             S.cached = cacheS ? cacheS + (size_t)q * T.n : nullptr;       // row q of the (queries x nodes) score table
             S.budget = budget;
             S.overBudget = false;
             S.trI = nullptr;
             if (q == traceQuery && trI) { S.trI = trI; S.trD = trD; S.trCap = trCap; S.trN = 0; }
-            S.begin(parent, childIdx, curLK, T.dist[node]);
+            S.begin(parent, childIdx, curLK, T.nd[node].dist);
             active = true;
         } else if (ws.overflow) {
             out[q].status = -3;                                       // workspace exhausted: the host retries with more
@@ -486,14 +487,14 @@ __global__ __launch_bounds__(64) void k_spr_search(const DevModel *__restrict__ 
             // accept rule and the four "same place" vetoes, M:9681-9700
             if (S.bestScore + P.thrPlacement > curLK) {
                 bool updated = true;
-                int topNode = T.up[node];
+                int topNode = T.nd[node].up;
                 if (S.bestNode == topNode) updated = false;
-                while (T.dist[topNode] == 0.0 && T.up[topNode] >= 0) topNode = T.up[topNode];
+                while (T.nd[topNode].dist == 0.0 && T.nd[topNode].up >= 0) topNode = T.nd[topNode].up;
                 if (S.bestNode == topNode && S.bl1 == 0.0) updated = false;
-                const int par = T.up[node];
-                const int sib = (T.c0[par] == node) ? T.c1[par] : T.c0[par];
+                const int par = T.nd[node].up;
+                const int sib = (T.nd[par].c0 == node) ? T.nd[par].c1 : T.nd[par].c0;
                 if (S.bestNode == sib) updated = false;
-                if (T.up[S.bestNode] == sib && S.bl0 == 0.0) updated = false;
+                if (T.nd[S.bestNode].up == sib && S.bl0 == 0.0) updated = false;
                 if (updated) { o.improvement = S.bestScore - curLK; o.placement = S.bestNode; }
             }
             active = false;
@@ -628,7 +629,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     for (auto &b : c->s_i64) b.release();
     c->s_words.release(); c->s_aux.release(); c->s_ais.release();
     for (auto &b : c->t_i32) b.release();
-    c->t_dist.release(); c->t_tip.release();
+    c->t_dist.release(); c->t_tip.release(); c->t_nodes.release();
     c->s_search_ws.release(); c->s_search_out.release(); c->s_counter.release(); c->s_cache.release();
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1271,12 +1272,21 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     TRY(h2d(c, c->t_dist, dist, (size_t)n));
     TRY(h2d(c, c->t_tip, isTip, (size_t)n));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    std::vector<NodeRec> recs((size_t)n);
+    for (int i = 0; i < n; i++) {
+        NodeRec &r = recs[i];
+        memset(&r, 0, sizeof r);
+        r.up = up[i]; r.c0 = child0[i]; r.c1 = child1[i];
+        r.lower = lower[i]; r.upRight = upRight[i]; r.upLeft = upLeft[i]; r.totUp = totUp[i];
+        r.mutId = mutList[i]; r.dist = dist[i]; r.isTip = isTip[i];
+    }
+    HIPCK(c, c->t_nodes.reserve((size_t)n * sizeof(NodeRec) + 64));
+    uint8_t *aligned = (uint8_t *)(((uintptr_t)c->t_nodes.p + 63) & ~(uintptr_t)63);
+    HIPCK(c, hipMemcpy(aligned, recs.data(), (size_t)n * sizeof(NodeRec), hipMemcpyHostToDevice));
     DevTree &T = c->dtree;
     T.n = n; T.root = root;
-    T.up = c->t_i32[0].p; T.c0 = c->t_i32[1].p; T.c1 = c->t_i32[2].p;
-    T.lower = c->t_i32[3].p; T.upRight = c->t_i32[4].p; T.upLeft = c->t_i32[5].p; T.totUp = c->t_i32[6].p;
-    T.mutId = c->t_i32[7].p;
-    T.dist = c->t_dist.p; T.isTip = c->t_tip.p;
+    T.nd = (const NodeRec *)aligned;
+    T.totUp = c->t_i32[6].p;
     c->h_tree_up.assign(up, up + n);
     c->h_tree_lower.assign(lower, lower + n);
     c->h_tree_dist.assign(dist, dist + n);

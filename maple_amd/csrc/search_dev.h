@@ -10,6 +10,14 @@
 #pragma once
 #include "genome_dev.h"
 
+// MAPLE_SEARCH_OP decides whether the list operations of the search are real calls or inlined into the kernel.
+// Measured (10 000-tip tree, deep round): inlined = 243 ms at 1 wave/SIMD, 2 min compile, 3 MB binary; calls = 257 ms
+// at 2 waves/SIMD, 25 s compile.  The search is bound by the dependent-instruction latency of single lanes either way,
+// so the smaller kernel with the higher occupancy is kept.
+#ifndef MAPLE_SEARCH_OP
+#define MAPLE_SEARCH_OP __noinline__
+#endif
+
 namespace maple {
 
 struct ArenaViewS {                    // same fields as ArenaView in maple_hip.hip (kept POD for kernel args)
@@ -27,13 +35,21 @@ struct MutViewS {
     const int32_t *cnt;
 };
 
+// One 64-byte record per node: a search step touches a node and its relatives, and with one record per cache line
+// that is one memory transaction per node instead of ten (the search is a chain of dependent loads).
+struct alignas(64) NodeRec {
+    int32_t up, c0, c1;                // -1 = none
+    int32_t lower, upRight, upLeft, totUp;   // list ids, -1 = None
+    int32_t mutId;                     // mutation-list id of the branch above the node, -1 = empty
+    double dist;
+    uint8_t isTip;                     // leaf without minor sequences
+    uint8_t pad[23];
+};
+
 struct DevTree {
     int32_t n, root;
-    const int32_t *up, *c0, *c1;       // -1 = none
-    const double *dist;
-    const uint8_t *isTip;              // leaf without minor sequences
-    const int32_t *lower, *upRight, *upLeft, *totUp;   // list ids, -1 = None
-    const int32_t *mutId;              // mutation-list id of the branch above the node, -1 = empty
+    const NodeRec *nd;
+    const int32_t *totUp;              // also kept as a flat column: the candidate list of the batch-scoring kernel
 };
 
 struct SearchParams {
@@ -137,7 +153,7 @@ template <bool RV, bool U, bool SS> struct Search {
         if (listId < 0) return -1;
         return ws.newHandle(av.words + av.ent_off[listId], av.aux + av.aux_off[listId], av.n_ent[listId], av.n_aux[listId]);
     }
-    __device__ __noinline__ int opPass(int hid, int mutId, bool dirUp)
+    __device__ MAPLE_SEARCH_OP int opPass(int hid, int mutId, bool dirUp)
     {
         if (!valid(hid) || mutId < 0) return hid;
         int cnt = mv.cnt[mutId];
@@ -148,7 +164,7 @@ template <bool RV, bool U, bool SS> struct Search {
         pass_walk(c.m.lRef, ref(hid), mv.mut3 + 3 * mv.off[mutId], cnt, dirUp, wr);
         return ws.commit(wr);
     }
-    __device__ __noinline__ int opMerge(int h1, double b1, bool t1, int h2, double b2, bool t2, bool upDown)
+    __device__ MAPLE_SEARCH_OP int opMerge(int h1, double b1, bool t1, int h2, double b2, bool t2, bool upDown)
     {
         if (!valid(h1) || !valid(h2)) return -2;
         if (!ws.reserve(len(h1) + len(h2))) return -2;
@@ -159,7 +175,7 @@ template <bool RV, bool U, bool SS> struct Search {
         if (r < 0) return -2;
         return ws.commit(wr);
     }
-    __device__ __noinline__ void opShortenInPlace(int hid)
+    __device__ MAPLE_SEARCH_OP void opShortenInPlace(int hid)
     {
         if (hid < 0) return;                                          // only real handles can be repointed
         int n = ws.h[hid].n;
@@ -171,28 +187,28 @@ template <bool RV, bool U, bool SS> struct Search {
         ws.h[hid] = TList{ws.w + ws.usedW, ws.aux + ws.usedA, wr.n, wr.na};
         ws.usedW += wr.n; ws.usedA += wr.na;
     }
-    __device__ __noinline__ double opAppend(int hP, int hC, bool isTipC, double bLen)
+    __device__ MAPLE_SEARCH_OP double opAppend(int hP, int hC, bool isTipC, double bLen)
     {
         nAppend++;
         return append_walk(c, ref(hP), ref(hC), isTipC, bLen);
     }
-    __device__ __noinline__ double opBlen(int hP, int hC, bool fromTipC)
+    __device__ MAPLE_SEARCH_OP double opBlen(int hP, int hC, bool fromTipC)
     {
         bool f;
         if (len(hP) + len(hC) > ws.L.capAis) { ws.overflow = true; return 0.0; }
         return blen_walk(c, ref(hP), ref(hC), fromTipC, ws.ais, 1, &f);
     }
-    __device__ __noinline__ bool opDiffer(int h1, int h2)
+    __device__ MAPLE_SEARCH_OP bool opDiffer(int h1, int h2)
     {
         if (!valid(h2)) return true;
         return differ_walk(c, ref(h1), ref(h2));
     }
     // rootVector(probVect, bLen, isFromTip, tree, node), M:4916-4996
-    __device__ __noinline__ int opRootVector(int hid, double bLen, bool isFromTip, int node)
+    __device__ MAPLE_SEARCH_OP int opRootVector(int hid, double bLen, bool isFromTip, int node)
     {
         int cur = hid;
         if (!valid(cur)) return -2;
-        for (int v = node; v >= 0; v = T.up[v]) { cur = opPass(cur, T.mutId[v], true); if (!valid(cur)) return -2; }
+        for (int v = node; v >= 0; v = T.nd[v].up) { cur = opPass(cur, T.nd[v].mutId, true); if (!valid(cur)) return -2; }
         if (!ws.reserve(len(cur))) return -2;
         Writer wr;
         wr.init(ws.w + ws.usedW, ws.aux + ws.usedA);
@@ -201,11 +217,11 @@ template <bool RV, bool U, bool SS> struct Search {
         if (cur < 0) return -2;
         // back down: root first ... node last (M:4988-4993); walk the path again from the top
         int depth = 0;
-        for (int v = node; v >= 0; v = T.up[v]) depth++;
+        for (int v = node; v >= 0; v = T.nd[v].up) depth++;
         for (int k = depth - 1; k >= 0; k--) {
             int v = node;
-            for (int s = 0; s < k; s++) v = T.up[v];
-            cur = opPass(cur, T.mutId[v], false);
+            for (int s = 0; s < k; s++) v = T.nd[v].up;
+            cur = opPass(cur, T.nd[v].mutId, false);
             if (cur < 0) return -2;                                  // always a real handle after root_walk
         }
         opShortenInPlace(cur);
@@ -224,8 +240,8 @@ template <bool RV, bool U, bool SS> struct Search {
         if (ws.nB >= ws.L.capB) { ws.overflow = true; return; }
         ws.best[ws.nB++] = BestRec{t1, hUp, hDown, hMid, hRpr, score, distance};
     }
-    __device__ inline int child(int v, int k) const { return k == 0 ? T.c0[v] : T.c1[v]; }
-    __device__ inline int upVectOf(int t1) const { return (T.c0[T.up[t1]] == t1) ? T.upRight[T.up[t1]] : T.upLeft[T.up[t1]]; }
+    __device__ inline int child(int v, int k) const { return k == 0 ? T.nd[v].c0 : T.nd[v].c1; }
+    __device__ inline int upVectOf(int t1) const { return (T.nd[T.nd[t1].up].c0 == t1) ? T.nd[T.nd[t1].up].upRight : T.nd[T.nd[t1].up].upLeft; }
 
     // search state
     int node, removed, sibling;
@@ -236,7 +252,7 @@ template <bool RV, bool U, bool SS> struct Search {
     int refineIdx;
 
     // seeding of nodesToVisit, M:6855-6962
-    __device__ __noinline__ void begin(int node_, int childIdx, double bestLK, double remBLen)
+    __device__ MAPLE_SEARCH_OP void begin(int node_, int childIdx, double bestLK, double remBLen)
     {
         node = node_;
         removed = child(node, childIdx);
@@ -245,44 +261,44 @@ template <bool RV, bool U, bool SS> struct Search {
         bestLKdiff = originalLK = bestLK;
         bestNode = sibling;
         refineIdx = 0;
-        int rpr = opPass(ownHandle(T.lower[removed]), T.mutId[removed], true);
-        hBestRpr = opPass(rpr, T.mutId[sibling], false);
-        isRemovedTip = T.isTip[removed];
-        if (T.up[node] >= 0) {
-            int parent = T.up[node];
-            bool first = T.c0[parent] == node;
-            int vectUpUp = treeList(first ? T.upRight[parent] : T.upLeft[parent]);
-            int pv1 = opPass(treeList(T.lower[sibling]), T.mutId[sibling], true);
+        int rpr = opPass(ownHandle(T.nd[removed].lower), T.nd[removed].mutId, true);
+        hBestRpr = opPass(rpr, T.nd[sibling].mutId, false);
+        isRemovedTip = T.nd[removed].isTip;
+        if (T.nd[node].up >= 0) {
+            int parent = T.nd[node].up;
+            bool first = T.nd[parent].c0 == node;
+            int vectUpUp = treeList(first ? T.nd[parent].upRight : T.nd[parent].upLeft);
+            int pv1 = opPass(treeList(T.nd[sibling].lower), T.nd[sibling].mutId, true);
             int rpr1 = rpr;
-            if (T.mutId[node] >= 0) { pv1 = opPass(pv1, T.mutId[node], true); rpr1 = opPass(rpr, T.mutId[node], true); }
-            double d = T.dist[sibling] + T.dist[node];
+            if (T.nd[node].mutId >= 0) { pv1 = opPass(pv1, T.nd[node].mutId, true); rpr1 = opPass(rpr, T.nd[node].mutId, true); }
+            double d = T.nd[sibling].dist + T.nd[node].dist;
             push(parent, first ? 1 : 2, true, pv1, d, bestLK, 0, rpr1);
-            vectUpUp = opPass(vectUpUp, T.mutId[node], false);
+            vectUpUp = opPass(vectUpUp, T.nd[node].mutId, false);
             rpr1 = rpr;
-            if (T.mutId[sibling] >= 0) { vectUpUp = opPass(vectUpUp, T.mutId[sibling], false); rpr1 = opPass(rpr, T.mutId[sibling], false); }
+            if (T.nd[sibling].mutId >= 0) { vectUpUp = opPass(vectUpUp, T.nd[sibling].mutId, false); rpr1 = opPass(rpr, T.nd[sibling].mutId, false); }
             push(sibling, 0, true, vectUpUp, d, bestLK, 0, rpr1);
-            bl0 = T.dist[node]; bl1 = T.dist[sibling]; bl2 = remBLen;
+            bl0 = T.nd[node].dist; bl1 = T.nd[sibling].dist; bl2 = remBLen;
         } else {
-            if (T.c0[sibling] >= 0) {                                // M:6916-6960, node is the root
-                int ch1 = T.c0[sibling], ch2 = T.c1[sibling];
-                int v1 = opPass(treeList(T.lower[ch2]), T.mutId[ch2], true);
-                v1 = opRootVector(v1, T.dist[ch2], T.isTip[ch2], node);
+            if (T.nd[sibling].c0 >= 0) {                                // M:6916-6960, node is the root
+                int ch1 = T.nd[sibling].c0, ch2 = T.nd[sibling].c1;
+                int v1 = opPass(treeList(T.nd[ch2].lower), T.nd[ch2].mutId, true);
+                v1 = opRootVector(v1, T.nd[ch2].dist, T.nd[ch2].isTip, node);
                 int r1 = hBestRpr;
-                if (T.mutId[ch1] >= 0) { r1 = opPass(hBestRpr, T.mutId[ch1], false); v1 = opPass(v1, T.mutId[ch1], false); }
-                push(ch1, 0, true, v1, T.dist[ch1], bestLK, 0, r1);
-                int v2 = opPass(treeList(T.lower[ch1]), T.mutId[ch1], true);
-                v2 = opRootVector(v2, T.dist[ch1], T.isTip[ch1], node);
+                if (T.nd[ch1].mutId >= 0) { r1 = opPass(hBestRpr, T.nd[ch1].mutId, false); v1 = opPass(v1, T.nd[ch1].mutId, false); }
+                push(ch1, 0, true, v1, T.nd[ch1].dist, bestLK, 0, r1);
+                int v2 = opPass(treeList(T.nd[ch1].lower), T.nd[ch1].mutId, true);
+                v2 = opRootVector(v2, T.nd[ch1].dist, T.nd[ch1].isTip, node);
                 int r2 = hBestRpr;
-                if (T.mutId[ch2] >= 0) { r2 = opPass(hBestRpr, T.mutId[ch2], false); v2 = opPass(v2, T.mutId[ch2], false); }
-                push(ch2, 0, true, v2, T.dist[ch2], bestLK, 0, r2);
+                if (T.nd[ch2].mutId >= 0) { r2 = opPass(hBestRpr, T.nd[ch2].mutId, false); v2 = opPass(v2, T.nd[ch2].mutId, false); }
+                push(ch2, 0, true, v2, T.nd[ch2].dist, bestLK, 0, r2);
             }
-            bl0 = 0.0; bl1 = T.dist[sibling]; bl2 = remBLen;
+            bl0 = 0.0; bl1 = T.nd[sibling].dist; bl2 = remBLen;
         }
         bestScore = originalLK;
     }
 
     // one iteration of "while nodesToVisit", M:6964-7434
-    __device__ __noinline__ void step()
+    __device__ MAPLE_SEARCH_OP void step()
     {
         StackItem it = ws.st[--ws.sp];
         const int t1 = it.t1;
@@ -292,23 +308,23 @@ template <bool RV, bool U, bool SS> struct Search {
         double distance = it.distance;
         double midProb;
         if (it.dir == 0) {                                           // moving from a parent to its child
-            const int upT = T.up[t1];
-            if (!(upT == node || upT < 0) && (T.dist[t1] > P.effNon0 || T.up[upT] < 0)) {
+            const int upT = T.nd[t1].up;
+            if (!(upT == node || upT < 0) && (T.nd[t1].dist > P.effNon0 || T.nd[upT].up < 0)) {
                 int midTot;
                 if (upd) {
-                    midTot = opMerge(hPassed, distance / 2, false, treeList(T.lower[t1]), distance / 2, T.isTip[t1], true);
+                    midTot = opMerge(hPassed, distance / 2, false, treeList(T.nd[t1].lower), distance / 2, T.nd[t1].isTip, true);
                     if (midTot < 0) return;
-                    if (!opDiffer(midTot, treeList(T.totUp[t1]))) upd = false;
+                    if (!opDiffer(midTot, treeList(T.nd[t1].totUp))) upd = false;
                 } else {
-                    midTot = treeList(T.totUp[t1]);
-                    distance = T.dist[t1];
+                    midTot = treeList(T.nd[t1].totUp);
+                    distance = T.nd[t1].dist;
                 }
                 if (!valid(midTot)) return;
                 if (cached && !it.upd) { midProb = cached[t1]; nAppend++; }   // only items that ARRIVED in the cached regime
                 else midProb = opAppend(midTot, hRpr, isRemovedTip, removedBLen);
                 if (budget > 0 && !cached && nAppend > budget) { overBudget = true; return; }
                 if (midProb > bestLKdiff - P.thrOptTopo) {            // M:7071-7082
-                    if (upd) record(t1, midProb, hPassed, treeList(T.lower[t1]), distance, midTot, hRpr);
+                    if (upd) record(t1, midProb, hPassed, treeList(T.nd[t1].lower), distance, midTot, hRpr);
                     else record(t1, midProb, -1, -1, 0.0, -1, hRpr);
                 }
                 if (midProb > bestLKdiff) { bestLKdiff = midProb; fails = 0; opShortenInPlace(hRpr); }
@@ -316,48 +332,48 @@ template <bool RV, bool U, bool SS> struct Search {
             } else midProb = it.lastLK;
             trace(t1, 0, upd, fails, it.lastLK, midProb);
             bool go;
-            if (P.strict) go = fails <= P.allowedFails && midProb > (bestLKdiff - P.thrLKtopology) && T.c0[t1] >= 0;
-            else go = (fails <= P.allowedFails || midProb > (bestLKdiff - P.thrLKtopology)) && T.c0[t1] >= 0;
+            if (P.strict) go = fails <= P.allowedFails && midProb > (bestLKdiff - P.thrLKtopology) && T.nd[t1].c0 >= 0;
+            else go = (fails <= P.allowedFails || midProb > (bestLKdiff - P.thrLKtopology)) && T.nd[t1].c0 >= 0;
             if (go) {
                 for (int k = 0; k < 2; k++) {                         // child 0 uses vectUpRight, child 1 vectUpLeft
                     const int ch = child(t1, k), other = child(t1, 1 - k);
                     int vUp;
                     if (upd) {
-                        int opv = opPass(treeList(T.lower[other]), T.mutId[other], true);
-                        vUp = opMerge(hPassed, distance, false, opv, T.dist[other], T.isTip[other], true);
+                        int opv = opPass(treeList(T.nd[other].lower), T.nd[other].mutId, true);
+                        vUp = opMerge(hPassed, distance, false, opv, T.nd[other].dist, T.nd[other].isTip, true);
                         if (vUp == -2) { ws.overflow = true; return; }
-                    } else vUp = treeList(k == 0 ? T.upRight[t1] : T.upLeft[t1]);
+                    } else vUp = treeList(k == 0 ? T.nd[t1].upRight : T.nd[t1].upLeft);
                     if (valid(vUp)) {
-                        int r1 = opPass(hRpr, T.mutId[ch], false);
-                        if (upd) { vUp = opPass(vUp, T.mutId[ch], false); push(ch, 0, true, vUp, T.dist[ch], midProb, fails, r1); }
+                        int r1 = opPass(hRpr, T.nd[ch].mutId, false);
+                        if (upd) { vUp = opPass(vUp, T.nd[ch].mutId, false); push(ch, 0, true, vUp, T.nd[ch].dist, midProb, fails, r1); }
                         else push(ch, 0, false, -1, 0.0, midProb, fails, r1);
                     }
                 }
             }
         } else {                                                     // crawling up from child (dir-1) to its parent t1
             const int other = child(t1, 2 - it.dir);
-            const int upT = T.up[t1];
+            const int upT = T.nd[t1].up;
             int midBottom = -1, vectUp = -1;
-            if (upT >= 0 && (T.dist[t1] > P.effNon0 || T.up[upT] < 0)) {
+            if (upT >= 0 && (T.nd[t1].dist > P.effNon0 || T.nd[upT].up < 0)) {
                 int midTot;
                 if (upd) {
-                    int opv = opPass(treeList(T.lower[other]), T.mutId[other], true);
-                    midBottom = opMerge(hPassed, distance, false, opv, T.dist[other], T.isTip[other], false);
+                    int opv = opPass(treeList(T.nd[other].lower), T.nd[other].mutId, true);
+                    midBottom = opMerge(hPassed, distance, false, opv, T.nd[other].dist, T.nd[other].isTip, false);
                     if (midBottom < 0) return;
-                    vectUp = opPass(treeList(upVectOf(t1)), T.mutId[t1], false);
-                    midTot = opMerge(vectUp, T.dist[t1] / 2, false, midBottom, T.dist[t1] / 2, false, true);
+                    vectUp = opPass(treeList(upVectOf(t1)), T.nd[t1].mutId, false);
+                    midTot = opMerge(vectUp, T.nd[t1].dist / 2, false, midBottom, T.nd[t1].dist / 2, false, true);
                     if (midTot < 0) return;
-                    int cached = treeList(T.totUp[t1]);
+                    int cached = treeList(T.nd[t1].totUp);
                     if (!valid(cached))                               // "Node has no probVectTotUp ... calculating new one", M:7198-7200
-                        cached = opMerge(vectUp, T.dist[t1] / 2, false, treeList(T.lower[t1]), T.dist[t1] / 2, false, true);
+                        cached = opMerge(vectUp, T.nd[t1].dist / 2, false, treeList(T.nd[t1].lower), T.nd[t1].dist / 2, false, true);
                     if (!opDiffer(midTot, cached)) upd = false;
-                } else midTot = treeList(T.totUp[t1]);
+                } else midTot = treeList(T.nd[t1].totUp);
                 if (!valid(midTot)) return;
                 if (cached && !it.upd) { midProb = cached[t1]; nAppend++; }   // only items that ARRIVED in the cached regime
                 else midProb = opAppend(midTot, hRpr, isRemovedTip, removedBLen);
                 if (budget > 0 && !cached && nAppend > budget) { overBudget = true; return; }
                 if (midProb >= (bestLKdiff - P.thrOptTopo)) {         // M:7293-7304 (>= here, > on the way down)
-                    if (upd) record(t1, midProb, vectUp, midBottom, T.dist[t1], midTot, hRpr);
+                    if (upd) record(t1, midProb, vectUp, midBottom, T.nd[t1].dist, midTot, hRpr);
                     else record(t1, midProb, -1, -1, 0.0, -1, hRpr);
                 }
                 if (midProb > bestLKdiff) { bestLKdiff = midProb; fails = 0; }
@@ -369,53 +385,53 @@ template <bool RV, bool U, bool SS> struct Search {
             else go = fails <= P.allowedFails || midProb > (bestLKdiff - P.thrLKtopology);
             if (!go) return;
             if (upT >= 0) {
-                const int upChild = (T.c0[upT] == t1) ? 0 : 1;
+                const int upChild = (T.nd[upT].c0 == t1) ? 0 : 1;
                 int vUp;
                 if (upd) {
-                    int vUpUp = opPass(treeList(upVectOf(t1)), T.mutId[t1], false);
-                    vUp = opMerge(vUpUp, T.dist[t1], false, hPassed, distance, false, true);
+                    int vUpUp = opPass(treeList(upVectOf(t1)), T.nd[t1].mutId, false);
+                    vUp = opMerge(vUpUp, T.nd[t1].dist, false, hPassed, distance, false, true);
                     if (vUp == -2) { ws.overflow = true; return; }
-                } else vUp = treeList(it.dir == 1 ? T.upLeft[t1] : T.upRight[t1]);
+                } else vUp = treeList(it.dir == 1 ? T.nd[t1].upLeft : T.nd[t1].upRight);
                 if (!valid(vUp)) return;
-                int r1 = opPass(hRpr, T.mutId[other], false);
-                if (upd) { vUp = opPass(vUp, T.mutId[other], false); push(other, 0, true, vUp, T.dist[other], midProb, fails, r1); }
+                int r1 = opPass(hRpr, T.nd[other].mutId, false);
+                if (upd) { vUp = opPass(vUp, T.nd[other].mutId, false); push(other, 0, true, vUp, T.nd[other].dist, midProb, fails, r1); }
                 else push(other, 0, false, -1, 0.0, midProb, fails, r1);
                 if (upd && midBottom < 0) {                           // M:7376-7384
-                    int opv = opPass(treeList(T.lower[other]), T.mutId[other], true);
-                    midBottom = opMerge(hPassed, distance, false, opv, T.dist[other], T.isTip[other], false);
+                    int opv = opPass(treeList(T.nd[other].lower), T.nd[other].mutId, true);
+                    midBottom = opMerge(hPassed, distance, false, opv, T.nd[other].dist, T.nd[other].isTip, false);
                     if (midBottom < 0) return;
                 }
-                r1 = opPass(hRpr, T.mutId[t1], true);
-                if (upd) { midBottom = opPass(midBottom, T.mutId[t1], true); push(upT, upChild + 1, true, midBottom, T.dist[t1], midProb, fails, r1); }
+                r1 = opPass(hRpr, T.nd[t1].mutId, true);
+                if (upd) { midBottom = opPass(midBottom, T.nd[t1].mutId, true); push(upT, upChild + 1, true, midBottom, T.nd[t1].dist, midProb, fails, r1); }
                 else push(upT, upChild + 1, false, -1, 0.0, midProb, fails, r1);
             } else {                                                  // t1 is the root, M:7406-7432
-                int r1 = opPass(hRpr, T.mutId[other], false);
+                int r1 = opPass(hRpr, T.nd[other].mutId, false);
                 if (upd) {
                     int vUp = opRootVector(hPassed, distance, false, t1);
-                    vUp = opPass(vUp, T.mutId[other], false);
+                    vUp = opPass(vUp, T.nd[other].mutId, false);
                     if (!valid(vUp)) { ws.overflow = true; return; }
-                    push(other, 0, true, vUp, T.dist[other], midProb, fails, r1);
+                    push(other, 0, true, vUp, T.nd[other].dist, midProb, fails, r1);
                 } else push(other, 0, false, -1, 0.0, midProb, fails, r1);
             }
         }
     }
 
     // refinement of one short-listed branch, M:7460-7639 (evaluatePlacement M:6790-6806 inlined)
-    __device__ __noinline__ int refine(const BestRec &r)
+    __device__ MAPLE_SEARCH_OP int refine(const BestRec &r)
     {
         if (!(r.score >= originalLK - P.thrOptTopo)) return 0;
         const int t1 = r.t1;
         int upV, downV, midTot;
         double distance;
         if (r.hUp == -1) {
-            upV = opPass(treeList(upVectOf(t1)), T.mutId[t1], false);
-            downV = treeList(T.lower[t1]);
-            distance = T.dist[t1];
-            midTot = treeList(T.totUp[t1]);
+            upV = opPass(treeList(upVectOf(t1)), T.nd[t1].mutId, false);
+            downV = treeList(T.nd[t1].lower);
+            distance = T.nd[t1].dist;
+            midTot = treeList(T.nd[t1].totUp);
         } else { upV = r.hUp; downV = r.hDown; distance = r.distance; midTot = r.hMid; }
         if (!valid(upV) || !valid(downV) || !valid(midTot)) return -1;
         const int rem = r.hRpr;
-        const bool ft = T.isTip[t1];
+        const bool ft = T.nd[t1].isTip;
         const int saveW = ws.usedW, saveA = ws.usedA, saveH = ws.nH;
         double app = opBlen(midTot, rem, isRemovedTip);
         int midLower = opMerge(downV, distance / 2, ft, rem, app, isRemovedTip, false);
