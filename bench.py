@@ -173,6 +173,8 @@ def main():
                "placements_per_s_kernel": float(res["nAppend"].sum() / (k_ms_spr * 1e-3)) if k_ms_spr else None,
                "placements_per_s_wall": float(res["nAppend"].sum() / wall),
                "params": "deep round: non-strict, allowedFailsTopology 4, thresholdLogLKtopology 14 log(lRef)"}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            spr["cpu_baseline"] = spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, my_nodes, res, kw, args.cpu_seconds)
 
     # HBM-side bytes per launch come from separate rocprofv3 PMC passes over this same command (a running process
     # cannot read its own PMCs); they are recorded, with the FETCH_SIZE calibration for this access pattern, in
@@ -214,6 +216,44 @@ def main():
     if distd is not None:
         distd.destroy_process_group()
     dev.close()
+
+
+def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, nodes, gpu_res, kw, cpu_seconds):
+    """The C oracle's SPR search (a port of findBestParentTopology + the worker body, oracle/maple_oracle_search.c)
+    on ONE host core over a bounded, evenly spread sample of the same pruned nodes; also cross-checks the GPU."""
+    from oracle.oracle_py import Oracle, OracleTree
+    orc = Oracle(ref_idx, root_freqs)
+    orc.set_model(UNREST_Q)
+    n = mirror.n_nodes
+    lists4 = []
+    for ids in (mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up):
+        have = np.nonzero(ids >= 0)[0]
+        lists4.append((have, dev.download_packed(ids[have])))
+    up = [None if p < 0 else int(p) for p in mirror.parent]
+    children = [[] if mirror.children[v, 0] < 0 else [int(mirror.children[v, 0]), int(mirror.children[v, 1])] for v in range(n)]
+    otree = OracleTree(orc, mirror.root, up, children, mirror.dist, [[] for _ in range(n)], [0] * n, lists4)
+    # grow the sample until the time budget is used: every 997th, 499th, ... node
+    done, t_used, placements, checked = 0, 0.0, 0, 0
+    stride = 997
+    sel_all = []
+    while t_used < cpu_seconds and stride >= 1:
+        sel = np.asarray([i for i in range(0, len(nodes), stride) if i not in set(sel_all)], dtype=np.int64)
+        if len(sel) == 0:
+            break
+        t0 = time.perf_counter()
+        o = orc.spr_worker(otree, nodes[sel], **kw)
+        t_used += time.perf_counter() - t0
+        placements += int(o["nAppend"].sum())
+        for k in ("status", "bestNode", "placement", "nAppend"):
+            if not np.array_equal(o[k], gpu_res[k][sel]):
+                raise SystemExit(f"GPU SPR search disagrees with the oracle on {k}")
+        checked += len(sel)
+        sel_all.extend(sel.tolist())
+        stride //= 2
+    return {"value": placements / t_used, "unit": "placements/s", "cores": 1, "kind": "port",
+            "sample": f"{checked} of the {len(nodes)} searches (evenly spread), {placements} candidate placements, "
+                      f"C oracle search (oracle/maple_oracle_search.c), {t_used:.1f} s; node ids, moves and candidate "
+                      "counts identical to the GPU's"}
 
 
 def cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs, cpu_seconds, t_out):

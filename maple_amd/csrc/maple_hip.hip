@@ -147,6 +147,9 @@ __global__ MAPLE_APPEND_ATTR void k_append(const DevModel *__restrict__ mp, Aren
 // NO barrier anywhere: wavefronts of very different list lengths never wait for each other.  (Measured: staging the
 // query in LDS behind __syncthreads() was 1.4x slower; dealing candidate chunks to XCDs for L2 affinity made no
 // difference -- the lists that miss L2 are served by the 256 MiB Infinity Cache.)
+#ifndef MAPLE_PAIRS_PER_LANE
+#define MAPLE_PAIRS_PER_LANE 1
+#endif
 template <bool RV, bool U, bool SS>
 __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ mp, ArenaView av, int nQ,
                                                    const int32_t *qList, int nC, const int32_t *cand, int isTip,
@@ -156,16 +159,35 @@ __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ 
     const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
-    const int nChunks = (nC + MAPLE_BLOCK - 1) / MAPLE_BLOCK;
+    constexpr int KPL = MAPLE_PAIRS_PER_LANE;
+    const int nChunks = (nC + MAPLE_BLOCK * KPL - 1) / (MAPLE_BLOCK * KPL);
     const int tiles = nQ * nChunks;
     for (int j = blockIdx.x; j < tiles; j += gridDim.x) {
         const int q = j / nChunks;
-        const int ci = (j - q * nChunks) * MAPLE_BLOCK + threadIdx.x;
-        if (ci < nC) {
-            const int cl = cand[ci];                                     // -1: this column has no list (score unused)
-            if (cl >= 0)
-                out[(long long)q * nC + ci] = append_walk(c, list_ref(av, cl), list_ref(av, qList[q]),
-                                                          qTip ? qTip[q] != 0 : isTip != 0, qBLen ? qBLen[q] : bLen);
+        const int base = (j - q * nChunks) * MAPLE_BLOCK * KPL + threadIdx.x;
+        const bool tipq = qTip ? qTip[q] != 0 : isTip != 0;
+        const double blq = qBLen ? qBLen[q] : bLen;
+        if (KPL == 1) {
+            if (base < nC) {
+                const int cl = cand[base];                               // -1: this column has no list (score unused)
+                if (cl >= 0) out[(long long)q * nC + base] = append_walk(c, list_ref(av, cl), list_ref(av, qList[q]), tipq, blq);
+            }
+        } else {
+            // a lane streams through its KPL candidates without waiting for the other 63 lanes at every pair
+            PairWalk<RV, U, SS> w(c, list_ref(av, qList[q]), tipq, blq);
+            int kk = 0, ci = -1;
+            bool active = false;
+            for (;;) {
+                if (!active) {
+                    if (kk >= KPL) break;
+                    ci = base + kk * MAPLE_BLOCK;
+                    kk++;
+                    if (ci >= nC || cand[ci] < 0) continue;
+                    w.start(list_ref(av, cand[ci]));
+                    active = true;
+                }
+                if (w.step()) { out[(long long)q * nC + ci] = w.finish(); active = false; }
+            }
         }
     }
 }
@@ -1203,6 +1225,7 @@ extern "C" int maple_evaluate_placement_batch(maple_ctx *c, int32_t n, const int
 // ---- device-resident forms ---------------------------------------------------------------------------
 static int ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b)
 {
+    if (c->ev_used >= 8192) c->ev_used = 0;       // nobody is reading these timings: recycle the event pairs
     if (c->ev_used + 2 > c->evs.size()) {
         hipEvent_t e0, e1;
         HIPCK(c, hipEventCreate(&e0));
@@ -1240,7 +1263,7 @@ extern "C" int maple_append_queries_dev(maple_ctx *c, int32_t nQ, const int32_t 
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    const long long tiles = (long long)nQ * ((nC + MAPLE_BLOCK - 1) / MAPLE_BLOCK);
+    const long long tiles = (long long)nQ * ((nC + MAPLE_BLOCK * MAPLE_PAIRS_PER_LANE - 1) / (MAPLE_BLOCK * MAPLE_PAIRS_PER_LANE));
     if (tiles > 0x7fffffffLL) return fail(c, MAPLE_ERR_ARG, "nQ x nC too large for one launch");
     const int grid = tiles < 256 * 8 ? (int)tiles : 256 * 8;
     hipEvent_t e0, e1;
@@ -1425,7 +1448,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             TRY(h2d(c, c->s_i32[6], ql.data(), (size_t)m));
             TRY(h2d(c, c->s_u8[3], qt.data(), (size_t)m));
             TRY(h2d(c, c->s_f64[3], qb.data(), (size_t)m));
-            const long long tiles = (long long)m * ((nT + MAPLE_BLOCK - 1) / MAPLE_BLOCK);
+            const long long tiles = (long long)m * ((nT + MAPLE_BLOCK * MAPLE_PAIRS_PER_LANE - 1) / (MAPLE_BLOCK * MAPLE_PAIRS_PER_LANE));
             const int grid = tiles < 256 * 8 ? (int)tiles : 256 * 8;
             hipEvent_t e0, e1;
             TRY(ev_pair(c, &e0, &e1));

@@ -157,10 +157,9 @@ class Device:
         self._ck(self.lib.maple_lists_sizes(self.h, len(ids), _ptr(ids), _ptr(ne), _ptr(na)))
         return ne, na
 
-    def download(self, ids):
-        """Download lists by id into the reference's tuple form (None for id -1)."""
-        ids = _i32(ids)
-        good = ids[ids >= 0]
+    def download_packed(self, ids) -> PackedLists:
+        """Download lists (all ids >= 0) in the packed CSR form."""
+        good = _i32(ids)
         ne, na = self.sizes(good)
         eo = np.zeros(len(good) + 1, dtype=np.int64)
         ao = np.zeros(len(good) + 1, dtype=np.int64)
@@ -172,6 +171,14 @@ class Device:
         if len(good):
             self._ck(self.lib.maple_lists_download(self.h, len(good), _ptr(good), _ptr(eo), _ptr(pos), _ptr(meta),
                                                    _ptr(ao), _ptr(aux)))
+        return PackedLists(eo, pos, meta, ao, aux)
+
+    def download(self, ids):
+        """Download lists by id into the reference's tuple form (None for id -1)."""
+        ids = _i32(ids)
+        good = ids[ids >= 0]
+        pk = self.download_packed(good)
+        eo, ao, pos, meta, aux = pk.ent_off, pk.aux_off, pk.pos, pk.meta, pk.aux
         out, k = [], 0
         for i in ids:
             if i < 0:

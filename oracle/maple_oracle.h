@@ -18,6 +18,7 @@
  */
 #ifndef MAPLE_ORACLE_H
 #define MAPLE_ORACLE_H
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -89,6 +90,40 @@ int   omo_evaluatePlacement(const OModel *m, const OEntry *midTot, int nMid, con
                             const OEntry *up, int nUp, double distance, const OEntry *rem, int nRem,
                             int isRemovedTip, int fromTip1, double defaultBLen, double *out4,
                             OEntry *tmp /* 3*cap */, int cap, double *scratch);
+
+/* ---- SPR search (oracle/maple_oracle_search.c) ---------------------------------------------------------- */
+typedef struct {
+    int n, root;
+    const int *up, *c0, *c1;             /* -1 = None                                          */
+    const double *dist;
+    const int *nMinor;                   /* len(minorSequences[node])                           */
+    const OEntry *ent;                   /* all genome lists of the tree, concatenated          */
+    const long long *start[4];           /* per kind (0 probVect, 1 probVectUpRight, 2 probVectUpLeft, 3 probVectTotUp) */
+    const int *len[4];                   /* 0 = None                                            */
+    const int *mut3;                     /* tree.mutations[], triples, CSR by node              */
+    const long long *mutOff;             /* [n+1]                                               */
+} OTree;
+
+typedef struct {
+    int strict, allowedFails;
+    double thrLKtopology, thrPlacement, thrOptTopo, thrConsec, effNon0, defaultBLen;
+} OSearchParams;
+
+typedef struct {
+    int bestNode, placement, status, nAppend;
+    double bestScore, improvement, currentLK;
+    double blen[3];
+    OEntry *rpr;                         /* optional caller buffer for bestRemovedPartials      */
+    int rprCap, rprN;
+} OSearchResult;
+
+/* findBestParentTopology(tree, node, child, bestLKdiff, removedBLen), M:6817-7724; 0 ok, -1 the reference raises,
+ * -3 arena too small */
+int omo_findBestParentTopology(const OModel *m, const OTree *t, const OSearchParams *p, int node, int child,
+                               double bestLKdiff, double removedBLen, OSearchResult *res, void *arenaMem, size_t arenaBytes);
+/* worker body of startTopologyUpdatesParallel, M:9615-9711, for the pruned nodes `nodes` */
+int omo_sprWorker(const OModel *m, const OTree *t, const OSearchParams *p, int n, const int *nodes, OSearchResult *out,
+                  void *arenaMem, size_t arenaBytes);
 
 /* batch driver (lists concatenated, off[] = CSR offsets by list index) used to time the CPU baseline */
 int   omo_appendProbNode_batch(const OModel *m, const OEntry *all, const long long *off, int n, const int *pl,

@@ -36,8 +36,8 @@ class OModel(C.Structure):
 
 
 def build(force=False):
-    src = os.path.join(HERE, "maple_oracle.c")
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(HERE, f) for f in ("maple_oracle.c", "maple_oracle_search.c", "maple_oracle.h")]
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", HERE, "-s"])
     return LIB
 
@@ -92,6 +92,112 @@ def from_entries(arr, n, u):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class OTreeC(C.Structure):
+    _fields_ = [("n", C.c_int), ("root", C.c_int), ("up", C.c_void_p), ("c0", C.c_void_p), ("c1", C.c_void_p),
+                ("dist", C.c_void_p), ("nMinor", C.c_void_p), ("ent", C.c_void_p), ("start", C.c_void_p * 4),
+                ("len", C.c_void_p * 4), ("mut3", C.c_void_p), ("mutOff", C.c_void_p)]
+
+
+class OSearchParamsC(C.Structure):
+    _fields_ = [("strict", C.c_int), ("allowedFails", C.c_int), ("thrLKtopology", C.c_double),
+                ("thrPlacement", C.c_double), ("thrOptTopo", C.c_double), ("thrConsec", C.c_double),
+                ("effNon0", C.c_double), ("defaultBLen", C.c_double)]
+
+
+class OSearchResultC(C.Structure):
+    _fields_ = [("bestNode", C.c_int), ("placement", C.c_int), ("status", C.c_int), ("nAppend", C.c_int),
+                ("bestScore", C.c_double), ("improvement", C.c_double), ("currentLK", C.c_double),
+                ("blen", C.c_double * 3), ("rpr", C.c_void_p), ("rprCap", C.c_int), ("rprN", C.c_int)]
+
+
+def packed_to_entries(pk, u):
+    """Packed CSR lists (maple_amd.genome_list.PackedLists, e.g. Device.download_packed) -> one OENTRY array + CSR
+    offsets, vectorised (the per-entry Python loop of to_entries is too slow for whole trees)."""
+    n = len(pk.pos) if len(pk.ent_off) > 1 else 0
+    n = int(pk.ent_off[-1])
+    pos = pk.pos[:n].astype(np.int64)
+    meta = pk.meta[:n].astype(np.int64)
+    typ = meta & 7
+    ref = (meta >> 3) & 3
+    has0 = (meta >> 5) & 1
+    has1 = (meta >> 6) & 1
+    flag = (meta >> 7) & 1
+    auxoff = meta >> 8
+    # aux base of the list each entry belongs to
+    counts = np.diff(pk.ent_off)
+    base = np.repeat(pk.aux_off[:-1], counts)
+    a0 = base + auxoff
+    arr = np.zeros(n, dtype=OENTRY)
+    arr["type"] = typ
+    arr["x"] = np.where((typ == 4) | (typ == 5), pos, ref)
+    arr["flag"] = flag if u else 0
+    aux = np.concatenate([pk.aux, np.zeros(8)])
+    d0 = np.where(has0 == 1, aux[np.minimum(a0, len(aux) - 1)], 0.0)
+    d1 = np.where(has1 == 1, aux[np.minimum(a0 + has0, len(aux) - 1)], 0.0)
+    arr["d0"], arr["d1"] = d0, d1
+    vbase = a0 + has0 + has1
+    isO = typ == 6
+    for k in range(4):
+        arr["vec"][:, k] = np.where(isO, aux[np.minimum(vbase + k, len(aux) - 1)], 0.0)
+    tail = has0 + has1
+    ln = np.where(isO, 3 + has0, np.where(typ == 5, 2, 2 + tail + np.where((tail > 0) & bool(u), 1, 0)))
+    arr["len"] = ln
+    return arr, pk.ent_off.copy()
+
+
+class OracleTree:
+    """A frozen tree in the oracle's layout: topology + the four genome lists of every node (tuple form or None)."""
+
+    def __init__(self, oracle, root, up, children, dist, mutations, n_minor, lists4):
+        u = oracle.u
+        n = len(up)
+        self.n = n
+        self.up = np.asarray([-1 if x is None else x for x in up], dtype=np.int32)
+        self.c0 = np.asarray([c[0] if c else -1 for c in children], dtype=np.int32)
+        self.c1 = np.asarray([c[1] if c else -1 for c in children], dtype=np.int32)
+        self.dist = np.asarray(dist, dtype=np.float64)
+        self.nMinor = np.asarray(n_minor, dtype=np.int32)
+        chunks, self.start, self.len = [], [], []
+        tot = 0
+        for kind in range(4):
+            st = np.zeros(n, dtype=np.int64)
+            ln = np.zeros(n, dtype=np.int32)
+            if isinstance(lists4[kind], tuple):                   # (node ids, packed lists) straight from the device
+                nodes_k, pk = lists4[kind]
+                arr, off = packed_to_entries(pk, u)
+                st[nodes_k] = tot + off[:-1]
+                ln[nodes_k] = np.diff(off)
+                tot += len(arr)
+                chunks.append(arr)
+            else:
+                for v in range(n):
+                    gl = lists4[kind][v]
+                    if gl:
+                        arr = to_entries([tuple(e) for e in gl], u)
+                        st[v], ln[v] = tot, len(arr)
+                        tot += len(arr)
+                        chunks.append(arr)
+            self.start.append(st)
+            self.len.append(ln)
+        self.ent = np.concatenate(chunks) if chunks else np.zeros(1, dtype=OENTRY)
+        off = np.zeros(n + 1, dtype=np.int64)
+        flat = []
+        for v in range(n):
+            flat.extend(mutations[v])
+            off[v + 1] = len(flat)
+        self.mut3 = np.ascontiguousarray(np.asarray(flat if flat else [[0, 0, 0]], dtype=np.int32).reshape(-1, 3))
+        self.mutOff = off
+        t = OTreeC()
+        t.n, t.root = n, root
+        t.up, t.c0, t.c1, t.dist, t.nMinor = _p(self.up), _p(self.c0), _p(self.c1), _p(self.dist), _p(self.nMinor)
+        t.ent = _p(self.ent)
+        for k in range(4):
+            t.start[k] = self.start[k].ctypes.data
+            t.len[k] = self.len[k].ctypes.data
+        t.mut3, t.mutOff = _p(self.mut3), _p(self.mutOff)
+        self.c = t
 
 
 class Oracle:
@@ -308,4 +414,34 @@ class Oracle:
         bl = np.ascontiguousarray(np.broadcast_to(bLen, n), dtype=np.float64)
         out = np.zeros(n)
         self.lib.omo_appendProbNode_batch(C.byref(self.m), _p(allent), _p(off), n, _p(pl), _p(cl), _p(tip), _p(bl), _p(out))
+        return out
+
+    # ---- SPR search -----------------------------------------------------------------------------
+    def spr_worker(self, tree, nodes, *, strict, allowedFails, thresholdLogLKtopology, thresholdTopologyPlacement,
+                   thresholdLogLKoptimizationTopology, thresholdLogLKconsecutivePlacement, effectivelyNon0BLen,
+                   arena_mb=256, want_removed_partials=False):
+        """startTopologyUpdatesParallel's worker body (M:9615-9711) for the pruned nodes `nodes`."""
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+        n = len(nodes)
+        sp = OSearchParamsC(int(bool(strict)), int(allowedFails), thresholdLogLKtopology, thresholdTopologyPlacement,
+                            thresholdLogLKoptimizationTopology, thresholdLogLKconsecutivePlacement, effectivelyNon0BLen,
+                            self.defaultBLen)
+        res = (OSearchResultC * n)()
+        bufs = []
+        if want_removed_partials:
+            for i in range(n):
+                b = np.zeros(4096, dtype=OENTRY)
+                bufs.append(b)
+                res[i].rpr = b.ctypes.data
+                res[i].rprCap = 4096
+        arena = np.zeros(arena_mb << 20, dtype=np.uint8)
+        self.lib.omo_sprWorker(C.byref(self.m), C.byref(tree.c), C.byref(sp), n, _p(nodes), res, _p(arena),
+                               C.c_size_t(arena.nbytes))
+        out = dict(bestNode=np.array([r.bestNode for r in res]), placement=np.array([r.placement for r in res]),
+                   status=np.array([r.status for r in res]), nAppend=np.array([r.nAppend for r in res]),
+                   bestScore=np.array([r.bestScore for r in res]), improvement=np.array([r.improvement for r in res]),
+                   currentLK=np.array([r.currentLK for r in res]), blen=np.array([[r.blen[0], r.blen[1], r.blen[2]] for r in res]))
+        if want_removed_partials:
+            out["removedPartials"] = [from_entries(bufs[i], res[i].rprN, self.u) if res[i].status == 0 else None
+                                      for i in range(n)]
         return out

@@ -173,3 +173,49 @@ def test_wide_searches_batch_scored_identically():
     mv = plain["placement"] >= 0
     assert (plain["bestScore"][mv] - 0.1 > plain["currentLK"][mv]).all()
     dev.close()
+
+
+def test_device_search_vs_oracle_search_on_gpu_built_tree():
+    """Beyond the reference's small recorded trees: every node of a 1500-tip synthetic tree (mirror built on the GPU)
+    searched by the device state machine and by the C oracle (itself pinned to the reference's records): node ids,
+    proposed moves and candidate counts bit-exact, scores to 1e-12."""
+    import math
+    from maple_amd.host import reference_tables, tip_genome_list
+    from maple_amd.runtime import Device
+    from maple_amd.synth import make_dataset
+    from maple_amd.tree_mirror import TreeMirror
+    from oracle.oracle_py import Oracle, OracleTree
+    data = make_dataset(n_samples=1500, l_ref=29903, seed=4, mean_diffs=30.0, frac_with_n=0.05, frac_ambig=0.05)
+    ref_idx, rf = reference_tables(data.ref)
+    Qm = [[-0.55, 0.06, 0.37, 0.12], [0.17, -2.6, 0.04, 2.39], [0.84, 0.13, -2.4, 1.43], [0.07, 0.48, 0.05, -0.6]]
+    dev = Device(ref_idx, rf, arena_bytes=1 << 30)
+    dev.set_model(Qm)
+    orc = Oracle(ref_idx, rf)
+    orc.set_model(Qm)
+    tips = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
+    m = TreeMirror(dev, data.parent, data.blen, tips).build()
+    n = m.n_nodes
+    dev.upload_tree(m.root, m.parent, m.children[:, 0], m.children[:, 1], m.dist, m.is_tip, m.lower, m.up_right, m.up_left,
+                    m.tot_up, -np.ones(n, dtype=np.int32))
+    lists4 = []
+    for ids in (m.lower, m.up_right, m.up_left, m.tot_up):
+        got = dev.download(ids)
+        lists4.append(got)
+    up = [None if p < 0 else int(p) for p in m.parent]
+    children = [[] if m.children[v, 0] < 0 else [int(m.children[v, 0]), int(m.children[v, 1])] for v in range(n)]
+    otree = OracleTree(orc, m.root, up, children, m.dist, [[] for _ in range(n)], [0] * n, lists4)
+    ll = math.log(dev.lRef)
+    nodes = np.arange(n)
+    for kw in (dict(strict=True, allowedFails=2, thresholdLogLKtopology=6.0 * ll),
+               dict(strict=False, allowedFails=4, thresholdLogLKtopology=14.0 * ll)):
+        kw.update(thresholdTopologyPlacement=-0.1, thresholdLogLKoptimizationTopology=ll,
+                  thresholdLogLKconsecutivePlacement=1.0, effectivelyNon0BLen=1.0 / (10 * dev.lRef))
+        sel = nodes if kw["strict"] else nodes[::7]                   # the deep round is ~100x the work on the CPU
+        g = dev.spr_search_batch(sel, **kw)
+        o = orc.spr_worker(otree, sel, **kw)
+        for k in ("status", "bestNode", "placement", "nAppend"):
+            assert np.array_equal(g[k], o[k]), k
+        for k in ("bestScore", "currentLK", "improvement", "blen"):
+            assert np.allclose(g[k], o[k], rtol=1e-11, atol=1e-15), k
+        assert g["nAppend"].sum() > 10000
+    dev.close()
