@@ -193,6 +193,7 @@ int maple_append_queries_dev(maple_ctx *ctx, int32_t nQ, const int32_t *qList_de
  * maple_timing_read sums the elapsed time of all launches since the last maple_timing_reset. */
 int maple_timing_reset(maple_ctx *ctx);
 int maple_timing_read(maple_ctx *ctx, int32_t *n_launches, double *total_ms);
+int maple_timing_read_each(maple_ctx *ctx, int32_t cap, float *ms, int32_t *n_launches);   /* one value per launch */
 /* algorithmic bytes (8*E + 8*B + 32*O + 8 per candidate, child list once per query) */
 int maple_append_algorithmic_bytes(maple_ctx *ctx, int32_t n, const int32_t *parentList, const int32_t *childList,
                                    int child_once, uint64_t *bytes);

@@ -416,6 +416,81 @@ template <bool RV, bool U, bool SS> struct Search {
         }
     }
 
+    // The cached regime of step() for trees without MAT local references, with the hot state in registers: items that
+    // arrive with needsUpdating == False only compare cached scores and push their relatives, so a whole-tree search
+    // is ~15 000 iterations of integer work.  Processes items until the stack is empty or its top item still needs
+    // updating.  Semantics are those of step() (same order, same tie-breaks); the removed list is one shared object in
+    // such trees, so the reference's in-place shorten() (M:7087) is done once, at the first improvement.
+    __device__ __forceinline__ void replayCached()
+    {
+        int sp = ws.sp, nB = ws.nB, nApp = nAppend;
+        double best = bestLKdiff;
+        const double thrOpt = P.thrOptTopo, thrCons = P.thrConsec, thrLK = P.thrLKtopology, eff = P.effNon0;
+        const int strict = P.strict, allowed = P.allowedFails, capS = ws.L.capS, capB = ws.L.capB;
+        StackItem *st = ws.st;
+        BestRec *br = ws.best;
+        const NodeRec *nd = T.nd;
+        const double *cs = cached;
+        bool wantShorten = false;
+        int hShorten = -1;
+        while (sp > 0 && !st[sp - 1].upd) {
+            const StackItem it = st[--sp];
+            const int t1 = it.t1;
+            const NodeRec r1 = nd[t1];
+            const int upT = r1.up;
+            int fails = it.fails;
+            double midProb = it.lastLK;
+            const bool rootChild = upT >= 0 && nd[upT].up < 0;
+            if (it.dir == 0) {
+                if (!(upT == node || upT < 0) && (r1.dist > eff || rootChild)) {
+                    if (r1.totUp < 0) continue;
+                    midProb = cs[t1]; nApp++;
+                    if (midProb > best - thrOpt) {
+                        if (nB >= capB) { ws.overflow = true; break; }
+                        br[nB++] = BestRec{t1, -1, -1, -1, it.hRpr, midProb, 0.0};
+                    }
+                    if (midProb > best) { best = midProb; fails = 0; if (!wantShorten) { wantShorten = true; hShorten = it.hRpr; } }
+                    else if (midProb < (it.lastLK - thrCons)) fails++;
+                }
+                bool go;
+                if (strict) go = fails <= allowed && midProb > (best - thrLK) && r1.c0 >= 0;
+                else go = (fails <= allowed || midProb > (best - thrLK)) && r1.c0 >= 0;
+                if (go) {
+                    if (sp + 2 > capS) { ws.overflow = true; break; }
+                    if (r1.upRight >= 0) { StackItem &o = st[sp++]; o.t1 = r1.c0; o.dir = 0; o.upd = 0; o.fails = (int16_t)fails; o.hPassed = -1; o.hRpr = it.hRpr; o.distance = 0.0; o.lastLK = midProb; }
+                    if (r1.upLeft >= 0) { StackItem &o = st[sp++]; o.t1 = r1.c1; o.dir = 0; o.upd = 0; o.fails = (int16_t)fails; o.hPassed = -1; o.hRpr = it.hRpr; o.distance = 0.0; o.lastLK = midProb; }
+                }
+            } else {
+                const int other = (it.dir == 1) ? r1.c1 : r1.c0;
+                if (upT >= 0 && (r1.dist > eff || rootChild)) {
+                    if (r1.totUp < 0) continue;
+                    midProb = cs[t1]; nApp++;
+                    if (midProb >= (best - thrOpt)) {
+                        if (nB >= capB) { ws.overflow = true; break; }
+                        br[nB++] = BestRec{t1, -1, -1, -1, it.hRpr, midProb, 0.0};
+                    }
+                    if (midProb > best) { best = midProb; fails = 0; }
+                    else if (midProb < (it.lastLK - thrCons)) fails++;
+                }
+                bool go;
+                if (strict) go = fails <= allowed && midProb > (best - thrLK);
+                else go = fails <= allowed || midProb > (best - thrLK);
+                if (!go) continue;
+                if (sp + 2 > capS) { ws.overflow = true; break; }
+                if (upT >= 0) {
+                    if (((it.dir == 1) ? r1.upLeft : r1.upRight) < 0) continue;
+                    { StackItem &o = st[sp++]; o.t1 = other; o.dir = 0; o.upd = 0; o.fails = (int16_t)fails; o.hPassed = -1; o.hRpr = it.hRpr; o.distance = 0.0; o.lastLK = midProb; }
+                    const int upChild = (nd[upT].c0 == t1) ? 0 : 1;
+                    { StackItem &o = st[sp++]; o.t1 = upT; o.dir = (int8_t)(upChild + 1); o.upd = 0; o.fails = (int16_t)fails; o.hPassed = -1; o.hRpr = it.hRpr; o.distance = 0.0; o.lastLK = midProb; }
+                } else {
+                    StackItem &o = st[sp++]; o.t1 = other; o.dir = 0; o.upd = 0; o.fails = (int16_t)fails; o.hPassed = -1; o.hRpr = it.hRpr; o.distance = 0.0; o.lastLK = midProb;
+                }
+            }
+        }
+        ws.sp = sp; ws.nB = nB; nAppend = nApp; bestLKdiff = best;
+        if (wantShorten) opShortenInPlace(hShorten);
+    }
+
     // refinement of one short-listed branch, M:7460-7639 (evaluatePlacement M:6790-6806 inlined)
     __device__ MAPLE_SEARCH_OP int refine(const BestRec &r)
     {

@@ -21,7 +21,7 @@ EXPORTS = [
     "maple_lists_upload", "maple_lists_sizes", "maple_lists_download", "maple_arena_mark", "maple_arena_release",
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
-    "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read",
+    "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
 ]
 
@@ -360,6 +360,12 @@ class Device:
 
     def timing_reset(self):
         self._ck(self.lib.maple_timing_reset(self.h))
+
+    def timing_read_each(self, cap=256):
+        ms = np.zeros(cap, dtype=np.float32)
+        n = C.c_int32()
+        self._ck(self.lib.maple_timing_read_each(self.h, int(cap), _ptr(ms), C.byref(n)))
+        return ms[: n.value].tolist()
 
     def timing_read(self):
         """(number of timed *_dev launches since the last reset, their summed HIP-event time in ms)."""

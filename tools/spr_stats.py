@@ -24,9 +24,11 @@ else:
     kw = dict(strict=False, allowedFails=4, thresholdLogLKtopology=14.0 * ll, thresholdTopologyPlacement=-0.1, thresholdLogLKoptimizationTopology=ll, thresholdLogLKconsecutivePlacement=1.0, effectivelyNon0BLen=1.0 / (10 * l_ref))
 nodes = np.arange(m.n_nodes)
 dev.spr_search_batch(nodes[:64], **kw)
+BUDGET = int(os.environ.get("WIDE_BUDGET", "0"))
 def run(sel, label):
-    dev.timing_reset(); t0 = time.perf_counter(); r = dev.spr_search_batch(sel, **kw); w = time.perf_counter() - t0
+    dev.timing_reset(); t0 = time.perf_counter(); r = dev.spr_search_batch(sel, wide_search_budget=BUDGET, **kw); w = time.perf_counter() - t0
     nl, ms = dev.timing_read()
+    print("   per launch ms:", [round(x, 1) for x in dev.timing_read_each()])
     na = r["nAppend"]
     print(f"{label}: queries {len(sel)} placements {na.sum()} kernel_ms {ms:.1f} wall_ms {1e3*w:.1f} -> {na.sum()/(ms*1e-3):.3g}/s | nAppend mean {na.mean():.0f} p50 {np.percentile(na,50):.0f} p99 {np.percentile(na,99):.0f} max {na.max()} | status<0: {(r['status']<0).sum()} launches {nl}")
     return r
