@@ -34,12 +34,28 @@ UNREST_Q = [[-0.5524, 0.0602, 0.3655, 0.1267],
             [0.0688, 0.4849, 0.0502, -0.6039]]
 
 
+def model_kwargs(mode, l_ref):
+    """Model tables of BASELINE.json's configs: [1] UNREST; [2] + per-site rates (--rateVariation); [3] + per-site
+    error rates (--estimateSiteSpecificErrorRate).  Seeded as SURVEY.md section 8d prescribes."""
+    kw = dict(Q=UNREST_Q)
+    if mode in ("ratevar", "siteerr"):
+        rng = np.random.default_rng(3)
+        kw["siteRates"] = np.clip(rng.gamma(0.5, 2.0, size=l_ref), 0.001, 0.005 * l_ref)
+    if mode == "siteerr":
+        rng = np.random.default_rng(4)
+        er = np.exp(rng.uniform(np.log(1e-10), np.log(1e-3), size=l_ref))
+        kw.update(usingErrorRate=True, errorRates=er, errorRateGlobal=float(er.mean()))
+    return kw
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=10000, help="tips of the synthetic tree (BASELINE configs[1]: 10k)")
+    ap.add_argument("--model", choices=["unrest", "ratevar", "siteerr"], default="unrest",
+                    help="unrest = configs[1] (default, the headline); ratevar = configs[2]; siteerr = configs[3]")
     ap.add_argument("--queries", type=int, default=256, help="query genome lists per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate host time spent on cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -71,11 +87,14 @@ def main():
     from maple_amd.tree_mirror import TreeMirror
 
     t_setup = time.time()
-    data = make_dataset(n_samples=args.samples, l_ref=29903, seed=1, mean_diffs=30.0)
+    data = make_dataset(n_samples=args.samples, l_ref=29903, seed=1, mean_diffs=30.0,
+                        rate_variation=(args.model != "unrest"))
     ref_idx, root_freqs = reference_tables(data.ref)
     dev = Device(ref_idx, root_freqs, device=local_rank, arena_bytes=4 << 30)
-    dev.set_model(UNREST_Q)
-    tip_lists = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
+    mkw = model_kwargs(args.model, len(ref_idx))
+    dev.set_model(**mkw)
+    tip_kw = dict(error_rates=mkw["errorRates"]) if args.model == "siteerr" else {}
+    tip_lists = {int(v): tip_genome_list(dl, ref_idx, **tip_kw) for v, dl in zip(data.tip_node, data.diffs)}
     mirror = TreeMirror(dev, data.parent, data.blen, tip_lists).build()
     l_ref = dev.lRef
     cand_nodes = mirror.candidates_by_length(1.0 / (10 * l_ref)) if args.sort else mirror.candidate_nodes(1.0 / (10 * l_ref))
@@ -174,7 +193,7 @@ def main():
                "placements_per_s_wall": float(res["nAppend"].sum() / wall),
                "params": "deep round: non-strict, allowedFailsTopology 4, thresholdLogLKtopology 14 log(lRef)"}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            spr["cpu_baseline"] = spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, my_nodes, res, kw, args.cpu_seconds)
+            spr["cpu_baseline"] = spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, my_nodes, res, kw, args.cpu_seconds, mkw)
 
     # HBM-side bytes per launch come from separate rocprofv3 PMC passes over this same command (a running process
     # cannot read its own PMCs); they are recorded, with the FETCH_SIZE calibration for this access pattern, in
@@ -183,7 +202,8 @@ def main():
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_append_queries.json")))
         w = pmc["workload"]
-        if (w["samples"], w["queries_per_gpu"], w["candidate_branches"]) == (args.samples, Q, int(Cn)) and not args.pairs:
+        if ((w["samples"], w["queries_per_gpu"], w["candidate_branches"]) == (args.samples, Q, int(Cn))
+                and not args.pairs and args.model == "unrest"):
             traffic = pmc["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -198,7 +218,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.samples} synthetic SARS-CoV-2 diff-lists (lRef 29903, ~30 diffs/sample), "
-                                   "UNREST, appendProbNode over queries x all candidate branches",
+                                   f"{ {'unrest': 'UNREST', 'ratevar': 'UNREST + per-site rates', 'siteerr': 'UNREST + per-site rates + per-site error rates'}[args.model] }, "
+                                   "appendProbNode over queries x all candidate branches",
                        "samples": args.samples, "queries_per_gpu": Q, "candidate_branches": int(Cn),
                        "pairs_per_step_per_gpu": int(n_pairs), "tree_nodes": int(mirror.n_nodes),
                        "parallelism": f"queries sharded round-robin over {world} GPU(s), tree mirror replicated",
@@ -211,19 +232,19 @@ def main():
             out["spr_search"] = spr
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs,
-                                               args.cpu_seconds, t_out)
+                                               args.cpu_seconds, t_out, mkw)
         print(json.dumps(out), flush=True)
     if distd is not None:
         distd.destroy_process_group()
     dev.close()
 
 
-def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, nodes, gpu_res, kw, cpu_seconds):
+def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, nodes, gpu_res, kw, cpu_seconds, mkw):
     """The C oracle's SPR search (a port of findBestParentTopology + the worker body, oracle/maple_oracle_search.c)
     on ONE host core over a bounded, evenly spread sample of the same pruned nodes; also cross-checks the GPU."""
     from oracle.oracle_py import Oracle, OracleTree
     orc = Oracle(ref_idx, root_freqs)
-    orc.set_model(UNREST_Q)
+    orc.set_model(**mkw)
     n = mirror.n_nodes
     lists4 = []
     for ids in (mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up):
@@ -256,12 +277,12 @@ def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, nodes, gpu_res, kw, cpu_s
                       "counts identical to the GPU's"}
 
 
-def cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs, cpu_seconds, t_out):
+def cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs, cpu_seconds, t_out, mkw):
     """The C oracle (a port of the reference's appendProbNode) timed on ONE host core on a bounded
     sample of the same (query, candidate) pairs; also cross-checks the GPU scores."""
     from oracle.oracle_py import Oracle
     orc = Oracle(ref_idx, root_freqs)
-    orc.set_model(UNREST_Q)
+    orc.set_model(**mkw)
     Cn = len(cand_lists)
     lists = dev.download(np.concatenate([cand_lists, q_lists]))
     packed = orc.pack_many(lists)

@@ -46,7 +46,25 @@ class TreeMirror:
         self.lower[np.asarray(tips, dtype=np.int64)] = ids
         self.launches = 0
 
-    def build(self):
+    def build(self, max_restarts=8):
+        """Build all lists; zero-length branches that turn out to be inconsistent with the data (mergeVectors returns
+        None, M:4757-4762; the reference then re-estimates the branch with updateBLen, M:5377-5414) are given the
+        length of one tenth of a mutation and the build is restarted."""
+        mark = self.dev.mark()
+        tip_ids = self.lower.copy()
+        for _ in range(max_restarts):
+            bad = self._build_once()
+            if bad is None:
+                return self
+            self.dist[bad] = np.maximum(self.dist[bad], 0.1 / self.dev.lRef)
+            self.dev.release(mark)
+            self.lower = tip_ids.copy()
+            self.up_right[:] = -1
+            self.up_left[:] = -1
+            self.tot_up[:] = -1
+        raise RuntimeError("inconsistent zero-length branches remain after restarts")
+
+    def _build_once(self):
         dev, ch, dist = self.dev, self.children, self.dist
         internal = np.nonzero(~self.is_tip)[0]
         maxd = int(self.depth.max())
@@ -59,7 +77,8 @@ class TreeMirror:
             out = dev.merge_batch(self.lower[c0], dist[c0], self.is_tip[c0], self.lower[c1], dist[c1], self.is_tip[c1],
                                   False)
             if (out < 0).any():
-                raise RuntimeError("inconsistent zero-length branches while building lower lists")
+                b = out < 0
+                return np.concatenate([c0[b], c1[b]])
             self.lower[nodes] = dev.shorten_batch(out)
             self.launches += 2
         # pass 2 (M:6226-6345): upper lists from the root down
@@ -93,11 +112,11 @@ class TreeMirror:
                 ur = dev.merge_batch(vu, dist[nn], False, self.lower[c1], dist[c1], self.is_tip[c1], True)
                 ul = dev.merge_batch(vu, dist[nn], False, self.lower[c0], dist[c0], self.is_tip[c0], True)
                 if (ur < 0).any() or (ul < 0).any():
-                    raise RuntimeError("inconsistent zero-length branches while building upper lists")
+                    return np.concatenate([nn[ur < 0], c1[ur < 0], nn[ul < 0], c0[ul < 0]])
                 self.up_right[nn] = dev.shorten_batch(ur)
                 self.up_left[nn] = dev.shorten_batch(ul)
                 self.launches += 4
-        return self
+        return None
 
     def candidate_nodes(self, min_blen):
         """Nodes whose mid-branch total list is a placement candidate (dist > effectivelyNon0BLen, M:8012)."""
