@@ -118,6 +118,14 @@ int maple_blen_batch(maple_ctx *ctx, int32_t n, const int32_t *parentList, const
                      const uint8_t *fromTipC, double *t, uint8_t *isFalse);
 /* areVectorsDifferent(pv1, pv2), M:5419-5472; list2 == -1 means None -> different */
 int maple_differ_batch(maple_ctx *ctx, int32_t n, const int32_t *list1, const int32_t *list2, uint8_t *out);
+/* Resident candidate sets for the placement loop (M:7972-8100): `lists[k]` is the parent-side list of candidate k
+ * (probVectTotUp of a branch, or probVect of a leaf for the minor-sequence test) and `frameIdx[k]` the index of the MAT
+ * reference frame it lives in.  A query is then scored against the whole set in ONE launch, given its genome list in
+ * every frame (frameLists[nFrames], e.g. produced level by level with maple_pass_branch_batch). */
+int maple_candset_create(maple_ctx *ctx, int32_t n, const int32_t *lists, const int32_t *frameIdx, int32_t nFrames,
+                         int32_t *setId);
+int maple_append_candset(maple_ctx *ctx, int32_t setId, const int32_t *frameLists, int isTipC, double bLen, double *outLK);
+int maple_minor_candset(maple_ctx *ctx, int32_t setId, const int32_t *frameLists, int onlyFindIdentical, uint8_t *out);
 /* findProbRoot(probVect) for lists already expressed in the root frame, M:4865-4912 */
 int maple_root_prob_batch(maple_ctx *ctx, int32_t n, const int32_t *list, double *outLK);
 /* isMinorSequence(probVect1, probVect2, onlyFindIdentical), M:5919-6004 -> 0 / 1 / 2 */

@@ -92,6 +92,8 @@ struct maple_ctx {
     DevBuf<uint8_t> s_search_out;
     DevBuf<int32_t> s_counter;
     DevBuf<double> s_cache;            // cached (query x node) scores of wide searches
+    struct CandSet { int32_t n = 0, nFrames = 0; int32_t *lists = nullptr, *frame = nullptr; };
+    std::vector<CandSet> candsets;     // resident candidate sets (maple_candset_create)
     int trace_query = -1;
     DevBuf<int32_t> s_trace_i;
     DevBuf<double> s_trace_d;
@@ -262,6 +264,29 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_root_prob(const DevModel *__res
     Ctx<RV, U, SS> c(m, lds);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         out[i] = root_prob_walk(c, list_ref(av, l[i]));
+}
+
+// One query against a resident candidate set: candidate k is scored against the query's list in ITS reference frame
+// (frameLists[frameIdx[k]]), so trees with MAT local references need one launch per query, not one per frame.
+template <bool RV, bool U, bool SS>
+__global__ MAPLE_APPEND_ATTR void k_append_candset(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *parent,
+                                                   const int32_t *frameIdx, const int32_t *frameLists, int isTip, double bLen,
+                                                   double *out)
+{
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = append_walk(c, list_ref(av, parent[i]), list_ref(av, frameLists[frameIdx[i]]), isTip != 0, bLen);
+}
+
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_minor_candset(int lRef, ArenaView av, int n, const int32_t *l1,
+                                                               const int32_t *frameIdx, const int32_t *frameLists,
+                                                               int onlyIdentical, uint8_t *out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = (uint8_t)minor_walk(lRef, list_ref(av, l1[i]), list_ref(av, frameLists[frameIdx[i]]), onlyIdentical != 0);
 }
 
 __global__ __launch_bounds__(MAPLE_BLOCK) void k_minor(int lRef, ArenaView av, int n, const int32_t *l1, const int32_t *l2,
@@ -655,6 +680,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     c->t_dist.release(); c->t_tip.release(); c->t_nodes.release();
     c->s_search_ws.release(); c->s_search_out.release(); c->s_counter.release(); c->s_cache.release();
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
+    for (auto &cs : c->candsets) { if (cs.lists) (void)hipFree(cs.lists); if (cs.frame) (void)hipFree(cs.frame); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return MAPLE_OK;
@@ -871,6 +897,8 @@ extern "C" int maple_mutations_upload(maple_ctx *c, int32_t n, const int64_t *of
 }
 
 // ---- helpers for batch calls -----------------------------------------------------------------------
+static int ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b);
+
 template <class T> static int h2d(maple_ctx *c, DevBuf<T> &b, const T *src, size_t n)
 {
     HIPCK(c, b.reserve(n ? n : 1));
@@ -1034,6 +1062,63 @@ extern "C" int maple_differ_batch(maple_ctx *c, int32_t n, const int32_t *l1, co
                                                                           c->s_u8[0].p));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(out, c->s_u8[0].p, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MAPLE_OK;
+}
+
+// ---- resident candidate sets (placement of one query at a time against the whole tree) --------------------------
+extern "C" int maple_candset_create(maple_ctx *c, int32_t n, const int32_t *lists, const int32_t *frameIdx, int32_t nFrames,
+                                    int32_t *setId)
+{
+    if (!c || n <= 0 || !lists || !frameIdx || nFrames <= 0 || !setId) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(check_ids(c, n, lists, false, "lists"));
+    for (int i = 0; i < n; i++)
+        if (frameIdx[i] < 0 || frameIdx[i] >= nFrames) return fail(c, MAPLE_ERR_ARG, "frameIdx[%d] out of range", i);
+    maple_ctx::CandSet cs;
+    cs.n = n; cs.nFrames = nFrames;
+    HIPCK(c, hipMalloc((void **)&cs.lists, n * sizeof(int32_t)));
+    HIPCK(c, hipMalloc((void **)&cs.frame, n * sizeof(int32_t)));
+    HIPCK(c, hipMemcpy(cs.lists, lists, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCK(c, hipMemcpy(cs.frame, frameIdx, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    *setId = (int32_t)c->candsets.size();
+    c->candsets.push_back(cs);
+    return MAPLE_OK;
+}
+
+extern "C" int maple_append_candset(maple_ctx *c, int32_t setId, const int32_t *frameLists, int isTipC, double bLen, double *out)
+{
+    if (!c || setId < 0 || setId >= (int32_t)c->candsets.size() || !frameLists || !out) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    const auto &cs = c->candsets[setId];
+    TRY(check_ids(c, cs.nFrames, frameLists, false, "frameLists"));
+    TRY(h2d(c, c->s_i32[0], frameLists, (size_t)cs.nFrames));
+    HIPCK(c, c->s_f64[0].reserve(cs.n));
+    hipEvent_t e0, e1;
+    TRY(ev_pair(c, &e0, &e1));
+    HIPCK(c, hipEventRecord(e0, c->stream));
+    DISPATCH3(c, k_append_candset, <<<grid_for(cs.n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), cs.n, cs.lists, cs.frame,
+                                                                                  c->s_i32[0].p, isTipC, bLen, c->s_f64[0].p));
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipEventRecord(e1, c->stream));
+    HIPCK(c, hipMemcpyAsync(out, c->s_f64[0].p, cs.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MAPLE_OK;
+}
+
+extern "C" int maple_minor_candset(maple_ctx *c, int32_t setId, const int32_t *frameLists, int onlyFindIdentical, uint8_t *out)
+{
+    if (!c || setId < 0 || setId >= (int32_t)c->candsets.size() || !frameLists || !out) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    const auto &cs = c->candsets[setId];
+    TRY(check_ids(c, cs.nFrames, frameLists, false, "frameLists"));
+    TRY(h2d(c, c->s_i32[0], frameLists, (size_t)cs.nFrames));
+    HIPCK(c, c->s_u8[0].reserve(cs.n));
+    hipLaunchKernelGGL(k_minor_candset, dim3(grid_for(cs.n)), dim3(MAPLE_BLOCK), 0, c->stream, c->lRef, view(c), cs.n, cs.lists,
+                       cs.frame, c->s_i32[0].p, onlyFindIdentical, c->s_u8[0].p);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(out, c->s_u8[0].p, cs.n, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return MAPLE_OK;
 }

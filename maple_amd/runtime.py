@@ -22,7 +22,8 @@ EXPORTS = [
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
     "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
-    "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
+    "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
+    "maple_minor_candset", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
 ]
 
 
@@ -245,6 +246,24 @@ class Device:
         out = np.zeros(len(l1), dtype=np.uint8)
         self._ck(self.lib.maple_differ_batch(self.h, len(l1), _ptr(l1), _ptr(l2), _ptr(out)))
         return out.astype(bool)
+
+    def candset_create(self, lists, frame_idx, n_frames):
+        lists, frame_idx = _i32(lists), _i32(frame_idx)
+        sid = C.c_int32()
+        self._ck(self.lib.maple_candset_create(self.h, len(lists), _ptr(lists), _ptr(frame_idx), int(n_frames), C.byref(sid)))
+        return sid.value, len(lists)
+
+    def append_candset(self, cset, frame_lists, isTipC, bLen):
+        fl = _i32(frame_lists)
+        out = np.zeros(cset[1])
+        self._ck(self.lib.maple_append_candset(self.h, cset[0], _ptr(fl), int(bool(isTipC)), C.c_double(bLen), _ptr(out)))
+        return out
+
+    def minor_candset(self, cset, frame_lists, onlyFindIdentical=False):
+        fl = _i32(frame_lists)
+        out = np.zeros(cset[1], dtype=np.uint8)
+        self._ck(self.lib.maple_minor_candset(self.h, cset[0], _ptr(fl), int(bool(onlyFindIdentical)), _ptr(out)))
+        return out
 
     def root_prob_batch(self, lists):
         lists = _i32(lists)

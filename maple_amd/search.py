@@ -77,6 +77,16 @@ class PlacementSearcher:
         path = [t.id_mut[t.root]] if t.id_mut[t.root] >= 0 else []
         self.root_vect = int(dev.root_vector_batch([t.id_lower[t.root]], [0.0], [False], [path])[0])
         self.is_tip = np.asarray([(not c) and (m == 0) for c, m in zip(t.children, t.n_minor)])
+        # resident candidate sets: frame index 0 is the root frame, then the frames in a fixed order
+        self.frame_order = [-1] + [f for fl in self.frame_levels for f in fl]
+        fidx = {f: i for i, f in enumerate(self.frame_order)}
+        cand_frames = [fidx[int(self.frame[v])] for v in self.cand] + [fidx[int(self.frame[t.root])]]
+        self.cset_cand = dev.candset_create(np.concatenate([t.id_totUp[self.cand], [self.root_vect]]), cand_frames,
+                                            len(self.frame_order))
+        self.cset_leaf = None
+        if len(self.leaves):
+            self.cset_leaf = dev.candset_create(t.id_lower[self.leaves], [fidx[int(self.frame[v])] for v in self.leaves],
+                                                len(self.frame_order))
 
     # ---------------------------------------------------------------------------------------------
     def _frame_lists(self, q_id):
@@ -111,13 +121,12 @@ class PlacementSearcher:
         fr = self.frame
         # one launch: the query against every candidate branch (+ the root), one launch: minor test on every leaf
         cand = self.cand
-        child_ids = np.asarray([U[int(fr[v])] for v in cand] + [U[int(fr[t.root])]], dtype=np.int32)
-        parent_ids = np.concatenate([t.id_totUp[cand], [self.root_vect]]).astype(np.int32)
-        sc = dev.append_batch(parent_ids, child_ids, True, p.oneMutBLen)
+        frame_lists = [U[f] for f in self.frame_order]
+        sc = dev.append_candset(self.cset_cand, frame_lists, True, p.oneMutBLen)
         score = dict(zip(cand.tolist(), sc[:-1].tolist()))
         minor = {}
-        if len(self.leaves):
-            mres = dev.minor_batch(t.id_lower[self.leaves], [U[int(fr[v])] for v in self.leaves], p.onlyFindIdentical)
+        if self.cset_leaf is not None:
+            mres = dev.minor_candset(self.cset_leaf, frame_lists, p.onlyFindIdentical)
             minor = dict(zip(self.leaves.tolist(), mres.tolist()))
         n_append = 1
 
