@@ -113,3 +113,79 @@ def tree_log_likelihood(dev: Device, tree: HostTree):
         return total + root_lk, root_lk
     finally:
         dev.release(mark)
+
+
+def rebuild_genome_lists(dev: Device, tree: HostTree):
+    """reCalculateAllGenomeLists (M:6013-6347) on the device for a tree WITH MAT local references: given only the
+    tips' lower lists (already uploaded by HostTree.upload) recompute probVect of every internal node (pass 1) and
+    probVectUpRight / probVectUpLeft / probVectTotUp of every node (pass 2), level by level, as batches of
+    passGenomeListThroughBranch / mergeVectors / rootVector / shorten launches.  Returns the four id arrays."""
+    n = tree.n
+    up = np.asarray([-1 if u is None else u for u in tree.up])
+    c0 = np.asarray([c[0] if c else -1 for c in tree.children])
+    c1 = np.asarray([c[1] if c else -1 for c in tree.children])
+    dist = np.asarray(tree.dist, dtype=np.float64)
+    tip = np.asarray([(not c) and (m == 0) for c, m in zip(tree.children, tree.n_minor)])
+    mut = tree.id_mut
+    order = tree.preorder()
+    depth = np.zeros(n, dtype=np.int64)
+    reach = np.zeros(n, dtype=bool)
+    for v in order:
+        reach[v] = True
+        if up[v] >= 0:
+            depth[v] = depth[up[v]] + 1
+    lower = -np.ones(n, dtype=np.int32)
+    leaves = np.nonzero(reach & (c0 < 0))[0]
+    lower[leaves] = tree.id_lower[leaves]
+    up_right = -np.ones(n, dtype=np.int32)
+    up_left = -np.ones(n, dtype=np.int32)
+    tot_up = -np.ones(n, dtype=np.int32)
+
+    def passed(ids, nodes, direction_up):
+        """lists `ids` moved across the branches above `nodes` (only where those carry mutations)"""
+        ids = np.asarray(ids, dtype=np.int32).copy()
+        need = np.nonzero(mut[nodes] >= 0)[0]
+        if len(need):
+            ids[need] = dev.pass_branch_batch(ids[need], mut[nodes[need]], direction_up)
+        return ids
+
+    internal = np.nonzero(reach & (c0 >= 0))[0]
+    maxd = int(depth[reach].max())
+    for d in range(maxd, -1, -1):                                   # pass 1, M:6031-6200
+        nodes = internal[depth[internal] == d]
+        if len(nodes) == 0:
+            continue
+        a, b = c0[nodes], c1[nodes]
+        out = dev.merge_batch(passed(lower[a], a, True), dist[a], tip[a], passed(lower[b], b, True), dist[b], tip[b], False)
+        if (out < 0).any():
+            raise RuntimeError("inconsistent lower lists (the reference would call updateBLen here)")
+        lower[nodes] = dev.shorten_batch(out)
+    r = tree.root                                                   # pass 2, M:6226-6345
+    if c0[r] >= 0:
+        path = [[int(mut[r])] if mut[r] >= 0 else []] * 2
+        kids = np.asarray([c1[r], c0[r]])
+        rv = dev.root_vector_batch(passed(lower[kids], kids, True), dist[kids], tip[kids], path)
+        up_right[r], up_left[r] = rv[0], rv[1]
+    for d in range(1, maxd + 1):
+        nodes = np.nonzero(reach & (depth == d))[0]
+        if len(nodes) == 0:
+            continue
+        p = up[nodes]
+        vect_up = passed(np.where(c0[p] == nodes, up_right[p], up_left[p]), nodes, False)
+        nz = dist[nodes] != 0.0
+        if nz.any():
+            nn = nodes[nz]
+            tu = dev.merge_batch(vect_up[nz], dist[nn] / 2, False, lower[nn], dist[nn] / 2, tip[nn], True)
+            ok = tu >= 0
+            tot_up[nn[ok]] = dev.shorten_batch(tu[ok])
+        inner = c0[nodes] >= 0
+        if inner.any():
+            nn, vu = nodes[inner], vect_up[inner]
+            a, b = c0[nn], c1[nn]
+            ur = dev.merge_batch(vu, dist[nn], False, passed(lower[b], b, True), dist[b], tip[b], True)
+            ul = dev.merge_batch(vu, dist[nn], False, passed(lower[a], a, True), dist[a], tip[a], True)
+            if (ur < 0).any() or (ul < 0).any():
+                raise RuntimeError("inconsistent upper lists (the reference would call updateBLen here)")
+            up_right[nn] = dev.shorten_batch(ur)
+            up_left[nn] = dev.shorten_batch(ul)
+    return lower, up_right, up_left, tot_up

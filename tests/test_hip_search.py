@@ -219,3 +219,34 @@ def test_device_search_vs_oracle_search_on_gpu_built_tree():
             assert np.allclose(g[k], o[k], rtol=1e-11, atol=1e-15), k
         assert g["nAppend"].sum() > 10000
     dev.close()
+
+
+def test_rebuild_all_genome_lists_matches_reference(env):
+    """reCalculateAllGenomeLists (M:6013-6347) as level-synchronous GPU batches, on the reference's own final tree
+    (with MAT local references): from the tips' lists alone, every other list of the tree must come out as the
+    reference computed it.
+
+    With an error model the reference's tips share their ambiguity vectors between samples (one object per
+    ambiguity code, rewritten in place by updateProbVectTerminalNode M:3966 for whichever tip is visited last with
+    that site's error rate), so its internal lists were merged from tip values that no longer exist in the final
+    tree; there only the lists that no such tip feeds can agree (more than half of them do)."""
+    from maple_amd.tree_host import rebuild_genome_lists
+    f, dev, tree = env
+    mark = dev.mark()
+    lower, up_right, up_left, tot_up = rebuild_genome_lists(dev, tree)
+    t = f["tree"]
+    exact = not f["model"]["usingErrorRate"]
+    checked = n_same = 0
+    for ids, key in ((lower, "probVect"), (up_right, "probVectUpRight"), (up_left, "probVectUpLeft"), (tot_up, "probVectTotUp")):
+        nodes = [v for v in tree.preorder() if t[key][v]]
+        assert all(ids[v] >= 0 for v in nodes), key
+        got = dev.download(ids[nodes])
+        for v, g in zip(nodes, got):
+            want = tup(t[key][v])
+            same = lists_match(g, want, 1e-9)
+            assert same or not exact, (key, v)
+            n_same += bool(same)
+            checked += 1
+    assert checked > 700
+    assert n_same > 0.5 * checked, (n_same, checked)
+    dev.release(mark)
