@@ -182,6 +182,29 @@ int maple_spr_search_batch(maple_ctx *ctx, int32_t n, const int32_t *nodes, cons
                            int32_t *placement, double *improvement, double *currentLK, int32_t *nAppend,
                            int32_t *status, int32_t *outRprList);
 
+typedef struct {
+    double oneMutBLen;                          /* M:3606 */
+    double effectivelyNon0BLen;                 /* M:3607 */
+    double thresholdLogLK;                      /* x log(lRef), M:3613 */
+    double thresholdLogLKoptimization;          /* x log(lRef), M:3610 */
+    double thresholdLogLKconsecutivePlacement;  /* M:63 */
+    int32_t allowedFails;                       /* M:50 */
+    int32_t strictStopRules;                    /* M:56 */
+    int32_t onlyFindIdentical;                  /* the minor-sequence mode of M:7976 (any error-model flag, HnZ, ...) */
+} maple_placement_params;
+
+/* findBestParentForNewSample (M:7912-8292) for nQ query samples against the uploaded (frozen) tree -- the batch shape
+ * of --findSamplePlacements / --lineageRefs (M:11190-11220).  qLists = the samples' genome lists in the root's
+ * reference frame.  Every query is scored against every branch in one launch (each in that branch's MAT reference
+ * frame), the reference's traversal, stop rules and tie-breaks are replayed on the device (one lane per query), and the
+ * short lists are refined in one batch (M:8101-8187).  Per query: bestNode, bestScore, blen3 = (top, bottom,
+ * appending; False -> 0.0), bestDiffs = id of the list the reference returns as bestDiffs (a new or an input list),
+ * nAppend = appendProbNode evaluations the REFERENCE would have issued, status: 0 placed by likelihood,
+ * 1 = the query is a minor sequence of bestNode (score 1.0, M:7986-8003), -6 short list or stack overflow. */
+int maple_placement_search_batch(maple_ctx *ctx, int32_t nQ, const int32_t *qLists, const maple_placement_params *params,
+                                 int32_t *bestNode, double *bestScore, double *blen3, int32_t *bestDiffs,
+                                 int32_t *nAppend, int32_t *status);
+
 /* Debugging aid: record the visit sequence of query index `query` of the next maple_spr_search_batch
  * (per visited item: t1, direction, needsUpdating, failedPasses | lastLK, midProb); -1 switches it off. */
 int maple_debug_trace_query(maple_ctx *ctx, int32_t query);

@@ -3,7 +3,9 @@
 #include "../../include/maple_hip.h"
 #include "genome_dev.h"
 #include "search_dev.h"
+#include "placement_dev.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -34,6 +36,17 @@ template <class T> struct DevBuf {     // grow-only device scratch
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct PlaceMeta {                     // derived from the uploaded tree, rebuilt when it or effectivelyNon0BLen changes
+    bool valid = false;
+    double effNon0 = -1.0;
+    int32_t nF = 0, maxDepth = 0;
+    std::vector<int32_t> frameOf;                  // per node
+    std::vector<int32_t> frameNode, frameParent;   // per frame (frame 0 = the root's reference, node -1)
+    std::vector<int32_t> levelStart;               // frames 1.. sorted by nesting depth; level l = [levelStart[l], levelStart[l+1])
+    std::vector<int32_t> cand, leaves;             // node ids
+    DevBuf<int32_t> d_frameOf, d_candIdx, d_leafIdx, d_candList, d_candFrame, d_leafList, d_leafFrame;
 };
 
 struct maple_ctx {
@@ -94,6 +107,13 @@ struct maple_ctx {
     DevBuf<double> s_cache;            // cached (query x node) scores of wide searches
     struct CandSet { int32_t n = 0, nFrames = 0; int32_t *lists = nullptr, *frame = nullptr; };
     std::vector<CandSet> candsets;     // resident candidate sets (maple_candset_create)
+    // batched placement (maple_placement_search_batch)
+    PlaceMeta *place = nullptr;
+    std::vector<int32_t> h_tree_c0, h_tree_c1, h_tree_mut, h_tree_totUp, h_tree_upRight, h_tree_upLeft;
+    DevBuf<int32_t> p_i32[4];
+    DevBuf<double> p_f64[2], p_score;
+    DevBuf<int16_t> p_i16;
+    DevBuf<uint8_t> p_u8, p_minor;
     int trace_query = -1;
     DevBuf<int32_t> s_trace_i;
     DevBuf<double> s_trace_d;
@@ -679,6 +699,15 @@ extern "C" int maple_destroy(maple_ctx *c)
     for (auto &b : c->t_i32) b.release();
     c->t_dist.release(); c->t_tip.release(); c->t_nodes.release();
     c->s_search_ws.release(); c->s_search_out.release(); c->s_counter.release(); c->s_cache.release();
+    for (auto &b : c->p_i32) b.release();
+    for (auto &b : c->p_f64) b.release();
+    c->p_score.release(); c->p_i16.release(); c->p_u8.release(); c->p_minor.release();
+    if (c->place) {
+        PlaceMeta &M = *c->place;
+        M.d_frameOf.release(); M.d_candIdx.release(); M.d_leafIdx.release(); M.d_candList.release(); M.d_candFrame.release();
+        M.d_leafList.release(); M.d_leafFrame.release();
+        delete c->place;
+    }
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     for (auto &cs : c->candsets) { if (cs.lists) (void)hipFree(cs.lists); if (cs.frame) (void)hipFree(cs.frame); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1400,6 +1429,14 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     c->h_tree_lower.assign(lower, lower + n);
     c->h_tree_dist.assign(dist, dist + n);
     c->h_tree_tip.assign(isTip, isTip + n);
+    c->h_tree_c0.assign(child0, child0 + n);
+    c->h_tree_c1.assign(child1, child1 + n);
+    c->h_tree_mut.assign(mutList, mutList + n);
+    c->h_tree_totUp.assign(totUp, totUp + n);
+    c->h_tree_upRight.assign(upRight, upRight + n);
+    c->h_tree_upLeft.assign(upLeft, upLeft + n);
+    if (!c->place) c->place = new PlaceMeta();
+    c->place->valid = false;
     c->tree_has_mut = false;
     for (int i = 0; i < n; i++) if (mutList[i] >= 0) c->tree_has_mut = true;
     c->tree_set = true;
@@ -1572,6 +1609,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
 // counter is only calibrated for 16 B/lane coalesced streams).  Every lane walks its own contiguous 512-byte "list"
 // with dependent 8-byte loads, exactly like a genome-list walk, over a buffer far larger than the 256 MiB Infinity
 // Cache; the byte count is known, so FETCH_SIZE / bytes is the correction factor for k_append*.
+#include "placement_host.h"
+
 __global__ __launch_bounds__(MAPLE_BLOCK) void k_calib_walk(const unsigned long long *buf, long long nLists, unsigned long long *sink)
 {
     unsigned long long acc = 0;

@@ -1,0 +1,346 @@
+// maple_placement_search_batch: findBestParentForNewSample (MAPLEv0.7.5.4.py:7912-8292) for MANY query samples on one
+// frozen tree (the shape of --findSamplePlacements / --lineageRefs, M:11190-11220, and of online batches).
+// Included at the end of maple_hip.hip; composes the library's own batch entry points plus three kernels:
+//   k_place_score  - every query against every candidate branch, each in the candidate's MAT reference frame
+//   k_place_minor  - isMinorSequence of every query against every leaf
+//   k_place_replay - the reference's depth-first traversal over those scores, one lane per query
+#pragma once
+
+template <bool RV, bool U, bool SS>
+__global__ MAPLE_APPEND_ATTR void k_place_score(const DevModel *__restrict__ mp, ArenaView av, int nQ, int nF,
+                                                const int32_t *qFrameLists, int nC, const int32_t *cand,
+                                                const int32_t *candFrame, double bLen, double *out)
+{
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const int nChunks = (nC + MAPLE_BLOCK - 1) / MAPLE_BLOCK;
+    const int tiles = nQ * nChunks;
+    for (int j = blockIdx.x; j < tiles; j += gridDim.x) {
+        const int q = j / nChunks;
+        const int k = (j - q * nChunks) * MAPLE_BLOCK + threadIdx.x;
+        if (k < nC)
+            out[(long long)q * nC + k] =
+                append_walk(c, list_ref(av, cand[k]), list_ref(av, qFrameLists[(long long)q * nF + candFrame[k]]), true, bLen);
+    }
+}
+
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_place_minor(int lRef, ArenaView av, int nQ, int nF, const int32_t *qFrameLists,
+                                                             int nL, const int32_t *leaf, const int32_t *leafFrame,
+                                                             int onlyIdentical, uint8_t *out)
+{
+    const long long tot = (long long)nQ * nL;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i / nL), k = (int)(i - (long long)q * nL);
+        out[i] = (uint8_t)minor_walk(lRef, list_ref(av, leaf[k]), list_ref(av, qFrameLists[(long long)q * nF + leafFrame[k]]),
+                                     onlyIdentical != 0);
+    }
+}
+
+static int place_meta(maple_ctx *c, double effNon0)
+{
+    PlaceMeta &M = *c->place;
+    if (M.valid && M.effNon0 == effNon0) return MAPLE_OK;
+    const int32_t n = c->dtree.n, root = c->dtree.root;
+    const auto &up = c->h_tree_up;
+    const auto &c0 = c->h_tree_c0, &c1 = c->h_tree_c1, &mut = c->h_tree_mut, &totUp = c->h_tree_totUp, &lower = c->h_tree_lower;
+    std::vector<int32_t> order, depth(n, 0), fdepth;
+    order.reserve(n);
+    std::vector<int32_t> st{root};
+    M.frameOf.assign(n, -1);
+    M.frameNode.assign(1, -1);
+    M.frameParent.assign(1, -1);
+    fdepth.assign(1, 0);
+    M.maxDepth = 0;
+    while (!st.empty()) {
+        const int32_t v = st.back();
+        st.pop_back();
+        order.push_back(v);
+        const int32_t pf = up[v] < 0 || v == root ? 0 : M.frameOf[up[v]];
+        if (v != root) depth[v] = depth[up[v]] + 1;
+        if (depth[v] > M.maxDepth) M.maxDepth = depth[v];
+        if (mut[v] >= 0) {
+            M.frameOf[v] = (int32_t)M.frameNode.size();
+            M.frameNode.push_back(v);
+            M.frameParent.push_back(pf);
+            fdepth.push_back(fdepth[pf] + 1);
+        } else M.frameOf[v] = pf;
+        if (c0[v] >= 0) { st.push_back(c0[v]); st.push_back(c1[v]); }
+    }
+    // renumber frames by nesting depth so that a level is a contiguous range (parents always in earlier levels)
+    const int32_t nF = (int32_t)M.frameNode.size();
+    std::vector<int32_t> perm(nF), inv(nF);
+    for (int i = 0; i < nF; i++) perm[i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return fdepth[a] < fdepth[b]; });
+    for (int i = 0; i < nF; i++) inv[perm[i]] = i;
+    std::vector<int32_t> fn(nF), fp(nF);
+    M.levelStart.clear();
+    for (int i = 0; i < nF; i++) {
+        fn[i] = M.frameNode[perm[i]];
+        fp[i] = M.frameParent[perm[i]] < 0 ? -1 : inv[M.frameParent[perm[i]]];
+        if (i > 0 && fdepth[perm[i]] != fdepth[perm[i - 1]]) M.levelStart.push_back(i);
+    }
+    M.levelStart.push_back(nF);
+    M.frameNode.swap(fn);
+    M.frameParent.swap(fp);
+    for (auto &f : M.frameOf) if (f >= 0) f = inv[f];
+    M.nF = nF;
+    M.cand.clear();
+    M.leaves.clear();
+    std::vector<int32_t> candIdx(n, -1), leafIdx(n, -1), candList, candFrame, leafList, leafFrame;
+    for (int32_t v : order) {
+        if (v != root && up[v] >= 0 && c->h_tree_dist[v] > effNon0 && totUp[v] >= 0) {      // M:8049
+            candIdx[v] = (int32_t)M.cand.size();
+            M.cand.push_back(v);
+            candList.push_back(totUp[v]);
+            candFrame.push_back(M.frameOf[v]);
+        }
+        if (c0[v] < 0) {
+            if (lower[v] < 0) return fail(c, MAPLE_ERR_STATE, "leaf %d has no lower genome list", v);
+            leafIdx[v] = (int32_t)M.leaves.size();
+            M.leaves.push_back(v);
+            leafList.push_back(lower[v]);
+            leafFrame.push_back(M.frameOf[v]);
+        }
+    }
+    // reserve one extra candidate column for the root vector (its list id is filled in per call)
+    candList.push_back(-1);
+    candFrame.push_back(M.frameOf[root]);
+    TRY(h2d(c, M.d_frameOf, M.frameOf.data(), (size_t)n));
+    TRY(h2d(c, M.d_candIdx, candIdx.data(), (size_t)n));
+    TRY(h2d(c, M.d_leafIdx, leafIdx.data(), (size_t)n));
+    TRY(h2d(c, M.d_candList, candList.data(), candList.size()));
+    TRY(h2d(c, M.d_candFrame, candFrame.data(), candFrame.size()));
+    TRY(h2d(c, M.d_leafList, leafList.data(), leafList.size()));
+    TRY(h2d(c, M.d_leafFrame, leafFrame.data(), leafFrame.size()));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    M.effNon0 = effNon0;
+    M.valid = true;
+    return MAPLE_OK;
+}
+
+template <class T> static int d2h_vec(maple_ctx *c, std::vector<T> &dst, const T *src, size_t n)
+{
+    dst.resize(n);
+    if (n) HIPCK(c, hipMemcpyAsync(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    return MAPLE_OK;
+}
+
+extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int32_t *qLists, const maple_placement_params *pp,
+                                            int32_t *bestNode, double *bestScore, double *blen3, int32_t *bestDiffs,
+                                            int32_t *nAppend, int32_t *status)
+{
+    if (!c || nQ < 0 || !qLists || !pp || !bestNode || !bestScore || !blen3 || !bestDiffs || !nAppend || !status)
+        return MAPLE_ERR_ARG;
+    if (nQ == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    if (!c->tree_set) return fail(c, MAPLE_ERR_STATE, "maple_tree_upload has not been called");
+    TRY(check_ids(c, nQ, qLists, false, "qLists"));
+    TRY(place_meta(c, pp->effectivelyNon0BLen));
+    PlaceMeta &M = *c->place;
+    const int32_t nF = M.nF, nC = (int32_t)M.cand.size(), nCols = nC + 1, nL = (int32_t)M.leaves.size();
+    const int32_t root = c->dtree.root;
+    const auto &mut = c->h_tree_mut;
+    // rootVector(probVect[root], False, False, tree, root), M:7958: does not depend on the query
+    int32_t rootVect = -1;
+    {
+        const double zero = 0.0;
+        const uint8_t nt = 0;
+        const int64_t off[2] = {0, mut[root] >= 0 ? 1 : 0};
+        const int32_t path[1] = {mut[root]};
+        TRY(maple_root_vector_batch(c, 1, &c->h_tree_lower[root], &zero, &nt, off, path, &rootVect));
+        HIPCK(c, hipMemcpyAsync(M.d_candList.p + nC, &rootVect, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+    }
+    PlaceParams P;
+    P.thrLK = pp->thresholdLogLK; P.thrOpt = pp->thresholdLogLKoptimization; P.thrConsec = pp->thresholdLogLKconsecutivePlacement;
+    P.allowedFails = pp->allowedFails; P.strict = pp->strictStopRules;
+    // queries per chunk: the score matrix stays below 2 GiB
+    const int64_t maxCells = (int64_t)1 << 28;
+    const int32_t chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(nQ, maxCells / std::max(nCols, 1)));
+    const int stackCap = M.maxDepth + 4, words = (nF + 31) / 32;
+    for (int32_t q0 = 0; q0 < nQ; q0 += chunk) {
+        const int32_t nq = std::min(chunk, nQ - q0);
+        // ---- the query list in every reference frame, level by level (passGenomeListThroughBranch, M:8082-8092)
+        std::vector<int32_t> U((size_t)nq * nF);
+        for (int q = 0; q < nq; q++) U[(size_t)q * nF] = qLists[q0 + q];
+        {
+            int32_t a = 1;
+            for (size_t l = 0; l < M.levelStart.size(); l++) {
+                const int32_t b = M.levelStart[l];
+                if (b > a) {
+                    const size_t cnt = (size_t)nq * (b - a);
+                    std::vector<int32_t> src(cnt), ml(cnt), out(cnt);
+                    std::vector<uint8_t> dirUp(cnt, 0);
+                    size_t k = 0;
+                    for (int q = 0; q < nq; q++)
+                        for (int f = a; f < b; f++, k++) { src[k] = U[(size_t)q * nF + M.frameParent[f]]; ml[k] = mut[M.frameNode[f]]; }
+                    TRY(maple_pass_branch_batch(c, (int32_t)cnt, src.data(), ml.data(), dirUp.data(), out.data()));
+                    k = 0;
+                    for (int q = 0; q < nq; q++)
+                        for (int f = a; f < b; f++, k++) U[(size_t)q * nF + f] = out[k];
+                }
+                a = b;
+            }
+        }
+        // ---- scores, minor tests, traversal
+        DevBuf<int32_t> &dU = c->p_i32[0];
+        TRY(h2d(c, dU, U.data(), U.size()));
+        HIPCK(c, c->p_score.reserve((size_t)nq * nCols));
+        HIPCK(c, c->p_minor.reserve((size_t)nq * std::max(nL, 1)));
+        {
+            const long long tiles = (long long)nq * ((nCols + MAPLE_BLOCK - 1) / MAPLE_BLOCK);
+            const int grid = tiles < 256 * 8 ? (int)tiles : 256 * 8;
+            hipEvent_t e0, e1;
+            TRY(ev_pair(c, &e0, &e1));
+            HIPCK(c, hipEventRecord(e0, c->stream));
+            DISPATCH3(c, k_place_score, <<<grid, MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), nq, nF, dU.p, nCols, M.d_candList.p,
+                                                                                M.d_candFrame.p, pp->oneMutBLen, c->p_score.p));
+            HIPCK(c, hipGetLastError());
+            HIPCK(c, hipEventRecord(e1, c->stream));
+        }
+        if (nL > 0) {
+            hipLaunchKernelGGL(k_place_minor, dim3(grid_for((int)std::min<long long>((long long)nq * nL, 1 << 30))), dim3(MAPLE_BLOCK), 0,
+                               c->stream, c->lRef, view(c), nq, nF, dU.p, nL, M.d_leafList.p, M.d_leafFrame.p,
+                               pp->onlyFindIdentical, c->p_minor.p);
+            HIPCK(c, hipGetLastError());
+        }
+        const size_t SL = MAPLE_PLACE_SHORTLIST;
+        HIPCK(c, c->p_i32[1].reserve((size_t)nq * stackCap));             // stack nodes
+        HIPCK(c, c->p_f64[0].reserve((size_t)nq * stackCap));             // stack lastLK
+        HIPCK(c, c->p_i16.reserve((size_t)nq * stackCap));                // stack fails
+        HIPCK(c, c->p_i32[2].reserve((size_t)nq * words));                // frame bits
+        HIPCK(c, c->p_i32[3].reserve((size_t)nq * (6 + SL)));             // status, minorNode, bestNode, nAppend, missed, nShort, slNode
+        HIPCK(c, c->p_f64[1].reserve((size_t)nq * (2 + SL)));             // bestLK, originalLK, slLK
+        HIPCK(c, c->p_u8.reserve((size_t)nq * (1 + SL)));                 // bestShort, slShort
+        PlaceOut o;
+        int32_t *ib = c->p_i32[3].p;
+        o.status = ib; o.minorNode = ib + nq; o.bestNode = ib + 2 * (size_t)nq; o.nAppend = ib + 3 * (size_t)nq;
+        o.missed = ib + 4 * (size_t)nq; o.nShort = ib + 5 * (size_t)nq; o.slNode = ib + 6 * (size_t)nq;
+        double *fb = c->p_f64[1].p;
+        o.bestLK = fb; o.originalLK = fb + nq; o.slLK = fb + 2 * (size_t)nq;
+        o.bestShort = c->p_u8.p; o.slShort = c->p_u8.p + nq;
+        hipLaunchKernelGGL(k_place_replay, dim3((nq + 63) / 64), dim3(64), 0, c->stream, c->dtree, P, nq, nCols, nC, c->p_score.p,
+                           M.d_candIdx.p, std::max(nL, 1), c->p_minor.p, M.d_leafIdx.p, M.d_frameOf.p, nF, stackCap, c->p_i32[1].p,
+                           c->p_f64[0].p, c->p_i16.p, (uint32_t *)c->p_i32[2].p, o);
+        HIPCK(c, hipGetLastError());
+        std::vector<int32_t> hi;
+        std::vector<double> hf;
+        std::vector<uint8_t> hb;
+        TRY(d2h_vec(c, hi, ib, (size_t)nq * (6 + SL)));
+        TRY(d2h_vec(c, hf, fb, (size_t)nq * (2 + SL)));
+        TRY(d2h_vec(c, hb, c->p_u8.p, (size_t)nq * (1 + SL)));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        const int32_t *hStatus = hi.data(), *hMinor = hi.data() + nq, *hBest = hi.data() + 2 * (size_t)nq,
+                      *hNApp = hi.data() + 3 * (size_t)nq, *hNShort = hi.data() + 5 * (size_t)nq,
+                      *hSlNode = hi.data() + 6 * (size_t)nq;
+        const double *hBestLK = hf.data(), *hOrig = hf.data() + nq;
+        const uint8_t *hBestShort = hb.data(), *hSlShort = hb.data() + nq;
+        // ---- shortened query lists that the outcome refers to (shorten, M:8066): distinct (query, frame) pairs
+        std::vector<int32_t> S((size_t)nq * nF, -1), shSrc;
+        std::vector<size_t> shKey;
+        auto want_short = [&](int q, int f) {
+            const size_t key = (size_t)q * nF + f;
+            if (S[key] == -1) { S[key] = -2; shKey.push_back(key); shSrc.push_back(U[key]); }
+        };
+        for (int q = 0; q < nq; q++) {
+            if (hStatus[q] < 0) continue;
+            const int nb = hStatus[q] == 1 ? hMinor[q] : hBest[q];
+            if (hBestShort[q]) want_short(q, M.frameOf[nb]);
+            if (hStatus[q] == 0)
+                for (int i = 0; i < hNShort[q]; i++)
+                    if (hSlShort[(size_t)q * SL + i]) want_short(q, M.frameOf[hSlNode[(size_t)q * SL + i]]);
+        }
+        if (!shSrc.empty()) {
+            std::vector<int32_t> out(shSrc.size());
+            TRY(maple_shorten_batch(c, (int32_t)shSrc.size(), shSrc.data(), out.data()));
+            for (size_t i = 0; i < shKey.size(); i++) S[shKey[i]] = out[i];
+        }
+        auto qlist = [&](int q, int node, bool shortened) {
+            const size_t key = (size_t)q * nF + M.frameOf[node];
+            return shortened ? S[key] : U[key];
+        };
+        // ---- short-list refinement, M:8101-8187: one batch over every (query, short-listed node)
+        std::vector<int32_t> rq, rnode, ridx;
+        for (int q = 0; q < nq; q++)
+            if (hStatus[q] == 0)
+                for (int i = 0; i < hNShort[q]; i++) { rq.push_back(q); rnode.push_back(hSlNode[(size_t)q * SL + i]); ridx.push_back(i); }
+        const size_t nr = rq.size();
+        std::vector<double> ev(4 * nr), comp(2 * nr);
+        if (nr) {
+            // the upper list of each distinct node, expressed below the node's own mutations
+            std::vector<int32_t> upOf(c->dtree.n, -2), needNode, needSrc, needMut;
+            for (size_t i = 0; i < nr; i++) {
+                const int32_t v = rnode[i];
+                if (upOf[v] != -2) continue;
+                const int32_t u = c->h_tree_up[v];
+                const int32_t uid = c->h_tree_c0[u] == v ? c->h_tree_upRight[u] : c->h_tree_upLeft[u];
+                if (uid < 0) return fail(c, MAPLE_ERR_STATE, "node %d has no upper genome list", u);
+                upOf[v] = uid;
+                if (mut[v] >= 0) { needNode.push_back(v); needSrc.push_back(uid); needMut.push_back(mut[v]); }
+            }
+            if (!needNode.empty()) {
+                std::vector<int32_t> out(needNode.size());
+                std::vector<uint8_t> dn(needNode.size(), 0);
+                TRY(maple_pass_branch_batch(c, (int32_t)needNode.size(), needSrc.data(), needMut.data(), dn.data(), out.data()));
+                for (size_t i = 0; i < needNode.size(); i++) upOf[needNode[i]] = out[i];
+            }
+            std::vector<int32_t> mid(nr), down(nr), upl(nr), ql(nr), ap(2 * nr), ac(2 * nr);
+            std::vector<double> dist(nr), abl(2 * nr);
+            std::vector<uint8_t> remTip(nr, 1), tip(nr), atip(2 * nr);
+            for (size_t i = 0; i < nr; i++) {
+                const int32_t v = rnode[i];
+                mid[i] = c->h_tree_totUp[v]; down[i] = c->h_tree_lower[v]; upl[i] = upOf[v]; dist[i] = c->h_tree_dist[v];
+                tip[i] = c->h_tree_tip[v];
+                ql[i] = qlist(rq[i], v, hSlShort[(size_t)rq[i] * SL + ridx[i]] != 0);
+            }
+            TRY(maple_evaluate_placement_batch(c, (int32_t)nr, mid.data(), down.data(), upl.data(), dist.data(), ql.data(),
+                                               remTip.data(), tip.data(), ev.data()));
+            for (size_t i = 0; i < nr; i++) {
+                ap[i] = ap[nr + i] = upl[i];
+                ac[i] = ac[nr + i] = down[i];
+                atip[i] = atip[nr + i] = tip[i];
+                abl[i] = dist[i];
+                abl[nr + i] = ev[4 * i + 1] + ev[4 * i + 2];
+            }
+            TRY(maple_append_batch(c, (int32_t)(2 * nr), ap.data(), ac.data(), atip.data(), abl.data(), comp.data()));
+        }
+        // ---- outcome per query
+        size_t r = 0;
+        for (int q = 0; q < nq; q++) {
+            const int g = q0 + q;
+            status[g] = hStatus[q];
+            nAppend[g] = hNApp[q];
+            blen3[3 * g] = blen3[3 * g + 1] = 0.0;
+            blen3[3 * g + 2] = pp->oneMutBLen;
+            if (hStatus[q] < 0) { bestNode[g] = -1; bestScore[g] = 0.0; bestDiffs[g] = -1; continue; }
+            if (hStatus[q] == 1) {                                        // M:7986-8003: placed as a minor sequence
+                bestNode[g] = hMinor[q]; bestScore[g] = 1.0;
+                bestDiffs[g] = qlist(q, hMinor[q], hBestShort[q] != 0);
+                continue;
+            }
+            int32_t bn = hBest[q];
+            double bs = hBestLK[q];
+            bool bshort = hBestShort[q] != 0;
+            if (bn != root) {                                             // M:8072 (the reference halves the bottom length here)
+                const double half = c->h_tree_dist[bn] / 2;
+                blen3[3 * g] = half; blen3[3 * g + 1] = half / 2;
+            }
+            for (int i = 0; i < hNShort[q]; i++, r++) {
+                const double optimized = ev[4 * r] + comp[nr + r] - comp[r];
+                if (optimized >= bs) {                                    // M:8176
+                    bn = rnode[r]; bs = optimized;
+                    blen3[3 * g] = ev[4 * r + 2]; blen3[3 * g + 1] = ev[4 * r + 1]; blen3[3 * g + 2] = ev[4 * r + 3];
+                    bshort = hSlShort[(size_t)q * SL + i] != 0;
+                }
+            }
+            if (bs == -INFINITY) bs = hOrig[q];
+            nAppend[g] += 3 * hNShort[q];
+            bestNode[g] = bn; bestScore[g] = bs;
+            bestDiffs[g] = qlist(q, bn, bshort);
+        }
+    }
+    return MAPLE_OK;
+}

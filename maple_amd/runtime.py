@@ -23,7 +23,7 @@ EXPORTS = [
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
     "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
-    "maple_minor_candset", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
+    "maple_minor_candset", "maple_placement_search_batch", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
 ]
 
 
@@ -38,6 +38,12 @@ class MapleSearchParams(C.Structure):
                 ("thresholdLogLKtopology", C.c_double), ("thresholdTopologyPlacement", C.c_double),
                 ("thresholdLogLKoptimizationTopology", C.c_double), ("thresholdLogLKconsecutivePlacement", C.c_double),
                 ("effectivelyNon0BLen", C.c_double), ("wideSearchBudget", C.c_int32)]
+
+
+class MaplePlacementParams(C.Structure):
+    _fields_ = [("oneMutBLen", C.c_double), ("effectivelyNon0BLen", C.c_double), ("thresholdLogLK", C.c_double),
+                ("thresholdLogLKoptimization", C.c_double), ("thresholdLogLKconsecutivePlacement", C.c_double),
+                ("allowedFails", C.c_int32), ("strictStopRules", C.c_int32), ("onlyFindIdentical", C.c_int32)]
 
 
 class MapleError(RuntimeError):
@@ -348,6 +354,22 @@ class Device:
                                                  _ptr(rpr)))
         if want_removed_partials:
             out["removedPartials"] = rpr
+        return out
+
+    def placement_search_batch(self, q_lists, *, oneMutBLen, effectivelyNon0BLen, thresholdLogLK,
+                               thresholdLogLKoptimization, thresholdLogLKconsecutivePlacement, allowedFails=5,
+                               strictStopRules=True, onlyFindIdentical=False):
+        """findBestParentForNewSample (M:7912-8292) for many query lists against the uploaded (frozen) tree."""
+        q = _i32(q_lists)
+        n = len(q)
+        pp = MaplePlacementParams(oneMutBLen, effectivelyNon0BLen, thresholdLogLK, thresholdLogLKoptimization,
+                                  thresholdLogLKconsecutivePlacement, int(allowedFails), int(bool(strictStopRules)),
+                                  int(bool(onlyFindIdentical)))
+        out = dict(bestNode=np.zeros(n, np.int32), bestScore=np.zeros(n), blen=np.zeros((n, 3)),
+                   bestDiffs=np.zeros(n, np.int32), nAppend=np.zeros(n, np.int32), status=np.zeros(n, np.int32))
+        self._ck(self.lib.maple_placement_search_batch(self.h, n, _ptr(q), C.byref(pp), _ptr(out["bestNode"]),
+                                                       _ptr(out["bestScore"]), _ptr(out["blen"]), _ptr(out["bestDiffs"]),
+                                                       _ptr(out["nAppend"]), _ptr(out["status"])))
         return out
 
     def debug_calib_walk(self, nbytes, repeats=1):

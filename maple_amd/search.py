@@ -105,6 +105,32 @@ class PlacementSearcher:
         S = {k: (int(s) if a != b else U[k]) for k, s, a, b in zip(keys, s_ids, ne_u, ne_s)}
         return U, S
 
+    def find_best_parent_batch(self, diffs_list):
+        """Many queries against the frozen tree in one native call (maple_placement_search_batch): scoring, the
+        reference's traversal (on the device, one lane per query) and the short-list refinement are all batched.
+        Returns a list of (bestNode, bestScore, bestBranchLengths, bestDiffs, info) like the single-query form."""
+        dev, p = self.dev, self.p
+        mark = dev.mark()
+        try:
+            q_ids = dev.upload(list(diffs_list))
+            out = dev.placement_search_batch(
+                q_ids, oneMutBLen=p.oneMutBLen, effectivelyNon0BLen=p.effectivelyNon0BLen, thresholdLogLK=p.thresholdLogLK,
+                thresholdLogLKoptimization=p.thresholdLogLKoptimization,
+                thresholdLogLKconsecutivePlacement=p.thresholdLogLKconsecutivePlacement, allowedFails=p.allowedFails,
+                strictStopRules=p.strictStopRules, onlyFindIdentical=p.onlyFindIdentical)
+            if (out["status"] < 0).any():
+                raise RuntimeError("placement search overflow (status %s)" % sorted(set(out["status"][out["status"] < 0])))
+            lists = dev.download(out["bestDiffs"])
+            res = []
+            for k in range(len(q_ids)):
+                minor = out["status"][k] == 1
+                res.append((int(out["bestNode"][k]), float(out["bestScore"][k]),
+                            None if minor else tuple(float(x) for x in out["blen"][k]), lists[k],
+                            dict(n_append=int(out["nAppend"][k]), minor=bool(minor))))
+            return res
+        finally:
+            dev.release(mark)
+
     def find_best_parent_for_new_sample(self, diffs, sample=None):
         """Returns (bestNode, bestScore, bestBranchLengths, bestDiffs, info); the first four as the reference."""
         dev, t, p = self.dev, self.tree, self.p

@@ -129,6 +129,36 @@ def test_placement_search_matches_reference(env):
     assert n_real > 20
 
 
+def test_batched_placement_matches_reference(env):
+    """The same 60 queries in ONE maple_placement_search_batch call (device-side traversal, one lane per query)."""
+    from maple_amd.search import PlacementParams, PlacementSearcher
+    f, dev, tree = env
+    ctx = f["context"]
+    flags = f["flags"]
+    only_identical = any(x in flags for x in ("--estimateErrorRate", "--estimateSiteSpecificErrorRate"))
+    ps = PlacementSearcher(dev, tree, PlacementParams(
+        oneMutBLen=ctx["oneMutBLen"], effectivelyNon0BLen=ctx["effectivelyNon0BLen"],
+        thresholdLogLK=ctx["thresholdLogLK"], thresholdLogLKoptimization=ctx["thresholdLogLKoptimization"],
+        thresholdLogLKconsecutivePlacement=ctx["thresholdLogLKconsecutivePlacement"],
+        allowedFails=ctx["allowedFails"], strictStopRules=ctx["strictStopRules"], onlyFindIdentical=only_identical))
+    recs = f["placements"]
+    res = ps.find_best_parent_batch([tup(r["query"]) for r in recs])
+    n_real = 0
+    for rec, (node, score, blens, best_diffs, info) in zip(recs, res):
+        want = rec["ret"]
+        assert node == want["bestNode"], (node, want["bestNode"])
+        assert close(score, want["bestScore"], 1e-9), (score, want["bestScore"])
+        if want["bestBranchLengths"] is None:
+            assert blens is None
+        else:
+            wb = [0.0 if b is False else b for b in want["bestBranchLengths"]]
+            assert all(close(g, w, 1e-8, 1e-15) for g, w in zip(blens, wb)), (blens, wb)
+            assert info["n_append"] == rec["n_append"], (info["n_append"], rec["n_append"])
+            n_real += 1
+        assert lists_match(best_diffs, tup(want["bestDiffs"]), 0.0), (best_diffs, want["bestDiffs"])
+    assert n_real > 20
+
+
 def test_tree_log_likelihood_matches_reference(env):
     """The parity metric of BASELINE.json: tree log-LK (calculateTreeLikelihood, M:9721) within 1e-6 relative
     (observed ~1e-14) on the reference's own final tree."""

@@ -37,3 +37,20 @@ for q in queries:
 dt = time.perf_counter() - t0
 print(f"{nq} placement searches on a {n + nq}-tip tree: {dt / nq * 1e3:.2f} ms/query, {nq / dt:.0f} queries/s; "
       f"reference-equivalent placements {tot} ({tot / dt:.3g}/s), branches scored {scored} ({scored / dt:.3g}/s)")
+# the same queries as ONE native batch (maple_placement_search_batch): device-side traversal, one lane per query
+is_tip = np.asarray([not c for c in children], dtype=np.uint8)
+dev.upload_tree(m.root, m.parent.astype(np.int32), m.children[:, 0].astype(np.int32), m.children[:, 1].astype(np.int32),
+                m.dist, is_tip, m.lower, m.up_right, m.up_left, m.tot_up, ht.id_mut)
+for reps in (1, 8):
+    qs = queries * reps
+    ps.find_best_parent_batch(qs[:4])
+    t0 = time.perf_counter()
+    res = ps.find_best_parent_batch(qs)
+    dt = time.perf_counter() - t0
+    tot_b = sum(r[4]["n_append"] for r in res)
+    print(f"batched: {len(qs)} queries in {dt * 1e3:.1f} ms = {len(qs) / dt:.0f} queries/s "
+          f"(reference-equivalent placements {tot_b / dt:.3g}/s, branches scored {len(qs) * (len(ps.cand) + 1) / dt:.3g}/s)")
+    if reps == 1:
+        single = [ps.find_best_parent_for_new_sample(q) for q in queries[:50]]
+        assert all(a[0] == b[0] and a[1] == b[1] and a[4]["n_append"] == b[4]["n_append"] for a, b in zip(single, res[:50]))
+        print("batched == single-query results on the first 50 queries")
