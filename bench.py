@@ -178,7 +178,7 @@ def main():
         kw = dict(strict=False, allowedFails=4, thresholdLogLKtopology=14.0 * log_lref, thresholdTopologyPlacement=-0.1,
                   thresholdLogLKoptimizationTopology=1.0 * log_lref, thresholdLogLKconsecutivePlacement=1.0,
                   effectivelyNon0BLen=1.0 / (10 * l_ref))
-        dev.spr_search_batch(my_nodes[:256], **kw)                      # warm-up
+        dev.spr_search_batch(my_nodes, **kw)                            # warm-up (also sizes the workspace)
         dev.timing_reset()
         t0 = time.perf_counter()
         res = dev.spr_search_batch(my_nodes, **kw)
@@ -192,6 +192,25 @@ def main():
                "placements_per_s_kernel": float(res["nAppend"].sum() / (k_ms_spr * 1e-3)) if k_ms_spr else None,
                "placements_per_s_wall": float(res["nAppend"].sum() / wall),
                "params": "deep round: non-strict, allowedFailsTopology 4, thresholdLogLKtopology 14 log(lRef)"}
+        # ---- and the batched placement search (findBestParentForNewSample for many samples on the frozen tree,
+        # M:7912-8292 / 11190-11220): all-branch scoring + device-side traversal + short-list refinement ----
+        pkw = dict(oneMutBLen=1.0 / l_ref, effectivelyNon0BLen=1.0 / (10 * l_ref), thresholdLogLK=18.0 * log_lref,
+                   thresholdLogLKoptimization=1.0 * log_lref, thresholdLogLKconsecutivePlacement=1.0)
+        from maple_amd.synth import perturb_diffs
+        mark = dev.mark()
+        prng = np.random.default_rng(11 + rank)
+        new_samples = [tip_genome_list(perturb_diffs(data.diffs[i], data.ref, prng), ref_idx, **tip_kw)
+                       for i in range(rank, len(data.diffs), world)][:Q]
+        new_ids = dev.upload(new_samples)                          # samples NOT in the tree (2 extra substitutions each)
+        dev.placement_search_batch(new_ids[:8], **pkw)
+        t0 = time.perf_counter()
+        pres = dev.placement_search_batch(new_ids, **pkw)
+        pwall = time.perf_counter() - t0
+        dev.release(mark)
+        placement = {"queries": int(Q), "wall_ms": 1e3 * pwall, "queries_per_s": Q / pwall,
+                     "reference_equivalent_placements_per_s": float(pres["nAppend"].sum() / pwall),
+                     "branches_scored_per_s": float(Q * (Cn + 1) / pwall),
+                     "minor_sequences": int((pres["status"] == 1).sum()), "failed": int((pres["status"] < 0).sum())}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             spr["cpu_baseline"] = spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, my_nodes, res, kw, args.cpu_seconds, mkw)
 
@@ -230,6 +249,7 @@ def main():
         }
         if spr is not None:
             out["spr_search"] = spr
+            out["placement_batch"] = placement
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs,
                                                args.cpu_seconds, t_out, mkw)

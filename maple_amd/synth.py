@@ -189,6 +189,26 @@ def make_dataset(
     )
 
 
+def perturb_diffs(diffs, ref: str, rng: np.random.Generator, n_extra: int = 2) -> list:
+    """A new sample close to an existing one: the same MAPLE entries plus `n_extra` substitutions at positions the
+    sample does not already touch (so it is neither identical to, nor a minor sequence of, the original)."""
+    covered = set()
+    for m in diffs:
+        for p in range(m[1], m[1] + (m[2] if len(m) > 2 else 1)):
+            covered.add(p)
+    out = list(diffs)
+    while n_extra > 0:
+        p = int(rng.integers(1, len(ref) + 1))
+        if p in covered:
+            continue
+        alt = [b for b in "acgt" if b != ref[p - 1]]
+        out.append((alt[int(rng.integers(3))], p))
+        covered.add(p)
+        n_extra -= 1
+    out.sort(key=lambda m: m[1])
+    return out
+
+
 def write_maple(data: SynthData, path: str) -> None:
     op = gzip.open if path.endswith(".gz") else open
     with op(path, "wt") as fh:

@@ -7,7 +7,7 @@ import bench
 from maple_amd.host import reference_tables, tip_genome_list
 from maple_amd.runtime import Device
 from maple_amd.search import PlacementParams, PlacementSearcher
-from maple_amd.synth import make_dataset
+from maple_amd.synth import make_dataset, perturb_diffs
 from maple_amd.tree_host import HostTree
 from maple_amd.tree_mirror import TreeMirror
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
@@ -28,7 +28,8 @@ l_ref = dev.lRef; ll = math.log(l_ref)
 ps = PlacementSearcher(dev, ht, PlacementParams(oneMutBLen=1.0 / l_ref, effectivelyNon0BLen=1.0 / (10 * l_ref),
                                                   thresholdLogLK=18.0 * ll, thresholdLogLKoptimization=ll,
                                                   thresholdLogLKconsecutivePlacement=1.0))
-queries = [tips[int(v)] for v in data.tip_node[:nq]]
+prng = np.random.default_rng(11)
+queries = [tip_genome_list(perturb_diffs(dl, data.ref, prng), ref_idx) for dl in data.diffs[:nq]]   # not in the tree
 ps.find_best_parent_for_new_sample(queries[0])
 t0 = time.perf_counter(); tot = 0; scored = 0
 for q in queries:
