@@ -189,3 +189,162 @@ def rebuild_genome_lists(dev: Device, tree: HostTree):
             up_right[nn] = dev.shorten_batch(ur)
             up_left[nn] = dev.shorten_batch(ul)
     return lower, up_right, up_left, tot_up
+
+
+def update_genome_lists(dev: Device, tree: HostTree, changed, changed_dist=None):
+    """updatePartials (M:5479-5815) in its GPU-native form: instead of the reference's one-node-at-a-time LIFO work
+    list, the lists invalidated by a set of local changes are repaired level by level, every level one batch of
+    passGenomeListThroughBranch / mergeVectors / areVectorsDifferent / shorten launches -- so that any number of
+    simultaneous changes costs the same number of launches as one.
+
+    ``changed``: nodes whose lower list (``tree.id_lower[v]``, already replaced by the caller) and/or branch length
+    (``tree.dist[v]``) changed; ``changed_dist`` (default: the same nodes) those whose branch length did.  Phase A walks up: a node whose child changed gets a new lower list, and propagates while
+    areVectorsDifferent(new, old) (M:5793).  Phase B walks down from every touched node: probVectTotUp is recomputed
+    where the node's lower list, length or upper vector changed (M:5525-5557, 5700-5713), probVectUpRight /
+    probVectUpLeft where the upper vector or the OTHER child changed (M:5559-5660, 5715-5735), and a child is visited
+    only if its upper vector was replaced, i.e. areVectorsDifferent(old, new) (M:5645-5658) -- the reference's own stop
+    rule, so the repaired region is the same up to that threshold.  A merge that comes out None between two zero-length
+    branches re-estimates the branch above the changed child like updateBLen (M:5385-5414).
+    ``tree.id_*`` and ``tree.dist`` are updated in place; returns the number of lists replaced."""
+    n = tree.n
+    up = np.asarray([-1 if u is None else u for u in tree.up])
+    c0 = np.asarray([c[0] if c else -1 for c in tree.children])
+    c1 = np.asarray([c[1] if c else -1 for c in tree.children])
+    tip = np.asarray([(not c) and (m == 0) for c, m in zip(tree.children, tree.n_minor)])
+    mut = tree.id_mut
+    dist = np.asarray(tree.dist, dtype=np.float64)
+    lower, up_right, up_left, tot_up = tree.id_lower, tree.id_upRight, tree.id_upLeft, tree.id_totUp
+    depth = np.zeros(n, dtype=np.int64)
+    for v in tree.preorder():
+        if up[v] >= 0:
+            depth[v] = depth[up[v]] + 1
+    replaced = 0
+
+    def passed(ids, nodes, direction_up):
+        ids = np.asarray(ids, dtype=np.int32).copy()
+        nodes = np.asarray(nodes)
+        need = np.nonzero(mut[nodes] >= 0)[0]
+        if len(need):
+            ids[need] = dev.pass_branch_batch(ids[need], mut[nodes[need]], direction_up)
+        return ids
+
+    def vect_up_of(nodes):
+        """the upper vector seen by each node, in the node's own reference frame (M:5503-5513)"""
+        p = up[nodes]
+        return passed(np.where(c0[p] == nodes, up_right[p], up_left[p]), nodes, False)
+
+    d_low = np.zeros(n, dtype=bool)          # own lower list or branch length changed
+    d_up = np.zeros(n, dtype=bool)           # the upper vector this node sees changed
+    d_child = np.zeros((n, 2), dtype=bool)   # child k's lower list or branch length changed
+    d_dist = np.zeros(n, dtype=bool)         # own branch length changed (enters the node's probVectUpRight/UpLeft too)
+    for v in (changed if changed_dist is None else changed_dist):
+        d_dist[v] = True
+    frontier = set()
+    for v in changed:
+        d_low[v] = True
+        if up[v] >= 0:
+            d_child[up[v], 0 if c0[up[v]] == v else 1] = True
+            frontier.add(int(up[v]))
+
+    # ---- phase A: lower lists, deepest first -------------------------------------------------------------------
+    while frontier:
+        dmax = max(depth[v] for v in frontier)
+        nodes = np.asarray(sorted(v for v in frontier if depth[v] == dmax))
+        frontier.difference_update(nodes.tolist())
+        a, b = c0[nodes], c1[nodes]
+        pa, pb = passed(lower[a], a, True), passed(lower[b], b, True)
+        out = dev.merge_batch(pa, dist[a], tip[a], pb, dist[b], tip[b], False)
+        for k in np.nonzero(out < 0)[0]:                                   # M:5689-5701
+            p = int(nodes[k])
+            if dist[a[k]] or dist[b[k]]:
+                raise RuntimeError("None vector from non-zero distances in the lower merge (the reference raises too)")
+            order = [0, 1] if d_child[p, 0] else [1, 0]
+            for which in order:
+                c = int(c0[p] if which == 0 else c1[p])
+                t, is_false = dev.blen_batch(vect_up_of(np.asarray([c])), [lower[c]], [bool(tip[c])])
+                dist[c] = 0.0 if is_false[0] else float(t[0])
+                tree.dist[c] = float(dist[c])
+                d_low[c] = d_dist[c] = True
+                d_child[p, which] = True
+                if dist[c]:
+                    break
+            o2 = dev.merge_batch(pa[k:k + 1], dist[a[k:k + 1]], tip[a[k:k + 1]], pb[k:k + 1], dist[b[k:k + 1]],
+                                 tip[b[k:k + 1]], False)
+            if o2[0] < 0:
+                raise RuntimeError("None vector after updateBLen")
+            out[k] = o2[0]
+        new = dev.shorten_batch(out)
+        old = lower[nodes]
+        diff = np.ones(len(nodes), dtype=bool)
+        has_old = old >= 0
+        if has_old.any():
+            diff[has_old] = dev.differ_batch(new[has_old], old[has_old]).astype(bool)   # (new, old), M:5793
+        lower[nodes] = new
+        replaced += len(nodes)
+        for v, ch in zip(nodes, diff):
+            if ch:
+                d_low[v] = True
+                if up[v] >= 0:
+                    d_child[up[v], 0 if c0[up[v]] == v else 1] = True
+                    frontier.add(int(up[v]))
+
+    # ---- phase B: upper lists, shallowest first ----------------------------------------------------------------
+    todo = set(np.nonzero(d_low | d_child.any(axis=1))[0].tolist())
+    while todo:
+        dmin = min(depth[v] for v in todo)
+        nodes = np.asarray(sorted(v for v in todo if depth[v] == dmin))
+        todo.difference_update(nodes.tolist())
+        inner = c0[nodes] >= 0
+        if nodes[0] == tree.root:
+            r = tree.root
+            if c0[r] >= 0:
+                path = [[int(mut[r])] if mut[r] >= 0 else []]
+                for which, store in ((1, up_right), (0, up_left)):         # upRight merges child 1, upLeft child 0
+                    if not d_child[r, which]:
+                        continue
+                    kid = np.asarray([c1[r] if which == 1 else c0[r]])
+                    nv = dev.root_vector_batch(passed(lower[kid], kid, True), dist[kid], tip[kid], path)
+                    target = int(c0[r] if which == 1 else c1[r])
+                    if store[r] < 0 or dev.differ_batch([store[r]], nv)[0]:
+                        store[r] = nv[0]
+                        replaced += 1
+                        d_up[target] = True
+                        todo.add(target)
+            continue
+        vect_up = vect_up_of(nodes)
+        # probVectTotUp
+        need = d_up[nodes] | d_low[nodes]
+        if need.any():
+            nn, vu = nodes[need], vect_up[need]
+            nz = dist[nn] != 0.0
+            tot_up[nn[~nz]] = -1
+            if nz.any():
+                m = nn[nz]
+                tu = dev.merge_batch(vu[nz], dist[m] / 2, False, lower[m], dist[m] / 2, tip[m], True)
+                if (tu < 0).any():
+                    raise RuntimeError("None probVectTotUp on a branch of non-zero length")
+                tot_up[m] = dev.shorten_batch(tu)
+                replaced += len(m)
+        # probVectUpRight (for child 0: upper vector + child 1) and probVectUpLeft (for child 1: upper vector + child 0)
+        for which, store in ((1, up_right), (0, up_left)):
+            need = inner & (d_up[nodes] | d_dist[nodes] | d_child[nodes, which])
+            if not need.any():
+                continue
+            nn, vu = nodes[need], vect_up[need]
+            kid = c1[nn] if which == 1 else c0[nn]
+            nv = dev.merge_batch(vu, dist[nn], False, passed(lower[kid], kid, True), dist[kid], tip[kid], True)
+            if (nv < 0).any():
+                raise RuntimeError("None upper vector (the reference would call updateBLen here)")
+            old = store[nn]
+            diff = np.ones(len(nn), dtype=bool)
+            has_old = old >= 0
+            if has_old.any():
+                diff[has_old] = dev.differ_batch(old[has_old], nv[has_old]).astype(bool)      # (old, new), M:5645
+            if diff.any():
+                sel = nn[diff]
+                store[sel] = dev.shorten_batch(nv[diff])
+                replaced += len(sel)
+                target = c0[sel] if which == 1 else c1[sel]
+                d_up[target] = True
+                todo.update(target.tolist())
+    return replaced

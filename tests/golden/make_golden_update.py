@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Golden vectors for updatePartials (M:5479-5815) -- BUILD CONTAINER ONLY.
+
+Re-runs the unmodified reference exactly like make_golden_search.py (same flags, hence the same final tree: the
+snapshot stored in search_<name>.json.gz is the BASE here and is not stored again), then, on a fresh deep copy of
+the frozen tree per case, applies one local change and lets the reference's own ``updatePartials`` repair the genome
+lists:
+
+* kind "dist":  dist[v] is multiplied or divided by 3; nodeList = [(v,2,True,False),(up[v],childNum,True,False)]
+  (the pair ``updateBLen(..., addToList=True)`` pushes, M:5412-5414);
+* kind "tip":   the lower list of tip a is replaced by a copy of that of tip b (same MAT reference frame);
+  same nodeList.
+
+Per case the file keeps the change, the lists that differ from the base afterwards (node -> four lists), and the
+tree log-likelihood after the repair.  Data only: tests/golden/update_<name>.json.gz.
+"""
+import contextlib
+import copy
+import gzip
+import io
+import json
+import os
+import random
+import runpy
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from make_golden import REF, ser_list  # noqa: E402
+from make_golden_search import RUNS, snapshot_tree  # noqa: E402
+
+KEYS = ("probVect", "probVectUpRight", "probVectUpLeft", "probVectTotUp")
+
+
+def run(name, n_cases=14):
+    flags = RUNS[name]
+    inp = os.path.join(HERE, "synth_small.maple.txt")
+    out_dir = tempfile.mkdtemp(prefix="maple_golden_update_")
+    holder = {}
+
+    def grab(frame, event, arg):
+        if "g" not in holder and frame.f_code.co_filename.endswith("MAPLEv0.7.5.4.py"):
+            holder["g"] = frame.f_globals
+
+    old = sys.argv
+    sys.argv = ["MAPLE", "--input", inp, "--output", os.path.join(out_dir, "out"), "--overwrite"] + flags
+    sys.setprofile(grab)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            runpy.run_path(REF, run_name="__main__")
+    except SystemExit:
+        pass
+    finally:
+        sys.setprofile(None)
+        sys.argv = old
+    g = holder["g"]
+    tree, t1 = g["tree"], g["t1"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        g["setAllDirty"](tree, t1)
+        g["reCalculateAllGenomeLists"](tree, t1)
+    base = json.loads(json.dumps(snapshot_tree(tree, t1)))
+    with gzip.open(os.path.join(HERE, f"search_{name}.json.gz"), "rt") as fh:
+        stored = json.load(fh)["tree"]
+    assert all(base[k] == stored[k] for k in KEYS + ("up", "children", "dist", "mutations")), "base tree differs from search fixture"
+
+    n = len(tree.up)
+    reach = []
+    st = [t1]
+    while st:
+        v = st.pop()
+        reach.append(v)
+        st.extend(tree.children[v])
+    frame = {}
+    for v in reach:
+        u = tree.up[v]
+        frame[v] = v if tree.mutations[v] else (frame[u] if u is not None else -1)
+    rng = random.Random(7)
+    tips = [v for v in reach if not tree.children[v] and not tree.minorSequences[v]]
+    inner = [v for v in reach if v != t1 and tree.dist[v] and tree.dist[v] > 1e-5]
+    cases = []
+    while len(cases) < n_cases:
+        tc = copy.deepcopy(tree)
+        kind = "dist" if len(cases) % 2 == 0 else "tip"
+        if kind == "dist":
+            v = rng.choice(inner)
+            factor = rng.choice([3.0, 1.0 / 3.0])
+            tc.dist[v] = tree.dist[v] * factor
+            change = dict(kind=kind, node=v, dist=tc.dist[v])
+        else:
+            a = rng.choice(tips)
+            same = [b for b in tips if b != a and frame[b] == frame[a] and tree.probVect[b] != tree.probVect[a]]
+            if not same:
+                continue
+            b = rng.choice(same)
+            tc.probVect[a] = copy.deepcopy(tree.probVect[b])
+            v = a
+            change = dict(kind=kind, node=a, source=b, probVect=ser_list(tc.probVect[a]))
+        u = tc.up[v]
+        cnum = 0 if tc.children[u][0] == v else 1
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                g["updatePartials"](tc, [(v, 2, True, False), (u, cnum, True, False)])
+                lk = g["calculateTreeLikelihood"](tc, t1)
+        except Exception as e:                      # the reference bails out on an inconsistent change: not a usable case
+            print("skipped", change["kind"], v, repr(e)[:80])
+            continue
+        after = json.loads(json.dumps(snapshot_tree(tc, t1)))
+        delta = {}
+        for key in KEYS:
+            for w in reach:
+                if after[key][w] != base[key][w]:
+                    delta.setdefault(str(w), {})[key] = after[key][w]
+        dist_delta = {str(w): after["dist"][w] for w in reach if after["dist"][w] != base["dist"][w]}
+        cases.append(dict(change=change, lists=delta, dist=dist_delta, treeLK=lk))
+        print(f"[{name}] case {len(cases)} {change['kind']} node {v}: {len(delta)} nodes touched, "
+              f"{len(dist_delta)} branch lengths changed, treeLK {lk:.6f}", flush=True)
+    path = os.path.join(HERE, f"update_{name}.json.gz")
+    with gzip.open(path, "wt") as fh:
+        json.dump(dict(name=name, base=f"search_{name}.json.gz", cases=cases), fh)
+    print(f"[{name}] -> {path} {os.path.getsize(path)/1e6:.2f} MB", flush=True)
+
+
+if __name__ == "__main__":
+    for nm in (sys.argv[1:] or ["synth_unrest"]):
+        run(nm)

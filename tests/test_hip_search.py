@@ -280,3 +280,59 @@ def test_rebuild_all_genome_lists_matches_reference(env):
     assert checked > 700
     assert n_same > 0.5 * checked, (n_same, checked)
     dev.release(mark)
+
+
+def test_update_partials_matches_reference():
+    """updatePartials (M:5479-5815) as level-synchronous GPU batches vs the reference's own repair of the same local
+    change (tests/golden/update_synth_unrest.json.gz: 7 branch-length changes, 7 tip replacements on the frozen tree).
+    Both stop propagating where areVectorsDifferent says "same", in a different visiting order, so lists are compared
+    with that function's own thresholds rather than bit for bit; the tree log-likelihood must agree to 1e-9."""
+    from maple_amd.runtime import Device
+    from maple_amd.tree_host import HostTree, tree_log_likelihood, update_genome_lists
+    f = load("synth_unrest")
+    with gzip.open(os.path.join(GOLDEN, "update_synth_unrest.json.gz"), "rt") as fh:
+        upd = json.load(fh)
+    ctx, t = f["context"], f["tree"]
+    dev = Device(ref_indices(ctx), ctx["rootFreqs"], thresholdProb=ctx["thresholdProb"],
+                 minBLenSensitivity=ctx["minBLenSensitivity"], thresholdDiffForUpdate=ctx["thresholdDiffForUpdate"],
+                 thresholdFoldChangeUpdate=ctx["thresholdFoldChangeUpdate"], defaultBLen=ctx["defaultBLen"],
+                 arena_bytes=256 << 20)
+    dev.set_model(**model_args(f["model"]))
+    keys = (("probVect", "id_lower"), ("probVectUpRight", "id_upRight"), ("probVectUpLeft", "id_upLeft"),
+            ("probVectTotUp", "id_totUp"))
+    n_lists = 0
+    for case in upd["cases"]:
+        tree = HostTree(t["root"], t["up"], t["children"], t["dist"], t["mutations"], t["nMinor"], t["probVect"],
+                        t["probVectUpRight"], t["probVectUpLeft"], t["probVectTotUp"]).upload(dev)
+        ch = case["change"]
+        v = ch["node"]
+        if ch["kind"] == "dist":
+            tree.dist[v] = ch["dist"]
+        else:
+            tree.id_lower[v] = dev.upload([tup(ch["probVect"])])[0]
+        replaced = update_genome_lists(dev, tree, [v])
+        assert replaced >= 2
+        # every list of every node against the reference's tree after ITS updatePartials
+        for key, attr in keys:
+            ids = getattr(tree, attr)
+            nodes, want = [], []
+            for w in tree.preorder():
+                ref = case["lists"].get(str(w), {}).get(key, t[key][w])
+                if w == v and key == "probVect" and ch["kind"] == "tip":
+                    ref = ch["probVect"]
+                if ref:
+                    nodes.append(w)
+                    want.append(tup(ref))
+                else:
+                    assert ids[w] < 0 or key != "probVectTotUp" or not tree.dist[w], (key, w)
+            assert all(ids[w] >= 0 for w in nodes), key
+            want_ids = dev.upload(want)
+            differ = dev.differ_batch(ids[nodes], want_ids) | dev.differ_batch(want_ids, ids[nodes])
+            assert not differ.any(), (ch, key, [nodes[i] for i in np.nonzero(differ)[0]][:5])
+            n_lists += len(nodes)
+        for w, d in case["dist"].items():
+            assert close(float(tree.dist[int(w)] or 0.0), float(d or 0.0), 1e-6, 1e-12), (w, tree.dist[int(w)], d)
+        got, _ = tree_log_likelihood(dev, tree)
+        assert close(got, case["treeLK"], 1e-9), (ch, got, case["treeLK"])
+    assert n_lists > 10000
+    dev.close()

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""update_genome_lists (level-synchronous updatePartials) and rebuild_genome_lists on the bench tree (GPU box)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from maple_amd.host import reference_tables, tip_genome_list
+from maple_amd.runtime import Device
+from maple_amd.synth import make_dataset
+from maple_amd.tree_host import HostTree, rebuild_genome_lists, update_genome_lists
+from maple_amd.tree_mirror import TreeMirror
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+data = make_dataset(n_samples=n, l_ref=29903, seed=1, mean_diffs=30.0)
+ref_idx, rf = reference_tables(data.ref)
+dev = Device(ref_idx, rf, arena_bytes=6 << 30)
+dev.set_model(bench.UNREST_Q)
+tips = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
+m = TreeMirror(dev, data.parent, data.blen, tips).build()
+nn = m.n_nodes
+up = [None if p < 0 else int(p) for p in m.parent]
+children = [[] if m.children[v, 0] < 0 else [int(m.children[v, 0]), int(m.children[v, 1])] for v in range(nn)]
+ht = HostTree(m.root, up, children, list(m.dist), [[] for _ in range(nn)], [0] * nn, None, None, None, None)
+ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp = m.lower.copy(), m.up_right.copy(), m.up_left.copy(), m.tot_up.copy()
+ht.id_mut = -np.ones(nn, dtype=np.int32)
+t0 = time.perf_counter()
+lo, ur, ul, tu = rebuild_genome_lists(dev, ht)
+dt = time.perf_counter() - t0
+print(f"full rebuild of all 4 lists of {nn} nodes: {dt * 1e3:.1f} ms")
+rng = np.random.default_rng(3)
+cand = np.nonzero((m.parent >= 0) & (m.dist > 1e-5))[0]
+for k in (1, 10, 100, 1000):
+    pick = rng.choice(cand, size=k, replace=False)
+    for v in pick:
+        ht.dist[v] = ht.dist[v] * 3.0
+    mark = dev.mark()
+    t0 = time.perf_counter()
+    rep = update_genome_lists(dev, ht, pick.tolist())
+    dt = time.perf_counter() - t0
+    print(f"{k} simultaneous branch-length changes: {rep} lists replaced in {dt * 1e3:.1f} ms ({dt / k * 1e3:.3f} ms per change)")
