@@ -348,3 +348,85 @@ def update_genome_lists(dev: Device, tree: HostTree, changed, changed_dist=None)
                 d_up[target] = True
                 todo.update(target.tolist())
     return replaced
+
+
+def optimize_branch_lengths_fast_pass(dev: Device, tree: HostTree, effectivelyNon0BLen, dirty=None):
+    """traverseTreeToOptimizeBranchLengths(tree, root, fastPass=True) (M:8727-8893): the two branches below the root
+    share their total length by a grid search on the merged root vector's likelihood (M:8743-8780, one
+    mergeVectors(returnLK) + findProbRoot launch over the whole grid), every other dirty branch gets
+    estimateBranchLengthWithDerivative(upper vector, lower list) (M:8821-8833) -- all from the same frozen lists, hence
+    ONE estimateBranchLength launch for the whole tree.  A length is replaced when it moves by more than 1 % (M:8873).
+    ``tree.dist`` is updated in place (the lists are not: call update_genome_lists / rebuild_genome_lists afterwards,
+    as the reference's caller does after a fast pass).  Returns (number of updates, dirty flags)."""
+    root = tree.root
+    if not tree.children[root]:
+        return 0, dirty
+    n = tree.n
+    mut = tree.id_mut
+    tip = np.asarray([(not c) and (m == 0) for c, m in zip(tree.children, tree.n_minor)])
+    dist = [float(x or 0.0) for x in tree.dist]
+    dirty = [True] * n if dirty is None else list(dirty)
+    l_ref = dev.lRef
+    mark = dev.mark()
+    try:
+        a, b = tree.children[root]
+        if dist[a] > effectivelyNon0BLen or dist[b] > effectivelyNon0BLen:
+            tot = (dist[a] + dist[b]) * l_ref
+            grid = []
+            for i in range(max(1, round(tot)) * 2 + 1):
+                b1 = min(tot, float(i) / 2)
+                b2 = max(tot - b1, 0.0)
+                grid.append((b1 / l_ref, b2 / l_ref))
+            pv = []
+            for c in (a, b):
+                lid = tree.id_lower[c]
+                if mut[c] >= 0:
+                    lid = dev.pass_branch_batch([lid], [mut[c]], True)[0]
+                pv.append(int(lid))
+            k = len(grid)
+            out, lk = dev.merge_batch([pv[0]] * k, [g[0] for g in grid], [bool(tip[a])] * k, [pv[1]] * k,
+                                      [g[1] for g in grid], [bool(tip[b])] * k, False, returnLK=True)
+            if (out < 0).any():
+                raise RuntimeError("None root vector in the root branch-length grid (the reference fails here too)")
+            if mut[root] >= 0:
+                out = dev.pass_branch_batch(out, [mut[root]] * k, True)
+            cost = lk + dev.root_prob_batch(out)
+            best, best_cost = None, float("-inf")
+            for i in range(k):
+                if cost[i] > best_cost:
+                    best_cost, best = float(cost[i]), grid[i][0]
+            both = dist[a] + dist[b]
+            dist[a] = best
+            dist[b] = max(both - best, 0.0)
+        # every other branch: the reference starts from the root's grandchildren (M:8812-8819)
+        nodes = []
+        # same visiting order as the reference (children of child 0, then of child 1, LIFO), M:8812-8822
+        stack = ([*tree.children[a]] if tree.children[a] else []) + ([*tree.children[b]] if tree.children[b] else [])
+        while stack:
+            v = stack.pop()
+            nodes.append(v)
+            stack.extend(tree.children[v])
+        nodes = np.asarray([v for v in nodes if dirty[v]], dtype=np.int64)
+        updates = 0
+        if len(nodes):
+            p = np.asarray([tree.up[v] for v in nodes])
+            first = np.asarray([tree.children[u][0] for u in p]) == nodes
+            up_vect = np.where(first, tree.id_upRight[p], tree.id_upLeft[p]).astype(np.int32)
+            need = np.nonzero(mut[nodes] >= 0)[0]
+            if len(need):
+                up_vect[need] = dev.pass_branch_batch(up_vect[need], mut[nodes[need]], False)
+            t, is_false = dev.blen_batch(up_vect, tree.id_lower[nodes], tip[nodes])
+            for v, tv, f in zip(nodes.tolist(), t.tolist(), is_false.tolist()):
+                best = 0.0 if f else tv
+                if best or dist[v]:
+                    if (not best) or (not dist[v]) or dist[v] / best > 1.01 or dist[v] / best < 0.99:   # M:8873
+                        dist[v] = best
+                        updates += 1
+                    else:
+                        dirty[v] = False
+                else:
+                    dirty[v] = False
+        tree.dist = dist
+        return updates, dirty
+    finally:
+        dev.release(mark)

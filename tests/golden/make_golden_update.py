@@ -115,9 +115,27 @@ def run(name, n_cases=14):
         cases.append(dict(change=change, lists=delta, dist=dist_delta, treeLK=lk))
         print(f"[{name}] case {len(cases)} {change['kind']} node {v}: {len(delta)} nodes touched, "
               f"{len(dist_delta)} branch lengths changed, treeLK {lk:.6f}", flush=True)
+    # ---- traverseTreeToOptimizeBranchLengths(fastPass=True), M:8727-8893: every dirty branch re-estimated from the
+    # SAME (frozen) genome lists, no updatePartials in between -- first on the converged tree, then with every
+    # branch length multiplied by a random factor in [0.4, 2.5] (lists left as they are)
+    sweeps = []
+    for perturbed in (False, True):
+        tc = copy.deepcopy(tree)
+        if perturbed:
+            for v in reach:
+                if v != t1 and tc.dist[v]:
+                    tc.dist[v] = tc.dist[v] * (0.4 + 2.1 * rng.random())
+        dist_in = [float(x or 0.0) for x in tc.dist]
+        with contextlib.redirect_stdout(io.StringIO()):
+            g["setAllDirty"](tc, t1)
+            updates = g["traverseTreeToOptimizeBranchLengths"](tc, t1, fastPass=True)
+        sweeps.append(dict(dist_in=dist_in, dist_out=[float(x or 0.0) for x in tc.dist], updates=updates,
+                           dirty_out=[bool(x) for x in tc.dirty]))
+        print(f"[{name}] fast branch-length pass (perturbed={perturbed}): {updates} updates", flush=True)
     path = os.path.join(HERE, f"update_{name}.json.gz")
     with gzip.open(path, "wt") as fh:
-        json.dump(dict(name=name, base=f"search_{name}.json.gz", cases=cases), fh)
+        json.dump(dict(name=name, base=f"search_{name}.json.gz", cases=cases, blen_sweeps=sweeps,
+                       effectivelyNon0BLen=g["effectivelyNon0BLen"]), fh)
     print(f"[{name}] -> {path} {os.path.getsize(path)/1e6:.2f} MB", flush=True)
 
 

@@ -336,3 +336,28 @@ def test_update_partials_matches_reference():
         assert close(got, case["treeLK"], 1e-9), (ch, got, case["treeLK"])
     assert n_lists > 10000
     dev.close()
+
+
+def test_branch_length_fast_pass_matches_reference(env):
+    """traverseTreeToOptimizeBranchLengths(fastPass=True) (M:8727-8893) as one estimateBranchLength launch + one root
+    grid launch: branch lengths and the number of updates of the reference, on the converged tree and on a tree whose
+    branch lengths were all perturbed."""
+    from maple_amd.tree_host import optimize_branch_lengths_fast_pass
+    f, dev, tree = env
+    if f["name"] != "synth_unrest":
+        pytest.skip("recorded for synth_unrest only")
+    with gzip.open(os.path.join(GOLDEN, "update_synth_unrest.json.gz"), "rt") as fh:
+        upd = json.load(fh)
+    saved = list(tree.dist)
+    try:
+        for rec in upd["blen_sweeps"]:
+            tree.dist = list(rec["dist_in"])
+            updates, dirty = optimize_branch_lengths_fast_pass(dev, tree, upd["effectivelyNon0BLen"])
+            assert updates == rec["updates"], (updates, rec["updates"])
+            reach = tree.preorder()
+            assert all(close(tree.dist[v], rec["dist_out"][v], 1e-7, 1e-15) for v in reach), \
+                [(v, tree.dist[v], rec["dist_out"][v]) for v in reach if not close(tree.dist[v], rec["dist_out"][v], 1e-7, 1e-15)][:5]
+            assert [dirty[v] for v in reach if v != tree.root and tree.up[v] != tree.root] == \
+                   [rec["dirty_out"][v] for v in reach if v != tree.root and tree.up[v] != tree.root]
+    finally:
+        tree.dist = saved
