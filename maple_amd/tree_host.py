@@ -27,6 +27,24 @@ class HostTree:
         self.probVectTotUp = probVectTotUp
         self.n = len(self.up)
 
+    @classmethod
+    def from_mirror(cls, mirror, dev: Device = None):
+        """The GPU-built TreeMirror (lists already in the arena, no MAT mutations) as a HostTree; with ``dev`` the
+        topology is also uploaded (maple_tree_upload) for the device-resident searches."""
+        nn = mirror.n_nodes
+        up = [None if p < 0 else int(p) for p in mirror.parent]
+        children = [[] if mirror.children[v, 0] < 0 else [int(mirror.children[v, 0]), int(mirror.children[v, 1])]
+                    for v in range(nn)]
+        t = cls(mirror.root, up, children, [float(x) for x in mirror.dist], [[] for _ in range(nn)], [0] * nn,
+                None, None, None, None)
+        t.id_lower, t.id_upRight = mirror.lower.copy(), mirror.up_right.copy()
+        t.id_upLeft, t.id_totUp = mirror.up_left.copy(), mirror.tot_up.copy()
+        t.id_mut = -np.ones(nn, dtype=np.int32)
+        if dev is not None:
+            dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist,
+                            mirror.is_tip, t.id_lower, t.id_upRight, t.id_upLeft, t.id_totUp, t.id_mut)
+        return t
+
     def preorder(self):
         """Visit order of startTopologyUpdatesParallel (M:9615-9618): pop the last pushed child first."""
         order, stack = [], [self.root]

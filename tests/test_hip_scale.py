@@ -157,3 +157,39 @@ def test_structural_properties(world):
     b = dev.download(back[:300])
     assert a == b
     dev.release(mark)
+
+
+def test_batched_placement_equals_single_query_search(world):
+    """maple_placement_search_batch (device-side traversal, one lane per query) against the one-query-at-a-time
+    PlacementSearcher (host replay) on new samples: same node, score, branch lengths, bestDiffs and the same number of
+    reference-equivalent appendProbNode evaluations, in every model mode."""
+    from maple_amd.host import tip_genome_list
+    from maple_amd.search import PlacementParams, PlacementSearcher
+    from maple_amd.synth import perturb_diffs
+    from maple_amd.tree_host import HostTree
+    mode, data, dev, orc, mirror = world
+    l_ref = dev.lRef
+    ll = math.log(l_ref)
+    tree = HostTree.from_mirror(mirror, dev)
+    ps = PlacementSearcher(dev, tree, PlacementParams(oneMutBLen=1.0 / l_ref, effectivelyNon0BLen=1.0 / (10 * l_ref),
+                                                      thresholdLogLK=18.0 * ll, thresholdLogLKoptimization=ll,
+                                                      thresholdLogLKconsecutivePlacement=1.0,
+                                                      onlyFindIdentical=(mode == "siteerr")))
+    rng = np.random.default_rng(21)
+    from maple_amd.host import reference_tables
+    ref_idx, _ = reference_tables(data.ref)
+    queries = [tip_genome_list(perturb_diffs(dl, data.ref, rng, n_extra=k % 3), ref_idx)
+               for k, dl in enumerate(data.diffs[:48])]                  # every third query is a copy of a tip
+    batch = ps.find_best_parent_batch(queries)
+    n_minor = 0
+    for q, got in zip(queries, batch):
+        want = ps.find_best_parent_for_new_sample(q)
+        assert got[0] == want[0] and got[1] == want[1], (got[:2], want[:2])
+        assert got[4]["minor"] == want[4]["minor"] and got[4]["n_append"] == want[4]["n_append"]
+        if want[2] is None:
+            assert got[2] is None
+            n_minor += 1
+        else:
+            assert tuple(0.0 if b is False else b for b in want[2]) == got[2]
+        assert got[3] == want[3]
+    assert 0 < n_minor < len(queries)

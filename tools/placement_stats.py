@@ -19,11 +19,7 @@ dev.set_model(bench.UNREST_Q)
 tips = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
 m = TreeMirror(dev, data.parent, data.blen, tips).build()
 nn = m.n_nodes
-up = [None if p < 0 else int(p) for p in m.parent]
-children = [[] if m.children[v, 0] < 0 else [int(m.children[v, 0]), int(m.children[v, 1])] for v in range(nn)]
-ht = HostTree(m.root, up, children, m.dist, [[] for _ in range(nn)], [0] * nn, None, None, None, None)
-ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp = m.lower, m.up_right, m.up_left, m.tot_up
-ht.id_mut = -np.ones(nn, dtype=np.int32)
+ht = HostTree.from_mirror(m, dev)
 l_ref = dev.lRef; ll = math.log(l_ref)
 ps = PlacementSearcher(dev, ht, PlacementParams(oneMutBLen=1.0 / l_ref, effectivelyNon0BLen=1.0 / (10 * l_ref),
                                                   thresholdLogLK=18.0 * ll, thresholdLogLKoptimization=ll,
@@ -39,9 +35,6 @@ dt = time.perf_counter() - t0
 print(f"{nq} placement searches on a {n + nq}-tip tree: {dt / nq * 1e3:.2f} ms/query, {nq / dt:.0f} queries/s; "
       f"reference-equivalent placements {tot} ({tot / dt:.3g}/s), branches scored {scored} ({scored / dt:.3g}/s)")
 # the same queries as ONE native batch (maple_placement_search_batch): device-side traversal, one lane per query
-is_tip = np.asarray([not c for c in children], dtype=np.uint8)
-dev.upload_tree(m.root, m.parent.astype(np.int32), m.children[:, 0].astype(np.int32), m.children[:, 1].astype(np.int32),
-                m.dist, is_tip, m.lower, m.up_right, m.up_left, m.tot_up, ht.id_mut)
 for reps in (1, 8):
     qs = queries * reps
     ps.find_best_parent_batch(qs[:4])

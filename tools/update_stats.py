@@ -17,11 +17,7 @@ dev.set_model(bench.UNREST_Q)
 tips = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
 m = TreeMirror(dev, data.parent, data.blen, tips).build()
 nn = m.n_nodes
-up = [None if p < 0 else int(p) for p in m.parent]
-children = [[] if m.children[v, 0] < 0 else [int(m.children[v, 0]), int(m.children[v, 1])] for v in range(nn)]
-ht = HostTree(m.root, up, children, list(m.dist), [[] for _ in range(nn)], [0] * nn, None, None, None, None)
-ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp = m.lower.copy(), m.up_right.copy(), m.up_left.copy(), m.tot_up.copy()
-ht.id_mut = -np.ones(nn, dtype=np.int32)
+ht = HostTree.from_mirror(m, dev)
 t0 = time.perf_counter()
 lo, ur, ul, tu = rebuild_genome_lists(dev, ht)
 dt = time.perf_counter() - t0
