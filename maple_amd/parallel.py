@@ -65,3 +65,52 @@ def gather_proposals(local_records, device=None):
     order = np.argsort(a[:, 0], kind="stable")
     a = a[order]
     return [(int(r[1]), int(r[2]), float(r[0])) for r in a]
+
+
+# ---- level 2: ONE query, its candidate branches sharded over the GPUs ---------------------------
+def shard_candidates(n_candidates: int, rank: int, world: int):
+    """Indices (into the candidate list) this rank scores: interleaved, so every rank gets the same mix of list lengths."""
+    return np.arange(rank, n_candidates, world)
+
+
+def allgather_interleaved(local, n_total: int, device=None):
+    """Inverse of shard_candidates for a per-candidate vector (scores f64 / flags u8): one all-gather of equal-size
+    (padded) shards, re-interleaved so that element k is candidate k on every rank.  The depth-first replay of
+    findBestParentForNewSample needs every score on its path (stop rules, M:8080-8093), not only the maximum, which is
+    why the exchange is an all-gather and not a reduction."""
+    import torch
+    import torch.distributed as dist
+    local = np.ascontiguousarray(local)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        assert len(local) == n_total
+        return local
+    world = dist.get_world_size()
+    m = (n_total + world - 1) // world
+    pad = torch.zeros(m, dtype=torch.from_numpy(local[:0]).dtype)
+    pad[: len(local)] = torch.from_numpy(local)
+    if device is not None:
+        pad = pad.to(device)
+    bufs = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    out = np.zeros(n_total, dtype=local.dtype)
+    for r, b in enumerate(bufs):
+        cnt = len(range(r, n_total, world))
+        out[r::world] = b[:cnt].cpu().numpy()
+    return out
+
+
+def argmax_allreduce(score: float, visit_index: int, device=None):
+    """Best placement over the ranks' shards without moving the scores: max score, ties resolved to the SMALLEST visit
+    index (the earliest depth-first visit wins under the reference's strict ``>``, M:7083, 8065).  Two all-reduces of
+    one element each (16 bytes over xGMI); returns (score, visit_index) identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(score), int(visit_index)
+    s = torch.tensor([score], dtype=torch.float64, device=device)
+    dist.all_reduce(s, op=dist.ReduceOp.MAX)
+    best = float(s.item())
+    big = np.iinfo(np.int64).max
+    i = torch.tensor([visit_index if score == best else big], dtype=torch.int64, device=device)
+    dist.all_reduce(i, op=dist.ReduceOp.MIN)
+    return best, int(i.item())

@@ -42,8 +42,13 @@ class _Diffs:
 
 
 class PlacementSearcher:
-    def __init__(self, dev: Device, tree: HostTree, params: PlacementParams):
+    """``rank`` / ``world`` (default: one GPU): level 2 of SURVEY section 8e -- the candidate branches and the leaves of
+    ONE query are sharded over the GPUs (maple_amd.parallel.shard_candidates), each rank scores its shard in one launch
+    and the score / minor-test vectors are all-gathered, after which every rank replays the same traversal."""
+
+    def __init__(self, dev: Device, tree: HostTree, params: PlacementParams, rank: int = 0, world: int = 1, device=None):
         self.dev, self.tree, self.p = dev, tree, params
+        self.rank, self.world, self.coll_device = rank, world, device
         t = tree
         n = t.n
         self.has_mut = np.asarray([bool(m) for m in t.mutations])
@@ -80,13 +85,16 @@ class PlacementSearcher:
         # resident candidate sets: frame index 0 is the root frame, then the frames in a fixed order
         self.frame_order = [-1] + [f for fl in self.frame_levels for f in fl]
         fidx = {f: i for i, f in enumerate(self.frame_order)}
-        cand_frames = [fidx[int(self.frame[v])] for v in self.cand] + [fidx[int(self.frame[t.root])]]
-        self.cset_cand = dev.candset_create(np.concatenate([t.id_totUp[self.cand], [self.root_vect]]), cand_frames,
+        from .parallel import shard_candidates
+        self.my_cand = self.cand[shard_candidates(len(self.cand), rank, world)]
+        self.my_leaves = self.leaves[shard_candidates(len(self.leaves), rank, world)]
+        cand_frames = [fidx[int(self.frame[v])] for v in self.my_cand] + [fidx[int(self.frame[t.root])]]
+        self.cset_cand = dev.candset_create(np.concatenate([t.id_totUp[self.my_cand], [self.root_vect]]), cand_frames,
                                             len(self.frame_order))
         self.cset_leaf = None
-        if len(self.leaves):
-            self.cset_leaf = dev.candset_create(t.id_lower[self.leaves], [fidx[int(self.frame[v])] for v in self.leaves],
-                                                len(self.frame_order))
+        if len(self.my_leaves):
+            self.cset_leaf = dev.candset_create(t.id_lower[self.my_leaves],
+                                                [fidx[int(self.frame[v])] for v in self.my_leaves], len(self.frame_order))
 
     # ---------------------------------------------------------------------------------------------
     def _frame_lists(self, q_id):
@@ -148,12 +156,14 @@ class PlacementSearcher:
         # one launch: the query against every candidate branch (+ the root), one launch: minor test on every leaf
         cand = self.cand
         frame_lists = [U[f] for f in self.frame_order]
-        sc = dev.append_candset(self.cset_cand, frame_lists, True, p.oneMutBLen)
-        score = dict(zip(cand.tolist(), sc[:-1].tolist()))
+        from .parallel import allgather_interleaved
+        sc = dev.append_candset(self.cset_cand, frame_lists, True, p.oneMutBLen)     # this rank's shard (+ the root)
+        score = dict(zip(cand.tolist(), allgather_interleaved(sc[:-1], len(cand), self.coll_device).tolist()))
         minor = {}
-        if self.cset_leaf is not None:
-            mres = dev.minor_candset(self.cset_leaf, frame_lists, p.onlyFindIdentical)
-            minor = dict(zip(self.leaves.tolist(), mres.tolist()))
+        if len(self.leaves):
+            mres = (dev.minor_candset(self.cset_leaf, frame_lists, p.onlyFindIdentical) if self.cset_leaf is not None
+                    else np.zeros(0, dtype=np.uint8))
+            minor = dict(zip(self.leaves.tolist(), allgather_interleaved(mres, len(self.leaves), self.coll_device).tolist()))
         n_append = 1
 
         def shorten(obj):

@@ -64,3 +64,51 @@ def test_two_rank_gather_matches_single_process():
     concat.sort(key=lambda m: m[2])
     assert res[0] == concat
     assert all(a[2] <= b[2] for a, b in zip(concat, concat[1:]))
+
+
+def _worker_level2(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from maple_amd.parallel import allgather_interleaved, argmax_allreduce, shard_candidates
+    rng = np.random.default_rng(3)
+    n = 1001                                                    # not a multiple of the world size
+    scores = np.round(rng.normal(size=n) * 3, 1)                # rounded -> exact ties exist
+    scores[[17, 400, 923]] = scores.max() + 1.0                 # a three-way tie for the best
+    flags = rng.integers(0, 3, size=n).astype(np.uint8)
+    visit = rng.permutation(n)                                  # depth-first visit index of each candidate
+    mine = shard_candidates(n, rank, world)
+    full = allgather_interleaved(scores[mine], n)
+    full_flags = allgather_interleaved(flags[mine], n)
+    k = mine[np.lexsort((visit[mine], -scores[mine]))[0]]       # local best, earliest visit among local ties
+    best = argmax_allreduce(float(scores[k]), int(visit[k]))
+    q.put((rank, full.tolist(), full_flags.tolist(), best))
+    dist.destroy_process_group()
+
+
+def test_two_rank_candidate_sharding_level2():
+    """One query, candidates sharded over the ranks: the all-gathered score vector equals the unsharded one on every
+    rank, and the two-step arg-max all-reduce picks the best score with the earliest visit among exact ties."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_level2, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(3)
+    n = 1001
+    scores = np.round(rng.normal(size=n) * 3, 1)
+    scores[[17, 400, 923]] = scores.max() + 1.0
+    flags = rng.integers(0, 3, size=n).astype(np.uint8)
+    visit = rng.permutation(n)
+    want_k = min((17, 400, 923), key=lambda i: visit[i])
+    for rank, full, full_flags, best in res:
+        assert full == scores.tolist()
+        assert full_flags == flags.tolist()
+        assert best == (float(scores[want_k]), int(visit[want_k]))

@@ -361,3 +361,32 @@ def test_branch_length_fast_pass_matches_reference(env):
                    [rec["dirty_out"][v] for v in reach if v != tree.root and tree.up[v] != tree.root]
     finally:
         tree.dist = saved
+
+
+def test_candidate_sharding_level2(env):
+    """SURVEY 8e level 2: three ranks' candidate / leaf shards of one query, re-interleaved, are exactly the
+    single-GPU score and minor-test vectors (the collective itself is covered by the gloo test)."""
+    from maple_amd.search import PlacementParams, PlacementSearcher
+    f, dev, tree = env
+    ctx = f["context"]
+    pp = PlacementParams(oneMutBLen=ctx["oneMutBLen"], effectivelyNon0BLen=ctx["effectivelyNon0BLen"],
+                         thresholdLogLK=ctx["thresholdLogLK"], thresholdLogLKoptimization=ctx["thresholdLogLKoptimization"],
+                         thresholdLogLKconsecutivePlacement=ctx["thresholdLogLKconsecutivePlacement"])
+    one = PlacementSearcher(dev, tree, pp)
+    world = 3
+    shards = [PlacementSearcher(dev, tree, pp, rank=r, world=world) for r in range(world)]
+    mark = dev.mark()
+    q_id = dev.upload([tup(f["placements"][3]["query"])])[0]
+    U, _ = one._frame_lists(q_id)
+    frame_lists = [U[fr] for fr in one.frame_order]
+    full = dev.append_candset(one.cset_cand, frame_lists, True, pp.oneMutBLen)
+    full_minor = dev.minor_candset(one.cset_leaf, frame_lists, False)
+    got = np.zeros(len(one.cand))
+    got_minor = np.zeros(len(one.leaves), dtype=np.uint8)
+    for r, s in enumerate(shards):
+        sc = dev.append_candset(s.cset_cand, frame_lists, True, pp.oneMutBLen)
+        assert sc[-1] == full[-1]                                   # every rank scores the root vector itself
+        got[r::world] = sc[:-1]
+        got_minor[r::world] = dev.minor_candset(s.cset_leaf, frame_lists, False)
+    assert np.array_equal(got, full[:-1]) and np.array_equal(got_minor, full_minor)
+    dev.release(mark)
