@@ -61,7 +61,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spr", action="store_true", help="skip the secondary SPR-search-round measurement")
     ap.add_argument("--pairs", action="store_true", help="experiment: explicit (parent, child) index arrays, untiled kernel")
-    ap.add_argument("--sort", action="store_true", help="experiment: order candidates by list length")
+    ap.add_argument("--no-sort", action="store_true",
+                    help="experiment: leave the candidate branches in tree pre-order instead of ordering them by list length")
     args = ap.parse_args()
 
     import torch
@@ -97,7 +98,7 @@ def main():
     tip_lists = {int(v): tip_genome_list(dl, ref_idx, **tip_kw) for v, dl in zip(data.tip_node, data.diffs)}
     mirror = TreeMirror(dev, data.parent, data.blen, tip_lists).build()
     l_ref = dev.lRef
-    cand_nodes = mirror.candidates_by_length(1.0 / (10 * l_ref)) if args.sort else mirror.candidate_nodes(1.0 / (10 * l_ref))
+    cand_nodes = mirror.candidate_nodes(1.0 / (10 * l_ref)) if args.no_sort else mirror.candidates_by_length(1.0 / (10 * l_ref))
     cand_lists = mirror.tot_up[cand_nodes]
     # queries of this rank: samples rank, rank+world, ... (round-robin like coreNum, M:12164-12195)
     q_nodes = np.asarray(data.tip_node[rank::world][: args.queries], dtype=np.int64)
@@ -218,14 +219,16 @@ def main():
     # cannot read its own PMCs); they are recorded, with the FETCH_SIZE calibration for this access pattern, in
     # profiles/pmc_k_append_queries.json and only reported when the workload is the one they were measured on.
     traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_append_queries.json")))
-        w = pmc["workload"]
-        if ((w["samples"], w["queries_per_gpu"], w["candidate_branches"]) == (args.samples, Q, int(Cn))
-                and not args.pairs and args.model == "unrest"):
-            traffic = pmc["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_k_append_queries*.json"))):
+        try:
+            pmc = json.load(open(path))
+            w = pmc["workload"]
+            if ((w["samples"], w["queries_per_gpu"], w["candidate_branches"], w.get("model", "unrest"))
+                    == (args.samples, Q, int(Cn), args.model) and not args.pairs):
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps

@@ -6,20 +6,28 @@
 //   k_place_replay - the reference's depth-first traversal over those scores, one lane per query
 #pragma once
 
+// same scheduling as k_append_queries (dynamic 64-candidate tiles per wavefront, candidate-chunk-major, candidates sorted by
+// list length), with the query taken in each candidate's MAT reference frame
 template <bool RV, bool U, bool SS>
 __global__ MAPLE_APPEND_ATTR void k_place_score(const DevModel *__restrict__ mp, ArenaView av, int nQ, int nF,
                                                 const int32_t *qFrameLists, int nC, const int32_t *cand,
-                                                const int32_t *candFrame, double bLen, double *out)
+                                                const int32_t *candFrame, double bLen, double *out, int *counter)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
-    const int nChunks = (nC + MAPLE_BLOCK - 1) / MAPLE_BLOCK;
-    const int tiles = nQ * nChunks;
-    for (int j = blockIdx.x; j < tiles; j += gridDim.x) {
-        const int q = j / nChunks;
-        const int k = (j - q * nChunks) * MAPLE_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int nChunks = (nC + 63) / 64;
+    const long long tiles = (long long)nQ * nChunks;
+    for (;;) {
+        int j = 0;
+        if (lane == 0) j = atomicAdd(counter, 1);
+        j = __builtin_amdgcn_readfirstlane(j);
+        if (j >= tiles) break;
+        const int ch = j / nQ;
+        const int q = j - ch * nQ;
+        const int k = ch * 64 + lane;
         if (k < nC)
             out[(long long)q * nC + k] =
                 append_walk(c, list_ref(av, cand[k]), list_ref(av, qFrameLists[(long long)q * nF + candFrame[k]]), true, bLen);
@@ -89,13 +97,17 @@ static int place_meta(maple_ctx *c, double effNon0)
     M.cand.clear();
     M.leaves.clear();
     std::vector<int32_t> candIdx(n, -1), leafIdx(n, -1), candList, candFrame, leafList, leafFrame;
+    for (int32_t v : order)
+        if (v != root && up[v] >= 0 && c->h_tree_dist[v] > effNon0 && totUp[v] >= 0) M.cand.push_back(v);      // M:8049
+    // columns sorted by list length: the 64 lanes of a scoring wavefront then finish together
+    std::stable_sort(M.cand.begin(), M.cand.end(), [&](int a, int b) { return c->h_n_ent[totUp[a]] < c->h_n_ent[totUp[b]]; });
+    for (size_t i = 0; i < M.cand.size(); i++) {
+        const int32_t v = M.cand[i];
+        candIdx[v] = (int32_t)i;
+        candList.push_back(totUp[v]);
+        candFrame.push_back(M.frameOf[v]);
+    }
     for (int32_t v : order) {
-        if (v != root && up[v] >= 0 && c->h_tree_dist[v] > effNon0 && totUp[v] >= 0) {      // M:8049
-            candIdx[v] = (int32_t)M.cand.size();
-            M.cand.push_back(v);
-            candList.push_back(totUp[v]);
-            candFrame.push_back(M.frameOf[v]);
-        }
         if (c0[v] < 0) {
             if (lower[v] < 0) return fail(c, MAPLE_ERR_STATE, "leaf %d has no lower genome list", v);
             leafIdx[v] = (int32_t)M.leaves.size();
@@ -191,13 +203,18 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
         HIPCK(c, c->p_score.reserve((size_t)nq * nCols));
         HIPCK(c, c->p_minor.reserve((size_t)nq * std::max(nL, 1)));
         {
-            const long long tiles = (long long)nq * ((nCols + MAPLE_BLOCK - 1) / MAPLE_BLOCK);
-            const int grid = tiles < 256 * 8 ? (int)tiles : 256 * 8;
+            const long long tiles = (long long)nq * ((nCols + 63) / 64);
+            if (tiles > 0x7fffffffLL - (1 << 20)) return fail(c, MAPLE_ERR_ARG, "placement chunk too large for one launch");
+            if (!c->d_tile_counters) HIPCK(c, hipMalloc((void **)&c->d_tile_counters, 64 * sizeof(int32_t)));
+            int32_t *counter = c->d_tile_counters + (c->tile_counter_next++ & 63);
+            HIPCK(c, hipMemsetAsync(counter, 0, sizeof(int32_t), c->stream));
+            const long long waves = (tiles + 3) / 4;
+            const int grid = waves < 256 * 4 ? (int)waves : 256 * 4;
             hipEvent_t e0, e1;
             TRY(ev_pair(c, &e0, &e1));
             HIPCK(c, hipEventRecord(e0, c->stream));
             DISPATCH3(c, k_place_score, <<<grid, MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), nq, nF, dU.p, nCols, M.d_candList.p,
-                                                                                M.d_candFrame.p, pp->oneMutBLen, c->p_score.p));
+                                                                                M.d_candFrame.p, pp->oneMutBLen, c->p_score.p, counter));
             HIPCK(c, hipGetLastError());
             HIPCK(c, hipEventRecord(e1, c->stream));
         }

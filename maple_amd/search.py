@@ -77,6 +77,8 @@ class PlacementSearcher:
         up = np.asarray([-1 if u is None else u for u in t.up])
         dist = np.asarray(t.dist)
         self.cand = np.nonzero((up >= 0) & (dist > params.effectivelyNon0BLen) & (t.id_totUp >= 0))[0]
+        # scored in order of list length, so that the 64 lanes of a wavefront finish together
+        self.cand = self.cand[np.argsort(dev.sizes(t.id_totUp[self.cand])[0], kind="stable")]
         self.leaves = np.asarray([v for v in range(n) if not t.children[v]], dtype=np.int64)
         # rootVector(probVect[root], False, False, tree, root) does not depend on the query (M:7958)
         path = [t.id_mut[t.root]] if t.id_mut[t.root] >= 0 else []
