@@ -292,10 +292,16 @@ template <bool RV, bool U, bool SS> struct PairWalk {
     double tf, Lk;
     bool dead;
     int lRef; double carry;            // hot scalars of the model kept in registers
+    // log(totalFactor) is owed every time the running product falls below minimumCarryOver (M:6772-6783), about once
+    // per pair -- i.e. in every third iteration SOME lane of a wavefront would run the ~90-instruction log() alone.
+    // The products are parked here instead and their logs are added, in the same order, by finish().
+    double carry1, carry2;
+    int nCarry;
 
-    __device__ PairWalk(const CT &c_, ListRef Cl_, bool isTipC_, double bLen_)
-        : c(c_), Cl(Cl_), cw((const unsigned long long *)Cl_.w), isTipC(isTipC_), bLen(bLen_), lRef(c_.m.lRef),
-          carry(c_.m.minimumCarryOver) {}
+    // cwStaged: the child list's words staged somewhere faster than Cl.w (the batch kernels keep the query in LDS)
+    __device__ PairWalk(const CT &c_, ListRef Cl_, bool isTipC_, double bLen_, const unsigned long long *cwStaged = nullptr)
+        : c(c_), Cl(Cl_), cw(cwStaged ? cwStaged : (const unsigned long long *)Cl_.w), isTipC(isTipC_), bLen(bLen_),
+          lRef(c_.m.lRef), carry(c_.m.minimumCarryOver) {}
 
     __device__ inline void start(ListRef P_)
     {
@@ -307,6 +313,8 @@ template <bool RV, bool U, bool SS> struct PairWalk {
         Lk = bLen * c.m.globalTotRate;                                   // M:6541
         if (U && isTipC) Lk += c.m.totError;                             // M:6542-6543
         dead = false;
+        carry1 = carry2 = 1.0;
+        nCarry = 0;
     }
 
     // one segment of the two-list walk; returns true when the end of the genome (or a dead end) is reached
@@ -348,7 +356,9 @@ template <bool RV, bool U, bool SS> struct PairWalk {
         if (pos == lRef || dead) return true;
         if (tf <= carry) {                                               // M:6772-6783
             if (tf < 2.2250738585072014e-308) { dead = true; return true; }
-            Lk += log(tf);
+            if (nCarry == 2) { Lk += log(carry1); carry1 = carry2; nCarry = 1; }     // a third one: settle the oldest
+            if (nCarry == 0) carry1 = tf; else carry2 = tf;
+            ++nCarry;
             tf = 1.0;
         }
         if (pa == pos) { ++ia; wa = pw[ia]; }
@@ -359,7 +369,10 @@ template <bool RV, bool U, bool SS> struct PairWalk {
     __device__ inline double finish() const
     {
         if (dead) return -INFINITY;
-        return (tf > 0.0) ? Lk + log(tf) : -INFINITY;
+        double lk = Lk;
+        if (nCarry >= 1) lk += log(carry1);
+        if (nCarry >= 2) lk += log(carry2);
+        return (tf > 0.0) ? lk + log(tf) : -INFINITY;
     }
 };
 

@@ -156,6 +156,7 @@ __device__ inline ListRef list_ref(const ArenaView &a, int id)
 // appendProbNode over arbitrary pairs ----------------------------------------------------------
 // 120 VGPRs / no scratch at 4 waves per SIMD measured fastest (5 waves spills, 3 waves loses latency hiding).
 #define MAPLE_APPEND_ATTR __launch_bounds__(MAPLE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#define MAPLE_QLDS 192                 // query-list words staged in LDS per wavefront (longer lists are read from HBM/L2)
 template <bool RV, bool U, bool SS>
 __global__ MAPLE_APPEND_ATTR void k_append(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *pl,
                                            const int32_t *cl, const uint8_t *tip, const double *bl, double *out)
@@ -184,10 +185,12 @@ __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ 
                                                    const uint8_t *qTip, const double *qBLen, int *counter)
 {
     __shared__ Lds lds;
+    __shared__ unsigned long long qlds[MAPLE_BLOCK / 64][MAPLE_QLDS];   // the tile's query list, one copy per wavefront
     const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     const int lane = threadIdx.x & 63;
+    unsigned long long *myq = qlds[threadIdx.x >> 6];
     const int nChunks = (nC + 63) / 64;
     const long long tiles = (long long)nQ * nChunks;
     for (;;) {
@@ -198,11 +201,32 @@ __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ 
         const int ch = j / nQ;
         const int q = j - ch * nQ;
         const int k = ch * 64 + lane;
+        const int ql = qList[q];
+        const int nq = av.n_ent[ql];
+        const ListRef qref = list_ref(av, ql);
+        const bool staged = nq <= MAPLE_QLDS;                             // wave-uniform
+        if (staged) {
+            // all 64 lanes walk the same query: its words go to LDS once per tile (no workgroup barrier: the LDS
+            // pipeline serves one wavefront's requests in order) and every step's query load is a ds_read
+            for (int i = lane; i < nq; i += 64) myq[i] = ((const unsigned long long *)qref.w)[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         const int cl = k < nC ? cand[k] : -1;                             // -1: this column has no list (score unused)
-        if (cl < 0) continue;
-        const bool tipq = qTip ? qTip[q] != 0 : isTip != 0;
-        const double blq = qBLen ? qBLen[q] : bLen;
-        out[(long long)q * ldOut + (outCol ? outCol[k] : k)] = append_walk(c, list_ref(av, cl), list_ref(av, qList[q]), tipq, blq);
+        if (cl >= 0) {
+            const bool tipq = qTip ? qTip[q] != 0 : isTip != 0;
+            const double blq = qBLen ? qBLen[q] : bLen;
+            double lk;
+            if (staged) {
+                PairWalk<RV, U, SS> w(c, qref, tipq, blq, myq);
+                w.start(list_ref(av, cl));
+                while (!w.step()) {}
+                lk = w.finish();
+            } else lk = append_walk(c, list_ref(av, cl), qref, tipq, blq);
+            out[(long long)q * ldOut + (outCol ? outCol[k] : k)] = lk;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
