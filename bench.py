@@ -74,13 +74,22 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the placement path has no CPU fallback")
+    # MAPLE_BENCH_BACKEND=gloo is a plumbing check of the N>1 path on a box with fewer GPUs than ranks (ranks then share
+    # GPUs and the collectives go through host memory); the driver's runs use nccl (= RCCL over xGMI), one GPU per rank
+    backend = os.environ.get("MAPLE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     distd = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         distd = dist
+    coll = (lambda t: t) if backend == "nccl" else (lambda t: t.cpu())
 
     from maple_amd.host import reference_tables, tip_genome_list
     from maple_amd.runtime import Device
@@ -134,6 +143,7 @@ def main():
         best_score, best_idx = t_out.view(Q, Cn).max(dim=1)
         rec = torch.stack([best_score, t_cand_nodes[best_idx].to(torch.float64)], dim=1)
         if distd is not None:
+            rec = coll(rec)
             gathered = [torch.empty_like(rec) for _ in range(world)]
             distd.all_gather(gathered, rec)
             rec = torch.cat(gathered, dim=0)
@@ -156,10 +166,10 @@ def main():
     elapsed = time.perf_counter() - t0
     n_launch, kernel_ms = dev.timing_read()
     if distd is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=cu)
+        te = coll(torch.tensor([elapsed], dtype=torch.float64, device=cu))
         distd.all_reduce(te, op=distd.ReduceOp.MAX)
         elapsed = float(te.item())
-        tp = torch.tensor([float(n_pairs)], dtype=torch.float64, device=cu)
+        tp = coll(torch.tensor([float(n_pairs)], dtype=torch.float64, device=cu))
         distd.all_reduce(tp, op=distd.ReduceOp.SUM)
         total_pairs = float(tp.item())
     else:
