@@ -165,7 +165,7 @@ typedef struct {
     double thresholdLogLKconsecutivePlacement;  /* M:63  */
     double effectivelyNon0BLen;                 /* M:3614 */
     int32_t wideSearchBudget;                   /* searches scoring more branches than this are batch-scored first
-                                                   (0 = default 512, < 0 = never); results do not depend on it */
+                                                   (0 = default 256, < 0 = never); results do not depend on it */
 } maple_search_params;
 
 /* The worker body of startTopologyUpdatesParallel (M:9615-9711) for n pruned nodes, each running

@@ -1447,6 +1447,24 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         r.up = up[i]; r.c0 = child0[i]; r.c1 = child1[i];
         r.lower = lower[i]; r.upRight = upRight[i]; r.upLeft = upLeft[i]; r.totUp = totUp[i];
         r.mutId = mutList[i]; r.dist = dist[i]; r.isTip = isTip[i];
+        r.upIsRoot = (up[i] >= 0 && up[up[i]] < 0) ? 1 : 0;
+        r.whichChild = (up[i] >= 0 && child1[up[i]] == i) ? 1 : 0;
+        r.preRank = i;
+    }
+    {   // depth-first ranks in the order the searches descend (the child pushed last, child 1, is visited first)
+        std::vector<int32_t> st;
+        std::vector<uint8_t> seen((size_t)n, 0);
+        int32_t next = 0;
+        if (root >= 0 && root < n) st.push_back(root);
+        while (!st.empty()) {
+            const int32_t v = st.back();
+            st.pop_back();
+            if (v < 0 || v >= n || seen[v]) continue;
+            seen[v] = 1;
+            recs[v].preRank = next++;
+            if (child0[v] >= 0) { st.push_back(child0[v]); st.push_back(child1[v]); }
+        }
+        for (int i = 0; i < n; i++) if (!seen[i]) recs[i].preRank = next++;   // nodes not reachable from the root
     }
     HIPCK(c, c->t_nodes.reserve((size_t)n * sizeof(NodeRec) + 64));
     uint8_t *aligned = (uint8_t *)(((uintptr_t)c->t_nodes.p + 63) & ~(uintptr_t)63);
@@ -1473,11 +1491,11 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         std::vector<int32_t> col;
         for (int i = 0; i < n; i++) if (totUp[i] >= 0) col.push_back(i);
         std::stable_sort(col.begin(), col.end(), [&](int a, int b) { return c->h_n_ent[totUp[a]] < c->h_n_ent[totUp[b]]; });
-        std::vector<int32_t> ids(col.size());
-        for (size_t i = 0; i < col.size(); i++) ids[i] = totUp[col[i]];
+        std::vector<int32_t> ids(col.size()), rank(col.size());
+        for (size_t i = 0; i < col.size(); i++) { ids[i] = totUp[col[i]]; rank[i] = recs[col[i]].preRank; }
         c->n_scored = (int32_t)col.size();
         TRY(h2d(c, c->t_i32[8], ids.data(), ids.size()));
-        TRY(h2d(c, c->t_scored_col, col.data(), col.size()));
+        TRY(h2d(c, c->t_scored_col, rank.data(), rank.size()));
         HIPCK(c, hipStreamSynchronize(c->stream));
     }
     c->tree_set = true;
@@ -1586,7 +1604,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // branch is a pure function of (query, branch), so those queries are scored against every branch by the batch
     // kernel (k_append_queries) and the state machine then only replays the traversal over the cached scores.
     // Only for trees without MAT local references for now (one frame: the removed list is the same everywhere).
-    int wideBudget = sp->wideSearchBudget == 0 ? 512 : sp->wideSearchBudget;
+    int wideBudget = sp->wideSearchBudget == 0 ? 256 : sp->wideSearchBudget;
     const bool hybrid = wideBudget > 0 && !c->tree_has_mut;
     TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0));
     if (hybrid) {

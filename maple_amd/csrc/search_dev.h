@@ -43,7 +43,12 @@ struct alignas(64) NodeRec {
     int32_t mutId;                     // mutation-list id of the branch above the node, -1 = empty
     double dist;
     uint8_t isTip;                     // leaf without minor sequences
-    uint8_t pad[23];
+    uint8_t upIsRoot;                  // the parent is the root (saves the dependent nd[up].up load of M:7182 / 6984)
+    uint8_t whichChild;                // 0 / 1: this node is child 0 / 1 of its parent
+    uint8_t pad0;
+    int32_t preRank;                   // rank in the search's own depth-first order (child 1's subtree first): the column of
+                                       // this node in a cached score row, so that a descent reads the row sequentially
+    uint8_t pad[16];
 };
 
 struct DevTree {
@@ -241,7 +246,7 @@ template <bool RV, bool U, bool SS> struct Search {
         ws.best[ws.nB++] = BestRec{t1, hUp, hDown, hMid, hRpr, score, distance};
     }
     __device__ inline int child(int v, int k) const { return k == 0 ? T.nd[v].c0 : T.nd[v].c1; }
-    __device__ inline int upVectOf(int t1) const { return (T.nd[T.nd[t1].up].c0 == t1) ? T.nd[T.nd[t1].up].upRight : T.nd[T.nd[t1].up].upLeft; }
+    __device__ inline int upVectOf(int t1) const { return T.nd[t1].whichChild ? T.nd[T.nd[t1].up].upLeft : T.nd[T.nd[t1].up].upRight; }
 
     // search state
     int node, removed, sibling;
@@ -309,7 +314,7 @@ template <bool RV, bool U, bool SS> struct Search {
         double midProb;
         if (it.dir == 0) {                                           // moving from a parent to its child
             const int upT = T.nd[t1].up;
-            if (!(upT == node || upT < 0) && (T.nd[t1].dist > P.effNon0 || T.nd[upT].up < 0)) {
+            if (!(upT == node || upT < 0) && (T.nd[t1].dist > P.effNon0 || T.nd[t1].upIsRoot)) {
                 int midTot;
                 if (upd) {
                     midTot = opMerge(hPassed, distance / 2, false, treeList(T.nd[t1].lower), distance / 2, T.nd[t1].isTip, true);
@@ -320,7 +325,7 @@ template <bool RV, bool U, bool SS> struct Search {
                     distance = T.nd[t1].dist;
                 }
                 if (!valid(midTot)) return;
-                if (cached && !it.upd) { midProb = cached[t1]; nAppend++; }   // only items that ARRIVED in the cached regime
+                if (cached && !it.upd) { midProb = cached[T.nd[t1].preRank]; nAppend++; }   // only items that ARRIVED in the cached regime
                 else midProb = opAppend(midTot, hRpr, isRemovedTip, removedBLen);
                 if (budget > 0 && !cached && nAppend > budget) { overBudget = true; return; }
                 if (midProb > bestLKdiff - P.thrOptTopo) {            // M:7071-7082
@@ -354,7 +359,7 @@ template <bool RV, bool U, bool SS> struct Search {
             const int other = child(t1, 2 - it.dir);
             const int upT = T.nd[t1].up;
             int midBottom = -1, vectUp = -1;
-            if (upT >= 0 && (T.nd[t1].dist > P.effNon0 || T.nd[upT].up < 0)) {
+            if (upT >= 0 && (T.nd[t1].dist > P.effNon0 || T.nd[t1].upIsRoot)) {
                 int midTot;
                 if (upd) {
                     int opv = opPass(treeList(T.nd[other].lower), T.nd[other].mutId, true);
@@ -369,7 +374,7 @@ template <bool RV, bool U, bool SS> struct Search {
                     if (!opDiffer(midTot, cached)) upd = false;
                 } else midTot = treeList(T.nd[t1].totUp);
                 if (!valid(midTot)) return;
-                if (cached && !it.upd) { midProb = cached[t1]; nAppend++; }   // only items that ARRIVED in the cached regime
+                if (cached && !it.upd) { midProb = cached[T.nd[t1].preRank]; nAppend++; }   // only items that ARRIVED in the cached regime
                 else midProb = opAppend(midTot, hRpr, isRemovedTip, removedBLen);
                 if (budget > 0 && !cached && nAppend > budget) { overBudget = true; return; }
                 if (midProb >= (bestLKdiff - P.thrOptTopo)) {         // M:7293-7304 (>= here, > on the way down)
@@ -385,7 +390,7 @@ template <bool RV, bool U, bool SS> struct Search {
             else go = fails <= P.allowedFails || midProb > (bestLKdiff - P.thrLKtopology);
             if (!go) return;
             if (upT >= 0) {
-                const int upChild = (T.nd[upT].c0 == t1) ? 0 : 1;
+                const int upChild = T.nd[t1].whichChild;
                 int vUp;
                 if (upd) {
                     int vUpUp = opPass(treeList(upVectOf(t1)), T.nd[t1].mutId, false);
@@ -433,18 +438,33 @@ template <bool RV, bool U, bool SS> struct Search {
         const double *cs = cached;
         bool wantShorten = false;
         int hShorten = -1;
-        while (sp > 0 && !st[sp - 1].upd) {
-            const StackItem it = st[--sp];
+        // the item pushed last is popped next: it stays in registers (`top`), so that the only load a visit depends on
+        // is the node record itself
+        StackItem top;
+        bool haveTop = false;
+        auto push = [&](int t1, int dir, int fails, int hRpr, double lastLK) {
+            if (haveTop) st[sp++] = top;
+            top.t1 = t1; top.dir = (int8_t)dir; top.upd = 0; top.fails = (int16_t)fails; top.hPassed = -1; top.hRpr = hRpr;
+            top.distance = 0.0; top.lastLK = lastLK;
+            haveTop = true;
+        };
+        for (;;) {
+            StackItem it;
+            if (haveTop) { it = top; haveTop = false; }
+            else {
+                if (sp <= 0 || st[sp - 1].upd) break;
+                it = st[--sp];
+            }
             const int t1 = it.t1;
             const NodeRec r1 = nd[t1];
             const int upT = r1.up;
             int fails = it.fails;
             double midProb = it.lastLK;
-            const bool rootChild = upT >= 0 && nd[upT].up < 0;
+            const bool rootChild = r1.upIsRoot != 0;
             if (it.dir == 0) {
                 if (!(upT == node || upT < 0) && (r1.dist > eff || rootChild)) {
                     if (r1.totUp < 0) continue;
-                    midProb = cs[t1]; nApp++;
+                    midProb = cs[r1.preRank]; nApp++;
                     if (midProb > best - thrOpt) {
                         if (nB >= capB) { ws.overflow = true; break; }
                         br[nB++] = BestRec{t1, -1, -1, -1, it.hRpr, midProb, 0.0};
@@ -456,15 +476,15 @@ template <bool RV, bool U, bool SS> struct Search {
                 if (strict) go = fails <= allowed && midProb > (best - thrLK) && r1.c0 >= 0;
                 else go = (fails <= allowed || midProb > (best - thrLK)) && r1.c0 >= 0;
                 if (go) {
-                    if (sp + 2 > capS) { ws.overflow = true; break; }
-                    if (r1.upRight >= 0) { StackItem &o = st[sp++]; o.t1 = r1.c0; o.dir = 0; o.upd = 0; o.fails = (int16_t)fails; o.hPassed = -1; o.hRpr = it.hRpr; o.distance = 0.0; o.lastLK = midProb; }
-                    if (r1.upLeft >= 0) { StackItem &o = st[sp++]; o.t1 = r1.c1; o.dir = 0; o.upd = 0; o.fails = (int16_t)fails; o.hPassed = -1; o.hRpr = it.hRpr; o.distance = 0.0; o.lastLK = midProb; }
+                    if (sp + 3 > capS) { ws.overflow = true; break; }
+                    if (r1.upRight >= 0) push(r1.c0, 0, fails, it.hRpr, midProb);
+                    if (r1.upLeft >= 0) push(r1.c1, 0, fails, it.hRpr, midProb);
                 }
             } else {
                 const int other = (it.dir == 1) ? r1.c1 : r1.c0;
                 if (upT >= 0 && (r1.dist > eff || rootChild)) {
                     if (r1.totUp < 0) continue;
-                    midProb = cs[t1]; nApp++;
+                    midProb = cs[r1.preRank]; nApp++;
                     if (midProb >= (best - thrOpt)) {
                         if (nB >= capB) { ws.overflow = true; break; }
                         br[nB++] = BestRec{t1, -1, -1, -1, it.hRpr, midProb, 0.0};
@@ -476,17 +496,15 @@ template <bool RV, bool U, bool SS> struct Search {
                 if (strict) go = fails <= allowed && midProb > (best - thrLK);
                 else go = fails <= allowed || midProb > (best - thrLK);
                 if (!go) continue;
-                if (sp + 2 > capS) { ws.overflow = true; break; }
+                if (sp + 3 > capS) { ws.overflow = true; break; }
                 if (upT >= 0) {
                     if (((it.dir == 1) ? r1.upLeft : r1.upRight) < 0) continue;
-                    { StackItem &o = st[sp++]; o.t1 = other; o.dir = 0; o.upd = 0; o.fails = (int16_t)fails; o.hPassed = -1; o.hRpr = it.hRpr; o.distance = 0.0; o.lastLK = midProb; }
-                    const int upChild = (nd[upT].c0 == t1) ? 0 : 1;
-                    { StackItem &o = st[sp++]; o.t1 = upT; o.dir = (int8_t)(upChild + 1); o.upd = 0; o.fails = (int16_t)fails; o.hPassed = -1; o.hRpr = it.hRpr; o.distance = 0.0; o.lastLK = midProb; }
-                } else {
-                    StackItem &o = st[sp++]; o.t1 = other; o.dir = 0; o.upd = 0; o.fails = (int16_t)fails; o.hPassed = -1; o.hRpr = it.hRpr; o.distance = 0.0; o.lastLK = midProb;
-                }
+                    push(other, 0, fails, it.hRpr, midProb);
+                    push(upT, (int)r1.whichChild + 1, fails, it.hRpr, midProb);
+                } else push(other, 0, fails, it.hRpr, midProb);
             }
         }
+        if (haveTop) st[sp++] = top;
         ws.sp = sp; ws.nB = nB; nAppend = nApp; bestLKdiff = best;
         if (wantShorten) opShortenInPlace(hShorten);
     }
