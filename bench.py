@@ -310,9 +310,27 @@ def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, nodes, gpu_res, kw, cpu_s
                       "counts identical to the GPU's"}
 
 
+def usable_host_threads():
+    """Threads this process may really use: the scheduler affinity, capped by the cgroup CPU quota of the container."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs, cpu_seconds, t_out, mkw):
-    """The C oracle (a port of the reference's appendProbNode) timed on ONE host core on a bounded
-    sample of the same (query, candidate) pairs; also cross-checks the GPU scores."""
+    """The C oracle (a port of the reference's appendProbNode) timed on a bounded sample of the same (query, candidate)
+    pairs, on one host core and on all host threads; also cross-checks the GPU scores."""
     from oracle.oracle_py import Oracle
     orc = Oracle(ref_idx, root_freqs)
     orc.set_model(**mkw)
@@ -336,9 +354,24 @@ def cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs, cpu_seco
     both_inf = np.isinf(ref) & np.isinf(gpu)
     err = np.abs(ref - gpu) / np.maximum(1.0, np.abs(ref))
     err[both_inf] = 0.0
-    return {"value": reps * nq * Cn / dt, "unit": "placements/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} pass(es) over {nq} queries x {Cn} candidate branches = {reps * nq * Cn} pairs of the "
-                      f"same workload, C oracle (oracle/maple_oracle.c), {dt:.1f} s",
+    single = reps * nq * Cn / dt
+    # the same loop on every host thread (OpenMP over the independent pairs): all queries, repeated for ~2 s of wall time
+    threads = usable_host_threads()
+    pl_all = np.tile(pl1, len(q_lists))
+    cl_all = np.repeat(np.arange(Cn, Cn + len(q_lists), dtype=np.int32), Cn)
+    orc.appendProbNode_batch(packed, pl_all, cl_all, True, 1.0 / dev.lRef, threads=threads)          # spin the pool up
+    reps_mt = int(max(1, round(2.0 * single * threads / len(pl_all))))
+    t0 = time.perf_counter()
+    for _ in range(reps_mt):
+        ref_mt = orc.appendProbNode_batch(packed, pl_all, cl_all, True, 1.0 / dev.lRef, threads=threads)
+    dt_mt = time.perf_counter() - t0
+    same = bool(np.array_equal(ref_mt[: len(ref)], ref))
+    return {"value": reps_mt * len(pl_all) / dt_mt, "unit": "placements/s", "cores": threads, "kind": "port",
+            "sample": f"{reps_mt} pass(es) over all {len(q_lists)} queries x {Cn} candidate branches of the same workload, "
+                      f"C oracle (oracle/maple_oracle.c) with OpenMP over the pairs on {threads} host threads (scheduler affinity capped by the container's CPU quota), {dt_mt:.1f} s wall"
+                      f" ({dt_mt * threads:.0f} thread-seconds); identical to the scalar run: {same}",
+            "single_core": {"value": single, "cores": 1,
+                            "sample": f"{reps} pass(es) over {nq} queries = {reps * nq * Cn} pairs, {dt:.1f} s"},
             "max_rel_diff_vs_gpu": float(err.max())}
 
 

@@ -1045,6 +1045,21 @@ int omo_evaluatePlacement(const OModel *m, const OEntry *midTot, int nMid, const
 }
 
 /* ---- batch driver for timing the CPU baseline (bench.py cpu_baseline leg only) --------------------- */
+/* threads <= 1: the scalar loop; > 1: the same loop dealt to that many OpenMP threads (the pairs are independent and
+ * the model is read-only), which is how a CPU would run this workload on all of the host's cores */
+int omo_appendProbNode_batch_mt(const OModel *m, const OEntry *all, const long long *off, int n, const int *pl,
+                                const int *cl, const unsigned char *tip, const double *bl, double *out, int threads)
+{
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 2048)
+    for (int i = 0; i < n; i++) {
+        const OEntry *P = all + off[pl[i]], *C = all + off[cl[i]];
+        omo_appendProbNode(m, P, (int)(off[pl[i] + 1] - off[pl[i]]), C, (int)(off[cl[i] + 1] - off[cl[i]]), tip[i],
+                           bl[i], &out[i]);
+    }
+    return 0;
+}
+
 int omo_appendProbNode_batch(const OModel *m, const OEntry *all, const long long *off, int n, const int *pl,
                              const int *cl, const unsigned char *tip, const double *bl, double *out)
 {

@@ -128,6 +128,8 @@ int omo_sprWorker(const OModel *m, const OTree *t, const OSearchParams *p, int n
 /* batch driver (lists concatenated, off[] = CSR offsets by list index) used to time the CPU baseline */
 int   omo_appendProbNode_batch(const OModel *m, const OEntry *all, const long long *off, int n, const int *pl,
                                const int *cl, const unsigned char *tip, const double *bl, double *out);
+int omo_appendProbNode_batch_mt(const OModel *m, const OEntry *all, const long long *off, int n, const int *pl,
+                                const int *cl, const unsigned char *tip, const double *bl, double *out, int threads);
 
 #ifdef __cplusplus
 }

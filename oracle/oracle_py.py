@@ -405,7 +405,7 @@ class Oracle:
         np.cumsum([len(a) for a in arrs], out=off[1:])
         return np.concatenate(arrs), off
 
-    def appendProbNode_batch(self, packed, parent_idx, child_idx, isTipC, bLen):
+    def appendProbNode_batch(self, packed, parent_idx, child_idx, isTipC, bLen, threads=1):
         allent, off = packed
         pl = np.ascontiguousarray(parent_idx, dtype=np.int32)
         cl = np.ascontiguousarray(child_idx, dtype=np.int32)
@@ -413,7 +413,11 @@ class Oracle:
         tip = np.ascontiguousarray(np.broadcast_to(isTipC, n), dtype=np.uint8)
         bl = np.ascontiguousarray(np.broadcast_to(bLen, n), dtype=np.float64)
         out = np.zeros(n)
-        self.lib.omo_appendProbNode_batch(C.byref(self.m), _p(allent), _p(off), n, _p(pl), _p(cl), _p(tip), _p(bl), _p(out))
+        if threads > 1:
+            self.lib.omo_appendProbNode_batch_mt(C.byref(self.m), _p(allent), _p(off), n, _p(pl), _p(cl), _p(tip), _p(bl),
+                                                 _p(out), int(threads))
+        else:
+            self.lib.omo_appendProbNode_batch(C.byref(self.m), _p(allent), _p(off), n, _p(pl), _p(cl), _p(tip), _p(bl), _p(out))
         return out
 
     # ---- SPR search -----------------------------------------------------------------------------
