@@ -46,6 +46,7 @@ struct PlaceMeta {                     // derived from the uploaded tree, rebuil
     std::vector<int32_t> frameNode, frameParent;   // per frame (frame 0 = the root's reference, node -1)
     std::vector<int32_t> levelStart;               // frames 1.. sorted by nesting depth; level l = [levelStart[l], levelStart[l+1])
     std::vector<int32_t> cand, leaves;             // node ids
+    std::vector<int32_t> h_candIdx, h_leafIdx;     // per node: column in the score / minor matrix or -1
     DevBuf<int32_t> d_frameOf, d_candIdx, d_leafIdx, d_candList, d_candFrame, d_leafList, d_leafFrame;
 };
 
@@ -112,6 +113,7 @@ struct maple_ctx {
     // batched placement (maple_placement_search_batch)
     PlaceMeta *place = nullptr;
     std::vector<int32_t> h_tree_c0, h_tree_c1, h_tree_mut, h_tree_totUp, h_tree_upRight, h_tree_upLeft;
+    std::vector<NodeRec> h_nodes;      // host copy of the node records (host-side traversal of tiny placement batches)
     DevBuf<int32_t> p_i32[4];
     DevBuf<double> p_f64[2], p_score;
     DevBuf<int16_t> p_i16;
@@ -1469,6 +1471,7 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     HIPCK(c, c->t_nodes.reserve((size_t)n * sizeof(NodeRec) + 64));
     uint8_t *aligned = (uint8_t *)(((uintptr_t)c->t_nodes.p + 63) & ~(uintptr_t)63);
     HIPCK(c, hipMemcpy(aligned, recs.data(), (size_t)n * sizeof(NodeRec), hipMemcpyHostToDevice));
+    c->h_nodes = recs;
     DevTree &T = c->dtree;
     T.n = n; T.root = root;
     T.nd = (const NodeRec *)aligned;

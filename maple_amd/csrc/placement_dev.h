@@ -33,25 +33,20 @@ struct PlaceOut {
 
 // node columns: candIdx[v] = column of v in the score matrix or -1 (M:8049: dist > effectivelyNon0BLen, up != None);
 // leafIdx[v] = column of v in the minor-sequence matrix or -1; frameOf[v] = index of v's MAT reference frame.
-__global__ __launch_bounds__(64) void k_place_replay(DevTree T, PlaceParams P, int nQ, int nCols, int rootCol,
-                                                     const double *__restrict__ score, const int32_t *__restrict__ candIdx,
-                                                     int nLeaf, const uint8_t *__restrict__ minor,
-                                                     const int32_t *__restrict__ leafIdx, const int32_t *__restrict__ frameOf,
-                                                     int nF, int stackCap, int32_t *stNode, double *stLK, int16_t *stFails,
-                                                     uint32_t *frameBits, PlaceOut o)
+// The traversal of ONE query.  Lane q of nQ keeps element i of its stack / frame bits at [i * nQ + q] (coalesced when a
+// wavefront runs 64 queries; the host calls it with nQ = 1, q = 0 on plain arrays for very small batches, where one
+// lane's ~1 us per visit would dominate the call).
+__host__ __device__ inline void place_replay_one(const NodeRec *nd, int root, const PlaceParams &P, int q, int nQ,
+                                                 const double *sc, int rootCol, const int32_t *candIdx, const uint8_t *mn,
+                                                 const int32_t *leafIdx, const int32_t *frameOf, int nF, int stackCap,
+                                                 int32_t *stNode, double *stLK, int16_t *stFails, uint32_t *frameBits,
+                                                 const PlaceOut &o)
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nQ) return;
-    const NodeRec *nd = T.nd;
-    const double *sc = score + (long long)q * nCols;
-    const uint8_t *mn = minor + (long long)q * nLeaf;
-    // lane-interleaved workspace: element i of lane q lives at [i * nQ + q] so a wavefront's accesses coalesce
     const int words = (nF + 31) >> 5;
     for (int i = 0; i < words; i++) frameBits[(long long)i * nQ + q] = 0u;
     int32_t *slN = o.slNode + (long long)q * MAPLE_PLACE_SHORTLIST;
     double *slL = o.slLK + (long long)q * MAPLE_PLACE_SHORTLIST;
     int nSl = 0, status = 0, minorNode = -1, missed = 0, nAppend = 1;
-    const int root = T.root;
     const NodeRec rr = nd[root];
     double bestLK = sc[rootCol];
     const double originalLK = bestLK;
@@ -121,6 +116,19 @@ __global__ __launch_bounds__(64) void k_place_replay(DevTree T, PlaceParams P, i
     o.status[q] = status; o.minorNode[q] = minorNode; o.bestNode[q] = bestNode;
     o.bestLK[q] = bestLK; o.originalLK[q] = originalLK;
     o.nAppend[q] = nAppend; o.missed[q] = missed; o.nShort[q] = nSl;
+}
+
+__global__ __launch_bounds__(64) void k_place_replay(DevTree T, PlaceParams P, int nQ, int nCols, int rootCol,
+                                                     const double *__restrict__ score, const int32_t *__restrict__ candIdx,
+                                                     int nLeaf, const uint8_t *__restrict__ minor,
+                                                     const int32_t *__restrict__ leafIdx, const int32_t *__restrict__ frameOf,
+                                                     int nF, int stackCap, int32_t *stNode, double *stLK, int16_t *stFails,
+                                                     uint32_t *frameBits, PlaceOut o)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nQ) return;
+    place_replay_one(T.nd, T.root, P, q, nQ, score + (long long)q * nCols, rootCol, candIdx, minor + (long long)q * nLeaf,
+                     leafIdx, frameOf, nF, stackCap, stNode, stLK, stFails, frameBits, o);
 }
 
 }  // namespace maple

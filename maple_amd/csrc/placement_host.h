@@ -96,7 +96,10 @@ static int place_meta(maple_ctx *c, double effNon0)
     M.nF = nF;
     M.cand.clear();
     M.leaves.clear();
-    std::vector<int32_t> candIdx(n, -1), leafIdx(n, -1), candList, candFrame, leafList, leafFrame;
+    std::vector<int32_t> &candIdx = M.h_candIdx, &leafIdx = M.h_leafIdx;
+    candIdx.assign(n, -1);
+    leafIdx.assign(n, -1);
+    std::vector<int32_t> candList, candFrame, leafList, leafFrame;
     for (int32_t v : order)
         if (v != root && up[v] >= 0 && c->h_tree_dist[v] > effNon0 && totUp[v] >= 0) M.cand.push_back(v);      // M:8049
     // columns sorted by list length: the 64 lanes of a scoring wavefront then finish together
@@ -225,31 +228,65 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
             HIPCK(c, hipGetLastError());
         }
         const size_t SL = MAPLE_PLACE_SHORTLIST;
-        HIPCK(c, c->p_i32[1].reserve((size_t)nq * stackCap));             // stack nodes
-        HIPCK(c, c->p_f64[0].reserve((size_t)nq * stackCap));             // stack lastLK
-        HIPCK(c, c->p_i16.reserve((size_t)nq * stackCap));                // stack fails
-        HIPCK(c, c->p_i32[2].reserve((size_t)nq * words));                // frame bits
-        HIPCK(c, c->p_i32[3].reserve((size_t)nq * (6 + SL)));             // status, minorNode, bestNode, nAppend, missed, nShort, slNode
-        HIPCK(c, c->p_f64[1].reserve((size_t)nq * (2 + SL)));             // bestLK, originalLK, slLK
-        HIPCK(c, c->p_u8.reserve((size_t)nq * (1 + SL)));                 // bestShort, slShort
-        PlaceOut o;
-        int32_t *ib = c->p_i32[3].p;
-        o.status = ib; o.minorNode = ib + nq; o.bestNode = ib + 2 * (size_t)nq; o.nAppend = ib + 3 * (size_t)nq;
-        o.missed = ib + 4 * (size_t)nq; o.nShort = ib + 5 * (size_t)nq; o.slNode = ib + 6 * (size_t)nq;
-        double *fb = c->p_f64[1].p;
-        o.bestLK = fb; o.originalLK = fb + nq; o.slLK = fb + 2 * (size_t)nq;
-        o.bestShort = c->p_u8.p; o.slShort = c->p_u8.p + nq;
-        hipLaunchKernelGGL(k_place_replay, dim3((nq + 63) / 64), dim3(64), 0, c->stream, c->dtree, P, nq, nCols, nC, c->p_score.p,
-                           M.d_candIdx.p, std::max(nL, 1), c->p_minor.p, M.d_leafIdx.p, M.d_frameOf.p, nF, stackCap, c->p_i32[1].p,
-                           c->p_f64[0].p, c->p_i16.p, (uint32_t *)c->p_i32[2].p, o);
-        HIPCK(c, hipGetLastError());
         std::vector<int32_t> hi;
         std::vector<double> hf;
         std::vector<uint8_t> hb;
-        TRY(d2h_vec(c, hi, ib, (size_t)nq * (6 + SL)));
-        TRY(d2h_vec(c, hf, fb, (size_t)nq * (2 + SL)));
-        TRY(d2h_vec(c, hb, c->p_u8.p, (size_t)nq * (1 + SL)));
-        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (nq <= 4) {
+            // a handful of queries (the sequential placement loop hands over one at a time): one lane's ~1 us per visit
+            // would dominate the call, so the scores come back (8 bytes per branch) and the SAME traversal function
+            // runs on the host
+            std::vector<double> hs;
+            std::vector<uint8_t> hm;
+            TRY(d2h_vec(c, hs, c->p_score.p, (size_t)nq * nCols));
+            TRY(d2h_vec(c, hm, c->p_minor.p, (size_t)nq * std::max(nL, 1)));
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            hi.assign((size_t)nq * (6 + SL), 0);
+            hf.assign((size_t)nq * (2 + SL), 0.0);
+            hb.assign((size_t)nq * (1 + SL), 0);
+            PlaceOut o;
+            int32_t *ib = hi.data();
+            o.status = ib; o.minorNode = ib + nq; o.bestNode = ib + 2 * (size_t)nq; o.nAppend = ib + 3 * (size_t)nq;
+            o.missed = ib + 4 * (size_t)nq; o.nShort = ib + 5 * (size_t)nq; o.slNode = ib + 6 * (size_t)nq;
+            o.bestLK = hf.data(); o.originalLK = hf.data() + nq; o.slLK = hf.data() + 2 * (size_t)nq;
+            o.bestShort = hb.data(); o.slShort = hb.data() + nq;
+            std::vector<int32_t> stN(stackCap);
+            std::vector<double> stL(stackCap);
+            std::vector<int16_t> stF(stackCap);
+            std::vector<uint32_t> bits(words);
+            for (int q = 0; q < nq; q++) {
+                // per-query outputs are addressed [.. + q] inside, the work arrays as lane 0 of 1
+                PlaceOut oq = o;
+                oq.status += q; oq.minorNode += q; oq.bestNode += q; oq.nAppend += q; oq.missed += q; oq.nShort += q;
+                oq.bestLK += q; oq.originalLK += q; oq.bestShort += q;
+                oq.slNode += (size_t)q * SL; oq.slLK += (size_t)q * SL; oq.slShort += (size_t)q * SL;
+                place_replay_one(c->h_nodes.data(), root, P, 0, 1, hs.data() + (size_t)q * nCols, nC, M.h_candIdx.data(),
+                                 hm.data() + (size_t)q * std::max(nL, 1), M.h_leafIdx.data(), M.frameOf.data(), nF, stackCap,
+                                 stN.data(), stL.data(), stF.data(), bits.data(), oq);
+            }
+        } else {
+            HIPCK(c, c->p_i32[1].reserve((size_t)nq * stackCap));         // stack nodes
+            HIPCK(c, c->p_f64[0].reserve((size_t)nq * stackCap));         // stack lastLK
+            HIPCK(c, c->p_i16.reserve((size_t)nq * stackCap));            // stack fails
+            HIPCK(c, c->p_i32[2].reserve((size_t)nq * words));            // frame bits
+            HIPCK(c, c->p_i32[3].reserve((size_t)nq * (6 + SL)));         // status, minorNode, bestNode, nAppend, missed, nShort, slNode
+            HIPCK(c, c->p_f64[1].reserve((size_t)nq * (2 + SL)));         // bestLK, originalLK, slLK
+            HIPCK(c, c->p_u8.reserve((size_t)nq * (1 + SL)));             // bestShort, slShort
+            PlaceOut o;
+            int32_t *ib = c->p_i32[3].p;
+            o.status = ib; o.minorNode = ib + nq; o.bestNode = ib + 2 * (size_t)nq; o.nAppend = ib + 3 * (size_t)nq;
+            o.missed = ib + 4 * (size_t)nq; o.nShort = ib + 5 * (size_t)nq; o.slNode = ib + 6 * (size_t)nq;
+            double *fb = c->p_f64[1].p;
+            o.bestLK = fb; o.originalLK = fb + nq; o.slLK = fb + 2 * (size_t)nq;
+            o.bestShort = c->p_u8.p; o.slShort = c->p_u8.p + nq;
+            hipLaunchKernelGGL(k_place_replay, dim3((nq + 63) / 64), dim3(64), 0, c->stream, c->dtree, P, nq, nCols, nC, c->p_score.p,
+                               M.d_candIdx.p, std::max(nL, 1), c->p_minor.p, M.d_leafIdx.p, M.d_frameOf.p, nF, stackCap,
+                               c->p_i32[1].p, c->p_f64[0].p, c->p_i16.p, (uint32_t *)c->p_i32[2].p, o);
+            HIPCK(c, hipGetLastError());
+            TRY(d2h_vec(c, hi, ib, (size_t)nq * (6 + SL)));
+            TRY(d2h_vec(c, hf, fb, (size_t)nq * (2 + SL)));
+            TRY(d2h_vec(c, hb, c->p_u8.p, (size_t)nq * (1 + SL)));
+            HIPCK(c, hipStreamSynchronize(c->stream));
+        }
         const int32_t *hStatus = hi.data(), *hMinor = hi.data() + nq, *hBest = hi.data() + 2 * (size_t)nq,
                       *hNApp = hi.data() + 3 * (size_t)nq, *hNShort = hi.data() + 5 * (size_t)nq,
                       *hSlNode = hi.data() + 6 * (size_t)nq;

@@ -142,8 +142,18 @@ class PlacementSearcher:
             dev.release(mark)
 
     def find_best_parent_for_new_sample(self, diffs, sample=None):
-        """Returns (bestNode, bestScore, bestBranchLengths, bestDiffs, info); the first four as the reference."""
-        dev, t, p = self.dev, self.tree, self.p
+        """Returns (bestNode, bestScore, bestBranchLengths, bestDiffs, info); the first four as the reference.
+        On one GPU this is one native call (maple_placement_search_batch with a single query: scoring on the GPU, the
+        traversal on the host for so small a batch); with the candidates sharded over several GPUs (world > 1) the
+        traversal is the Python replay below, after the all-gather of the score shards."""
+        if self.world == 1:
+            return self.find_best_parent_batch([diffs])[0]
+        return self.find_best_parent_host_replay(diffs, sample)
+
+    def find_best_parent_host_replay(self, diffs, sample=None):
+        """The same search with the reference's traversal replayed in Python over the all-branch scores (the form the
+        multi-GPU candidate sharding uses; also an independent implementation for the tests)."""
+        dev = self.dev
         mark = dev.mark()
         try:
             return self._search(diffs, sample)

@@ -183,7 +183,7 @@ def test_batched_placement_equals_single_query_search(world):
     batch = ps.find_best_parent_batch(queries)
     n_minor = 0
     for q, got in zip(queries, batch):
-        want = ps.find_best_parent_for_new_sample(q)
+        want = ps.find_best_parent_host_replay(q)
         assert got[0] == want[0] and got[1] == want[1], (got[:2], want[:2])
         assert got[4]["minor"] == want[4]["minor"] and got[4]["n_append"] == want[4]["n_append"]
         if want[2] is None:

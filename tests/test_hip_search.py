@@ -98,8 +98,10 @@ def test_nodes_not_searched(env):
     assert (out["placement"] == -1).all()
 
 
-def test_placement_search_matches_reference(env):
-    """a12: findBestParentForNewSample on the frozen tree for 60 new samples."""
+@pytest.mark.parametrize("path", ["native", "host_replay"])
+def test_placement_search_matches_reference(env, path):
+    """a12: findBestParentForNewSample on the frozen tree for 60 new samples, one query per call: the native call
+    (GPU scoring + the traversal function on the host) and the Python replay over the same all-branch scores."""
     from maple_amd.search import PlacementParams, PlacementSearcher
     f, dev, tree = env
     ctx = f["context"]
@@ -112,8 +114,9 @@ def test_placement_search_matches_reference(env):
         thresholdLogLKconsecutivePlacement=ctx["thresholdLogLKconsecutivePlacement"],
         allowedFails=ctx["allowedFails"], strictStopRules=ctx["strictStopRules"], onlyFindIdentical=only_identical))
     n_real = 0
+    search = ps.find_best_parent_for_new_sample if path == "native" else ps.find_best_parent_host_replay
     for rec in f["placements"]:
-        node, score, blens, best_diffs, info = ps.find_best_parent_for_new_sample(tup(rec["query"]))
+        node, score, blens, best_diffs, info = search(tup(rec["query"]))
         want = rec["ret"]
         assert node == want["bestNode"], (node, want["bestNode"])
         assert close(score, want["bestScore"], 1e-9), (score, want["bestScore"])

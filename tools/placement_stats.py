@@ -26,13 +26,13 @@ ps = PlacementSearcher(dev, ht, PlacementParams(oneMutBLen=1.0 / l_ref, effectiv
                                                   thresholdLogLKconsecutivePlacement=1.0))
 prng = np.random.default_rng(11)
 queries = [tip_genome_list(perturb_diffs(dl, data.ref, prng), ref_idx) for dl in data.diffs[:nq]]   # not in the tree
-ps.find_best_parent_for_new_sample(queries[0])
+ps.find_best_parent_host_replay(queries[0])
 t0 = time.perf_counter(); tot = 0; scored = 0
 for q in queries:
-    node, score, bl, diffs, info = ps.find_best_parent_for_new_sample(q)
+    node, score, bl, diffs, info = ps.find_best_parent_host_replay(q)
     tot += info["n_append"]; scored += info.get("candidates_scored", 0)
 dt = time.perf_counter() - t0
-print(f"{nq} placement searches on a {n + nq}-tip tree: {dt / nq * 1e3:.2f} ms/query, {nq / dt:.0f} queries/s; "
+print(f"Python replay: {nq} placement searches on a {n + nq}-tip tree: {dt / nq * 1e3:.2f} ms/query, {nq / dt:.0f} queries/s; "
       f"reference-equivalent placements {tot} ({tot / dt:.3g}/s), branches scored {scored} ({scored / dt:.3g}/s)")
 # the same queries as ONE native batch (maple_placement_search_batch): device-side traversal, one lane per query
 for reps in (1, 8):
@@ -45,6 +45,13 @@ for reps in (1, 8):
     print(f"batched: {len(qs)} queries in {dt * 1e3:.1f} ms = {len(qs) / dt:.0f} queries/s "
           f"(reference-equivalent placements {tot_b / dt:.3g}/s, branches scored {len(qs) * (len(ps.cand) + 1) / dt:.3g}/s)")
     if reps == 1:
-        single = [ps.find_best_parent_for_new_sample(q) for q in queries[:50]]
+        single = [ps.find_best_parent_host_replay(q) for q in queries[:50]]
         assert all(a[0] == b[0] and a[1] == b[1] and a[4]["n_append"] == b[4]["n_append"] for a, b in zip(single, res[:50]))
         print("batched == single-query results on the first 50 queries")
+# one query per native call (the sequential placement loop's shape)
+ps.find_best_parent_batch(queries[:1])
+t0 = time.perf_counter()
+for q in queries[:100]:
+    ps.find_best_parent_batch([q])
+dt = time.perf_counter() - t0
+print(f"native call per query: {dt / 100 * 1e3:.2f} ms/query")
