@@ -222,6 +222,34 @@ def main():
                      "reference_equivalent_placements_per_s": float(pres["nAppend"].sum() / pwall),
                      "branches_scored_per_s": float(Q * (Cn + 1) / pwall),
                      "minor_sequences": int((pres["status"] == 1).sum()), "failed": int((pres["status"] < 0).sum())}
+        # ---- the same deep round on the same tree after giving it MAT local references (setUpMAT's rule, 50 descendants
+        # per reference node, M:166 / 6152-6164): the form real MAPLE trees have; lists are shorter, every search crosses
+        # reference frames ----
+        from maple_amd.mat import add_local_references
+        from maple_amd.tree_host import HostTree
+        ht = HostTree.from_mirror(mirror)
+        t0 = time.perf_counter()
+        n_ref = add_local_references(dev, ht, 50)
+        mat_s = time.perf_counter() - t0
+        dev.upload_tree(ht.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist, mirror.is_tip,
+                        ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp, ht.id_mut)
+        dev.spr_search_batch(my_nodes, **kw)
+        dev.timing_reset()
+        t0 = time.perf_counter()
+        res_m = dev.spr_search_batch(my_nodes, **kw)
+        wall_m = time.perf_counter() - t0
+        n_lm, k_ms_m = dev.timing_read()
+        spr_mat = {"reference_nodes": int(n_ref), "setup_s": round(mat_s, 2), "queries": int(len(my_nodes)),
+                   "candidate_placements": int(res_m["nAppend"].sum()), "failed_or_overflow": int((res_m["status"] < 0).sum()),
+                   "proposed_moves": int((res_m["placement"] >= 0).sum()), "kernel_ms": k_ms_m, "launches": n_lm,
+                   "wall_ms": 1e3 * wall_m, "placements_per_s_kernel": float(res_m["nAppend"].sum() / (k_ms_m * 1e-3)),
+                   "placements_per_s_wall": float(res_m["nAppend"].sum() / wall_m),
+                   "same_moves_as_without_local_references": bool(np.array_equal(res_m["placement"], res["placement"])
+                                                                  and np.array_equal(res_m["nAppend"], res["nAppend"]))}
+        # back to the tree the rest of the run refers to
+        dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist,
+                        mirror.is_tip, mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up,
+                        -np.ones(mirror.n_nodes, dtype=np.int32))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             spr["cpu_baseline"] = spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, my_nodes, res, kw, args.cpu_seconds, mkw)
 
@@ -262,6 +290,7 @@ def main():
         }
         if spr is not None:
             out["spr_search"] = spr
+            out["spr_search_local_refs"] = spr_mat
             out["placement_batch"] = placement
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs,

@@ -46,6 +46,7 @@ struct PlaceMeta {                     // derived from the uploaded tree, rebuil
     std::vector<int32_t> frameNode, frameParent;   // per frame (frame 0 = the root's reference, node -1)
     std::vector<int32_t> levelStart;               // frames 1.. sorted by nesting depth; level l = [levelStart[l], levelStart[l+1])
     std::vector<int32_t> cand, leaves;             // node ids
+    std::vector<int32_t> order;                    // nodes reachable from the root, depth-first
     std::vector<int32_t> h_candIdx, h_leafIdx;     // per node: column in the score / minor matrix or -1
     DevBuf<int32_t> d_frameOf, d_candIdx, d_leafIdx, d_candList, d_candFrame, d_leafList, d_leafFrame;
 };
@@ -102,7 +103,7 @@ struct maple_ctx {
     std::vector<uint8_t> h_tree_tip;
     bool tree_has_mut = false;
     int32_t n_scored = 0;              // nodes with a probVectTotUp, sorted by list length: t_i32[8] = list ids, t_scored_col = node ids
-    DevBuf<int32_t> t_scored_col;
+    DevBuf<int32_t> t_scored_col, t_scored_frame;
     // SPR search workspace
     DevBuf<uint8_t> s_search_ws;
     DevBuf<uint8_t> s_search_out;
@@ -485,7 +486,8 @@ __global__ __launch_bounds__(64) void k_spr_search(const DevModel *__restrict__ 
                                                    int32_t *counter, SearchOut *out, uint2 *poolW, double *poolA,
                                                    unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
                                                    int traceQuery, int32_t *trI, double *trD, int trCap, int32_t *trN,
-                                                   int activeLanes, const double *cacheS, int budget)
+                                                   int activeLanes, const double *cacheS, int budget, const int32_t *rTable, int nF,
+                                                   const int32_t *cacheRow)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(64) void k_spr_search(const DevModel *__restrict__ 
             if (q >= n) break;
             node = nodes[q];
             ws.usedW = ws.usedA = ws.nH = ws.sp = ws.nB = 0;
-            ws.overflow = false;
+            ws.overflow = 0;
             S.nAppend = 0;
             SearchOut &o = out[q];
             o.bestNode = -1; o.placement = -1; o.status = 0; o.nAppend = 0;
@@ -531,7 +533,9 @@ __global__ __launch_bounds__(64) void k_spr_search(const DevModel *__restrict__ 
             o.currentLK = curLK;
             if (!(curLK < P.thrPlacement || T.nd[node].dist != 0.0)) { o.status = 2; continue; }   // M:9674
             ws.usedW = ws.usedA = ws.nH = 0;
-            S.cached = cacheS ? cacheS + (size_t)q * T.n : nullptr;       // row q of the (queries x nodes) score table
+            const size_t row = cacheRow ? (size_t)cacheRow[q] : (size_t)q;
+            S.cached = cacheS ? cacheS + row * T.n : nullptr;             // this query's row of the (queries x nodes) score table
+            S.rTable = (cacheS && rTable) ? rTable + row * nF : nullptr;  // and of the (queries x frames) removed lists
             S.budget = budget;
             S.overBudget = false;
             S.trI = nullptr;
@@ -540,6 +544,7 @@ __global__ __launch_bounds__(64) void k_spr_search(const DevModel *__restrict__ 
             active = true;
         } else if (ws.overflow) {
             out[q].status = -3;                                       // workspace exhausted: the host retries with more
+            out[q].nAppend = ws.overflow;                             // (which capacity, for MAPLE_DEBUG)
             active = false;
         } else if (S.overBudget) {
             out[q].status = -5;                                       // a wide search: the host batch-scores it and re-runs it
@@ -715,7 +720,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     for (auto &b : c->s_i64) b.release();
     c->s_words.release(); c->s_aux.release(); c->s_ais.release();
     for (auto &b : c->t_i32) b.release();
-    c->t_dist.release(); c->t_tip.release(); c->t_nodes.release(); c->t_scored_col.release();
+    c->t_dist.release(); c->t_tip.release(); c->t_nodes.release(); c->t_scored_col.release(); c->t_scored_frame.release();
     if (c->d_tile_counters) (void)hipFree(c->d_tile_counters);
     c->s_search_ws.release(); c->s_search_out.release(); c->s_counter.release(); c->s_cache.release();
     for (auto &b : c->p_i32) b.release();
@@ -1422,12 +1427,70 @@ extern "C" int maple_append_queries_dev(maple_ctx *c, int32_t nQ, const int32_t 
                                  nC, nullptr, nullptr, nullptr);
 }
 
+#include "placement_host.h"
+
+// MAT reference frames of the uploaded tree: frame 0 is the root's reference, every node whose branch carries mutations
+// opens a new one for its clade.  Frames are numbered by nesting depth (a parent frame always has a smaller index).
+static int compute_frames(maple_ctx *c)
+{
+    PlaceMeta &M = *c->place;
+    const int32_t n = c->dtree.n, root = c->dtree.root;
+    const auto &up = c->h_tree_up;
+    const auto &c0 = c->h_tree_c0, &c1 = c->h_tree_c1, &mut = c->h_tree_mut;
+    std::vector<int32_t> &order = M.order;
+    std::vector<int32_t> depth(n, 0), fdepth;
+    order.clear();
+    order.reserve(n);
+    std::vector<int32_t> st{root};
+    M.frameOf.assign(n, -1);
+    M.frameNode.assign(1, -1);
+    M.frameParent.assign(1, -1);
+    fdepth.assign(1, 0);
+    M.maxDepth = 0;
+    while (!st.empty()) {
+        const int32_t v = st.back();
+        st.pop_back();
+        order.push_back(v);
+        const int32_t pf = up[v] < 0 || v == root ? 0 : M.frameOf[up[v]];
+        if (v != root) depth[v] = depth[up[v]] + 1;
+        if (depth[v] > M.maxDepth) M.maxDepth = depth[v];
+        if (mut[v] >= 0) {
+            M.frameOf[v] = (int32_t)M.frameNode.size();
+            M.frameNode.push_back(v);
+            M.frameParent.push_back(pf);
+            fdepth.push_back(fdepth[pf] + 1);
+        } else M.frameOf[v] = pf;
+        if (c0[v] >= 0) { st.push_back(c0[v]); st.push_back(c1[v]); }
+    }
+    // renumber frames by nesting depth so that a level is a contiguous range (parents always in earlier levels)
+    const int32_t nF = (int32_t)M.frameNode.size();
+    std::vector<int32_t> perm(nF), inv(nF);
+    for (int i = 0; i < nF; i++) perm[i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return fdepth[a] < fdepth[b]; });
+    for (int i = 0; i < nF; i++) inv[perm[i]] = i;
+    std::vector<int32_t> fn(nF), fp(nF);
+    M.levelStart.clear();
+    for (int i = 0; i < nF; i++) {
+        fn[i] = M.frameNode[perm[i]];
+        fp[i] = M.frameParent[perm[i]] < 0 ? -1 : inv[M.frameParent[perm[i]]];
+        if (i > 0 && fdepth[perm[i]] != fdepth[perm[i - 1]]) M.levelStart.push_back(i);
+    }
+    M.levelStart.push_back(nF);
+    M.frameNode.swap(fn);
+    M.frameParent.swap(fp);
+    for (auto &f : M.frameOf) if (f >= 0) f = inv[f];
+    M.nF = nF;
+    for (auto &f : M.frameOf) if (f < 0) f = 0;                           // nodes not reachable from the root
+    return MAPLE_OK;
+}
+
 // ---- tree mirror + SPR search ------------------------------------------------------------------------
 extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const int32_t *up, const int32_t *child0,
                                  const int32_t *child1, const double *dist, const uint8_t *isTip, const int32_t *lower,
                                  const int32_t *upRight, const int32_t *upLeft, const int32_t *totUp, const int32_t *mutList)
 {
-    if (!c || n <= 0 || !up || !child0 || !child1 || !dist || !isTip || !lower || !upRight || !upLeft || !totUp || !mutList)
+    if (!c || n <= 0 || root < 0 || root >= n || !up || !child0 || !child1 || !dist || !isTip || !lower || !upRight || !upLeft
+        || !totUp || !mutList)
         return MAPLE_ERR_ARG;
     HIPCK(c, hipSetDevice(c->device));
     TRY(check_ids(c, n, lower, true, "lower"));
@@ -1442,6 +1505,21 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     TRY(h2d(c, c->t_dist, dist, (size_t)n));
     TRY(h2d(c, c->t_tip, isTip, (size_t)n));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    c->h_tree_up.assign(up, up + n);
+    c->h_tree_lower.assign(lower, lower + n);
+    c->h_tree_dist.assign(dist, dist + n);
+    c->h_tree_tip.assign(isTip, isTip + n);
+    c->h_tree_c0.assign(child0, child0 + n);
+    c->h_tree_c1.assign(child1, child1 + n);
+    c->h_tree_mut.assign(mutList, mutList + n);
+    c->h_tree_totUp.assign(totUp, totUp + n);
+    c->h_tree_upRight.assign(upRight, upRight + n);
+    c->h_tree_upLeft.assign(upLeft, upLeft + n);
+    if (!c->place) c->place = new PlaceMeta();
+    c->place->valid = false;
+    c->dtree.n = n; c->dtree.root = root;
+    TRY(compute_frames(c));
+    const PlaceMeta &F = *c->place;
     std::vector<NodeRec> recs((size_t)n);
     for (int i = 0; i < n; i++) {
         NodeRec &r = recs[i];
@@ -1452,6 +1530,10 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         r.upIsRoot = (up[i] >= 0 && up[up[i]] < 0) ? 1 : 0;
         r.whichChild = (up[i] >= 0 && child1[up[i]] == i) ? 1 : 0;
         r.preRank = i;
+        r.frameOf = F.frameOf[i];
+        r.c0Frame = child0[i] >= 0 ? F.frameOf[child0[i]] : r.frameOf;
+        r.c1Frame = child1[i] >= 0 ? F.frameOf[child1[i]] : r.frameOf;
+        r.upFrame = up[i] >= 0 ? F.frameOf[up[i]] : r.frameOf;
     }
     {   // depth-first ranks in the order the searches descend (the child pushed last, child 1, is visited first)
         std::vector<int32_t> st;
@@ -1476,29 +1558,18 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     T.n = n; T.root = root;
     T.nd = (const NodeRec *)aligned;
     T.totUp = c->t_i32[6].p;
-    c->h_tree_up.assign(up, up + n);
-    c->h_tree_lower.assign(lower, lower + n);
-    c->h_tree_dist.assign(dist, dist + n);
-    c->h_tree_tip.assign(isTip, isTip + n);
-    c->h_tree_c0.assign(child0, child0 + n);
-    c->h_tree_c1.assign(child1, child1 + n);
-    c->h_tree_mut.assign(mutList, mutList + n);
-    c->h_tree_totUp.assign(totUp, totUp + n);
-    c->h_tree_upRight.assign(upRight, upRight + n);
-    c->h_tree_upLeft.assign(upLeft, upLeft + n);
-    if (!c->place) c->place = new PlaceMeta();
-    c->place->valid = false;
     c->tree_has_mut = false;
     for (int i = 0; i < n; i++) if (mutList[i] >= 0) c->tree_has_mut = true;
     {   // the batch-scoring kernel wants its candidates sorted by list length (uniform wavefronts)
         std::vector<int32_t> col;
         for (int i = 0; i < n; i++) if (totUp[i] >= 0) col.push_back(i);
         std::stable_sort(col.begin(), col.end(), [&](int a, int b) { return c->h_n_ent[totUp[a]] < c->h_n_ent[totUp[b]]; });
-        std::vector<int32_t> ids(col.size()), rank(col.size());
-        for (size_t i = 0; i < col.size(); i++) { ids[i] = totUp[col[i]]; rank[i] = recs[col[i]].preRank; }
+        std::vector<int32_t> ids(col.size()), rank(col.size()), fr(col.size());
+        for (size_t i = 0; i < col.size(); i++) { ids[i] = totUp[col[i]]; rank[i] = recs[col[i]].preRank; fr[i] = recs[col[i]].frameOf; }
         c->n_scored = (int32_t)col.size();
         TRY(h2d(c, c->t_i32[8], ids.data(), ids.size()));
         TRY(h2d(c, c->t_scored_col, rank.data(), rank.size()));
+        TRY(h2d(c, c->t_scored_frame, fr.data(), fr.size()));
         HIPCK(c, hipStreamSynchronize(c->stream));
     }
     c->tree_set = true;
@@ -1548,8 +1619,11 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     const int capW0 = ws_entries_per_lane > 0 ? ws_entries_per_lane : 16384;
     // Runs the searches `todo` (results into ho[slot[]]).  Queries whose per-lane workspace overflowed (status -3) are
     // re-run with 8x the workspace, twice at most.  cacheS (optional) = row-major (|todo| x T.n) cached scores.
-    auto run_queries = [&](std::vector<int32_t> todo, std::vector<int32_t> slot, const double *cacheS, int budgetNow) -> int {
-        int capW = capW0;
+    auto run_queries = [&](std::vector<int32_t> todo, std::vector<int32_t> slot, const double *cacheS, int budgetNow,
+                           const int32_t *rTable, int nF) -> int {
+        int capW = cacheS ? 4 * capW0 : capW0;                          // the few cached (whole-tree) searches get room up front
+        std::vector<int32_t> rows(todo.size());                        // row of each query in the cache / frame tables
+        for (size_t k = 0; k < rows.size(); k++) rows[k] = (int32_t)k;
         for (int attempt = 0; attempt < 3 && !todo.empty(); attempt++, capW *= 8) {
             const int m = (int)todo.size();
             WsLayout L;
@@ -1557,7 +1631,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             L.capA = 3 * L.capW;
             L.capH = L.capW / 8 + 256;
             L.capS = 1024 * (attempt + 1);
-            L.capB = 1024 * (attempt + 1);
+            L.capB = (cacheS ? 4096 : 1024) * (attempt + 1);             // whole-tree (cached) searches short-list far more branches
             L.capAis = 8192 * (attempt + 1);
             LaneBytes LB = lane_bytes(L);
             // lanes: one query per lane while they last; at most 2 wavefronts per SIMD (the kernel's occupancy) and a
@@ -1575,6 +1649,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             HIPCK(c, c->s_search_ws.reserve((size_t)lanes * LB.total));
             HIPCK(c, hipMemsetAsync(c->s_counter.p, 0, sizeof(int32_t), c->stream));
             TRY(h2d(c, c->s_i32[0], todo.data(), (size_t)m));
+            if (cacheS) TRY(h2d(c, c->s_i32[1], rows.data(), (size_t)m));
             HIPCK(c, c->s_search_out.reserve((size_t)m * sizeof(SearchOut)));
             SearchOut *dout = (SearchOut *)c->s_search_out.p;
             hipEvent_t e0, e1;
@@ -1585,20 +1660,25 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                                                                          poolA, poolUsed, poolCapW, poolCapA,
                                                                          attempt == 0 ? c->trace_query : -1, c->s_trace_i.p,
                                                                          c->s_trace_d.p, 4096, c->s_trace_i.p ? c->s_trace_i.p + 4 * 4096 : nullptr,
-                                                                         activeLanes, cacheS, budgetNow));
+                                                                         activeLanes, cacheS, budgetNow, rTable, nF,
+                                                                         cacheS ? c->s_i32[1].p : nullptr));
             HIPCK(c, hipGetLastError());
             HIPCK(c, hipEventRecord(e1, c->stream));
             std::vector<SearchOut> part(m);
             HIPCK(c, hipMemcpyAsync(part.data(), dout, (size_t)m * sizeof(SearchOut), hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
-            std::vector<int32_t> todo2, slot2;
+            std::vector<int32_t> todo2, slot2, rows2;
             for (int k = 0; k < m; k++) {
                 ho[slot[k]] = part[k];
-                if (part[k].status == -3 && attempt < 2) { todo2.push_back(todo[k]); slot2.push_back(slot[k]); }
+                if (part[k].status == -3 && attempt < 2) {
+                    todo2.push_back(todo[k]); slot2.push_back(slot[k]); rows2.push_back(rows[k]);
+                    if (getenv("MAPLE_DEBUG")) fprintf(stderr, "[maple]   node %d ran out of workspace (capacity kind %d)\n", todo[k], part[k].nAppend);
+                }
             }
+            if (getenv("MAPLE_DEBUG")) fprintf(stderr, "[maple] search launch: %d queries, %zu retried with more workspace\n", m, todo2.size());
             todo.swap(todo2);
             slot.swap(slot2);
-            cacheS = nullptr;                                          // rows no longer line up: retries run uncached
+            rows.swap(rows2);
             budgetNow = 0;
         }
         return MAPLE_OK;
@@ -1608,17 +1688,33 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // kernel (k_append_queries) and the state machine then only replays the traversal over the cached scores.
     // Only for trees without MAT local references for now (one frame: the removed list is the same everywhere).
     int wideBudget = sp->wideSearchBudget == 0 ? 256 : sp->wideSearchBudget;
-    const bool hybrid = wideBudget > 0 && !c->tree_has_mut;
-    TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0));
+    const bool hybrid = wideBudget > 0;
+    TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
     if (hybrid) {
         std::vector<int32_t> wide;
         for (int i = 0; i < n; i++) if (ho[i].status == -5) wide.push_back(i);
-        const int nT = c->dtree.n;
+        const PlaceMeta &F = *c->place;
+        const int nT = c->dtree.n, nF = c->tree_has_mut ? F.nF : 1;
         const size_t rowBytes = (size_t)nT * sizeof(double);
         size_t chunk = (size_t)(4ull << 30) / rowBytes;
         if (chunk < 1) chunk = 1;
-        for (size_t w0 = 0; w0 < wide.size(); w0 += chunk) {
-            const int m = (int)std::min(chunk, wide.size() - w0);
+        size_t w0 = 0;
+        while (w0 < wide.size()) {
+            int m = (int)std::min(chunk, wide.size() - w0);
+            if (nF > 1) {
+                // the removed list goes into EVERY reference frame: bound the batch by what the arena can take
+                const int64_t freeEnt = (c->cap_ent - c->used_ent) / 3, freeAux = (c->cap_aux - c->used_aux) / 3;
+                int64_t needEnt = 0, needAux = 0;
+                int k = 0;
+                for (; k < m; k++) {
+                    const int32_t l = c->h_tree_lower[nodes[wide[w0 + k]]];
+                    needEnt += (int64_t)nF * (c->h_n_ent[l] + 24);
+                    needAux += (int64_t)nF * (c->h_n_aux[l] + 8);
+                    if (needEnt > freeEnt || needAux > freeAux) break;
+                }
+                if (k == 0) return fail(c, MAPLE_ERR_NOMEM, "arena too small for the per-frame lists of one wide search");
+                m = k;
+            }
             std::vector<int32_t> qn(m), ql(m), sl(m);
             std::vector<uint8_t> qt(m);
             std::vector<double> qb(m);
@@ -1630,12 +1726,64 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 qb[k] = c->h_tree_dist[node];                          // removedBLen = dist[node] (M:9644)
             }
             HIPCK(c, c->s_cache.reserve((size_t)m * nT));
-            TRY(h2d(c, c->s_i32[6], ql.data(), (size_t)m));
             TRY(h2d(c, c->s_u8[3], qt.data(), (size_t)m));
             TRY(h2d(c, c->s_f64[3], qb.data(), (size_t)m));
-            TRY(launch_append_queries(c, c->stream, m, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, 0, 0.0, c->s_cache.p, nT,
-                                      c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p));
-            TRY(run_queries(qn, sl, c->s_cache.p, 0));
+            if (nF == 1) {
+                TRY(h2d(c, c->s_i32[6], ql.data(), (size_t)m));
+                TRY(launch_append_queries(c, c->stream, m, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, 0, 0.0, c->s_cache.p, nT,
+                                          c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p));
+                TRY(run_queries(qn, sl, c->s_cache.p, 0, nullptr, 0));
+            } else {
+                // the removed list in every MAT reference frame, along the paths the traversal itself takes
+                // (passGenomeListThroughBranch up the chain of enclosing frames, M:6844-6847 / 7392, then down into every
+                // other frame from the nearest frame already known, M:7119 / 7342)
+                int64_t mark = 0;
+                TRY(maple_arena_mark(c, &mark));
+                std::vector<int32_t> R((size_t)m * nF, -1), cur(m), src, ml, out;
+                std::vector<uint8_t> dir;
+                for (int k = 0; k < m; k++) { cur[k] = F.frameOf[qn[k]]; R[(size_t)k * nF + cur[k]] = ql[k]; }
+                for (;;) {                                             // up, one enclosing frame per round
+                    src.clear(); ml.clear();
+                    std::vector<int> who;
+                    for (int k = 0; k < m; k++)
+                        if (cur[k] != 0) { who.push_back(k); src.push_back(R[(size_t)k * nF + cur[k]]); ml.push_back(c->h_tree_mut[F.frameNode[cur[k]]]); }
+                    if (who.empty()) break;
+                    dir.assign(who.size(), 1);
+                    out.resize(who.size());
+                    TRY(maple_pass_branch_batch(c, (int32_t)who.size(), src.data(), ml.data(), dir.data(), out.data()));
+                    for (size_t i = 0; i < who.size(); i++) {
+                        const int k = who[i];
+                        cur[k] = F.frameParent[cur[k]];
+                        R[(size_t)k * nF + cur[k]] = out[i];
+                    }
+                }
+                int a = 1;
+                for (size_t l = 0; l < F.levelStart.size(); l++) {     // down, one nesting level per round
+                    const int b = F.levelStart[l];
+                    src.clear(); ml.clear();
+                    std::vector<size_t> where;
+                    for (int k = 0; k < m; k++)
+                        for (int f = a; f < b; f++)
+                            if (R[(size_t)k * nF + f] < 0) {
+                                where.push_back((size_t)k * nF + f);
+                                src.push_back(R[(size_t)k * nF + F.frameParent[f]]);
+                                ml.push_back(c->h_tree_mut[F.frameNode[f]]);
+                            }
+                    if (!where.empty()) {
+                        dir.assign(where.size(), 0);
+                        out.resize(where.size());
+                        TRY(maple_pass_branch_batch(c, (int32_t)where.size(), src.data(), ml.data(), dir.data(), out.data()));
+                        for (size_t i = 0; i < where.size(); i++) R[where[i]] = out[i];
+                    }
+                    a = b;
+                }
+                TRY(h2d(c, c->s_i32[6], R.data(), R.size()));
+                TRY(launch_place_score(c, m, nF, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, c->t_scored_frame.p, 0, 0.0,
+                                       c->s_cache.p, nT, c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p));
+                TRY(run_queries(qn, sl, c->s_cache.p, 0, c->s_i32[6].p, nF));
+                TRY(maple_arena_release(c, mark));
+            }
+            w0 += (size_t)m;
         }
     }
     for (int i = 0; i < n; i++) {
@@ -1663,8 +1811,6 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
 // counter is only calibrated for 16 B/lane coalesced streams).  Every lane walks its own contiguous 512-byte "list"
 // with dependent 8-byte loads, exactly like a genome-list walk, over a buffer far larger than the 256 MiB Infinity
 // Cache; the byte count is known, so FETCH_SIZE / bytes is the correction factor for k_append*.
-#include "placement_host.h"
-
 __global__ __launch_bounds__(MAPLE_BLOCK) void k_calib_walk(const unsigned long long *buf, long long nLists, unsigned long long *sink)
 {
     unsigned long long acc = 0;

@@ -11,7 +11,8 @@
 template <bool RV, bool U, bool SS>
 __global__ MAPLE_APPEND_ATTR void k_place_score(const DevModel *__restrict__ mp, ArenaView av, int nQ, int nF,
                                                 const int32_t *qFrameLists, int nC, const int32_t *cand,
-                                                const int32_t *candFrame, double bLen, double *out, int *counter)
+                                                const int32_t *candFrame, int isTip, double bLen, double *out, long long ldOut,
+                                                const int32_t *outCol, const uint8_t *qTip, const double *qBLen, int *counter)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
@@ -28,10 +29,35 @@ __global__ MAPLE_APPEND_ATTR void k_place_score(const DevModel *__restrict__ mp,
         const int ch = j / nQ;
         const int q = j - ch * nQ;
         const int k = ch * 64 + lane;
-        if (k < nC)
-            out[(long long)q * nC + k] =
-                append_walk(c, list_ref(av, cand[k]), list_ref(av, qFrameLists[(long long)q * nF + candFrame[k]]), true, bLen);
+        if (k < nC) {
+            const int ql = qFrameLists[(long long)q * nF + candFrame[k]];
+            if (ql >= 0)
+                out[(long long)q * ldOut + (outCol ? outCol[k] : k)] =
+                    append_walk(c, list_ref(av, cand[k]), list_ref(av, ql), qTip ? qTip[q] != 0 : isTip != 0, qBLen ? qBLen[q] : bLen);
+        }
     }
+}
+
+// one launch of k_place_score on the context's stream (timed): out[q * ldOut + (outCol ? outCol[k] : k)]
+static int launch_place_score(maple_ctx *c, int nQ, int nF, const int32_t *qFrameLists, int nC, const int32_t *cand,
+                              const int32_t *candFrame, int isTip, double bLen, double *out, long long ldOut,
+                              const int32_t *outCol, const uint8_t *qTip, const double *qBLen)
+{
+    const long long tiles = (long long)nQ * ((nC + 63) / 64);
+    if (tiles > 0x7fffffffLL - (1 << 20)) return fail(c, MAPLE_ERR_ARG, "nQ x nC too large for one launch");
+    if (!c->d_tile_counters) HIPCK(c, hipMalloc((void **)&c->d_tile_counters, 64 * sizeof(int32_t)));
+    int32_t *counter = c->d_tile_counters + (c->tile_counter_next++ & 63);
+    HIPCK(c, hipMemsetAsync(counter, 0, sizeof(int32_t), c->stream));
+    const long long waves = (tiles + 3) / 4;
+    const int grid = waves < 256 * 4 ? (int)waves : 256 * 4;
+    hipEvent_t e0, e1;
+    TRY(ev_pair(c, &e0, &e1));
+    HIPCK(c, hipEventRecord(e0, c->stream));
+    DISPATCH3(c, k_place_score, <<<grid, MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), nQ, nF, qFrameLists, nC, cand, candFrame, isTip,
+                                                                        bLen, out, ldOut, outCol, qTip, qBLen, counter));
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipEventRecord(e1, c->stream));
+    return MAPLE_OK;
 }
 
 __global__ __launch_bounds__(MAPLE_BLOCK) void k_place_minor(int lRef, ArenaView av, int nQ, int nF, const int32_t *qFrameLists,
@@ -52,48 +78,8 @@ static int place_meta(maple_ctx *c, double effNon0)
     if (M.valid && M.effNon0 == effNon0) return MAPLE_OK;
     const int32_t n = c->dtree.n, root = c->dtree.root;
     const auto &up = c->h_tree_up;
-    const auto &c0 = c->h_tree_c0, &c1 = c->h_tree_c1, &mut = c->h_tree_mut, &totUp = c->h_tree_totUp, &lower = c->h_tree_lower;
-    std::vector<int32_t> order, depth(n, 0), fdepth;
-    order.reserve(n);
-    std::vector<int32_t> st{root};
-    M.frameOf.assign(n, -1);
-    M.frameNode.assign(1, -1);
-    M.frameParent.assign(1, -1);
-    fdepth.assign(1, 0);
-    M.maxDepth = 0;
-    while (!st.empty()) {
-        const int32_t v = st.back();
-        st.pop_back();
-        order.push_back(v);
-        const int32_t pf = up[v] < 0 || v == root ? 0 : M.frameOf[up[v]];
-        if (v != root) depth[v] = depth[up[v]] + 1;
-        if (depth[v] > M.maxDepth) M.maxDepth = depth[v];
-        if (mut[v] >= 0) {
-            M.frameOf[v] = (int32_t)M.frameNode.size();
-            M.frameNode.push_back(v);
-            M.frameParent.push_back(pf);
-            fdepth.push_back(fdepth[pf] + 1);
-        } else M.frameOf[v] = pf;
-        if (c0[v] >= 0) { st.push_back(c0[v]); st.push_back(c1[v]); }
-    }
-    // renumber frames by nesting depth so that a level is a contiguous range (parents always in earlier levels)
-    const int32_t nF = (int32_t)M.frameNode.size();
-    std::vector<int32_t> perm(nF), inv(nF);
-    for (int i = 0; i < nF; i++) perm[i] = i;
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return fdepth[a] < fdepth[b]; });
-    for (int i = 0; i < nF; i++) inv[perm[i]] = i;
-    std::vector<int32_t> fn(nF), fp(nF);
-    M.levelStart.clear();
-    for (int i = 0; i < nF; i++) {
-        fn[i] = M.frameNode[perm[i]];
-        fp[i] = M.frameParent[perm[i]] < 0 ? -1 : inv[M.frameParent[perm[i]]];
-        if (i > 0 && fdepth[perm[i]] != fdepth[perm[i - 1]]) M.levelStart.push_back(i);
-    }
-    M.levelStart.push_back(nF);
-    M.frameNode.swap(fn);
-    M.frameParent.swap(fp);
-    for (auto &f : M.frameOf) if (f >= 0) f = inv[f];
-    M.nF = nF;
+    const auto &c0 = c->h_tree_c0, &totUp = c->h_tree_totUp, &lower = c->h_tree_lower;
+    const std::vector<int32_t> &order = M.order;                          // compute_frames(), at maple_tree_upload
     M.cand.clear();
     M.leaves.clear();
     std::vector<int32_t> &candIdx = M.h_candIdx, &leafIdx = M.h_leafIdx;
@@ -206,20 +192,8 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
         HIPCK(c, c->p_score.reserve((size_t)nq * nCols));
         HIPCK(c, c->p_minor.reserve((size_t)nq * std::max(nL, 1)));
         {
-            const long long tiles = (long long)nq * ((nCols + 63) / 64);
-            if (tiles > 0x7fffffffLL - (1 << 20)) return fail(c, MAPLE_ERR_ARG, "placement chunk too large for one launch");
-            if (!c->d_tile_counters) HIPCK(c, hipMalloc((void **)&c->d_tile_counters, 64 * sizeof(int32_t)));
-            int32_t *counter = c->d_tile_counters + (c->tile_counter_next++ & 63);
-            HIPCK(c, hipMemsetAsync(counter, 0, sizeof(int32_t), c->stream));
-            const long long waves = (tiles + 3) / 4;
-            const int grid = waves < 256 * 4 ? (int)waves : 256 * 4;
-            hipEvent_t e0, e1;
-            TRY(ev_pair(c, &e0, &e1));
-            HIPCK(c, hipEventRecord(e0, c->stream));
-            DISPATCH3(c, k_place_score, <<<grid, MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), nq, nF, dU.p, nCols, M.d_candList.p,
-                                                                                M.d_candFrame.p, pp->oneMutBLen, c->p_score.p, counter));
-            HIPCK(c, hipGetLastError());
-            HIPCK(c, hipEventRecord(e1, c->stream));
+            TRY(launch_place_score(c, nq, nF, dU.p, nCols, M.d_candList.p, M.d_candFrame.p, 1, pp->oneMutBLen, c->p_score.p, nCols,
+                                   nullptr, nullptr, nullptr));
         }
         if (nL > 0) {
             hipLaunchKernelGGL(k_place_minor, dim3(grid_for((int)std::min<long long>((long long)nq * nL, 1 << 30))), dim3(MAPLE_BLOCK), 0,

@@ -48,7 +48,8 @@ struct alignas(64) NodeRec {
     uint8_t pad0;
     int32_t preRank;                   // rank in the search's own depth-first order (child 1's subtree first): the column of
                                        // this node in a cached score row, so that a descent reads the row sequentially
-    uint8_t pad[16];
+    int32_t frameOf;                   // index of the MAT reference frame the node's lists are expressed in (0 = the root's)
+    int32_t c0Frame, c1Frame, upFrame; // the frames of its relatives: a frame change is visible without loading them
 };
 
 struct DevTree {
@@ -95,14 +96,14 @@ struct LaneWs {
     uint2 *w; double *aux; TList *h; StackItem *st; BestRec *best; double *ais;
     int32_t usedW, usedA, nH, sp, nB;
     WsLayout L;
-    bool overflow;
+    int overflow;                      // 0, or which capacity ran out: 1 handles, 2 list words/aux, 3 coefficients, 4 stack, 5 short list, 6 other
     __device__ inline int newHandle(const uint2 *w_, const double *a_, int n, int na)
     {
-        if (nH >= L.capH) { overflow = true; return -2; }
+        if (nH >= L.capH) { overflow = 1; return -2; }
         h[nH] = TList{w_, a_, n, na};
         return nH++;
     }
-    __device__ inline bool reserve(int nw) { if (usedW + nw > L.capW || usedA + 5 * nw > L.capA) { overflow = true; return false; } return true; }
+    __device__ inline bool reserve(int nw) { if (usedW + nw > L.capW || usedA + 5 * nw > L.capA) { overflow = 2; return false; } return true; }
     __device__ inline int commit(const Writer &wr)
     {
         int hid = newHandle(w + usedW, aux + usedA, wr.n, wr.na);
@@ -124,6 +125,9 @@ template <bool RV, bool U, bool SS> struct Search {
     // appendProbNode(probVectTotUp[t1], removed list, ...) -- a pure function of (query, branch) that a batch kernel
     // computes ~50x faster per placement.  `cached` (if set) is this query's row of such scores, indexed by node.
     const double *cached = nullptr;
+    // with MAT local references: this query's removed list in every reference frame (arena list ids, one per frame),
+    // prepared by the host along the same up-then-down paths the traversal takes
+    const int32_t *rTable = nullptr;
     int budget = 0;                    // > 0: give up (status -5) after this many traversal placements without a cache
     bool overBudget = false;
     // optional visit trace of ONE query (debugging / parity of the visit sequence)
@@ -200,7 +204,7 @@ template <bool RV, bool U, bool SS> struct Search {
     __device__ MAPLE_SEARCH_OP double opBlen(int hP, int hC, bool fromTipC)
     {
         bool f;
-        if (len(hP) + len(hC) > ws.L.capAis) { ws.overflow = true; return 0.0; }
+        if (len(hP) + len(hC) > ws.L.capAis) { ws.overflow = 3; return 0.0; }
         return blen_walk(c, ref(hP), ref(hC), fromTipC, ws.ais, 1, &f);
     }
     __device__ MAPLE_SEARCH_OP bool opDiffer(int h1, int h2)
@@ -235,14 +239,14 @@ template <bool RV, bool U, bool SS> struct Search {
 
     __device__ inline void push(int t1, int dir, bool upd, int hPassed, double distance, double lastLK, int fails, int hRpr)
     {
-        if (ws.sp >= ws.L.capS) { ws.overflow = true; return; }
+        if (ws.sp >= ws.L.capS) { ws.overflow = 4; return; }
         StackItem &s = ws.st[ws.sp++];
         s.t1 = t1; s.dir = (int8_t)dir; s.upd = upd ? 1 : 0; s.fails = (int16_t)fails;
         s.hPassed = hPassed; s.hRpr = hRpr; s.distance = distance; s.lastLK = lastLK;
     }
     __device__ inline void record(int t1, double score, int hUp, int hDown, double distance, int hMid, int hRpr)
     {
-        if (ws.nB >= ws.L.capB) { ws.overflow = true; return; }
+        if (ws.nB >= ws.L.capB) { ws.overflow = 5; return; }
         ws.best[ws.nB++] = BestRec{t1, hUp, hDown, hMid, hRpr, score, distance};
     }
     __device__ inline int child(int v, int k) const { return k == 0 ? T.nd[v].c0 : T.nd[v].c1; }
@@ -346,7 +350,7 @@ template <bool RV, bool U, bool SS> struct Search {
                     if (upd) {
                         int opv = opPass(treeList(T.nd[other].lower), T.nd[other].mutId, true);
                         vUp = opMerge(hPassed, distance, false, opv, T.nd[other].dist, T.nd[other].isTip, true);
-                        if (vUp == -2) { ws.overflow = true; return; }
+                        if (vUp == -2) { if (!ws.overflow) ws.overflow = 6; return; }
                     } else vUp = treeList(k == 0 ? T.nd[t1].upRight : T.nd[t1].upLeft);
                     if (valid(vUp)) {
                         int r1 = opPass(hRpr, T.nd[ch].mutId, false);
@@ -395,7 +399,7 @@ template <bool RV, bool U, bool SS> struct Search {
                 if (upd) {
                     int vUpUp = opPass(treeList(upVectOf(t1)), T.nd[t1].mutId, false);
                     vUp = opMerge(vUpUp, T.nd[t1].dist, false, hPassed, distance, false, true);
-                    if (vUp == -2) { ws.overflow = true; return; }
+                    if (vUp == -2) { if (!ws.overflow) ws.overflow = 6; return; }
                 } else vUp = treeList(it.dir == 1 ? T.nd[t1].upLeft : T.nd[t1].upRight);
                 if (!valid(vUp)) return;
                 int r1 = opPass(hRpr, T.nd[other].mutId, false);
@@ -414,14 +418,14 @@ template <bool RV, bool U, bool SS> struct Search {
                 if (upd) {
                     int vUp = opRootVector(hPassed, distance, false, t1);
                     vUp = opPass(vUp, T.nd[other].mutId, false);
-                    if (!valid(vUp)) { ws.overflow = true; return; }
+                    if (!valid(vUp)) { if (!ws.overflow) ws.overflow = 6; return; }
                     push(other, 0, true, vUp, T.nd[other].dist, midProb, fails, r1);
                 } else push(other, 0, false, -1, 0.0, midProb, fails, r1);
             }
         }
     }
 
-    // The cached regime of step() for trees without MAT local references, with the hot state in registers: items that
+    // The cached regime of step(), with the hot state in registers: items that
     // arrive with needsUpdating == False only compare cached scores and push their relatives, so a whole-tree search
     // is ~15 000 iterations of integer work.  Processes items until the stack is empty or its top item still needs
     // updating.  Semantics are those of step() (same order, same tie-breaks); the removed list is one shared object in
@@ -436,8 +440,10 @@ template <bool RV, bool U, bool SS> struct Search {
         BestRec *br = ws.best;
         const NodeRec *nd = T.nd;
         const double *cs = cached;
-        bool wantShorten = false;
-        int hShorten = -1;
+        // the reference shortens the removed list in place at every improvement (M:7087); in the cached regime that has no
+        // reader before the refinement, so the (few distinct) own handles are remembered and shortened on the way out
+        int hShorten[4] = {-1, -1, -1, -1};
+        const int32_t *rT = rTable;
         // the item pushed last is popped next: it stays in registers (`top`), so that the only load a visit depends on
         // is the node record itself
         StackItem top;
@@ -466,19 +472,23 @@ template <bool RV, bool U, bool SS> struct Search {
                     if (r1.totUp < 0) continue;
                     midProb = cs[r1.preRank]; nApp++;
                     if (midProb > best - thrOpt) {
-                        if (nB >= capB) { ws.overflow = true; break; }
+                        if (nB >= capB) { ws.overflow = 5; break; }
                         br[nB++] = BestRec{t1, -1, -1, -1, it.hRpr, midProb, 0.0};
                     }
-                    if (midProb > best) { best = midProb; fails = 0; if (!wantShorten) { wantShorten = true; hShorten = it.hRpr; } }
-                    else if (midProb < (it.lastLK - thrCons)) fails++;
+                    if (midProb > best) {
+                        best = midProb; fails = 0;
+                        if (it.hRpr >= 0 && hShorten[0] != it.hRpr && hShorten[1] != it.hRpr && hShorten[2] != it.hRpr && hShorten[3] != it.hRpr) {
+                            hShorten[3] = hShorten[2]; hShorten[2] = hShorten[1]; hShorten[1] = hShorten[0]; hShorten[0] = it.hRpr;
+                        }
+                    } else if (midProb < (it.lastLK - thrCons)) fails++;
                 }
                 bool go;
                 if (strict) go = fails <= allowed && midProb > (best - thrLK) && r1.c0 >= 0;
                 else go = (fails <= allowed || midProb > (best - thrLK)) && r1.c0 >= 0;
                 if (go) {
-                    if (sp + 3 > capS) { ws.overflow = true; break; }
-                    if (r1.upRight >= 0) push(r1.c0, 0, fails, it.hRpr, midProb);
-                    if (r1.upLeft >= 0) push(r1.c1, 0, fails, it.hRpr, midProb);
+                    if (sp + 3 > capS) { ws.overflow = 4; break; }
+                    if (r1.upRight >= 0) push(r1.c0, 0, fails, (rT && r1.c0Frame != r1.frameOf) ? treeList(rT[r1.c0Frame]) : it.hRpr, midProb);
+                    if (r1.upLeft >= 0) push(r1.c1, 0, fails, (rT && r1.c1Frame != r1.frameOf) ? treeList(rT[r1.c1Frame]) : it.hRpr, midProb);
                 }
             } else {
                 const int other = (it.dir == 1) ? r1.c1 : r1.c0;
@@ -486,7 +496,7 @@ template <bool RV, bool U, bool SS> struct Search {
                     if (r1.totUp < 0) continue;
                     midProb = cs[r1.preRank]; nApp++;
                     if (midProb >= (best - thrOpt)) {
-                        if (nB >= capB) { ws.overflow = true; break; }
+                        if (nB >= capB) { ws.overflow = 5; break; }
                         br[nB++] = BestRec{t1, -1, -1, -1, it.hRpr, midProb, 0.0};
                     }
                     if (midProb > best) { best = midProb; fails = 0; }
@@ -496,17 +506,21 @@ template <bool RV, bool U, bool SS> struct Search {
                 if (strict) go = fails <= allowed && midProb > (best - thrLK);
                 else go = fails <= allowed || midProb > (best - thrLK);
                 if (!go) continue;
-                if (sp + 3 > capS) { ws.overflow = true; break; }
+                if (sp + 3 > capS) { ws.overflow = 4; break; }
                 if (upT >= 0) {
                     if (((it.dir == 1) ? r1.upLeft : r1.upRight) < 0) continue;
-                    push(other, 0, fails, it.hRpr, midProb);
-                    push(upT, (int)r1.whichChild + 1, fails, it.hRpr, midProb);
-                } else push(other, 0, fails, it.hRpr, midProb);
+                    const int oFrame = (it.dir == 1) ? r1.c1Frame : r1.c0Frame;
+                    push(other, 0, fails, (rT && oFrame != r1.frameOf) ? treeList(rT[oFrame]) : it.hRpr, midProb);
+                    push(upT, (int)r1.whichChild + 1, fails, (rT && r1.upFrame != r1.frameOf) ? treeList(rT[r1.upFrame]) : it.hRpr, midProb);
+                } else {
+                    const int oFrame = (it.dir == 1) ? r1.c1Frame : r1.c0Frame;
+                    push(other, 0, fails, (rT && oFrame != r1.frameOf) ? treeList(rT[oFrame]) : it.hRpr, midProb);
+                }
             }
         }
         if (haveTop) st[sp++] = top;
         ws.sp = sp; ws.nB = nB; nAppend = nApp; bestLKdiff = best;
-        if (wantShorten) opShortenInPlace(hShorten);
+        for (int k = 0; k < 4; k++) if (hShorten[k] >= 0) opShortenInPlace(hShorten[k]);
     }
 
     // refinement of one short-listed branch, M:7460-7639 (evaluatePlacement M:6790-6806 inlined)

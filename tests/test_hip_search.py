@@ -208,6 +208,87 @@ def test_wide_searches_batch_scored_identically():
     dev.close()
 
 
+def test_hybrid_search_with_local_references_matches_reference(env):
+    """The wide-search regime on the reference's own trees, which carry MAT local references: with a budget of 8
+    placements nearly every search is handed to the batch kernel (removed list re-expressed in every reference frame,
+    scores cached, traversal replayed) -- results must still be the reference's."""
+    f, dev, tree = env
+    ctx = f["context"]
+    assert any(len(m) for m in tree.mutations)
+    rnd = f["spr"][1]                                                  # the deep-round parameter set
+    ps, calls = rnd["params"], rnd["calls"]
+    nodes = [tree.children[c["node"]][c["child"]] for c in calls]
+    kw = dict(strict=ps["strict"], allowedFails=ps["fails"], thresholdLogLKtopology=ps["thr"],
+              thresholdTopologyPlacement=ps["place"],
+              thresholdLogLKoptimizationTopology=ctx["thresholdLogLKoptimizationTopology"],
+              thresholdLogLKconsecutivePlacement=ctx["thresholdLogLKconsecutivePlacement"],
+              effectivelyNon0BLen=ctx["effectivelyNon0BLen"])
+    out = dev.spr_search_batch(nodes, wide_search_budget=8, **kw)
+    plain = dev.spr_search_batch(nodes, wide_search_budget=-1, **kw)
+    assert (np.asarray([c["n_append"] for c in calls]) > 8).sum() > 100
+    for k, c in enumerate(calls):
+        want = c["ret"]
+        assert out["status"][k] == 0
+        assert int(out["bestNode"][k]) == want["bestNode"], (k, out["bestNode"][k], want["bestNode"])
+        assert int(out["nAppend"][k]) == c["n_append"], (k, out["nAppend"][k], c["n_append"])
+        assert close(float(out["bestScore"][k]), want["bestScore"], 1e-8)
+    for key in ("status", "bestNode", "placement", "nAppend"):
+        assert np.array_equal(plain[key], out[key]), key
+    for key in ("bestScore", "blen", "improvement"):
+        assert np.allclose(plain[key], out[key], rtol=1e-11, atol=1e-15), key
+
+
+def test_hybrid_search_on_big_tree_with_local_references():
+    """A 1500-tip tree given MAT local references the way setUpMAT does (maple_amd.mat, 30 descendants per clade):
+    lane-only search, hybrid search and the C oracle's search agree on every node id, move and candidate count."""
+    import math
+    from maple_amd.host import reference_tables, tip_genome_list
+    from maple_amd.mat import add_local_references
+    from maple_amd.runtime import Device
+    from maple_amd.synth import make_dataset
+    from maple_amd.tree_host import HostTree
+    from maple_amd.tree_mirror import TreeMirror
+    from oracle.oracle_py import Oracle, OracleTree
+    data = make_dataset(n_samples=1500, l_ref=29903, seed=6, mean_diffs=30.0, frac_with_n=0.05, frac_ambig=0.05)
+    ref_idx, rf = reference_tables(data.ref)
+    Qm = [[-0.55, 0.06, 0.37, 0.12], [0.17, -2.6, 0.04, 2.39], [0.84, 0.13, -2.4, 1.43], [0.07, 0.48, 0.05, -0.6]]
+    dev = Device(ref_idx, rf, arena_bytes=2 << 30)
+    dev.set_model(Qm)
+    orc = Oracle(ref_idx, rf)
+    orc.set_model(Qm)
+    tips = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
+    m = TreeMirror(dev, data.parent, data.blen, tips).build()
+    ht = HostTree.from_mirror(m)
+    n_ref = add_local_references(dev, ht, 30)
+    assert n_ref > 20
+    n = ht.n
+    up = np.asarray([-1 if u is None else u for u in ht.up], dtype=np.int32)
+    c0 = np.asarray([c[0] if c else -1 for c in ht.children], dtype=np.int32)
+    c1 = np.asarray([c[1] if c else -1 for c in ht.children], dtype=np.int32)
+    dist = np.asarray([float(x or 0.0) for x in ht.dist])
+    dev.upload_tree(ht.root, up, c0, c1, dist, m.is_tip, ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp, ht.id_mut)
+    lists4 = [dev.download(ids) for ids in (ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp)]
+    otree = OracleTree(orc, ht.root, ht.up, ht.children, dist, ht.mutations, [0] * n, lists4)
+    ll = math.log(dev.lRef)
+    kw = dict(strict=False, allowedFails=4, thresholdLogLKtopology=14.0 * ll, thresholdTopologyPlacement=-0.1,
+              thresholdLogLKoptimizationTopology=ll, thresholdLogLKconsecutivePlacement=1.0,
+              effectivelyNon0BLen=1.0 / (10 * dev.lRef))
+    nodes = np.arange(n)
+    plain = dev.spr_search_batch(nodes, wide_search_budget=-1, **kw)
+    hybrid = dev.spr_search_batch(nodes, wide_search_budget=64, **kw)
+    assert (plain["status"] >= 0).all() and (plain["nAppend"] > 64).sum() > 50
+    for k in ("status", "bestNode", "placement", "nAppend"):
+        assert np.array_equal(plain[k], hybrid[k]), k
+    for k in ("bestScore", "blen", "improvement", "currentLK"):
+        assert np.allclose(plain[k], hybrid[k], rtol=1e-11, atol=1e-15), k
+    sel = nodes[::5]
+    o = orc.spr_worker(otree, sel, **kw)
+    for k in ("status", "bestNode", "placement", "nAppend"):
+        assert np.array_equal(hybrid[k][sel], o[k]), k
+    assert np.allclose(hybrid["bestScore"][sel], o["bestScore"], rtol=1e-11, atol=1e-15)
+    dev.close()
+
+
 def test_device_search_vs_oracle_search_on_gpu_built_tree():
     """Beyond the reference's small recorded trees: every node of a 1500-tip synthetic tree (mirror built on the GPU)
     searched by the device state machine and by the C oracle (itself pinned to the reference's records): node ids,
