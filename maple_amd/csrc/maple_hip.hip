@@ -1686,7 +1686,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // Wide searches (the non-strict rounds let ~1 query in 5 walk the whole tree): in the cached regime the score of a
     // branch is a pure function of (query, branch), so those queries are scored against every branch by the batch
     // kernel (k_append_queries) and the state machine then only replays the traversal over the cached scores.
-    // Only for trees without MAT local references for now (one frame: the removed list is the same everywhere).
+    // With MAT local references the removed list is first expressed in every reference frame (below).
     int wideBudget = sp->wideSearchBudget == 0 ? 256 : sp->wideSearchBudget;
     const bool hybrid = wideBudget > 0;
     TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
