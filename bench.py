@@ -100,7 +100,9 @@ def main():
     data = make_dataset(n_samples=args.samples, l_ref=29903, seed=1, mean_diffs=30.0,
                         rate_variation=(args.model != "unrest"))
     ref_idx, root_freqs = reference_tables(data.ref)
-    dev = Device(ref_idx, root_freqs, device=local_rank, arena_bytes=4 << 30)
+    # genome-list arena: 4 GiB is plenty at 10 000 samples; bigger trees get more of the 288 GB (the per-frame removed
+    # lists of the wide searches on trees with local references are the big temporary)
+    dev = Device(ref_idx, root_freqs, device=local_rank, arena_bytes=max(4 << 30, args.samples * (640 << 10)))
     mkw = model_kwargs(args.model, len(ref_idx))
     dev.set_model(**mkw)
     tip_kw = dict(error_rates=mkw["errorRates"]) if args.model == "siteerr" else {}

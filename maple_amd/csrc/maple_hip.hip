@@ -1710,9 +1710,16 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                     const int32_t l = c->h_tree_lower[nodes[wide[w0 + k]]];
                     needEnt += (int64_t)nF * (c->h_n_ent[l] + 24);
                     needAux += (int64_t)nF * (c->h_n_aux[l] + 8);
-                    if (needEnt > freeEnt || needAux > freeAux) break;
+                    if (needEnt > freeEnt || needAux > freeAux || (int64_t)(k + 1) * nF > (8ll << 20)) break;
                 }
-                if (k == 0) return fail(c, MAPLE_ERR_NOMEM, "arena too small for the per-frame lists of one wide search");
+                if (k < m && k < 2048) {
+                    // Too many frames for this arena (a 100 000-tip tree has ~2 000): batches this small would turn the
+                    // replay into a chain of one-lane launches.  The remaining wide searches run lane-only instead.
+                    std::vector<int32_t> rest, restSlot;
+                    for (size_t w = w0; w < wide.size(); w++) { rest.push_back(nodes[wide[w]]); restSlot.push_back(wide[w]); }
+                    TRY(run_queries(rest, restSlot, nullptr, 0, nullptr, 0));
+                    break;
+                }
                 m = k;
             }
             std::vector<int32_t> qn(m), ql(m), sl(m);

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""One-off check at scale (GPU box): on a tree with MAT local references the hybrid (batch-scored, replayed) deep round
+must equal the lane-only search query by query."""
+import math, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from maple_amd.host import reference_tables, tip_genome_list
+from maple_amd.mat import add_local_references
+from maple_amd.runtime import Device
+from maple_amd.synth import make_dataset
+from maple_amd.tree_host import HostTree
+from maple_amd.tree_mirror import TreeMirror
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
+data = make_dataset(n_samples=n, l_ref=29903, seed=1, mean_diffs=30.0)
+ref_idx, rf = reference_tables(data.ref)
+dev = Device(ref_idx, rf, arena_bytes=max(4 << 30, n * (640 << 10)))
+dev.set_model(bench.UNREST_Q)
+tips = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
+m = TreeMirror(dev, data.parent, data.blen, tips).build()
+ht = HostTree.from_mirror(m)
+print("reference nodes", add_local_references(dev, ht, 50))
+dev.upload_tree(ht.root, m.parent, m.children[:, 0], m.children[:, 1], m.dist, m.is_tip, ht.id_lower, ht.id_upRight,
+                ht.id_upLeft, ht.id_totUp, ht.id_mut)
+ll = math.log(dev.lRef)
+kw = dict(strict=False, allowedFails=4, thresholdLogLKtopology=14.0 * ll, thresholdTopologyPlacement=-0.1,
+          thresholdLogLKoptimizationTopology=ll, thresholdLogLKconsecutivePlacement=1.0, effectivelyNon0BLen=1.0 / (10 * dev.lRef))
+nodes = np.arange(ht.n)
+t0 = time.time(); hyb = dev.spr_search_batch(nodes, **kw); t1 = time.time()
+pla = dev.spr_search_batch(nodes, wide_search_budget=-1, **kw); t2 = time.time()
+print(f"hybrid {t1 - t0:.1f} s, lane-only {t2 - t1:.1f} s, placements {pla['nAppend'].sum()}")
+for k in ("status", "bestNode", "placement", "nAppend"):
+    print(k, "equal:", np.array_equal(hyb[k], pla[k]), "mismatches:", int((hyb[k] != pla[k]).sum()))
+for k in ("bestScore", "improvement", "currentLK"):
+    print(k, "max abs diff:", float(np.abs(hyb[k] - pla[k]).max()))
