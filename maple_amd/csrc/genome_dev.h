@@ -279,6 +279,18 @@ __device__ __forceinline__ int site_factor(const Ctx<RV, U, SS> &c, const Ent &e
 // like the reference, so the result is bit-for-bit that of the CPU restatement (apart from log()).
 // Every entry carries its last position, so the end of the current segment is min(end1, end2) for every type pair,
 // and "advance the cursor whose entry ends here" is the reference's stepping rule (M:6545-6770) in one line.
+// bit (t1 * 8 + t2) set: an entry pair of these types needs per-site work (types 0-3 nucleotides, 4 R, 5 N, 6 O)
+__host__ __device__ constexpr unsigned long long work_table()
+{
+    unsigned long long w = 0;
+    for (int a = 0; a < 7; a++)
+        for (int b = 0; b < 7; b++) {
+            const bool work = (a != 5) && (b != 5) && !(a == 4 && b == 4) && !(a == b && a < 4);
+            if (work) w |= 1ull << (a * 8 + b);
+        }
+    return w;
+}
+
 template <bool RV, bool U, bool SS> struct PairWalk {
     typedef Ctx<RV, U, SS> CT;
     const CT &c;
@@ -324,9 +336,10 @@ template <bool RV, bool U, bool SS> struct PairWalk {
         const uint32_t m1 = (uint32_t)(wa >> 32), m2 = (uint32_t)(wb >> 32);
         const int t1 = m1 & 7u, t2 = m2 & 7u;
         const int pos = min(pa, pb);
-        // a site needs work unless N is involved, both sides are reference runs, or both show the same nucleotide
-        const bool work = (t1 != 5) & (t2 != 5) & !((t1 == 4) & (t2 == 4)) & !((t1 == t2) & (t1 < 4));
-        if (work) {
+        // a site needs work unless N is involved, both sides are reference runs, or both show the same nucleotide:
+        // one bit per (t1, t2) of a 64-bit table instead of six compares
+        constexpr unsigned long long WORK = work_table();
+        if ((WORK >> (t1 * 8 + t2)) & 1ull) {
             const int site = pos - 1;
             if (t1 == 6 || t2 == 6 || (m1 & (1u << 6))) {               // O vector or observation beyond the root
                 Ent e1, e2;
@@ -352,15 +365,17 @@ template <bool RV, bool U, bool SS> struct PairWalk {
                 } else if (cl == 0.0) dead = true;                       // zero-length mismatch: -inf (M:6663, 6742)
                 tf *= f;
             }
+            // the running product and the dead flag only change here, so only here can they end or rescale the walk
+            if (dead) return true;
+            if (tf <= carry) {                                           // M:6772-6783
+                if (tf < 2.2250738585072014e-308) { dead = true; return true; }
+                if (nCarry == 2) { Lk += log(carry1); carry1 = carry2; nCarry = 1; }     // a third one: settle the oldest
+                if (nCarry == 0) carry1 = tf; else carry2 = tf;
+                ++nCarry;
+                tf = 1.0;
+            }
         }
-        if (pos == lRef || dead) return true;
-        if (tf <= carry) {                                               // M:6772-6783
-            if (tf < 2.2250738585072014e-308) { dead = true; return true; }
-            if (nCarry == 2) { Lk += log(carry1); carry1 = carry2; nCarry = 1; }     // a third one: settle the oldest
-            if (nCarry == 0) carry1 = tf; else carry2 = tf;
-            ++nCarry;
-            tf = 1.0;
-        }
+        if (pos == lRef) return true;
         if (pa == pos) { ++ia; wa = pw[ia]; }
         if (pb == pos) { ++ib; wb = cw[ib]; }
         return false;
