@@ -464,6 +464,11 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_evalplace(const DevModel *__res
 }
 
 
+// 248 VGPRs let only 2 wavefronts share a SIMD; the search is latency-bound, so capping it at 128 VGPRs (4 wavefronts,
+// some state spilled to scratch) is faster: deep round 134 -> 103 ms (3 waves 115, 5 waves 144, 8 waves 186).
+#ifndef MAPLE_SPR_ATTR
+#define MAPLE_SPR_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 // SPR regraft search: one lane = one query (state machine in search_dev.h) ---------------------------
 struct LaneBytes { size_t w, aux, h, st, best, ais, total; };
 static LaneBytes lane_bytes(const WsLayout &L)
@@ -481,7 +486,7 @@ static LaneBytes lane_bytes(const WsLayout &L)
 }
 
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(64) void k_spr_search(const DevModel *__restrict__ mp, ArenaView av, MutView mv, DevTree T, SearchParams P, int n,
+__global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel *__restrict__ mp, ArenaView av, MutView mv, DevTree T, SearchParams P, int n,
                                                    const int32_t *nodes, WsLayout L, LaneBytes LB, uint8_t *wsBase,
                                                    int32_t *counter, SearchOut *out, uint2 *poolW, double *poolA,
                                                    unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
@@ -1634,14 +1639,14 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             L.capB = (cacheS ? 4096 : 1024) * (attempt + 1);             // whole-tree (cached) searches short-list far more branches
             L.capAis = 8192 * (attempt + 1);
             LaneBytes LB = lane_bytes(L);
-            // lanes: one query per lane while they last; at most 2 wavefronts per SIMD (the kernel's occupancy) and a
+            // lanes: one query per lane while they last; at most 4 wavefronts per SIMD (the kernel's occupancy) and a
             // workspace footprint bounded to ~48 GB of the 288 GB
             const long long wsBudget = 48ll << 30;
             long long maxLanes = wsBudget / (long long)LB.total;
-            if (maxLanes > 2048 * 64) maxLanes = 2048 * 64;
+            if (maxLanes > 4096 * 64) maxLanes = 4096 * 64;
             if (maxLanes < 64) maxLanes = 64;
             const int lanesWanted = (int)(m < maxLanes ? m : maxLanes);
-            int activeLanes = (lanesWanted + 16383) / 16384;           // per wavefront (measured: 2 lanes beat 4, 10 and 1 at 20k queries)
+            int activeLanes = (lanesWanted + 16383) / 16384;           // per wavefront (measured at 20k queries: 2 lanes beat 1, 4 and 10)
             if (activeLanes < 1) activeLanes = 1;
             if (activeLanes > 64) activeLanes = 64;
             const int nWaves = (lanesWanted + activeLanes - 1) / activeLanes;
