@@ -158,7 +158,10 @@ __device__ inline ListRef list_ref(const ArenaView &a, int id)
 
 // appendProbNode over arbitrary pairs ----------------------------------------------------------
 // 120 VGPRs / no scratch at 4 waves per SIMD measured fastest (5 waves spills, 3 waves loses latency hiding).
-#define MAPLE_APPEND_ATTR __launch_bounds__(MAPLE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef MAPLE_APPEND_WAVES
+#define MAPLE_APPEND_WAVES 4
+#endif
+#define MAPLE_APPEND_ATTR __launch_bounds__(MAPLE_BLOCK) __attribute__((amdgpu_waves_per_eu(MAPLE_APPEND_WAVES, MAPLE_APPEND_WAVES)))
 #define MAPLE_QLDS 192                 // query-list words staged in LDS per wavefront (longer lists are read from HBM/L2)
 template <bool RV, bool U, bool SS>
 __global__ MAPLE_APPEND_ATTR void k_append(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *pl,
@@ -1393,7 +1396,7 @@ static int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int3
     int32_t *counter = c->d_tile_counters + (c->tile_counter_next++ & 63);
     HIPCK(c, hipMemsetAsync(counter, 0, sizeof(int32_t), s));
     const long long waves = (tiles + 3) / 4;
-    const int grid = waves < 256 * 4 ? (int)waves : 256 * 4;          // 4 workgroups of 4 wavefronts per CU = the occupancy limit
+    const int grid = waves < 256 * MAPLE_APPEND_WAVES ? (int)waves : 256 * MAPLE_APPEND_WAVES;   // workgroups of 4 wavefronts, MAPLE_APPEND_WAVES per CU = the occupancy limit
     hipEvent_t e0, e1;
     TRY(ev_pair(c, &e0, &e1));
     HIPCK(c, hipEventRecord(e0, s));

@@ -49,7 +49,7 @@ static int launch_place_score(maple_ctx *c, int nQ, int nF, const int32_t *qFram
     int32_t *counter = c->d_tile_counters + (c->tile_counter_next++ & 63);
     HIPCK(c, hipMemsetAsync(counter, 0, sizeof(int32_t), c->stream));
     const long long waves = (tiles + 3) / 4;
-    const int grid = waves < 256 * 4 ? (int)waves : 256 * 4;
+    const int grid = waves < 256 * MAPLE_APPEND_WAVES ? (int)waves : 256 * MAPLE_APPEND_WAVES;
     hipEvent_t e0, e1;
     TRY(ev_pair(c, &e0, &e1));
     HIPCK(c, hipEventRecord(e0, c->stream));
