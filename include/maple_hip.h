@@ -102,6 +102,11 @@ int maple_arena_stats(maple_ctx *ctx, int64_t *n_lists, int64_t *n_entries, int6
 int maple_mutations_upload(maple_ctx *ctx, int32_t n_lists, const int64_t *off, const int32_t *mut3,
                            int32_t *first_id);
 
+/* Where the reference wraps a call in try/except (findBestRoot, M:7793-7828; the SPR worker, M:9703), an item that
+ * hits a state the reference raises on must not fail the whole batch: with tolerate != 0 the list-producing batch
+ * operators return list id -2 for such an item instead of MAPLE_ERR_FATAL.  Off by default. */
+int maple_set_fatal_policy(maple_ctx *ctx, int tolerate);
+
 /* ---- batched operators (host index arrays in, host results out) -------------- */
 /* appendProbNode(probVectP, probVectC, isTipC, bLen), M:6505-6785 -> log-LK (may be -inf) */
 int maple_append_batch(maple_ctx *ctx, int32_t n, const int32_t *parentList, const int32_t *childList,

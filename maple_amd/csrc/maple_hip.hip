@@ -121,6 +121,7 @@ struct maple_ctx {
     DevBuf<uint8_t> p_u8, p_minor;
     int32_t *d_tile_counters = nullptr;    // ring of tile counters for the dynamically scheduled kernels
     int tile_counter_next = 0;
+    bool tolerate_fatal = false;       // maple_set_fatal_policy
     int trace_query = -1;
     DevBuf<int32_t> s_trace_i;
     DevBuf<double> s_trace_d;
@@ -907,6 +908,13 @@ extern "C" int maple_lists_download(maple_ctx *c, int32_t n, const int32_t *ids,
     return MAPLE_OK;
 }
 
+extern "C" int maple_set_fatal_policy(maple_ctx *c, int tolerate)
+{
+    if (!c) return MAPLE_ERR_ARG;
+    c->tolerate_fatal = tolerate != 0;
+    return MAPLE_OK;
+}
+
 extern "C" int maple_arena_mark(maple_ctx *c, int64_t *mark)
 {
     if (!c || !mark) return MAPLE_ERR_ARG;
@@ -988,7 +996,10 @@ static int commit_lists(maple_ctx *c, int32_t n, const std::vector<int64_t> &wof
     int32_t next_id = (int32_t)c->h_n_ent.size();
     for (int i = 0; i < n; i++) {
         if (ne[i] == -1) { outList[i] = -1; continue; }
-        if (ne[i] < 0) return fail(c, MAPLE_ERR_FATAL, "item %d hit a state the reference treats as fatal (%d)", i, ne[i]);
+        if (ne[i] < 0) {
+            if (c->tolerate_fatal) { outList[i] = -2; continue; }
+            return fail(c, MAPLE_ERR_FATAL, "item %d hit a state the reference treats as fatal (%d)", i, ne[i]);
+        }
         dw[i] = ue; da[i] = ua;
         rows_eo.push_back(ue); rows_ao.push_back(ua); rows_ne.push_back(ne[i]); rows_na.push_back(na[i]);
         ue += ne[i]; ua += na[i];

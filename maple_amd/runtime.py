@@ -23,7 +23,7 @@ EXPORTS = [
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
     "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
-    "maple_minor_candset", "maple_placement_search_batch", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
+    "maple_minor_candset", "maple_placement_search_batch", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
 ]
 
 
@@ -194,6 +194,10 @@ class Device:
                 out.append(unpack_list(pos[eo[k]:eo[k + 1]], meta[eo[k]:eo[k + 1]], aux[ao[k]:ao[k + 1]], self.u))
                 k += 1
         return out
+
+    def set_fatal_policy(self, tolerate: bool):
+        """tolerate=True: an item that hits a state the reference raises on gets list id -2 instead of failing its batch."""
+        self._ck(self.lib.maple_set_fatal_policy(self.h, int(bool(tolerate))))
 
     def mark(self):
         m = C.c_int64()

@@ -448,3 +448,136 @@ def optimize_branch_lengths_fast_pass(dev: Device, tree: HostTree, effectivelyNo
         return updates, dirty
     finally:
         dev.release(mark)
+
+
+def find_best_root(dev: Device, tree: HostTree, *, strictTopologyStopRules, allowedFailsTopology, thresholdLogLKtopology,
+                   thresholdLogLKoptimizationTopology, thresholdLogLKconsecutivePlacement):
+    """The search of findBestRoot (M:7730-7840): the relative log-likelihood of re-rooting the tree on each branch.
+
+    The score of a branch depends only on the path from the current root to it (the partials passed down, the
+    likelihood to remove), not on the search's running best, so the scores of ALL branches are produced level by level
+    -- per level three mergeVectors(returnLK) launches, the passes into the root frame and one findProbRoot launch --
+    and the reference's depth-first traversal with its stop rules (M:7800-7830) is replayed on the host over them.
+    Returns (bestNode, bestLKdiff, bestNodes {node: score within thresholdLogLKoptimizationTopology of the best},
+    nodesVisitedRoot) as the reference has them when its search loop ends; re-rooting itself (reRootTree, M:7842-7873)
+    is tree surgery and stays with the caller."""
+    root = tree.root
+    ch = tree.children
+    mut = tree.id_mut
+    n_minor = np.asarray(tree.n_minor, dtype=np.int32)
+    tip = np.asarray([(not c) and (m == 0) for c, m in zip(ch, tree.n_minor)])
+    dist = np.asarray([float(x or 0.0) for x in tree.dist])
+    up = tree.up
+    mark = dev.mark()
+    dev.set_fatal_policy(True)            # the reference tries each rooting inside try/except (M:7793-7828)
+    try:
+        def passed(ids, nodes, direction_up):
+            ids = np.asarray(ids, dtype=np.int32).copy()
+            nodes = np.asarray(nodes)
+            need = np.nonzero(mut[nodes] >= 0)[0]
+            if len(need):
+                ids[need] = dev.pass_branch_batch(ids[need], mut[nodes[need]], direction_up)
+            return ids
+
+        def root_prob_of(lists, nodes):
+            """findProbRoot(list, node=t1, ...): through every mutated branch between t1 and the root, then the root sum"""
+            lists = np.asarray(lists, dtype=np.int32).copy()
+            cur = np.asarray(nodes).copy()
+            alive = np.ones(len(cur), dtype=bool)
+            while alive.any():
+                idx = np.nonzero(alive)[0]
+                need = idx[mut[cur[idx]] >= 0]
+                if len(need):
+                    lists[need] = dev.pass_branch_batch(lists[need], mut[cur[need]], True)
+                nxt = np.asarray([-1 if up[v] is None else up[v] for v in cur[idx]])
+                cur[idx] = np.where(nxt >= 0, nxt, cur[idx])
+                alive[idx] = nxt >= 0
+            return dev.root_prob_batch(lists)
+
+        score = {}            # (t1, i) -> score of rooting on the branch above children[t1][i]
+        if not ch[root]:
+            return root, 0.0, {root: 0.0}, 1
+        c1, c2 = ch[root]
+        v1 = passed([tree.id_lower[c2]], [c2], True)     # what child1 sees from above: the other child's lower list
+        v2 = passed([tree.id_lower[c1]], [c1], True)
+        root_list = tree.id_lower[root]
+        original = float(root_prob_of([root_list], [root])[0])
+        _, lk0 = dev.merge_batch(v1, [dist[c2]], [tip[c2]], v2, [dist[c1]], [tip[c1]], False, returnLK=True,
+                                 numMinor1=[n_minor[c2]], numMinor2=[n_minor[c1]])
+        original += float(lk0[0])
+        items = []            # (t1, passed list, distance, isTip, numMinor, LKtoRemove)
+        if ch[c1]:
+            items.append((c1, int(passed(v1, [c1], False)[0]), dist[c1] + dist[c2], bool(tip[c2]), int(n_minor[c2]), original))
+        if ch[c2]:
+            items.append((c2, int(passed(v2, [c2], False)[0]), dist[c2] + dist[c1], bool(tip[c1]), int(n_minor[c1]), original))
+        to_pass = {}          # (t1, i) -> (list to hand to child i, its LKtoRemove)
+        while items:
+            t = np.asarray([it[0] for it in items])
+            pas = np.asarray([it[1] for it in items], dtype=np.int32)
+            dis = np.asarray([it[2] for it in items])
+            ptip = np.asarray([it[3] for it in items])
+            pmin = np.asarray([it[4] for it in items], dtype=np.int32)
+            rem = np.asarray([it[5] for it in items])
+            k0 = np.asarray([ch[v][0] for v in t])
+            k1 = np.asarray([ch[v][1] for v in t])
+            pv = [passed(tree.id_lower[k0], k0, True), passed(tree.id_lower[k1], k1, True)]
+            kids = [k0, k1]
+            _, lkc = dev.merge_batch(pv[0], dist[k0], tip[k0], pv[1], dist[k1], tip[k1], False, returnLK=True,
+                                     numMinor1=n_minor[k0], numMinor2=n_minor[k1])
+            new_rem = rem + lkc
+            nxt = []
+            for i in (0, 1):
+                a, b = kids[1 - i], kids[i]
+                up_vect, lk = dev.merge_batch(pv[1 - i], dist[a], tip[a], pas, dis, ptip, False, returnLK=True,
+                                              numMinor1=n_minor[a], numMinor2=pmin)
+                ok = up_vect >= 0
+                new_root, lk_root = dev.merge_batch(np.where(ok, up_vect, pv[i]), dist[b] / 2, False, pv[i], dist[b] / 2, tip[b],
+                                                    False, returnLK=True, numMinor1=np.zeros(len(t), np.int32), numMinor2=n_minor[b])
+                ok &= new_root >= 0
+                rp = root_prob_of(np.where(ok, new_root, pv[i]), t)
+                sc = rp + lk_root + lk - new_rem
+                vect = passed(np.where(ok, up_vect, pv[i]), b, False)
+                changed = np.nonzero(ok & (mut[b] >= 0))[0]
+                if len(changed):
+                    vect[changed] = dev.shorten_batch(vect[changed])             # M:7834-7835
+                for j in range(len(t)):
+                    if not ok[j]:
+                        continue                                                  # "Stopping root search at node ..." (M:7827)
+                    score[(int(t[j]), i)] = float(sc[j])
+                    if ch[int(b[j])]:
+                        nxt.append((int(b[j]), int(vect[j]), float(dist[b[j]]), False, 0, float(new_rem[j] - lk[j])))
+            items = nxt
+        # ---- the reference's traversal over the scores, M:7786-7838
+        best_node, best, visited = root, 0.0, 1
+        best_nodes = {root: 0.0}
+        stack = []
+        if ch[c1]:
+            stack.append((c1, 0.0, 0))
+        if ch[c2]:
+            stack.append((c2, 0.0, 0))
+        while stack:
+            visited += 1
+            t1, last_lk, fails = stack.pop()
+            for i in (0, 1):
+                if (t1, i) not in score:
+                    continue
+                sc = score[(t1, i)]
+                kid = ch[t1][i]
+                fails_new = fails
+                if sc > best:
+                    best, best_node, fails_new = sc, kid, 0
+                elif sc < last_lk - thresholdLogLKconsecutivePlacement:
+                    fails_new += 1
+                if sc >= best - thresholdLogLKoptimizationTopology:
+                    best_nodes[kid] = sc
+                go = False
+                if ch[kid]:
+                    within = sc > best - thresholdLogLKtopology
+                    go = (fails_new <= allowedFailsTopology and within) if strictTopologyStopRules else \
+                         (fails_new <= allowedFailsTopology or within)
+                if go:
+                    stack.append((kid, sc, fails_new))
+        return best_node, best, best_nodes, visited
+    finally:
+        dev.set_fatal_policy(False)
+        dev.release(mark)

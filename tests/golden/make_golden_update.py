@@ -132,9 +132,35 @@ def run(name, n_cases=14):
         sweeps.append(dict(dist_in=dist_in, dist_out=[float(x or 0.0) for x in tc.dist], updates=updates,
                            dirty_out=[bool(x) for x in tc.dirty]))
         print(f"[{name}] fast branch-length pass (perturbed={perturbed}): {updates} updates", flush=True)
+    # ---- findBestRoot (M:7730-7905) on the frozen tree: the search part (the re-rooting itself is tree surgery).
+    # Two parameter sets; locals are read when the function returns (bestNodes is only re-keyed when it re-roots).
+    roots = []
+    for strict, fails, thr in ((True, g["allowedFailsTopology"], g["thresholdLogLKtopology"]),
+                               (False, 4, 14.0 * g["thresholdLogLKtopology"] / max(1e-300, g["thresholdLogLKtopology"]) * 1.0)):
+        if not strict:
+            thr = g["thresholdLogLKtopology"] * 2.0
+        tc = copy.deepcopy(tree)
+        got = {}
+
+        def prof(frame, event, arg):
+            if event == "return" and frame.f_code.co_name == "findBestRoot":
+                loc = frame.f_locals
+                got.update(bestNode=loc["bestNode"], bestLKdiff=loc["bestLKdiff"], visited=loc["nodesVisitedRoot"],
+                           bestNodes={str(k): v for k, v in loc["bestNodes"].items()}, newRoot=arg)
+        sys.setprofile(prof)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                g["findBestRoot"](tc, t1, strictTopologyStopRules=strict, allowedFailsTopology=fails, thresholdLogLKtopology=thr,
+                                  aBayesPlusOn=False)
+        finally:
+            sys.setprofile(None)
+        got.update(strict=strict, fails=fails, thr=thr, rerooted=got["bestNode"] != t1)
+        roots.append(got)
+        print(f"[{name}] findBestRoot strict={strict}: bestNode {got['bestNode']} (root {t1}), bestLKdiff {got['bestLKdiff']:.6f}, "
+              f"{got['visited']} nodes visited, {len(got['bestNodes'])} within the threshold", flush=True)
     path = os.path.join(HERE, f"update_{name}.json.gz")
     with gzip.open(path, "wt") as fh:
-        json.dump(dict(name=name, base=f"search_{name}.json.gz", cases=cases, blen_sweeps=sweeps,
+        json.dump(dict(name=name, base=f"search_{name}.json.gz", cases=cases, blen_sweeps=sweeps, find_best_root=roots,
                        effectivelyNon0BLen=g["effectivelyNon0BLen"]), fh)
     print(f"[{name}] -> {path} {os.path.getsize(path)/1e6:.2f} MB", flush=True)
 

@@ -474,3 +474,27 @@ def test_candidate_sharding_level2(env):
         got_minor[r::world] = dev.minor_candset(s.cset_leaf, frame_lists, False)
     assert np.array_equal(got, full[:-1]) and np.array_equal(got_minor, full_minor)
     dev.release(mark)
+
+
+def test_find_best_root_matches_reference(env):
+    """findBestRoot's search (M:7730-7840) as level-synchronous GPU batches + host replay: best node, number of nodes
+    visited and the relative log-likelihood of every branch the reference keeps in bestNodes (224 of them)."""
+    from maple_amd.tree_host import find_best_root
+    f, dev, tree = env
+    if f["name"] != "synth_unrest":
+        pytest.skip("recorded for synth_unrest only")
+    with gzip.open(os.path.join(GOLDEN, "update_synth_unrest.json.gz"), "rt") as fh:
+        upd = json.load(fh)
+    ctx = f["context"]
+    for rec in upd["find_best_root"]:
+        node, best, best_nodes, visited = find_best_root(
+            dev, tree, strictTopologyStopRules=rec["strict"], allowedFailsTopology=rec["fails"],
+            thresholdLogLKtopology=rec["thr"], thresholdLogLKoptimizationTopology=ctx["thresholdLogLKoptimizationTopology"],
+            thresholdLogLKconsecutivePlacement=ctx["thresholdLogLKconsecutivePlacement"])
+        assert node == rec["bestNode"] and visited == rec["visited"], (node, rec["bestNode"], visited, rec["visited"])
+        assert close(best, rec["bestLKdiff"], 1e-9, 1e-9)
+        want = {int(k): v for k, v in rec["bestNodes"].items()}
+        assert set(best_nodes) == set(want)
+        assert all(close(best_nodes[k], want[k], 1e-7, 1e-7) for k in want), \
+            [(k, best_nodes[k], want[k]) for k in want if not close(best_nodes[k], want[k], 1e-7, 1e-7)][:5]
+        assert len(want) > 100

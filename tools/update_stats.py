@@ -33,3 +33,18 @@ for k in (1, 10, 100, 1000):
     rep = update_genome_lists(dev, ht, pick.tolist())
     dt = time.perf_counter() - t0
     print(f"{k} simultaneous branch-length changes: {rep} lists replaced in {dt * 1e3:.1f} ms ({dt / k * 1e3:.3f} ms per change)")
+# findBestRoot's search + the fast branch-length pass on the same tree
+import math
+from maple_amd.tree_host import find_best_root, optimize_branch_lengths_fast_pass
+ht2 = HostTree.from_mirror(m)
+ll = math.log(dev.lRef)
+t0 = time.perf_counter()
+node, best, best_nodes, visited = find_best_root(dev, ht2, strictTopologyStopRules=True, allowedFailsTopology=2,
+                                                 thresholdLogLKtopology=6.0 * ll, thresholdLogLKoptimizationTopology=ll,
+                                                 thresholdLogLKconsecutivePlacement=1.0)
+dt = time.perf_counter() - t0
+print(f"findBestRoot search: all {nn - 1} branches scored in {dt * 1e3:.1f} ms; best node {node} (root {ht2.root}), "
+      f"score {best:.4f}, {visited} nodes visited by the reference's traversal, {len(best_nodes)} kept")
+t0 = time.perf_counter()
+upd, _ = optimize_branch_lengths_fast_pass(dev, ht2, 1.0 / (10 * dev.lRef))
+print(f"fast branch-length pass: {upd} of {nn - 1} lengths replaced in {(time.perf_counter() - t0) * 1e3:.1f} ms")
