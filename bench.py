@@ -191,16 +191,21 @@ def main():
         kw = dict(strict=False, allowedFails=4, thresholdLogLKtopology=14.0 * log_lref, thresholdTopologyPlacement=-0.1,
                   thresholdLogLKoptimizationTopology=1.0 * log_lref, thresholdLogLKconsecutivePlacement=1.0,
                   effectivelyNon0BLen=1.0 / (10 * l_ref))
+        from maple_amd.parallel import sharded_spr_round
         dev.spr_search_batch(my_nodes, **kw)                            # warm-up (also sizes the workspace)
         dev.timing_reset()
+        if distd is not None:
+            distd.barrier()
         t0 = time.perf_counter()
-        res = dev.spr_search_batch(my_nodes, **kw)
+        # this rank's share of the round + ONE all-gather of the proposed moves, sorted on every rank (M:12306-12312)
+        moves, res = sharded_spr_round(dev, nodes_all, kw, rank, world, device=(cu if backend == "nccl" else None))
         wall = time.perf_counter() - t0
         n_l, k_ms_spr = dev.timing_read()
         st = res["status"]
         spr = {"queries": int(len(my_nodes)), "searched": int((st == 0).sum()), "not_searched": int((st > 0).sum()),
                "failed_or_overflow": int((st < 0).sum()), "candidate_placements": int(res["nAppend"].sum()),
-               "proposed_moves": int((res["placement"] >= 0).sum()), "kernel_ms": k_ms_spr, "launches": n_l,
+               "proposed_moves": int((res["placement"] >= 0).sum()), "proposed_moves_all_ranks": len(moves),
+               "kernel_ms": k_ms_spr, "launches": n_l,
                "wall_ms": 1e3 * wall,
                "placements_per_s_kernel": float(res["nAppend"].sum() / (k_ms_spr * 1e-3)) if k_ms_spr else None,
                "placements_per_s_wall": float(res["nAppend"].sum() / wall),

@@ -114,3 +114,16 @@ def argmax_allreduce(score: float, visit_index: int, device=None):
     i = torch.tensor([visit_index if score == best else big], dtype=torch.int64, device=device)
     dist.all_reduce(i, op=dist.ReduceOp.MIN)
     return best, int(i.item())
+
+
+def sharded_spr_round(dev, nodes, search_kwargs, rank: int = 0, world: int = 1, device=None):
+    """One SPR search (sub)round over several GPUs -- what the reference does with Pool.map over its cores
+    (M:12283-12316): ``nodes`` (the dirty nodes in pre-order, identical on every rank) are dealt round-robin like
+    coreNum, this rank searches its share on its GPU (maple_spr_search_batch), and the proposed moves of all ranks are
+    combined with ONE all-gather and sorted by improvement.  Returns (moves, local_result) with moves =
+    [(node, placement, improvement), ...] identical on every rank."""
+    nodes = np.asarray(nodes)
+    mine = nodes[rank::world]
+    res = dev.spr_search_batch(mine, **search_kwargs)
+    rec = pack_proposals(mine, res["placement"], res["improvement"])
+    return gather_proposals(rec, device=device), res

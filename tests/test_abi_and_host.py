@@ -133,3 +133,32 @@ def test_sharding_covers_every_node_once(fname):
     if tree.children[tree.root]:
         assert core[tree.children[tree.root][0]] == 1
         assert tree.preorder()[1] == tree.children[tree.root][1]
+
+
+def test_perturb_diffs_makes_a_distinct_valid_sample():
+    """synth.perturb_diffs: the new sample keeps every entry of the original, adds exactly n_extra substitutions at
+    untouched positions, stays sorted and converts to a well-formed genome list."""
+    import numpy as np
+    from maple_amd.host import reference_tables, tip_genome_list
+    from maple_amd.synth import make_dataset, perturb_diffs
+    d = make_dataset(n_samples=40, l_ref=3000, seed=9, mean_diffs=12.0, frac_with_n=0.3, frac_ambig=0.3, n_run_len=(5, 80))
+    ref_idx, _ = reference_tables(d.ref)
+    rng = np.random.default_rng(1)
+    for dl in d.diffs:
+        new = perturb_diffs(dl, d.ref, rng, n_extra=2)
+        assert len(new) == len(dl) + 2 and all(e in new for e in dl)
+        assert [e[1] for e in new] == sorted(e[1] for e in new)
+        added = [e for e in new if e not in dl]
+        assert all(e[0] != d.ref[e[1] - 1] for e in added)
+        gl = tip_genome_list(new, ref_idx)
+        pos = 0
+        for e in gl:
+            pos = e[1] if e[0] in (4, 5) else pos + 1
+        assert pos == len(d.ref)
+
+
+def test_usable_host_threads_is_positive_and_bounded():
+    import os
+    import bench
+    n = bench.usable_host_threads()
+    assert 1 <= n <= (os.cpu_count() or 1)
