@@ -52,32 +52,51 @@ __host__ __device__ inline void place_replay_one(const NodeRec *nd, int root, co
     const double originalLK = bestLK;
     int bestNode = root;
     int sp = 0;
+    // the item pushed last is popped next: it stays in registers (top*), so a visit waits for the node record only
+    int topNode = -1, topFails = 0;
+    double topLK = 0.0;
+    bool haveTop = false;
+#define MAPLE_PLACE_PUSH(NODE, LK, FAILS)                                                                              \
+    do {                                                                                                               \
+        if (haveTop) {                                                                                                 \
+            stNode[(long long)sp * nQ + q] = topNode; stLK[(long long)sp * nQ + q] = topLK;                            \
+            stFails[(long long)sp * nQ + q] = (int16_t)topFails; sp++;                                                 \
+        }                                                                                                              \
+        topNode = (NODE); topLK = (LK); topFails = (FAILS); haveTop = true;                                            \
+    } while (0)
     if (rr.c0 < 0) {
         if (leafIdx[root] >= 0 && mn[leafIdx[root]] == 1) { status = 1; minorNode = root; nAppend = 0; }
     } else {
-        stNode[(long long)sp * nQ + q] = rr.c0; stLK[(long long)sp * nQ + q] = bestLK; stFails[(long long)sp * nQ + q] = 0; sp++;
-        stNode[(long long)sp * nQ + q] = rr.c1; stLK[(long long)sp * nQ + q] = bestLK; stFails[(long long)sp * nQ + q] = 0; sp++;
+        MAPLE_PLACE_PUSH(rr.c0, bestLK, 0);
+        MAPLE_PLACE_PUSH(rr.c1, bestLK, 0);
     }
-    while (sp > 0 && status == 0) {                                       // M:7972-8100
-        sp--;
-        const int t1 = stNode[(long long)sp * nQ + q];
-        const double parentLK = stLK[(long long)sp * nQ + q];
-        int fails = stFails[(long long)sp * nQ + q];
-        const NodeRec r = nd[t1];
+    while ((haveTop || sp > 0) && status == 0) {                          // M:7972-8100
+        int t1, fails;
+        double parentLK;
+        if (haveTop) { t1 = topNode; parentLK = topLK; fails = topFails; haveTop = false; }
+        else {
+            sp--;
+            t1 = stNode[(long long)sp * nQ + q];
+            parentLK = stLK[(long long)sp * nQ + q];
+            fails = stFails[(long long)sp * nQ + q];
+        }
+        // three independent loads, then two: the visit's dependent chain is two memory latencies deep
         const int ci = candIdx[t1];
+        const int li = leafIdx[t1];
+        const NodeRec r = nd[t1];
+        const double sci = ci >= 0 ? sc[ci] : 0.0;
+        const int cmp = li >= 0 ? mn[li] : 0;
         if (r.c0 < 0) {
-            const int li = leafIdx[t1];
-            const int cmp = li >= 0 ? mn[li] : 0;
             if (cmp == 1) { status = 1; minorNode = t1; break; }           // M:7986-8003
             if (cmp == 2) missed++;
         }
         double lk = parentLK;
         if (ci >= 0) {
-            lk = sc[ci];
+            lk = sci;
             nAppend++;
             bool keep = false;
             if (lk >= bestLK) {                                           // M:8065-8073
-                const int f = frameOf[t1];
+                const int f = r.frameOf;
                 frameBits[(long long)(f >> 5) * nQ + q] |= 1u << (f & 31);
                 bestLK = lk; bestNode = t1; fails = 0; keep = true;
             } else if (lk > bestLK - P.thrOpt) keep = true;               // M:8074-8075
@@ -96,11 +115,12 @@ __host__ __device__ inline void place_replay_one(const NodeRec *nd, int root, co
         const bool within = lk > bestLK - P.thrLK;
         const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);   // M:8080-8093
         if (go && r.c0 >= 0) {
-            if (sp + 2 > stackCap) { status = -6; break; }
-            stNode[(long long)sp * nQ + q] = r.c0; stLK[(long long)sp * nQ + q] = lk; stFails[(long long)sp * nQ + q] = (int16_t)fails; sp++;
-            stNode[(long long)sp * nQ + q] = r.c1; stLK[(long long)sp * nQ + q] = lk; stFails[(long long)sp * nQ + q] = (int16_t)fails; sp++;
+            if (sp + 3 > stackCap) { status = -6; break; }
+            MAPLE_PLACE_PUSH(r.c0, lk, fails);
+            MAPLE_PLACE_PUSH(r.c1, lk, fails);
         }
     }
+#undef MAPLE_PLACE_PUSH
     // final filter of the short list (M:8109) and the state of each entry's query list object
     int k = 0;
     for (int i = 0; i < nSl; i++)
