@@ -193,3 +193,47 @@ def test_batched_placement_equals_single_query_search(world):
             assert tuple(0.0 if b is False else b for b in want[2]) == got[2]
         assert got[3] == want[3]
     assert 0 < n_minor < len(queries)
+
+
+def test_batch_kernel_with_queries_longer_than_the_lds_stage():
+    """k_append_queries keeps the tile's query words in LDS up to 192 entries and reads longer lists from memory: both
+    paths against the oracle (samples with ~150 and ~400 differences give lists on either side of the limit)."""
+    import torch
+    from maple_amd.host import reference_tables, tip_genome_list
+    from maple_amd.runtime import Device
+    from maple_amd.synth import make_dataset
+    from oracle.oracle_py import Oracle
+    data = make_dataset(n_samples=96, l_ref=29903, seed=12, mean_diffs=30.0, frac_with_n=0.2, frac_ambig=0.2)
+    long_a = make_dataset(n_samples=4, l_ref=29903, seed=13, mean_diffs=150.0)
+    long_b = make_dataset(n_samples=4, l_ref=29903, seed=14, mean_diffs=400.0)
+    ref_idx, rf = reference_tables(data.ref)
+    dev = Device(ref_idx, rf, arena_bytes=256 << 20)
+    dev.set_model(Q)
+    orc = Oracle(ref_idx, rf)
+    orc.set_model(Q)
+    cands = [tip_genome_list(dl, ref_idx) for dl in data.diffs]
+    # the long samples were drawn against their own random references: re-use only their positions / bases on this one
+    queries = []
+    for ds in (long_a, long_b):
+        for dl in ds.diffs:
+            fixed = [(("acgt".replace(data.ref[e[1] - 1], ""))[e[1] % 3], e[1]) for e in dl if e[0] in "acgt"]
+            queries.append(tip_genome_list(sorted(set(fixed), key=lambda e: e[1]), ref_idx))
+    n_ent = [len(q) for q in queries]
+    assert min(n_ent) < 192 < max(n_ent), n_ent
+    c_ids = dev.upload(cands)
+    q_ids = dev.upload(queries)
+    cu = torch.device("cuda", 0)
+    t_q = torch.from_numpy(q_ids.astype(np.int32)).to(cu)
+    t_c = torch.from_numpy(c_ids.astype(np.int32)).to(cu)
+    out = torch.empty(len(queries) * len(cands), dtype=torch.float64, device=cu)
+    torch.cuda.synchronize()
+    dev.append_queries_dev(len(queries), t_q.data_ptr(), len(cands), t_c.data_ptr(), True, 1.0 / dev.lRef, out.data_ptr(),
+                           torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(len(queries), len(cands))
+    for qi, q in enumerate(queries):
+        for ci in range(0, len(cands), 7):
+            want = orc.appendProbNode(cands[ci], q, True, 1.0 / dev.lRef)
+            g = float(got[qi, ci])
+            assert (math.isinf(want) and math.isinf(g)) or rel(g, want) < 1e-12, (qi, ci, g, want)
+    dev.close()
