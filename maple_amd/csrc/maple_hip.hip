@@ -88,8 +88,8 @@ struct maple_ctx {
     DevBuf<double> s_f64[4];
     DevBuf<uint8_t> s_u8[4];
     DevBuf<int64_t> s_i64[6];
-    DevBuf<uint2> s_words;
-    DevBuf<double> s_aux;
+    DevBuf<uint2> s_words, s_pool_w;
+    DevBuf<double> s_aux, s_pool_a;
     DevBuf<double> s_ais;
     // tree mirror (topology + list ids), maple_tree_upload
     DevTree dtree{};
@@ -102,6 +102,7 @@ struct maple_ctx {
     std::vector<double> h_tree_dist;
     std::vector<uint8_t> h_tree_tip;
     bool tree_has_mut = false;
+    int32_t tree_max_ent = 0;          // longest genome list of the uploaded tree (entries)
     int32_t n_scored = 0;              // nodes with a probVectTotUp, sorted by list length: t_i32[8] = list ids, t_scored_col = node ids
     DevBuf<int32_t> t_scored_col, t_scored_frame;
     // SPR search workspace
@@ -545,6 +546,7 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             const size_t row = cacheRow ? (size_t)cacheRow[q] : (size_t)q;
             S.cached = cacheS ? cacheS + row * T.n : nullptr;             // this query's row of the (queries x nodes) score table
             S.rTable = (cacheS && rTable) ? rTable + row * nF : nullptr;  // and of the (queries x frames) removed lists
+            S.fShort[0] = S.fShort[1] = S.fShort[2] = S.fShort[3] = -1;
             S.budget = budget;
             S.overBudget = false;
             S.trI = nullptr;
@@ -552,7 +554,10 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             S.begin(parent, childIdx, curLK, T.nd[node].dist);
             active = true;
         } else if (ws.overflow) {
-            out[q].status = -3;                                       // workspace exhausted: the host retries with more
+            // workspace exhausted: in the budgeted pass the search is simply handed to the batch path like a wide one (it
+            // restarts there with 4x the room and allocates far less once scores are cached); otherwise the host retries
+            // it with more
+            out[q].status = (S.budget > 0 && !S.cached) ? -5 : -3;
             out[q].nAppend = ws.overflow;                             // (which capacity, for MAPLE_DEBUG)
             active = false;
         } else if (S.overBudget) {
@@ -575,7 +580,11 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             o.nAppend = S.nAppend;
             if (S.trI) *trN = S.trN;
             if (poolW) {                                             // hand bestRemovedPartials out through the pool
-                TList rp = S.L(S.hBestRpr);
+                int hOut = S.hBestRpr;
+                if (hOut <= -10 && S.rTable)                          // a frame-table list the reference shortened in place
+                    for (int k = 0; k < 4; k++)
+                        if (S.fShort[k] >= 0 && -(hOut + 10) == S.rTable[S.fShort[k]]) { hOut = S.opShortenCopy(hOut); break; }
+                TList rp = S.L(hOut);
                 long long ow = (long long)atomicAdd(&poolUsed[0], (unsigned long long)rp.n);
                 long long oa = (long long)atomicAdd(&poolUsed[1], (unsigned long long)rp.na);
                 if (ow + rp.n <= poolCapW && oa + rp.na <= poolCapA) {
@@ -727,7 +736,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     for (auto &b : c->s_f64) b.release();
     for (auto &b : c->s_u8) b.release();
     for (auto &b : c->s_i64) b.release();
-    c->s_words.release(); c->s_aux.release(); c->s_ais.release();
+    c->s_words.release(); c->s_aux.release(); c->s_ais.release(); c->s_pool_w.release(); c->s_pool_a.release();
     for (auto &b : c->t_i32) b.release();
     c->t_dist.release(); c->t_tip.release(); c->t_nodes.release(); c->t_scored_col.release(); c->t_scored_frame.release();
     if (c->d_tile_counters) (void)hipFree(c->d_tile_counters);
@@ -984,8 +993,10 @@ static int need_model(maple_ctx *c)
 
 // Move freshly produced scratch lists into the arena and hand out ids (or -1 for None).
 static int commit_lists(maple_ctx *c, int32_t n, const std::vector<int64_t> &woff, const std::vector<int64_t> &aoff,
-                        int32_t *d_n_ent, int32_t *d_n_aux, int32_t *outList)
+                        int32_t *d_n_ent, int32_t *d_n_aux, int32_t *outList, const uint2 *srcW = nullptr,
+                        const double *srcA = nullptr)
 {
+    if (!srcW) { srcW = c->s_words.p; srcA = c->s_aux.p; }             // the batch operators' shared scratch
     std::vector<int32_t> ne(n), na(n);
     HIPCK(c, hipMemcpyAsync(ne.data(), d_n_ent, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(na.data(), d_n_aux, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1013,7 +1024,7 @@ static int commit_lists(maple_ctx *c, int32_t n, const std::vector<int64_t> &wof
     int waves_per_block = MAPLE_BLOCK / 64;
     int g = (n + waves_per_block - 1) / waves_per_block;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_commit, dim3(g), dim3(MAPLE_BLOCK), 0, c->stream, n, c->s_words.p, c->s_aux.p, c->s_i64[4].p,
+    hipLaunchKernelGGL(k_commit, dim3(g), dim3(MAPLE_BLOCK), 0, c->stream, n, srcW, srcA, c->s_i64[4].p,
                        c->s_i64[5].p, d_n_ent, d_n_aux, c->s_i64[2].p, c->s_i64[3].p, c->d_words, c->d_aux);
     HIPCK(c, hipGetLastError());
     if (!rows_ne.empty())
@@ -1578,7 +1589,12 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     T.nd = (const NodeRec *)aligned;
     T.totUp = c->t_i32[6].p;
     c->tree_has_mut = false;
-    for (int i = 0; i < n; i++) if (mutList[i] >= 0) c->tree_has_mut = true;
+    c->tree_max_ent = 0;
+    for (int i = 0; i < n; i++) {
+        if (mutList[i] >= 0) c->tree_has_mut = true;
+        for (const int32_t *col : {lower, upRight, upLeft, totUp})
+            if (col[i] >= 0) c->tree_max_ent = std::max(c->tree_max_ent, c->h_n_ent[col[i]]);
+    }
     {   // the batch-scoring kernel wants its candidates sorted by list length (uniform wavefronts)
         std::vector<int32_t> col;
         for (int i = 0; i < n; i++) if (totUp[i] >= 0) col.push_back(i);
@@ -1629,13 +1645,16 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             long long ne = lid >= 0 ? c->h_n_ent[lid] : 0, na = lid >= 0 ? c->h_n_aux[lid] : 0;
             poolCapW += 3 * ne + 64; poolCapA += 3 * na + 5 * ne + 64;
         }
-        HIPCK(c, c->s_words.reserve((size_t)poolCapW));
-        HIPCK(c, c->s_aux.reserve((size_t)poolCapA));
-        poolW = c->s_words.p; poolA = c->s_aux.p;
+        // its own buffers: the batch operators' scratch is reused by the per-frame passes of the wide searches
+        HIPCK(c, c->s_pool_w.reserve((size_t)poolCapW));
+        HIPCK(c, c->s_pool_a.reserve((size_t)poolCapA));
+        poolW = c->s_pool_w.p; poolA = c->s_pool_a.p;
     }
     HIPCK(c, hipMemsetAsync(c->s_counter.p, 0, 8 * sizeof(int32_t), c->stream));
     unsigned long long *poolUsed = (unsigned long long *)(c->s_counter.p + 2);
-    const int capW0 = ws_entries_per_lane > 0 ? ws_entries_per_lane : 16384;
+    // per-lane list workspace: a search near the root of a tree with long lists (rate variation: many O vectors) merges
+    // lists of several hundred entries a few hundred times before it is handed over or done
+    const int capW0 = ws_entries_per_lane > 0 ? ws_entries_per_lane : std::max(16384, 64 * c->tree_max_ent);
     // Runs the searches `todo` (results into ho[slot[]]).  Queries whose per-lane workspace overflowed (status -3) are
     // re-run with 8x the workspace, twice at most.  cacheS (optional) = row-major (|todo| x T.n) cached scores.
     auto run_queries = [&](std::vector<int32_t> todo, std::vector<int32_t> slot, const double *cacheS, int budgetNow,
@@ -1647,15 +1666,15 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             const int m = (int)todo.size();
             WsLayout L;
             L.capW = capW;
-            L.capA = 3 * L.capW;
+            L.capA = 5 * L.capW;                                        // O-vector-heavy lists (rate variation) carry up to 4-5 aux doubles per entry
             L.capH = L.capW / 8 + 256;
             L.capS = 1024 * (attempt + 1);
             L.capB = (cacheS ? 4096 : 1024) * (attempt + 1);             // whole-tree (cached) searches short-list far more branches
             L.capAis = 8192 * (attempt + 1);
             LaneBytes LB = lane_bytes(L);
             // lanes: one query per lane while they last; at most 4 wavefronts per SIMD (the kernel's occupancy) and a
-            // workspace footprint bounded to ~48 GB of the 288 GB
-            const long long wsBudget = 48ll << 30;
+            // workspace footprint bounded to ~96 GB of the 288 GB
+            const long long wsBudget = 96ll << 30;
             long long maxLanes = wsBudget / (long long)LB.total;
             if (maxLanes > 4096 * 64) maxLanes = 4096 * 64;
             if (maxLanes < 64) maxLanes = 64;
@@ -1698,7 +1717,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             todo.swap(todo2);
             slot.swap(slot2);
             rows.swap(rows2);
-            budgetNow = 0;
+            // (the budget stays: a retried search that turns out to be wide still goes to the batch path)
         }
         return MAPLE_OK;
     };
@@ -1828,7 +1847,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         HIPCK(c, hipMemcpyAsync(c->s_i32[2].p, ne.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipMemcpyAsync(c->s_i32[3].p, na.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
-        TRY(commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outRprList));
+        TRY(commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outRprList, poolW, poolA));
     }
     return MAPLE_OK;
 }

@@ -128,6 +128,7 @@ template <bool RV, bool U, bool SS> struct Search {
     // with MAT local references: this query's removed list in every reference frame (arena list ids, one per frame),
     // prepared by the host along the same up-then-down paths the traversal takes
     const int32_t *rTable = nullptr;
+    int fShort[4] = {-1, -1, -1, -1};  // frames whose frame-table list the reference would have shortened in place (M:7087)
     int budget = 0;                    // > 0: give up (status -5) after this many traversal placements without a cache
     bool overBudget = false;
     // optional visit trace of ONE query (debugging / parity of the visit sequence)
@@ -195,6 +196,20 @@ template <bool RV, bool U, bool SS> struct Search {
         if (wr.n == n) return;                                        // nothing merged: keep the old storage
         ws.h[hid] = TList{ws.w + ws.usedW, ws.aux + ws.usedA, wr.n, wr.na};
         ws.usedW += wr.n; ws.usedA += wr.na;
+    }
+    // shorten() of a list this lane does not own (a tree / frame-table list): a shortened copy under a new handle
+    __device__ MAPLE_SEARCH_OP int opShortenCopy(int hid)
+    {
+        const int n = len(hid);
+        if (!ws.reserve(n)) return hid;
+        Writer wr;
+        wr.init(ws.w + ws.usedW, ws.aux + ws.usedA);
+        shorten_walk(c, ref(hid), n, wr);
+        if (wr.n == n) return hid;
+        const int h = ws.newHandle(ws.w + ws.usedW, ws.aux + ws.usedA, wr.n, wr.na);
+        if (h < 0) return hid;
+        ws.usedW += wr.n; ws.usedA += wr.na;
+        return h;
     }
     __device__ MAPLE_SEARCH_OP double opAppend(int hP, int hC, bool isTipC, double bLen)
     {
@@ -479,6 +494,11 @@ template <bool RV, bool U, bool SS> struct Search {
                         best = midProb; fails = 0;
                         if (it.hRpr >= 0 && hShorten[0] != it.hRpr && hShorten[1] != it.hRpr && hShorten[2] != it.hRpr && hShorten[3] != it.hRpr) {
                             hShorten[3] = hShorten[2]; hShorten[2] = hShorten[1]; hShorten[1] = hShorten[0]; hShorten[0] = it.hRpr;
+                        } else if (it.hRpr <= -10 && rT) {
+                            const int f = r1.frameOf;
+                            if (fShort[0] != f && fShort[1] != f && fShort[2] != f && fShort[3] != f) {
+                                fShort[3] = fShort[2]; fShort[2] = fShort[1]; fShort[1] = fShort[0]; fShort[0] = f;
+                            }
                         }
                     } else if (midProb < (it.lastLK - thrCons)) fails++;
                 }

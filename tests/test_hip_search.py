@@ -223,15 +223,18 @@ def test_hybrid_search_with_local_references_matches_reference(env):
               thresholdLogLKoptimizationTopology=ctx["thresholdLogLKoptimizationTopology"],
               thresholdLogLKconsecutivePlacement=ctx["thresholdLogLKconsecutivePlacement"],
               effectivelyNon0BLen=ctx["effectivelyNon0BLen"])
-    out = dev.spr_search_batch(nodes, wide_search_budget=8, **kw)
+    out = dev.spr_search_batch(nodes, wide_search_budget=8, want_removed_partials=True, **kw)
     plain = dev.spr_search_batch(nodes, wide_search_budget=-1, **kw)
     assert (np.asarray([c["n_append"] for c in calls]) > 8).sum() > 100
+    rpr = dev.download(out["removedPartials"])
     for k, c in enumerate(calls):
         want = c["ret"]
         assert out["status"][k] == 0
         assert int(out["bestNode"][k]) == want["bestNode"], (k, out["bestNode"][k], want["bestNode"])
         assert int(out["nAppend"][k]) == c["n_append"], (k, out["nAppend"][k], c["n_append"])
         assert close(float(out["bestScore"][k]), want["bestScore"], 1e-8)
+        # bestRemovedPartials: the removed list in the best branch's reference frame, shortened where the reference did
+        assert lists_match(rpr[k], tup(want["bestRemovedPartials"]), 1e-7), (k, rpr[k][:3], want["bestRemovedPartials"][:3])
     for key in ("status", "bestNode", "placement", "nAppend"):
         assert np.array_equal(plain[key], out[key]), key
     for key in ("bestScore", "blen", "improvement"):

@@ -10,11 +10,14 @@ from maple_amd.synth import make_dataset
 from maple_amd.tree_mirror import TreeMirror
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 strict = len(sys.argv) > 2 and sys.argv[2] == "fast"
-data = make_dataset(n_samples=n, l_ref=29903, seed=1, mean_diffs=30.0)
+MODEL = os.environ.get("MODEL", "unrest")
+data = make_dataset(n_samples=n, l_ref=29903, seed=1, mean_diffs=30.0, rate_variation=(MODEL != "unrest"))
 ref_idx, rf = reference_tables(data.ref)
 dev = Device(ref_idx, rf, arena_bytes=(4 << 30) if n <= 20000 else (24 << 30))
-dev.set_model(bench.UNREST_Q)
-tips = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
+mkw = bench.model_kwargs(MODEL, len(ref_idx))
+dev.set_model(**mkw)
+tip_kw = dict(error_rates=mkw["errorRates"]) if MODEL == "siteerr" else {}
+tips = {int(v): tip_genome_list(dl, ref_idx, **tip_kw) for v, dl in zip(data.tip_node, data.diffs)}
 t0 = time.time(); m = TreeMirror(dev, data.parent, data.blen, tips).build(); print("mirror build s", time.time() - t0, dev.stats())
 l_ref = dev.lRef; ll = math.log(l_ref)
 dev.upload_tree(m.root, m.parent, m.children[:, 0], m.children[:, 1], m.dist, m.is_tip, m.lower, m.up_right, m.up_left, m.tot_up, -np.ones(m.n_nodes, dtype=np.int32))
