@@ -559,6 +559,7 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             // it with more
             out[q].status = (S.budget > 0 && !S.cached) ? -5 : -3;
             out[q].nAppend = ws.overflow;                             // (which capacity, for MAPLE_DEBUG)
+            out[q].bestNode = -2;                                     // marks "handed over because it ran out of room"
             active = false;
         } else if (S.overBudget) {
             out[q].status = -5;                                       // a wide search: the host batch-scores it and re-runs it
@@ -1657,9 +1658,11 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     const int capW0 = ws_entries_per_lane > 0 ? ws_entries_per_lane : std::max(16384, 64 * c->tree_max_ent);
     // Runs the searches `todo` (results into ho[slot[]]).  Queries whose per-lane workspace overflowed (status -3) are
     // re-run with 8x the workspace, twice at most.  cacheS (optional) = row-major (|todo| x T.n) cached scores.
+    bool heavyQueries = false;
     auto run_queries = [&](std::vector<int32_t> todo, std::vector<int32_t> slot, const double *cacheS, int budgetNow,
                            const int32_t *rTable, int nF) -> int {
-        int capW = cacheS ? 4 * capW0 : capW0;                          // the few cached (whole-tree) searches get room up front
+        // the few cached (whole-tree) searches get room up front; more when the budgeted pass already ran out of it
+        int capW = cacheS ? (heavyQueries ? 8 : 4) * capW0 : capW0;
         std::vector<int32_t> rows(todo.size());                        // row of each query in the cache / frame tables
         for (size_t k = 0; k < rows.size(); k++) rows[k] = (int32_t)k;
         for (int attempt = 0; attempt < 3 && !todo.empty(); attempt++, capW *= 8) {
@@ -1730,7 +1733,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
     if (hybrid) {
         std::vector<int32_t> wide;
-        for (int i = 0; i < n; i++) if (ho[i].status == -5) wide.push_back(i);
+        for (int i = 0; i < n; i++)
+            if (ho[i].status == -5) { wide.push_back(i); if (ho[i].bestNode == -2) heavyQueries = true; }
         const PlaceMeta &F = *c->place;
         const int nT = c->dtree.n, nF = c->tree_has_mut ? F.nF : 1;
         const size_t rowBytes = (size_t)nT * sizeof(double);
