@@ -12,11 +12,14 @@ from maple_amd.synth import make_dataset
 from maple_amd.tree_host import HostTree
 from maple_amd.tree_mirror import TreeMirror
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
-data = make_dataset(n_samples=n, l_ref=29903, seed=1, mean_diffs=30.0)
+MODEL = os.environ.get("MODEL", "unrest")
+data = make_dataset(n_samples=n, l_ref=29903, seed=1, mean_diffs=30.0, rate_variation=(MODEL != "unrest"))
 ref_idx, rf = reference_tables(data.ref)
 dev = Device(ref_idx, rf, arena_bytes=max(4 << 30, n * (640 << 10)))
-dev.set_model(bench.UNREST_Q)
-tips = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
+mkw = bench.model_kwargs(MODEL, len(ref_idx))
+dev.set_model(**mkw)
+tip_kw = dict(error_rates=mkw["errorRates"]) if MODEL == "siteerr" else {}
+tips = {int(v): tip_genome_list(dl, ref_idx, **tip_kw) for v, dl in zip(data.tip_node, data.diffs)}
 m = TreeMirror(dev, data.parent, data.blen, tips).build()
 ht = HostTree.from_mirror(m)
 print("reference nodes", add_local_references(dev, ht, 50))
@@ -26,10 +29,24 @@ ll = math.log(dev.lRef)
 kw = dict(strict=False, allowedFails=4, thresholdLogLKtopology=14.0 * ll, thresholdTopologyPlacement=-0.1,
           thresholdLogLKoptimizationTopology=ll, thresholdLogLKconsecutivePlacement=1.0, effectivelyNon0BLen=1.0 / (10 * dev.lRef))
 nodes = np.arange(ht.n)
-t0 = time.time(); hyb = dev.spr_search_batch(nodes, **kw); t1 = time.time()
-pla = dev.spr_search_batch(nodes, wide_search_budget=-1, **kw); t2 = time.time()
+t0 = time.time(); hyb = dev.spr_search_batch(nodes, want_removed_partials=True, **kw); t1 = time.time()
+pla = dev.spr_search_batch(nodes, wide_search_budget=-1, want_removed_partials=True, **kw); t2 = time.time()
 print(f"hybrid {t1 - t0:.1f} s, lane-only {t2 - t1:.1f} s, placements {pla['nAppend'].sum()}")
 for k in ("status", "bestNode", "placement", "nAppend"):
     print(k, "equal:", np.array_equal(hyb[k], pla[k]), "mismatches:", int((hyb[k] != pla[k]).sum()))
 for k in ("bestScore", "improvement", "currentLK"):
     print(k, "max abs diff:", float(np.abs(hyb[k] - pla[k]).max()))
+ok = (hyb["status"] == 0)
+la = dev.download(hyb["removedPartials"][ok]); lb = dev.download(pla["removedPartials"][ok])
+print("bestRemovedPartials lists equal:", sum(1 for a, b in zip(la, lb) if a == b), "of", len(la))
+# batched placement (device traversal, frames) against the host replay on new samples
+from maple_amd.search import PlacementParams, PlacementSearcher
+from maple_amd.synth import perturb_diffs
+ps = PlacementSearcher(dev, ht, PlacementParams(oneMutBLen=1.0 / dev.lRef, effectivelyNon0BLen=1.0 / (10 * dev.lRef), thresholdLogLK=18.0 * ll,
+                                                  thresholdLogLKoptimization=ll, thresholdLogLKconsecutivePlacement=1.0,
+                                                  onlyFindIdentical=(MODEL == "siteerr")))
+prng = np.random.default_rng(5)
+qs = [tip_genome_list(perturb_diffs(dl, data.ref, prng, n_extra=k % 3), ref_idx, **tip_kw) for k, dl in enumerate(data.diffs[:64])]
+batch = ps.find_best_parent_batch(qs)
+same = sum(1 for q, g in zip(qs, batch) if (lambda w: g[0] == w[0] and g[1] == w[1] and g[3] == w[3] and g[4]["n_append"] == w[4]["n_append"])(ps.find_best_parent_host_replay(q)))
+print("batched placement == host replay on the tree with local references:", same, "of", len(qs))
