@@ -102,7 +102,7 @@ def main():
     ref_idx, root_freqs = reference_tables(data.ref)
     # genome-list arena: 4 GiB is plenty at 10 000 samples; bigger trees get more of the 288 GB (the per-frame removed
     # lists of the wide searches on trees with local references are the big temporary)
-    dev = Device(ref_idx, root_freqs, device=local_rank, arena_bytes=max(4 << 30, args.samples * (640 << 10)))
+    dev = Device(ref_idx, root_freqs, device=local_rank, arena_bytes=min(128 << 30, max(4 << 30, args.samples * (640 << 10))))
     mkw = model_kwargs(args.model, len(ref_idx))
     dev.set_model(**mkw)
     tip_kw = dict(error_rates=mkw["errorRates"]) if args.model == "siteerr" else {}

@@ -46,7 +46,7 @@ class TreeMirror:
         self.lower[np.asarray(tips, dtype=np.int64)] = ids
         self.launches = 0
 
-    def build(self, max_restarts=8):
+    def build(self, max_restarts=64):
         """Build all lists; zero-length branches that turn out to be inconsistent with the data (mergeVectors returns
         None, M:4757-4762; the reference then re-estimates the branch with updateBLen, M:5377-5414) are given the
         length of one tenth of a mutation and the build is restarted."""
@@ -76,9 +76,16 @@ class TreeMirror:
             c0, c1 = ch[nodes, 0], ch[nodes, 1]
             out = dev.merge_batch(self.lower[c0], dist[c0], self.is_tip[c0], self.lower[c1], dist[c1], self.is_tip[c1],
                                   False)
-            if (out < 0).any():
-                b = out < 0
-                return np.concatenate([c0[b], c1[b]])
+            b = out < 0
+            if b.any():
+                # a child's branch length does not enter the child's own lower list: lengthen the two branches and merge
+                # these pairs again instead of starting the whole build over
+                bump = np.concatenate([c0[b], c1[b]])
+                dist[bump] = np.maximum(dist[bump], 0.1 / dev.lRef)
+                out[b] = dev.merge_batch(self.lower[c0[b]], dist[c0[b]], self.is_tip[c0[b]], self.lower[c1[b]], dist[c1[b]],
+                                         self.is_tip[c1[b]], False)
+                if (out < 0).any():
+                    return np.concatenate([c0[out < 0], c1[out < 0]])
             self.lower[nodes] = dev.shorten_batch(out)
             self.launches += 2
         # pass 2 (M:6226-6345): upper lists from the root down
