@@ -60,6 +60,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate host time spent on cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spr", action="store_true", help="skip the secondary SPR-search-round measurement")
+    ap.add_argument("--spr-fast", action="store_true",
+                    help="secondary SPR round with the reference's fast initial parameters (strict, 2 fails, 6 log lRef) "
+                         "instead of the deep round; for very large trees")
+    ap.add_argument("--no-local-refs", action="store_true", help="skip the SPR round on the tree with MAT local references")
     ap.add_argument("--pairs", action="store_true", help="experiment: explicit (parent, child) index arrays, untiled kernel")
     ap.add_argument("--no-sort", action="store_true",
                     help="experiment: leave the candidate branches in tree pre-order instead of ordering them by list length")
@@ -188,7 +192,11 @@ def main():
         dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist,
                         mirror.is_tip, mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up,
                         -np.ones(mirror.n_nodes, dtype=np.int32))
-        kw = dict(strict=False, allowedFails=4, thresholdLogLKtopology=14.0 * log_lref, thresholdTopologyPlacement=-0.1,
+        if args.spr_fast:
+            kw = dict(strict=True, allowedFails=2, thresholdLogLKtopology=6.0 * log_lref)
+        else:
+            kw = dict(strict=False, allowedFails=4, thresholdLogLKtopology=14.0 * log_lref)
+        kw.update(thresholdTopologyPlacement=-0.1,
                   thresholdLogLKoptimizationTopology=1.0 * log_lref, thresholdLogLKconsecutivePlacement=1.0,
                   effectivelyNon0BLen=1.0 / (10 * l_ref))
         from maple_amd.parallel import sharded_spr_round
@@ -209,7 +217,8 @@ def main():
                "wall_ms": 1e3 * wall,
                "placements_per_s_kernel": float(res["nAppend"].sum() / (k_ms_spr * 1e-3)) if k_ms_spr else None,
                "placements_per_s_wall": float(res["nAppend"].sum() / wall),
-               "params": "deep round: non-strict, allowedFailsTopology 4, thresholdLogLKtopology 14 log(lRef)"}
+               "params": ("fast round: strict, allowedFailsTopology 2, thresholdLogLKtopology 6 log(lRef)" if args.spr_fast else
+                          "deep round: non-strict, allowedFailsTopology 4, thresholdLogLKtopology 14 log(lRef)")}
         # ---- and the batched placement search (findBestParentForNewSample for many samples on the frozen tree,
         # M:7912-8292 / 11190-11220): all-branch scoring + device-side traversal + short-list refinement ----
         pkw = dict(oneMutBLen=1.0 / l_ref, effectivelyNon0BLen=1.0 / (10 * l_ref), thresholdLogLK=18.0 * log_lref,
@@ -229,34 +238,36 @@ def main():
                      "reference_equivalent_placements_per_s": float(pres["nAppend"].sum() / pwall),
                      "branches_scored_per_s": float(Q * (Cn + 1) / pwall),
                      "minor_sequences": int((pres["status"] == 1).sum()), "failed": int((pres["status"] < 0).sum())}
-        # ---- the same deep round on the same tree after giving it MAT local references (setUpMAT's rule, 50 descendants
-        # per reference node, M:166 / 6152-6164): the form real MAPLE trees have; lists are shorter, every search crosses
-        # reference frames ----
-        from maple_amd.mat import add_local_references
-        from maple_amd.tree_host import HostTree
-        ht = HostTree.from_mirror(mirror)
-        t0 = time.perf_counter()
-        n_ref = add_local_references(dev, ht, 50)
-        mat_s = time.perf_counter() - t0
-        dev.upload_tree(ht.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist, mirror.is_tip,
-                        ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp, ht.id_mut)
-        dev.spr_search_batch(my_nodes, **kw)
-        dev.timing_reset()
-        t0 = time.perf_counter()
-        res_m = dev.spr_search_batch(my_nodes, **kw)
-        wall_m = time.perf_counter() - t0
-        n_lm, k_ms_m = dev.timing_read()
-        spr_mat = {"reference_nodes": int(n_ref), "setup_s": round(mat_s, 2), "queries": int(len(my_nodes)),
-                   "candidate_placements": int(res_m["nAppend"].sum()), "failed_or_overflow": int((res_m["status"] < 0).sum()),
-                   "proposed_moves": int((res_m["placement"] >= 0).sum()), "kernel_ms": k_ms_m, "launches": n_lm,
-                   "wall_ms": 1e3 * wall_m, "placements_per_s_kernel": float(res_m["nAppend"].sum() / (k_ms_m * 1e-3)),
-                   "placements_per_s_wall": float(res_m["nAppend"].sum() / wall_m),
-                   "same_moves_as_without_local_references": bool(np.array_equal(res_m["placement"], res["placement"])
-                                                                  and np.array_equal(res_m["nAppend"], res["nAppend"]))}
-        # back to the tree the rest of the run refers to
-        dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist,
-                        mirror.is_tip, mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up,
-                        -np.ones(mirror.n_nodes, dtype=np.int32))
+        spr_mat = None
+        if not args.no_local_refs:
+            # ---- the same deep round on the same tree after giving it MAT local references (setUpMAT's rule, 50 descendants
+            # per reference node, M:166 / 6152-6164): the form real MAPLE trees have; lists are shorter, every search crosses
+            # reference frames ----
+            from maple_amd.mat import add_local_references
+            from maple_amd.tree_host import HostTree
+            ht = HostTree.from_mirror(mirror)
+            t0 = time.perf_counter()
+            n_ref = add_local_references(dev, ht, 50)
+            mat_s = time.perf_counter() - t0
+            dev.upload_tree(ht.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist, mirror.is_tip,
+                            ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp, ht.id_mut)
+            dev.spr_search_batch(my_nodes, **kw)
+            dev.timing_reset()
+            t0 = time.perf_counter()
+            res_m = dev.spr_search_batch(my_nodes, **kw)
+            wall_m = time.perf_counter() - t0
+            n_lm, k_ms_m = dev.timing_read()
+            spr_mat = {"reference_nodes": int(n_ref), "setup_s": round(mat_s, 2), "queries": int(len(my_nodes)),
+                       "candidate_placements": int(res_m["nAppend"].sum()), "failed_or_overflow": int((res_m["status"] < 0).sum()),
+                       "proposed_moves": int((res_m["placement"] >= 0).sum()), "kernel_ms": k_ms_m, "launches": n_lm,
+                       "wall_ms": 1e3 * wall_m, "placements_per_s_kernel": float(res_m["nAppend"].sum() / (k_ms_m * 1e-3)),
+                       "placements_per_s_wall": float(res_m["nAppend"].sum() / wall_m),
+                       "same_moves_as_without_local_references": bool(np.array_equal(res_m["placement"], res["placement"])
+                                                                      and np.array_equal(res_m["nAppend"], res["nAppend"]))}
+            # back to the tree the rest of the run refers to
+            dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist,
+                            mirror.is_tip, mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up,
+                            -np.ones(mirror.n_nodes, dtype=np.int32))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             spr["cpu_baseline"] = spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, my_nodes, res, kw, args.cpu_seconds, mkw)
 
@@ -297,7 +308,8 @@ def main():
         }
         if spr is not None:
             out["spr_search"] = spr
-            out["spr_search_local_refs"] = spr_mat
+            if spr_mat is not None:
+                out["spr_search_local_refs"] = spr_mat
             out["placement_batch"] = placement
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs,
