@@ -211,7 +211,9 @@ def main():
         n_l, k_ms_spr = dev.timing_read()
         st = res["status"]
         spr = {"queries": int(len(my_nodes)), "searched": int((st == 0).sum()), "not_searched": int((st > 0).sum()),
-               "failed_or_overflow": int((st < 0).sum()), "candidate_placements": int(res["nAppend"].sum()),
+               "failed_or_overflow": int((st < 0).sum()),
+               "status_counts": {str(int(k)): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
+               "candidate_placements": int(res["nAppend"].sum()),
                "proposed_moves": int((res["placement"] >= 0).sum()), "proposed_moves_all_ranks": len(moves),
                "kernel_ms": k_ms_spr, "launches": n_l,
                "wall_ms": 1e3 * wall,

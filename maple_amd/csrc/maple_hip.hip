@@ -35,6 +35,15 @@ template <class T> struct DevBuf {     // grow-only device scratch
         cap = (e == hipSuccess) ? want : 0;
         return e;
     }
+    hipError_t reserve_exact(size_t n)     // for the very large buffers: no growth margin
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        cap = (e == hipSuccess) ? n : 0;
+        return e;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
@@ -1677,7 +1686,14 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             LaneBytes LB = lane_bytes(L);
             // lanes: one query per lane while they last; at most 4 wavefronts per SIMD (the kernel's occupancy) and a
             // workspace footprint bounded to ~96 GB of the 288 GB
-            const long long wsBudget = 96ll << 30;
+            long long wsBudget = 96ll << 30;
+            {   // ... and to 70 % of what is free on the device right now (plus what this buffer already holds)
+                size_t freeB = 0, totalB = 0;
+                if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+                    const long long avail = (long long)((double)(freeB + c->s_search_ws.cap) * 0.7);
+                    if (avail < wsBudget) wsBudget = avail;
+                }
+            }
             long long maxLanes = wsBudget / (long long)LB.total;
             if (maxLanes > 4096 * 64) maxLanes = 4096 * 64;
             if (maxLanes < 64) maxLanes = 64;
@@ -1687,7 +1703,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             if (activeLanes > 64) activeLanes = 64;
             const int nWaves = (lanesWanted + activeLanes - 1) / activeLanes;
             const int lanes = nWaves * activeLanes;
-            HIPCK(c, c->s_search_ws.reserve((size_t)lanes * LB.total));
+            HIPCK(c, c->s_search_ws.reserve_exact((size_t)lanes * LB.total));
             HIPCK(c, hipMemsetAsync(c->s_counter.p, 0, sizeof(int32_t), c->stream));
             TRY(h2d(c, c->s_i32[0], todo.data(), (size_t)m));
             if (cacheS) TRY(h2d(c, c->s_i32[1], rows.data(), (size_t)m));
@@ -1738,7 +1754,15 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         const PlaceMeta &F = *c->place;
         const int nT = c->dtree.n, nF = c->tree_has_mut ? F.nF : 1;
         const size_t rowBytes = (size_t)nT * sizeof(double);
-        size_t chunk = (size_t)(4ull << 30) / rowBytes;
+        size_t cacheBudget = (size_t)4ull << 30;                      // (query x node) score table: 4 GiB, more on big trees
+        {
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+                const size_t quarter = (freeB + c->s_cache.cap * sizeof(double)) / 4;
+                cacheBudget = std::max(cacheBudget, std::min(quarter, (size_t)32ull << 30));
+            }
+        }
+        size_t chunk = cacheBudget / rowBytes;
         if (chunk < 1) chunk = 1;
         size_t w0 = 0;
         while (w0 < wide.size()) {
