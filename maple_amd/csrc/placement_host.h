@@ -191,10 +191,12 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
         TRY(h2d(c, dU, U.data(), U.size()));
         HIPCK(c, c->p_score.reserve((size_t)nq * nCols));
         HIPCK(c, c->p_minor.reserve((size_t)nq * std::max(nL, 1)));
-        {
+        if (nF == 1)   // one reference frame: the plain batch kernel (query words staged in LDS) does the same job faster
+            TRY(launch_append_queries(c, c->stream, nq, dU.p, nCols, M.d_candList.p, 1, pp->oneMutBLen, c->p_score.p, nCols,
+                                      nullptr, nullptr, nullptr));
+        else
             TRY(launch_place_score(c, nq, nF, dU.p, nCols, M.d_candList.p, M.d_candFrame.p, 1, pp->oneMutBLen, c->p_score.p, nCols,
                                    nullptr, nullptr, nullptr));
-        }
         if (nL > 0) {
             hipLaunchKernelGGL(k_place_minor, dim3(grid_for((int)std::min<long long>((long long)nq * nL, 1 << 30))), dim3(MAPLE_BLOCK), 0,
                                c->stream, c->lRef, view(c), nq, nF, dU.p, nL, M.d_leafList.p, M.d_leafFrame.p,
