@@ -57,6 +57,8 @@ struct PlaceMeta {                     // derived from the uploaded tree, rebuil
     std::vector<int32_t> cand, leaves;             // node ids
     std::vector<int32_t> order;                    // nodes reachable from the root, depth-first
     std::vector<int32_t> h_candIdx, h_leafIdx;     // per node: column in the score / minor matrix or -1
+    std::vector<ScanRec> h_scan;                   // the tree in traversal order (placement_dev.h)
+    DevBuf<ScanRec> d_scan;
     DevBuf<int32_t> d_frameOf, d_candIdx, d_leafIdx, d_candList, d_candFrame, d_leafList, d_leafFrame;
 };
 
@@ -756,7 +758,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     c->p_score.release(); c->p_i16.release(); c->p_u8.release(); c->p_minor.release();
     if (c->place) {
         PlaceMeta &M = *c->place;
-        M.d_frameOf.release(); M.d_candIdx.release(); M.d_leafIdx.release(); M.d_candList.release(); M.d_candFrame.release();
+        M.d_scan.release(); M.d_frameOf.release(); M.d_candIdx.release(); M.d_leafIdx.release(); M.d_candList.release(); M.d_candFrame.release();
         M.d_leafList.release(); M.d_leafFrame.release();
         delete c->place;
     }

@@ -31,15 +31,26 @@ struct PlaceOut {
     uint8_t *bestShort;
 };
 
-// node columns: candIdx[v] = column of v in the score matrix or -1 (M:8049: dist > effectivelyNon0BLen, up != None);
-// leafIdx[v] = column of v in the minor-sequence matrix or -1; frameOf[v] = index of v's MAT reference frame.
-// The traversal of ONE query.  Lane q of nQ keeps element i of its stack / frame bits at [i * nQ + q] (coalesced when a
-// wavefront runs 64 queries; the host calls it with nQ = 1, q = 0 on plain arrays for very small batches, where one
-// lane's ~1 us per visit would dominate the call).
-__host__ __device__ inline void place_replay_one(const NodeRec *nd, int root, const PlaceParams &P, int q, int nQ,
-                                                 const double *sc, int rootCol, const int32_t *candIdx, const uint8_t *mn,
-                                                 const int32_t *leafIdx, const int32_t *frameOf, int nF, int stackCap,
-                                                 int32_t *stNode, double *stLK, int16_t *stFails, uint32_t *frameBits,
+// The tree in the traversal's own depth-first order (the child pushed last, child 1, first): rank r+1 is the first child
+// visited after rank r, and r + size skips r's clade.  A descent is then a forward scan over this array (sequential
+// loads that can be issued ahead) instead of a chase through child pointers, and the LIFO stack of the reference
+// becomes one (lastLK, fails) slot per depth: the state a node leaves for its children.
+struct alignas(32) ScanRec {
+    int32_t node;                      // external node id
+    int32_t size;                      // nodes in the clade rooted here (itself included)
+    int32_t depth;                     // root = 0
+    int32_t candCol;                   // column in the score matrix or -1 (M:8049: dist > effectivelyNon0BLen, up != None)
+    int32_t leafCol;                   // column in the minor-sequence matrix; >= 0 exactly for leaves
+    int32_t frame;                     // MAT reference frame of the node
+    int32_t pad[2];
+};
+
+// The traversal of ONE query over the scan array.  Lane q of nQ keeps element i of its per-depth state / frame bits at
+// [i * nQ + q] (coalesced when a wavefront runs 64 queries; the host calls it with nQ = 1, q = 0 on plain arrays for
+// very small batches, where one lane's latency would dominate the call).  frameOf[v] = frame of node v.
+__host__ __device__ inline void place_replay_one(const ScanRec *R, int nReach, const PlaceParams &P, int q, int nQ,
+                                                 const double *sc, int rootCol, const uint8_t *mn, const int32_t *frameOf,
+                                                 int nF, int stateCap, double *stLK, int16_t *stFails, uint32_t *frameBits,
                                                  const PlaceOut &o)
 {
     const int words = (nF + 31) >> 5;
@@ -47,56 +58,44 @@ __host__ __device__ inline void place_replay_one(const NodeRec *nd, int root, co
     int32_t *slN = o.slNode + (long long)q * MAPLE_PLACE_SHORTLIST;
     double *slL = o.slLK + (long long)q * MAPLE_PLACE_SHORTLIST;
     int nSl = 0, status = 0, minorNode = -1, missed = 0, nAppend = 1;
-    const NodeRec rr = nd[root];
+    const ScanRec rr = R[0];
+    const int root = rr.node;
     double bestLK = sc[rootCol];
     const double originalLK = bestLK;
     int bestNode = root;
-    int sp = 0;
-    // the item pushed last is popped next: it stays in registers (top*), so a visit waits for the node record only
-    int topNode = -1, topFails = 0;
-    double topLK = 0.0;
-    bool haveTop = false;
-#define MAPLE_PLACE_PUSH(NODE, LK, FAILS)                                                                              \
-    do {                                                                                                               \
-        if (haveTop) {                                                                                                 \
-            stNode[(long long)sp * nQ + q] = topNode; stLK[(long long)sp * nQ + q] = topLK;                            \
-            stFails[(long long)sp * nQ + q] = (int16_t)topFails; sp++;                                                 \
-        }                                                                                                              \
-        topNode = (NODE); topLK = (LK); topFails = (FAILS); haveTop = true;                                            \
-    } while (0)
-    if (rr.c0 < 0) {
-        if (leafIdx[root] >= 0 && mn[leafIdx[root]] == 1) { status = 1; minorNode = root; nAppend = 0; }
-    } else {
-        MAPLE_PLACE_PUSH(rr.c0, bestLK, 0);
-        MAPLE_PLACE_PUSH(rr.c1, bestLK, 0);
-    }
-    while ((haveTop || sp > 0) && status == 0) {                          // M:7972-8100
-        int t1, fails;
+    if (rr.leafCol >= 0 && mn[rr.leafCol] == 1) { status = 1; minorNode = root; nAppend = 0; }
+    // (lastLK, fails) a node hands to its children: in registers for the node just visited, in the per-depth slots for
+    // the ancestors a skipped or finished clade returns to
+    double curLK = bestLK;
+    int curFails = 0, prevDepth = 0;
+    stLK[q] = bestLK; stFails[q] = 0;                                     // depth 0
+    int r = rr.leafCol >= 0 ? nReach : 1;
+    ScanRec rec = r < nReach ? R[r] : rr;
+    while (r < nReach && status == 0) {                                   // M:7972-8100
+        // the traversal is almost always r -> r+1 (a leaf's clade is itself): the next record is issued before it is known
+        // to be needed.  (A 4-deep window of records AND their scores was slower, 4.7 vs 3.3 ms per batch: loads return
+        // in order, so the one load a visit does wait for queues behind the prefetches.)
+        const ScanRec ahead = R[r + 1 < nReach ? r + 1 : r];
+        const int d = rec.depth;
+        if (d >= stateCap) { status = -6; break; }
         double parentLK;
-        if (haveTop) { t1 = topNode; parentLK = topLK; fails = topFails; haveTop = false; }
-        else {
-            sp--;
-            t1 = stNode[(long long)sp * nQ + q];
-            parentLK = stLK[(long long)sp * nQ + q];
-            fails = stFails[(long long)sp * nQ + q];
-        }
-        // three independent loads, then two: the visit's dependent chain is two memory latencies deep
-        const int ci = candIdx[t1];
-        const int li = leafIdx[t1];
-        const NodeRec r = nd[t1];
-        const double sci = ci >= 0 ? sc[ci] : 0.0;
-        const int cmp = li >= 0 ? mn[li] : 0;
-        if (r.c0 < 0) {
+        int fails;
+        if (d == prevDepth + 1) { parentLK = curLK; fails = curFails; }
+        else { parentLK = stLK[(long long)(d - 1) * nQ + q]; fails = stFails[(long long)(d - 1) * nQ + q]; }
+        const double sci = rec.candCol >= 0 ? sc[rec.candCol] : 0.0;
+        const int cmp = rec.leafCol >= 0 ? mn[rec.leafCol] : 0;
+        const int t1 = rec.node;
+        if (rec.leafCol >= 0) {
             if (cmp == 1) { status = 1; minorNode = t1; break; }           // M:7986-8003
             if (cmp == 2) missed++;
         }
         double lk = parentLK;
-        if (ci >= 0) {
+        if (rec.candCol >= 0) {
             lk = sci;
             nAppend++;
             bool keep = false;
             if (lk >= bestLK) {                                           // M:8065-8073
-                const int f = r.frameOf;
+                const int f = rec.frame;
                 frameBits[(long long)(f >> 5) * nQ + q] |= 1u << (f & 31);
                 bestLK = lk; bestNode = t1; fails = 0; keep = true;
             } else if (lk > bestLK - P.thrOpt) keep = true;               // M:8074-8075
@@ -114,13 +113,11 @@ __host__ __device__ inline void place_replay_one(const NodeRec *nd, int root, co
         }
         const bool within = lk > bestLK - P.thrLK;
         const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);   // M:8080-8093
-        if (go && r.c0 >= 0) {
-            if (sp + 3 > stackCap) { status = -6; break; }
-            MAPLE_PLACE_PUSH(r.c0, lk, fails);
-            MAPLE_PLACE_PUSH(r.c1, lk, fails);
-        }
+        stLK[(long long)d * nQ + q] = lk; stFails[(long long)d * nQ + q] = (int16_t)fails;
+        curLK = lk; curFails = fails; prevDepth = d;
+        if ((go && rec.leafCol < 0) || rec.size == 1) { r += 1; rec = ahead; }   // into the clade, or past a leaf
+        else { r += rec.size; if (r < nReach) rec = R[r]; }               // past a pruned clade
     }
-#undef MAPLE_PLACE_PUSH
     // final filter of the short list (M:8109) and the state of each entry's query list object
     int k = 0;
     for (int i = 0; i < nSl; i++)
@@ -138,17 +135,16 @@ __host__ __device__ inline void place_replay_one(const NodeRec *nd, int root, co
     o.nAppend[q] = nAppend; o.missed[q] = missed; o.nShort[q] = nSl;
 }
 
-__global__ __launch_bounds__(64) void k_place_replay(DevTree T, PlaceParams P, int nQ, int nCols, int rootCol,
-                                                     const double *__restrict__ score, const int32_t *__restrict__ candIdx,
-                                                     int nLeaf, const uint8_t *__restrict__ minor,
-                                                     const int32_t *__restrict__ leafIdx, const int32_t *__restrict__ frameOf,
-                                                     int nF, int stackCap, int32_t *stNode, double *stLK, int16_t *stFails,
-                                                     uint32_t *frameBits, PlaceOut o)
+__global__ __launch_bounds__(64) void k_place_replay(const ScanRec *__restrict__ R, int nReach, PlaceParams P, int nQ, int nCols,
+                                                     int rootCol, const double *__restrict__ score, int nLeaf,
+                                                     const uint8_t *__restrict__ minor, const int32_t *__restrict__ frameOf,
+                                                     int nF, int stateCap, double *stLK, int16_t *stFails, uint32_t *frameBits,
+                                                     PlaceOut o)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nQ) return;
-    place_replay_one(T.nd, T.root, P, q, nQ, score + (long long)q * nCols, rootCol, candIdx, minor + (long long)q * nLeaf,
-                     leafIdx, frameOf, nF, stackCap, stNode, stLK, stFails, frameBits, o);
+    place_replay_one(R, nReach, P, q, nQ, score + (long long)q * nCols, rootCol, minor + (long long)q * nLeaf, frameOf, nF,
+                     stateCap, stLK, stFails, frameBits, o);
 }
 
 }  // namespace maple

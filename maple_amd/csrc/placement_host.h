@@ -105,6 +105,21 @@ static int place_meta(maple_ctx *c, double effNon0)
             leafFrame.push_back(M.frameOf[v]);
         }
     }
+    {   // the tree in traversal order: clade sizes and depths over compute_frames()'s depth-first order
+        const size_t nr = order.size();
+        std::vector<int32_t> size(n, 1), depth(n, 0);
+        for (size_t i = nr; i-- > 0;) { const int32_t v = order[i]; if (v != root && up[v] >= 0) size[up[v]] += size[v]; }
+        M.h_scan.assign(nr, ScanRec{});
+        for (size_t i = 0; i < nr; i++) {
+            const int32_t v = order[i];
+            if (v != root && up[v] >= 0) depth[v] = depth[up[v]] + 1;
+            ScanRec &r = M.h_scan[i];
+            r.node = v; r.size = size[v]; r.depth = depth[v];
+            r.candCol = candIdx[v]; r.leafCol = leafIdx[v]; r.frame = M.frameOf[v];
+            r.pad[0] = r.pad[1] = 0;
+        }
+        TRY(h2d(c, M.d_scan, M.h_scan.data(), nr));
+    }
     // reserve one extra candidate column for the root vector (its list id is filled in per call)
     candList.push_back(-1);
     candFrame.push_back(M.frameOf[root]);
@@ -225,7 +240,6 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
             o.missed = ib + 4 * (size_t)nq; o.nShort = ib + 5 * (size_t)nq; o.slNode = ib + 6 * (size_t)nq;
             o.bestLK = hf.data(); o.originalLK = hf.data() + nq; o.slLK = hf.data() + 2 * (size_t)nq;
             o.bestShort = hb.data(); o.slShort = hb.data() + nq;
-            std::vector<int32_t> stN(stackCap);
             std::vector<double> stL(stackCap);
             std::vector<int16_t> stF(stackCap);
             std::vector<uint32_t> bits(words);
@@ -235,14 +249,13 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
                 oq.status += q; oq.minorNode += q; oq.bestNode += q; oq.nAppend += q; oq.missed += q; oq.nShort += q;
                 oq.bestLK += q; oq.originalLK += q; oq.bestShort += q;
                 oq.slNode += (size_t)q * SL; oq.slLK += (size_t)q * SL; oq.slShort += (size_t)q * SL;
-                place_replay_one(c->h_nodes.data(), root, P, 0, 1, hs.data() + (size_t)q * nCols, nC, M.h_candIdx.data(),
-                                 hm.data() + (size_t)q * std::max(nL, 1), M.h_leafIdx.data(), M.frameOf.data(), nF, stackCap,
-                                 stN.data(), stL.data(), stF.data(), bits.data(), oq);
+                place_replay_one(M.h_scan.data(), (int)M.h_scan.size(), P, 0, 1, hs.data() + (size_t)q * nCols, nC,
+                                 hm.data() + (size_t)q * std::max(nL, 1), M.frameOf.data(), nF, stackCap, stL.data(), stF.data(),
+                                 bits.data(), oq);
             }
         } else {
-            HIPCK(c, c->p_i32[1].reserve((size_t)nq * stackCap));         // stack nodes
-            HIPCK(c, c->p_f64[0].reserve((size_t)nq * stackCap));         // stack lastLK
-            HIPCK(c, c->p_i16.reserve((size_t)nq * stackCap));            // stack fails
+            HIPCK(c, c->p_f64[0].reserve((size_t)nq * stackCap));         // per-depth lastLK
+            HIPCK(c, c->p_i16.reserve((size_t)nq * stackCap));            // per-depth fails
             HIPCK(c, c->p_i32[2].reserve((size_t)nq * words));            // frame bits
             HIPCK(c, c->p_i32[3].reserve((size_t)nq * (6 + SL)));         // status, minorNode, bestNode, nAppend, missed, nShort, slNode
             HIPCK(c, c->p_f64[1].reserve((size_t)nq * (2 + SL)));         // bestLK, originalLK, slLK
@@ -254,9 +267,9 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
             double *fb = c->p_f64[1].p;
             o.bestLK = fb; o.originalLK = fb + nq; o.slLK = fb + 2 * (size_t)nq;
             o.bestShort = c->p_u8.p; o.slShort = c->p_u8.p + nq;
-            hipLaunchKernelGGL(k_place_replay, dim3((nq + 63) / 64), dim3(64), 0, c->stream, c->dtree, P, nq, nCols, nC, c->p_score.p,
-                               M.d_candIdx.p, std::max(nL, 1), c->p_minor.p, M.d_leafIdx.p, M.d_frameOf.p, nF, stackCap,
-                               c->p_i32[1].p, c->p_f64[0].p, c->p_i16.p, (uint32_t *)c->p_i32[2].p, o);
+            hipLaunchKernelGGL(k_place_replay, dim3((nq + 63) / 64), dim3(64), 0, c->stream, M.d_scan.p, (int)M.h_scan.size(), P, nq,
+                               nCols, nC, c->p_score.p, std::max(nL, 1), c->p_minor.p, M.d_frameOf.p, nF, stackCap, c->p_f64[0].p,
+                               c->p_i16.p, (uint32_t *)c->p_i32[2].p, o);
             HIPCK(c, hipGetLastError());
             TRY(d2h_vec(c, hi, ib, (size_t)nq * (6 + SL)));
             TRY(d2h_vec(c, hf, fb, (size_t)nq * (2 + SL)));
