@@ -116,3 +116,77 @@ class GenomeOps:
         finally:
             d.release(mark)
         return tuple(float(x) for x in out[0])
+
+
+class TreeOps:
+    """The tree-level functions of the path under the reference's own names, on a ``HostTree`` whose lists live in the
+    device arena (``tree.upload(dev)`` or ``HostTree.from_mirror``).  Thin delegation: the work is in
+    ``maple_spr_search_batch`` / ``maple_placement_search_batch`` and the level-synchronous batches of ``tree_host``."""
+
+    def __init__(self, dev: Device, tree):
+        self.dev, self.tree = dev, tree
+        self._searcher = None
+        self._searcher_key = None
+
+    def upload_topology(self):
+        """(Re)send the topology and list ids after the host changed the tree (maple_tree_upload)."""
+        t = self.tree
+        up = np.asarray([-1 if u is None else u for u in t.up], dtype=np.int32)
+        c0 = np.asarray([c[0] if c else -1 for c in t.children], dtype=np.int32)
+        c1 = np.asarray([c[1] if c else -1 for c in t.children], dtype=np.int32)
+        tip = np.asarray([(not c) and (m == 0) for c, m in zip(t.children, t.n_minor)], dtype=np.uint8)
+        dist = np.asarray([float(x or 0.0) for x in t.dist])
+        self.dev.upload_tree(t.root, up, c0, c1, dist, tip, t.id_lower, t.id_upRight, t.id_upLeft, t.id_totUp, t.id_mut)
+        self._searcher = None
+
+    # M:7912 -- returns (bestNode, bestScore, bestBranchLengths, bestDiffs) like the reference
+    def findBestParentForNewSample(self, diffs, *, oneMutBLen, effectivelyNon0BLen, thresholdLogLK, thresholdLogLKoptimization,
+                                   thresholdLogLKconsecutivePlacement, allowedFails=5, strictStopRules=True,
+                                   onlyFindIdentical=False):
+        from .search import PlacementParams, PlacementSearcher
+        key = (oneMutBLen, effectivelyNon0BLen, thresholdLogLK, thresholdLogLKoptimization,
+               thresholdLogLKconsecutivePlacement, allowedFails, strictStopRules, onlyFindIdentical)
+        if self._searcher is None or self._searcher_key != key:
+            self._searcher = PlacementSearcher(self.dev, self.tree, PlacementParams(
+                oneMutBLen=oneMutBLen, effectivelyNon0BLen=effectivelyNon0BLen, thresholdLogLK=thresholdLogLK,
+                thresholdLogLKoptimization=thresholdLogLKoptimization,
+                thresholdLogLKconsecutivePlacement=thresholdLogLKconsecutivePlacement, allowedFails=allowedFails,
+                strictStopRules=strictStopRules, onlyFindIdentical=onlyFindIdentical))
+            self._searcher_key = key
+        return self._searcher.find_best_parent_for_new_sample(diffs)[:4]
+
+    # M:9580 -- the worker body for `nodes`; returns the list of (node, placement, improvement) the reference's worker returns
+    def startTopologyUpdatesParallel(self, nodes, *, strictTopologyStopRules, allowedFailsTopology, thresholdLogLKtopology,
+                                     thresholdTopologyPlacement, thresholdLogLKoptimizationTopology,
+                                     thresholdLogLKconsecutivePlacement, effectivelyNon0BLen):
+        res = self.dev.spr_search_batch(nodes, strict=strictTopologyStopRules, allowedFails=allowedFailsTopology,
+                                        thresholdLogLKtopology=thresholdLogLKtopology,
+                                        thresholdTopologyPlacement=thresholdTopologyPlacement,
+                                        thresholdLogLKoptimizationTopology=thresholdLogLKoptimizationTopology,
+                                        thresholdLogLKconsecutivePlacement=thresholdLogLKconsecutivePlacement,
+                                        effectivelyNon0BLen=effectivelyNon0BLen)
+        return [(int(n), int(p), float(i)) for n, p, i in zip(nodes, res["placement"], res["improvement"]) if p >= 0]
+
+    def reCalculateAllGenomeLists(self):                                   # M:6013
+        from .tree_host import rebuild_genome_lists
+        t = self.tree
+        t.id_lower, t.id_upRight, t.id_upLeft, t.id_totUp = rebuild_genome_lists(self.dev, t)
+
+    def updatePartials(self, changed_nodes):                               # M:5479 (level-synchronous, any number of changes)
+        from .tree_host import update_genome_lists
+        return update_genome_lists(self.dev, self.tree, list(changed_nodes))
+
+    def calculateTreeLikelihood(self):                                     # M:9721
+        from .tree_host import tree_log_likelihood
+        return tree_log_likelihood(self.dev, self.tree)[0]
+
+    def traverseTreeToOptimizeBranchLengths(self, effectivelyNon0BLen, fastPass=True):   # M:8727
+        from .tree_host import optimize_branch_lengths_fast_pass
+        if not fastPass:
+            raise NotImplementedError("the sequential sweep updates partials after every branch: call the fast pass, then "
+                                      "updatePartials / reCalculateAllGenomeLists")
+        return optimize_branch_lengths_fast_pass(self.dev, self.tree, effectivelyNon0BLen)[0]
+
+    def findBestRoot(self, **kw):                                          # M:7730 (the search; re-rooting stays with the caller)
+        from .tree_host import find_best_root
+        return find_best_root(self.dev, self.tree, **kw)

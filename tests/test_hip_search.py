@@ -501,3 +501,30 @@ def test_find_best_root_matches_reference(env):
         assert all(close(best_nodes[k], want[k], 1e-7, 1e-7) for k in want), \
             [(k, best_nodes[k], want[k]) for k in want if not close(best_nodes[k], want[k], 1e-7, 1e-7)][:5]
         assert len(want) > 100
+
+
+def test_tree_ops_under_reference_names(env):
+    """maple_amd.ops.TreeOps: the tree-level functions under the reference's names give the recorded answers."""
+    from maple_amd.ops import TreeOps
+    f, dev, tree = env
+    ctx = f["context"]
+    ops = TreeOps(dev, tree)
+    if "treeLK" in f:
+        assert close(ops.calculateTreeLikelihood(), f["treeLK"], 1e-9)
+    rnd = f["spr"][0]
+    ps = rnd["params"]
+    nodes = [tree.children[c["node"]][c["child"]] for c in rnd["calls"]]
+    moves = ops.startTopologyUpdatesParallel(
+        nodes, strictTopologyStopRules=ps["strict"], allowedFailsTopology=ps["fails"], thresholdLogLKtopology=ps["thr"],
+        thresholdTopologyPlacement=ps["place"], thresholdLogLKoptimizationTopology=ctx["thresholdLogLKoptimizationTopology"],
+        thresholdLogLKconsecutivePlacement=ctx["thresholdLogLKconsecutivePlacement"],
+        effectivelyNon0BLen=ctx["effectivelyNon0BLen"])
+    assert sorted((m[0], m[1]) for m in moves) == sorted((m[0], m[1]) for m in rnd["proposedMoves"])
+    rec = f["placements"][0]
+    only_identical = any(x in f["flags"] for x in ("--estimateErrorRate", "--estimateSiteSpecificErrorRate"))
+    node, score, blens, diffs = ops.findBestParentForNewSample(
+        tup(rec["query"]), oneMutBLen=ctx["oneMutBLen"], effectivelyNon0BLen=ctx["effectivelyNon0BLen"],
+        thresholdLogLK=ctx["thresholdLogLK"], thresholdLogLKoptimization=ctx["thresholdLogLKoptimization"],
+        thresholdLogLKconsecutivePlacement=ctx["thresholdLogLKconsecutivePlacement"], allowedFails=ctx["allowedFails"],
+        strictStopRules=ctx["strictStopRules"], onlyFindIdentical=only_identical)
+    assert node == rec["ret"]["bestNode"] and close(score, rec["ret"]["bestScore"], 1e-9)
