@@ -56,6 +56,8 @@ def gather_proposals(local_records, device=None):
         dist.all_gather(counts, cnt)
         counts = [int(c.item()) for c in counts]
         m = max(counts) if counts else 0
+        if m == 0:                                                  # nobody proposes a move: nothing to exchange
+            return []
         pad = torch.zeros((m, 3), dtype=torch.float64, device=rec.device)
         pad[: rec.shape[0]] = rec
         bufs = [torch.zeros_like(pad) for _ in range(world)]
