@@ -206,6 +206,11 @@ typedef struct {
  * appending; False -> 0.0), bestDiffs = id of the list the reference returns as bestDiffs (a new or an input list),
  * nAppend = appendProbNode evaluations the REFERENCE would have issued, status: 0 placed by likelihood,
  * 1 = the query is a minor sequence of bestNode (score 1.0, M:7986-8003), -6 short list or stack overflow. */
+/* Optional: derive the per-tree tables of the placement search (candidate columns, traversal order) and the root vector
+ * (rootVector(probVect[root]), M:7958, one new arena list) now, OUTSIDE any arena mark of the caller, so that the
+ * searches that follow do not recompute them; they are dropped when the tree is uploaded again or the arena is released
+ * below them. */
+int maple_placement_prepare(maple_ctx *ctx, const maple_placement_params *params);
 int maple_placement_search_batch(maple_ctx *ctx, int32_t nQ, const int32_t *qLists, const maple_placement_params *params,
                                  int32_t *bestNode, double *bestScore, double *blen3, int32_t *bestDiffs,
                                  int32_t *nAppend, int32_t *status);

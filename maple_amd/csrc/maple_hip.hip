@@ -6,6 +6,7 @@
 #include "placement_dev.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -56,6 +57,7 @@ struct PlaceMeta {                     // derived from the uploaded tree, rebuil
     std::vector<int32_t> levelStart;               // frames 1.. sorted by nesting depth; level l = [levelStart[l], levelStart[l+1])
     std::vector<int32_t> cand, leaves;             // node ids
     std::vector<int32_t> order;                    // nodes reachable from the root, depth-first
+    int32_t rootVect = -1;                         // rootVector(probVect[root]) of the uploaded tree (list id), kept while it lives
     std::vector<int32_t> h_candIdx, h_leafIdx;     // per node: column in the score / minor matrix or -1
     std::vector<ScanRec> h_scan;                   // the tree in traversal order (placement_dev.h)
     DevBuf<ScanRec> d_scan;
@@ -950,6 +952,7 @@ extern "C" int maple_arena_release(maple_ctx *c, int64_t mark)
     c->used_ent = c->h_ent_off[mark];
     c->used_aux = c->h_aux_off[mark];
     c->h_ent_off.resize(mark); c->h_aux_off.resize(mark); c->h_n_ent.resize(mark); c->h_n_aux.resize(mark);
+    if (c->place && c->place->rootVect >= mark) c->place->rootVect = -1;     // the cached root vector went with the release
     return MAPLE_OK;
 }
 
@@ -1559,6 +1562,7 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     c->h_tree_upLeft.assign(upLeft, upLeft + n);
     if (!c->place) c->place = new PlaceMeta();
     c->place->valid = false;
+    c->place->rootVect = -1;
     c->dtree.n = n; c->dtree.root = root;
     TRY(compute_frames(c));
     const PlaceMeta &F = *c->place;

@@ -143,6 +143,25 @@ template <class T> static int d2h_vec(maple_ctx *c, std::vector<T> &dst, const T
     return MAPLE_OK;
 }
 
+extern "C" int maple_placement_prepare(maple_ctx *c, const maple_placement_params *pp)
+{
+    if (!c || !pp) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    if (!c->tree_set) return fail(c, MAPLE_ERR_STATE, "maple_tree_upload has not been called");
+    TRY(place_meta(c, pp->effectivelyNon0BLen));
+    PlaceMeta &M = *c->place;
+    if (M.rootVect < 0) {
+        const int32_t root = c->dtree.root;
+        const double zero = 0.0;
+        const uint8_t nt = 0;
+        const int64_t off[2] = {0, c->h_tree_mut[root] >= 0 ? 1 : 0};
+        const int32_t path[1] = {c->h_tree_mut[root]};
+        TRY(maple_root_vector_batch(c, 1, &c->h_tree_lower[root], &zero, &nt, off, path, &M.rootVect));
+    }
+    return MAPLE_OK;
+}
+
 extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int32_t *qLists, const maple_placement_params *pp,
                                             int32_t *bestNode, double *bestScore, double *blen3, int32_t *bestDiffs,
                                             int32_t *nAppend, int32_t *status)
@@ -159,17 +178,24 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
     const int32_t nF = M.nF, nC = (int32_t)M.cand.size(), nCols = nC + 1, nL = (int32_t)M.leaves.size();
     const int32_t root = c->dtree.root;
     const auto &mut = c->h_tree_mut;
+    const bool dbg = getenv("MAPLE_DEBUG_PLACE") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tus = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return (long long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count();
+    };
+    auto t0 = tnow();
     // rootVector(probVect[root], False, False, tree, root), M:7958: does not depend on the query
-    int32_t rootVect = -1;
-    {
+    // (kept across calls while the arena is not released below it: call maple_placement_prepare before taking a mark)
+    if (M.rootVect < 0) {
         const double zero = 0.0;
         const uint8_t nt = 0;
         const int64_t off[2] = {0, mut[root] >= 0 ? 1 : 0};
         const int32_t path[1] = {mut[root]};
-        TRY(maple_root_vector_batch(c, 1, &c->h_tree_lower[root], &zero, &nt, off, path, &rootVect));
-        HIPCK(c, hipMemcpyAsync(M.d_candList.p + nC, &rootVect, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIPCK(c, hipStreamSynchronize(c->stream));
+        TRY(maple_root_vector_batch(c, 1, &c->h_tree_lower[root], &zero, &nt, off, path, &M.rootVect));
     }
+    const int32_t rootVect = M.rootVect;
+    HIPCK(c, hipMemcpyAsync(M.d_candList.p + nC, &rootVect, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    auto t1 = tnow();
     PlaceParams P;
     P.thrLK = pp->thresholdLogLK; P.thrOpt = pp->thresholdLogLKoptimization; P.thrConsec = pp->thresholdLogLKconsecutivePlacement;
     P.allowedFails = pp->allowedFails; P.strict = pp->strictStopRules;
@@ -201,6 +227,7 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
                 a = b;
             }
         }
+        auto t2 = tnow();
         // ---- scores, minor tests, traversal
         DevBuf<int32_t> &dU = c->p_i32[0];
         TRY(h2d(c, dU, U.data(), U.size()));
@@ -276,6 +303,7 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
             TRY(d2h_vec(c, hb, c->p_u8.p, (size_t)nq * (1 + SL)));
             HIPCK(c, hipStreamSynchronize(c->stream));
         }
+        auto t3 = tnow();
         const int32_t *hStatus = hi.data(), *hMinor = hi.data() + nq, *hBest = hi.data() + 2 * (size_t)nq,
                       *hNApp = hi.data() + 3 * (size_t)nq, *hNShort = hi.data() + 5 * (size_t)nq,
                       *hSlNode = hi.data() + 6 * (size_t)nq;
@@ -305,6 +333,7 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
             const size_t key = (size_t)q * nF + M.frameOf[node];
             return shortened ? S[key] : U[key];
         };
+        auto t4 = tnow();
         // ---- short-list refinement, M:8101-8187: one batch over every (query, short-listed node)
         std::vector<int32_t> rq, rnode, ridx;
         for (int q = 0; q < nq; q++)
@@ -350,6 +379,9 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
             }
             TRY(maple_append_batch(c, (int32_t)(2 * nr), ap.data(), ac.data(), atip.data(), abl.data(), comp.data()));
         }
+        auto t5 = tnow();
+        if (dbg) fprintf(stderr, "[maple] placement batch of %d: root vector %lld us, frames %lld, score+minor+traversal %lld, shorten %lld, refine %lld\n",
+                         nq, tus(t0, t1), tus(t1, t2), tus(t2, t3), tus(t3, t4), tus(t4, t5));
         // ---- outcome per query
         size_t r = 0;
         for (int q = 0; q < nq; q++) {

@@ -23,7 +23,7 @@ EXPORTS = [
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
     "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
-    "maple_minor_candset", "maple_placement_search_batch", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
+    "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
 ]
 
 
@@ -359,6 +359,14 @@ class Device:
         if want_removed_partials:
             out["removedPartials"] = rpr
         return out
+
+    def placement_prepare(self, *, oneMutBLen, effectivelyNon0BLen, thresholdLogLK, thresholdLogLKoptimization,
+                          thresholdLogLKconsecutivePlacement, allowedFails=5, strictStopRules=True, onlyFindIdentical=False):
+        """Per-tree tables + root vector of the placement search, created outside any arena mark of the caller."""
+        pp = MaplePlacementParams(oneMutBLen, effectivelyNon0BLen, thresholdLogLK, thresholdLogLKoptimization,
+                                  thresholdLogLKconsecutivePlacement, int(allowedFails), int(bool(strictStopRules)),
+                                  int(bool(onlyFindIdentical)))
+        self._ck(self.lib.maple_placement_prepare(self.h, C.byref(pp)))
 
     def placement_search_batch(self, q_lists, *, oneMutBLen, effectivelyNon0BLen, thresholdLogLK,
                                thresholdLogLKoptimization, thresholdLogLKconsecutivePlacement, allowedFails=5,

@@ -115,11 +115,23 @@ class PlacementSearcher:
         S = {k: (int(s) if a != b else U[k]) for k, s, a, b in zip(keys, s_ids, ne_u, ne_s)}
         return U, S
 
+    def _prepare_native(self):
+        if getattr(self, "_prepared", False) or not getattr(self.dev, "n_nodes", 0):
+            return
+        p = self.p
+        self.dev.placement_prepare(
+            oneMutBLen=p.oneMutBLen, effectivelyNon0BLen=p.effectivelyNon0BLen, thresholdLogLK=p.thresholdLogLK,
+            thresholdLogLKoptimization=p.thresholdLogLKoptimization,
+            thresholdLogLKconsecutivePlacement=p.thresholdLogLKconsecutivePlacement, allowedFails=p.allowedFails,
+            strictStopRules=p.strictStopRules, onlyFindIdentical=p.onlyFindIdentical)
+        self._prepared = True
+
     def find_best_parent_batch(self, diffs_list):
         """Many queries against the frozen tree in one native call (maple_placement_search_batch): scoring, the
         reference's traversal (on the device, one lane per query) and the short-list refinement are all batched.
         Returns a list of (bestNode, bestScore, bestBranchLengths, bestDiffs, info) like the single-query form."""
         dev, p = self.dev, self.p
+        self._prepare_native()                                       # per-tree tables and root vector, before the mark
         mark = dev.mark()
         try:
             q_ids = dev.upload(list(diffs_list))
