@@ -13,7 +13,8 @@ from maple_amd.tree_host import HostTree
 from maple_amd.tree_mirror import TreeMirror
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
 MODEL = os.environ.get("MODEL", "unrest")
-data = make_dataset(n_samples=n, l_ref=29903, seed=1, mean_diffs=30.0, rate_variation=(MODEL != "unrest"))
+SEED = int(os.environ.get("SEED", "1"))
+data = make_dataset(n_samples=n, l_ref=29903, seed=SEED, mean_diffs=30.0, rate_variation=(MODEL != "unrest"), frac_with_n=0.05, frac_ambig=0.05)
 ref_idx, rf = reference_tables(data.ref)
 dev = Device(ref_idx, rf, arena_bytes=max(4 << 30, n * (640 << 10)))
 mkw = bench.model_kwargs(MODEL, len(ref_idx))
@@ -50,3 +51,16 @@ qs = [tip_genome_list(perturb_diffs(dl, data.ref, prng, n_extra=k % 3), ref_idx,
 batch = ps.find_best_parent_batch(qs)
 same = sum(1 for q, g in zip(qs, batch) if (lambda w: g[0] == w[0] and g[1] == w[1] and g[3] == w[3] and g[4]["n_append"] == w[4]["n_append"])(ps.find_best_parent_host_replay(q)))
 print("batched placement == host replay on the tree with local references:", same, "of", len(qs))
+# the C oracle's search (pinned to the reference's records) on a sample of the nodes of the same tree
+if os.environ.get("ORACLE"):
+    from oracle.oracle_py import Oracle, OracleTree
+    orc = Oracle(ref_idx, rf)
+    orc.set_model(**mkw)
+    lists4 = [dev.download(ids) for ids in (ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp)]
+    otree = OracleTree(orc, ht.root, ht.up, ht.children, np.asarray([float(x or 0.0) for x in ht.dist]), ht.mutations, [0] * ht.n, lists4)
+    sel = nodes[::int(os.environ["ORACLE"])]
+    o = orc.spr_worker(otree, sel, **kw)
+    for k in ("status", "bestNode", "placement", "nAppend"):
+        print("oracle", k, "equal:", np.array_equal(hyb[k][sel], o[k]), "mismatches:", int((hyb[k][sel] != o[k]).sum()))
+    fin = np.isfinite(o["bestScore"]) & np.isfinite(hyb["bestScore"][sel])
+    print("oracle bestScore max rel diff:", float((np.abs(hyb["bestScore"][sel][fin] - o["bestScore"][fin]) / np.maximum(1.0, np.abs(o["bestScore"][fin]))).max()))
