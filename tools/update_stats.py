@@ -48,3 +48,22 @@ print(f"findBestRoot search: all {nn - 1} branches scored in {dt * 1e3:.1f} ms; 
 t0 = time.perf_counter()
 upd, _ = optimize_branch_lengths_fast_pass(dev, ht2, 1.0 / (10 * dev.lRef))
 print(f"fast branch-length pass: {upd} of {nn - 1} lengths replaced in {(time.perf_counter() - t0) * 1e3:.1f} ms")
+# consistency at scale, with MAT local references: the repaired lists against a full rebuild of the changed tree
+from maple_amd.mat import add_local_references
+from maple_amd.tree_host import tree_log_likelihood
+ht3 = HostTree.from_mirror(m)
+print("reference nodes", add_local_references(dev, ht3, 50))
+pick = rng.choice(cand, size=200, replace=False)
+for v in pick:
+    ht3.dist[v] = ht3.dist[v] * 2.5
+rep = update_genome_lists(dev, ht3, pick.tolist())
+lk_upd, _ = tree_log_likelihood(dev, ht3)
+lo, ur, ul, tu = rebuild_genome_lists(dev, ht3)
+bad = 0
+for a, b in ((ht3.id_lower, lo), (ht3.id_upRight, ur), (ht3.id_upLeft, ul), (ht3.id_totUp, tu)):
+    ok = (a >= 0) & (b >= 0)
+    bad += int((dev.differ_batch(a[ok], b[ok]) | dev.differ_batch(b[ok], a[ok])).sum()) + int(((a >= 0) != (b >= 0)).sum())
+ht3.id_lower, ht3.id_upRight, ht3.id_upLeft, ht3.id_totUp = lo, ur, ul, tu
+lk_reb, _ = tree_log_likelihood(dev, ht3)
+print(f"200 changes on the tree with local references: {rep} lists replaced; lists that differ from a full rebuild by the "
+      f"reference's own thresholds: {bad}; tree log-LK {lk_upd:.6f} vs {lk_reb:.6f} (rel {abs(lk_upd - lk_reb) / abs(lk_reb):.1e})")
