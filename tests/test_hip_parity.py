@@ -250,3 +250,50 @@ def test_append_queries_dev_matches_pair_batches(env):
                 assert close(float(got[q, k]), float(want[q, k]), 1e-12), (q, k, got[q, k], want[q, k])
             if recs[q]["bLen"] == bl:
                 assert close(float(got[q, q]), recs[q]["ret"], REL)
+
+
+def test_edge_cases_through_the_c_abi():
+    """Empty batches, whole-genome N / R lists, bad list ids and an exhausted arena: defined results or a clean error
+    (MapleError with the library's message), never a crash."""
+    from maple_amd.runtime import Device, MapleError
+    from oracle.oracle_py import Oracle
+    l_ref = 500
+    ref_idx = np.arange(l_ref, dtype=np.uint8) % 4
+    rf = [0.3, 0.2, 0.2, 0.3]
+    Qm = [[-0.9, 0.2, 0.5, 0.2], [0.3, -1.4, 0.1, 1.0], [0.8, 0.1, -1.3, 0.4], [0.1, 0.6, 0.1, -0.8]]
+    dev = Device(ref_idx, rf, arena_bytes=1 << 20)
+    dev.set_model(Qm)
+    orc = Oracle(ref_idx, rf)
+    orc.set_model(Qm)
+    # empty batches
+    assert len(dev.append_batch([], [], [], [])) == 0
+    assert len(dev.merge_batch([], [], [], [], [], [], False)) == 0
+    assert len(dev.shorten_batch([])) == 0
+    # degenerate lists: everything unknown / everything reference / one site each side
+    all_n, all_r = [(5, l_ref)], [(4, l_ref)]
+    one = [(4, 249), (2, int(ref_idx[249])), (4, l_ref)] if ref_idx[249] != 2 else [(4, 249), (1, int(ref_idx[249])), (4, l_ref)]
+    ids = dev.upload([all_n, all_r, one])
+    pairs = [(0, 0), (0, 1), (1, 0), (1, 1), (1, 2), (2, 1), (2, 2), (0, 2)]
+    lists = [all_n, all_r, one]
+    got = dev.append_batch([ids[a] for a, b in pairs], [ids[b] for a, b in pairs], True, 1e-3)
+    for (a, b), g in zip(pairs, got):
+        want = orc.appendProbNode(lists[a], lists[b], True, 1e-3)
+        assert (math.isinf(want) and math.isinf(g)) or close(float(g), want, 1e-12), (a, b, g, want)
+    merged = dev.download(dev.merge_batch([ids[a] for a, b in pairs], 1e-3, True, [ids[b] for a, b in pairs], 2e-3, True, False))
+    for (a, b), g in zip(pairs, merged):
+        want = orc.mergeVectors(lists[a], 1e-3, True, lists[b], 2e-3, True)
+        assert (want is None and g is None) or lists_match(g, want, 1e-12), (a, b, g, want)
+    # a list id that does not exist
+    with pytest.raises(MapleError):
+        dev.append_batch([999999], [ids[0]], True, 1e-3)
+    with pytest.raises(MapleError):
+        dev.shorten_batch([-7])
+    # arena exhaustion is reported, and the context stays usable after releasing
+    mark = dev.mark()
+    big = [(4, 1)] + [((k % 3 + 1 + int(ref_idx[k])) % 4, int(ref_idx[k])) for k in range(1, l_ref - 1)] + [(4, l_ref)]
+    with pytest.raises(MapleError):
+        for _ in range(4000):
+            dev.upload([big] * 64)
+    dev.release(mark)
+    assert close(float(dev.append_batch([ids[1]], [ids[2]], True, 1e-3)[0]), orc.appendProbNode(all_r, one, True, 1e-3), 1e-12)
+    dev.close()
