@@ -1704,7 +1704,10 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             if (maxLanes > 4096 * 64) maxLanes = 4096 * 64;
             if (maxLanes < 64) maxLanes = 64;
             const int lanesWanted = (int)(m < maxLanes ? m : maxLanes);
-            int activeLanes = (lanesWanted + 16383) / 16384;           // per wavefront (measured at 20k queries: 2 lanes beat 1, 4 and 10)
+            // searching lanes per wavefront (measured at 20k queries: the long searches of a non-strict round like 2 lanes,
+            // 42 vs 46 ms with 1; the short ones of a strict round like 1, 31 vs 37 ms with 2; more is always worse)
+            const int lanesDiv = P.strict ? 32768 : 16384;
+            int activeLanes = (lanesWanted + lanesDiv - 1) / lanesDiv;
             if (activeLanes < 1) activeLanes = 1;
             if (activeLanes > 64) activeLanes = 64;
             const int nWaves = (lanesWanted + activeLanes - 1) / activeLanes;
