@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""One-off check at scale (GPU box): on a tree with MAT local references the hybrid (batch-scored, replayed) deep round
+"""Stress check at scale (GPU box, run by hand: python tests/stress_mat_hybrid.py N; not collected by pytest): on a tree with MAT local references the hybrid (batch-scored, replayed) deep round
 must equal the lane-only search query by query."""
 import math, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root (bench, maple_amd, oracle)
 import bench
 from maple_amd.host import reference_tables, tip_genome_list
 from maple_amd.mat import add_local_references
