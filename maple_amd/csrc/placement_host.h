@@ -199,9 +199,10 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
     PlaceParams P;
     P.thrLK = pp->thresholdLogLK; P.thrOpt = pp->thresholdLogLKoptimization; P.thrConsec = pp->thresholdLogLKconsecutivePlacement;
     P.allowedFails = pp->allowedFails; P.strict = pp->strictStopRules;
-    // queries per chunk: the score matrix stays below 2 GiB
+    // queries per chunk: the score matrix stays below 2 GiB and the per-frame query lists below 8 M arena lists
     const int64_t maxCells = (int64_t)1 << 28;
-    const int32_t chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(nQ, maxCells / std::max(nCols, 1)));
+    const int64_t byFrames = std::max<int64_t>(1, ((int64_t)8 << 20) / std::max(nF, 1));
+    const int32_t chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nQ, byFrames), maxCells / std::max(nCols, 1)));
     const int stackCap = M.maxDepth + 4, words = (nF + 31) / 32;
     for (int32_t q0 = 0; q0 < nQ; q0 += chunk) {
         const int32_t nq = std::min(chunk, nQ - q0);
