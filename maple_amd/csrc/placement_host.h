@@ -1,9 +1,10 @@
 // maple_placement_search_batch: findBestParentForNewSample (MAPLEv0.7.5.4.py:7912-8292) for MANY query samples on one
 // frozen tree (the shape of --findSamplePlacements / --lineageRefs, M:11190-11220, and of online batches).
-// Included at the end of maple_hip.hip; composes the library's own batch entry points plus three kernels:
+// Included by maple_hip.hip ahead of the tree-mirror section; composes the library's own batch entry points plus three kernels:
 //   k_place_score  - every query against every candidate branch, each in the candidate's MAT reference frame
 //   k_place_minor  - isMinorSequence of every query against every leaf
-//   k_place_replay - the reference's depth-first traversal over those scores, one lane per query
+//   k_place_replay - the reference's depth-first traversal over those scores, one lane per query (a forward scan of the tree
+//                    laid out in traversal order)
 #pragma once
 
 // same scheduling as k_append_queries (dynamic 64-candidate tiles per wavefront, candidate-chunk-major, candidates sorted by
