@@ -118,6 +118,11 @@ struct maple_ctx {
     int32_t tree_max_ent = 0;          // longest genome list of the uploaded tree (entries)
     int32_t n_scored = 0;              // nodes with a probVectTotUp, sorted by list length: t_i32[8] = list ids, t_scored_col = node ids
     DevBuf<int32_t> t_scored_col, t_scored_frame;
+    DevBuf<SScan> t_scan;              // the tree in the searches' depth-first order (search_dev.h), per effectivelyNon0BLen
+    DevBuf<int32_t> t_scan_parent;
+    bool scan_valid = false;
+    double scan_eff = -1.0;
+    int32_t tree_max_depth = 0;
     // SPR search workspace
     DevBuf<uint8_t> s_search_ws;
     DevBuf<uint8_t> s_search_out;
@@ -518,8 +523,12 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
     Ctx<RV, U, SS> c(m, lds);
     // only the first `activeLanes` lanes of every wavefront search: with few queries it is better to spread them
     // over many wavefronts (a wavefront executes the union of its lanes' control paths) than to fill 64-wide waves
-    if ((int)threadIdx.x >= activeLanes) return;
-    const size_t lane = (size_t)blockIdx.x * activeLanes + threadIdx.x;
+    // Cached (whole-tree) launches run ONE search per wavefront (activeLanes == 1): lane 0 is the state machine, and all 64
+    // lanes join it whenever the search descends into a clade in the cached regime (wave_scan_clade, search_dev.h).
+    const bool coop = T.scan != nullptr;
+    if (!coop && (int)threadIdx.x >= activeLanes) return;
+    const bool searcher = (int)threadIdx.x < activeLanes;
+    const size_t lane = (size_t)blockIdx.x * activeLanes + (searcher ? threadIdx.x : 0);
     uint8_t *base = wsBase + lane * LB.total;
     LaneWs ws;
     ws.w = (uint2 *)base;
@@ -530,13 +539,19 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
     ws.ais = (double *)(base + LB.w + LB.aux + LB.h + LB.st + LB.best);
     ws.L = L;
     Search<RV, U, SS> S(c, av, mv, T, P, ws);
-    bool active = false;
-    int q = -1, node = -1;
+    extern __shared__ double dynLds[];   // coop: per-depth (lastLK, failedPasses) slots of the clade scan
+    double *slotLK = dynLds;
+    int *slotFails = (int *)(dynLds + T.scanDepthCap);
+    unsigned *slotOwner = (unsigned *)(slotFails + T.scanDepthCap);
+    bool active = false, done = !searcher;
+    int q = -1, node = -1, curRow = 0;
     double curLK = 0.0;
     for (;;) {
+        S.wantScan = false;
+        if (!done) do {                 // (`continue` below ends this pass of the state machine)
         if (!active) {
             q = atomicAdd(counter, 1);
-            if (q >= n) break;
+            if (q >= n) { done = true; break; }
             node = nodes[q];
             ws.usedW = ws.usedA = ws.nH = ws.sp = ws.nB = 0;
             ws.overflow = 0;
@@ -546,6 +561,7 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             o.bestScore = 0.0; o.improvement = 0.0; o.currentLK = 0.0;
             o.blen[0] = o.blen[1] = o.blen[2] = 0.0;
             o.rprWoff = o.rprAoff = -1; o.rprN = o.rprNA = 0;
+            o.nShortList = o.nSteps = 0; o.tStep = o.tReplay = o.tRefine = 0;
             const int parent = T.nd[node].up;
             if (parent < 0) { o.status = 1; continue; }               // the root cannot be re-placed (M:9626)
             // current placement cost, M:9629-9646
@@ -557,6 +573,7 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             if (!(curLK < P.thrPlacement || T.nd[node].dist != 0.0)) { o.status = 2; continue; }   // M:9674
             ws.usedW = ws.usedA = ws.nH = 0;
             const size_t row = cacheRow ? (size_t)cacheRow[q] : (size_t)q;
+            curRow = (int)row;
             S.cached = cacheS ? cacheS + row * T.n : nullptr;             // this query's row of the (queries x nodes) score table
             S.rTable = (cacheS && rTable) ? rTable + row * nF : nullptr;  // and of the (queries x frames) removed lists
             S.fShort[0] = S.fShort[1] = S.fShort[2] = S.fShort[3] = -1;
@@ -578,10 +595,24 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             out[q].status = -5;                                       // a wide search: the host batch-scores it and re-runs it
             active = false;
         } else if (ws.sp > 0) {
+#ifdef MAPLE_SPR_PROFILE
+            const long long t0 = wall_clock64();
+            const bool rep = S.cached && !ws.st[ws.sp - 1].upd;
+            if (rep) S.replayCached(); else { S.step(); out[q].nSteps++; }
+            if (rep) out[q].tReplay += wall_clock64() - t0; else out[q].tStep += wall_clock64() - t0;
+#else
             if (S.cached && !ws.st[ws.sp - 1].upd) S.replayCached();
             else S.step();
+#endif
         } else if (S.refineIdx < ws.nB) {
+#ifdef MAPLE_SPR_PROFILE
+            const long long t0 = wall_clock64();
+            out[q].nShortList++;
             int r = S.refine(ws.best[S.refineIdx++]);
+            out[q].tRefine += wall_clock64() - t0;
+#else
+            int r = S.refine(ws.best[S.refineIdx++]);
+#endif
             if (r < 0 && !ws.overflow) {                              // the reference raises here; its worker swallows it (M:9703)
                 SearchOut &o = out[q];
                 o.status = -1; o.nAppend = S.nAppend;
@@ -622,6 +653,45 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             }
             active = false;
         }
+        } while (0);
+        if (!coop) {
+            if (done) break;
+            continue;
+        }
+        // ---- wave-level part: every lane is here, lane 0 decides ----
+        if (__builtin_amdgcn_readfirstlane(S.wantScan ? 1 : 0)) {
+            const int rowU = __builtin_amdgcn_readfirstlane(curRow);
+            const double *cs = cacheS + (size_t)rowU * T.n;
+            const int32_t *rT = rTable ? rTable + (size_t)rowU * nF : nullptr;
+            ScanState st;
+            st.best = readfirst_f64(S.bestLKdiff);
+            st.nB = __builtin_amdgcn_readfirstlane(ws.nB);
+            st.nApp = __builtin_amdgcn_readfirstlane(S.nAppend);
+            st.overflow = 0;
+            st.shortenSeed = false;
+            for (int k = 0; k < 4; k++) st.fShort[k] = __builtin_amdgcn_readfirstlane(S.fShort[k]);
+            const int hSeed = __builtin_amdgcn_readfirstlane(S.scanItem.hRpr);
+            BestRec *br = (BestRec *)(wsBase + (size_t)blockIdx.x * activeLanes * LB.total + LB.w + LB.aux + LB.h + LB.st);
+#ifdef MAPLE_SPR_PROFILE
+            const long long tScan0 = wall_clock64();
+#endif
+            wave_scan_clade(T.scan, T.scanParent, cs, rT, __builtin_amdgcn_readfirstlane(S.scanRank),
+                            __builtin_amdgcn_readfirstlane(S.scanFirstScored ? 1 : 0) != 0,
+                            __builtin_amdgcn_readfirstlane(S.scanSeedFrame), hSeed, readfirst_f64(S.scanItem.lastLK),
+                            __builtin_amdgcn_readfirstlane((int)S.scanItem.fails), P, br, L.capB, slotLK, slotFails,
+                            slotOwner, T.scanDepthCap, st);
+#ifdef MAPLE_SPR_PROFILE
+            if (searcher) out[q].tReplay += wall_clock64() - tScan0;
+#endif
+            if (searcher) {
+                S.bestLKdiff = st.best; ws.nB = st.nB; S.nAppend = st.nApp;
+                if (st.overflow && !ws.overflow) ws.overflow = st.overflow;
+                for (int k = 0; k < 4; k++) S.fShort[k] = st.fShort[k];
+                if (st.shortenSeed) S.opShortenInPlace(hSeed);
+            }
+            continue;
+        }
+        if (__builtin_amdgcn_readfirstlane(done ? 1 : 0)) break;
     }
 }
 
@@ -752,7 +822,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     for (auto &b : c->s_i64) b.release();
     c->s_words.release(); c->s_aux.release(); c->s_ais.release(); c->s_pool_w.release(); c->s_pool_a.release();
     for (auto &b : c->t_i32) b.release();
-    c->t_dist.release(); c->t_tip.release(); c->t_nodes.release(); c->t_scored_col.release(); c->t_scored_frame.release();
+    c->t_dist.release(); c->t_tip.release(); c->t_nodes.release(); c->t_scored_col.release(); c->t_scored_frame.release(); c->t_scan.release(); c->t_scan_parent.release();
     if (c->d_tile_counters) (void)hipFree(c->d_tile_counters);
     c->s_search_ws.release(); c->s_search_out.release(); c->s_counter.release(); c->s_cache.release();
     for (auto &b : c->p_i32) b.release();
@@ -1604,6 +1674,8 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     T.n = n; T.root = root;
     T.nd = (const NodeRec *)aligned;
     T.totUp = c->t_i32[6].p;
+    c->scan_valid = false;
+    T.scan = nullptr; T.scanParent = nullptr; T.scanDepthCap = 0;
     c->tree_has_mut = false;
     c->tree_max_ent = 0;
     for (int i = 0; i < n; i++) {
@@ -1718,15 +1790,28 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             if (cacheS) TRY(h2d(c, c->s_i32[1], rows.data(), (size_t)m));
             HIPCK(c, c->s_search_out.reserve((size_t)m * sizeof(SearchOut)));
             SearchOut *dout = (SearchOut *)c->s_search_out.p;
+            // cached (whole-tree) searches descend by scanning the tree in their own depth-first order; the per-depth slots
+            // of every searching lane live in LDS (deeper trees fall back to popping one node at a time)
+            DevTree Tk = c->dtree;
+            size_t dynLds = 0;
+            int launchLanes = activeLanes, launchWaves = nWaves;
+            if (cacheS && c->scan_valid && (size_t)(c->tree_max_depth + 2) * 16 <= (48u << 10)) {
+                Tk.scan = c->t_scan.p;
+                Tk.scanParent = c->t_scan_parent.p;
+                Tk.scanDepthCap = c->tree_max_depth + 2;
+                dynLds = ((size_t)Tk.scanDepthCap * 16 + 15) & ~(size_t)15;
+                launchLanes = 1;                                         // one search per wavefront, 64 lanes per clade scan
+                launchWaves = lanes;                                     // (the workspace is sized for `lanes` searches at a time)
+            } else { Tk.scan = nullptr; Tk.scanParent = nullptr; Tk.scanDepthCap = 0; }
             hipEvent_t e0, e1;
             TRY(ev_pair(c, &e0, &e1));
             HIPCK(c, hipEventRecord(e0, c->stream));
-            DISPATCH3(c, k_spr_search, <<<nWaves, 64, 0, c->stream>>>(c->d_model, view(c), mview(c), c->dtree, P, m, c->s_i32[0].p,
+            DISPATCH3(c, k_spr_search, <<<launchWaves, 64, dynLds, c->stream>>>(c->d_model, view(c), mview(c), Tk, P, m, c->s_i32[0].p,
                                                                          L, LB, c->s_search_ws.p, c->s_counter.p, dout, poolW,
                                                                          poolA, poolUsed, poolCapW, poolCapA,
                                                                          attempt == 0 ? c->trace_query : -1, c->s_trace_i.p,
                                                                          c->s_trace_d.p, 4096, c->s_trace_i.p ? c->s_trace_i.p + 4 * 4096 : nullptr,
-                                                                         activeLanes, cacheS, budgetNow, rTable, nF,
+                                                                         launchLanes, cacheS, budgetNow, rTable, nF,
                                                                          cacheS ? c->s_i32[1].p : nullptr));
             HIPCK(c, hipGetLastError());
             HIPCK(c, hipEventRecord(e1, c->stream));
@@ -1756,6 +1841,45 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     int wideBudget = sp->wideSearchBudget == 0 ? 256 : sp->wideSearchBudget;
     const bool hybrid = wideBudget > 0;
     TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
+    if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !getenv("MAPLE_NO_SCAN")) {
+        // the tree in the searches' own depth-first order (SScan, search_dev.h): clade sizes, depths and the per-node facts
+        // the cached-regime descent tests
+        const int32_t nT = c->dtree.n;
+        std::vector<int32_t> byRank(nT, -1);
+        for (int i = 0; i < nT; i++) byRank[c->h_nodes[i].preRank] = i;
+        std::vector<SScan> sc((size_t)nT);
+        std::vector<int32_t> size(nT, 1), depth(nT, 0);
+        int32_t maxDepth = 0;
+        for (int r = 0; r < nT; r++) {                                      // parents precede their clades in rank order
+            const int v = byRank[r];
+            const int u = c->h_tree_up[v];
+            if (u >= 0 && v != c->dtree.root && c->h_nodes[u].preRank < r) depth[v] = depth[u] + 1;
+            maxDepth = std::max(maxDepth, depth[v]);
+        }
+        for (int r = nT - 1; r >= 0; r--) {
+            const int v = byRank[r];
+            const int u = c->h_tree_up[v];
+            if (u >= 0 && v != c->dtree.root && c->h_nodes[u].preRank < r) size[u] += size[v];
+        }
+        for (int r = 0; r < nT; r++) {
+            const int v = byRank[r];
+            const NodeRec &nr = c->h_nodes[v];
+            uint32_t fl = 0;
+            if (nr.up >= 0 && (nr.dist > P.effNon0 || nr.upIsRoot)) fl |= SS_SCORED;
+            if (nr.totUp >= 0) fl |= SS_TOTUP;
+            if (nr.c0 >= 0) fl |= SS_INNER;
+            if (nr.up >= 0 && (nr.whichChild ? c->h_nodes[nr.up].upLeft : c->h_nodes[nr.up].upRight) >= 0) fl |= SS_ENTER;
+            sc[r] = SScan{v, size[v], depth[v], ((uint32_t)nr.frameOf << 4) | fl};
+        }
+        std::vector<int32_t> prank((size_t)nT, 0);
+        for (int r = 0; r < nT; r++) { const int u = c->h_tree_up[byRank[r]]; prank[r] = u >= 0 ? c->h_nodes[u].preRank : 0; }
+        TRY(h2d(c, c->t_scan, sc.data(), sc.size()));
+        TRY(h2d(c, c->t_scan_parent, prank.data(), prank.size()));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        c->tree_max_depth = maxDepth;
+        c->scan_eff = P.effNon0;
+        c->scan_valid = true;
+    }
     if (hybrid) {
         std::vector<int32_t> wide;
         for (int i = 0; i < n; i++)
@@ -1868,6 +1992,19 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             w0 += (size_t)m;
         }
     }
+#ifdef MAPLE_SPR_PROFILE
+    {
+        long long ts = 0, tr = 0, tf = 0, ns = 0, nl = 0, mxs = 0, mxr = 0, mxf = 0, mxl = 0;
+        for (int i = 0; i < n; i++) {
+            ts += ho[i].tStep; tr += ho[i].tReplay; tf += ho[i].tRefine; ns += ho[i].nSteps; nl += ho[i].nShortList;
+            mxs = std::max<long long>(mxs, ho[i].tStep); mxr = std::max<long long>(mxr, ho[i].tReplay);
+            mxf = std::max<long long>(mxf, ho[i].tRefine); mxl = std::max<long long>(mxl, ho[i].nShortList);
+        }
+        fprintf(stderr, "[maple] profile over %d searches (last launch each): step %.1f ms total (max %.2f), replay %.1f (max %.2f), "
+                        "refine %.1f (max %.2f); %lld updating steps, %lld short-listed branches (max %lld)\n",
+                n, ts * 1e-5, mxs * 1e-5, tr * 1e-5, mxr * 1e-5, tf * 1e-5, mxf * 1e-5, ns, nl, mxl);
+    }
+#endif
     for (int i = 0; i < n; i++) {
         bestNode[i] = ho[i].bestNode; bestScore[i] = ho[i].bestScore;
         blen3[3 * i] = ho[i].blen[0]; blen3[3 * i + 1] = ho[i].blen[1]; blen3[3 * i + 2] = ho[i].blen[2];

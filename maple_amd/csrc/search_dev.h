@@ -52,10 +52,28 @@ struct alignas(64) NodeRec {
     int32_t c0Frame, c1Frame, upFrame; // the frames of its relatives: a frame change is visible without loading them
 };
 
+// The tree once more, in the order a search descends (NodeRec::preRank: the child pushed last, child 1, first): rank
+// r + 1 is the first node visited after rank r and r + size skips r's clade, so the cached-regime descent into a clade is a
+// forward scan over this array and over the search's score row (both read sequentially) instead of a chase through
+// 64-byte node records and a stack in memory.
+struct alignas(16) SScan {
+    int32_t node;                      // node id
+    int32_t size;                      // nodes in the clade rooted here (itself included)
+    int32_t depth;                     // root = 0
+    uint32_t ff;                       // frame << 4 | flags
+};
+enum { SS_SCORED = 1,                  // up != None and (dist > effectivelyNon0BLen or the parent is the root), M:6984
+       SS_TOTUP = 2,                   // has a probVectTotUp
+       SS_INNER = 4,                   // has children
+       SS_ENTER = 8 };                 // the parent pushes it: its probVectUpRight / probVectUpLeft for this child exists (M:7105-7160)
+
 struct DevTree {
     int32_t n, root;
     const NodeRec *nd;
     const int32_t *totUp;              // also kept as a flat column: the candidate list of the batch-scoring kernel
+    const SScan *scan;                 // [n] by preRank, or null (then the cached regime pops one node at a time)
+    const int32_t *scanParent;         // [n] by preRank: the rank of the parent
+    int32_t scanDepthCap;              // per-depth slots a searching lane owns in LDS
 };
 
 struct SearchParams {
@@ -86,6 +104,8 @@ struct SearchOut {                     // per query
     double blen[3];
     int64_t rprWoff, rprAoff;          // bestRemovedPartials inside the output pool (-1 = not stored)
     int32_t rprN, rprNA;
+    int32_t nShortList, nSteps;        // profile: short-listed branches refined, state-machine steps (updating regime)
+    int64_t tStep, tReplay, tRefine;   // profile (MAPLE_SPR_PROFILE builds): wall_clock64 ticks (10 ns) per phase
 };
 
 struct WsLayout {                      // per-lane workspace capacities
@@ -129,6 +149,10 @@ template <bool RV, bool U, bool SS> struct Search {
     // prepared by the host along the same up-then-down paths the traversal takes
     const int32_t *rTable = nullptr;
     int fShort[4] = {-1, -1, -1, -1};  // frames whose frame-table list the reference would have shortened in place (M:7087)
+    // hand-over of a cached-regime descent to the whole wavefront (wave_scan_clade)
+    StackItem scanItem;
+    int scanRank = 0, scanSeedFrame = 0;
+    bool scanFirstScored = false, wantScan = false;
     int budget = 0;                    // > 0: give up (status -5) after this many traversal placements without a cache
     bool overBudget = false;
     // optional visit trace of ONE query (debugging / parity of the visit sequence)
@@ -482,6 +506,17 @@ template <bool RV, bool U, bool SS> struct Search {
             int fails = it.fails;
             double midProb = it.lastLK;
             const bool rootChild = r1.upIsRoot != 0;
+            if (it.dir == 0 && T.scan) {
+                // The whole clade below this item goes to the wavefront (wave_scan_clade): this lane hands the item over
+                // and applies the outcome; what the LIFO stack would do with the item and everything it pushes happens
+                // there in the same order (a pushed clade is finished before anything older is popped).
+                scanItem = it;
+                scanRank = r1.preRank;
+                scanSeedFrame = r1.frameOf;
+                scanFirstScored = !(upT == node || upT < 0) && (r1.dist > eff || rootChild);
+                wantScan = true;
+                break;
+            }
             if (it.dir == 0) {
                 if (!(upT == node || upT < 0) && (r1.dist > eff || rootChild)) {
                     if (r1.totUp < 0) continue;
@@ -581,5 +616,151 @@ template <bool RV, bool U, bool SS> struct Search {
         return 0;
     }
 };
+
+// ---- cached-regime descent into one clade, by the whole wavefront ------------------------------------------------------
+// All 64 lanes load 64 consecutive records of the tree in the search's depth-first order and the 64 scores of the
+// search's row that go with them (two coalesced streams), then the reference's order-dependent rules -- running best,
+// failedPasses, the short list, the strict / non-strict stop rule (M:7071-7103) -- are applied record by record from
+// those registers (v_readlane with a wave-uniform index): no stack, no dependent global load per visit.  A record that is
+// not descended into skips its clade (r += size).  (lastLK, failedPasses) handed from a node to its children live in
+// one LDS slot per depth below the clade's root.  Every value that steers control flow is wave-uniform.
+struct ScanState {                     // wave-uniform in / out
+    double best;
+    int nB, nApp, overflow;
+    bool shortenSeed;                  // an improvement was found with the item's own removed list (shorten() it, M:7087)
+    int fShort[4];
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readfirst_f64(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline void wave_scan_clade(const SScan *__restrict__ SC, const int32_t *__restrict__ PR, const double *__restrict__ cs,
+                                       const int32_t *__restrict__ rT, int r, bool firstScored, int seedFrame, int hSeed,
+                                       double lastLK, int fails0, const SearchParams &P, BestRec *br, int capB, double *slotLK,
+                                       int *slotFails, unsigned *slotOwner, int cap, ScanState &S)
+{
+    const int lane = threadIdx.x & 63;
+    const double thrOpt = P.thrOptTopo, thrCons = P.thrConsec, thrLK = P.thrLKtopology;
+    const int strict = P.strict, allowed = P.allowedFails;
+    const SScan head = SC[r];
+    const int end = r + head.size, d0 = head.depth;
+    double best = S.best;
+    int nB = S.nB, nApp = S.nApp;
+    bool first = true;
+    for (int k = lane; k < cap; k += 64) slotOwner[k] = 0u;
+    unsigned serial = 1;                                                    // chunk number: slot ownership keys grow with it
+    while (r < end) {
+        const int n = min(64, end - r);
+        const bool valid = lane < n;
+        const int idx = valid ? r + lane : end - 1;
+        const SScan rec = SC[idx];
+        const double scv = cs[idx];
+        const int pl = PR[idx] - r;                                         // lane of the parent; < 0: an earlier chunk
+        const int d = rec.depth, f = (int)(rec.ff >> 4);
+        const uint32_t fl = rec.ff & 15u;
+        const bool isFirst = first && lane == 0;
+        const bool enter = isFirst || (fl & SS_ENTER);
+        const bool scoredHere = isFirst ? firstScored : (fl & SS_SCORED) != 0;
+        const bool dropped = scoredHere && !(fl & SS_TOTUP);                // visited, nothing scored, nothing pushed
+        const bool counts = scoredHere && !dropped;                        // one appendProbNode evaluation when visited
+        // ---- every record's (score it hands on, failedPasses, descended into?) under the CURRENT running best: the state
+        // flows from parent to child, so a record is resolved once its parent is; records whose parent lies before the
+        // chunk read the parent's slot
+        double myMp = 0.0;
+        int myFails = 0;
+        bool vis = false, go = false, resolved = false;
+        auto settle = [&](double pMp, int pFails, bool pGo) {
+            vis = pGo && enter;
+            myMp = counts ? scv : pMp;
+            myFails = pFails + ((counts && myMp < (pMp - thrCons)) ? 1 : 0);
+            const bool within = myMp > (best - thrLK);
+            const bool rule = strict ? (myFails <= allowed && within) : (myFails <= allowed || within);
+            go = vis && !dropped && (fl & SS_INNER) && rule;
+            resolved = true;
+        };
+        if (valid) {
+            if (isFirst) settle(lastLK, fails0, true);
+            else if (pl < 0) settle(slotLK[d - d0 - 1], slotFails[d - d0 - 1], true);
+        }
+        while (__ballot(valid && !resolved)) {
+            const int src = pl < 0 ? lane : pl;
+            const int pRes = __shfl(resolved ? 1 : 0, src, 64);
+            const double pMp = __shfl(myMp, src, 64);
+            const int pFails = __shfl(myFails, src, 64);
+            const int pGo = __shfl(go ? 1 : 0, src, 64);
+            if (valid && !resolved && pRes) settle(pMp, pFails, pGo != 0);
+        }
+        // ---- a visited record that beats the running best changes the rules for everything after it: records before the
+        // first such one are final; that one is applied on its own and the scan resumes behind it
+        const unsigned long long imp = __ballot(valid && vis && counts && scv > best);
+        const int nFinal = imp ? (int)__ffsll((long long)imp) - 1 : n;
+        const bool fin = lane < nFinal;
+        const unsigned long long cntM = __ballot(fin && vis && counts);
+        nApp += __popcll(cntM);
+        const bool rec1 = fin && vis && counts && myMp > (best - thrOpt);   // M:7071: the short list (on the way down: >)
+        const unsigned long long recM = __ballot(rec1);
+        const int nRec = __popcll(recM);
+        if (nRec) {
+            if (nB + nRec > capB) { S.overflow = 5; break; }
+            if (rec1) {
+                const int hr = (rT && f != seedFrame) ? -(rT[f] + 10) : hSeed;
+                const int at = nB + __popcll(recM & ((1ull << lane) - 1ull));
+                br[at] = BestRec{rec.node, -1, -1, -1, hr, myMp, 0.0};
+            }
+            nB += nRec;
+        }
+        // what a descended record hands to children in later chunks: the last such record of each depth owns the slot
+        const bool keep = fin && go;
+        if (__ballot(keep && (d - d0 >= cap))) { S.overflow = 4; break; }
+        const unsigned key = serial * 64u + (unsigned)lane;
+        if (keep) atomicMax(&slotOwner[d - d0], key);
+        if (keep && slotOwner[d - d0] == key) { slotLK[d - d0] = myMp; slotFails[d - d0] = myFails; }
+        serial++;
+        int next;
+        if (imp) {
+            // the improving record, alone (its parent's state is final): M:7083-7091
+            const int i = nFinal;
+            const int di = __builtin_amdgcn_readlane(d, i), fi = __builtin_amdgcn_readlane(f, i);
+            const int sizei = __builtin_amdgcn_readlane(rec.size, i);
+            const uint32_t fli = (uint32_t)__builtin_amdgcn_readlane((int)fl, i);
+            const double mp = readlane_f64(scv, i);
+            const int hr = (rT && fi != seedFrame) ? -(rT[fi] + 10) : hSeed;
+            nApp++;
+            if (nB >= capB) { S.overflow = 5; break; }
+            if (lane == 0) br[nB] = BestRec{__builtin_amdgcn_readlane(rec.node, i), -1, -1, -1, hr, mp, 0.0};
+            nB++;
+            best = mp;
+            if (hr >= 0) S.shortenSeed = true;
+            else if (hr <= -10 && rT) {
+                if (S.fShort[0] != fi && S.fShort[1] != fi && S.fShort[2] != fi && S.fShort[3] != fi) {
+                    S.fShort[3] = S.fShort[2]; S.fShort[2] = S.fShort[1]; S.fShort[1] = S.fShort[0]; S.fShort[0] = fi;
+                }
+            }
+            const bool goi = (fli & SS_INNER) != 0;                         // failedPasses = 0 and the score IS the best
+            if (goi) {
+                if (di - d0 >= cap) { S.overflow = 4; break; }
+                if (lane == 0) { slotLK[di - d0] = mp; slotFails[di - d0] = 0; slotOwner[di - d0] = serial * 64u; }
+                serial++;
+                next = i + 1;
+            } else next = i + sizei;
+        } else {
+            // skip the clade of the outermost record that is not descended into and reaches past this chunk
+            const unsigned long long blk = __ballot(valid && !go && (lane + rec.size > n));
+            next = blk ? ((int)__ffsll((long long)blk) - 1) : n;
+            if (blk) next += __builtin_amdgcn_readlane(rec.size, next);
+        }
+        first = false;
+        r += next;
+    }
+    S.best = best; S.nB = nB; S.nApp = nApp;
+}
 
 } // namespace maple

@@ -16,6 +16,7 @@ import io
 import json
 import os
 import random
+import re
 import runpy
 import sys
 import tempfile
@@ -32,7 +33,41 @@ RUNS = {
                      "--noFastTopologyInitialSearch"],
     "synth_siteerr": ["--model", "UNREST", "--rateVariation", "--estimateSiteSpecificErrorRate",
                       "--maxNumDescendantsForMATClade", "12"],
+    # the reference's own example alignment (lRef 29 903, 112 samples): SURVEY.md section 8c
+    "example_unrest": ["--model", "UNREST", "--numTopologyImprovements", "0", "--noFastTopologyInitialSearch"],
+    "example_siteerr": ["--model", "UNREST", "--rateVariation", "--estimateSiteSpecificErrorRate"],
+    # BASELINE configs[0]: --model JC; the reference raises after SPR round 1 (EM is not implemented for JC, M:10877-10879)
+    # with the round-1 tree in place, log-LK -44775.7276008509
+    "example_jc": ["--model", "JC"],
+    # real SARS-CoV-2 data: the first 600 samples of example_files/sameRef_B.1.429.maple.gz
+    "b1429_unrest": ["--model", "UNREST", "--numTopologyImprovements", "0", "--noFastTopologyInitialSearch"],
 }
+EXAMPLE_DIR = "/root/reference/example_files"
+INPUTS = {                                   # default: tests/golden/synth_small.maple.txt
+    "example_unrest": os.path.join(EXAMPLE_DIR, "MAPLE_alignment_example.txt"),
+    "example_siteerr": os.path.join(EXAMPLE_DIR, "MAPLE_alignment_example.txt"),
+    "example_jc": os.path.join(EXAMPLE_DIR, "MAPLE_alignment_example.txt"),
+    "b1429_unrest": ("prefix", os.path.join(EXAMPLE_DIR, "sameRef_B.1.429.maple.gz"), 600),
+}
+
+
+def input_path(name, tmp_dir):
+    """The alignment a run reads: a committed / reference file, or the first N samples of one (written to tmp_dir)."""
+    spec = INPUTS.get(name, os.path.join(HERE, "synth_small.maple.txt"))
+    if isinstance(spec, str):
+        return spec
+    _, src, n_keep = spec
+    op = gzip.open if src.endswith(".gz") else open
+    out = os.path.join(tmp_dir, f"{name}_input.maple.txt")
+    n_rec = 0
+    with op(src, "rt") as fi, open(out, "w") as fo:
+        for line in fi:
+            if line.startswith(">"):
+                n_rec += 1
+                if n_rec > n_keep + 1:          # record 1 is the reference
+                    break
+            fo.write(line)
+    return out
 
 
 def snapshot_tree(tree, root):
@@ -69,8 +104,8 @@ def perturb(diffs, ref, rng):
 
 
 def run(name, flags):
-    inp = os.path.join(HERE, "synth_small.maple.txt")
     out_dir = tempfile.mkdtemp(prefix="maple_golden_search_")
+    inp = input_path(name, out_dir)
     argv = ["MAPLE", "--input", inp, "--output", os.path.join(out_dir, "out"), "--overwrite"] + flags
     holder = {}
 
@@ -88,11 +123,15 @@ def run(name, flags):
             runpy.run_path(REF, run_name="__main__")
     except SystemExit:
         pass
+    except Exception as e:                  # --model JC: "EM for given model JC not implemented" after round 1
+        print(f"[{name}] the reference raised: {e!r}; continuing with the tree it had built", flush=True)
     finally:
         sys.setprofile(None)
         sys.argv = old
     g = holder["g"]
     tree, t1 = g["tree"], g["t1"]
+    run_log = log.getvalue()
+    printed_lk = [float(x) for x in re.findall(r"ikelihood[^\n]*?(-\d+\.\d+)", run_log)]
     with contextlib.redirect_stdout(io.StringIO()):
         g["setAllDirty"](tree, t1)
         g["reCalculateAllGenomeLists"](tree, t1)
@@ -116,10 +155,20 @@ def run(name, flags):
             "oneMutBLen", "effectivelyNon0BLen", "thresholdLogLK", "thresholdLogLKoptimization",
             "thresholdLogLKoptimizationTopology", "thresholdLogLKtopology", "thresholdLogLKconsecutivePlacement",
             "allowedFails", "allowedFailsTopology", "defaultBLen", "maxReplacements", "strictStopRules",
-            "thresholdTopologyPlacement", "thresholdLogLKtopologyInitial", "allowedFailsTopologyInitial"]
+            "thresholdTopologyPlacement", "thresholdLogLKtopologyInitial", "allowedFailsTopologyInitial",
+            "minBranchSupport"]
     ctx = {k: g[k] for k in keys}
     ctx["rootFreqs"] = list(g["rootFreqs"])
     ctx["ref"] = g["ref"]
+
+    # ---- the --numCores shard lists: coreNum[node] of assignCoreNumbers (M:12164-12195) for 2 and 3 cores ----
+    core_numbers = {}
+    for nc in (2, 3):
+        with contextlib.redirect_stdout(io.StringIO()):
+            g["assignCoreNumbers"](tree, t1, nc)
+        core_numbers[str(nc)] = list(tree.coreNum)
+    with contextlib.redirect_stdout(io.StringIO()):
+        g["assignCoreNumbers"](tree, t1, 1)
 
     # ---- a11 / a13: SPR searches on the frozen tree, two parameter sets (fast initial round, deep round) ----
     param_sets = [
@@ -177,12 +226,17 @@ def run(name, flags):
               f"{sum(c['n_append'] for c in calls)} appendProbNode calls", flush=True)
 
     # ---- a12: placement searches for new samples on the frozen tree ----
+    # (the reference imports math.exp only under --findSamplePlacements / --lineageRefs / --aBayesPlus (M:289-290), the
+    # modes whose call site passes computePlacementSupportOnly=True; the runs here do not set them)
+    import math
+    g.setdefault("exp", math.exp)
     rng = random.Random(123)
     from maple_amd.host import read_maple_file
     _, data = read_maple_file(inp)
+    n_place = 60 if len(tree.up) < 400 else 40
     names = sorted(data)
     placements = []
-    for k in range(60):
+    for k in range(n_place):
         base = data[names[rng.randrange(len(names))]]
         diffs = perturb(base, g["ref"], rng)
         tcopy = copy.deepcopy(tree)
@@ -200,15 +254,25 @@ def run(name, flags):
                 ret = g["findBestParentForNewSample"](tcopy, t1, q, f"new{k}", False)
             finally:
                 sys.setprofile(None)
+        # the same query through the computePlacementSupportOnly=True exit (M:8101-8290), the form process_chunk
+        # consumes (M:11200): (possiblePlacements, bestPlacementTotalLh)
+        tcopy2 = copy.deepcopy(tree)
+        with contextlib.redirect_stdout(io.StringIO()):
+            q2 = g["probVectTerminalNode"](diffs, None, None)
+            sup = g["findBestParentForNewSample"](tcopy2, t1, q2, f"new{k}", True)
         placements.append(dict(diffs=[list(e) for e in diffs], query=q_ser, n_append=state["n_append"],
                                ret=dict(bestNode=ret[0], bestScore=ret[1],
                                         bestBranchLengths=None if ret[2] is None else list(ret[2]),
-                                        bestDiffs=ser_list(ret[3]))))
+                                        bestDiffs=ser_list(ret[3])),
+                               supports=dict(possiblePlacements=[[p[0], p[1], [0.0 if b is False else b for b in p[2]]]
+                                                                 for p in sup[0]],
+                                             bestPlacementTotalLh=ser_list(sup[1]))))
     print(f"[{name}] {len(placements)} placement searches, "
           f"{sum(p['n_append'] for p in placements)} appendProbNode calls", flush=True)
 
     fixture = dict(name=name, flags=flags, context=ctx, model=model, tree=snap, spr=spr, placements=placements,
-                   treeLK=tree_lk, rootLK=root_lk)
+                   treeLK=tree_lk, rootLK=root_lk, printedLKs=printed_lk, coreNum=core_numbers,
+                   input=os.path.basename(inp))
     path = os.path.join(HERE, f"search_{name}.json.gz")
     with gzip.open(path, "wt") as fh:
         json.dump(fixture, fh)
