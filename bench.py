@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- candidate SPR placements / second on MI355X (BASELINE.json metric).
 
-A *step* is one pass of the hot path over one batch of synthetic input: every query genome list of
-this rank is scored with appendProbNode (M:6505-6785) against every candidate branch of a
-synthetic SARS-CoV-2-like tree (the mid-branch ``probVectTotUp`` lists, M:8050), followed by the
-per-query arg-max and -- for N>1 -- one RCCL all-gather of the (score, branch) proposals, the
-analogue of the reference's gather-and-sort of proposed moves (M:12306-12312).  Queries are sharded
-round-robin over ranks exactly like ``assignCoreNumbers`` (M:12164-12195); the tree mirror is
-replicated; per-GPU work is fixed (weak scaling).
+Workload (default = BASELINE.json configs[2], the largest single-GPU configuration): a synthetic tree of 100 000
+SARS-CoV-2-like samples (lRef 29 903, ~30 diffs/sample), UNREST + per-site rates (--rateVariation), tree mirror
+resident in HBM.  A *step* is one pass of the hot path over one batch of pruned nodes: the worker body of
+startTopologyUpdatesParallel (M:9580-9716) -- findBestParentTopology (M:6817-7724) for every node of the batch with the
+deep-round parameters of the reference's SPR rounds (non-strict, allowedFailsTopology 4, 14 log lRef) -- followed by
+the combine step of M:12306-12312 (one all-gather of the proposed moves when N > 1, sorted by improvement).  By default
+the batch is EVERY node of the tree (one whole search round, as the reference runs it with all nodes dirty); with
+`--batch B` it is the next B nodes of the tree's pre-order.  Either way the nodes are dealt round-robin over the ranks
+in pre-order exactly like assignCoreNumbers (M:12164-12195): total work per step is fixed (strong scaling), the tree
+mirror is replicated.
+
+`value` = candidate placements (appendProbNode evaluations the reference's search issues, M:7011 / 7223, counted by the
+search itself) of all ranks in the K timed steps / wall time (max over ranks).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  Inputs (tree mirror, query lists, pair index arrays) are resident
-in HBM before the timed region starts.
+Prints ONE JSON line on rank 0.  Everything the searches read is resident in HBM before the timed region starts.
 """
 import argparse
+import glob
 import json
+import math
 import os
 import sys
 import time
@@ -32,6 +39,8 @@ UNREST_Q = [[-0.5524, 0.0602, 0.3655, 0.1267],
             [0.1666, -2.6077, 0.0405, 2.4006],
             [0.8421, 0.1305, -2.4012, 1.4286],
             [0.0688, 0.4849, 0.0502, -0.6039]]
+MODEL_TEXT = {"unrest": "UNREST", "ratevar": "UNREST + per-site rates (--rateVariation)",
+              "siteerr": "UNREST + per-site rates + per-site error rates (--rateVariation --estimateSiteSpecificErrorRate)"}
 
 
 def model_kwargs(mode, l_ref):
@@ -48,34 +57,57 @@ def model_kwargs(mode, l_ref):
     return kw
 
 
+def search_kwargs(l_ref, fast=False):
+    """Parameters of the reference's SPR rounds (M:53-57, 3609-3614): the deep round, or the fast initial round."""
+    ll = math.log(l_ref)
+    kw = (dict(strict=True, allowedFails=2, thresholdLogLKtopology=6.0 * ll) if fast else
+          dict(strict=False, allowedFails=4, thresholdLogLKtopology=14.0 * ll))
+    kw.update(thresholdTopologyPlacement=-0.1, thresholdLogLKoptimizationTopology=1.0 * ll,
+              thresholdLogLKconsecutivePlacement=1.0, effectivelyNon0BLen=1.0 / (10 * l_ref))
+    return kw
+
+
+def preorder_nodes(mirror):
+    """Pre-order with child 0 first: the order assignCoreNumbers numbers the nodes in (M:12164-12195)."""
+    order, stack = [], [mirror.root]
+    ch = mirror.children
+    while stack:
+        v = stack.pop()
+        order.append(v)
+        if ch[v, 0] >= 0:
+            stack.append(int(ch[v, 1]))
+            stack.append(int(ch[v, 0]))
+    return np.asarray(order, dtype=np.int64)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--samples", type=int, default=10000, help="tips of the synthetic tree (BASELINE configs[1]: 10k)")
-    ap.add_argument("--model", choices=["unrest", "ratevar", "siteerr"], default="unrest",
-                    help="unrest = configs[1] (default, the headline); ratevar = configs[2]; siteerr = configs[3]")
-    ap.add_argument("--queries", type=int, default=256, help="query genome lists per GPU per step")
+    ap.add_argument("--samples", type=int, default=100000,
+                    help="tips of the synthetic tree (default: BASELINE configs[2]; 10000 = configs[1], 1000000 = configs[3])")
+    ap.add_argument("--model", choices=["unrest", "ratevar", "siteerr"], default="ratevar",
+                    help="ratevar = configs[2] (default); unrest = configs[1]; siteerr = configs[3]")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="pruned nodes searched per step, over all GPUs (default 0 = every node of the tree: one whole SPR "
+                         "search round per step, what the reference does per round, M:12283-12316)")
+    ap.add_argument("--spr-fast", action="store_true",
+                    help="the reference's fast initial round (strict, 2 fails, 6 log lRef) instead of the deep round")
+    ap.add_argument("--queries", type=int, default=256, help="query lists of the all-pairs scoring sub-block")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate host time spent on cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-spr", action="store_true", help="skip the secondary SPR-search-round measurement")
-    ap.add_argument("--spr-fast", action="store_true",
-                    help="secondary SPR round with the reference's fast initial parameters (strict, 2 fails, 6 log lRef) "
-                         "instead of the deep round; for very large trees")
-    ap.add_argument("--no-local-refs", action="store_true", help="skip the SPR round on the tree with MAT local references")
-    ap.add_argument("--pairs", action="store_true", help="experiment: explicit (parent, child) index arrays, untiled kernel")
-    ap.add_argument("--no-sort", action="store_true",
-                    help="experiment: leave the candidate branches in tree pre-order instead of ordering them by list length")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sub-blocks (all-pairs kernel, batched placement, local references)")
+    ap.add_argument("--local-refs", action="store_true",
+                    help="also run the steps on the same tree after giving it MAT local references (default when samples <= 20000)")
     args = ap.parse_args()
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the placement path has no CPU fallback")
     # MAPLE_BENCH_BACKEND=gloo is a plumbing check of the N>1 path on a box with fewer GPUs than ranks (ranks then share
@@ -93,9 +125,11 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         distd = dist
-    coll = (lambda t: t) if backend == "nccl" else (lambda t: t.cpu())
+    cu = torch.device("cuda", local_rank)
+    coll_dev = cu if backend == "nccl" else None
 
     from maple_amd.host import reference_tables, tip_genome_list
+    from maple_amd.parallel import gather_proposals, pack_proposals
     from maple_amd.runtime import Device
     from maple_amd.synth import make_dataset
     from maple_amd.tree_mirror import TreeMirror
@@ -104,8 +138,8 @@ def main():
     data = make_dataset(n_samples=args.samples, l_ref=29903, seed=1, mean_diffs=30.0,
                         rate_variation=(args.model != "unrest"))
     ref_idx, root_freqs = reference_tables(data.ref)
-    # genome-list arena: 4 GiB is plenty at 10 000 samples; bigger trees get more of the 288 GB (the per-frame removed
-    # lists of the wide searches on trees with local references are the big temporary)
+    # genome-list arena: bigger trees get more of the 288 GB (the per-frame removed lists of the wide searches on trees
+    # with local references are the big temporary)
     dev = Device(ref_idx, root_freqs, device=local_rank, arena_bytes=min(128 << 30, max(4 << 30, args.samples * (640 << 10))))
     mkw = model_kwargs(args.model, len(ref_idx))
     dev.set_model(**mkw)
@@ -113,218 +147,222 @@ def main():
     tip_lists = {int(v): tip_genome_list(dl, ref_idx, **tip_kw) for v, dl in zip(data.tip_node, data.diffs)}
     mirror = TreeMirror(dev, data.parent, data.blen, tip_lists).build()
     l_ref = dev.lRef
-    cand_nodes = mirror.candidate_nodes(1.0 / (10 * l_ref)) if args.no_sort else mirror.candidates_by_length(1.0 / (10 * l_ref))
-    cand_lists = mirror.tot_up[cand_nodes]
-    # queries of this rank: samples rank, rank+world, ... (round-robin like coreNum, M:12164-12195)
-    q_nodes = np.asarray(data.tip_node[rank::world][: args.queries], dtype=np.int64)
-    q_lists = mirror.lower[q_nodes]
-    Q, Cn = len(q_lists), len(cand_lists)
-    n_pairs = Q * Cn
-    parent_ids = np.tile(cand_lists.astype(np.int32), Q)
-    child_ids = np.repeat(q_lists.astype(np.int32), Cn)
-    # 8 B per entry word + 8 B per stored scalar (4 per O vector) + 8 B result per candidate;
-    # the query list is counted once per query per launch
-    q_ne, q_na = dev.sizes(q_lists)
-    alg_bytes = dev.append_algorithmic_bytes(parent_ids) + 8 * int(q_ne.sum() + q_na.sum())
-    cu = torch.device("cuda", local_rank)
-    t_q = torch.from_numpy(q_lists.astype(np.int32)).to(cu)
-    t_c = torch.from_numpy(cand_lists.astype(np.int32)).to(cu)
-    t_out = torch.empty(n_pairs, dtype=torch.float64, device=cu)
-    t_cand_nodes = torch.from_numpy(cand_nodes.astype(np.int64)).to(cu)
-    stream = torch.cuda.current_stream().cuda_stream
+    no_mut = -np.ones(mirror.n_nodes, dtype=np.int32)
+
+    def upload_plain_tree():
+        dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist, mirror.is_tip,
+                        mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up, no_mut)
+    upload_plain_tree()
+    kw = search_kwargs(l_ref, args.spr_fast)
+    order = preorder_nodes(mirror)
+    B = min(args.batch, len(order)) if args.batch > 0 else len(order)
     setup_s = time.time() - t_setup
 
-    if args.pairs:
-        t_parent = torch.from_numpy(parent_ids).to(cu)
-        t_child = torch.from_numpy(child_ids).to(cu)
-        t_tip = torch.ones(n_pairs, dtype=torch.uint8, device=cu)
-        t_blen = torch.full((n_pairs,), 1.0 / l_ref, dtype=torch.float64, device=cu)
+    def batch_of(i):
+        """This rank's share of step i: the next B nodes of the pre-order (wrapping), dealt round-robin (coreNum)."""
+        sel = np.arange(i * B, (i + 1) * B) % len(order)
+        return order[sel][rank::world]
 
-    def step():
-        if args.pairs:
-            dev.append_batch_dev(n_pairs, t_parent.data_ptr(), t_child.data_ptr(), t_tip.data_ptr(), t_blen.data_ptr(),
-                                 t_out.data_ptr(), stream)
-        else:
-            dev.append_queries_dev(Q, t_q.data_ptr(), Cn, t_c.data_ptr(), True, 1.0 / l_ref, t_out.data_ptr(), stream)
-        best_score, best_idx = t_out.view(Q, Cn).max(dim=1)
-        rec = torch.stack([best_score, t_cand_nodes[best_idx].to(torch.float64)], dim=1)
-        if distd is not None:
-            rec = coll(rec)
-            gathered = [torch.empty_like(rec) for _ in range(world)]
-            distd.all_gather(gathered, rec)
-            rec = torch.cat(gathered, dim=0)
-        return rec
+    dbg = os.environ.get("MAPLE_DEBUG") is not None
 
-    for _ in range(args.warmup):
-        step()
+    def step(i):
+        ta = time.perf_counter()
+        mine = batch_of(i)
+        tb = time.perf_counter()
+        res = dev.spr_search_batch(mine, **kw)
+        if dbg:
+            print(f"[bench] step {i}: batch_of {1e3 * (tb - ta):.1f} ms, spr_search_batch {1e3 * (time.perf_counter() - tb):.1f} ms",
+                  file=sys.stderr, flush=True)
+        bad = res["status"][(res["status"] < -1)]
+        if len(bad):
+            raise SystemExit(f"SPR search failed: status {sorted(set(bad.tolist()))} (workspace / pool capacity)")
+        rec = pack_proposals(mine, res["placement"], res["improvement"])
+        moves = gather_proposals(rec, device=coll_dev) if distd is not None else rec
+        return res, moves
+
+    for i in range(args.warmup):
+        step(args.steps + i)                              # (other batches than the timed ones; also sizes every buffer)
     torch.cuda.synchronize()
     if distd is not None:
         distd.barrier()
     torch.cuda.synchronize()
     dev.timing_reset()
+    placements = 0
+    status_counts = {}
+    n_moves = 0
+    kept = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rec = step()
+    for i in range(args.steps):
+        res, moves = step(i)
+        placements += int(res["nAppend"][res["status"] >= -1].sum())
+        kept.append(res)
     torch.cuda.synchronize()
     if distd is not None:
         distd.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    n_launch, kernel_ms = dev.timing_read()
+    n_score, ms_score, pairs_score, bytes_score = dev.timing_read_kind(Device.KIND_SPR_SCORE)
+    n_lane, ms_lane, _, _ = dev.timing_read_kind(Device.KIND_SPR_SEARCH)
+    n_rep, ms_rep, _, _ = dev.timing_read_kind(Device.KIND_SPR_REPLAY)
+    for res in kept:
+        for k, v in zip(*np.unique(res["status"], return_counts=True)):
+            status_counts[str(int(k))] = status_counts.get(str(int(k)), 0) + int(v)
+        n_moves += int((res["placement"] >= 0).sum())
+    searches = sum(len(r["status"]) for r in kept)
     if distd is not None:
-        te = coll(torch.tensor([elapsed], dtype=torch.float64, device=cu))
-        distd.all_reduce(te, op=distd.ReduceOp.MAX)
-        elapsed = float(te.item())
-        tp = coll(torch.tensor([float(n_pairs)], dtype=torch.float64, device=cu))
-        distd.all_reduce(tp, op=distd.ReduceOp.SUM)
-        total_pairs = float(tp.item())
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cu)
+        t = t if backend == "nccl" else t.cpu()
+        distd.all_reduce(t, op=distd.ReduceOp.MAX)
+        elapsed = float(t.item())
+        t = torch.tensor([float(placements), float(searches)], dtype=torch.float64, device=cu)
+        t = t if backend == "nccl" else t.cpu()
+        distd.all_reduce(t, op=distd.ReduceOp.SUM)
+        total_placements, total_searches = float(t[0].item()), float(t[1].item())
     else:
-        total_pairs = float(n_pairs)
+        total_placements, total_searches = float(placements), float(searches)
 
-    # ---- secondary measurement: one device-resident SPR search round (findBestParentTopology for every node
-    # of this rank's shard, M:9580-9716), reported next to the headline, never mixed into it ----
-    spr = None
-    if not args.no_spr:
-        import math
-        log_lref = math.log(l_ref)
-        nodes_all = np.arange(mirror.n_nodes)
-        my_nodes = nodes_all[rank::world]
-        dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist,
-                        mirror.is_tip, mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up,
-                        -np.ones(mirror.n_nodes, dtype=np.int32))
-        if args.spr_fast:
-            kw = dict(strict=True, allowedFails=2, thresholdLogLKtopology=6.0 * log_lref)
-        else:
-            kw = dict(strict=False, allowedFails=4, thresholdLogLKtopology=14.0 * log_lref)
-        kw.update(thresholdTopologyPlacement=-0.1,
-                  thresholdLogLKoptimizationTopology=1.0 * log_lref, thresholdLogLKconsecutivePlacement=1.0,
-                  effectivelyNon0BLen=1.0 / (10 * l_ref))
-        from maple_amd.parallel import sharded_spr_round
-        dev.spr_search_batch(my_nodes, **kw)                            # warm-up (also sizes the workspace)
-        dev.timing_reset()
-        if distd is not None:
-            distd.barrier()
-        t0 = time.perf_counter()
-        # this rank's share of the round + ONE all-gather of the proposed moves, sorted on every rank (M:12306-12312)
-        moves, res = sharded_spr_round(dev, nodes_all, kw, rank, world, device=(cu if backend == "nccl" else None))
-        wall = time.perf_counter() - t0
-        n_l, k_ms_spr = dev.timing_read()
-        st = res["status"]
-        spr = {"queries": int(len(my_nodes)), "searched": int((st == 0).sum()), "not_searched": int((st > 0).sum()),
-               "failed_or_overflow": int((st < 0).sum()),
-               "status_counts": {str(int(k)): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
-               "candidate_placements": int(res["nAppend"].sum()),
-               "proposed_moves": int((res["placement"] >= 0).sum()), "proposed_moves_all_ranks": len(moves),
-               "kernel_ms": k_ms_spr, "launches": n_l,
-               "wall_ms": 1e3 * wall,
-               "placements_per_s_kernel": float(res["nAppend"].sum() / (k_ms_spr * 1e-3)) if k_ms_spr else None,
-               "placements_per_s_wall": float(res["nAppend"].sum() / wall),
-               "params": ("fast round: strict, allowedFailsTopology 2, thresholdLogLKtopology 6 log(lRef)" if args.spr_fast else
-                          "deep round: non-strict, allowedFailsTopology 4, thresholdLogLKtopology 14 log(lRef)")}
-        # ---- and the batched placement search (findBestParentForNewSample for many samples on the frozen tree,
-        # M:7912-8292 / 11190-11220): all-branch scoring + device-side traversal + short-list refinement ----
-        pkw = dict(oneMutBLen=1.0 / l_ref, effectivelyNon0BLen=1.0 / (10 * l_ref), thresholdLogLK=18.0 * log_lref,
-                   thresholdLogLKoptimization=1.0 * log_lref, thresholdLogLKconsecutivePlacement=1.0)
-        from maple_amd.synth import perturb_diffs
-        mark = dev.mark()
-        prng = np.random.default_rng(11 + rank)
-        new_samples = [tip_genome_list(perturb_diffs(data.diffs[i], data.ref, prng), ref_idx, **tip_kw)
-                       for i in range(rank, len(data.diffs), world)][:Q]
-        new_ids = dev.upload(new_samples)                          # samples NOT in the tree (2 extra substitutions each)
-        dev.placement_search_batch(new_ids[:8], **pkw)
-        t0 = time.perf_counter()
-        pres = dev.placement_search_batch(new_ids, **pkw)
-        pwall = time.perf_counter() - t0
-        dev.release(mark)
-        placement = {"queries": int(Q), "wall_ms": 1e3 * pwall, "queries_per_s": Q / pwall,
-                     "reference_equivalent_placements_per_s": float(pres["nAppend"].sum() / pwall),
-                     "branches_scored_per_s": float(Q * (Cn + 1) / pwall),
-                     "minor_sequences": int((pres["status"] == 1).sum()), "failed": int((pres["status"] < 0).sum())}
-        spr_mat = None
-        if not args.no_local_refs:
-            # ---- the same deep round on the same tree after giving it MAT local references (setUpMAT's rule, 50 descendants
-            # per reference node, M:166 / 6152-6164): the form real MAPLE trees have; lists are shorter, every search crosses
-            # reference frames ----
-            from maple_amd.mat import add_local_references
-            from maple_amd.tree_host import HostTree
-            ht = HostTree.from_mirror(mirror)
-            t0 = time.perf_counter()
-            n_ref = add_local_references(dev, ht, 50)
-            mat_s = time.perf_counter() - t0
-            dev.upload_tree(ht.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist, mirror.is_tip,
-                            ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp, ht.id_mut)
-            dev.spr_search_batch(my_nodes, **kw)
-            dev.timing_reset()
-            t0 = time.perf_counter()
-            res_m = dev.spr_search_batch(my_nodes, **kw)
-            wall_m = time.perf_counter() - t0
-            n_lm, k_ms_m = dev.timing_read()
-            spr_mat = {"reference_nodes": int(n_ref), "setup_s": round(mat_s, 2), "queries": int(len(my_nodes)),
-                       "candidate_placements": int(res_m["nAppend"].sum()), "failed_or_overflow": int((res_m["status"] < 0).sum()),
-                       "proposed_moves": int((res_m["placement"] >= 0).sum()), "kernel_ms": k_ms_m, "launches": n_lm,
-                       "wall_ms": 1e3 * wall_m, "placements_per_s_kernel": float(res_m["nAppend"].sum() / (k_ms_m * 1e-3)),
-                       "placements_per_s_wall": float(res_m["nAppend"].sum() / wall_m),
-                       "same_moves_as_without_local_references": bool(np.array_equal(res_m["placement"], res["placement"])
-                                                                      and np.array_equal(res_m["nAppend"], res["nAppend"]))}
-            # back to the tree the rest of the run refers to
-            dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist,
-                            mirror.is_tip, mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up,
-                            -np.ones(mirror.n_nodes, dtype=np.int32))
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            spr["cpu_baseline"] = spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, my_nodes, res, kw, args.cpu_seconds, mkw)
+    extras = {}
+    if not args.no_extras and rank == 0:
+        extras = sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_plain_tree, torch, cu)
 
-    # HBM-side bytes per launch come from separate rocprofv3 PMC passes over this same command (a running process
-    # cannot read its own PMCs); they are recorded, with the FETCH_SIZE calibration for this access pattern, in
-    # profiles/pmc_k_append_queries.json and only reported when the workload is the one they were measured on.
+    # HBM-side bytes per scoring launch come from separate rocprofv3 PMC passes over this same command (a running process
+    # cannot read its own PMCs); they are recorded under profiles/ and only reported for the workload they were measured on.
     traffic = None
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_k_append_queries*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_spr_score*.json"))):
         try:
             pmc = json.load(open(path))
             w = pmc["workload"]
-            if ((w["samples"], w["queries_per_gpu"], w["candidate_branches"], w.get("model", "unrest"))
-                    == (args.samples, Q, int(Cn), args.model) and not args.pairs):
+            if (w["samples"], w["model"], w["batch"], w["n_gpus"]) == (args.samples, args.model, B, world):
                 traffic = pmc["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = total_pairs * args.steps / elapsed
-        k_ms = kernel_ms / max(1, n_launch)
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        value = total_placements / elapsed
+        k_ms = ms_score / max(1, n_score)
+        achieved = (bytes_score / (ms_score * 1e-3) / 1e9) if ms_score else 0.0
         out = {
             "metric": "candidate SPR placements/sec", "value": value, "unit": "placements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.samples} synthetic SARS-CoV-2 diff-lists (lRef 29903, ~30 diffs/sample), "
-                                   f"{ {'unrest': 'UNREST', 'ratevar': 'UNREST + per-site rates', 'siteerr': 'UNREST + per-site rates + per-site error rates'}[args.model] }, "
-                                   "appendProbNode over queries x all candidate branches",
-                       "samples": args.samples, "queries_per_gpu": Q, "candidate_branches": int(Cn),
-                       "pairs_per_step_per_gpu": int(n_pairs), "tree_nodes": int(mirror.n_nodes),
-                       "parallelism": f"queries sharded round-robin over {world} GPU(s), tree mirror replicated",
+                                   f"{MODEL_TEXT[args.model]}; SPR search (findBestParentTopology + worker, "
+                                   f"{'fast initial' if args.spr_fast else 'deep'}-round parameters) for {B} pruned nodes per step",
+                       "samples": args.samples, "model": args.model, "tree_nodes": int(mirror.n_nodes),
+                       "searches_per_step": int(B), "searches_timed": int(total_searches),
+                       "candidate_placements_timed": int(total_placements),
+                       "parallelism": f"each step's {B} pruned nodes dealt round-robin in pre-order (coreNum) over {world} GPU(s), "
+                                      "tree mirror replicated, one all-gather of proposed moves per step",
                        "setup_s": round(setup_s, 1)},
-            "roofline": {"bound": "hbm", "kernel": "k_append_queries", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": k_ms, "launches_timed": n_launch},
+            "roofline": {"bound": "hbm", "kernel": "k_append_queries (the dense scoring launches inside the search)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": bytes_score / max(1, n_score),
+                         "kernel_ms": k_ms, "launches_timed": n_score, "pairs_per_launch": pairs_score / max(1, n_score),
+                         "note": "rank 0's launches; algorithmic bytes = SURVEY 8d (8E + 8A + 8 per candidate branch per "
+                                 "query, each query list once per launch)"},
+            "spr_search": {"status_counts": status_counts, "proposed_moves_rank0": n_moves,
+                           "kernel_ms_rank0": {"budgeted_lane_searches": ms_lane, "dense_scoring": ms_score,
+                                               "replay_and_refinement": ms_rep},
+                           "launches_rank0": {"budgeted_lane_searches": n_lane, "dense_scoring": n_score,
+                                              "replay_and_refinement": n_rep},
+                           "params": ("fast round: strict, allowedFailsTopology 2, thresholdLogLKtopology 6 log(lRef)"
+                                      if args.spr_fast else
+                                      "deep round: non-strict, allowedFailsTopology 4, thresholdLogLKtopology 14 log(lRef)")},
         }
-        if spr is not None:
-            out["spr_search"] = spr
-            if spr_mat is not None:
-                out["spr_search_local_refs"] = spr_mat
-            out["placement_batch"] = placement
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs,
-                                               args.cpu_seconds, t_out, mkw)
+            out["cpu_baseline"] = spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, batch_of, kept, kw, args.cpu_seconds, mkw,
+                                                   args.steps)
         print(json.dumps(out), flush=True)
     if distd is not None:
+        distd.barrier()
         distd.destroy_process_group()
     dev.close()
 
 
-def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, nodes, gpu_res, kw, cpu_seconds, mkw):
-    """The C oracle's SPR search (a port of findBestParentTopology + the worker body, oracle/maple_oracle_search.c)
-    on ONE host core over a bounded, evenly spread sample of the same pruned nodes; also cross-checks the GPU."""
+def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_plain_tree, torch, cu):
+    """Secondary measurements next to the headline, never mixed into it (rank 0 only)."""
+    from maple_amd.host import tip_genome_list
+    from maple_amd.runtime import Device
+    from maple_amd.synth import perturb_diffs
+    l_ref = dev.lRef
+    out = {}
+    # ---- the all-pairs scoring kernel on its own: Q query lists x every candidate branch (appendProbNode, M:8050) ----
+    cand_nodes = mirror.candidates_by_length(1.0 / (10 * l_ref))
+    cand_lists = mirror.tot_up[cand_nodes]
+    q_nodes = np.asarray(data.tip_node[: args.queries], dtype=np.int64)
+    q_lists = mirror.lower[q_nodes]
+    Q, Cn = len(q_lists), len(cand_lists)
+    t_q = torch.from_numpy(q_lists.astype(np.int32)).to(cu)
+    t_c = torch.from_numpy(cand_lists.astype(np.int32)).to(cu)
+    t_out = torch.empty(Q * Cn, dtype=torch.float64, device=cu)
+    stream = torch.cuda.current_stream().cuda_stream
+    q_ne, q_na = dev.sizes(q_lists)
+    alg = dev.append_algorithmic_bytes(np.tile(cand_lists.astype(np.int32), Q)) + 8 * int(q_ne.sum() + q_na.sum())
+    for _ in range(2):
+        dev.append_queries_dev(Q, t_q.data_ptr(), Cn, t_c.data_ptr(), True, 1.0 / l_ref, t_out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    dev.timing_reset()
+    for _ in range(5):
+        dev.append_queries_dev(Q, t_q.data_ptr(), Cn, t_c.data_ptr(), True, 1.0 / l_ref, t_out.data_ptr(), stream)
+        best_score, best_idx = t_out.view(Q, Cn).max(dim=1)
+    torch.cuda.synchronize()
+    n_l, ms, _, _ = dev.timing_read_kind(Device.KIND_APPEND_QUERIES)
+    out["all_pairs_kernel"] = {"queries": int(Q), "candidate_branches": int(Cn), "kernel_ms": ms / max(1, n_l),
+                               "pairs_per_s": Q * Cn / (ms / max(1, n_l) * 1e-3),
+                               "algorithmic_GBps": alg / (ms / max(1, n_l) * 1e-3) / 1e9,
+                               "frac_of_hbm_peak": alg / (ms / max(1, n_l) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # ---- batched placement search (findBestParentForNewSample for many samples on the frozen tree, M:7912-8292 /
+    # 11190-11220): all-branch scoring + device-side traversal + short-list refinement ----
+    ll = math.log(l_ref)
+    pkw = dict(oneMutBLen=1.0 / l_ref, effectivelyNon0BLen=1.0 / (10 * l_ref), thresholdLogLK=18.0 * ll,
+               thresholdLogLKoptimization=1.0 * ll, thresholdLogLKconsecutivePlacement=1.0)
+    mark = dev.mark()
+    prng = np.random.default_rng(11)
+    new_samples = [tip_genome_list(perturb_diffs(data.diffs[i], data.ref, prng), ref_idx, **tip_kw) for i in range(Q)]
+    new_ids = dev.upload(new_samples)                              # samples NOT in the tree (2 extra substitutions each)
+    dev.placement_search_batch(new_ids[:8], **pkw)
+    t0 = time.perf_counter()
+    pres = dev.placement_search_batch(new_ids, **pkw)
+    pwall = time.perf_counter() - t0
+    dev.release(mark)
+    out["placement_batch"] = {"queries": int(Q), "wall_ms": 1e3 * pwall, "queries_per_s": Q / pwall,
+                              "reference_equivalent_placements_per_s": float(pres["nAppend"].sum() / pwall),
+                              "branches_scored_per_s": float(Q * (Cn + 1) / pwall),
+                              "minor_sequences": int((pres["status"] == 1).sum()), "failed": int((pres["status"] < 0).sum())}
+    if args.local_refs or args.samples <= 20000:
+        # ---- the same steps on the same tree after giving it MAT local references (setUpMAT's rule, 50 descendants per
+        # reference node, M:166 / 6152-6164): the form real MAPLE trees have; lists are shorter, searches cross frames ----
+        from maple_amd.mat import add_local_references
+        from maple_amd.tree_host import HostTree
+        ht = HostTree.from_mirror(mirror)
+        t0 = time.perf_counter()
+        n_ref = add_local_references(dev, ht, 50)
+        mat_s = time.perf_counter() - t0
+        dev.upload_tree(ht.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist, mirror.is_tip,
+                        ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp, ht.id_mut)
+        nsteps = max(1, min(args.steps, 4))
+        dev.spr_search_batch(order[np.arange(nsteps * B, (nsteps + 1) * B) % len(order)], **kw)
+        dev.timing_reset()
+        t0 = time.perf_counter()
+        pl = fails = 0
+        for i in range(nsteps):
+            r = dev.spr_search_batch(order[np.arange(i * B, (i + 1) * B) % len(order)], **kw)
+            pl += int(r["nAppend"][r["status"] >= -1].sum())
+            fails += int((r["status"] < -1).sum())
+        wall = time.perf_counter() - t0
+        out["spr_search_local_refs"] = {"reference_nodes": int(n_ref), "setup_s": round(mat_s, 2), "steps": nsteps,
+                                        "candidate_placements": pl, "failed_or_overflow": fails, "wall_ms": 1e3 * wall,
+                                        "placements_per_s": pl / wall}
+        upload_plain_tree()
+    return out
+
+
+def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, batch_of, gpu_results, kw, cpu_seconds, mkw, steps):
+    """The C oracle's SPR search (a port of findBestParentTopology + the worker body, oracle/maple_oracle_search.c,
+    pinned to the reference's recorded searches) on ONE host core over a bounded, evenly spread sample of the timed
+    searches; also cross-checks the GPU's node ids, moves and candidate counts."""
     from oracle.oracle_py import Oracle, OracleTree
     orc = Oracle(ref_idx, root_freqs)
     orc.set_model(**mkw)
@@ -332,32 +370,40 @@ def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, nodes, gpu_res, kw, cpu_s
     lists4 = []
     for ids in (mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up):
         have = np.nonzero(ids >= 0)[0]
+        have = have[np.argsort(ids[have], kind="stable")]              # arena order: the download moves whole runs
         lists4.append((have, dev.download_packed(ids[have])))
     up = [None if p < 0 else int(p) for p in mirror.parent]
     children = [[] if mirror.children[v, 0] < 0 else [int(mirror.children[v, 0]), int(mirror.children[v, 1])] for v in range(n)]
     otree = OracleTree(orc, mirror.root, up, children, mirror.dist, [[] for _ in range(n)], [0] * n, lists4)
-    # grow the sample until the time budget is used: every 997th, 499th, ... node
-    done, t_used, placements, checked = 0, 0.0, 0, 0
+    nodes = np.concatenate([batch_of(i) for i in range(steps)])
+    gpu = {k: np.concatenate([r[k] for r in gpu_results]) for k in ("status", "bestNode", "placement", "nAppend")}
+    # grow the sample until the time budget is used: every 997th search, then every 499th, ...
+    t_used, placements, checked = 0.0, 0, 0
     stride = 997
-    sel_all = []
+    seen = set()
     while t_used < cpu_seconds and stride >= 1:
-        sel = np.asarray([i for i in range(0, len(nodes), stride) if i not in set(sel_all)], dtype=np.int64)
+        sel = np.asarray([i for i in range(0, len(nodes), stride) if i not in seen], dtype=np.int64)
         if len(sel) == 0:
             break
+        # bound one call by what is left of the budget (a whole-tree search costs ~10 ms on this core)
+        est = max(1e-9, t_used / max(1, placements)) if placements else 6e-8
+        budget_pl = max(1.0, (cpu_seconds - t_used) / est)
+        cum = np.cumsum(gpu["nAppend"][sel].astype(np.float64))
+        sel = sel[: max(1, int(np.searchsorted(cum, budget_pl)) + 1)]
         t0 = time.perf_counter()
         o = orc.spr_worker(otree, nodes[sel], **kw)
         t_used += time.perf_counter() - t0
         placements += int(o["nAppend"].sum())
         for k in ("status", "bestNode", "placement", "nAppend"):
-            if not np.array_equal(o[k], gpu_res[k][sel]):
+            if not np.array_equal(o[k], gpu[k][sel]):
                 raise SystemExit(f"GPU SPR search disagrees with the oracle on {k}")
         checked += len(sel)
-        sel_all.extend(sel.tolist())
+        seen.update(sel.tolist())
         stride //= 2
     return {"value": placements / t_used, "unit": "placements/s", "cores": 1, "kind": "port",
-            "sample": f"{checked} of the {len(nodes)} searches (evenly spread), {placements} candidate placements, "
-                      f"C oracle search (oracle/maple_oracle_search.c), {t_used:.1f} s; node ids, moves and candidate "
-                      "counts identical to the GPU's"}
+            "sample": f"{checked} of the {len(nodes)} timed searches (evenly spread), {placements} candidate placements, "
+                      f"C oracle search (oracle/maple_oracle_search.c) on one host core, {t_used:.1f} s; node ids, moves "
+                      "and candidate counts identical to the GPU's"}
 
 
 def usable_host_threads():
@@ -376,53 +422,6 @@ def usable_host_threads():
         except (OSError, ValueError):
             pass
     return n
-
-
-def cpu_baseline(dev, mirror, cand_lists, q_lists, ref_idx, root_freqs, cpu_seconds, t_out, mkw):
-    """The C oracle (a port of the reference's appendProbNode) timed on a bounded sample of the same (query, candidate)
-    pairs, on one host core and on all host threads; also cross-checks the GPU scores."""
-    from oracle.oracle_py import Oracle
-    orc = Oracle(ref_idx, root_freqs)
-    orc.set_model(**mkw)
-    Cn = len(cand_lists)
-    lists = dev.download(np.concatenate([cand_lists, q_lists]))
-    packed = orc.pack_many(lists)
-    # calibrate on one query, then time as many queries as fit the budget
-    pl1 = np.arange(Cn, dtype=np.int32)
-    t0 = time.perf_counter()
-    orc.appendProbNode_batch(packed, pl1, np.full(Cn, Cn, dtype=np.int32), True, 1.0 / dev.lRef)
-    per_query = max(1e-6, time.perf_counter() - t0)
-    nq = int(max(1, min(len(q_lists), cpu_seconds / per_query)))
-    reps = int(max(1, round(cpu_seconds / (per_query * nq))))
-    pl = np.tile(pl1, nq)
-    cl = np.repeat(np.arange(Cn, Cn + nq, dtype=np.int32), Cn)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        ref = orc.appendProbNode_batch(packed, pl, cl, True, 1.0 / dev.lRef)
-    dt = time.perf_counter() - t0
-    gpu = t_out[: nq * Cn].cpu().numpy()
-    both_inf = np.isinf(ref) & np.isinf(gpu)
-    err = np.abs(ref - gpu) / np.maximum(1.0, np.abs(ref))
-    err[both_inf] = 0.0
-    single = reps * nq * Cn / dt
-    # the same loop on every host thread (OpenMP over the independent pairs): all queries, repeated for ~2 s of wall time
-    threads = usable_host_threads()
-    pl_all = np.tile(pl1, len(q_lists))
-    cl_all = np.repeat(np.arange(Cn, Cn + len(q_lists), dtype=np.int32), Cn)
-    orc.appendProbNode_batch(packed, pl_all, cl_all, True, 1.0 / dev.lRef, threads=threads)          # spin the pool up
-    reps_mt = int(max(1, round(2.0 * single * threads / len(pl_all))))
-    t0 = time.perf_counter()
-    for _ in range(reps_mt):
-        ref_mt = orc.appendProbNode_batch(packed, pl_all, cl_all, True, 1.0 / dev.lRef, threads=threads)
-    dt_mt = time.perf_counter() - t0
-    same = bool(np.array_equal(ref_mt[: len(ref)], ref))
-    return {"value": reps_mt * len(pl_all) / dt_mt, "unit": "placements/s", "cores": threads, "kind": "port",
-            "sample": f"{reps_mt} pass(es) over all {len(q_lists)} queries x {Cn} candidate branches of the same workload, "
-                      f"C oracle (oracle/maple_oracle.c) with OpenMP over the pairs on {threads} host threads (scheduler affinity capped by the container's CPU quota), {dt_mt:.1f} s wall"
-                      f" ({dt_mt * threads:.0f} thread-seconds); identical to the scalar run: {same}",
-            "single_core": {"value": single, "cores": 1,
-                            "sample": f"{reps} pass(es) over {nq} queries = {reps * nq * Cn} pairs, {dt:.1f} s"},
-            "max_rel_diff_vs_gpu": float(err.max())}
 
 
 if __name__ == "__main__":

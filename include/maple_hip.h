@@ -223,7 +223,11 @@ int maple_debug_trace_query(maple_ctx *ctx, int32_t query);
 int maple_debug_calib_walk(maple_ctx *ctx, uint64_t bytes, int32_t repeats, float *ms);
 int maple_debug_trace_read(maple_ctx *ctx, int32_t *n, int32_t *items4 /*[4*4096]*/, double *vals2 /*[2*4096]*/);
 
-/* ---- device-resident forms (inputs already in HBM; asynchronous on `stream`) --- */
+/* ---- device-resident forms (inputs already in HBM; asynchronous on `stream`) ---
+ * `stream` is the caller's hipStream_t, used verbatim: NULL is the legacy default stream (what
+ * torch.cuda.current_stream().cuda_stream is unless the caller switched streams), so the launch is ordered with the
+ * caller's other work on that stream.  (The context's own stream, used by the host-buffer entry points, is
+ * non-blocking: it is NOT ordered against the default stream; those entry points return only after their work is done.) */
 int maple_append_batch_dev(maple_ctx *ctx, int32_t n, const int32_t *parentList_dev, const int32_t *childList_dev,
                            const uint8_t *isTipC_dev, const double *bLen_dev, double *outLK_dev, void *stream);
 /* Q queries x C candidates (the placement loop, M:8050, and the cached regime of the SPR search, M:6993-7011):
@@ -235,6 +239,13 @@ int maple_append_queries_dev(maple_ctx *ctx, int32_t nQ, const int32_t *qList_de
 int maple_timing_reset(maple_ctx *ctx);
 int maple_timing_read(maple_ctx *ctx, int32_t *n_launches, double *total_ms);
 int maple_timing_read_each(maple_ctx *ctx, int32_t cap, float *ms, int32_t *n_launches);   /* one value per launch */
+/* The same, restricted to one kind of launch since the last reset, with the work it did:
+ *   1 = dense scoring inside maple_spr_search_batch (k_append_queries / k_place_score: units = (query, branch) pairs,
+ *       alg_bytes = SURVEY 8d bytes: 8 E + 8 A + 8 per candidate branch per query, each query list once per launch),
+ *   2 = budgeted lane searches, 3 = searches replayed over cached scores (units = searches),
+ *   4 = maple_append_queries_dev, 5 = maple_append_batch_dev, 6 = scoring inside maple_placement_search_batch (units = pairs). */
+int maple_timing_read_kind(maple_ctx *ctx, int32_t kind, int32_t *n_launches, double *total_ms, double *units,
+                           double *alg_bytes);
 /* algorithmic bytes (8*E + 8*B + 32*O + 8 per candidate, child list once per query) */
 int maple_append_algorithmic_bytes(maple_ctx *ctx, int32_t n, const int32_t *parentList, const int32_t *childList,
                                    int child_once, uint64_t *bytes);

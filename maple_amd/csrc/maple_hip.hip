@@ -69,6 +69,12 @@ struct maple_ctx {
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> evs;       // pairs (start, stop) of timed *_dev launches since the last reset
     size_t ev_used = 0;
+    // what each timed launch was: kind (MAPLE_K_*), units of work (pairs scored / searches run) and the algorithmic
+    // bytes of SURVEY 8d for the scoring kernels
+    std::vector<int32_t> ev_kind;
+    std::vector<double> ev_units, ev_bytes;
+    std::vector<double> cand_bytes_prefix;       // per scored column of the uploaded tree: 8E + 8A + 8, summed (host)
+    double scored_bytes_total = 0.0;
     std::string err;
     maple_params params{};
     int32_t lRef = 0;
@@ -145,6 +151,9 @@ struct maple_ctx {
     DevBuf<int32_t> s_trace_i;
     DevBuf<double> s_trace_d;
 };
+
+enum { MAPLE_K_OTHER = 0, MAPLE_K_SPR_SCORE = 1, MAPLE_K_SPR_SEARCH = 2, MAPLE_K_SPR_REPLAY = 3, MAPLE_K_APPEND_QUERIES = 4,
+       MAPLE_K_APPEND_PAIRS = 5, MAPLE_K_PLACE_SCORE = 6 };
 
 static int fail(maple_ctx *c, int code, const char *fmt, ...)
 {
@@ -988,15 +997,32 @@ extern "C" int maple_lists_download(maple_ctx *c, int32_t n, const int32_t *ids,
     HIPCK(c, hipSetDevice(c->device));
     int rc = check_ids(c, n, ids, false, "ids");
     if (rc) return rc;
+    // lists that sit back to back in the arena AND in the caller's buffers (the usual case: a tree's lists, downloaded in id
+    // order) move with one copy per run instead of one per list
     std::vector<uint2> w;
-    for (int i = 0; i < n; i++) {
-        int id = ids[i];
-        int ne = c->h_n_ent[id], na = c->h_n_aux[id];
-        w.resize(ne);
-        HIPCK(c, hipMemcpyAsync(w.data(), c->d_words + c->h_ent_off[id], ne * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
-        if (na) HIPCK(c, hipMemcpyAsync(aux + aux_off[i], c->d_aux + c->h_aux_off[id], na * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    int i = 0;
+    while (i < n) {
+        int j = i;
+        int64_t ne = 0, na = 0;
+        while (j < n) {
+            const int id = ids[j];
+            if (j > i) {
+                const int pid = ids[j - 1];
+                if (c->h_ent_off[id] != c->h_ent_off[pid] + c->h_n_ent[pid] || c->h_aux_off[id] != c->h_aux_off[pid] + c->h_n_aux[pid]
+                    || ent_off[j] != ent_off[j - 1] + c->h_n_ent[pid] || aux_off[j] != aux_off[j - 1] + c->h_n_aux[pid])
+                    break;
+            }
+            ne += c->h_n_ent[id]; na += c->h_n_aux[id];
+            j++;
+            if (ne > (int64_t)32 << 20) break;
+        }
+        const int id0 = ids[i];
+        w.resize((size_t)ne);
+        HIPCK(c, hipMemcpyAsync(w.data(), c->d_words + c->h_ent_off[id0], ne * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+        if (na) HIPCK(c, hipMemcpyAsync(aux + aux_off[i], c->d_aux + c->h_aux_off[id0], na * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
-        for (int k = 0; k < ne; k++) { pos[ent_off[i] + k] = (int32_t)w[k].x; meta[ent_off[i] + k] = w[k].y; }
+        for (int64_t k = 0; k < ne; k++) { pos[ent_off[i] + k] = (int32_t)w[k].x; meta[ent_off[i] + k] = w[k].y; }
+        i = j;
     }
     return MAPLE_OK;
 }
@@ -1060,7 +1086,7 @@ extern "C" int maple_mutations_upload(maple_ctx *c, int32_t n, const int64_t *of
 }
 
 // ---- helpers for batch calls -----------------------------------------------------------------------
-static int ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b);
+static int ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b, int kind, double units, double bytes);
 
 template <class T> static int h2d(maple_ctx *c, DevBuf<T> &b, const T *src, size_t n)
 {
@@ -1264,7 +1290,7 @@ extern "C" int maple_append_candset(maple_ctx *c, int32_t setId, const int32_t *
     TRY(h2d(c, c->s_i32[0], frameLists, (size_t)cs.nFrames));
     HIPCK(c, c->s_f64[0].reserve(cs.n));
     hipEvent_t e0, e1;
-    TRY(ev_pair(c, &e0, &e1));
+    TRY(ev_pair(c, &e0, &e1, MAPLE_K_OTHER, (double)cs.n, 0.0));
     HIPCK(c, hipEventRecord(e0, c->stream));
     DISPATCH3(c, k_append_candset, <<<grid_for(cs.n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), cs.n, cs.lists, cs.frame,
                                                                                   c->s_i32[0].p, isTipC, bLen, c->s_f64[0].p));
@@ -1477,9 +1503,12 @@ extern "C" int maple_evaluate_placement_batch(maple_ctx *c, int32_t n, const int
 }
 
 // ---- device-resident forms ---------------------------------------------------------------------------
-static int ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b)
+static int ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b, int kind = 0, double units = 0.0, double bytes = 0.0)
 {
     if (c->ev_used >= 8192) c->ev_used = 0;       // nobody is reading these timings: recycle the event pairs
+    const size_t slot = c->ev_used / 2;
+    if (c->ev_kind.size() <= slot) { c->ev_kind.resize(slot + 1); c->ev_units.resize(slot + 1); c->ev_bytes.resize(slot + 1); }
+    c->ev_kind[slot] = kind; c->ev_units[slot] = units; c->ev_bytes[slot] = bytes;
     if (c->ev_used + 2 > c->evs.size()) {
         hipEvent_t e0, e1;
         HIPCK(c, hipEventCreate(&e0));
@@ -1495,7 +1524,7 @@ static int ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b)
 // one launch of k_append_queries on stream s (timed with an event pair): out[q * ldOut + (outCol ? outCol[k] : k)]
 static int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int32_t *qList, int nC, const int32_t *cand,
                                  int isTip, double bLen, double *out, long long ldOut, const int32_t *outCol,
-                                 const uint8_t *qTip, const double *qBLen)
+                                 const uint8_t *qTip, const double *qBLen, int kind, double algBytes)
 {
     const long long tiles = (long long)nQ * ((nC + 63) / 64);
     if (tiles > 0x7fffffffLL - (1 << 20)) return fail(c, MAPLE_ERR_ARG, "nQ x nC too large for one launch");
@@ -1505,7 +1534,7 @@ static int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int3
     const long long waves = (tiles + 3) / 4;
     const int grid = waves < 256 * MAPLE_APPEND_WAVES ? (int)waves : 256 * MAPLE_APPEND_WAVES;   // workgroups of 4 wavefronts, MAPLE_APPEND_WAVES per CU = the occupancy limit
     hipEvent_t e0, e1;
-    TRY(ev_pair(c, &e0, &e1));
+    TRY(ev_pair(c, &e0, &e1, kind, (double)nQ * (double)nC, algBytes));
     HIPCK(c, hipEventRecord(e0, s));
     DISPATCH3(c, k_append_queries, <<<grid, MAPLE_BLOCK, 0, s>>>(c->d_model, view(c), nQ, qList, nC, cand, isTip, bLen, out, ldOut,
                                                                   outCol, qTip, qBLen, counter));
@@ -1521,9 +1550,9 @@ extern "C" int maple_append_batch_dev(maple_ctx *c, int32_t n, const int32_t *pl
     if (n == 0) return MAPLE_OK;
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;                               // the caller's stream, verbatim (NULL = the legacy default stream)
     hipEvent_t e0, e1;
-    TRY(ev_pair(c, &e0, &e1));
+    TRY(ev_pair(c, &e0, &e1, MAPLE_K_APPEND_PAIRS, (double)n, 0.0));
     HIPCK(c, hipEventRecord(e0, s));
     DISPATCH3(c, k_append, <<<grid_for(n), MAPLE_BLOCK, 0, s>>>(c->d_model, view(c), n, pl, cl, tip, bl, out));
     HIPCK(c, hipGetLastError());
@@ -1538,8 +1567,8 @@ extern "C" int maple_append_queries_dev(maple_ctx *c, int32_t nQ, const int32_t 
     if (nQ == 0 || nC == 0) return MAPLE_OK;
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
-    return launch_append_queries(c, stream ? (hipStream_t)stream : c->stream, nQ, qList_dev, nC, cand_dev, isTipC, bLen, out_dev,
-                                 nC, nullptr, nullptr, nullptr);
+    return launch_append_queries(c, (hipStream_t)stream, nQ, qList_dev, nC, cand_dev, isTipC, bLen, out_dev,
+                                 nC, nullptr, nullptr, nullptr, MAPLE_K_APPEND_QUERIES, 0.0);
 }
 
 #include "placement_host.h"
@@ -1690,6 +1719,8 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         std::vector<int32_t> ids(col.size()), rank(col.size()), fr(col.size());
         for (size_t i = 0; i < col.size(); i++) { ids[i] = totUp[col[i]]; rank[i] = recs[col[i]].preRank; fr[i] = recs[col[i]].frameOf; }
         c->n_scored = (int32_t)col.size();
+        c->scored_bytes_total = 0.0;                                       // 8 E + 8 A + 8 (result) per candidate
+        for (size_t i = 0; i < col.size(); i++) c->scored_bytes_total += 8.0 * c->h_n_ent[ids[i]] + 8.0 * c->h_n_aux[ids[i]] + 8.0;
         TRY(h2d(c, c->t_i32[8], ids.data(), ids.size()));
         TRY(h2d(c, c->t_scored_col, rank.data(), rank.size()));
         TRY(h2d(c, c->t_scored_frame, fr.data(), fr.size()));
@@ -1713,6 +1744,12 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     if (!c->tree_set) return fail(c, MAPLE_ERR_STATE, "maple_tree_upload has not been called");
     for (int i = 0; i < n; i++)
         if (nodes[i] < 0 || nodes[i] >= c->dtree.n) return fail(c, MAPLE_ERR_ARG, "nodes[%d] = %d is not a node", i, nodes[i]);
+    const bool dbgT = getenv("MAPLE_DEBUG") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration_cast<std::chrono::microseconds>(b - a).count() * 1e-3;
+    };
+    const auto tStart = tnow();
     SearchParams P;
     P.strict = sp->strictTopologyStopRules; P.allowedFails = sp->allowedFailsTopology;
     P.thrLKtopology = sp->thresholdLogLKtopology; P.thrPlacement = sp->thresholdTopologyPlacement;
@@ -1774,6 +1811,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             }
             long long maxLanes = wsBudget / (long long)LB.total;
             if (maxLanes > 4096 * 64) maxLanes = 4096 * 64;
+            // lanes pull searches from a counter: more wavefronts than the GPU holds at once (4 per SIMD) only cost workspace
+            if (cacheS && maxLanes > 8192) maxLanes = 8192;
             if (maxLanes < 64) maxLanes = 64;
             const int lanesWanted = (int)(m < maxLanes ? m : maxLanes);
             // searching lanes per wavefront (measured at 20k queries: the long searches of a non-strict round like 2 lanes,
@@ -1782,9 +1821,20 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             int activeLanes = (lanesWanted + lanesDiv - 1) / lanesDiv;
             if (activeLanes < 1) activeLanes = 1;
             if (activeLanes > 64) activeLanes = 64;
-            const int nWaves = (lanesWanted + activeLanes - 1) / activeLanes;
+            int nWaves = (lanesWanted + activeLanes - 1) / activeLanes;
+            if (nWaves > 8192) nWaves = 8192;
             const int lanes = nWaves * activeLanes;
-            HIPCK(c, c->s_search_ws.reserve_exact((size_t)lanes * LB.total));
+            const auto tWs0 = tnow();
+            {   // grow-only and at least doubling (a 20 GB hipMalloc costs ~0.7 s): batches of slowly growing size must not
+                // reallocate every time
+                size_t need = (size_t)lanes * LB.total;
+                if (need > c->s_search_ws.cap) {
+                    const size_t top = (size_t)maxLanes * LB.total;
+                    need = std::min(std::max(need, 2 * c->s_search_ws.cap), std::max(top, need));
+                }
+                HIPCK(c, c->s_search_ws.reserve_exact(need));
+            }
+            if (dbgT) fprintf(stderr, "[maple]   workspace %d lanes x %zu B: reserve %.1f ms\n", lanes, (size_t)LB.total, tms(tWs0, tnow()));
             HIPCK(c, hipMemsetAsync(c->s_counter.p, 0, sizeof(int32_t), c->stream));
             TRY(h2d(c, c->s_i32[0], todo.data(), (size_t)m));
             if (cacheS) TRY(h2d(c, c->s_i32[1], rows.data(), (size_t)m));
@@ -1804,7 +1854,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 launchWaves = lanes;                                     // (the workspace is sized for `lanes` searches at a time)
             } else { Tk.scan = nullptr; Tk.scanParent = nullptr; Tk.scanDepthCap = 0; }
             hipEvent_t e0, e1;
-            TRY(ev_pair(c, &e0, &e1));
+            TRY(ev_pair(c, &e0, &e1, cacheS ? MAPLE_K_SPR_REPLAY : MAPLE_K_SPR_SEARCH, (double)m, 0.0));
             HIPCK(c, hipEventRecord(e0, c->stream));
             DISPATCH3(c, k_spr_search, <<<launchWaves, 64, dynLds, c->stream>>>(c->d_model, view(c), mview(c), Tk, P, m, c->s_i32[0].p,
                                                                          L, LB, c->s_search_ws.p, c->s_counter.p, dout, poolW,
@@ -1841,6 +1891,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     int wideBudget = sp->wideSearchBudget == 0 ? 256 : sp->wideSearchBudget;
     const bool hybrid = wideBudget > 0;
     TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
+    if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: budgeted pass done\n", tms(tStart, tnow()));
     if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !getenv("MAPLE_NO_SCAN")) {
         // the tree in the searches' own depth-first order (SScan, search_dev.h): clade sizes, depths and the per-node facts
         // the cached-regime descent tests
@@ -1931,14 +1982,25 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 qt[k] = c->h_tree_tip[node];                           // isRemovedTip (M:6846)
                 qb[k] = c->h_tree_dist[node];                          // removedBLen = dist[node] (M:9644)
             }
-            HIPCK(c, c->s_cache.reserve((size_t)m * nT));
+            if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: wide chunk of %d searches starts\n", tms(tStart, tnow()), m);
+            {
+                size_t need = (size_t)m * nT;
+                if (need > c->s_cache.cap) need = std::min(std::max(need, 2 * c->s_cache.cap), std::max(chunk * (size_t)nT, need));
+                HIPCK(c, c->s_cache.reserve_exact(need));
+            }
+            if (dbgT) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] t=%.1f ms: score table reserved\n", tms(tStart, tnow())); }
             TRY(h2d(c, c->s_u8[3], qt.data(), (size_t)m));
             TRY(h2d(c, c->s_f64[3], qb.data(), (size_t)m));
             if (nF == 1) {
                 TRY(h2d(c, c->s_i32[6], ql.data(), (size_t)m));
+                double qBytes = 0.0;                                   // each query list once per launch
+                for (int k = 0; k < m; k++) qBytes += 8.0 * c->h_n_ent[ql[k]] + 8.0 * c->h_n_aux[ql[k]];
                 TRY(launch_append_queries(c, c->stream, m, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, 0, 0.0, c->s_cache.p, nT,
-                                          c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p));
+                                          c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p, MAPLE_K_SPR_SCORE,
+                                          (double)m * c->scored_bytes_total + qBytes));
+                if (dbgT) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] t=%.1f ms: scored\n", tms(tStart, tnow())); }
                 TRY(run_queries(qn, sl, c->s_cache.p, 0, nullptr, 0));
+                if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: replayed\n", tms(tStart, tnow()));
             } else {
                 // the removed list in every MAT reference frame, along the paths the traversal itself takes
                 // (passGenomeListThroughBranch up the chain of enclosing frames, M:6844-6847 / 7392, then down into every
@@ -1984,8 +2046,11 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                     a = b;
                 }
                 TRY(h2d(c, c->s_i32[6], R.data(), R.size()));
+                double qBytes = 0.0;                                   // every frame's copy of the query that is read
+                for (size_t k = 0; k < R.size(); k++) if (R[k] >= 0) qBytes += 8.0 * c->h_n_ent[R[k]] + 8.0 * c->h_n_aux[R[k]];
                 TRY(launch_place_score(c, m, nF, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, c->t_scored_frame.p, 0, 0.0,
-                                       c->s_cache.p, nT, c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p));
+                                       c->s_cache.p, nT, c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p, MAPLE_K_SPR_SCORE,
+                                       (double)m * c->scored_bytes_total + qBytes));
                 TRY(run_queries(qn, sl, c->s_cache.p, 0, c->s_i32[6].p, nF));
                 TRY(maple_arena_release(c, mark));
             }
@@ -2121,6 +2186,26 @@ extern "C" int maple_timing_read(maple_ctx *c, int32_t *n_launches, double *tota
     }
     *n_launches = (int32_t)(c->ev_used / 2);
     *total_ms = tot;
+    return MAPLE_OK;
+}
+
+extern "C" int maple_timing_read_kind(maple_ctx *c, int32_t kind, int32_t *n_launches, double *total_ms, double *units,
+                                      double *alg_bytes)
+{
+    if (!c || !n_launches || !total_ms) return MAPLE_ERR_ARG;
+    double tot = 0.0, u = 0.0, b = 0.0;
+    int32_t n = 0;
+    for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
+        if (c->ev_kind[k / 2] != kind) continue;
+        float ms = 0.f;
+        HIPCK(c, hipEventSynchronize(c->evs[k + 1]));
+        HIPCK(c, hipEventElapsedTime(&ms, c->evs[k], c->evs[k + 1]));
+        tot += ms; u += c->ev_units[k / 2]; b += c->ev_bytes[k / 2];
+        n++;
+    }
+    *n_launches = n; *total_ms = tot;
+    if (units) *units = u;
+    if (alg_bytes) *alg_bytes = b;
     return MAPLE_OK;
 }
 

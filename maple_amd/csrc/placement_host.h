@@ -42,7 +42,8 @@ __global__ MAPLE_APPEND_ATTR void k_place_score(const DevModel *__restrict__ mp,
 // one launch of k_place_score on the context's stream (timed): out[q * ldOut + (outCol ? outCol[k] : k)]
 static int launch_place_score(maple_ctx *c, int nQ, int nF, const int32_t *qFrameLists, int nC, const int32_t *cand,
                               const int32_t *candFrame, int isTip, double bLen, double *out, long long ldOut,
-                              const int32_t *outCol, const uint8_t *qTip, const double *qBLen)
+                              const int32_t *outCol, const uint8_t *qTip, const double *qBLen, int kind = MAPLE_K_PLACE_SCORE,
+                              double algBytes = 0.0)
 {
     const long long tiles = (long long)nQ * ((nC + 63) / 64);
     if (tiles > 0x7fffffffLL - (1 << 20)) return fail(c, MAPLE_ERR_ARG, "nQ x nC too large for one launch");
@@ -52,7 +53,7 @@ static int launch_place_score(maple_ctx *c, int nQ, int nF, const int32_t *qFram
     const long long waves = (tiles + 3) / 4;
     const int grid = waves < 256 * MAPLE_APPEND_WAVES ? (int)waves : 256 * MAPLE_APPEND_WAVES;
     hipEvent_t e0, e1;
-    TRY(ev_pair(c, &e0, &e1));
+    TRY(ev_pair(c, &e0, &e1, kind, (double)nQ * (double)nC, algBytes));
     HIPCK(c, hipEventRecord(e0, c->stream));
     DISPATCH3(c, k_place_score, <<<grid, MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), nQ, nF, qFrameLists, nC, cand, candFrame, isTip,
                                                                         bLen, out, ldOut, outCol, qTip, qBLen, counter));
@@ -237,7 +238,7 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
         HIPCK(c, c->p_minor.reserve((size_t)nq * std::max(nL, 1)));
         if (nF == 1)   // one reference frame: the plain batch kernel (query words staged in LDS) does the same job faster
             TRY(launch_append_queries(c, c->stream, nq, dU.p, nCols, M.d_candList.p, 1, pp->oneMutBLen, c->p_score.p, nCols,
-                                      nullptr, nullptr, nullptr));
+                                      nullptr, nullptr, nullptr, MAPLE_K_PLACE_SCORE, 0.0));
         else
             TRY(launch_place_score(c, nq, nF, dU.p, nCols, M.d_candList.p, M.d_candFrame.p, 1, pp->oneMutBLen, c->p_score.p, nCols,
                                    nullptr, nullptr, nullptr));

@@ -24,6 +24,7 @@ EXPORTS = [
     "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
+    "maple_timing_read_kind",
 ]
 
 
@@ -425,6 +426,14 @@ class Device:
         n, ms = C.c_int32(), C.c_double()
         self._ck(self.lib.maple_timing_read(self.h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    KIND_SPR_SCORE, KIND_SPR_SEARCH, KIND_SPR_REPLAY, KIND_APPEND_QUERIES, KIND_APPEND_PAIRS, KIND_PLACE_SCORE = 1, 2, 3, 4, 5, 6
+
+    def timing_read_kind(self, kind):
+        """(launches, summed HIP-event ms, units of work, algorithmic bytes) of one kind of timed launch since the reset."""
+        n, ms, u, b = C.c_int32(), C.c_double(), C.c_double(), C.c_double()
+        self._ck(self.lib.maple_timing_read_kind(self.h, int(kind), C.byref(n), C.byref(ms), C.byref(u), C.byref(b)))
+        return n.value, ms.value, u.value, b.value
 
     def append_algorithmic_bytes(self, parent, child=None, child_once=False):
         parent = _i32(parent)

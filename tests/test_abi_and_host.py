@@ -91,9 +91,12 @@ def test_tip_lists_and_reader_match_reference(fname):
     from maple_amd.host import read_maple_file, reference_tables, tip_genome_list
     with gzip.open(os.path.join(GOLDEN, fname), "rt") as fh:
         f = json.load(fh)
-    ref, data = read_maple_file(os.path.join(GOLDEN, "synth_small.maple.txt"))
-    assert ref == f["context"]["ref"] and len(data) == 160
-    ref_idx, root_freqs = reference_tables(ref)
+    if f.get("input", "synth_small.maple.txt") == "synth_small.maple.txt":
+        ref, data = read_maple_file(os.path.join(GOLDEN, "synth_small.maple.txt"))
+        assert ref == f["context"]["ref"] and len(data) == 160
+    else:                              # the reference's own example files are not copied into the repository
+        ref = f["context"]["ref"]
+    ref_idx, root_freqs = reference_tables(ref, "JC" if "JC" in f["flags"] else "UNREST")
     assert root_freqs == f["context"]["rootFreqs"]
     m = f["model"]
     for rec in f["placements"]:
@@ -122,6 +125,13 @@ def test_sharding_covers_every_node_once(fname):
     tree = HostTree(t["root"], t["up"], t["children"], t["dist"], t["mutations"], t["nMinor"], t["probVect"],
                     t["probVectUpRight"], t["probVectUpLeft"], t["probVectTotUp"])
     reachable = sorted(tree.preorder())       # tree surgery leaves unused node slots behind
+    with gzip.open(os.path.join(GOLDEN, fname), "rt") as fh:
+        core_ref = json.load(fh).get("coreNum", {})
+    for nc, ref_core in core_ref.items():       # the reference's own assignCoreNumbers(tree, t1, nc), M:12164-12195
+        got = tree.assign_core_numbers(int(nc))
+        assert [got[v] for v in reachable] == [ref_core[v] for v in reachable], nc
+        for r in range(int(nc)):
+            assert shard_nodes(tree, r, int(nc)) == [v for v in tree.preorder() if ref_core[v] == r]
     for world in (1, 2, 8):
         shards = [shard_nodes(tree, r, world) for r in range(world)]
         flat = sorted(v for s in shards for v in s)
