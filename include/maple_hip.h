@@ -215,6 +215,19 @@ int maple_placement_search_batch(maple_ctx *ctx, int32_t nQ, const int32_t *qLis
                                  int32_t *bestNode, double *bestScore, double *blen3, int32_t *bestDiffs,
                                  int32_t *nAppend, int32_t *status);
 
+/* The same search through the computePlacementSupportOnly=True exit of findBestParentForNewSample (M:7940, 7986,
+ * 8101-8290) -- what process_chunk consumes for --lineageRefs / --findSamplePlacements (M:11190-11220): a leaf the query
+ * is a minor sequence of does not end the search, every refined branch within max(thresholdLogLKoptimization,
+ * thresholdLogLKoptimizationTopology) of the best becomes a possible placement, zero-top-length placements are moved to
+ * the top of their polytomy, supports are exp(score) normalised.  Per query g: possiblePlacements =
+ * (outNode, outSupport, outBlen3 = top, bottom, appending)[outOff[g] .. outOff[g+1]) with support >= minBranchSupport, in
+ * the reference's order (unsorted); bestTotalLh[g] = list id of bestPlacementTotalLh (-1 = its empty list).
+ * cap = capacity of the three output arrays (entries). */
+int maple_placement_supports_batch(maple_ctx *ctx, int32_t nQ, const int32_t *qLists, const maple_placement_params *params,
+                                   double thresholdLogLKoptimizationTopology, double minBranchSupport, int64_t cap,
+                                   int64_t *outOff, int32_t *outNode, double *outSupport, double *outBlen3,
+                                   int32_t *bestTotalLh, int32_t *status);
+
 /* Debugging aid: record the visit sequence of query index `query` of the next maple_spr_search_batch
  * (per visited item: t1, direction, needsUpdating, failedPasses | lastLK, midProb); -1 switches it off. */
 int maple_debug_trace_query(maple_ctx *ctx, int32_t query);

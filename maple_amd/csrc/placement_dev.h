@@ -15,6 +15,10 @@ struct PlaceParams {
     double thrConsec;                  // thresholdLogLKconsecutivePlacement, M:63
     int32_t allowedFails;              // M:50
     int32_t strict;                    // strictStopRules, M:56
+    // computePlacementSupportOnly=True (M:7940, 7986, 8109): a leaf the query is a minor sequence of does not end the
+    // search, and the short list is kept down to max(thresholdLogLKoptimization, thresholdLogLKoptimizationTopology)
+    int32_t supportOnly;
+    double thrFilter;                  // what the final filter of the short list keeps: score >= best - thrFilter
 };
 
 #define MAPLE_PLACE_SHORTLIST 128      // entries within thresholdLogLKoptimization of the best, per query
@@ -63,7 +67,7 @@ __host__ __device__ inline void place_replay_one(const ScanRec *R, int nReach, c
     double bestLK = sc[rootCol];
     const double originalLK = bestLK;
     int bestNode = root;
-    if (rr.leafCol >= 0 && mn[rr.leafCol] == 1) { status = 1; minorNode = root; nAppend = 0; }
+    if (!P.supportOnly && rr.leafCol >= 0 && mn[rr.leafCol] == 1) { status = 1; minorNode = root; nAppend = 0; }
     // (lastLK, fails) a node hands to its children: in registers for the node just visited, in the per-depth slots for
     // the ancestors a skipped or finished clade returns to
     double curLK = bestLK;
@@ -86,8 +90,9 @@ __host__ __device__ inline void place_replay_one(const ScanRec *R, int nReach, c
         const int cmp = rec.leafCol >= 0 ? mn[rec.leafCol] : 0;
         const int t1 = rec.node;
         if (rec.leafCol >= 0) {
-            if (cmp == 1) { status = 1; minorNode = t1; break; }           // M:7986-8003
-            if (cmp == 2) missed++;
+            if (cmp == 1) {                                               // M:7986-8003
+                if (!P.supportOnly) { status = 1; minorNode = t1; break; }
+            } else if (cmp == 2) missed++;
         }
         double lk = parentLK;
         if (rec.candCol >= 0) {
@@ -103,7 +108,7 @@ __host__ __device__ inline void place_replay_one(const ScanRec *R, int nReach, c
                 if (nSl == MAPLE_PLACE_SHORTLIST) {                       // drop what the final filter (M:8109) would drop anyway
                     int k = 0;
                     for (int i = 0; i < nSl; i++)
-                        if (slL[i] >= bestLK - P.thrOpt) { slN[k] = slN[i]; slL[k] = slL[i]; k++; }
+                        if (slL[i] >= bestLK - P.thrFilter) { slN[k] = slN[i]; slL[k] = slL[i]; k++; }
                     nSl = k;
                 }
                 if (nSl == MAPLE_PLACE_SHORTLIST) { status = -6; break; }
@@ -121,7 +126,7 @@ __host__ __device__ inline void place_replay_one(const ScanRec *R, int nReach, c
     // final filter of the short list (M:8109) and the state of each entry's query list object
     int k = 0;
     for (int i = 0; i < nSl; i++)
-        if (slL[i] >= bestLK - P.thrOpt) { slN[k] = slN[i]; slL[k] = slL[i]; k++; }
+        if (slL[i] >= bestLK - P.thrFilter) { slN[k] = slN[i]; slL[k] = slL[i]; k++; }
     nSl = k;
     uint8_t *slS = o.slShort + (long long)q * MAPLE_PLACE_SHORTLIST;
     for (int i = 0; i < nSl; i++) {

@@ -164,12 +164,47 @@ extern "C" int maple_placement_prepare(maple_ctx *c, const maple_placement_param
     return MAPLE_OK;
 }
 
+// what the computePlacementSupportOnly=True exit of findBestParentForNewSample hands back (M:8101-8290), CSR over queries
+struct SupportsOut {
+    double thrOptTopo, minBranchSupport;
+    int64_t cap;
+    int64_t *off;                      // [nQ + 1]
+    int32_t *node;                     // possiblePlacements: node, support, (top, bottom, appending)
+    double *support, *blen3;
+    int32_t *bestTotalLh;              // [nQ] list id of bestPlacementTotalLh (-1 = the reference's empty list)
+};
+
+static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists, const maple_placement_params *pp,
+                                 int32_t *bestNode, double *bestScore, double *blen3, int32_t *bestDiffs,
+                                 int32_t *nAppend, int32_t *status, SupportsOut *sup);
+
 extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int32_t *qLists, const maple_placement_params *pp,
                                             int32_t *bestNode, double *bestScore, double *blen3, int32_t *bestDiffs,
                                             int32_t *nAppend, int32_t *status)
 {
     if (!c || nQ < 0 || !qLists || !pp || !bestNode || !bestScore || !blen3 || !bestDiffs || !nAppend || !status)
         return MAPLE_ERR_ARG;
+    return placement_search_impl(c, nQ, qLists, pp, bestNode, bestScore, blen3, bestDiffs, nAppend, status, nullptr);
+}
+
+extern "C" int maple_placement_supports_batch(maple_ctx *c, int32_t nQ, const int32_t *qLists, const maple_placement_params *pp,
+                                              double thresholdLogLKoptimizationTopology, double minBranchSupport, int64_t cap,
+                                              int64_t *outOff, int32_t *outNode, double *outSupport, double *outBlen3,
+                                              int32_t *bestTotalLh, int32_t *status)
+{
+    if (!c || nQ < 0 || !qLists || !pp || cap < 0 || !outOff || !outNode || !outSupport || !outBlen3 || !bestTotalLh || !status)
+        return MAPLE_ERR_ARG;
+    SupportsOut sup{thresholdLogLKoptimizationTopology, minBranchSupport, cap, outOff, outNode, outSupport, outBlen3, bestTotalLh};
+    outOff[0] = 0;
+    std::vector<int32_t> bn(nQ), bd(nQ), na(nQ);
+    std::vector<double> bs(nQ), bl(3 * (size_t)nQ);
+    return placement_search_impl(c, nQ, qLists, pp, bn.data(), bs.data(), bl.data(), bd.data(), na.data(), status, &sup);
+}
+
+static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists, const maple_placement_params *pp,
+                                 int32_t *bestNode, double *bestScore, double *blen3, int32_t *bestDiffs,
+                                 int32_t *nAppend, int32_t *status, SupportsOut *sup)
+{
     if (nQ == 0) return MAPLE_OK;
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
@@ -201,6 +236,8 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
     PlaceParams P;
     P.thrLK = pp->thresholdLogLK; P.thrOpt = pp->thresholdLogLKoptimization; P.thrConsec = pp->thresholdLogLKconsecutivePlacement;
     P.allowedFails = pp->allowedFails; P.strict = pp->strictStopRules;
+    P.supportOnly = sup ? 1 : 0;
+    P.thrFilter = sup ? std::max(pp->thresholdLogLKoptimization, sup->thrOptTopo) : pp->thresholdLogLKoptimization;
     // queries per chunk: the score matrix stays below 2 GiB and the per-frame query lists below 8 M arena lists
     const int64_t maxCells = (int64_t)1 << 28;
     const int64_t byFrames = std::max<int64_t>(1, ((int64_t)8 << 20) / std::max(nF, 1));
@@ -344,6 +381,7 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
                 for (int i = 0; i < hNShort[q]; i++) { rq.push_back(q); rnode.push_back(hSlNode[(size_t)q * SL + i]); ridx.push_back(i); }
         const size_t nr = rq.size();
         std::vector<double> ev(4 * nr), comp(2 * nr);
+        std::vector<int32_t> refinedUp;                                   // the upper list each refined branch was evaluated with
         if (nr) {
             // the upper list of each distinct node, expressed below the node's own mutations
             std::vector<int32_t> upOf(c->dtree.n, -2), needNode, needSrc, needMut;
@@ -373,6 +411,7 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
             }
             TRY(maple_evaluate_placement_batch(c, (int32_t)nr, mid.data(), down.data(), upl.data(), dist.data(), ql.data(),
                                                remTip.data(), tip.data(), ev.data()));
+            refinedUp = upl;
             for (size_t i = 0; i < nr; i++) {
                 ap[i] = ap[nr + i] = upl[i];
                 ac[i] = ac[nr + i] = down[i];
@@ -385,6 +424,110 @@ extern "C" int maple_placement_search_batch(maple_ctx *c, int32_t nQ, const int3
         auto t5 = tnow();
         if (dbg) fprintf(stderr, "[maple] placement batch of %d: root vector %lld us, frames %lld, score+minor+traversal %lld, shorten %lld, refine %lld\n",
                          nq, tus(t0, t1), tus(t1, t2), tus(t2, t3), tus(t3, t4), tus(t4, t5));
+        if (sup) {
+            // ---- computePlacementSupportOnly=True, M:8101-8290: every refined branch is a possible placement; the mid-branch
+            // vector of each (newMidVector, M:8131) is produced by one more merge batch from the optimised lengths
+            const double eff = pp->effectivelyNon0BLen;
+            std::vector<int32_t> midList(nr, -1);
+            if (nr) {
+                std::vector<int32_t> l1(nr), l2(nr);
+                std::vector<double> b1(nr), b2(nr);
+                std::vector<uint8_t> t1(nr, 0), t2(nr), ud(nr, 1);
+                std::vector<int32_t> upOf2(nr);
+                // (the same upper lists the refinement used)
+                for (size_t i = 0; i < nr; i++) {
+                    const int32_t v = rnode[i];
+                    l2[i] = c->h_tree_lower[v]; b1[i] = ev[4 * i + 2]; b2[i] = ev[4 * i + 1]; t2[i] = c->h_tree_tip[v];
+                }
+                TRY(maple_merge_batch(c, (int32_t)nr, refinedUp.data(), b1.data(), t1.data(), l2.data(), b2.data(), t2.data(), ud.data(),
+                                      nullptr, nullptr, midList.data(), nullptr));
+            }
+            const auto &up = c->h_tree_up;
+            const auto &dist = c->h_tree_dist;
+            size_t r2 = 0;
+            for (int q = 0; q < nq; q++) {
+                const int g = q0 + q;
+                status[g] = hStatus[q];
+                int64_t o = sup->off[g];
+                sup->off[g + 1] = o;
+                sup->bestTotalLh[g] = -1;
+                if (hStatus[q] < 0) continue;
+                int32_t bn = hBest[q];
+                double bs = hBestLK[q];
+                double bb[3] = {0.0, 0.0, pp->oneMutBLen};
+                if (bn != root) { const double half = dist[bn] / 2; bb[0] = half; bb[1] = half / 2; }
+                int32_t bmid = -1;
+                std::vector<int32_t> pn, pm;
+                std::vector<double> pc, pb;
+                bool rootDone = false, haveRoot = false;
+                int32_t rootNode = -1, rootMid = -1;
+                double rootCost = 0.0, rootB[3] = {0, 0, 0};
+                for (int i = 0; i < hNShort[q]; i++, r2++) {
+                    const double sc = hf[2 * (size_t)nq + (size_t)q * SL + i];
+                    if (!(sc >= hBestLK[q] - pp->thresholdLogLKoptimization || sc >= hBestLK[q] - sup->thrOptTopo)) continue;   // M:8109
+                    const int32_t t1n = rnode[r2];
+                    const double optimized = ev[4 * r2] + comp[nr + r2] - comp[r2];
+                    const double top = ev[4 * r2 + 2], bottom = ev[4 * r2 + 1], app = ev[4 * r2 + 3];
+                    if (optimized >= bs) { bn = t1n; bs = optimized; bb[0] = top; bb[1] = bottom; bb[2] = app; bmid = midList[r2]; }
+                    bool different = true;                                 // M:8190-8201
+                    if (top <= eff) different = false;
+                    if (dist[t1n] <= eff && up[t1n] >= 0 && up[up[t1n]] >= 0) different = false;
+                    if (!rootDone && top <= eff) {                         // M:8203-8212
+                        int32_t tn = up[t1n];
+                        while (dist[tn] <= eff && up[tn] >= 0) tn = up[tn];
+                        if (up[tn] < 0) {
+                            rootDone = true; haveRoot = true;
+                            rootNode = tn; rootCost = optimized; rootB[0] = top; rootB[1] = bottom; rootB[2] = app; rootMid = midList[r2];
+                        }
+                    } else if (different) {
+                        pn.push_back(t1n); pc.push_back(optimized); pm.push_back(midList[r2]);
+                        pb.push_back(top); pb.push_back(bottom); pb.push_back(app);
+                    }
+                }
+                if (bs == -INFINITY) bs = hOrig[q];
+                if (haveRoot) {                                            // M:8219-8237
+                    bool add = true;
+                    if (c->h_tree_c0[root] >= 0)
+                        for (int32_t v : pn) if (v == c->h_tree_c0[root] || v == c->h_tree_c1[root]) { add = false; break; }
+                    if (add) {
+                        pn.push_back(rootNode); pc.push_back(rootCost); pm.push_back(rootMid);
+                        pb.push_back(rootB[0]); pb.push_back(rootB[1]); pb.push_back(rootB[2]);
+                    }
+                }
+                if (pn.empty()) {                                          // M:8241-8245
+                    pn.push_back(bn); pc.push_back(bs); pm.push_back(bmid);
+                    pb.push_back(bb[0]); pb.push_back(bb[1]); pb.push_back(bb[2]);
+                }
+                for (size_t i = 0; i < pn.size(); i++) {                   // M:8248-8262
+                    const double top = pb[3 * i];
+                    if (top <= eff) {
+                        int32_t tn = pn[i];
+                        while (dist[tn] <= eff && up[tn] >= 0) tn = up[tn];
+                        if (up[tn] >= 0) {
+                            tn = up[tn];
+                            while (dist[tn] <= eff && up[tn] >= 0) tn = up[tn];
+                            pn[i] = tn;
+                            pb[3 * i + 1] = top; pb[3 * i] = dist[tn];
+                        }
+                    }
+                }
+                double tot = 0.0;                                          // M:8265-8275
+                for (auto &x : pc) { x = exp(x); tot += x; }
+                for (auto &x : pc) x = tot ? x / tot : 0.0;
+                double hi = 0.0;
+                for (size_t i = 0; i < pn.size(); i++) {                   // M:8278-8287
+                    if (pc[i] >= sup->minBranchSupport) {
+                        if (o >= sup->cap) return fail(c, MAPLE_ERR_ARG, "supports output capacity %lld exhausted", (long long)sup->cap);
+                        sup->node[o] = pn[i]; sup->support[o] = pc[i];
+                        sup->blen3[3 * o] = pb[3 * i]; sup->blen3[3 * o + 1] = pb[3 * i + 1]; sup->blen3[3 * o + 2] = pb[3 * i + 2];
+                        o++;
+                    }
+                    if (pc[i] > hi) { hi = pc[i]; sup->bestTotalLh[g] = pm[i]; }
+                }
+                sup->off[g + 1] = o;
+            }
+            continue;
+        }
         // ---- outcome per query
         size_t r = 0;
         for (int q = 0; q < nq; q++) {

@@ -24,7 +24,7 @@ EXPORTS = [
     "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
-    "maple_timing_read_kind",
+    "maple_timing_read_kind", "maple_placement_supports_batch",
 ]
 
 
@@ -384,6 +384,31 @@ class Device:
                                                        _ptr(out["bestScore"]), _ptr(out["blen"]), _ptr(out["bestDiffs"]),
                                                        _ptr(out["nAppend"]), _ptr(out["status"])))
         return out
+
+    def placement_supports_batch(self, q_lists, *, oneMutBLen, effectivelyNon0BLen, thresholdLogLK,
+                                 thresholdLogLKoptimization, thresholdLogLKconsecutivePlacement,
+                                 thresholdLogLKoptimizationTopology, minBranchSupport=0.01, allowedFails=5,
+                                 strictStopRules=True, onlyFindIdentical=False):
+        """findBestParentForNewSample(..., computePlacementSupportOnly=True) (M:8101-8290) for many query lists: per query
+        (possiblePlacements = [(node, support, (top, bottom, appending)), ...], list id of bestPlacementTotalLh or -1)."""
+        q = _i32(q_lists)
+        n = len(q)
+        pp = MaplePlacementParams(oneMutBLen, effectivelyNon0BLen, thresholdLogLK, thresholdLogLKoptimization,
+                                  thresholdLogLKconsecutivePlacement, int(allowedFails), int(bool(strictStopRules)),
+                                  int(bool(onlyFindIdentical)))
+        cap = 128 * max(1, n)
+        off = np.zeros(n + 1, np.int64)
+        node, supp, bl = np.zeros(cap, np.int32), np.zeros(cap), np.zeros((cap, 3))
+        best, status = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self._ck(self.lib.maple_placement_supports_batch(self.h, n, _ptr(q), C.byref(pp),
+                                                         C.c_double(thresholdLogLKoptimizationTopology),
+                                                         C.c_double(minBranchSupport), C.c_int64(cap), _ptr(off), _ptr(node),
+                                                         _ptr(supp), _ptr(bl), _ptr(best), _ptr(status)))
+        out = []
+        for g in range(n):
+            a, b = off[g], off[g + 1]
+            out.append(([(int(node[i]), float(supp[i]), tuple(float(x) for x in bl[i])) for i in range(a, b)], int(best[g])))
+        return out, status
 
     def debug_calib_walk(self, nbytes, repeats=1):
         ms = C.c_float()

@@ -8,8 +8,8 @@ tie-breaks and short-list refinement are replayed over the cached scores.  Resul
 score, branch lengths, bestDiffs) are those of the reference; the number of appendProbNode
 evaluations the *reference* would have issued is reported as ``n_append``.
 
-Not implemented (off by default, outside BASELINE's configs): HnZ, time trees,
---deeperSearchForLongBranches, computePlacementSupportOnly.
+``find_placement_supports`` is the computePlacementSupportOnly=True exit (M:8101-8290).
+Not implemented (off by default, outside BASELINE's configs): HnZ, time trees, --deeperSearchForLongBranches.
 """
 from __future__ import annotations
 
@@ -79,7 +79,7 @@ class PlacementSearcher:
         self.cand = np.nonzero((up >= 0) & (dist > params.effectivelyNon0BLen) & (t.id_totUp >= 0))[0]
         # scored in order of list length, so that the 64 lanes of a wavefront finish together
         self.cand = self.cand[np.argsort(dev.sizes(t.id_totUp[self.cand])[0], kind="stable")]
-        self.leaves = np.asarray([v for v in range(n) if not t.children[v]], dtype=np.int64)
+        self.leaves = np.asarray([v for v in order if not t.children[v]], dtype=np.int64)   # reachable ones: surgery leaves dead slots
         # rootVector(probVect[root], False, False, tree, root) does not depend on the query (M:7958)
         path = [t.id_mut[t.root]] if t.id_mut[t.root] >= 0 else []
         self.root_vect = int(dev.root_vector_batch([t.id_lower[t.root]], [0.0], [False], [path])[0])
@@ -150,6 +150,29 @@ class PlacementSearcher:
                             None if minor else tuple(float(x) for x in out["blen"][k]), lists[k],
                             dict(n_append=int(out["nAppend"][k]), minor=bool(minor))))
             return res
+        finally:
+            dev.release(mark)
+
+    def find_placement_supports(self, diffs_list, thresholdLogLKoptimizationTopology, minBranchSupport=0.01):
+        """findBestParentForNewSample(tree, root, diffs, sample, computePlacementSupportOnly=True) for many samples on the
+        frozen tree (the call of process_chunk, M:11200): per sample (possiblePlacements, bestPlacementTotalLh) as the
+        reference returns them (M:8264-8290); possiblePlacements = [(node, support, (top, bottom, appending)), ...]."""
+        dev, p = self.dev, self.p
+        self._prepare_native()
+        mark = dev.mark()
+        try:
+            q_ids = dev.upload(list(diffs_list))
+            res, status = dev.placement_supports_batch(
+                q_ids, oneMutBLen=p.oneMutBLen, effectivelyNon0BLen=p.effectivelyNon0BLen, thresholdLogLK=p.thresholdLogLK,
+                thresholdLogLKoptimization=p.thresholdLogLKoptimization,
+                thresholdLogLKconsecutivePlacement=p.thresholdLogLKconsecutivePlacement,
+                thresholdLogLKoptimizationTopology=thresholdLogLKoptimizationTopology, minBranchSupport=minBranchSupport,
+                allowedFails=p.allowedFails, strictStopRules=p.strictStopRules, onlyFindIdentical=p.onlyFindIdentical)
+            if (status < 0).any():
+                raise RuntimeError("placement search overflow (status %s)" % sorted(set(status[status < 0])))
+            ids = [b for _, b in res]
+            lists = dev.download(ids)
+            return [(pl, [] if lst is None else lst) for (pl, _), lst in zip(res, lists)]
         finally:
             dev.release(mark)
 

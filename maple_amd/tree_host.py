@@ -81,13 +81,39 @@ class HostTree:
         self.id_mut = -np.ones(self.n, dtype=np.int32)
         if midx:
             self.id_mut[np.asarray(midx)] = dev.upload_mutations([self.mutations[i] for i in midx])
+        return self.upload_topology(dev)
+
+    def upload_topology(self, dev: Device):
+        """(Re-)upload the topology and the list ids (maple_tree_upload) -- after tree surgery or a repair of the lists."""
         up = np.asarray([-1 if u is None else u for u in self.up], dtype=np.int32)
         c0 = np.asarray([c[0] if c else -1 for c in self.children], dtype=np.int32)
         c1 = np.asarray([c[1] if c else -1 for c in self.children], dtype=np.int32)
         is_tip = np.asarray([(not c) and (m == 0) for c, m in zip(self.children, self.n_minor)], dtype=np.uint8)
-        dev.upload_tree(self.root, up, c0, c1, self.dist, is_tip, self.id_lower, self.id_upRight, self.id_upLeft,
+        dist = np.asarray([float(x or 0.0) for x in self.dist])
+        dev.upload_tree(self.root, up, c0, c1, dist, is_tip, self.id_lower, self.id_upRight, self.id_upLeft,
                         self.id_totUp, self.id_mut)
         return self
+
+    def apply_topology(self, root, up, children, dist, n_minor):
+        """Tree surgery done by the host (placeSampleOnTree / cutAndPasteNode stay host code): take over the new arrays,
+        growing the per-node tables for nodes that did not exist (their lists are missing: id -1).  Returns the nodes
+        whose parent, children or branch length changed -- what update_genome_lists needs to be told."""
+        n_new = len(up)
+        changed = []
+        for v in range(n_new):
+            if v >= self.n:
+                changed.append(v)
+            elif self.up[v] != up[v] or list(self.children[v]) != list(children[v] or []) \
+                    or float(self.dist[v] or 0.0) != float(dist[v] or 0.0):
+                changed.append(v)
+        grow = n_new - self.n
+        if grow > 0:
+            for name in ("id_lower", "id_upRight", "id_upLeft", "id_totUp", "id_mut"):
+                setattr(self, name, np.concatenate([getattr(self, name), -np.ones(grow, dtype=np.int32)]))
+            self.mutations = self.mutations + [[] for _ in range(grow)]
+        self.root, self.up, self.children = root, list(up), [list(c) if c else [] for c in children]
+        self.dist, self.n_minor, self.n = [float(x or 0.0) for x in dist], list(n_minor), n_new
+        return changed
 
 
 def tree_log_likelihood(dev: Device, tree: HostTree):
@@ -448,6 +474,113 @@ def optimize_branch_lengths_fast_pass(dev: Device, tree: HostTree, effectivelyNo
         return updates, dirty
     finally:
         dev.release(mark)
+
+
+def optimize_branch_lengths(dev: Device, tree: HostTree, effectivelyNon0BLen, dirty=None, batch=256):
+    """traverseTreeToOptimizeBranchLengths(tree, root) with the reference's DEFAULT arguments (fastPass=False,
+    M:8727-8893; every call site of the reference uses this form: M:11059, 11728, 11806, 11854, 11864, 11900, 11906,
+    11979, 12256): a Gauss-Seidel sweep in the reference's visiting order -- every dirty branch is re-estimated with
+    estimateBranchLengthWithDerivative(upper vector, lower list) from lists that already reflect every earlier change,
+    and a branch that moves by more than 1 % (M:8873) is followed at once by the repair of the genome lists around it
+    (updatePartials, M:8875-8878: here update_genome_lists).
+
+    GPU form: the estimates of the next `batch` branches in visiting order are produced by ONE
+    estimateBranchLength launch; an estimate stays valid for as long as neither list it was computed from has been
+    replaced by a repair since (list ids are compared), so the sweep only goes back to the GPU for estimates when a
+    repair reached a branch that was already estimated -- the result is that of the one-at-a-time sweep.
+    ``tree.dist`` and the genome lists are updated in place.  Returns (number of updates, dirty flags, nodes updated in
+    order)."""
+    root = tree.root
+    if not tree.children[root]:
+        return 0, dirty, []
+    n = tree.n
+    mut = tree.id_mut
+    tip = np.asarray([(not c) and (m == 0) for c, m in zip(tree.children, tree.n_minor)])
+    dirty = [True] * n if dirty is None else list(dirty)
+    l_ref = dev.lRef
+    a, b = tree.children[root]
+    dist = tree.dist
+    for v in range(n):
+        dist[v] = float(dist[v] or 0.0)
+    if dist[a] > effectivelyNon0BLen or dist[b] > effectivelyNon0BLen:                  # M:8743-8810
+        mark = dev.mark()
+        tot = (dist[a] + dist[b]) * l_ref
+        grid = []
+        for i in range(max(1, round(tot)) * 2 + 1):
+            b1 = min(tot, float(i) / 2)
+            b2 = max(tot - b1, 0.0)
+            grid.append((b1 / l_ref, b2 / l_ref))
+        pv = []
+        for c in (a, b):
+            lid = tree.id_lower[c]
+            if mut[c] >= 0:
+                lid = dev.pass_branch_batch([lid], [mut[c]], True)[0]
+            pv.append(int(lid))
+        k = len(grid)
+        out, lk = dev.merge_batch([pv[0]] * k, [g[0] for g in grid], [bool(tip[a])] * k, [pv[1]] * k,
+                                  [g[1] for g in grid], [bool(tip[b])] * k, False, returnLK=True)
+        if (out < 0).any():
+            raise RuntimeError("None root vector in the root branch-length grid (the reference fails here too)")
+        if mut[root] >= 0:
+            out = dev.pass_branch_batch(out, [mut[root]] * k, True)
+        cost = lk + dev.root_prob_batch(out)
+        best, best_cost = None, float("-inf")
+        for i in range(k):
+            if cost[i] > best_cost:
+                best_cost, best = float(cost[i]), grid[i][0]
+        dev.release(mark)
+        both = dist[a] + dist[b]
+        if best != dist[a]:
+            dist[a] = best
+            update_genome_lists(dev, tree, [a])
+        b2 = max(both - best, 0.0)
+        if b2 != dist[b]:
+            dist[b] = b2
+            update_genome_lists(dev, tree, [b])
+    order = []
+    stack = ([*tree.children[a]] if tree.children[a] else []) + ([*tree.children[b]] if tree.children[b] else [])
+    while stack:                                                       # the reference's visiting order, M:8812-8822 / 8890
+        v = stack.pop()
+        order.append(v)
+        stack.extend(tree.children[v])
+    todo = [v for v in order if dirty[v]]
+    updates, updated_nodes = 0, []
+    pos = 0
+    while pos < len(todo):
+        chunk = np.asarray(todo[pos:pos + batch], dtype=np.int64)
+        mark = dev.mark()
+        p = np.asarray([tree.up[v] for v in chunk])
+        first = np.asarray([tree.children[u][0] for u in p]) == chunk
+        up_id = np.where(first, tree.id_upRight[p], tree.id_upLeft[p]).astype(np.int32)
+        low_id = tree.id_lower[chunk].copy()
+        up_vect = up_id.copy()
+        need = np.nonzero(mut[chunk] >= 0)[0]
+        if len(need):
+            up_vect[need] = dev.pass_branch_batch(up_vect[need], mut[chunk[need]], False)
+        t, is_false = dev.blen_batch(up_vect, low_id, tip[chunk])
+        dev.release(mark)                                             # (the passed copies were only needed for the estimates)
+        done = 0
+        for k, v in enumerate(chunk.tolist()):
+            u = tree.up[v]
+            cur_up = tree.id_upRight[u] if tree.children[u][0] == v else tree.id_upLeft[u]
+            if cur_up != up_id[k] or tree.id_lower[v] != low_id[k]:
+                break                                                 # a repair replaced one of its inputs: estimate again
+            best = 0.0 if is_false[k] else float(t[k])
+            if best or dist[v]:
+                if (not best) or (not dist[v]) or dist[v] / best > 1.01 or dist[v] / best < 0.99:   # M:8873
+                    dist[v] = best
+                    updates += 1
+                    updated_nodes.append(v)
+                    update_genome_lists(dev, tree, [v])
+                else:
+                    dirty[v] = False
+            else:
+                dirty[v] = False
+            done += 1
+        pos += max(done, 0)
+        if done == 0:                                                 # cannot happen (a fresh estimate is always valid)
+            raise RuntimeError("branch-length sweep made no progress")
+    return updates, dirty, updated_nodes
 
 
 def find_best_root(dev: Device, tree: HostTree, *, strictTopologyStopRules, allowedFailsTopology, thresholdLogLKtopology,

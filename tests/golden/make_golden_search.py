@@ -103,7 +103,13 @@ def perturb(diffs, ref, rng):
     return out
 
 
-def run(name, flags):
+def frozen_reference_tree(name, flags):
+    """Run the unmodified reference as __main__ on the run's input and return (its globals, the tree it ended with, root,
+    printed log-likelihoods, input path) with every genome list recomputed from the tips.  With an error model the
+    reference's tips share ambiguity vectors with one another (one table object per IUPAC code) and
+    reCalculateAllGenomeLists rewrites them in place tip by tip (updateProbVectTerminalNode, M:3966 / 6130), so that an
+    internal list depends on which tip was visited last; the tips are de-aliased first, which makes every list of the
+    frozen tree a function of its tips' lists."""
     out_dir = tempfile.mkdtemp(prefix="maple_golden_search_")
     inp = input_path(name, out_dir)
     argv = ["MAPLE", "--input", inp, "--output", os.path.join(out_dir, "out"), "--overwrite"] + flags
@@ -132,12 +138,20 @@ def run(name, flags):
     tree, t1 = g["tree"], g["t1"]
     run_log = log.getvalue()
     printed_lk = [float(x) for x in re.findall(r"ikelihood[^\n]*?(-\d+\.\d+)", run_log)]
+    for v in range(len(tree.up)):
+        if tree.probVect[v] is not None and not tree.children[v]:
+            tree.probVect[v] = copy.deepcopy(tree.probVect[v])
     with contextlib.redirect_stdout(io.StringIO()):
         g["setAllDirty"](tree, t1)
         g["reCalculateAllGenomeLists"](tree, t1)
         g["assignCoreNumbers"](tree, t1, 1)
     for i in range(len(tree.replacements)):
         tree.replacements[i] = 0
+    return g, tree, t1, printed_lk, inp
+
+
+def run(name, flags):
+    g, tree, t1, printed_lk, inp = frozen_reference_tree(name, flags)
     snap = snapshot_tree(tree, t1)
     with contextlib.redirect_stdout(io.StringIO()):
         tree_lk = g["calculateTreeLikelihood"](tree, t1)          # the parity metric "tree log-LK" (M:9721-9779)

@@ -28,37 +28,13 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 from make_golden import REF, ser_list  # noqa: E402
-from make_golden_search import RUNS, snapshot_tree  # noqa: E402
+from make_golden_search import RUNS, frozen_reference_tree, snapshot_tree  # noqa: E402
 
 KEYS = ("probVect", "probVectUpRight", "probVectUpLeft", "probVectTotUp")
 
 
 def run(name, n_cases=14):
-    flags = RUNS[name]
-    inp = os.path.join(HERE, "synth_small.maple.txt")
-    out_dir = tempfile.mkdtemp(prefix="maple_golden_update_")
-    holder = {}
-
-    def grab(frame, event, arg):
-        if "g" not in holder and frame.f_code.co_filename.endswith("MAPLEv0.7.5.4.py"):
-            holder["g"] = frame.f_globals
-
-    old = sys.argv
-    sys.argv = ["MAPLE", "--input", inp, "--output", os.path.join(out_dir, "out"), "--overwrite"] + flags
-    sys.setprofile(grab)
-    try:
-        with contextlib.redirect_stdout(io.StringIO()):
-            runpy.run_path(REF, run_name="__main__")
-    except SystemExit:
-        pass
-    finally:
-        sys.setprofile(None)
-        sys.argv = old
-    g = holder["g"]
-    tree, t1 = g["tree"], g["t1"]
-    with contextlib.redirect_stdout(io.StringIO()):
-        g["setAllDirty"](tree, t1)
-        g["reCalculateAllGenomeLists"](tree, t1)
+    g, tree, t1, _, _ = frozen_reference_tree(name, RUNS[name])
     base = json.loads(json.dumps(snapshot_tree(tree, t1)))
     with gzip.open(os.path.join(HERE, f"search_{name}.json.gz"), "rt") as fh:
         stored = json.load(fh)["tree"]
@@ -132,6 +108,38 @@ def run(name, n_cases=14):
         sweeps.append(dict(dist_in=dist_in, dist_out=[float(x or 0.0) for x in tc.dist], updates=updates,
                            dirty_out=[bool(x) for x in tc.dirty]))
         print(f"[{name}] fast branch-length pass (perturbed={perturbed}): {updates} updates", flush=True)
+    # ---- the sweep the reference really runs: traverseTreeToOptimizeBranchLengths(tree, t1) with its default arguments
+    # (fastPass=False: one updatePartials after every changed branch, M:8875-8878; call sites M:11059 ... 12256), on the
+    # converged tree and on the tree with every length perturbed (lists recomputed for the perturbed lengths first)
+    full_sweeps = []
+    rng2 = random.Random(11)
+    for perturbed in (False, True):
+        tc = copy.deepcopy(tree)
+        with contextlib.redirect_stdout(io.StringIO()):
+            if perturbed:
+                for v in reach:
+                    if v != t1 and tc.dist[v]:
+                        tc.dist[v] = tc.dist[v] * (0.4 + 2.1 * rng2.random())
+                g["setAllDirty"](tc, t1)
+                g["reCalculateAllGenomeLists"](tc, t1)
+            g["setAllDirty"](tc, t1)
+            lk_in = g["calculateTreeLikelihood"](tc, t1)
+            dist_in = [float(x or 0.0) for x in tc.dist]
+            order = []
+
+            def prof3(frame, event, arg):
+                if event == "call" and frame.f_code.co_name == "updatePartials":
+                    order.append(frame.f_locals["nodeList"][0][0])
+            sys.setprofile(prof3)
+            try:
+                updates = g["traverseTreeToOptimizeBranchLengths"](tc, t1)
+            finally:
+                sys.setprofile(None)
+            lk_out = g["calculateTreeLikelihood"](tc, t1)
+        full_sweeps.append(dict(dist_in=dist_in, dist_out=[float(x or 0.0) for x in tc.dist], updates=updates,
+                                update_order=order, dirty_out=[bool(x) for x in tc.dirty], treeLK_in=lk_in, treeLK_out=lk_out))
+        print(f"[{name}] full branch-length sweep (perturbed={perturbed}): {updates} updates, LK {lk_in:.6f} -> {lk_out:.6f}",
+              flush=True)
     # ---- findBestRoot (M:7730-7905) on the frozen tree: the search part (the re-rooting itself is tree surgery).
     # Two parameter sets; locals are read when the function returns (bestNodes is only re-keyed when it re-roots).
     roots = []
@@ -160,11 +168,12 @@ def run(name, n_cases=14):
               f"{got['visited']} nodes visited, {len(got['bestNodes'])} within the threshold", flush=True)
     path = os.path.join(HERE, f"update_{name}.json.gz")
     with gzip.open(path, "wt") as fh:
-        json.dump(dict(name=name, base=f"search_{name}.json.gz", cases=cases, blen_sweeps=sweeps, find_best_root=roots,
+        json.dump(dict(name=name, base=f"search_{name}.json.gz", cases=cases, blen_sweeps=sweeps, blen_full_sweeps=full_sweeps,
+                       find_best_root=roots,
                        effectivelyNon0BLen=g["effectivelyNon0BLen"]), fh)
     print(f"[{name}] -> {path} {os.path.getsize(path)/1e6:.2f} MB", flush=True)
 
 
 if __name__ == "__main__":
-    for nm in (sys.argv[1:] or ["synth_unrest"]):
+    for nm in (sys.argv[1:] or ["synth_unrest", "synth_siteerr"]):
         run(nm)

@@ -41,8 +41,19 @@ def env(request):
     dev.close()
 
 
+def load_update(name):
+    path = os.path.join(GOLDEN, f"update_{name}.json.gz")
+    if not os.path.exists(path):
+        pytest.skip(f"no update records for {name}")
+    with gzip.open(path, "rt") as fh:
+        return json.load(fh)
+
+
+UPDATE_NAMES = sorted(f[len("update_"):-len(".json.gz")] for f in os.listdir(GOLDEN) if f.startswith("update_"))
+
+
 def test_fixture_present():
-    assert NAMES
+    assert NAMES and UPDATE_NAMES
 
 
 def test_spr_search_matches_reference(env):
@@ -160,6 +171,37 @@ def test_batched_placement_matches_reference(env):
             n_real += 1
         assert lists_match(best_diffs, tup(want["bestDiffs"]), 0.0), (best_diffs, want["bestDiffs"])
     assert n_real > 20
+
+
+def test_placement_supports_match_reference(env):
+    """f3: the computePlacementSupportOnly=True return of findBestParentForNewSample (M:8101-8290), the form the
+    reference's batch-placement call site consumes (process_chunk, M:11200): possiblePlacements (node, support, branch
+    lengths) in the reference's order and bestPlacementTotalLh, for the recorded queries, in ONE batch call."""
+    from maple_amd.search import PlacementParams, PlacementSearcher
+    f, dev, tree = env
+    if "supports" not in f["placements"][0]:
+        pytest.skip("fixture without supports records")
+    ctx = f["context"]
+    flags = f["flags"]
+    only_identical = any(x in flags for x in ("--estimateErrorRate", "--estimateSiteSpecificErrorRate"))
+    ps = PlacementSearcher(dev, tree, PlacementParams(
+        oneMutBLen=ctx["oneMutBLen"], effectivelyNon0BLen=ctx["effectivelyNon0BLen"],
+        thresholdLogLK=ctx["thresholdLogLK"], thresholdLogLKoptimization=ctx["thresholdLogLKoptimization"],
+        thresholdLogLKconsecutivePlacement=ctx["thresholdLogLKconsecutivePlacement"],
+        allowedFails=ctx["allowedFails"], strictStopRules=ctx["strictStopRules"], onlyFindIdentical=only_identical))
+    recs = f["placements"]
+    got = ps.find_placement_supports([tup(r["query"]) for r in recs], ctx["thresholdLogLKoptimizationTopology"],
+                                     ctx["minBranchSupport"])
+    n_multi = 0
+    for rec, (placements, total_lh) in zip(recs, got):
+        want = rec["supports"]
+        assert [p[0] for p in placements] == [p[0] for p in want["possiblePlacements"]], (placements, want["possiblePlacements"])
+        for g, w in zip(placements, want["possiblePlacements"]):
+            assert close(g[1], w[1], 1e-7), (g, w)
+            assert all(close(a, b, 1e-7, 1e-15) for a, b in zip(g[2], w[2])), (g, w)
+        assert lists_match(total_lh, tup(want["bestPlacementTotalLh"]), 1e-7), (total_lh[:3], want["bestPlacementTotalLh"][:3])
+        n_multi += len(placements) > 1
+    assert n_multi > 0 or f["name"].startswith("b1429")      # (no query of that fixture has two supported placements)
 
 
 def test_tree_log_likelihood_matches_reference(env):
@@ -352,7 +394,9 @@ def test_rebuild_all_genome_lists_matches_reference(env):
     mark = dev.mark()
     lower, up_right, up_left, tot_up = rebuild_genome_lists(dev, tree)
     t = f["tree"]
-    exact = not f["model"]["usingErrorRate"]
+    # (with an error model too: the fixtures' tips are de-aliased before the reference recomputes its lists, see
+    # make_golden_search.frozen_reference_tree, so every list is a function of the tips' lists)
+    exact = True
     checked = n_same = 0
     for ids, key in ((lower, "probVect"), (up_right, "probVectUpRight"), (up_left, "probVectUpLeft"), (tot_up, "probVectTotUp")):
         nodes = [v for v in tree.preorder() if t[key][v]]
@@ -365,20 +409,20 @@ def test_rebuild_all_genome_lists_matches_reference(env):
             n_same += bool(same)
             checked += 1
     assert checked > min(700, 3 * len(nodes) // 2)
-    assert n_same > 0.5 * checked, (n_same, checked)
+    assert n_same == checked, (n_same, checked)
     dev.release(mark)
 
 
-def test_update_partials_matches_reference():
+@pytest.mark.parametrize("uname", UPDATE_NAMES)
+def test_update_partials_matches_reference(uname):
     """updatePartials (M:5479-5815) as level-synchronous GPU batches vs the reference's own repair of the same local
     change (tests/golden/update_synth_unrest.json.gz: 7 branch-length changes, 7 tip replacements on the frozen tree).
     Both stop propagating where areVectorsDifferent says "same", in a different visiting order, so lists are compared
     with that function's own thresholds rather than bit for bit; the tree log-likelihood must agree to 1e-9."""
     from maple_amd.runtime import Device
     from maple_amd.tree_host import HostTree, tree_log_likelihood, update_genome_lists
-    f = load("synth_unrest")
-    with gzip.open(os.path.join(GOLDEN, "update_synth_unrest.json.gz"), "rt") as fh:
-        upd = json.load(fh)
+    f = load(uname)
+    upd = load_update(uname)
     ctx, t = f["context"], f["tree"]
     dev = Device(ref_indices(ctx), ctx["rootFreqs"], thresholdProb=ctx["thresholdProb"],
                  minBLenSensitivity=ctx["minBLenSensitivity"], thresholdDiffForUpdate=ctx["thresholdDiffForUpdate"],
@@ -398,7 +442,7 @@ def test_update_partials_matches_reference():
         else:
             tree.id_lower[v] = dev.upload([tup(ch["probVect"])])[0]
         replaced = update_genome_lists(dev, tree, [v])
-        assert replaced >= 2
+        assert replaced >= 1
         # every list of every node against the reference's tree after ITS updatePartials
         for key, attr in keys:
             ids = getattr(tree, attr)
@@ -431,10 +475,7 @@ def test_branch_length_fast_pass_matches_reference(env):
     branch lengths were all perturbed."""
     from maple_amd.tree_host import optimize_branch_lengths_fast_pass
     f, dev, tree = env
-    if f["name"] != "synth_unrest":
-        pytest.skip("recorded for synth_unrest only")
-    with gzip.open(os.path.join(GOLDEN, "update_synth_unrest.json.gz"), "rt") as fh:
-        upd = json.load(fh)
+    upd = load_update(f["name"])
     saved = list(tree.dist)
     try:
         for rec in upd["blen_sweeps"]:
@@ -448,6 +489,48 @@ def test_branch_length_fast_pass_matches_reference(env):
                    [rec["dirty_out"][v] for v in reach if v != tree.root and tree.up[v] != tree.root]
     finally:
         tree.dist = saved
+
+
+@pytest.mark.parametrize("uname", UPDATE_NAMES)
+def test_branch_length_sweep_matches_reference(uname):
+    """f4: traverseTreeToOptimizeBranchLengths(tree, root) with the reference's default arguments (fastPass=False: the
+    form every call site uses, M:8727-8893) -- a Gauss-Seidel sweep in the reference's order, one repair of the genome
+    lists after every changed branch -- on the converged tree and on the tree with every length perturbed: the
+    reference's number of updates, the nodes it updated in its order, every branch length, and the tree log-likelihood
+    before and after."""
+    from maple_amd.runtime import Device
+    from maple_amd.tree_host import HostTree, optimize_branch_lengths, rebuild_genome_lists, tree_log_likelihood
+    f = load(uname)
+    upd = load_update(uname)
+    if "blen_full_sweeps" not in upd:
+        pytest.skip("fixture without full-sweep records")
+    ctx, t = f["context"], f["tree"]
+    for rec in upd["blen_full_sweeps"]:
+        dev = Device(ref_indices(ctx), ctx["rootFreqs"], thresholdProb=ctx["thresholdProb"],
+                     minBLenSensitivity=ctx["minBLenSensitivity"], thresholdDiffForUpdate=ctx["thresholdDiffForUpdate"],
+                     thresholdFoldChangeUpdate=ctx["thresholdFoldChangeUpdate"], defaultBLen=ctx["defaultBLen"],
+                     arena_bytes=512 << 20)
+        dev.set_model(**model_args(f["model"]))
+        tree = HostTree(t["root"], t["up"], t["children"], rec["dist_in"], t["mutations"], t["nMinor"], t["probVect"],
+                        t["probVectUpRight"], t["probVectUpLeft"], t["probVectTotUp"]).upload(dev)
+        # the lists of the tree with the recorded input lengths (the reference recomputed them the same way)
+        tree.id_lower, tree.id_upRight, tree.id_upLeft, tree.id_totUp = rebuild_genome_lists(dev, tree)
+        lk_in, _ = tree_log_likelihood(dev, tree)
+        assert close(lk_in, rec["treeLK_in"], 1e-9), (lk_in, rec["treeLK_in"])
+        updates, dirty, updated = optimize_branch_lengths(dev, tree, upd["effectivelyNon0BLen"])
+        lk_out, _ = tree_log_likelihood(dev, tree)
+        reach = tree.preorder()
+        worst = max(abs(tree.dist[v] - rec["dist_out"][v]) / max(abs(rec["dist_out"][v]), 1e-9) for v in reach)
+        print(f"{uname}: {updates} updates (reference {rec['updates']}), LK {lk_in:.6f} -> {lk_out:.6f} "
+              f"(reference {rec['treeLK_out']:.6f}), worst branch-length difference {worst:.2e}")
+        assert updates == rec["updates"], (updates, rec["updates"])
+        root_kids = set(tree.children[tree.root])
+        assert [v for v in updated] == [v for v in rec["update_order"] if v not in root_kids], "updated branches / their order"
+        assert all(close(tree.dist[v], rec["dist_out"][v], 1e-6, 1e-12) for v in reach), \
+            [(v, tree.dist[v], rec["dist_out"][v]) for v in reach if not close(tree.dist[v], rec["dist_out"][v], 1e-6, 1e-12)][:5]
+        assert close(lk_out, rec["treeLK_out"], 1e-9), (lk_out, rec["treeLK_out"])
+        assert lk_out >= lk_in - 1e-6
+        dev.close()
 
 
 def test_candidate_sharding_level2(env):
@@ -484,10 +567,7 @@ def test_find_best_root_matches_reference(env):
     visited and the relative log-likelihood of every branch the reference keeps in bestNodes (224 of them)."""
     from maple_amd.tree_host import find_best_root
     f, dev, tree = env
-    if f["name"] != "synth_unrest":
-        pytest.skip("recorded for synth_unrest only")
-    with gzip.open(os.path.join(GOLDEN, "update_synth_unrest.json.gz"), "rt") as fh:
-        upd = json.load(fh)
+    upd = load_update(f["name"])
     ctx = f["context"]
     for rec in upd["find_best_root"]:
         node, best, best_nodes, visited = find_best_root(
@@ -528,3 +608,107 @@ def test_tree_ops_under_reference_names(env):
         thresholdLogLKconsecutivePlacement=ctx["thresholdLogLKconsecutivePlacement"], allowedFails=ctx["allowedFails"],
         strictStopRules=ctx["strictStopRules"], onlyFindIdentical=only_identical)
     assert node == rec["ret"]["bestNode"] and close(score, rec["ret"]["bestScore"], 1e-9)
+
+
+# ---- end-to-end: the metric's second half (final tree log-LK) on sequences of tree states the reference produced ----
+E2E_NAMES = sorted(f[len("e2e_"):-len(".json.gz")] for f in os.listdir(GOLDEN) if f.startswith("e2e_"))
+
+
+def _e2e_env(name):
+    from maple_amd.runtime import Device
+    with gzip.open(os.path.join(GOLDEN, f"e2e_{name}.json.gz"), "rt") as fh:
+        f = json.load(fh)
+    ctx = f["context"]
+    dev = Device(ref_indices(ctx), ctx["rootFreqs"], thresholdProb=ctx["thresholdProb"],
+                 minBLenSensitivity=ctx["minBLenSensitivity"], thresholdDiffForUpdate=ctx["thresholdDiffForUpdate"],
+                 thresholdFoldChangeUpdate=ctx["thresholdFoldChangeUpdate"], defaultBLen=ctx["defaultBLen"],
+                 arena_bytes=1 << 30)
+    return f, dev
+
+
+def _tree_from_topology(dev, topo, tips):
+    """HostTree of a recorded tree state: topology + the tips' lists; every other list rebuilt on the GPU."""
+    from maple_amd.tree_host import HostTree, rebuild_genome_lists
+    n = len(topo["up"])
+    pv = [None] * n
+    for v, lst in tips.items():
+        if int(v) < n and not topo["children"][int(v)]:
+            pv[int(v)] = lst
+    tree = HostTree(topo["root"], topo["up"], topo["children"], topo["dist"], [[] for _ in range(n)], topo["nMinor"], pv,
+                    [None] * n, [None] * n, [None] * n).upload(dev)
+    tree.id_lower, tree.id_upRight, tree.id_upLeft, tree.id_totUp = rebuild_genome_lists(dev, tree)
+    return tree
+
+
+@pytest.mark.parametrize("name", E2E_NAMES)
+def test_applied_spr_moves_tree_likelihood(name):
+    """Metric part 2 on the reference's own SPR rounds: for every move the reference APPLIED (40 in a row, starting from a
+    tree with 30 tips misplaced), the tree it produced is rebuilt on the GPU from the tips alone and its log-likelihood
+    (calculateTreeLikelihood, M:9721-9779) must be the reference's to 1e-9; the reference's predicted improvement and the
+    realised change of log-likelihood agree within its own --debugging bound of 0.5 (M:9508-9565)."""
+    from maple_amd.tree_host import tree_log_likelihood
+    f, dev = _e2e_env(name)
+    if not f["spr_moves"]:
+        pytest.skip("no applied SPR moves recorded")
+    worst = 0.0
+    for k, mv in enumerate(f["spr_moves"]):
+        dev.set_model(mv["Q"])
+        mark = dev.mark()
+        tree = _tree_from_topology(dev, mv["after"], f["tips"])
+        lk, _ = tree_log_likelihood(dev, tree)
+        dev.release(mark)
+        assert close(lk, mv["lk_after_fresh"], 1e-9), (k, lk, mv["lk_after_fresh"])
+        worst = max(worst, abs(lk - mv["lk_after_fresh"]) / abs(lk))
+        # predicted vs realised: the reference's own pair of numbers first (its --debugging bound is 0.5; a few of its large
+        # moves miss that by themselves, e.g. 58.2 predicted / 56.2 realised), then ours against its prediction
+        realised = mv["lk_after_incremental"] - mv["lk_before"]
+        bound = max(0.5, 0.05 * abs(mv["improvement"]))
+        assert abs(realised - mv["improvement"]) <= bound, (k, realised, mv["improvement"])
+        assert abs(lk - mv["lk_before"] - mv["improvement"]) <= bound, (k, lk - mv["lk_before"], mv["improvement"])
+        assert abs((lk - mv["lk_before"]) - realised) <= 1e-3, (k, lk - mv["lk_before"], realised)
+    assert len(f["spr_moves"]) >= 20
+    print(f"{name}: {len(f['spr_moves'])} applied moves, worst relative log-LK difference {worst:.2e}")
+    dev.close()
+
+
+@pytest.mark.parametrize("name", E2E_NAMES)
+def test_online_sample_additions(name):
+    """BASELINE configs[4] in small (online update of a frozen tree): new samples are added one after the other -- placement
+    search on the GPU (must be the reference's node, score and branch lengths), the reference's tree edit applied from
+    the record, incremental repair of the genome lists on the GPU (update_genome_lists) -- and after every addition the
+    tree log-likelihood must be the reference's."""
+    from maple_amd.search import PlacementParams, PlacementSearcher
+    from maple_amd.tree_host import tree_log_likelihood, update_genome_lists
+    f, dev = _e2e_env(name)
+    ctx = f["context"]
+    dev.set_model(**model_args(f["model"]))
+    tree = _tree_from_topology(dev, f["online_start"], f["tips"])
+    lk, _ = tree_log_likelihood(dev, tree)
+    assert close(lk, f["online_start_LK"], 1e-9), (lk, f["online_start_LK"])
+    params = PlacementParams(oneMutBLen=ctx["oneMutBLen"], effectivelyNon0BLen=ctx["effectivelyNon0BLen"],
+                             thresholdLogLK=ctx["thresholdLogLK"], thresholdLogLKoptimization=ctx["thresholdLogLKoptimization"],
+                             thresholdLogLKconsecutivePlacement=ctx["thresholdLogLKconsecutivePlacement"],
+                             allowedFails=ctx["allowedFails"], strictStopRules=ctx["strictStopRules"])
+    worst = 0.0
+    for k, rec in enumerate(f["online"]):
+        tree.upload_topology(dev)
+        ps = PlacementSearcher(dev, tree, params)
+        node, score, blens, best_diffs, info = ps.find_best_parent_for_new_sample(tup(rec["query"]))
+        want = rec["ret"]
+        assert node == want["bestNode"], (k, node, want["bestNode"])
+        assert close(score, want["bestScore"], 1e-8), (k, score, want["bestScore"])
+        if want["bestBranchLengths"] is None:
+            assert blens is None
+        else:
+            assert all(close(float(g or 0.0), w, 1e-7, 1e-15) for g, w in zip(blens, want["bestBranchLengths"])), (k, blens, want)
+        after = rec["after"]
+        changed = tree.apply_topology(after["root"], after["up"], after["children"], after["dist"], after["nMinor"])
+        for v, lst in rec["new_tips"].items():
+            tree.id_lower[int(v)] = dev.upload([tup(lst)])[0]
+        if changed:
+            update_genome_lists(dev, tree, changed)
+        lk, _ = tree_log_likelihood(dev, tree)
+        assert close(lk, rec["treeLK"], 1e-8), (k, lk, rec["treeLK"])
+        worst = max(worst, abs(lk - rec["treeLK"]) / abs(lk))
+    print(f"{name}: {len(f['online'])} samples added, worst relative log-LK difference {worst:.2e}")
+    dev.close()
