@@ -235,6 +235,14 @@ int maple_debug_trace_query(maple_ctx *ctx, int32_t query);
  * (one lane = one contiguous 512-byte list, dependent 8-byte loads); returns the total time. */
 int maple_debug_calib_walk(maple_ctx *ctx, uint64_t bytes, int32_t repeats, float *ms);
 int maple_debug_trace_read(maple_ctx *ctx, int32_t *n, int32_t *items4 /*[4*4096]*/, double *vals2 /*[2*4096]*/);
+/* Parity hooks for the two innermost device functions (one lane per call):
+ * getPartialVec(i12, totLen, mutMatrix, errorRate, vect, upNode, flag), M:4073-4141, with the call's own 4x4 matrix
+ * (M16[16*i..], row-major) and vect4[4*i..] (read when i12 == 6); whether `flag` matters follows the model's usingErrorRate
+ * (M:4109).  simplify(vec, refA), M:3697-3717 -> 0-3 nucleotide, 4 = R, 6 = keep the vector, -1 = the reference raises. */
+int maple_debug_gpv_batch(maple_ctx *ctx, int32_t n, const int32_t *i12, const double *totLen, const double *M16,
+                          const double *errorRate, const double *vect4, const uint8_t *upNode, const uint8_t *flag,
+                          double *out4);
+int maple_debug_simplify_batch(maple_ctx *ctx, int32_t n, const double *vec4, const int32_t *refA, int32_t *out);
 
 /* ---- device-resident forms (inputs already in HBM; asynchronous on `stream`) ---
  * `stream` is the caller's hipStream_t, used verbatim: NULL is the legacy default stream (what

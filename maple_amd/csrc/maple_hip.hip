@@ -2133,6 +2133,79 @@ extern "C" int maple_debug_calib_walk(maple_ctx *c, uint64_t bytes, int32_t repe
     return MAPLE_OK;
 }
 
+// Parity hooks for the two innermost device functions, which no batched operator exposes on their own: getPartialVec
+// (M:4073-4141) with the caller's matrix (the reference passes mutMatrices[pos] = Q * siteRates[pos]) and simplify
+// (M:3697-3717).  One lane per call.
+struct MatCtx {                        // what gpv_vec / gpv_nuc need from a context: q(r, i, j) of THIS call's matrix
+    const double *M;
+    __device__ inline double q(double, int i, int j) const { return M[i * 4 + j]; }
+};
+struct ThrCtx { struct { double thresholdProb, thresholdProb4; } m; };
+
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_debug_gpv(int n, int usingErrorRate, const int32_t *i12, const double *totLen,
+                                                           const double *M16, const double *errorRate, const double *vect,
+                                                           const uint8_t *upNode, const uint8_t *flag, double *out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        MatCtx c{M16 + 16 * (size_t)i};
+        double o[4];
+        if (i12[i] == 6) gpv_vec(c, 1.0, vect + 4 * (size_t)i, totLen[i], upNode[i] != 0, o);
+        else if (usingErrorRate) gpv_nuc<MatCtx, true>(c, 1.0, i12[i], totLen[i], errorRate[i], upNode[i] != 0, flag[i] != 0, o);
+        else gpv_nuc<MatCtx, false>(c, 1.0, i12[i], totLen[i], errorRate[i], upNode[i] != 0, false, o);
+        for (int k = 0; k < 4; k++) out[4 * (size_t)i + k] = o[k];
+    }
+}
+
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_debug_simplify(int n, double thresholdProb, double thresholdProb4, const double *vec,
+                                                                const int32_t *refA, int32_t *out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        ThrCtx c;
+        c.m.thresholdProb = thresholdProb; c.m.thresholdProb4 = thresholdProb4;
+        out[i] = simplify(c, vec + 4 * (size_t)i, refA[i]);
+    }
+}
+
+extern "C" int maple_debug_gpv_batch(maple_ctx *c, int32_t n, const int32_t *i12, const double *totLen, const double *M16,
+                                     const double *errorRate, const double *vect4, const uint8_t *upNode, const uint8_t *flag,
+                                     double *out4)
+{
+    if (!c || n < 0 || !i12 || !totLen || !M16 || !errorRate || !vect4 || !upNode || !flag || !out4) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    TRY(h2d(c, c->s_i32[0], i12, (size_t)n));
+    TRY(h2d(c, c->s_f64[0], totLen, (size_t)n));
+    TRY(h2d(c, c->s_f64[1], M16, (size_t)16 * n));
+    TRY(h2d(c, c->s_f64[2], errorRate, (size_t)n));
+    TRY(h2d(c, c->s_f64[3], vect4, (size_t)4 * n));
+    TRY(h2d(c, c->s_u8[0], upNode, (size_t)n));
+    TRY(h2d(c, c->s_u8[1], flag, (size_t)n));
+    HIPCK(c, c->s_aux.reserve((size_t)4 * n));
+    hipLaunchKernelGGL(k_debug_gpv, dim3(grid_for(n)), dim3(MAPLE_BLOCK), 0, c->stream, n, c->dm.usingErrorRate, c->s_i32[0].p,
+                       c->s_f64[0].p, c->s_f64[1].p, c->s_f64[2].p, c->s_f64[3].p, c->s_u8[0].p, c->s_u8[1].p, c->s_aux.p);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(out4, c->s_aux.p, (size_t)4 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MAPLE_OK;
+}
+
+extern "C" int maple_debug_simplify_batch(maple_ctx *c, int32_t n, const double *vec4, const int32_t *refA, int32_t *out)
+{
+    if (!c || n < 0 || !vec4 || !refA || !out) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(h2d(c, c->s_f64[0], vec4, (size_t)4 * n));
+    TRY(h2d(c, c->s_i32[0], refA, (size_t)n));
+    HIPCK(c, c->s_i32[1].reserve(n));
+    hipLaunchKernelGGL(k_debug_simplify, dim3(grid_for(n)), dim3(MAPLE_BLOCK), 0, c->stream, n, c->dm.thresholdProb,
+                       c->dm.thresholdProb4, c->s_f64[0].p, c->s_i32[0].p, c->s_i32[1].p);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(out, c->s_i32[1].p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return MAPLE_OK;
+}
+
 // debugging aid: record the visit sequence (t1, direction, needsUpdating, failedPasses, lastLK, midProb) of one query
 extern "C" int maple_debug_trace_query(maple_ctx *c, int32_t query)
 {

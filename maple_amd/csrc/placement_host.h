@@ -202,10 +202,11 @@ extern "C" int maple_placement_supports_batch(maple_ctx *c, int32_t nQ, const in
 }
 
 static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists, const maple_placement_params *pp,
-                                 int32_t *bestNode, double *bestScore, double *blen3, int32_t *bestDiffs,
+                                 int32_t *bestNode, double *bestScore, double *blen3, int32_t *bestDiffsOut,
                                  int32_t *nAppend, int32_t *status, SupportsOut *sup)
 {
     if (nQ == 0) return MAPLE_OK;
+    int32_t *const bestDiffs = bestDiffsOut;
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
     if (!c->tree_set) return fail(c, MAPLE_ERR_STATE, "maple_tree_upload has not been called");
@@ -241,10 +242,24 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
     // queries per chunk: the score matrix stays below 2 GiB and the per-frame query lists below 8 M arena lists
     const int64_t maxCells = (int64_t)1 << 28;
     const int64_t byFrames = std::max<int64_t>(1, ((int64_t)8 << 20) / std::max(nF, 1));
-    const int32_t chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nQ, byFrames), maxCells / std::max(nCols, 1)));
+    int32_t chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nQ, byFrames), maxCells / std::max(nCols, 1)));
+    {   // ... and what a chunk adds to the arena -- every query re-expressed in every MAT frame, its shortened copies, the
+        // refinement's upper lists -- has to fit in a third of what is free (the SPR wide path bounds itself the same way)
+        int64_t maxEnt = 1, maxAux = 1;
+        for (int q = 0; q < nQ; q++) { maxEnt = std::max<int64_t>(maxEnt, c->h_n_ent[qLists[q]]); maxAux = std::max<int64_t>(maxAux, c->h_n_aux[qLists[q]]); }
+        const int64_t perQueryEnt = (int64_t)(nF + 2) * (maxEnt + 32), perQueryAux = (int64_t)(nF + 2) * (maxAux + 16);
+        const int64_t byEnt = (c->cap_ent - c->used_ent) / 3 / perQueryEnt, byAux = (c->cap_aux - c->used_aux) / 3 / perQueryAux;
+        const int64_t byLists = (c->cap_lists - (int64_t)c->h_n_ent.size()) / 3 / (2 * (int64_t)nF + 8);
+        const int64_t byArena = std::max<int64_t>(1, std::min(std::min(byEnt, byAux), byLists));
+        if (byArena < chunk) chunk = (int32_t)byArena;
+        if (const char *e = getenv("MAPLE_PLACE_MAX_CHUNK")) chunk = std::max(1, std::min(chunk, atoi(e)));   // (tests: force chunking)
+    }
+    const bool manyChunks = chunk < nQ;
     const int stackCap = M.maxDepth + 4, words = (nF + 31) / 32;
     for (int32_t q0 = 0; q0 < nQ; q0 += chunk) {
         const int32_t nq = std::min(chunk, nQ - q0);
+        int64_t chunkMark = 0;
+        if (manyChunks) TRY(maple_arena_mark(c, &chunkMark));       // a chunk's temporaries go when it is done (below)
         // ---- the query list in every reference frame, level by level (passGenomeListThroughBranch, M:8082-8092)
         std::vector<int32_t> U((size_t)nq * nF);
         for (int q = 0; q < nq; q++) U[(size_t)q * nF] = qLists[q0 + q];
@@ -526,8 +541,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                 }
                 sup->off[g + 1] = o;
             }
-            continue;
-        }
+        } else {
         // ---- outcome per query
         size_t r = 0;
         for (int q = 0; q < nq; q++) {
@@ -561,6 +575,31 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
             nAppend[g] += 3 * hNShort[q];
             bestNode[g] = bn; bestScore[g] = bs;
             bestDiffs[g] = qlist(q, bn, bshort);
+        }
+        }
+        if (manyChunks) {
+            int32_t *bestDiffs = sup ? sup->bestTotalLh : bestDiffsOut;   // the list ids this call hands to the caller
+            // keep only what the caller was handed: the bestDiffs lists made by this chunk move to the bottom of the arena
+            // (down to the chunk's mark), everything else the chunk allocated is released
+            std::vector<int32_t> keep;
+            for (int q = 0; q < nq; q++) if (bestDiffs[q0 + q] >= chunkMark) keep.push_back(bestDiffs[q0 + q]);
+            std::sort(keep.begin(), keep.end());
+            keep.erase(std::unique(keep.begin(), keep.end()), keep.end());
+            std::vector<int64_t> eo(keep.size() + 1, 0), ao(keep.size() + 1, 0);
+            for (size_t i = 0; i < keep.size(); i++) { eo[i + 1] = eo[i] + c->h_n_ent[keep[i]]; ao[i + 1] = ao[i] + c->h_n_aux[keep[i]]; }
+            std::vector<int32_t> pos((size_t)std::max<int64_t>(1, eo.back()));
+            std::vector<uint32_t> meta((size_t)std::max<int64_t>(1, eo.back()));
+            std::vector<double> aux((size_t)std::max<int64_t>(1, ao.back()));
+            if (!keep.empty())
+                TRY(maple_lists_download(c, (int32_t)keep.size(), keep.data(), eo.data(), pos.data(), meta.data(), ao.data(), aux.data()));
+            TRY(maple_arena_release(c, chunkMark));
+            int32_t first = 0;
+            if (!keep.empty())
+                TRY(maple_lists_upload(c, (int32_t)keep.size(), eo.data(), pos.data(), meta.data(), ao.data(), aux.data(), &first));
+            for (int q = 0; q < nq; q++) {
+                int32_t &b = bestDiffs[q0 + q];
+                if (b >= chunkMark) b = first + (int32_t)(std::lower_bound(keep.begin(), keep.end(), b) - keep.begin());
+            }
         }
     }
     return MAPLE_OK;

@@ -24,7 +24,7 @@ EXPORTS = [
     "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
-    "maple_timing_read_kind", "maple_placement_supports_batch",
+    "maple_timing_read_kind", "maple_placement_supports_batch", "maple_debug_gpv_batch", "maple_debug_simplify_batch",
 ]
 
 
@@ -409,6 +409,23 @@ class Device:
             a, b = off[g], off[g + 1]
             out.append(([(int(node[i]), float(supp[i]), tuple(float(x) for x in bl[i])) for i in range(a, b)], int(best[g])))
         return out, status
+
+    def debug_gpv_batch(self, i12, totLen, mutMatrix, errorRate, vect, upNode, flag):
+        """getPartialVec (M:4073-4141) for n calls, each with its own 4x4 matrix; vect rows are read where i12 == 6."""
+        i12 = _i32(i12)
+        n = len(i12)
+        M = _f64(np.asarray(mutMatrix, dtype=np.float64).reshape(n, 16))
+        v = _f64(np.asarray(vect, dtype=np.float64).reshape(n, 4))
+        out = np.zeros((n, 4))
+        self._ck(self.lib.maple_debug_gpv_batch(self.h, n, _ptr(i12), _ptr(_f64(totLen)), _ptr(M), _ptr(_f64(errorRate)), _ptr(v),
+                                                _ptr(_u8(upNode)), _ptr(_u8(flag)), _ptr(out)))
+        return out
+
+    def debug_simplify_batch(self, vec, refA):
+        v = _f64(np.asarray(vec, dtype=np.float64).reshape(-1, 4))
+        out = np.zeros(len(v), dtype=np.int32)
+        self._ck(self.lib.maple_debug_simplify_batch(self.h, len(v), _ptr(v), _ptr(_i32(refA)), _ptr(out)))
+        return out
 
     def debug_calib_walk(self, nbytes, repeats=1):
         ms = C.c_float()

@@ -197,6 +197,68 @@ def test_structural_functions(env):
         assert [bool(g) for g in got] == [r["ret"] for r in recs]
 
 
+def test_getPartialVec_and_simplify_on_the_gpu(env):
+    """a3 / a4 directly on the HIP path: every recorded getPartialVec (M:4073-4141) and simplify (M:3697-3717) call of
+    the reference through the one-lane-per-call hooks, plus the negative-clamp exits (M:4096, 4106, 4122, 4139: any
+    component that goes negative turns the whole vector into [0.25] * 4) on inputs built to reach each of them."""
+    f, dev, o = env
+    Q = f["models"][0]["Q"]
+    n_calls = 0
+    for u, recs in _u_groups(f, "getPartialVec").items():
+        dev.set_model(Q, usingErrorRate=u, errorRateGlobal=1e-4)
+        got = dev.debug_gpv_batch([r["i12"] for r in recs], [r["totLen"] or 0.0 for r in recs], [r["mutMatrix"] for r in recs],
+                                  [r["errorRate"] or 0.0 for r in recs],
+                                  [r["vect"] if r["vect"] is not None else [0.0] * 4 for r in recs],
+                                  [bool(r["upNode"]) for r in recs], [bool(r["flag"]) for r in recs])
+        for g, r in zip(got, recs):
+            assert all(close(float(a), b, REL, 0.0) for a, b in zip(g, r["ret"])), (g, r["ret"])
+        n_calls += len(recs)
+    assert n_calls > 50
+    dev.set_model(Q)
+    recs = f["calls"]["simplify"]
+    got = dev.debug_simplify_batch([r["vec"] for r in recs], [r["refA"] for r in recs])
+    assert [int(g) for g in got] == [r["ret"] for r in recs]
+    # the clamp exits: a matrix with a strongly negative diagonal and a long branch drives a component below zero
+    M = [[-40.0, 10.0, 20.0, 10.0], [5.0, -30.0, 5.0, 20.0], [10.0, 10.0, -50.0, 30.0], [1.0, 2.0, 3.0, -6.0]]
+    cases = [(6, 0.5, [0.7, 0.1, 0.1, 0.1], False, False, 0.0),      # O vector, downward (M:4106)
+             (6, 0.5, [0.7, 0.1, 0.1, 0.1], True, False, 0.0),       # O vector, upward (M:4096)
+             (0, 0.5, None, False, False, 0.0),                      # one-hot, the observed nucleotide's entry (M:4139)
+             (2, 0.1, None, True, False, 0.0),                       # one-hot, upward
+             (0, 0.5, None, False, True, 0.01),                      # error-smeared one-hot (M:4122), only with an error model
+             (1, 1e-3, None, False, False, 0.0)]                     # and one that stays positive
+    for u in (False, True):
+        dev.set_model(Q, usingErrorRate=u, errorRateGlobal=1e-4)
+        o.set_model(Q, usingErrorRate=u, errorRateGlobal=1e-4)
+        got = dev.debug_gpv_batch([c[0] for c in cases], [c[1] for c in cases], [M] * len(cases), [c[5] for c in cases],
+                                  [c[2] or [0.0] * 4 for c in cases], [c[3] for c in cases], [c[4] for c in cases])
+        n_clamped = 0
+        for g, c in zip(got, cases):
+            want = o.getPartialVec(c[0], c[1], M, c[5], c[2], c[3], c[4])
+            assert [float(x) for x in g] == want, (c, g, want)
+            n_clamped += want == [0.25] * 4
+        assert n_clamped >= 4
+
+
+def test_appendProbNode_log_of_zero_is_minus_infinity(env):
+    """Documented deviation: where appendProbNode's running product reaches exactly 0 (an O vector with a zero component
+    met by that nucleotide over a zero-length branch) the reference's final math.log(totalFactor) raises ValueError, which
+    its callers do not catch; kernel and oracle return -inf, the value the reference itself uses for an impossible
+    attachment (M:6663, 6742)."""
+    f, dev, o = env
+    dev.set_model(f["models"][0]["Q"])
+    o.set_model(f["models"][0]["Q"])
+    l_ref = dev.lRef
+    parent = [(4, 10), (6, int(dev.ref_idx[10]), [0.5, 0.5, 0.0, 0.0] if dev.ref_idx[10] != 2 else [0.5, 0.0, 0.0, 0.5]), (4, l_ref)]
+    zero_nuc = 2 if dev.ref_idx[10] != 2 else 1
+    child = [(4, 10), (zero_nuc, int(dev.ref_idx[10])), (4, l_ref)]
+    mark = dev.mark()
+    ids = dev.upload([parent, child])
+    got = dev.append_batch([ids[0]], [ids[1]], [False], [0.0])[0]
+    dev.release(mark)
+    assert got == float("-inf"), got
+    assert o.appendProbNode(parent, child, False, 0.0) == float("-inf")
+
+
 def test_ops_mirror_reads_like_the_reference(env):
     """The same-name host functions (maple_amd.ops) on a few records per function."""
     from maple_amd.ops import GenomeOps

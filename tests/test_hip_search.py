@@ -204,6 +204,40 @@ def test_placement_supports_match_reference(env):
     assert n_multi > 0 or f["name"].startswith("b1429")      # (no query of that fixture has two supported placements)
 
 
+def test_batched_placement_in_chunks_is_the_same(env, monkeypatch):
+    """A batch too large for the arena is processed in chunks whose temporaries are released; the lists handed back
+    (bestDiffs) are compacted to the bottom of the arena and must still be the reference's."""
+    f, dev, tree = env
+    ctx = f["context"]
+    flags = f["flags"]
+    only_identical = any(x in flags for x in ("--estimateErrorRate", "--estimateSiteSpecificErrorRate"))
+    kw = dict(oneMutBLen=ctx["oneMutBLen"], effectivelyNon0BLen=ctx["effectivelyNon0BLen"], thresholdLogLK=ctx["thresholdLogLK"],
+              thresholdLogLKoptimization=ctx["thresholdLogLKoptimization"],
+              thresholdLogLKconsecutivePlacement=ctx["thresholdLogLKconsecutivePlacement"], allowedFails=ctx["allowedFails"],
+              strictStopRules=ctx["strictStopRules"], onlyFindIdentical=only_identical)
+    recs = f["placements"]
+    dev.placement_prepare(**kw)
+    mark = dev.mark()
+    q_ids = dev.upload([tup(r["query"]) for r in recs])
+    whole = dev.placement_search_batch(q_ids, **kw)
+    whole_lists = dev.download(whole["bestDiffs"])
+    used_whole = dev.stats()["n_entries"]
+    dev.release(mark)
+    monkeypatch.setenv("MAPLE_PLACE_MAX_CHUNK", "7")
+    mark = dev.mark()
+    q_ids = dev.upload([tup(r["query"]) for r in recs])
+    parts = dev.placement_search_batch(q_ids, **kw)
+    part_lists = dev.download(parts["bestDiffs"])
+    used_parts = dev.stats()["n_entries"]
+    dev.release(mark)
+    for k in ("bestNode", "bestScore", "blen", "nAppend", "status"):
+        assert np.array_equal(whole[k], parts[k]), k
+    assert whole_lists == part_lists
+    for rec, lst in zip(recs, part_lists):
+        assert lists_match(lst, tup(rec["ret"]["bestDiffs"]), 0.0)
+    assert used_parts <= used_whole
+
+
 def test_tree_log_likelihood_matches_reference(env):
     """The parity metric of BASELINE.json: tree log-LK (calculateTreeLikelihood, M:9721) within 1e-6 relative
     (observed ~1e-14) on the reference's own final tree."""
