@@ -306,13 +306,25 @@ def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_pl
     dev.timing_reset()
     for _ in range(5):
         dev.append_queries_dev(Q, t_q.data_ptr(), Cn, t_c.data_ptr(), True, 1.0 / l_ref, t_out.data_ptr(), stream)
-        best_score, best_idx = t_out.view(Q, Cn).max(dim=1)
     torch.cuda.synchronize()
     n_l, ms, _, _ = dev.timing_read_kind(Device.KIND_APPEND_QUERIES)
+    # the same pairs with the arg-max fused into the kernel (wavefront reduction per 64-candidate tile, no score matrix)
+    t_best = torch.empty(Q, dtype=torch.float64, device=cu)
+    t_idx = torch.empty(Q, dtype=torch.int32, device=cu)
+    dev.append_queries_argmax_dev(Q, t_q.data_ptr(), Cn, t_c.data_ptr(), 0, True, 1.0 / l_ref, t_best.data_ptr(), t_idx.data_ptr(), stream)
+    torch.cuda.synchronize()
+    dev.timing_reset()
+    for _ in range(5):
+        dev.append_queries_argmax_dev(Q, t_q.data_ptr(), Cn, t_c.data_ptr(), 0, True, 1.0 / l_ref, t_best.data_ptr(), t_idx.data_ptr(), stream)
+    torch.cuda.synchronize()
+    n_f, ms_f, _, _ = dev.timing_read_kind(Device.KIND_APPEND_QUERIES)
+    m_best, m_idx = t_out.view(Q, Cn).max(dim=1)
+    fused_ok = bool(torch.equal(m_best, t_best))
     out["all_pairs_kernel"] = {"queries": int(Q), "candidate_branches": int(Cn), "kernel_ms": ms / max(1, n_l),
                                "pairs_per_s": Q * Cn / (ms / max(1, n_l) * 1e-3),
                                "algorithmic_GBps": alg / (ms / max(1, n_l) * 1e-3) / 1e9,
-                               "frac_of_hbm_peak": alg / (ms / max(1, n_l) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                               "frac_of_hbm_peak": alg / (ms / max(1, n_l) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "fused_argmax_kernel_ms": ms_f / max(1, n_f), "fused_argmax_equals_matrix_max": fused_ok}
     # ---- batched placement search (findBestParentForNewSample for many samples on the frozen tree, M:7912-8292 /
     # 11190-11220): all-branch scoring + device-side traversal + short-list refinement ----
     ll = math.log(l_ref)

@@ -255,6 +255,21 @@ int maple_append_batch_dev(maple_ctx *ctx, int32_t n, const int32_t *parentList_
  * out_dev[q*C + k] = appendProbNode(list cand[k], list qList[q], isTipC, bLen); one lane per pair, no index arrays. */
 int maple_append_queries_dev(maple_ctx *ctx, int32_t nQ, const int32_t *qList_dev, int32_t nC, const int32_t *cand_dev,
                              int isTipC, double bLen, double *out_dev, void *stream);
+/* The same pairs without the score matrix: per query the best score and the index (into cand_dev) of the candidate that
+ * has it -- a wavefront reduction over each tile of 64 candidates, one 16-byte record per (query, tile), then one
+ * wavefront per query over its tiles.  Exact ties go to the smallest visitRank_dev[k] (NULL: the smallest k), the
+ * reference's "first of equal scores wins" (strict >, M:7083 / 8065). */
+int maple_append_queries_argmax_dev(maple_ctx *ctx, int32_t nQ, const int32_t *qList_dev, int32_t nC, const int32_t *cand_dev,
+                                    const int32_t *visitRank_dev, int isTipC, double bLen, double *bestScore_dev,
+                                    int32_t *bestIdx_dev, void *stream);
+/* Multi-GPU arg-max over RCCL (level 2: the candidates of one query sharded over the GPUs; one
+ * process per GPU).  maple_comm_unique_id on one rank, broadcast the 128 bytes by any means, maple_comm_init on every
+ * rank.  maple_argmax_allreduce_dev, in place and asynchronous on `stream`: score[i] = max over ranks, idx[i] = the
+ * smallest idx among the ranks holding that score (idx = depth-first visit index: the earliest visit wins a tie).  Two
+ * ncclAllReduce of n 8-byte words (max of order-preserving keys, min of offered indices).  RCCL is dlopen'ed. */
+int maple_comm_unique_id(maple_ctx *ctx, uint8_t *id128);
+int maple_comm_init(maple_ctx *ctx, int32_t world, int32_t rank, const uint8_t *id128);
+int maple_argmax_allreduce_dev(maple_ctx *ctx, int32_t n, double *score_dev, int32_t *idx_dev, void *stream);
 /* Every *_dev launch is bracketed by a pair of HIP events recorded on the launch's own stream.
  * maple_timing_read sums the elapsed time of all launches since the last maple_timing_reset. */
 int maple_timing_reset(maple_ctx *ctx);

@@ -17,6 +17,18 @@
 
 using namespace maple;
 
+// RCCL is used through dlopen only (maple_comm_*, below): types from the header, no link-time dependency
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    const char *(*GetErrorString)(ncclResult_t);
+};
+static RcclApi g_rccl{};
+
 // =================================================================================================
 // context
 // =================================================================================================
@@ -124,6 +136,11 @@ struct maple_ctx {
     int32_t tree_max_ent = 0;          // longest genome list of the uploaded tree (entries)
     int32_t n_scored = 0;              // nodes with a probVectTotUp, sorted by list length: t_i32[8] = list ids, t_scored_col = node ids
     DevBuf<int32_t> t_scored_col, t_scored_frame;
+    DevBuf<uint8_t> s_tilebest;        // (query, 64-candidate tile) records of maple_append_queries_argmax_dev
+    void *rccl_lib = nullptr;          // RCCL, loaded on first use (maple_comm_*)
+    void *rccl_comm = nullptr;
+    int rccl_world = 1, rccl_rank = 0;
+    DevBuf<unsigned long long> s_comm_u64;
     DevBuf<SScan> t_scan;              // the tree in the searches' depth-first order (search_dev.h), per effectivelyNon0BLen
     DevBuf<int32_t> t_scan_parent;
     bool scan_valid = false;
@@ -213,11 +230,14 @@ __global__ MAPLE_APPEND_ATTR void k_append(const DevModel *__restrict__ mp, Aren
 //   static 256-candidate tiles, query-major 2.56 | chunk-major 2.29 | dynamic 64-candidate tiles, query-major 2.30 |
 //   dynamic + chunk-major 1.85 | + candidates sorted by length 1.53.
 // (Staging the query in LDS behind __syncthreads() was 1.4x slower; several queries per tile lost balance: 2.06 at 4.)
+struct alignas(16) TileBest { double score; int32_t rank, idx; };
+
 template <bool RV, bool U, bool SS>
 __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ mp, ArenaView av, int nQ,
                                                    const int32_t *qList, int nC, const int32_t *cand, int isTip,
                                                    double bLen, double *out, long long ldOut, const int32_t *outCol,
-                                                   const uint8_t *qTip, const double *qBLen, int *counter)
+                                                   const uint8_t *qTip, const double *qBLen, int *counter,
+                                                   TileBest *tileBest, const int32_t *visitRank)
 {
     __shared__ Lds lds;
     __shared__ unsigned long long qlds[MAPLE_BLOCK / 64][MAPLE_QLDS];   // the tile's query list, one copy per wavefront
@@ -228,6 +248,8 @@ __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ 
     unsigned long long *myq = qlds[threadIdx.x >> 6];
     const int nChunks = (nC + 63) / 64;
     const long long tiles = (long long)nQ * nChunks;
+    double tbScore = -INFINITY;
+    int tbRank = 0x7fffffff, tbIdx = -1;
     for (;;) {
         int j = 0;
         if (lane == 0) j = atomicAdd(counter, 1);
@@ -259,10 +281,41 @@ __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ 
                 while (!w.step()) {}
                 lk = w.finish();
             } else lk = append_walk(c, list_ref(av, cl), qref, tipq, blq);
-            out[(long long)q * ldOut + (outCol ? outCol[k] : k)] = lk;
+            if (!tileBest) out[(long long)q * ldOut + (outCol ? outCol[k] : k)] = lk;
+            else { tbScore = lk; tbRank = visitRank ? visitRank[k] : k; tbIdx = k; }
+        }
+        if (tileBest) {
+            // the wavefront reduction of north_star: best score of the tile's 64 candidates, exact ties to the EARLIEST visit
+            // (the reference keeps the first of equal scores: strict >, M:7083 / 8065); one 16-byte record per (query, tile)
+            // instead of 64 scores
+            for (int m2 = 32; m2 >= 1; m2 >>= 1) {
+                const double os = __shfl_xor(tbScore, m2, 64);
+                const int orank = __shfl_xor(tbRank, m2, 64), oidx = __shfl_xor(tbIdx, m2, 64);
+                if (os > tbScore || (os == tbScore && orank < tbRank)) { tbScore = os; tbRank = orank; tbIdx = oidx; }
+            }
+            if (lane == 0) tileBest[(long long)q * nChunks + ch] = TileBest{tbScore, tbRank, tbIdx};
+            tbScore = -INFINITY; tbRank = 0x7fffffff; tbIdx = -1;
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// per query: the best of its tiles (same order: score, then earliest visit)
+__global__ __launch_bounds__(64) void k_argmax_reduce(int nQ, int nChunks, const TileBest *tb, double *bestScore, int32_t *bestIdx)
+{
+    const int q = blockIdx.x;
+    if (q >= nQ) return;
+    TileBest b{-INFINITY, 0x7fffffff, -1};
+    for (int i = threadIdx.x; i < nChunks; i += 64) {
+        const TileBest t = tb[(long long)q * nChunks + i];
+        if (t.score > b.score || (t.score == b.score && t.rank < b.rank)) b = t;
+    }
+    for (int m2 = 32; m2 >= 1; m2 >>= 1) {
+        const double os = __shfl_xor(b.score, m2, 64);
+        const int orank = __shfl_xor(b.rank, m2, 64), oidx = __shfl_xor(b.idx, m2, 64);
+        if (os > b.score || (os == b.score && orank < b.rank)) { b.score = os; b.rank = orank; b.idx = oidx; }
+    }
+    if (threadIdx.x == 0) { bestScore[q] = b.score; bestIdx[q] = b.idx; }
 }
 
 // per-item scratch placement for list-producing kernels
@@ -831,7 +884,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     for (auto &b : c->s_i64) b.release();
     c->s_words.release(); c->s_aux.release(); c->s_ais.release(); c->s_pool_w.release(); c->s_pool_a.release();
     for (auto &b : c->t_i32) b.release();
-    c->t_dist.release(); c->t_tip.release(); c->t_nodes.release(); c->t_scored_col.release(); c->t_scored_frame.release(); c->t_scan.release(); c->t_scan_parent.release();
+    c->t_dist.release(); c->t_tip.release(); c->t_nodes.release(); c->t_scored_col.release(); c->t_scored_frame.release(); c->t_scan.release(); c->t_scan_parent.release(); c->s_tilebest.release(); c->s_comm_u64.release();
     if (c->d_tile_counters) (void)hipFree(c->d_tile_counters);
     c->s_search_ws.release(); c->s_search_out.release(); c->s_counter.release(); c->s_cache.release();
     for (auto &b : c->p_i32) b.release();
@@ -845,6 +898,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     }
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     for (auto &cs : c->candsets) { if (cs.lists) (void)hipFree(cs.lists); if (cs.frame) (void)hipFree(cs.frame); }
+    if (c->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->rccl_comm);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return MAPLE_OK;
@@ -1524,7 +1578,8 @@ static int ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b, int kind = 0, dou
 // one launch of k_append_queries on stream s (timed with an event pair): out[q * ldOut + (outCol ? outCol[k] : k)]
 static int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int32_t *qList, int nC, const int32_t *cand,
                                  int isTip, double bLen, double *out, long long ldOut, const int32_t *outCol,
-                                 const uint8_t *qTip, const double *qBLen, int kind, double algBytes)
+                                 const uint8_t *qTip, const double *qBLen, int kind, double algBytes, TileBest *tileBest = nullptr,
+                                 const int32_t *visitRank = nullptr)
 {
     const long long tiles = (long long)nQ * ((nC + 63) / 64);
     if (tiles > 0x7fffffffLL - (1 << 20)) return fail(c, MAPLE_ERR_ARG, "nQ x nC too large for one launch");
@@ -1537,7 +1592,7 @@ static int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int3
     TRY(ev_pair(c, &e0, &e1, kind, (double)nQ * (double)nC, algBytes));
     HIPCK(c, hipEventRecord(e0, s));
     DISPATCH3(c, k_append_queries, <<<grid, MAPLE_BLOCK, 0, s>>>(c->d_model, view(c), nQ, qList, nC, cand, isTip, bLen, out, ldOut,
-                                                                  outCol, qTip, qBLen, counter));
+                                                                  outCol, qTip, qBLen, counter, tileBest, visitRank));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipEventRecord(e1, s));
     return MAPLE_OK;
@@ -1569,6 +1624,131 @@ extern "C" int maple_append_queries_dev(maple_ctx *c, int32_t nQ, const int32_t 
     TRY(need_model(c));
     return launch_append_queries(c, (hipStream_t)stream, nQ, qList_dev, nC, cand_dev, isTipC, bLen, out_dev,
                                  nC, nullptr, nullptr, nullptr, MAPLE_K_APPEND_QUERIES, 0.0);
+}
+
+// Q queries x C candidates without the score matrix: per query the best score and the candidate that has it (exact
+// ties to the smallest visitRank, or to the smallest index when visitRank is NULL).
+extern "C" int maple_append_queries_argmax_dev(maple_ctx *c, int32_t nQ, const int32_t *qList_dev, int32_t nC,
+                                               const int32_t *cand_dev, const int32_t *visitRank_dev, int isTipC, double bLen,
+                                               double *bestScore_dev, int32_t *bestIdx_dev, void *stream)
+{
+    if (!c || nQ < 0 || nC < 0 || !qList_dev || !cand_dev || !bestScore_dev || !bestIdx_dev) return MAPLE_ERR_ARG;
+    if (nQ == 0 || nC == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    const int nChunks = (nC + 63) / 64;
+    HIPCK(c, c->s_tilebest.reserve((size_t)nQ * nChunks * sizeof(TileBest)));
+    TileBest *tb = (TileBest *)c->s_tilebest.p;
+    TRY(launch_append_queries(c, (hipStream_t)stream, nQ, qList_dev, nC, cand_dev, isTipC, bLen, nullptr, 0, nullptr, nullptr, nullptr,
+                              MAPLE_K_APPEND_QUERIES, 0.0, tb, visitRank_dev));
+    hipLaunchKernelGGL(k_argmax_reduce, dim3(nQ), dim3(64), 0, (hipStream_t)stream, nQ, nChunks, tb, bestScore_dev, bestIdx_dev);
+    HIPCK(c, hipGetLastError());
+    return MAPLE_OK;
+}
+
+// ---- RCCL: the arg-max over the ranks' candidate shards (SURVEY 8b / 8e level 2) -----------------------------------------
+// RCCL is loaded at run time (dlopen: the copy the process already has, e.g. PyTorch's, is reused), so the library itself
+// links against nothing but the HIP runtime.  The communicator's unique id travels out of band (the host broadcasts the
+// 128 bytes, e.g. with torch.distributed).
+static int rccl_load(maple_ctx *c)
+{
+    if (c->rccl_lib) return MAPLE_OK;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail(c, MAPLE_ERR_STATE, "RCCL (librccl.so) cannot be loaded: %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(c, MAPLE_ERR_STATE, "librccl.so lacks the expected entry points");
+    c->rccl_lib = h;
+    return MAPLE_OK;
+}
+#define NCCLCK(c, call)                                                                                     \
+    do {                                                                                                    \
+        ncclResult_t r_ = (call);                                                                           \
+        if (r_ != ncclSuccess)                                                                              \
+            return fail((c), MAPLE_ERR_HIP, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+    } while (0)
+
+extern "C" int maple_comm_unique_id(maple_ctx *c, uint8_t *id128)
+{
+    if (!c || !id128) return MAPLE_ERR_ARG;
+    TRY(rccl_load(c));
+    ncclUniqueId id;
+    NCCLCK(c, g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, 128);
+    return MAPLE_OK;
+}
+
+extern "C" int maple_comm_init(maple_ctx *c, int32_t world, int32_t rank, const uint8_t *id128)
+{
+    if (!c || world < 1 || rank < 0 || rank >= world || !id128) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(rccl_load(c));
+    if (c->rccl_comm) { NCCLCK(c, g_rccl.CommDestroy((ncclComm_t)c->rccl_comm)); c->rccl_comm = nullptr; }
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclComm_t comm;
+    NCCLCK(c, g_rccl.CommInitRank(&comm, world, id, rank));
+    c->rccl_comm = comm; c->rccl_world = world; c->rccl_rank = rank;
+    return MAPLE_OK;
+}
+
+// order-preserving image of a double in an unsigned 64-bit integer (so that an integer max IS the float max), and back
+__device__ inline unsigned long long f64_key(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__global__ void k_argmax_pack(int n, const double *score, unsigned long long *key)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key[i] = f64_key(score[i]);
+}
+// after the max all-reduce of the keys: ranks that hold the winning score offer their visit index, the others "infinity"
+__global__ void k_argmax_offer(int n, const double *score, const unsigned long long *best, const int32_t *idx, unsigned long long *offer)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) offer[i] = (f64_key(score[i]) == best[i]) ? (unsigned long long)(uint32_t)idx[i] : ~0ull;
+}
+__global__ void k_argmax_unpack(int n, const unsigned long long *best, const unsigned long long *offer, double *score, int32_t *idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const unsigned long long k = best[i];
+        const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+        score[i] = __longlong_as_double((long long)b);
+        idx[i] = (int32_t)(uint32_t)offer[i];
+    }
+}
+
+// In place, on `stream`: score[i] = max over ranks, idx[i] = the SMALLEST idx among the ranks that hold that score (the
+// earliest depth-first visit wins an exact tie, like the reference's strict >, M:7083 / 8065).  Two all-reduces of n
+// 8-byte words over xGMI (max of the order-preserving keys, then min of the offered indices).
+extern "C" int maple_argmax_allreduce_dev(maple_ctx *c, int32_t n, double *score_dev, int32_t *idx_dev, void *stream)
+{
+    if (!c || n < 0 || !score_dev || !idx_dev) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    if (!c->rccl_comm) return fail(c, MAPLE_ERR_STATE, "maple_comm_init has not been called");
+    HIPCK(c, hipSetDevice(c->device));
+    HIPCK(c, c->s_comm_u64.reserve((size_t)2 * n));
+    unsigned long long *key = c->s_comm_u64.p, *offer = key + n;
+    hipStream_t s = (hipStream_t)stream;
+    const int g = (n + 255) / 256;
+    hipLaunchKernelGGL(k_argmax_pack, dim3(g), dim3(256), 0, s, n, score_dev, key);
+    NCCLCK(c, g_rccl.AllReduce(key, key, (size_t)n, ncclUint64, ncclMax, (ncclComm_t)c->rccl_comm, s));
+    hipLaunchKernelGGL(k_argmax_offer, dim3(g), dim3(256), 0, s, n, score_dev, key, idx_dev, offer);
+    NCCLCK(c, g_rccl.AllReduce(offer, offer, (size_t)n, ncclUint64, ncclMin, (ncclComm_t)c->rccl_comm, s));
+    hipLaunchKernelGGL(k_argmax_unpack, dim3(g), dim3(256), 0, s, n, key, offer, score_dev, idx_dev);
+    HIPCK(c, hipGetLastError());
+    return MAPLE_OK;
 }
 
 #include "placement_host.h"

@@ -25,6 +25,7 @@ EXPORTS = [
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
     "maple_timing_read_kind", "maple_placement_supports_batch", "maple_debug_gpv_batch", "maple_debug_simplify_batch",
+    "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev",
 ]
 
 
@@ -453,6 +454,22 @@ class Device:
         self._ck(self.lib.maple_append_queries_dev(self.h, int(nQ), C.c_void_p(qlist_ptr), int(nC), C.c_void_p(cand_ptr),
                                                    int(bool(isTipC)), C.c_double(bLen), C.c_void_p(out_ptr),
                                                    C.c_void_p(stream)))
+
+    def append_queries_argmax_dev(self, nQ, qlist_ptr, nC, cand_ptr, rank_ptr, isTipC, bLen, best_score_ptr, best_idx_ptr, stream=0):
+        self._ck(self.lib.maple_append_queries_argmax_dev(self.h, int(nQ), C.c_void_p(qlist_ptr), int(nC), C.c_void_p(cand_ptr),
+                                                          C.c_void_p(rank_ptr), int(bool(isTipC)), C.c_double(bLen),
+                                                          C.c_void_p(best_score_ptr), C.c_void_p(best_idx_ptr), C.c_void_p(stream)))
+
+    def comm_unique_id(self):
+        buf = np.zeros(128, dtype=np.uint8)
+        self._ck(self.lib.maple_comm_unique_id(self.h, _ptr(buf)))
+        return buf
+
+    def comm_init(self, world, rank, unique_id):
+        self._ck(self.lib.maple_comm_init(self.h, int(world), int(rank), _ptr(_u8(unique_id))))
+
+    def argmax_allreduce_dev(self, n, score_ptr, idx_ptr, stream=0):
+        self._ck(self.lib.maple_argmax_allreduce_dev(self.h, int(n), C.c_void_p(score_ptr), C.c_void_p(idx_ptr), C.c_void_p(stream)))
 
     def timing_reset(self):
         self._ck(self.lib.maple_timing_reset(self.h))

@@ -314,6 +314,47 @@ def test_append_queries_dev_matches_pair_batches(env):
                 assert close(float(got[q, q]), recs[q]["ret"], REL)
 
 
+def test_fused_argmax_equals_argmax_of_the_score_matrix(env):
+    """The wavefront-reduction output mode of the batch kernel (maple_append_queries_argmax_dev): per query the best score
+    and its candidate, bit-identical to the arg-max of the full score matrix with exact ties going to the smallest visit
+    rank; and the RCCL arg-max all-reduce on a one-rank communicator (identity)."""
+    import torch
+    f, dev, o = env
+    mid, recs = max(by_model(f, "appendProbNode").items(), key=lambda kv: len(kv[1]))
+    dev.set_model(**model_args(f["models"][mid]))
+    mark = dev.mark()
+    parents = dev.upload([tup(r["P"]) for r in recs] * 3)                  # duplicates: exact ties to break
+    kids = dev.upload([tup(r["C"]) for r in recs[:24]])
+    cu = torch.device("cuda", 0)
+    t_q = torch.from_numpy(kids.astype(np.int32)).to(cu)
+    t_c = torch.from_numpy(parents.astype(np.int32)).to(cu)
+    Q, Cn = len(kids), len(parents)
+    rank = np.random.default_rng(5).permutation(Cn).astype(np.int32)
+    t_rank = torch.from_numpy(rank).to(cu)
+    full = torch.empty(Q * Cn, dtype=torch.float64, device=cu)
+    best = torch.empty(Q, dtype=torch.float64, device=cu)
+    idx = torch.empty(Q, dtype=torch.int32, device=cu)
+    torch.cuda.synchronize()
+    dev.append_queries_dev(Q, t_q.data_ptr(), Cn, t_c.data_ptr(), False, 1e-4, full.data_ptr(), 0)
+    dev.append_queries_argmax_dev(Q, t_q.data_ptr(), Cn, t_c.data_ptr(), t_rank.data_ptr(), False, 1e-4, best.data_ptr(),
+                                  idx.data_ptr(), 0)
+    torch.cuda.synchronize()
+    m = full.cpu().numpy().reshape(Q, Cn)
+    for q in range(Q):
+        top = m[q].max()
+        ties = np.nonzero(m[q] == top)[0]
+        want = ties[np.argmin(rank[ties])]
+        assert best[q].item() == top and int(idx[q].item()) == int(want), (q, best[q].item(), top, idx[q].item(), want)
+        assert len(ties) >= 3 or not np.isfinite(top)
+    # RCCL entry point, one rank: the all-reduce must leave (score, idx) as they are
+    dev.comm_init(1, 0, dev.comm_unique_id())
+    before = (best.clone(), idx.clone())
+    dev.argmax_allreduce_dev(Q, best.data_ptr(), idx.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(best, before[0]) and torch.equal(idx, before[1])
+    dev.release(mark)
+
+
 def test_edge_cases_through_the_c_abi():
     """Empty batches, whole-genome N / R lists, bad list ids and an exhausted arena: defined results or a clean error
     (MapleError with the library's message), never a crash."""

@@ -237,3 +237,36 @@ def test_batch_kernel_with_queries_longer_than_the_lds_stage():
             g = float(got[qi, ci])
             assert (math.isinf(want) and math.isinf(g)) or rel(g, want) < 1e-12, (qi, ci, g, want)
     dev.close()
+
+
+def test_bench_two_ranks_plumbing():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank) on a box with ONE GPU:
+    MAPLE_BENCH_BACKEND=gloo lets both ranks share it and sends the collectives through host memory.  Checks the N > 1
+    path end to end: pre-order sharding of each step's batch, the all-gather of proposed moves, the max-over-ranks
+    timing and the sum of the ranks' candidate placements."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--samples", "1500", "--model", "unrest", "--batch", "600", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+              "--no-extras"]
+    env = dict(os.environ, MAPLE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert two.returncode == 0, two.stderr[-2000:]
+    line2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True,
+                         timeout=900, env=env, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    line1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line2["n_gpus"] == 2 and line1["n_gpus"] == 1 and line2["scaling"] == "strong"
+    # the same searches, whoever ran them: the same total of candidate placements
+    assert line2["config"]["searches_timed"] == line1["config"]["searches_timed"] == 2 * 600
+    assert line2["config"]["candidate_placements_timed"] == line1["config"]["candidate_placements_timed"]
+    assert line2["value"] > 0 and line2["roofline"]["frac"] >= 0
