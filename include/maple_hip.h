@@ -93,7 +93,8 @@ int maple_lists_sizes(maple_ctx *ctx, int32_t n, const int32_t *ids, int32_t *n_
 /* Download into caller buffers sized from maple_lists_sizes (CSR, same layout as upload). */
 int maple_lists_download(maple_ctx *ctx, int32_t n, const int32_t *ids, const int64_t *ent_off, int32_t *pos,
                          uint32_t *meta, const int64_t *aux_off, double *aux);
-/* Stack discipline for temporaries: everything created after `mark` is dropped. */
+/* Stack discipline for temporaries: everything created after `mark` is dropped -- genome lists AND MAT mutation lists
+ * (maple_mutations_upload); the mark is opaque. */
 int maple_arena_mark(maple_ctx *ctx, int64_t *mark);
 int maple_arena_release(maple_ctx *ctx, int64_t mark);
 int maple_arena_stats(maple_ctx *ctx, int64_t *n_lists, int64_t *n_entries, int64_t *n_aux, int64_t *cap_entries);
@@ -129,6 +130,7 @@ int maple_differ_batch(maple_ctx *ctx, int32_t n, const int32_t *list1, const in
  * every frame (frameLists[nFrames], e.g. produced level by level with maple_pass_branch_batch). */
 int maple_candset_create(maple_ctx *ctx, int32_t n, const int32_t *lists, const int32_t *frameIdx, int32_t nFrames,
                          int32_t *setId);
+int maple_candset_destroy(maple_ctx *ctx, int32_t setId);   /* frees the set's device arrays (the id is not reused) */
 int maple_append_candset(maple_ctx *ctx, int32_t setId, const int32_t *frameLists, int isTipC, double bLen, double *outLK);
 int maple_minor_candset(maple_ctx *ctx, int32_t setId, const int32_t *frameLists, int onlyFindIdentical, uint8_t *out);
 /* findProbRoot(probVect) for lists already expressed in the root frame, M:4865-4912 */
@@ -157,6 +159,8 @@ int maple_evaluate_placement_batch(maple_ctx *ctx, int32_t n, const int32_t *mid
  * up / child0 / child1 use -1 for None; isTip[n] = leaf with no minor sequences (the `isTip` tests of
  * M:6986, 7129, 9645); lower/upRight/upLeft/totUp are list ids (probVect, probVectUpRight,
  * probVectUpLeft, probVectTotUp; -1 = None); mutList[n] = mutation-list id of tree.mutations[n], -1 if empty. */
+/* (validated: index ranges, both-or-neither children, children pointing back to their parent, no cycle below the root --
+ * MAPLE_ERR_ARG otherwise; node slots not reachable from the root are ignored) */
 int maple_tree_upload(maple_ctx *ctx, int32_t n, int32_t root, const int32_t *up, const int32_t *child0,
                       const int32_t *child1, const double *dist, const uint8_t *isTip, const int32_t *lower,
                       const int32_t *upRight, const int32_t *upLeft, const int32_t *totUp, const int32_t *mutList);

@@ -1088,16 +1088,24 @@ extern "C" int maple_set_fatal_policy(maple_ctx *c, int tolerate)
     return MAPLE_OK;
 }
 
+// A mark is the number of genome lists in its low 40 bits and the number of MAT mutation lists above: releasing it drops
+// both kinds of temporaries.
 extern "C" int maple_arena_mark(maple_ctx *c, int64_t *mark)
 {
     if (!c || !mark) return MAPLE_ERR_ARG;
-    *mark = (int64_t)c->h_n_ent.size();
+    *mark = (int64_t)c->h_n_ent.size() | ((int64_t)c->h_mut_cnt.size() << 40);
     return MAPLE_OK;
 }
 
-extern "C" int maple_arena_release(maple_ctx *c, int64_t mark)
+extern "C" int maple_arena_release(maple_ctx *c, int64_t markBoth)
 {
-    if (!c || mark < 0 || mark > (int64_t)c->h_n_ent.size()) return MAPLE_ERR_ARG;
+    if (!c || markBoth < 0) return MAPLE_ERR_ARG;
+    const int64_t mark = markBoth & (((int64_t)1 << 40) - 1), mmark = markBoth >> 40;
+    if (mark > (int64_t)c->h_n_ent.size() || mmark > (int64_t)c->h_mut_cnt.size()) return MAPLE_ERR_ARG;
+    if (mmark < (int64_t)c->h_mut_cnt.size()) {
+        c->used_mut = c->h_mut_off[mmark];
+        c->h_mut_off.resize(mmark); c->h_mut_cnt.resize(mmark);
+    }
     if (mark == (int64_t)c->h_n_ent.size()) return MAPLE_OK;
     c->used_ent = c->h_ent_off[mark];
     c->used_aux = c->h_aux_off[mark];
@@ -1334,12 +1342,25 @@ extern "C" int maple_candset_create(maple_ctx *c, int32_t n, const int32_t *list
     return MAPLE_OK;
 }
 
+extern "C" int maple_candset_destroy(maple_ctx *c, int32_t setId)
+{
+    if (!c || setId < 0 || setId >= (int32_t)c->candsets.size()) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    auto &cs = c->candsets[setId];
+    if (cs.lists) (void)hipFree(cs.lists);
+    if (cs.frame) (void)hipFree(cs.frame);
+    cs.lists = cs.frame = nullptr;
+    cs.n = 0;
+    return MAPLE_OK;
+}
+
 extern "C" int maple_append_candset(maple_ctx *c, int32_t setId, const int32_t *frameLists, int isTipC, double bLen, double *out)
 {
     if (!c || setId < 0 || setId >= (int32_t)c->candsets.size() || !frameLists || !out) return MAPLE_ERR_ARG;
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
     const auto &cs = c->candsets[setId];
+    if (!cs.lists) return fail(c, MAPLE_ERR_ARG, "candidate set %d has been destroyed", setId);
     TRY(check_ids(c, cs.nFrames, frameLists, false, "frameLists"));
     TRY(h2d(c, c->s_i32[0], frameLists, (size_t)cs.nFrames));
     HIPCK(c, c->s_f64[0].reserve(cs.n));
@@ -1360,6 +1381,7 @@ extern "C" int maple_minor_candset(maple_ctx *c, int32_t setId, const int32_t *f
     if (!c || setId < 0 || setId >= (int32_t)c->candsets.size() || !frameLists || !out) return MAPLE_ERR_ARG;
     HIPCK(c, hipSetDevice(c->device));
     const auto &cs = c->candsets[setId];
+    if (!cs.lists) return fail(c, MAPLE_ERR_ARG, "candidate set %d has been destroyed", setId);
     TRY(check_ids(c, cs.nFrames, frameLists, false, "frameLists"));
     TRY(h2d(c, c->s_i32[0], frameLists, (size_t)cs.nFrames));
     HIPCK(c, c->s_u8[0].reserve(cs.n));
@@ -1824,6 +1846,29 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     const int32_t nml = (int32_t)c->h_mut_cnt.size();
     for (int i = 0; i < n; i++)
         if (mutList[i] >= nml) return fail(c, MAPLE_ERR_ARG, "mutList[%d] is not a mutation-list id", i);
+    // the topology arrays are trusted by everything below (depth-first orders, frames, the kernels): check them here
+    if (up[root] >= 0) return fail(c, MAPLE_ERR_ARG, "the root (%d) has a parent", root);
+    for (int i = 0; i < n; i++) {
+        if (up[i] < -1 || up[i] >= n || child0[i] < -1 || child0[i] >= n || child1[i] < -1 || child1[i] >= n)
+            return fail(c, MAPLE_ERR_ARG, "node %d: up / child index out of range", i);
+        if ((child0[i] >= 0) != (child1[i] >= 0)) return fail(c, MAPLE_ERR_ARG, "node %d has exactly one child", i);
+        if (child0[i] >= 0 && (child0[i] == child1[i] || child0[i] == i || child1[i] == i))
+            return fail(c, MAPLE_ERR_ARG, "node %d: malformed children", i);
+    }
+    {   // every node reachable from the root must be the child its parent says it is, and be reached once (no cycles)
+        std::vector<uint8_t> seen((size_t)n, 0);
+        std::vector<int32_t> st{root};
+        while (!st.empty()) {
+            const int32_t v = st.back();
+            st.pop_back();
+            if (seen[v]) return fail(c, MAPLE_ERR_ARG, "node %d is reached twice from the root (cycle or shared child)", v);
+            seen[v] = 1;
+            if (child0[v] >= 0) {
+                if (up[child0[v]] != v || up[child1[v]] != v) return fail(c, MAPLE_ERR_ARG, "children of node %d do not point back to it", v);
+                st.push_back(child0[v]); st.push_back(child1[v]);
+            }
+        }
+    }
     const int32_t *src[9] = {up, child0, child1, lower, upRight, upLeft, totUp, mutList, nullptr};
     for (int k = 0; k < 8; k++) TRY(h2d(c, c->t_i32[k], src[k], (size_t)n));
     TRY(h2d(c, c->t_dist, dist, (size_t)n));

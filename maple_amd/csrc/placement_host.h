@@ -581,8 +581,9 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
             int32_t *bestDiffs = sup ? sup->bestTotalLh : bestDiffsOut;   // the list ids this call hands to the caller
             // keep only what the caller was handed: the bestDiffs lists made by this chunk move to the bottom of the arena
             // (down to the chunk's mark), everything else the chunk allocated is released
+            const int64_t listMark = chunkMark & (((int64_t)1 << 40) - 1);      // (a mark also carries the mutation-list count)
             std::vector<int32_t> keep;
-            for (int q = 0; q < nq; q++) if (bestDiffs[q0 + q] >= chunkMark) keep.push_back(bestDiffs[q0 + q]);
+            for (int q = 0; q < nq; q++) if (bestDiffs[q0 + q] >= listMark) keep.push_back(bestDiffs[q0 + q]);
             std::sort(keep.begin(), keep.end());
             keep.erase(std::unique(keep.begin(), keep.end()), keep.end());
             std::vector<int64_t> eo(keep.size() + 1, 0), ao(keep.size() + 1, 0);
@@ -598,7 +599,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                 TRY(maple_lists_upload(c, (int32_t)keep.size(), eo.data(), pos.data(), meta.data(), ao.data(), aux.data(), &first));
             for (int q = 0; q < nq; q++) {
                 int32_t &b = bestDiffs[q0 + q];
-                if (b >= chunkMark) b = first + (int32_t)(std::lower_bound(keep.begin(), keep.end(), b) - keep.begin());
+                if (b >= listMark) b = first + (int32_t)(std::lower_bound(keep.begin(), keep.end(), b) - keep.begin());
             }
         }
     }

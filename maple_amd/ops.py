@@ -139,10 +139,12 @@ class TreeOps:
         self.dev.upload_tree(t.root, up, c0, c1, dist, tip, t.id_lower, t.id_upRight, t.id_upLeft, t.id_totUp, t.id_mut)
         self._searcher = None
 
-    # M:7912 -- returns (bestNode, bestScore, bestBranchLengths, bestDiffs) like the reference
+    # M:7912 -- returns (bestNode, bestScore, bestBranchLengths, bestDiffs) like the reference; with
+    # computePlacementSupportOnly=True (possiblePlacements, bestPlacementTotalLh), M:8264-8290
     def findBestParentForNewSample(self, diffs, *, oneMutBLen, effectivelyNon0BLen, thresholdLogLK, thresholdLogLKoptimization,
                                    thresholdLogLKconsecutivePlacement, allowedFails=5, strictStopRules=True,
-                                   onlyFindIdentical=False):
+                                   onlyFindIdentical=False, computePlacementSupportOnly=False,
+                                   thresholdLogLKoptimizationTopology=None, minBranchSupport=0.01):
         from .search import PlacementParams, PlacementSearcher
         key = (oneMutBLen, effectivelyNon0BLen, thresholdLogLK, thresholdLogLKoptimization,
                thresholdLogLKconsecutivePlacement, allowedFails, strictStopRules, onlyFindIdentical)
@@ -153,6 +155,9 @@ class TreeOps:
                 thresholdLogLKconsecutivePlacement=thresholdLogLKconsecutivePlacement, allowedFails=allowedFails,
                 strictStopRules=strictStopRules, onlyFindIdentical=onlyFindIdentical))
             self._searcher_key = key
+        if computePlacementSupportOnly:
+            thr = thresholdLogLKoptimization if thresholdLogLKoptimizationTopology is None else thresholdLogLKoptimizationTopology
+            return self._searcher.find_placement_supports([diffs], thr, minBranchSupport)[0]
         return self._searcher.find_best_parent_for_new_sample(diffs)[:4]
 
     # M:9580 -- the worker body for `nodes`; returns the list of (node, placement, improvement) the reference's worker returns
@@ -165,6 +170,10 @@ class TreeOps:
                                         thresholdLogLKoptimizationTopology=thresholdLogLKoptimizationTopology,
                                         thresholdLogLKconsecutivePlacement=thresholdLogLKconsecutivePlacement,
                                         effectivelyNon0BLen=effectivelyNon0BLen)
+        bad = res["status"][res["status"] < -1]
+        if len(bad):      # -1 is the reference's swallowed exception (M:9703); anything below is a capacity problem, not "no move"
+            raise RuntimeError(f"SPR search could not finish some queries (status {sorted(set(bad.tolist()))}: workspace, "
+                               "removed-partials pool or short-list capacity)")
         return [(int(n), int(p), float(i)) for n, p, i in zip(nodes, res["placement"], res["improvement"]) if p >= 0]
 
     def reCalculateAllGenomeLists(self):                                   # M:6013
@@ -180,12 +189,11 @@ class TreeOps:
         from .tree_host import tree_log_likelihood
         return tree_log_likelihood(self.dev, self.tree)[0]
 
-    def traverseTreeToOptimizeBranchLengths(self, effectivelyNon0BLen, fastPass=True):   # M:8727
-        from .tree_host import optimize_branch_lengths_fast_pass
-        if not fastPass:
-            raise NotImplementedError("the sequential sweep updates partials after every branch: call the fast pass, then "
-                                      "updatePartials / reCalculateAllGenomeLists")
-        return optimize_branch_lengths_fast_pass(self.dev, self.tree, effectivelyNon0BLen)[0]
+    def traverseTreeToOptimizeBranchLengths(self, effectivelyNon0BLen, fastPass=False):  # M:8727 (default: the Gauss-Seidel sweep)
+        from .tree_host import optimize_branch_lengths, optimize_branch_lengths_fast_pass
+        if fastPass:
+            return optimize_branch_lengths_fast_pass(self.dev, self.tree, effectivelyNon0BLen)[0]
+        return optimize_branch_lengths(self.dev, self.tree, effectivelyNon0BLen)[0]
 
     def findBestRoot(self, **kw):                                          # M:7730 (the search; re-rooting stays with the caller)
         from .tree_host import find_best_root

@@ -118,6 +118,25 @@ def argmax_allreduce(score: float, visit_index: int, device=None):
     return best, int(i.item())
 
 
+def argmax_allreduce_native(dev, score_tensor, idx_tensor, stream=0):
+    """The same reduction for whole vectors that already sit in HBM, through the library's RCCL entry point
+    (maple_argmax_allreduce_dev: two ncclAllReduce of 8-byte words, in place, asynchronous on `stream`).  The
+    communicator is created on first use: rank 0's unique id is broadcast with torch.distributed."""
+    import torch
+    import torch.distributed as dist
+    if not getattr(dev, "_comm_ready", False):
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        uid = torch.from_numpy(dev.comm_unique_id() if rank == 0 else np.zeros(128, dtype=np.uint8))
+        if world > 1:
+            holder = uid.to(score_tensor.device) if dist.get_backend() == "nccl" else uid
+            dist.broadcast(holder, src=0)
+            uid = holder.cpu()
+        dev.comm_init(world, rank, uid.numpy())
+        dev._comm_ready = True
+    dev.argmax_allreduce_dev(score_tensor.numel(), score_tensor.data_ptr(), idx_tensor.data_ptr(), stream)
+
+
 def sharded_spr_round(dev, nodes, search_kwargs, rank: int = 0, world: int = 1, device=None):
     """One SPR search (sub)round over several GPUs -- what the reference does with Pool.map over its cores
     (M:12283-12316): ``nodes`` (the dirty nodes in pre-order, identical on every rank) are dealt round-robin like
@@ -125,7 +144,10 @@ def sharded_spr_round(dev, nodes, search_kwargs, rank: int = 0, world: int = 1, 
     combined with ONE all-gather and sorted by improvement.  Returns (moves, local_result) with moves =
     [(node, placement, improvement), ...] identical on every rank."""
     nodes = np.asarray(nodes)
-    mine = nodes[rank::world]
+    mine = nodes[rank::world]               # `nodes` in pre-order: this is coreNum[node] == rank (shard_nodes)
     res = dev.spr_search_batch(mine, **search_kwargs)
+    bad = res["status"][res["status"] < -1]
+    if len(bad):
+        raise RuntimeError(f"SPR search could not finish some queries (status {sorted(set(bad.tolist()))})")
     rec = pack_proposals(mine, res["placement"], res["improvement"])
     return gather_proposals(rec, device=device), res

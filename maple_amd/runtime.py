@@ -25,7 +25,7 @@ EXPORTS = [
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
     "maple_timing_read_kind", "maple_placement_supports_batch", "maple_debug_gpv_batch", "maple_debug_simplify_batch",
-    "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev",
+    "maple_candset_destroy", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev",
 ]
 
 
@@ -264,6 +264,9 @@ class Device:
         sid = C.c_int32()
         self._ck(self.lib.maple_candset_create(self.h, len(lists), _ptr(lists), _ptr(frame_idx), int(n_frames), C.byref(sid)))
         return sid.value, len(lists)
+
+    def candset_destroy(self, cset):
+        self._ck(self.lib.maple_candset_destroy(self.h, int(cset[0])))
 
     def append_candset(self, cset, frame_lists, isTipC, bLen):
         fl = _i32(frame_lists)

@@ -98,6 +98,19 @@ class PlacementSearcher:
             self.cset_leaf = dev.candset_create(t.id_lower[self.my_leaves],
                                                 [fidx[int(self.frame[v])] for v in self.my_leaves], len(self.frame_order))
 
+    def close(self):
+        """Free the resident candidate sets (one PlacementSearcher per tree state: the sequential placement loop makes many)."""
+        for cs in (self.cset_cand, self.cset_leaf):
+            if cs is not None:
+                self.dev.candset_destroy(cs)
+        self.cset_cand = self.cset_leaf = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     # ---------------------------------------------------------------------------------------------
     def _frame_lists(self, q_id):
         """Query list in every frame (U), its shortened form (S) -- all on the device."""
