@@ -238,6 +238,9 @@ int maple_debug_trace_query(maple_ctx *ctx, int32_t query);
 /* PMC calibration: `repeats` launches of a kernel that reads `bytes` bytes with this library's access pattern
  * (one lane = one contiguous 512-byte list, dependent 8-byte loads); returns the total time. */
 int maple_debug_calib_walk(maple_ctx *ctx, uint64_t bytes, int32_t repeats, float *ms);
+/* ... and of WRITE_SIZE: mode 1 = `bytes` written as a coalesced stream, mode 2 = one 8-byte store into every 64-byte line
+ * of a `bytes`-long buffer (the way the score matrix is written: bytes / 8 useful bytes). */
+int maple_debug_calib_write(maple_ctx *ctx, uint64_t bytes, int32_t mode, int32_t repeats, float *ms);
 int maple_debug_trace_read(maple_ctx *ctx, int32_t *n, int32_t *items4 /*[4*4096]*/, double *vals2 /*[2*4096]*/);
 /* Parity hooks for the two innermost device functions (one lane per call):
  * getPartialVec(i12, totLen, mutMatrix, errorRate, vect, upNode, flag), M:4073-4141, with the call's own 4x4 matrix

@@ -2335,6 +2335,36 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_calib_walk(const unsigned long 
     if (acc == 0x123456789abcdefull) *sink = acc;
 }
 
+// WRITE_SIZE calibration: mode 1 writes `bytes` as a coalesced 8-byte-per-lane stream, mode 2 writes ONE 8-byte value into
+// every 64-byte line of the buffer (the score-matrix pattern of k_append_queries: a lane's score lands in a line of its own)
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_calib_write(unsigned long long *buf, long long nWords, int strideWords)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i * strideWords < nWords; i += (long long)gridDim.x * blockDim.x)
+        buf[i * strideWords] = (unsigned long long)i;
+}
+
+extern "C" int maple_debug_calib_write(maple_ctx *c, uint64_t bytes, int32_t mode, int32_t repeats, float *ms)
+{
+    if (!c || bytes < 512 || repeats <= 0 || mode < 1 || mode > 2) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    unsigned long long *buf = nullptr;
+    HIPCK(c, hipMalloc((void **)&buf, bytes));
+    HIPCK(c, hipMemset(buf, 0, bytes));
+    HIPCK(c, hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    HIPCK(c, hipEventCreate(&e0));
+    HIPCK(c, hipEventCreate(&e1));
+    HIPCK(c, hipEventRecord(e0, c->stream));
+    for (int r = 0; r < repeats; r++)
+        hipLaunchKernelGGL(k_calib_write, dim3(4096), dim3(MAPLE_BLOCK), 0, c->stream, buf, (long long)(bytes / 8), mode == 1 ? 1 : 8);
+    HIPCK(c, hipEventRecord(e1, c->stream));
+    HIPCK(c, hipEventSynchronize(e1));
+    if (ms) HIPCK(c, hipEventElapsedTime(ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    return MAPLE_OK;
+}
+
 extern "C" int maple_debug_calib_walk(maple_ctx *c, uint64_t bytes, int32_t repeats, float *ms)
 {
     if (!c || bytes < 512 || repeats <= 0) return MAPLE_ERR_ARG;

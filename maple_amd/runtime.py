@@ -25,7 +25,7 @@ EXPORTS = [
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
     "maple_timing_read_kind", "maple_placement_supports_batch", "maple_debug_gpv_batch", "maple_debug_simplify_batch",
-    "maple_candset_destroy", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev",
+    "maple_candset_destroy", "maple_debug_calib_write", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev",
 ]
 
 
@@ -434,6 +434,11 @@ class Device:
     def debug_calib_walk(self, nbytes, repeats=1):
         ms = C.c_float()
         self._ck(self.lib.maple_debug_calib_walk(self.h, C.c_uint64(nbytes), int(repeats), C.byref(ms)))
+        return ms.value
+
+    def debug_calib_write(self, nbytes, mode, repeats=1):
+        ms = C.c_float()
+        self._ck(self.lib.maple_debug_calib_write(self.h, C.c_uint64(nbytes), int(mode), int(repeats), C.byref(ms)))
         return ms.value
 
     def debug_trace_query(self, q):

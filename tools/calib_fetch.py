@@ -8,3 +8,6 @@ dev = Device(np.zeros(100, dtype=np.uint8), [0.25] * 4, arena_bytes=16 << 20)
 nbytes = 2 << 30
 ms = dev.debug_calib_walk(nbytes, 3)
 print(f"calib: {nbytes} bytes x 3 launches in {ms:.3f} ms -> {3 * nbytes / ms / 1e6:.1f} GB/s")
+for mode, what in ((1, "coalesced 8-byte stream"), (2, "one 8-byte store per 64-byte line")):
+    ms = dev.debug_calib_write(nbytes, mode, 1)
+    print(f"calib write mode {mode} ({what}): buffer {nbytes} bytes in {ms:.3f} ms")

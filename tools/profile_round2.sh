@@ -13,6 +13,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_L
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -f csv -d $OUT/sq2 -- $B > $OUT/sq2.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -f csv -d $OUT/tcc -- $B > $OUT/tcc.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/calib -- python $R/tools/calib_fetch.py > $OUT/calib.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/calibw -- python $R/tools/calib_fetch.py > $OUT/calibw.log 2>&1
 python $R/tools/summarize_round2.py $NAME $OUT "$EXTRA" > $OUT/summary.md 2> $OUT/summary.err
 cp $OUT/summary.md $OUT/../${NAME}_summary.md 2>/dev/null
 tail -40 $OUT/summary.md

@@ -46,7 +46,7 @@ if st:
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
 for f in glob.glob(out + "/*/*/*_counter_collection.csv"):
-    if "/calib/" in f:
+    if "/calib/" in f or "/calibw/" in f:
         continue
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
@@ -58,6 +58,12 @@ if f:
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_calib_walk" in r["Kernel_Name"]]
     if v:
         calib = (sum(v) / len(v)) * 1024 / (2 << 30)
+wcal = {}
+f = one(out + "/calibw/*/*_counter_collection.csv")
+if f:
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_calib_write" in r["Kernel_Name"]]
+    if len(v) >= 2:
+        wcal = {"stream": v[0] * 1024 / (2 << 30), "per_line_store": v[1] * 1024 / ((2 << 30) / 8)}
 lines.append("\n## PMC, average per dispatch (kernels of the search)\n\n")
 lines.append("| kernel | dispatches | FETCH_SIZE MB | WRITE_SIZE MB | VALU / SALU / VMEM_RD / LDS / BRANCH wave-insts (M) | "
              "WAVE_CYCLES / WAIT_ANY / ACTIVE_VALU (M) | TCC hit / miss (M) | VGPR SGPR LDS scratch |\n|---|---|---|---|---|---|---|---|\n")
@@ -77,6 +83,10 @@ for k, d in agg.items():
                  f"{avg(d,'SQ_INSTS_LDS')/1e6:.1f} / {avg(d,'SQ_INSTS_BRANCH')/1e6:.1f} | "
                  f"{avg(d,'SQ_WAVE_CYCLES')/1e6:.0f} / {avg(d,'SQ_WAIT_ANY')/1e6:.0f} / {avg(d,'SQ_ACTIVE_INST_VALU')/1e6:.0f} | "
                  f"{avg(d,'TCC_HIT_sum')/1e6:.1f} / {avg(d,'TCC_MISS_sum')/1e6:.1f} | {' '.join(str(x) for x in meta[k])} |\n")
+if wcal:
+    lines.append(f"\nWRITE_SIZE calibration (k_calib_write over a 2 GiB buffer): a coalesced 8-byte stream is reported as "
+                 f"{wcal['stream']:.4f} of the bytes written; one 8-byte store into every 64-byte line (the score-matrix pattern) as "
+                 f"{wcal['per_line_store']:.2f} x the useful bytes.\n")
 if calib:
     lines.append(f"\nFETCH_SIZE calibration for this library's access pattern (k_calib_walk: 2 GiB read by dependent 8-byte "
                  f"per-lane walks): the counter reports {calib:.4f} of the bytes read.\n")
@@ -87,7 +97,7 @@ if sk and bench:
     pairs = bench["roofline"]["pairs_per_launch"]
     alg = bench["roofline"]["algorithmic_bytes_per_launch"]
     fetch_b = avg(d, "FETCH_SIZE") * 1024 / (calib or 1.0)
-    write_b = avg(d, "WRITE_SIZE") * 1024
+    write_b = avg(d, "WRITE_SIZE") * 1024 / (wcal.get("stream") or 1.0)      # HBM-side bytes (partial-line stores included)
     traffic = fetch_b + write_b
     lines.append(f"\n## `k_append_queries` inside the search, per (query, branch) pair\n\n"
                  f"* pairs per launch (bench run) {pairs:.4g}, algorithmic bytes per launch {alg:.4g} ({alg/pairs:.0f} B / pair)\n"
