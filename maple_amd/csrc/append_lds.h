@@ -1,0 +1,197 @@
+// maple_amd/csrc/append_lds.h -- appendProbNode (MAPLEv0.7.5.4.py:6505-6785) with the genome lists behind memory accessors.
+//
+// The batch-scoring kernel is bound by the vector-memory address path, not by HBM or the VALU: one lane walks one
+// (candidate list, query list) pair, so every load of a list word or of a stored branch length touches a cache line of its
+// own (rocprofv3: 285 vector-memory instructions per 64 pairs, waves parked on s_waitcnt 62 % of their life,
+// profiles/r02_100k_ratevar.md).  A tile's 64 candidate lists are shared by EVERY query, so k_append_queries_lds stages
+// them in LDS once per workgroup with coalesced loads and lets 8 wavefronts walk them from there for a block of queries.
+// For that the walk reads its lists through small accessor types, so that LDS-resident lists are read with ds_read
+// (address space 3) instead of flat loads.  The arithmetic is the PairWalk of genome_dev.h, operation for operation: the
+// result is bit-identical.
+#pragma once
+#include "genome_dev.h"
+
+namespace maple {
+
+typedef __attribute__((address_space(3))) const unsigned long long *lds_u64p;
+typedef __attribute__((address_space(3))) const double *lds_f64p;
+
+struct MemG {                          // words and aux doubles in global memory (or anywhere, through generic pointers)
+    const unsigned long long *w;
+    const double *a;
+    __device__ __forceinline__ unsigned long long word(int i) const { return w[i]; }
+    __device__ __forceinline__ double aux(uint32_t off) const { return a[off]; }
+};
+struct MemL {                          // both in LDS
+    lds_u64p w;
+    lds_f64p a;
+    __device__ __forceinline__ unsigned long long word(int i) const { return w[i]; }
+    __device__ __forceinline__ double aux(uint32_t off) const { return a[off]; }
+};
+struct MemLG {                         // words in LDS, aux doubles in global memory (the staged query list)
+    lds_u64p w;
+    const double *a;
+    __device__ __forceinline__ unsigned long long word(int i) const { return w[i]; }
+    __device__ __forceinline__ double aux(uint32_t off) const { return a[off]; }
+};
+
+struct EntV {                          // a decoded entry with its payload in registers
+    int pos, type, ref;
+    bool hasD0, hasD1, flag;
+    double d0, d1;
+    double v[4];                       // type 6
+};
+
+template <class M> __device__ __forceinline__ void decode_v(unsigned long long w, const M &mem, EntV &e)
+{
+    const uint32_t meta = (uint32_t)(w >> 32);
+    e.pos = (int)(uint32_t)w;
+    e.type = meta & 7u;
+    e.ref = (meta >> 3) & 3u;
+    e.hasD0 = meta & (1u << 5);
+    e.hasD1 = meta & (1u << 6);
+    e.flag = meta & (1u << 7);
+    uint32_t off = meta >> 8;
+    e.d0 = 0.0; e.d1 = 0.0;
+    if (e.hasD0) { e.d0 = mem.aux(off); off++; }
+    if (e.hasD1) { e.d1 = mem.aux(off); off++; }
+    if (e.type == 6) { e.v[0] = mem.aux(off); e.v[1] = mem.aux(off + 1); e.v[2] = mem.aux(off + 2); e.v[3] = mem.aux(off + 3); }
+}
+
+// site_factor of genome_dev.h on register-resident entries (M:6611-6761)
+template <bool RV, bool U, bool SS>
+__device__ __forceinline__ double site_factor_v(const Ctx<RV, U, SS> &c, const EntV &e1, const EntV &e2, int site, bool isTipC, double bLen)
+{
+    typedef Ctx<RV, U, SS> CT;
+    const double *rf = c.rf;
+    double cl = bLen;                                                   // M:6586-6599
+    if (e1.type < 5) { if (e1.hasD1) cl += e1.d1; else if (e1.hasD0) cl += e1.d0; }
+    else if (e1.hasD0) cl += e1.d0;
+    if (e2.type < 5) { if (e2.hasD0 && !e2.hasD1) cl += e2.d0; }
+    else if (e2.hasD0) cl += e2.d0;
+    const double r = c.rate(site);
+    const bool flag1 = U && e1.type < 5 && e1.hasD0 && e1.flag;
+    const bool flag2 = U && e2.type < 5 && (isTipC || (e2.hasD0 && e2.flag));
+    double f;
+    if (e1.type == 6 && e2.type == 6) {                                 // M:6677-6686
+        double t3[4];
+        gpv_vec(c, r, e2.v, cl, false, t3);
+        double tot = 0.0;
+        for (int j = 0; j < 4; j++) tot += e1.v[j] * t3[j];
+        f = tot;
+    } else if (e1.type == 6) {                                          // O over nucleotide/R, M:6687-6703
+        int i2 = (e2.type == 4) ? e1.ref : e2.type;
+        double p = sel4(e1.v, i2);
+        if (p > 0.02) f = p;
+        else {
+            double t3[4];
+            gpv_nuc<CT, U>(c, r, i2, cl, flag2 ? c.err(site) : 0.0, false, flag2, t3);
+            double tot = 0.0;
+            for (int j = 0; j < 4; j++) tot += e1.v[j] * t3[j];
+            f = tot;
+        }
+    } else if (e2.type == 6) {                                          // nucleotide/R over O, M:6611-6633, 6744-6761
+        int i1 = (e1.type == 4) ? e2.ref : e1.type;
+        double p = sel4(e2.v, i1);
+        if (p > 0.02) f = p;
+        else if (e1.hasD1) {
+            double t2[4], t3[4];
+            gpv_vec(c, r, e2.v, cl, false, t3);
+            gpv_nuc<CT, U>(c, r, i1, e1.d0, c.err(site), false, flag1, t2);
+            double tot = 0.0;
+            if (e1.type == 4) { for (int i = 0; i < 4; i++) tot += t3[i] * t2[i] * rf[i]; }
+            else { for (int i = 0; i < 4; i++) tot += t2[i] * t3[i] * rf[i]; }
+            f = tot / rf[i1];
+        } else if (cl != 0.0) {
+            double t3[4];
+            gpv_vec(c, r, e2.v, cl, false, t3);
+            f = sel4(t3, i1);
+        } else f = p;
+    } else {                                                            // two nucleotides, observation beyond the root on the
+        int i1 = (e1.type == 4) ? e2.ref : e1.type;                     // parent side (M:6644-6654, 6726-6733)
+        int i2 = (e2.type == 4) ? e1.ref : e2.type;
+        double t2[4], t3[4];
+        double er = c.err(site);
+        gpv_nuc<CT, U>(c, r, i2, cl, er, false, flag2, t3);
+        gpv_nuc<CT, U>(c, r, i1, e1.d0, er, false, flag1, t2);
+        double tot = 0.0;
+        if (e1.type == 4) { for (int i = 0; i < 4; i++) tot += t3[i] * t2[i] * rf[i]; }
+        else { for (int j = 0; j < 4; j++) tot += rf[j] * t3[j] * t2[j]; }
+        f = tot / rf[i1];
+    }
+    return f;
+}
+
+// PairWalk of genome_dev.h over accessors: P = parent (candidate) list, C = child (query) list
+template <bool RV, bool U, bool SS, class PM, class CM>
+__device__ __forceinline__ double append_walk_m(const Ctx<RV, U, SS> &c, const PM &P, const CM &C, bool isTipC, double bLen)
+{
+    const int lRef = c.m.lRef;
+    const double carry = c.m.minimumCarryOver;
+    unsigned long long wa = P.word(0), wb = C.word(0);
+    int ia = 0, ib = 0;
+    double tf = 1.0;
+    double Lk = bLen * c.m.globalTotRate;                               // M:6541
+    if (U && isTipC) Lk += c.m.totError;                                // M:6542-6543
+    double carry1 = 1.0, carry2 = 1.0;
+    int nCarry = 0;
+    constexpr unsigned long long WORK = work_table();
+    for (;;) {
+        const int pa = (int)(uint32_t)wa, pb = (int)(uint32_t)wb;
+        const uint32_t m1 = (uint32_t)(wa >> 32), m2 = (uint32_t)(wb >> 32);
+        const int t1 = m1 & 7u, t2 = m2 & 7u;
+        const int pos = min(pa, pb);
+        if ((WORK >> (t1 * 8 + t2)) & 1ull) {
+            const int site = pos - 1;
+            bool dead = false;
+            if (t1 == 6 || t2 == 6 || (m1 & (1u << 6))) {               // O vector or observation beyond the root
+                EntV e1, e2;
+                decode_v(wa, P, e1);
+                decode_v(wb, C, e2);
+                tf *= site_factor_v(c, e1, e2, site, isTipC, bLen);
+            } else {                                                     // two different nucleotides (R = the reference one)
+                double cl = bLen;                                        // M:6640-6668, 6713-6742
+                if (m1 & (1u << 5)) cl += P.aux(m1 >> 8);
+                if ((m2 & (1u << 5)) && !(m2 & (1u << 6))) cl += C.aux(m2 >> 8);
+                const int i1 = (t1 == 4) ? (int)((m2 >> 3) & 3u) : t1;
+                const int i2 = (t2 == 4) ? (int)((m1 >> 3) & 3u) : t2;
+                const double qv = c.q(c.rate(site), i1, i2);
+                double f = fmin_py(0.25, qv * cl);
+                if (U) {
+                    const bool flag1 = (t1 != 4) && (m1 & (1u << 5)) && (m1 & (1u << 7));
+                    const bool flag2 = isTipC || ((m2 & (1u << 5)) && (m2 & (1u << 7)));
+                    if (t1 == 4) { if (flag2) f += c.err(site) * 0.33333; else if (cl == 0.0) dead = true; }
+                    else if (flag1 || flag2) f += (double)((int)flag1 + (int)flag2) * 0.33333 * c.err(site);
+                    else if (cl == 0.0) dead = true;
+                } else if (cl == 0.0) dead = true;                       // zero-length mismatch: -inf (M:6663, 6742)
+                tf *= f;
+            }
+            if (dead) return -INFINITY;
+            if (tf <= carry) {                                           // M:6772-6783
+                if (tf < 2.2250738585072014e-308) return -INFINITY;
+                if (nCarry == 2) { Lk += log(carry1); carry1 = carry2; nCarry = 1; }
+                if (nCarry == 0) carry1 = tf; else carry2 = tf;
+                ++nCarry;
+                tf = 1.0;
+            }
+        }
+        if (pos == lRef) break;
+#ifdef MAPLE_WALK_BRANCHFREE
+        // both cursors reloaded every step (a list always ends at lRef, so the index never runs past its last entry): two
+        // reads that are cheap when the lists sit in LDS, instead of two exec-mask branches on the scalar unit
+        ia += (pa == pos) ? 1 : 0;
+        ib += (pb == pos) ? 1 : 0;
+        wa = P.word(ia);
+        wb = C.word(ib);
+#else
+        if (pa == pos) { ++ia; wa = P.word(ia); }
+        if (pb == pos) { ++ib; wb = C.word(ib); }
+#endif
+    }
+    double lk = Lk;
+    if (nCarry >= 1) lk += log(carry1);
+    if (nCarry >= 2) lk += log(carry2);
+    return (tf > 0.0) ? lk + log(tf) : -INFINITY;
+}
+
+}  // namespace maple

@@ -44,16 +44,23 @@ __device__ inline void stage_model(const DevModel &m, Lds &s)
     __syncthreads();
 }
 
+typedef __attribute__((address_space(1))) const double *glb_f64p;
 template <bool RV, bool U, bool SS> struct Ctx {
     const DevModel &m;
     const double *Q;                   // LDS
     const double *rf;                  // LDS
-    __device__ Ctx(const DevModel &m_, const Lds &s) : m(m_), Q(s.Q), rf(s.rf) {}
+    // The per-site tables are gathered at every site that needs work.  Their base pointers are read from the model ONCE,
+    // here: through `m` each gather was a scalar load of the pointer, a wait, and then a flat load of the value -- two
+    // dependent memory latencies in the middle of a lane's walk.  (Address space 1: a global_load, not a flat one.)
+    glb_f64p sr, er;
+    double errorRate;
+    __device__ Ctx(const DevModel &m_, const Lds &s)
+        : m(m_), Q(s.Q), rf(s.rf), sr((glb_f64p)m_.siteRates), er((glb_f64p)m_.errorRates), errorRate(m_.errorRate) {}
     // site rate multiplier of mutMatrices[pos] = Q * siteRates[pos]  (M:6361-6366)
-    __device__ inline double rate(int pos) const { return RV ? m.siteRates[pos] : 1.0; }
+    __device__ inline double rate(int pos) const { return RV ? sr[pos] : 1.0; }
     __device__ inline double q(double r, int i, int j) const { return RV ? Q[i * 4 + j] * r : Q[i * 4 + j]; }
     // errorRate resolved like "if usingErrorRate and errorRateSiteSpecific: errorRate=errorRates[pos]"
-    __device__ inline double err(int pos) const { return (U && SS) ? m.errorRates[pos] : m.errorRate; }
+    __device__ inline double err(int pos) const { return (U && SS) ? er[pos] : errorRate; }
 };
 
 // ---- packed lists -----------------------------------------------------------------

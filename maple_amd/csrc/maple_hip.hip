@@ -4,6 +4,7 @@
 #include "genome_dev.h"
 #include "search_dev.h"
 #include "placement_dev.h"
+#include "append_lds.h"
 
 #include <algorithm>
 #include <chrono>
@@ -297,6 +298,128 @@ __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ 
             tbScore = -INFINITY; tbRank = 0x7fffffff; tbIdx = -1;
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+
+// The same Q x C scoring with the tile's 64 candidate lists staged in LDS (append_lds.h): a workgroup of 8 wavefronts takes
+// a unit = (chunk of 64 candidates, block of MAPLE_LDS_QB queries), copies the chunk's words and aux doubles into LDS with
+// coalesced loads, and its wavefronts then pull the block's queries from an LDS counter: one query x the 64 staged
+// candidates per tile, candidate words / stored lengths / O vectors and the query's words all read with ds_read.  Chunks
+// too long for the LDS budget, and queries longer than the strip, are walked from global memory as before.
+#ifndef MAPLE_LDS_BLOCK
+#define MAPLE_LDS_BLOCK 512            // 8 wavefronts share a staged chunk; 2 workgroups per CU
+#endif
+#ifndef MAPLE_LDS_WAVES
+#define MAPLE_LDS_WAVES 4
+#endif
+#define MAPLE_LDS_CAPW 4096            // candidate words per staged chunk (32 KB)
+#define MAPLE_LDS_CAPA 1536            // candidate aux doubles per staged chunk (12 KB)
+#ifndef MAPLE_LDS_QB
+#define MAPLE_LDS_QB 512            // queries per unit: 128 / 256 / 512 measured 549 / 544 / 538 ms per launch at 100k tips
+#endif
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(MAPLE_LDS_BLOCK) __attribute__((amdgpu_waves_per_eu(MAPLE_LDS_WAVES, MAPLE_LDS_WAVES)))
+void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ, const int32_t *qList, int nC, const int32_t *cand,
+                          int isTip, double bLen, double *out, long long ldOut, const int32_t *outCol, const uint8_t *qTip,
+                          const double *qBLen, int *counter, TileBest *tileBest, const int32_t *visitRank)
+{
+    __shared__ Lds lds;
+    __shared__ unsigned long long cW[MAPLE_LDS_CAPW];
+    __shared__ double cA[MAPLE_LDS_CAPA];
+    __shared__ int cwoff[65], caoff[65];
+    __shared__ unsigned long long qstrip[MAPLE_LDS_BLOCK / 64][MAPLE_QLDS];
+    __shared__ int sUnit, sNext, sStaged;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nChunks = (nC + 63) / 64, nQB = (nQ + MAPLE_LDS_QB - 1) / MAPLE_LDS_QB;
+    const long long units = (long long)nChunks * nQB;
+    unsigned long long *myq = qstrip[wave];
+    double tbScore = -INFINITY;
+    int tbRank = 0x7fffffff, tbIdx = -1;
+    for (;;) {
+        if (tid == 0) sUnit = atomicAdd(counter, 1);
+        __syncthreads();
+        const int unit = sUnit;
+        if (unit >= units) break;
+        const int ch = unit / nQB, qb = unit - ch * nQB;
+        // this lane's candidate and where its list sits in the staged chunk
+        const int k = ch * 64 + lane;
+        const int cl = k < nC ? cand[k] : -1;
+        if (wave == 0) {
+            int ne = cl >= 0 ? av.n_ent[cl] : 0, na = cl >= 0 ? av.n_aux[cl] : 0;
+            int pw = ne, pa = na;                                          // inclusive prefix sums over the 64 lists
+            for (int d = 1; d < 64; d <<= 1) {
+                const int ow = __shfl_up(pw, d, 64), oa = __shfl_up(pa, d, 64);
+                if (lane >= d) { pw += ow; pa += oa; }
+            }
+            cwoff[lane] = pw - ne; caoff[lane] = pa - na;
+            if (lane == 63) { cwoff[64] = pw; caoff[64] = pa; sStaged = (pw <= MAPLE_LDS_CAPW && pa <= MAPLE_LDS_CAPA) ? 1 : 0; sNext = 0; }
+        }
+        __syncthreads();
+        const bool stagedC = sStaged != 0;
+        if (stagedC) {                                                     // 8 lists per wavefront, coalesced within a list
+            constexpr int perWave = (64 + MAPLE_LDS_BLOCK / 64 - 1) / (MAPLE_LDS_BLOCK / 64);
+            for (int i = wave * perWave; i < min(64, wave * perWave + perWave); i++) {
+                const int kk = ch * 64 + i;
+                if (kk >= nC) break;
+                const int li = cand[kk];
+                const unsigned long long *sw = (const unsigned long long *)(av.words + av.ent_off[li]);
+                const double *sa = av.aux + av.aux_off[li];
+                const int w0 = cwoff[i], nw = cwoff[i + 1] - w0, a0 = caoff[i], na2 = caoff[i + 1] - a0;
+                for (int j = lane; j < nw; j += 64) cW[w0 + j] = sw[j];
+                for (int j = lane; j < na2; j += 64) cA[a0 + j] = sa[j];
+            }
+        }
+        __syncthreads();
+        const int myW = cwoff[lane], myA = caoff[lane];
+        for (;;) {
+            int qi = 0;
+            if (lane == 0) qi = atomicAdd(&sNext, 1);
+            qi = __builtin_amdgcn_readfirstlane(qi);
+            const int q = qb * MAPLE_LDS_QB + qi;
+            if (qi >= MAPLE_LDS_QB || q >= nQ) break;
+            const int ql = qList[q];
+            const int nq = av.n_ent[ql];
+            const ListRef qref = list_ref(av, ql);
+            const bool stagedQ = nq <= MAPLE_QLDS;                          // wave-uniform
+            if (stagedQ) {
+                for (int i = lane; i < nq; i += 64) myq[i] = ((const unsigned long long *)qref.w)[i];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            if (cl >= 0) {
+                const bool tipq = qTip ? qTip[q] != 0 : isTip != 0;
+                const double blq = qBLen ? qBLen[q] : bLen;
+                const MemLG qL{(lds_u64p)myq, qref.aux};
+                const MemG qG{(const unsigned long long *)qref.w, qref.aux};
+                double lk;
+                if (stagedC) {
+                    const MemL pL{(lds_u64p)(cW + myW), (lds_f64p)(cA + myA)};
+                    lk = stagedQ ? append_walk_m(c, pL, qL, tipq, blq) : append_walk_m(c, pL, qG, tipq, blq);
+                } else {
+                    const ListRef pr = list_ref(av, cl);
+                    const MemG pG{(const unsigned long long *)pr.w, pr.aux};
+                    lk = stagedQ ? append_walk_m(c, pG, qL, tipq, blq) : append_walk_m(c, pG, qG, tipq, blq);
+                }
+                if (!tileBest) out[(long long)q * ldOut + (outCol ? outCol[k] : k)] = lk;
+                else { tbScore = lk; tbRank = visitRank ? visitRank[k] : k; tbIdx = k; }
+            }
+            if (tileBest) {
+                for (int m2 = 32; m2 >= 1; m2 >>= 1) {
+                    const double os = __shfl_xor(tbScore, m2, 64);
+                    const int orank = __shfl_xor(tbRank, m2, 64), oidx = __shfl_xor(tbIdx, m2, 64);
+                    if (os > tbScore || (os == tbScore && orank < tbRank)) { tbScore = os; tbRank = orank; tbIdx = oidx; }
+                }
+                if (lane == 0) tileBest[(long long)q * nChunks + ch] = TileBest{tbScore, tbRank, tbIdx};
+                tbScore = -INFINITY; tbRank = 0x7fffffff; tbIdx = -1;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();                                                   // nobody may still read the chunk when it is restaged
     }
 }
 
@@ -1613,6 +1736,14 @@ static int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int3
     hipEvent_t e0, e1;
     TRY(ev_pair(c, &e0, &e1, kind, (double)nQ * (double)nC, algBytes));
     HIPCK(c, hipEventRecord(e0, s));
+    static const bool noLds = getenv("MAPLE_APPEND_GLOBAL") != nullptr;
+    if (nQ >= 32 && !noLds) {
+        // enough queries to reuse a staged candidate chunk: the LDS kernel, 2 workgroups of 8 wavefronts per CU
+        const long long units = (long long)((nC + 63) / 64) * ((nQ + MAPLE_LDS_QB - 1) / MAPLE_LDS_QB);
+        const int gridL = units < 512 ? (int)units : 512;
+        DISPATCH3(c, k_append_queries_lds, <<<gridL, MAPLE_LDS_BLOCK, 0, s>>>(c->d_model, view(c), nQ, qList, nC, cand, isTip, bLen, out,
+                                                                            ldOut, outCol, qTip, qBLen, counter, tileBest, visitRank));
+    } else
     DISPATCH3(c, k_append_queries, <<<grid, MAPLE_BLOCK, 0, s>>>(c->d_model, view(c), nQ, qList, nC, cand, isTip, bLen, out, ldOut,
                                                                   outCol, qTip, qBLen, counter, tileBest, visitRank));
     HIPCK(c, hipGetLastError());

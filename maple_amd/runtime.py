@@ -59,7 +59,8 @@ def load_library():
     """Load libmaple_hip.so; raises if it has not been built (see __graft_entry__.build)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        lib_path = os.environ.get("MAPLE_HIP_LIB", LIB_PATH)         # (kernel-variant experiments: another build of the library)
+        if not os.path.exists(lib_path):
             raise MapleError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`; "
                              "there is no CPU fallback for the placement path")
         # PyTorch-ROCm ships its own HIP runtime; whichever copy of libamdhip64 is loaded first serves the whole
@@ -68,7 +69,7 @@ def load_library():
             import torch  # noqa: F401
         except ImportError:
             pass
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(lib_path)
         lib.maple_last_error.restype = C.c_char_p
         for name in EXPORTS:
             getattr(lib, name)       # fail early if a declared symbol is not exported
