@@ -16,23 +16,31 @@ namespace maple {
 typedef __attribute__((address_space(3))) const unsigned long long *lds_u64p;
 typedef __attribute__((address_space(3))) const double *lds_f64p;
 
+// rate(i, site, c): the per-site rate multiplier at the site entry i ends on (a site that needs work is always the last
+// -- the only -- site of a single-site entry of one of the two lists).  Staged lists carry it next to their words, gathered
+// once at staging time: in the walk the gather from the 240 KB siteRates table was the longest wait of a step.
 struct MemG {                          // words and aux doubles in global memory (or anywhere, through generic pointers)
     const unsigned long long *w;
     const double *a;
     __device__ __forceinline__ unsigned long long word(int i) const { return w[i]; }
     __device__ __forceinline__ double aux(uint32_t off) const { return a[off]; }
+    template <class C> __device__ __forceinline__ double rate(int, int site, const C &c) const { return c.rate(site); }
 };
-struct MemL {                          // both in LDS
+struct MemL {                          // words, aux doubles and per-entry site rates in LDS
     lds_u64p w;
     lds_f64p a;
+    lds_f64p r;
     __device__ __forceinline__ unsigned long long word(int i) const { return w[i]; }
     __device__ __forceinline__ double aux(uint32_t off) const { return a[off]; }
+    template <class C> __device__ __forceinline__ double rate(int i, int, const C &) const { return r[i]; }
 };
-struct MemLG {                         // words in LDS, aux doubles in global memory (the staged query list)
+struct MemLG {                         // words and site rates in LDS, aux doubles in global memory (the staged query list)
     lds_u64p w;
     const double *a;
+    lds_f64p r;
     __device__ __forceinline__ unsigned long long word(int i) const { return w[i]; }
     __device__ __forceinline__ double aux(uint32_t off) const { return a[off]; }
+    template <class C> __device__ __forceinline__ double rate(int i, int, const C &) const { return r[i]; }
 };
 
 struct EntV {                          // a decoded entry with its payload in registers
@@ -60,7 +68,8 @@ template <class M> __device__ __forceinline__ void decode_v(unsigned long long w
 
 // site_factor of genome_dev.h on register-resident entries (M:6611-6761)
 template <bool RV, bool U, bool SS>
-__device__ __forceinline__ double site_factor_v(const Ctx<RV, U, SS> &c, const EntV &e1, const EntV &e2, int site, bool isTipC, double bLen)
+__device__ __forceinline__ double site_factor_v(const Ctx<RV, U, SS> &c, const EntV &e1, const EntV &e2, int site, double r,
+                                                bool isTipC, double bLen)
 {
     typedef Ctx<RV, U, SS> CT;
     const double *rf = c.rf;
@@ -69,7 +78,6 @@ __device__ __forceinline__ double site_factor_v(const Ctx<RV, U, SS> &c, const E
     else if (e1.hasD0) cl += e1.d0;
     if (e2.type < 5) { if (e2.hasD0 && !e2.hasD1) cl += e2.d0; }
     else if (e2.hasD0) cl += e2.d0;
-    const double r = c.rate(site);
     const bool flag1 = U && e1.type < 5 && e1.hasD0 && e1.flag;
     const bool flag2 = U && e2.type < 5 && (isTipC || (e2.hasD0 && e2.flag));
     double f;
@@ -144,18 +152,19 @@ __device__ __forceinline__ double append_walk_m(const Ctx<RV, U, SS> &c, const P
         if ((WORK >> (t1 * 8 + t2)) & 1ull) {
             const int site = pos - 1;
             bool dead = false;
+            const double r = RV ? ((pa == pos) ? P.rate(ia, site, c) : C.rate(ib, site, c)) : 1.0;
             if (t1 == 6 || t2 == 6 || (m1 & (1u << 6))) {               // O vector or observation beyond the root
                 EntV e1, e2;
                 decode_v(wa, P, e1);
                 decode_v(wb, C, e2);
-                tf *= site_factor_v(c, e1, e2, site, isTipC, bLen);
+                tf *= site_factor_v(c, e1, e2, site, r, isTipC, bLen);
             } else {                                                     // two different nucleotides (R = the reference one)
                 double cl = bLen;                                        // M:6640-6668, 6713-6742
                 if (m1 & (1u << 5)) cl += P.aux(m1 >> 8);
                 if ((m2 & (1u << 5)) && !(m2 & (1u << 6))) cl += C.aux(m2 >> 8);
                 const int i1 = (t1 == 4) ? (int)((m2 >> 3) & 3u) : t1;
                 const int i2 = (t2 == 4) ? (int)((m1 >> 3) & 3u) : t2;
-                const double qv = c.q(c.rate(site), i1, i2);
+                const double qv = c.q(r, i1, i2);
                 double f = fmin_py(0.25, qv * cl);
                 if (U) {
                     const bool flag1 = (t1 != 4) && (m1 & (1u << 5)) && (m1 & (1u << 7));

@@ -302,41 +302,43 @@ __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ 
 }
 
 
-// The same Q x C scoring with the tile's 64 candidate lists staged in LDS (append_lds.h): a workgroup of 8 wavefronts takes
-// a unit = (chunk of 64 candidates, block of MAPLE_LDS_QB queries), copies the chunk's words and aux doubles into LDS with
-// coalesced loads, and its wavefronts then pull the block's queries from an LDS counter: one query x the 64 staged
-// candidates per tile, candidate words / stored lengths / O vectors and the query's words all read with ds_read.  Chunks
-// too long for the LDS budget, and queries longer than the strip, are walked from global memory as before.
-#ifndef MAPLE_LDS_BLOCK
-#define MAPLE_LDS_BLOCK 512            // 8 wavefronts share a staged chunk; 2 workgroups per CU
-#endif
-#ifndef MAPLE_LDS_WAVES
-#define MAPLE_LDS_WAVES 4
-#endif
-#define MAPLE_LDS_CAPW 4096            // candidate words per staged chunk (32 KB)
+// The same Q x C scoring with the tile's 64 candidate lists staged in LDS (append_lds.h): a workgroup of 16 wavefronts (one
+// per CU) takes a unit = (chunk of 64 candidates, block of MAPLE_LDS_QB queries), copies the chunk's words and aux doubles into
+// LDS with coalesced loads -- and, with per-site rates, the rate of every entry's last site next to it -- and its
+// wavefronts then pull the block's queries from an LDS counter: one query x the 64 staged candidates per tile, candidate
+// words / stored lengths / O vectors / site rates and the query's words and rates all read with ds_read.  Chunks too long for
+// the LDS budget, and queries longer than the strip, are walked from global memory as before.
+#define MAPLE_LDS_BLOCK 1024
+#define MAPLE_LDS_CAPW 4096            // candidate words per staged chunk (32 KB, + 32 KB of site rates with rate variation)
 #define MAPLE_LDS_CAPA 1536            // candidate aux doubles per staged chunk (12 KB)
 #ifndef MAPLE_LDS_QB
-#define MAPLE_LDS_QB 512            // queries per unit: 128 / 256 / 512 measured 549 / 544 / 538 ms per launch at 100k tips
+#define MAPLE_LDS_QB 512               // queries per unit: 128 / 256 / 512 measured 549 / 544 / 538 ms per launch at 100k tips
 #endif
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(MAPLE_LDS_BLOCK) __attribute__((amdgpu_waves_per_eu(MAPLE_LDS_WAVES, MAPLE_LDS_WAVES)))
+__global__ __launch_bounds__(MAPLE_LDS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ, const int32_t *qList, int nC, const int32_t *cand,
                           int isTip, double bLen, double *out, long long ldOut, const int32_t *outCol, const uint8_t *qTip,
                           const double *qBLen, int *counter, TileBest *tileBest, const int32_t *visitRank)
 {
+    constexpr int NW = MAPLE_LDS_BLOCK / 64;
     __shared__ Lds lds;
-    __shared__ unsigned long long cW[MAPLE_LDS_CAPW];
-    __shared__ double cA[MAPLE_LDS_CAPA];
     __shared__ int cwoff[65], caoff[65];
-    __shared__ unsigned long long qstrip[MAPLE_LDS_BLOCK / 64][MAPLE_QLDS];
     __shared__ int sUnit, sNext, sStaged;
+    extern __shared__ unsigned long long dynU64[];
+    // dynamic LDS: candidate words | candidate aux | [candidate rates] | per-wavefront query words | [per-wavefront query rates]
+    unsigned long long *cW = dynU64;
+    double *cA = (double *)(cW + MAPLE_LDS_CAPW);
+    double *cR = cA + MAPLE_LDS_CAPA;
+    unsigned long long *qW = (unsigned long long *)(cR + (RV ? MAPLE_LDS_CAPW : 0));
+    double *qR = (double *)(qW + NW * MAPLE_QLDS);
     const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nChunks = (nC + 63) / 64, nQB = (nQ + MAPLE_LDS_QB - 1) / MAPLE_LDS_QB;
     const long long units = (long long)nChunks * nQB;
-    unsigned long long *myq = qstrip[wave];
+    unsigned long long *myq = qW + wave * MAPLE_QLDS;
+    double *myqR = qR + wave * MAPLE_QLDS;
     double tbScore = -INFINITY;
     int tbRank = 0x7fffffff, tbIdx = -1;
     for (;;) {
@@ -360,8 +362,8 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
         }
         __syncthreads();
         const bool stagedC = sStaged != 0;
-        if (stagedC) {                                                     // 8 lists per wavefront, coalesced within a list
-            constexpr int perWave = (64 + MAPLE_LDS_BLOCK / 64 - 1) / (MAPLE_LDS_BLOCK / 64);
+        if (stagedC) {                                                     // 4 lists per wavefront, coalesced within a list
+            constexpr int perWave = (64 + NW - 1) / NW;
             for (int i = wave * perWave; i < min(64, wave * perWave + perWave); i++) {
                 const int kk = ch * 64 + i;
                 if (kk >= nC) break;
@@ -369,7 +371,11 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
                 const unsigned long long *sw = (const unsigned long long *)(av.words + av.ent_off[li]);
                 const double *sa = av.aux + av.aux_off[li];
                 const int w0 = cwoff[i], nw = cwoff[i + 1] - w0, a0 = caoff[i], na2 = caoff[i + 1] - a0;
-                for (int j = lane; j < nw; j += 64) cW[w0 + j] = sw[j];
+                for (int j = lane; j < nw; j += 64) {
+                    const unsigned long long w = sw[j];
+                    cW[w0 + j] = w;
+                    if (RV) cR[w0 + j] = c.rate((int)(uint32_t)w - 1);
+                }
                 for (int j = lane; j < na2; j += 64) cA[a0 + j] = sa[j];
             }
         }
@@ -386,7 +392,11 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
             const ListRef qref = list_ref(av, ql);
             const bool stagedQ = nq <= MAPLE_QLDS;                          // wave-uniform
             if (stagedQ) {
-                for (int i = lane; i < nq; i += 64) myq[i] = ((const unsigned long long *)qref.w)[i];
+                for (int i = lane; i < nq; i += 64) {
+                    const unsigned long long w = ((const unsigned long long *)qref.w)[i];
+                    myq[i] = w;
+                    if (RV) myqR[i] = c.rate((int)(uint32_t)w - 1);
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -394,11 +404,11 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
             if (cl >= 0) {
                 const bool tipq = qTip ? qTip[q] != 0 : isTip != 0;
                 const double blq = qBLen ? qBLen[q] : bLen;
-                const MemLG qL{(lds_u64p)myq, qref.aux};
+                const MemLG qL{(lds_u64p)myq, qref.aux, (lds_f64p)myqR};
                 const MemG qG{(const unsigned long long *)qref.w, qref.aux};
                 double lk;
                 if (stagedC) {
-                    const MemL pL{(lds_u64p)(cW + myW), (lds_f64p)(cA + myA)};
+                    const MemL pL{(lds_u64p)(cW + myW), (lds_f64p)(cA + myA), (lds_f64p)(cR + myW)};
                     lk = stagedQ ? append_walk_m(c, pL, qL, tipq, blq) : append_walk_m(c, pL, qG, tipq, blq);
                 } else {
                     const ListRef pr = list_ref(av, cl);
@@ -421,6 +431,12 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
         }
         __syncthreads();                                                   // nobody may still read the chunk when it is restaged
     }
+}
+template <bool RV> static size_t lds_kernel_dyn_bytes()
+{
+    constexpr int NW = MAPLE_LDS_BLOCK / 64;
+    return (size_t)MAPLE_LDS_CAPW * 8 + (size_t)MAPLE_LDS_CAPA * 8 + (RV ? (size_t)MAPLE_LDS_CAPW * 8 : 0)
+           + (size_t)NW * MAPLE_QLDS * 8 * (RV ? 2 : 1);
 }
 
 // per query: the best of its tiles (same order: score, then earliest visit)
@@ -1738,11 +1754,22 @@ static int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int3
     HIPCK(c, hipEventRecord(e0, s));
     static const bool noLds = getenv("MAPLE_APPEND_GLOBAL") != nullptr;
     if (nQ >= 32 && !noLds) {
-        // enough queries to reuse a staged candidate chunk: the LDS kernel, 2 workgroups of 8 wavefronts per CU
+        // enough queries to reuse a staged candidate chunk: the LDS kernel, one workgroup of 16 wavefronts per CU
         const long long units = (long long)((nC + 63) / 64) * ((nQ + MAPLE_LDS_QB - 1) / MAPLE_LDS_QB);
-        const int gridL = units < 512 ? (int)units : 512;
-        DISPATCH3(c, k_append_queries_lds, <<<gridL, MAPLE_LDS_BLOCK, 0, s>>>(c->d_model, view(c), nQ, qList, nC, cand, isTip, bLen, out,
-                                                                            ldOut, outCol, qTip, qBLen, counter, tileBest, visitRank));
+        const int gridL = units < 256 ? (int)units : 256;
+        const bool rv_ = c->dm.useRateVariation;
+        const size_t dyn = rv_ ? lds_kernel_dyn_bytes<true>() : lds_kernel_dyn_bytes<false>();
+        static bool attrSet = false;
+        if (!attrSet) {                                                // more than 64 KB of LDS per workgroup has to be asked for
+#define MAPLE_SET_LDS(RV_, U_, SS_) HIPCK(c, hipFuncSetAttribute((const void *)k_append_queries_lds<RV_, U_, SS_>, \
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kernel_dyn_bytes<RV_>()))
+            MAPLE_SET_LDS(false, false, false); MAPLE_SET_LDS(true, false, false); MAPLE_SET_LDS(false, true, false);
+            MAPLE_SET_LDS(false, true, true); MAPLE_SET_LDS(true, true, false); MAPLE_SET_LDS(true, true, true);
+#undef MAPLE_SET_LDS
+            attrSet = true;
+        }
+        DISPATCH3(c, k_append_queries_lds, <<<gridL, MAPLE_LDS_BLOCK, dyn, s>>>(c->d_model, view(c), nQ, qList, nC, cand, isTip, bLen, out,
+                                                                              ldOut, outCol, qTip, qBLen, counter, tileBest, visitRank));
     } else
     DISPATCH3(c, k_append_queries, <<<grid, MAPLE_BLOCK, 0, s>>>(c->d_model, view(c), nQ, qList, nC, cand, isTip, bLen, out, ldOut,
                                                                   outCol, qTip, qBLen, counter, tileBest, visitRank));
@@ -2086,6 +2113,9 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     return MAPLE_OK;
 }
 
+#ifndef MAPLE_WIDE_BUDGET_DEFAULT
+#define MAPLE_WIDE_BUDGET_DEFAULT 256
+#endif
 extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *nodes, const maple_search_params *sp,
                                       int32_t ws_entries_per_lane, int32_t *bestNode, double *bestScore, double *blen3,
                                       int32_t *placement, double *improvement, double *currentLK, int32_t *nAppend,
@@ -2173,10 +2203,12 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             const int lanesWanted = (int)(m < maxLanes ? m : maxLanes);
             // searching lanes per wavefront (measured at 20k queries: the long searches of a non-strict round like 2 lanes,
             // 42 vs 46 ms with 1; the short ones of a strict round like 1, 31 vs 37 ms with 2; more is always worse)
-            const int lanesDiv = P.strict ? 32768 : 16384;
+            // (at 200k queries with the budget of a 100 000-tip tree: 2 / 4 / 8 / 13 / 24 lanes -> 825 / 645 / 512 / 424 / 417 ms)
+            const int lanesDiv = P.strict ? 32768 : (lanesWanted > 65536 ? 8192 : 16384);
             int activeLanes = (lanesWanted + lanesDiv - 1) / lanesDiv;
             if (activeLanes < 1) activeLanes = 1;
             if (activeLanes > 64) activeLanes = 64;
+            if (const char *e = getenv("MAPLE_SPR_LANES")) activeLanes = std::max(1, std::min(64, atoi(e)));   // (experiments)
             int nWaves = (lanesWanted + activeLanes - 1) / activeLanes;
             if (nWaves > 8192) nWaves = 8192;
             const int lanes = nWaves * activeLanes;
@@ -2244,7 +2276,12 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // branch is a pure function of (query, branch), so those queries are scored against every branch by the batch
     // kernel (k_append_queries) and the state machine then only replays the traversal over the cached scores.
     // With MAT local references the removed list is first expressed in every reference frame (below).
-    int wideBudget = sp->wideSearchBudget == 0 ? 256 : sp->wideSearchBudget;
+    // A search that scores more branches than the budget is handed to the dense path, which costs it one appendProbNode per
+    // branch of the tree -- so the budget that pays grows with the tree: 1/64 of the scored branches, measured best at 10 000
+    // tips (256: 91 ms per round; 128: 100, 384: 97) and at 100 000 (2 048: 1.08 s; 256: 2.69, 1 024: 1.13, 4 096: 1.20)
+    int wideBudget = sp->wideSearchBudget == 0 ? std::max(MAPLE_WIDE_BUDGET_DEFAULT, std::min(8192, c->n_scored / 64))
+                                               : sp->wideSearchBudget;
+    if (const char *e = getenv("MAPLE_WIDE_BUDGET")) wideBudget = atoi(e);        // (experiments)
     const bool hybrid = wideBudget > 0;
     TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
     if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: budgeted pass done\n", tms(tStart, tnow()));

@@ -657,13 +657,27 @@ __device__ inline void wave_scan_clade(const SScan *__restrict__ SC, const int32
     bool first = true;
     for (int k = lane; k < cap; k += 64) slotOwner[k] = 0u;
     unsigned serial = 1;                                                    // chunk number: slot ownership keys grow with it
+    // the next chunk is nearly always the 64 records that follow: its three loads are issued before the current chunk is
+    // resolved, so that the HBM latency of the score row (read once, never cached) overlaps with the rule evaluation
+    int rAhead = -1;
+    SScan recAhead = head;
+    double scvAhead = 0.0;
+    int prAhead = 0;
     while (r < end) {
         const int n = min(64, end - r);
         const bool valid = lane < n;
         const int idx = valid ? r + lane : end - 1;
-        const SScan rec = SC[idx];
-        const double scv = cs[idx];
-        const int pl = PR[idx] - r;                                         // lane of the parent; < 0: an earlier chunk
+        SScan rec;
+        double scv;
+        int prk;
+        if (r == rAhead) { rec = recAhead; scv = scvAhead; prk = prAhead; }
+        else { rec = SC[idx]; scv = cs[idx]; prk = PR[idx]; }
+        if (r + 64 < end) {
+            rAhead = r + 64;
+            const int idx2 = min(rAhead + lane, end - 1);
+            recAhead = SC[idx2]; scvAhead = cs[idx2]; prAhead = PR[idx2];
+        }
+        const int pl = prk - r;                                             // lane of the parent; < 0: an earlier chunk
         const int d = rec.depth, f = (int)(rec.ff >> 4);
         const uint32_t fl = rec.ff & 15u;
         const bool isFirst = first && lane == 0;
