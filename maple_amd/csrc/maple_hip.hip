@@ -2257,6 +2257,21 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             HIPCK(c, hipMemcpyAsync(part.data(), dout, (size_t)m * sizeof(SearchOut), hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
             std::vector<int32_t> todo2, slot2, rows2;
+            {   // what this launch did, for maple_timing_read_kind: candidate placements it scored itself (lane searches that
+                // finished: each reads a candidate list and writes a score, SURVEY 8d, plus its removed list once) or replayed
+                // from the score table (8 bytes each)
+                const double meanCand = c->n_scored ? c->scored_bytes_total / c->n_scored : 0.0;
+                double units = 0.0, bytes = 0.0;
+                for (int k = 0; k < m; k++) {
+                    if (part[k].status != 0 && part[k].status != -1) continue;
+                    units += part[k].nAppend;
+                    const int32_t l = c->h_tree_lower[todo[k]];
+                    const double qb = l >= 0 ? 8.0 * c->h_n_ent[l] + 8.0 * c->h_n_aux[l] : 0.0;
+                    bytes += cacheS ? 8.0 * part[k].nAppend + qb : meanCand * part[k].nAppend + qb;
+                }
+                const size_t slotEv = c->ev_used / 2 - 1;
+                c->ev_units[slotEv] = units; c->ev_bytes[slotEv] = bytes;
+            }
             for (int k = 0; k < m; k++) {
                 ho[slot[k]] = part[k];
                 if (part[k].status == -3 && attempt < 2) {

@@ -90,31 +90,39 @@ if wcal:
 if calib:
     lines.append(f"\nFETCH_SIZE calibration for this library's access pattern (k_calib_walk: 2 GiB read by dependent 8-byte "
                  f"per-lane walks): the counter reports {calib:.4f} of the bytes read.\n")
-# the scoring kernel: per pair numbers + the json bench.py reads
-sk = next((k for k in agg if "k_append_queries" in k), None)
-if sk and bench:
-    d = agg[sk]
-    pairs = bench["roofline"]["pairs_per_launch"]
-    alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+# per kernel: HBM-side traffic per launch (calibrated), and for the scoring kernel the per-pair instruction counts
+traffic = {}
+for key in ("k_append_queries_lds", "k_append_queries", "k_spr_search"):
+    k = next((x for x in agg if x.startswith(key + "<") or x == key), None)
+    if not k:
+        continue
+    d = agg[k]
     fetch_b = avg(d, "FETCH_SIZE") * 1024 / (calib or 1.0)
     write_b = avg(d, "WRITE_SIZE") * 1024 / (wcal.get("stream") or 1.0)      # HBM-side bytes (partial-line stores included)
-    traffic = fetch_b + write_b
-    lines.append(f"\n## `k_append_queries` inside the search, per (query, branch) pair\n\n"
-                 f"* pairs per launch (bench run) {pairs:.4g}, algorithmic bytes per launch {alg:.4g} ({alg/pairs:.0f} B / pair)\n"
-                 f"* HBM traffic per launch: FETCH {fetch_b/1e9:.2f} GB (calibrated) + WRITE {write_b/1e9:.2f} GB = "
-                 f"{traffic/1e9:.2f} GB = {traffic/alg:.3f} of the algorithmic bytes\n"
-                 f"* wave-instructions per 64 pairs: VALU {avg(d,'SQ_INSTS_VALU')/pairs*64:.0f}, SALU {avg(d,'SQ_INSTS_SALU')/pairs*64:.0f}, "
-                 f"VMEM_RD {avg(d,'SQ_INSTS_VMEM_RD')/pairs*64:.0f}, LDS {avg(d,'SQ_INSTS_LDS')/pairs*64:.0f}, "
-                 f"BRANCH {avg(d,'SQ_INSTS_BRANCH')/pairs*64:.0f}\n"
-                 f"* wave cycles: waiting {avg(d,'SQ_WAIT_ANY')/avg(d,'SQ_WAVE_CYCLES'):.2f} of a wave's life, VALU active "
-                 f"{avg(d,'SQ_ACTIVE_INST_VALU')/avg(d,'SQ_WAVE_CYCLES'):.2f}\n")
+    traffic[key] = fetch_b + write_b
+    lines.append(f"\n* `{key}`: HBM traffic per launch FETCH {fetch_b/1e9:.2f} GB (calibrated) + WRITE {write_b/1e9:.2f} GB = "
+                 f"{traffic[key]/1e9:.2f} GB\n")
+if bench:
+    roofs = [bench.get("roofline"), bench.get("roofline_second_kernel")]
+    sc = next((r for r in roofs if r and r["kernel"].startswith("k_append")), None)
+    sk = next((k for k in agg if "k_append_queries" in k), None)
+    if sc and sk:
+        d = agg[sk]
+        pairs, alg = sc["units_per_launch"], sc["algorithmic_bytes_per_launch"]
+        t = traffic.get("k_append_queries_lds") or traffic.get("k_append_queries") or float("nan")
+        lines.append(f"\n## the dense scoring kernel inside the search, per (query, branch) pair\n\n"
+                     f"* pairs per launch (bench run) {pairs:.4g}, algorithmic bytes per launch {alg:.4g} ({alg/pairs:.0f} B / pair); "
+                     f"HBM traffic per launch {t/1e9:.2f} GB = {t/alg:.3f} of the algorithmic bytes\n"
+                     f"* wave-instructions per 64 pairs: VALU {avg(d,'SQ_INSTS_VALU')/pairs*64:.0f}, SALU {avg(d,'SQ_INSTS_SALU')/pairs*64:.0f}, "
+                     f"VMEM_RD {avg(d,'SQ_INSTS_VMEM_RD')/pairs*64:.0f}, LDS {avg(d,'SQ_INSTS_LDS')/pairs*64:.0f}, "
+                     f"BRANCH {avg(d,'SQ_INSTS_BRANCH')/pairs*64:.0f}\n"
+                     f"* wave cycles: waiting {avg(d,'SQ_WAIT_ANY')/avg(d,'SQ_WAVE_CYCLES'):.2f} of a wave's life, issue-stalled "
+                     f"{avg(d,'SQ_WAIT_INST_ANY')/avg(d,'SQ_WAVE_CYCLES'):.2f}, VALU active {avg(d,'SQ_ACTIVE_INST_VALU')/avg(d,'SQ_WAVE_CYCLES'):.2f}\n")
     w = bench["config"]
-    pj = {"kernel": "k_append_queries (dense scoring inside maple_spr_search_batch)", "fetch_size_kb": avg(d, "FETCH_SIZE"),
-          "write_size_kb": avg(d, "WRITE_SIZE"), "calibration_counted_over_read": calib,
-          "traffic_bytes_per_launch": traffic, "pairs_per_launch_profiled_run": pairs,
+    pj = {"traffic_bytes_per_launch": traffic, "calibration": {"fetch_counted_over_read": calib, "write": wcal},
           "workload": {"samples": w["samples"], "model": w["model"], "batch": w["searches_per_step"], "n_gpus": bench["n_gpus"]},
           "source": f"profiles/{name}.md"}
-    json.dump(pj, open(os.path.join(out, "pmc_spr_score.json"), "w"), indent=1)
+    json.dump(pj, open(os.path.join(out, "pmc_spr.json"), "w"), indent=1)
 if bench:
     lines.append("\n## bench.py line of the same build (un-profiled run)\n\n```json\n" + json.dumps(bench) + "\n```\n")
 sys.stdout.write("".join(lines))
