@@ -202,8 +202,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     n_score, ms_score, pairs_score, bytes_score = dev.timing_read_kind(Device.KIND_SPR_SCORE)
-    n_lane, ms_lane, _, _ = dev.timing_read_kind(Device.KIND_SPR_SEARCH)
-    n_rep, ms_rep, _, _ = dev.timing_read_kind(Device.KIND_SPR_REPLAY)
+    n_s, ms_s, u_s, b_s = dev.timing_read_kind(Device.KIND_SPR_SEARCH)
+    n_r, ms_r, u_r, b_r = dev.timing_read_kind(Device.KIND_SPR_REPLAY)
+    n_lane, ms_lane, n_rep, ms_rep = n_s, ms_s, n_r, ms_r
     for res in kept:
         for k, v in zip(*np.unique(res["status"], return_counts=True)):
             status_counts[str(int(k))] = status_counts.get(str(int(k)), 0) + int(v)
@@ -247,8 +248,6 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(kernel.split()[0]),
                     "algorithmic_bytes_per_launch": bytes_ / max(1, n), "kernel_ms": ms / max(1, n), "launches_timed": n,
                     "units_per_launch": units / max(1, n), "note": what}
-        n_s, ms_s, u_s, b_s = dev.timing_read_kind(Device.KIND_SPR_SEARCH)
-        n_r, ms_r, u_r, b_r = dev.timing_read_kind(Device.KIND_SPR_REPLAY)
         roof_search = roof("k_spr_search (the search state machine: budgeted lane searches + replay / refinement launches)",
                            n_s + n_r, ms_s + ms_r, b_s + b_r, u_s + u_r,
                            "rank 0's launches; algorithmic bytes = SURVEY 8d per candidate placement the launch scored itself "

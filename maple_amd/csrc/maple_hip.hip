@@ -2095,10 +2095,16 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         for (const int32_t *col : {lower, upRight, upLeft, totUp})
             if (col[i] >= 0) c->tree_max_ent = std::max(c->tree_max_ent, c->h_n_ent[col[i]]);
     }
-    {   // the batch-scoring kernel wants its candidates sorted by list length (uniform wavefronts)
+    {   // The dense scoring of the whole-tree searches takes its candidates in the searches' own depth-first order: the 64
+        // scores of a tile then land next to each other in the search's row of the score table (a contiguous 512-byte
+        // store instead of 64 partial-line stores, which WRITE_SIZE counts 4x), and neighbours in the tree have lists of
+        // similar length anyway.  Measured at 100 000 tips: 1 017 -> 940 ms per round against candidates sorted by length.
         std::vector<int32_t> col;
         for (int i = 0; i < n; i++) if (totUp[i] >= 0) col.push_back(i);
-        std::stable_sort(col.begin(), col.end(), [&](int a, int b) { return c->h_n_ent[totUp[a]] < c->h_n_ent[totUp[b]]; });
+        if (getenv("MAPLE_SCORED_ORDER_LENGTH"))
+            std::stable_sort(col.begin(), col.end(), [&](int a, int b) { return c->h_n_ent[totUp[a]] < c->h_n_ent[totUp[b]]; });
+        else
+            std::stable_sort(col.begin(), col.end(), [&](int a, int b) { return recs[a].preRank < recs[b].preRank; });
         std::vector<int32_t> ids(col.size()), rank(col.size()), fr(col.size());
         for (size_t i = 0; i < col.size(); i++) { ids[i] = totUp[col[i]]; rank[i] = recs[col[i]].preRank; fr[i] = recs[col[i]].frameOf; }
         c->n_scored = (int32_t)col.size();
