@@ -140,7 +140,9 @@ def main():
     ref_idx, root_freqs = reference_tables(data.ref)
     # genome-list arena: bigger trees get more of the 288 GB (the per-frame removed lists of the wide searches on trees
     # with local references are the big temporary)
-    dev = Device(ref_idx, root_freqs, device=local_rank, arena_bytes=min(128 << 30, max(4 << 30, args.samples * (640 << 10))))
+    # (the tree's own lists take ~10 KB per sample; the sub-block with local references needs the large arena)
+    per_sample = (640 << 10) if (args.local_refs and not args.no_extras) else (64 << 10)
+    dev = Device(ref_idx, root_freqs, device=local_rank, arena_bytes=min(128 << 30, max(4 << 30, args.samples * per_sample)))
     mkw = model_kwargs(args.model, len(ref_idx))
     dev.set_model(**mkw)
     tip_kw = dict(error_rates=mkw["errorRates"]) if args.model == "siteerr" else {}

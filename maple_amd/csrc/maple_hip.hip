@@ -146,6 +146,7 @@ struct maple_ctx {
     DevBuf<int32_t> t_scan_parent;
     bool scan_valid = false;
     double scan_eff = -1.0;
+    std::vector<int32_t> h_depth;      // per node: distance from the root in branches
     int32_t tree_max_depth = 0;
     // SPR search workspace
     DevBuf<uint8_t> s_search_ws;
@@ -308,6 +309,9 @@ __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ 
 // wavefronts then pull the block's queries from an LDS counter: one query x the 64 staged candidates per tile, candidate
 // words / stored lengths / O vectors / site rates and the query's words and rates all read with ds_read.  Chunks too long for
 // the LDS budget, and queries longer than the strip, are walked from global memory as before.
+#ifndef MAPLE_ZERO_DIST_BUDGET
+#define MAPLE_ZERO_DIST_BUDGET 16      // traversal placements a search from a zero-length branch gets before the dense tier
+#endif
 #define MAPLE_LDS_BLOCK 1024
 #define MAPLE_LDS_CAPW 4096            // candidate words per staged chunk (32 KB, + 32 KB of site rates with rate variation)
 #define MAPLE_LDS_CAPA 1536            // candidate aux doubles per staged chunk (12 KB)
@@ -778,7 +782,14 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             S.cached = cacheS ? cacheS + row * T.n : nullptr;             // this query's row of the (queries x nodes) score table
             S.rTable = (cacheS && rTable) ? rTable + row * nF : nullptr;  // and of the (queries x frames) removed lists
             S.fShort[0] = S.fShort[1] = S.fShort[2] = S.fShort[3] = -1;
-            S.budget = budget;
+            // A pruned node on a zero-length branch is searched with removedBLen = 0 (M:9644).  Without an error model a
+            // mismatch over zero length is impossible (-inf, M:6663), -inf never counts as a failed pass, and the search
+            // walks the whole tree by the reference's own rules (tools/wide_stats.py, 100 000-tip bench tree: all 37 536
+            // whole-tree searches of a deep round sit on zero-length branches and none of the other 136 494 does): it goes
+            // to the dense tier after a token budget instead of spending the full one here first.  With an error model the
+            // mismatch has a finite cost and such searches end like any other (1 000 000-tip run), so no hint then.  (A
+            // routing hint only: the dense tier runs the same search from the start.)
+            S.budget = (!U && budget > MAPLE_ZERO_DIST_BUDGET && T.nd[node].dist == 0.0) ? MAPLE_ZERO_DIST_BUDGET : budget;
             S.overBudget = false;
             S.trI = nullptr;
             if (q == traceQuery && trI) { S.trI = trI; S.trD = trD; S.trCap = trCap; S.trN = 0; }
@@ -798,9 +809,10 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
         } else if (ws.sp > 0) {
 #ifdef MAPLE_SPR_PROFILE
             const long long t0 = wall_clock64();
-            const bool rep = S.cached && !ws.st[ws.sp - 1].upd;
-            if (rep) S.replayCached(); else { S.step(); out[q].nSteps++; }
-            if (rep) out[q].tReplay += wall_clock64() - t0; else out[q].tStep += wall_clock64() - t0;
+            const bool notUpd = !ws.st[ws.sp - 1].upd;
+            const bool rep = S.cached && notUpd;
+            if (rep) S.replayCached(); else { S.step(); if (!notUpd) out[q].nSteps++; }
+            if (notUpd) out[q].tReplay += wall_clock64() - t0; else out[q].tStep += wall_clock64() - t0;
 #else
             if (S.cached && !ws.st[ws.sp - 1].upd) S.replayCached();
             else S.step();
@@ -2077,6 +2089,13 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
             if (child0[v] >= 0) { st.push_back(child0[v]); st.push_back(child1[v]); }
         }
         for (int i = 0; i < n; i++) if (!seen[i]) recs[i].preRank = next++;   // nodes not reachable from the root
+        std::vector<int32_t> byRank((size_t)n, 0);
+        for (int i = 0; i < n; i++) byRank[recs[i].preRank] = i;
+        c->h_depth.assign((size_t)n, 0);
+        for (int r = 0; r < n; r++) {                                          // parents precede their children in rank order
+            const int v = byRank[r], u = up[v];
+            if (u >= 0 && seen[v] && recs[u].preRank < r) c->h_depth[v] = c->h_depth[u] + 1;
+        }
     }
     HIPCK(c, c->t_nodes.reserve((size_t)n * sizeof(NodeRec) + 64));
     uint8_t *aligned = (uint8_t *)(((uintptr_t)c->t_nodes.p + 63) & ~(uintptr_t)63);
@@ -2181,6 +2200,18 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         int capW = cacheS ? (heavyQueries ? 8 : 4) * capW0 : capW0;
         std::vector<int32_t> rows(todo.size());                        // row of each query in the cache / frame tables
         for (size_t k = 0; k < rows.size(); k++) rows[k] = (int32_t)k;
+        if (!getenv("MAPLE_NO_LPT")) {
+            // Lanes pull searches from a counter, so a launch ends one search after the last one is pulled: the expensive
+            // searches go first.  The expensive ones are those near the root (long lists: an updating step there merges
+            // several hundred entries; measured up to 100 ms of updating steps in one search of the 100 000-tip tree
+            // against 4 ms on average) -- nodes in order of depth.
+            std::vector<int32_t> ord(todo.size());
+            for (size_t k = 0; k < ord.size(); k++) ord[k] = (int32_t)k;
+            std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return c->h_depth[todo[a]] < c->h_depth[todo[b]]; });
+            std::vector<int32_t> t2(todo.size()), s2(todo.size()), r2(todo.size());
+            for (size_t k = 0; k < ord.size(); k++) { t2[k] = todo[ord[k]]; s2[k] = slot[ord[k]]; r2[k] = rows[ord[k]]; }
+            todo.swap(t2); slot.swap(s2); rows.swap(r2);
+        }
         for (int attempt = 0; attempt < 3 && !todo.empty(); attempt++, capW *= 8) {
             const int m = (int)todo.size();
             WsLayout L;
@@ -2304,8 +2335,6 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                                                : sp->wideSearchBudget;
     if (const char *e = getenv("MAPLE_WIDE_BUDGET")) wideBudget = atoi(e);        // (experiments)
     const bool hybrid = wideBudget > 0;
-    TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
-    if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: budgeted pass done\n", tms(tStart, tnow()));
     if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !getenv("MAPLE_NO_SCAN")) {
         // the tree in the searches' own depth-first order (SScan, search_dev.h): clade sizes, depths and the per-node facts
         // the cached-regime descent tests
@@ -2345,6 +2374,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         c->scan_eff = P.effNon0;
         c->scan_valid = true;
     }
+    TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
+    if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: budgeted pass done\n", tms(tStart, tnow()));
     if (hybrid) {
         std::vector<int32_t> wide;
         for (int i = 0; i < n; i++)
@@ -2353,11 +2384,12 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         const int nT = c->dtree.n, nF = c->tree_has_mut ? F.nF : 1;
         const size_t rowBytes = (size_t)nT * sizeof(double);
         size_t cacheBudget = (size_t)4ull << 30;                      // (query x node) score table: 4 GiB, more on big trees
-        {
+        {   // a row of a 1 000 000-tip tree is 16 MB and every launch over the table wants thousands of searches (one per
+            // wavefront): up to half of what is free, 96 GiB at most
             size_t freeB = 0, totalB = 0;
             if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-                const size_t quarter = (freeB + c->s_cache.cap * sizeof(double)) / 4;
-                cacheBudget = std::max(cacheBudget, std::min(quarter, (size_t)32ull << 30));
+                const size_t half = (freeB + c->s_cache.cap * sizeof(double)) / 2;
+                cacheBudget = std::max(cacheBudget, std::min(half, (size_t)96ull << 30));
             }
         }
         size_t chunk = cacheBudget / rowBytes;
@@ -2473,15 +2505,32 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     }
 #ifdef MAPLE_SPR_PROFILE
     {
-        long long ts = 0, tr = 0, tf = 0, ns = 0, nl = 0, mxs = 0, mxr = 0, mxf = 0, mxl = 0;
+        for (int pass = 0; pass < 2; pass++) {
+        long long ts = 0, tr = 0, tf = 0, ns = 0, nl = 0, mxs = 0, mxr = 0, mxf = 0, mxl = 0, cnt = 0, visits = 0;
         for (int i = 0; i < n; i++) {
+            if (pass == 1 && !(ho[i].status == 0 && ho[i].nAppend <= wideBudget)) continue;   // pass 1: finished by the lane tier
+            cnt++; visits += ho[i].nAppend;
             ts += ho[i].tStep; tr += ho[i].tReplay; tf += ho[i].tRefine; ns += ho[i].nSteps; nl += ho[i].nShortList;
             mxs = std::max<long long>(mxs, ho[i].tStep); mxr = std::max<long long>(mxr, ho[i].tReplay);
             mxf = std::max<long long>(mxf, ho[i].tRefine); mxl = std::max<long long>(mxl, ho[i].nShortList);
         }
-        fprintf(stderr, "[maple] profile over %d searches (last launch each): step %.1f ms total (max %.2f), replay %.1f (max %.2f), "
-                        "refine %.1f (max %.2f); %lld updating steps, %lld short-listed branches (max %lld)\n",
-                n, ts * 1e-5, mxs * 1e-5, tr * 1e-5, mxr * 1e-5, tf * 1e-5, mxf * 1e-5, ns, nl, mxl);
+        {
+            std::vector<double> tot;
+            for (int i = 0; i < n; i++) {
+                const bool laneTier = ho[i].status == 0 && ho[i].nAppend <= wideBudget;
+                if (ho[i].status != 0 || (pass == 1) != laneTier) continue;
+                tot.push_back((ho[i].tStep + ho[i].tReplay + ho[i].tRefine) * 1e-5);
+            }
+            std::sort(tot.begin(), tot.end());
+            if (!tot.empty())
+                fprintf(stderr, "[maple] per-search time, %s (%zu): median %.2f ms, p90 %.2f, p99 %.2f, p99.9 %.2f, max %.2f\n",
+                        pass ? "lane tier" : "dense tier", tot.size(), tot[tot.size() / 2], tot[tot.size() * 9 / 10],
+                        tot[tot.size() * 99 / 100], tot[tot.size() * 999 / 1000], tot.back());
+        }
+        fprintf(stderr, "[maple] profile over %lld searches (%s; last launch each; %lld placements): updating steps %.1f ms total (max %.2f), "
+                        "other visits %.1f (max %.2f), refine %.1f (max %.2f); %lld updating steps, %lld short-listed branches (max %lld)\n",
+                cnt, pass ? "lane tier only" : "all", visits, ts * 1e-5, mxs * 1e-5, tr * 1e-5, mxr * 1e-5, tf * 1e-5, mxf * 1e-5, ns, nl, mxl);
+        }
     }
 #endif
     for (int i = 0; i < n; i++) {

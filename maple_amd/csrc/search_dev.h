@@ -686,32 +686,58 @@ __device__ inline void wave_scan_clade(const SScan *__restrict__ SC, const int32
         const bool dropped = scoredHere && !(fl & SS_TOTUP);                // visited, nothing scored, nothing pushed
         const bool counts = scoredHere && !dropped;                        // one appendProbNode evaluation when visited
         // ---- every record's (score it hands on, failedPasses, descended into?) under the CURRENT running best: the state
-        // flows from parent to child, so a record is resolved once its parent is; records whose parent lies before the
-        // chunk read the parent's slot
-        double myMp = 0.0;
-        int myFails = 0;
-        bool vis = false, go = false, resolved = false;
-        auto settle = [&](double pMp, int pFails, bool pGo) {
-            vis = pGo && enter;
-            myMp = counts ? scv : pMp;
-            myFails = pFails + ((counts && myMp < (pMp - thrCons)) ? 1 : 0);
-            const bool within = myMp > (best - thrLK);
-            const bool rule = strict ? (myFails <= allowed && within) : (myFails <= allowed || within);
-            go = vis && !dropped && (fl & SS_INNER) && rule;
-            resolved = true;
-        };
+        // flows from parent to child.  Three prefix computations along the parent pointers inside the chunk, each by pointer jumping (log2 of the longest
+        // chain rounds, one ds_bpermute per round): the score a record hands on (its own if it is scored, else that of the
+        // nearest scored ancestor), failedPasses (a sum of per-record drops along the path) and "every ancestor was
+        // descended into".  A record whose parent lies before the chunk starts from the parent's slot.
+        const bool rootLane = !valid || isFirst || pl < 0;
+        double inMp = 0.0;
+        int inFails = 0;
         if (valid) {
-            if (isFirst) settle(lastLK, fails0, true);
-            else if (pl < 0) settle(slotLK[d - d0 - 1], slotFails[d - d0 - 1], true);
+            if (isFirst) { inMp = lastLK; inFails = fails0; }
+            else if (pl < 0) { inMp = slotLK[d - d0 - 1]; inFails = slotFails[d - d0 - 1]; }
         }
-        while (__ballot(valid && !resolved)) {
-            const int src = pl < 0 ? lane : pl;
-            const int pRes = __shfl(resolved ? 1 : 0, src, 64);
-            const double pMp = __shfl(myMp, src, 64);
-            const int pFails = __shfl(myFails, src, 64);
-            const int pGo = __shfl(go ? 1 : 0, src, 64);
-            if (valid && !resolved && pRes) settle(pMp, pFails, pGo != 0);
+        // (1) myMp: own score, or the nearest scored ancestor's (the parent's incoming score for a chain that leaves the chunk)
+        double myMp = counts ? scv : inMp;
+        {
+            bool has = counts || rootLane;
+            int ptr = rootLane ? lane : pl;
+            while (__ballot(!has)) {
+                const int src = has ? lane : ptr;
+                const int oHasPtr = __shfl((has ? 64 : 0) | ptr, src, 64);   // the ancestor's (resolved?, its pointer)
+                const double oMp = __shfl(myMp, src, 64);
+                if (!has) {
+                    if (oHasPtr & 64) { myMp = oMp; has = true; }
+                    else ptr = oHasPtr & 63;
+                }
+            }
         }
+        const double pMpIn = __shfl(myMp, rootLane ? lane : pl, 64);       // (every lane takes part: the source must be active)
+        const double pMp = rootLane ? inMp : pMpIn;
+        // (2) failedPasses = the parent's + (scored here and the score fell by more than thresholdLogLKconsecutivePlacement)
+        int myFails = inFails + ((counts && myMp < (pMp - thrCons)) ? 1 : 0);
+        {
+            int ptr = rootLane ? -1 : pl;
+            while (__ballot(ptr >= 0)) {
+                const int o = __shfl((myFails << 8) | (ptr + 1), ptr >= 0 ? ptr : lane, 64);
+                if (ptr >= 0) { myFails += o >> 8; ptr = (o & 255) - 1; }
+            }
+        }
+        // (3) descended into: the record's own rule and every ancestor's
+        const bool within = myMp > (best - thrLK);
+        const bool rule = strict ? (myFails <= allowed && within) : (myFails <= allowed || within);
+        const bool ownGo = valid && enter && !dropped && (fl & SS_INNER) && rule;   // descended into, if it is visited at all
+        bool go = ownGo;
+        {
+            int ptr = rootLane ? -1 : pl;
+            while (__ballot(ptr >= 0)) {
+                const int o = __shfl((go ? 256 : 0) | (ptr + 1), ptr >= 0 ? ptr : lane, 64);
+                if (ptr >= 0) { go = go && (o & 256); ptr = (o & 255) - 1; }
+            }
+        }
+        const int pGoIn = __shfl(go ? 1 : 0, rootLane ? lane : pl, 64);
+        const bool pGo = rootLane || pGoIn != 0;
+        const bool vis = valid && pGo && enter;
         // ---- a visited record that beats the running best changes the rules for everything after it: records before the
         // first such one are final; that one is applied on its own and the scan resumes behind it
         const unsigned long long imp = __ballot(valid && vis && counts && scv > best);
