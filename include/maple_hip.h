@@ -148,6 +148,20 @@ int maple_shorten_batch(maple_ctx *ctx, int32_t n, const int32_t *list, int32_t 
 int maple_root_vector_batch(maple_ctx *ctx, int32_t n, const int32_t *list, const double *bLen,
                             const uint8_t *isFromTip, const int64_t *pathOff, const int32_t *pathMutLists,
                             int32_t *outList);
+/* updatePartials(tree, nodeList), M:5479-5815, for ANY number of simultaneous local changes (maple_amd/csrc/update_host.h).
+ * The tree is the caller's own: n nodes as plain columns -- up / child0 / child1 (-1 = none), isTip (leaf without minor
+ * sequences), mutList (mutation-list id of the branch above the node, -1 = none), depth (branches from the root), dist,
+ * and the four list-id columns lower / upRight / upLeft / totUp (-1 = None).  changed[] = nodes whose lower list (already
+ * replaced in lower[]) and/or branch length (already replaced in dist[]) changed.  The invalidated lists are repaired level
+ * by level -- lower lists upwards while areVectorsDifferent(new, old) (M:5793), then probVectTotUp / probVectUpRight /
+ * probVectUpLeft downwards while areVectorsDifferent(old, new) (M:5645-5658) -- and lower / upRight / upLeft / totUp
+ * (and dist[], where a None merge between two zero-length branches makes the reference re-estimate a length,
+ * M:5385-5414) are updated IN PLACE with the ids of the new lists; *nReplaced = lists replaced.  New lists are bump-
+ * allocated in the arena; the old ones stay where they are (maple_arena_mark / _release around a trial change). */
+int maple_update_partials(maple_ctx *ctx, int32_t n, int32_t root, const int32_t *up, const int32_t *child0,
+                          const int32_t *child1, const uint8_t *isTip, const int32_t *mutList, const int32_t *depth,
+                          double *dist, int32_t *lower, int32_t *upRight, int32_t *upLeft, int32_t *totUp, int32_t nChanged,
+                          const int32_t *changed, int32_t *nReplaced);
 /* evaluatePlacement(midTot, downVect, upVect, distance, removedPartials, isRemovedTip, ..., fromTip1), M:6790-6806
  * out4[i*4..] = appendingCost, bestBottomLength, bestTopLength, bestAppendingLength (False -> 0.0) */
 int maple_evaluate_placement_batch(maple_ctx *ctx, int32_t n, const int32_t *midTot, const int32_t *downVect,

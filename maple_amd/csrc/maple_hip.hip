@@ -165,6 +165,15 @@ struct maple_ctx {
     DevBuf<uint8_t> p_u8, p_minor;
     int32_t *d_tile_counters = nullptr;    // ring of tile counters for the dynamically scheduled kernels
     int tile_counter_next = 0;
+    void *upd = nullptr;               // UpdateScratch of maple_update_partials (update_host.h)
+    // Staging of the small per-call argument columns of the batch operators: they are gathered in pinned host memory and go
+    // to the device in ONE copy per call (a dozen separate copies from pageable memory cost ~0.2 ms per call, most of a
+    // single-change updatePartials).  Two arenas used in turn: see stage_begin.
+    uint8_t *stg_h[2] = {nullptr, nullptr}, *stg_d[2] = {nullptr, nullptr};
+    size_t stg_cap[2] = {0, 0}, stg_used = 0, stg_flushed = 0;
+    int stg_cur = 0;
+    bool commit_pending = false;       // commit_lists left its copy kernel running on `stream`: entry points that launch on a
+                                       // caller's stream wait for it first (settle)
     bool tolerate_fatal = false;       // maple_set_fatal_policy
     int trace_query = -1;
     DevBuf<int32_t> s_trace_i;
@@ -912,13 +921,18 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
 __global__ __launch_bounds__(MAPLE_BLOCK) void k_commit(int n, const uint2 *sw, const double *sa, const int64_t *swoff,
                                                         const int64_t *saoff, const int32_t *n_ent, const int32_t *n_aux,
                                                         const int64_t *dst_w, const int64_t *dst_a, uint2 *words,
-                                                        double *aux)
+                                                        double *aux, const int32_t *rowId, int64_t *t_ent_off,
+                                                        int64_t *t_aux_off, int32_t *t_n_ent, int32_t *t_n_aux)
 {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int i = wave; i < n; i += nwaves) {
         if (n_ent[i] < 0) continue;
+        if (rowId && lane == 0) {                                          // the new list's row of the list table
+            const int r = rowId[i];
+            t_ent_off[r] = dst_w[i]; t_aux_off[r] = dst_a[i]; t_n_ent[r] = n_ent[i]; t_n_aux[r] = n_aux[i];
+        }
         const uint2 *s = sw + swoff[i];
         uint2 *d = words + dst_w[i];
         for (int k = lane; k < n_ent[i]; k += 64) d[k] = s[k];
@@ -1021,9 +1035,13 @@ extern "C" int maple_create(maple_ctx **out, int device, int32_t lRef, const uin
     return MAPLE_OK;
 }
 
+static void update_scratch_free(maple_ctx *c);   // update_host.h
+
 extern "C" int maple_destroy(maple_ctx *c)
 {
     if (!c) return MAPLE_OK;
+    update_scratch_free(c);
+    for (int k = 0; k < 2; k++) { if (c->stg_h[k]) (void)hipHostFree(c->stg_h[k]); if (c->stg_d[k]) (void)hipFree(c->stg_d[k]); }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_cumBases, c->d_rflec, c->d_model, c->d_words, c->d_aux, c->d_ent_off, c->d_aux_off, c->d_n_ent, c->d_n_aux, c->d_mut3, c->d_mut_off,
@@ -1309,26 +1327,71 @@ template <class T> static int h2d(maple_ctx *c, DevBuf<T> &b, const T *src, size
 }
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
+// Start staging the arguments of one batch call (at most `bytes` of them).  The two arenas alternate from call to call:
+// every batch operator synchronises its stream at least once after its first stage_flush, so by the time an arena comes
+// round again every copy out of it -- including a trailing asynchronous one -- has completed.
+static int stage_begin(maple_ctx *c, size_t bytes)
+{
+    c->stg_cur ^= 1;
+    const int k = c->stg_cur;
+    bytes += 4096;
+    if (bytes > c->stg_cap[k]) {
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (c->stg_h[k]) (void)hipHostFree(c->stg_h[k]);
+        if (c->stg_d[k]) (void)hipFree(c->stg_d[k]);
+        c->stg_h[k] = nullptr; c->stg_d[k] = nullptr; c->stg_cap[k] = 0;
+        const size_t want = std::max(bytes * 2, (size_t)1 << 20);
+        HIPCK(c, hipHostMalloc((void **)&c->stg_h[k], want, hipHostMallocDefault));
+        HIPCK(c, hipMalloc((void **)&c->stg_d[k], want));
+        c->stg_cap[k] = want;
+    }
+    c->stg_used = c->stg_flushed = 0;
+    return MAPLE_OK;
+}
+// n items of `src` into the staging arena; returns where they will be on the device after stage_flush (null if out of room:
+// stage_begin was given too small a bound)
+template <class T> static T *stage_put(maple_ctx *c, const T *src, size_t n)
+{
+    const int k = c->stg_cur;
+    const size_t off = (c->stg_used + 15) & ~(size_t)15, bytes = n * sizeof(T);
+    if (off + bytes > c->stg_cap[k]) return nullptr;
+    if (bytes) memcpy(c->stg_h[k] + off, src, bytes);
+    c->stg_used = off + bytes;
+    return (T *)(c->stg_d[k] + off);
+}
+static int stage_flush(maple_ctx *c)
+{
+    const int k = c->stg_cur;
+    if (c->stg_used > c->stg_flushed)
+        HIPCK(c, hipMemcpyAsync(c->stg_d[k] + c->stg_flushed, c->stg_h[k] + c->stg_flushed, c->stg_used - c->stg_flushed,
+                                hipMemcpyHostToDevice, c->stream));
+    c->stg_flushed = c->stg_used;
+    return MAPLE_OK;
+}
+#define STAGE(var, c, src, n) auto *var = stage_put((c), (src), (size_t)(n)); if (!var) return fail((c), MAPLE_ERR_NOMEM, "argument staging overflow")
+
 static int need_model(maple_ctx *c)
 {
     if (!c->model_set) return fail(c, MAPLE_ERR_STATE, "maple_set_model has not been called");
     return MAPLE_OK;
 }
 
-// Move freshly produced scratch lists into the arena and hand out ids (or -1 for None).
-static int commit_lists(maple_ctx *c, int32_t n, const std::vector<int64_t> &woff, const std::vector<int64_t> &aoff,
-                        int32_t *d_n_ent, int32_t *d_n_aux, int32_t *outList, const uint2 *srcW = nullptr,
-                        const double *srcA = nullptr)
+// Move freshly produced scratch lists into the arena and hand out ids (or -1 for None).  d_woff / d_aoff: the per-item
+// scratch offsets, already on the device.  One synchronisation (the sizes come back), then one staged copy (destinations and
+// list ids) and the copy kernel, which also writes the new rows of the device-side list table; nothing waits for it.
+static int commit_lists(maple_ctx *c, int32_t n, const int64_t *d_woff, const int64_t *d_aoff, int32_t *d_n_ent, int32_t *d_n_aux,
+                        int32_t *outList, const uint2 *srcW = nullptr, const double *srcA = nullptr)
 {
     if (!srcW) { srcW = c->s_words.p; srcA = c->s_aux.p; }             // the batch operators' shared scratch
     std::vector<int32_t> ne(n), na(n);
     HIPCK(c, hipMemcpyAsync(ne.data(), d_n_ent, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(na.data(), d_n_aux, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    std::vector<int64_t> dw(n, -1), da(n, -1), rows_eo, rows_ao;
-    std::vector<int32_t> rows_ne, rows_na;
+    std::vector<int64_t> dw(n, -1), da(n, -1);
+    std::vector<int32_t> rowId(n, -1);
     int64_t ue = c->used_ent, ua = c->used_aux;
-    int32_t next_id = (int32_t)c->h_n_ent.size();
+    const int64_t first = (int64_t)c->h_n_ent.size();
+    int32_t next_id = (int32_t)first;
     for (int i = 0; i < n; i++) {
         if (ne[i] == -1) { outList[i] = -1; continue; }
         if (ne[i] < 0) {
@@ -1336,26 +1399,36 @@ static int commit_lists(maple_ctx *c, int32_t n, const std::vector<int64_t> &wof
             return fail(c, MAPLE_ERR_FATAL, "item %d hit a state the reference treats as fatal (%d)", i, ne[i]);
         }
         dw[i] = ue; da[i] = ua;
-        rows_eo.push_back(ue); rows_ao.push_back(ua); rows_ne.push_back(ne[i]); rows_na.push_back(na[i]);
         ue += ne[i]; ua += na[i];
+        rowId[i] = next_id;
         outList[i] = next_id++;
     }
     if (ue > c->cap_ent || ua > c->cap_aux) return fail(c, MAPLE_ERR_NOMEM, "arena full while committing %d lists", n);
-    TRY(h2d(c, c->s_i64[2], dw.data(), (size_t)n));
-    TRY(h2d(c, c->s_i64[3], da.data(), (size_t)n));
-    TRY(h2d(c, c->s_i64[4], woff.data(), (size_t)n));
-    TRY(h2d(c, c->s_i64[5], aoff.data(), (size_t)n));
+    if (next_id > c->cap_lists) return fail(c, MAPLE_ERR_NOMEM, "list table full (%lld)", (long long)c->cap_lists);
+    for (int i = 0; i < n; i++) {
+        if (rowId[i] < 0) continue;
+        c->h_ent_off.push_back(dw[i]); c->h_aux_off.push_back(da[i]); c->h_n_ent.push_back(ne[i]); c->h_n_aux.push_back(na[i]);
+    }
+    STAGE(d_dw, c, dw.data(), n);
+    STAGE(d_da, c, da.data(), n);
+    STAGE(d_row, c, rowId.data(), n);
+    TRY(stage_flush(c));
     int waves_per_block = MAPLE_BLOCK / 64;
     int g = (n + waves_per_block - 1) / waves_per_block;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_commit, dim3(g), dim3(MAPLE_BLOCK), 0, c->stream, n, srcW, srcA, c->s_i64[4].p,
-                       c->s_i64[5].p, d_n_ent, d_n_aux, c->s_i64[2].p, c->s_i64[3].p, c->d_words, c->d_aux);
+    hipLaunchKernelGGL(k_commit, dim3(g), dim3(MAPLE_BLOCK), 0, c->stream, n, srcW, srcA, d_woff, d_aoff, d_n_ent, d_n_aux, d_dw,
+                       d_da, c->d_words, c->d_aux, d_row, c->d_ent_off, c->d_aux_off, c->d_n_ent, c->d_n_aux);
     HIPCK(c, hipGetLastError());
-    if (!rows_ne.empty())
-        TRY(push_list_rows(c, (int32_t)rows_ne.size(), rows_eo.data(), rows_ao.data(), rows_ne.data(), rows_na.data()));
-    else HIPCK(c, hipStreamSynchronize(c->stream));
     c->used_ent = ue;
     c->used_aux = ua;
+    c->commit_pending = true;
+    return MAPLE_OK;
+}
+
+// lists committed on the library's stream are not yet visible to work on another stream: wait once
+static int settle(maple_ctx *c)
+{
+    if (c->commit_pending) { HIPCK(c, hipStreamSynchronize(c->stream)); c->commit_pending = false; }
     return MAPLE_OK;
 }
 
@@ -1400,29 +1473,24 @@ extern "C" int maple_merge_batch(maple_ctx *c, int32_t n, const int32_t *l1, con
     }
     HIPCK(c, c->s_words.reserve((size_t)tot));
     HIPCK(c, c->s_aux.reserve((size_t)(5 * tot)));
-    TRY(h2d(c, c->s_i32[0], l1, (size_t)n));
-    TRY(h2d(c, c->s_i32[1], l2, (size_t)n));
-    TRY(h2d(c, c->s_f64[0], b1, (size_t)n));
-    TRY(h2d(c, c->s_f64[1], b2, (size_t)n));
-    TRY(h2d(c, c->s_u8[0], t1, (size_t)n));
-    TRY(h2d(c, c->s_u8[1], t2, (size_t)n));
-    TRY(h2d(c, c->s_u8[2], ud, (size_t)n));
+    TRY(stage_begin(c, (size_t)n * 96 + 512));
+    STAGE(dl1, c, l1, n); STAGE(dl2, c, l2, n); STAGE(db1, c, b1, n); STAGE(db2, c, b2, n);
+    STAGE(dt1, c, t1, n); STAGE(dt2, c, t2, n); STAGE(dud, c, ud, n);
     const int32_t *dnm1 = nullptr, *dnm2 = nullptr;
-    if (nm1) { TRY(h2d(c, c->s_i32[4], nm1, (size_t)n)); dnm1 = c->s_i32[4].p; }
-    if (nm2) { TRY(h2d(c, c->s_i32[5], nm2, (size_t)n)); dnm2 = c->s_i32[5].p; }
-    TRY(h2d(c, c->s_i64[0], woff.data(), (size_t)n));
-    TRY(h2d(c, c->s_i64[1], aoff.data(), (size_t)n));
+    if (nm1) { STAGE(p1, c, nm1, n); dnm1 = p1; }
+    if (nm2) { STAGE(p2, c, nm2, n); dnm2 = p2; }
+    STAGE(dwo, c, woff.data(), n); STAGE(dao, c, aoff.data(), n);
+    TRY(stage_flush(c));
     HIPCK(c, c->s_i32[2].reserve(n));
     HIPCK(c, c->s_i32[3].reserve(n));
     double *dlk = nullptr;
     if (outLK) { HIPCK(c, c->s_f64[2].reserve(n)); dlk = c->s_f64[2].p; }
-    OutSpec o{c->s_words.p, c->s_aux.p, c->s_i64[0].p, c->s_i64[1].p, c->s_i32[2].p, c->s_i32[3].p};
-    DISPATCH3(c, k_merge, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, c->s_i32[0].p, c->s_f64[0].p,
-                                                                         c->s_u8[0].p, c->s_i32[1].p, c->s_f64[1].p,
-                                                                         c->s_u8[1].p, c->s_u8[2].p, dnm1, dnm2, o, dlk));
+    OutSpec o{c->s_words.p, c->s_aux.p, dwo, dao, c->s_i32[2].p, c->s_i32[3].p};
+    DISPATCH3(c, k_merge, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl1, db1, dt1, dl2, db2, dt2, dud, dnm1,
+                                                                         dnm2, o, dlk));
     HIPCK(c, hipGetLastError());
     if (outLK) HIPCK(c, hipMemcpyAsync(outLK, dlk, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    return commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outList);
+    return commit_lists(c, n, dwo, dao, c->s_i32[2].p, c->s_i32[3].p, outList);
 }
 
 extern "C" int maple_blen_batch(maple_ctx *c, int32_t n, const int32_t *pl, const int32_t *cl, const uint8_t *tip,
@@ -1438,14 +1506,12 @@ extern "C" int maple_blen_batch(maple_ctx *c, int32_t n, const int32_t *pl, cons
     int64_t tot = 0;
     for (int i = 0; i < n; i++) { aoff[i] = tot; tot += (int64_t)c->h_n_ent[pl[i]] + c->h_n_ent[cl[i]]; }
     HIPCK(c, c->s_ais.reserve((size_t)tot));
-    TRY(h2d(c, c->s_i32[0], pl, (size_t)n));
-    TRY(h2d(c, c->s_i32[1], cl, (size_t)n));
-    TRY(h2d(c, c->s_u8[0], tip, (size_t)n));
-    TRY(h2d(c, c->s_i64[0], aoff.data(), (size_t)n));
+    TRY(stage_begin(c, (size_t)n * 32 + 256));
+    STAGE(dpl, c, pl, n); STAGE(dcl, c, cl, n); STAGE(dtip, c, tip, n); STAGE(dao, c, aoff.data(), n);
+    TRY(stage_flush(c));
     HIPCK(c, c->s_f64[0].reserve(n));
     HIPCK(c, c->s_u8[1].reserve(n));
-    DISPATCH3(c, k_blen, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
-                                                                        c->s_u8[0].p, c->s_ais.p, c->s_i64[0].p,
+    DISPATCH3(c, k_blen, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dpl, dcl, dtip, c->s_ais.p, dao,
                                                                         c->s_f64[0].p, c->s_u8[1].p));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(t, c->s_f64[0].p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1462,11 +1528,11 @@ extern "C" int maple_differ_batch(maple_ctx *c, int32_t n, const int32_t *l1, co
     TRY(need_model(c));
     TRY(check_ids(c, n, l1, false, "list1"));
     TRY(check_ids(c, n, l2, true, "list2"));
-    TRY(h2d(c, c->s_i32[0], l1, (size_t)n));
-    TRY(h2d(c, c->s_i32[1], l2, (size_t)n));
+    TRY(stage_begin(c, (size_t)n * 8 + 128));
+    STAGE(dl1, c, l1, n); STAGE(dl2, c, l2, n);
+    TRY(stage_flush(c));
     HIPCK(c, c->s_u8[0].reserve(n));
-    DISPATCH3(c, k_differ, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
-                                                                          c->s_u8[0].p));
+    DISPATCH3(c, k_differ, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl1, dl2, c->s_u8[0].p));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(out, c->s_u8[0].p, n, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -1596,18 +1662,15 @@ extern "C" int maple_pass_branch_batch(maple_ctx *c, int32_t n, const int32_t *l
     }
     HIPCK(c, c->s_words.reserve((size_t)tot));
     HIPCK(c, c->s_aux.reserve((size_t)(5 * tot)));
-    TRY(h2d(c, c->s_i32[0], l, (size_t)n));
-    TRY(h2d(c, c->s_i32[1], ml, (size_t)n));
-    TRY(h2d(c, c->s_u8[0], up, (size_t)n));
-    TRY(h2d(c, c->s_i64[0], woff.data(), (size_t)n));
-    TRY(h2d(c, c->s_i64[1], aoff.data(), (size_t)n));
+    TRY(stage_begin(c, (size_t)n * 64 + 256));
+    STAGE(dl, c, l, n); STAGE(dml, c, ml, n); STAGE(dup, c, up, n); STAGE(dwo, c, woff.data(), n); STAGE(dao, c, aoff.data(), n);
+    TRY(stage_flush(c));
     HIPCK(c, c->s_i32[2].reserve(n));
     HIPCK(c, c->s_i32[3].reserve(n));
-    OutSpec o{c->s_words.p, c->s_aux.p, c->s_i64[0].p, c->s_i64[1].p, c->s_i32[2].p, c->s_i32[3].p};
-    hipLaunchKernelGGL(k_pass, dim3(grid_for(n)), dim3(MAPLE_BLOCK), 0, c->stream, c->lRef, view(c), mview(c), n,
-                       c->s_i32[0].p, c->s_i32[1].p, c->s_u8[0].p, o);
+    OutSpec o{c->s_words.p, c->s_aux.p, dwo, dao, c->s_i32[2].p, c->s_i32[3].p};
+    hipLaunchKernelGGL(k_pass, dim3(grid_for(n)), dim3(MAPLE_BLOCK), 0, c->stream, c->lRef, view(c), mview(c), n, dl, dml, dup, o);
     HIPCK(c, hipGetLastError());
-    return commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outList);
+    return commit_lists(c, n, dwo, dao, c->s_i32[2].p, c->s_i32[3].p, outList);
 }
 
 extern "C" int maple_shorten_batch(maple_ctx *c, int32_t n, const int32_t *l, int32_t *outList)
@@ -1622,15 +1685,15 @@ extern "C" int maple_shorten_batch(maple_ctx *c, int32_t n, const int32_t *l, in
     for (int i = 0; i < n; i++) { woff[i] = tot; aoff[i] = 5 * tot; tot += c->h_n_ent[l[i]]; }
     HIPCK(c, c->s_words.reserve((size_t)tot));
     HIPCK(c, c->s_aux.reserve((size_t)(5 * tot)));
-    TRY(h2d(c, c->s_i32[0], l, (size_t)n));
-    TRY(h2d(c, c->s_i64[0], woff.data(), (size_t)n));
-    TRY(h2d(c, c->s_i64[1], aoff.data(), (size_t)n));
+    TRY(stage_begin(c, (size_t)n * 56 + 256));
+    STAGE(dl, c, l, n); STAGE(dwo, c, woff.data(), n); STAGE(dao, c, aoff.data(), n);
+    TRY(stage_flush(c));
     HIPCK(c, c->s_i32[2].reserve(n));
     HIPCK(c, c->s_i32[3].reserve(n));
-    OutSpec o{c->s_words.p, c->s_aux.p, c->s_i64[0].p, c->s_i64[1].p, c->s_i32[2].p, c->s_i32[3].p};
-    DISPATCH3(c, k_shorten, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, c->s_i32[0].p, o));
+    OutSpec o{c->s_words.p, c->s_aux.p, dwo, dao, c->s_i32[2].p, c->s_i32[3].p};
+    DISPATCH3(c, k_shorten, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl, o));
     HIPCK(c, hipGetLastError());
-    return commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outList);
+    return commit_lists(c, n, dwo, dao, c->s_i32[2].p, c->s_i32[3].p, outList);
 }
 
 extern "C" int maple_root_vector_batch(maple_ctx *c, int32_t n, const int32_t *l, const double *bl, const uint8_t *tip,
@@ -1657,23 +1720,17 @@ extern "C" int maple_root_vector_batch(maple_ctx *c, int32_t n, const int32_t *l
     HIPCK(c, c->s_words.reserve((size_t)(3 * tot)));
     HIPCK(c, c->s_aux.reserve((size_t)(15 * tot)));
     const int64_t np = pathOff[n];
-    TRY(h2d(c, c->s_i32[0], l, (size_t)n));
-    TRY(h2d(c, c->s_f64[0], bl, (size_t)n));
-    TRY(h2d(c, c->s_u8[0], tip, (size_t)n));
-    TRY(h2d(c, c->s_i64[0], woff.data(), (size_t)n));
-    TRY(h2d(c, c->s_i64[1], aoff.data(), (size_t)n));
-    TRY(h2d(c, c->s_i64[2], pathOff, (size_t)n + 1));
-    TRY(h2d(c, c->s_i32[1], pathMut, (size_t)np));
-    TRY(h2d(c, c->s_i64[3], capOff.data(), (size_t)n + 1));
+    TRY(stage_begin(c, (size_t)n * 96 + (size_t)np * 4 + 512));
+    STAGE(dl, c, l, n); STAGE(dbl, c, bl, n); STAGE(dtip, c, tip, n); STAGE(dwo, c, woff.data(), n); STAGE(dao, c, aoff.data(), n);
+    STAGE(dpo, c, pathOff, n + 1); STAGE(dpm, c, pathMut, np); STAGE(dco, c, capOff.data(), n + 1);
+    TRY(stage_flush(c));
     HIPCK(c, c->s_i32[2].reserve(n));
     HIPCK(c, c->s_i32[3].reserve(n));
-    OutSpec o{c->s_words.p, c->s_aux.p, c->s_i64[0].p, c->s_i64[1].p, c->s_i32[2].p, c->s_i32[3].p};
-    DISPATCH3(c, k_root_vector, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), mview(c), n, c->s_i32[0].p,
-                                                                               c->s_f64[0].p, c->s_u8[0].p, c->s_i64[2].p,
-                                                                               c->s_i32[1].p, c->s_i64[3].p, o));
+    OutSpec o{c->s_words.p, c->s_aux.p, dwo, dao, c->s_i32[2].p, c->s_i32[3].p};
+    DISPATCH3(c, k_root_vector, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), mview(c), n, dl, dbl, dtip, dpo, dpm,
+                                                                               dco, o));
     HIPCK(c, hipGetLastError());
-    HIPCK(c, hipStreamSynchronize(c->stream));   // commit_lists reuses s_i64[2..5]
-    return commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outList);
+    return commit_lists(c, n, dwo, dao, c->s_i32[2].p, c->s_i32[3].p, outList);
 }
 
 extern "C" int maple_evaluate_placement_batch(maple_ctx *c, int32_t n, const int32_t *midTot, const int32_t *down,
@@ -1797,6 +1854,7 @@ extern "C" int maple_append_batch_dev(maple_ctx *c, int32_t n, const int32_t *pl
     if (n == 0) return MAPLE_OK;
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
+    TRY(settle(c));
     hipStream_t s = (hipStream_t)stream;                               // the caller's stream, verbatim (NULL = the legacy default stream)
     hipEvent_t e0, e1;
     TRY(ev_pair(c, &e0, &e1, MAPLE_K_APPEND_PAIRS, (double)n, 0.0));
@@ -1814,6 +1872,7 @@ extern "C" int maple_append_queries_dev(maple_ctx *c, int32_t nQ, const int32_t 
     if (nQ == 0 || nC == 0) return MAPLE_OK;
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
+    TRY(settle(c));
     return launch_append_queries(c, (hipStream_t)stream, nQ, qList_dev, nC, cand_dev, isTipC, bLen, out_dev,
                                  nC, nullptr, nullptr, nullptr, MAPLE_K_APPEND_QUERIES, 0.0);
 }
@@ -1828,6 +1887,7 @@ extern "C" int maple_append_queries_argmax_dev(maple_ctx *c, int32_t nQ, const i
     if (nQ == 0 || nC == 0) return MAPLE_OK;
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
+    TRY(settle(c));
     const int nChunks = (nC + 63) / 64;
     HIPCK(c, c->s_tilebest.reserve((size_t)nQ * nChunks * sizeof(TileBest)));
     TileBest *tb = (TileBest *)c->s_tilebest.p;
@@ -1944,6 +2004,7 @@ extern "C" int maple_argmax_allreduce_dev(maple_ctx *c, int32_t n, double *score
 }
 
 #include "placement_host.h"
+#include "update_host.h"
 
 // MAT reference frames of the uploaded tree: frame 0 is the root's reference, every node whose branch carries mutations
 // opens a new one for its clade.  Frames are numbered by nesting depth (a parent frame always has a smaller index).
@@ -2549,7 +2610,10 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         HIPCK(c, hipMemcpyAsync(c->s_i32[2].p, ne.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipMemcpyAsync(c->s_i32[3].p, na.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
-        TRY(commit_lists(c, n, woff, aoff, c->s_i32[2].p, c->s_i32[3].p, outRprList, poolW, poolA));
+        TRY(stage_begin(c, (size_t)n * 48 + 256));
+        STAGE(dwo, c, woff.data(), n); STAGE(dao, c, aoff.data(), n);
+        TRY(stage_flush(c));
+        TRY(commit_lists(c, n, dwo, dao, c->s_i32[2].p, c->s_i32[3].p, outRprList, poolW, poolA));
     }
     return MAPLE_OK;
 }

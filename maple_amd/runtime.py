@@ -21,7 +21,7 @@ EXPORTS = [
     "maple_lists_upload", "maple_lists_sizes", "maple_lists_download", "maple_arena_mark", "maple_arena_release",
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
-    "maple_evaluate_placement_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
+    "maple_evaluate_placement_batch", "maple_update_partials", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
     "maple_timing_read_kind", "maple_placement_supports_batch", "maple_debug_gpv_batch", "maple_debug_simplify_batch",
@@ -323,6 +323,22 @@ class Device:
         self._ck(self.lib.maple_root_vector_batch(self.h, n, _ptr(lists), _ptr(bl), _ptr(tip), _ptr(off), _ptr(pm),
                                                   _ptr(out)))
         return out
+
+    def update_partials(self, root, up, c0, c1, tip, mut, depth, dist, lower, up_right, up_left, tot_up, changed):
+        """maple_update_partials: the four list-id columns and ``dist`` are updated IN PLACE (they must be C-contiguous
+        int32 / float64 arrays -- nothing is copied); returns the number of lists replaced."""
+        for name, arr, dt in (("up", up, np.int32), ("child0", c0, np.int32), ("child1", c1, np.int32), ("isTip", tip, np.uint8),
+                              ("mutList", mut, np.int32), ("depth", depth, np.int32), ("dist", dist, np.float64),
+                              ("lower", lower, np.int32), ("upRight", up_right, np.int32), ("upLeft", up_left, np.int32),
+                              ("totUp", tot_up, np.int32)):
+            if not (isinstance(arr, np.ndarray) and arr.dtype == dt and arr.flags.c_contiguous and len(arr) == len(up)):
+                raise ValueError(f"update_partials: column {name} must be a C-contiguous {np.dtype(dt).name} array of {len(up)}")
+        ch = _i32(changed)
+        n_rep = C.c_int32(0)
+        self._ck(self.lib.maple_update_partials(self.h, len(up), int(root), _ptr(up), _ptr(c0), _ptr(c1), _ptr(tip), _ptr(mut),
+                                                _ptr(depth), _ptr(dist), _ptr(lower), _ptr(up_right), _ptr(up_left), _ptr(tot_up),
+                                                len(ch), _ptr(ch), C.byref(n_rep)))
+        return int(n_rep.value)
 
     def evaluate_placement_batch(self, midTot, down, up, distance, removed, isRemovedTip, fromTip1):
         midTot, down, up, removed = _i32(midTot), _i32(down), _i32(up), _i32(removed)

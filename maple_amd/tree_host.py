@@ -18,7 +18,8 @@ class HostTree:
         self.root = root
         self.up = list(up)
         self.children = [list(c) for c in children]
-        self.dist = list(dist)
+        self._cols = None
+        self.dist = dist
         self.mutations = [list(m) for m in mutations]
         self.n_minor = list(n_minor)
         self.probVect = probVect
@@ -26,6 +27,33 @@ class HostTree:
         self.probVectUpLeft = probVectUpLeft
         self.probVectTotUp = probVectTotUp
         self.n = len(self.up)
+
+    @property
+    def dist(self):
+        """Branch lengths as one float64 column (None / False of the reference's tree = 0.0); assign elements in place."""
+        return self._dist
+
+    @dist.setter
+    def dist(self, value):
+        if isinstance(value, np.ndarray):
+            self._dist = np.ascontiguousarray(value, dtype=np.float64)
+        else:
+            self._dist = np.asarray([float(x or 0.0) for x in value], dtype=np.float64)
+
+    def columns(self):
+        """The topology as plain columns (up, child0, child1, isTip, depth: int32 / uint8 arrays, -1 = none) -- what the
+        C ABI takes; cached until apply_topology changes the tree."""
+        if self._cols is None:
+            up = np.asarray([-1 if u is None else u for u in self.up], dtype=np.int32)
+            c0 = np.asarray([c[0] if c else -1 for c in self.children], dtype=np.int32)
+            c1 = np.asarray([c[1] if c else -1 for c in self.children], dtype=np.int32)
+            tip = np.asarray([(not c) and (m == 0) for c, m in zip(self.children, self.n_minor)], dtype=np.uint8)
+            depth = np.zeros(self.n, dtype=np.int32)
+            for v in self.preorder():
+                if up[v] >= 0:
+                    depth[v] = depth[up[v]] + 1
+            self._cols = (up, c0, c1, tip, depth)
+        return self._cols
 
     @classmethod
     def from_mirror(cls, mirror, dev: Device = None):
@@ -85,12 +113,8 @@ class HostTree:
 
     def upload_topology(self, dev: Device):
         """(Re-)upload the topology and the list ids (maple_tree_upload) -- after tree surgery or a repair of the lists."""
-        up = np.asarray([-1 if u is None else u for u in self.up], dtype=np.int32)
-        c0 = np.asarray([c[0] if c else -1 for c in self.children], dtype=np.int32)
-        c1 = np.asarray([c[1] if c else -1 for c in self.children], dtype=np.int32)
-        is_tip = np.asarray([(not c) and (m == 0) for c, m in zip(self.children, self.n_minor)], dtype=np.uint8)
-        dist = np.asarray([float(x or 0.0) for x in self.dist])
-        dev.upload_tree(self.root, up, c0, c1, dist, is_tip, self.id_lower, self.id_upRight, self.id_upLeft,
+        up, c0, c1, is_tip, _ = self.columns()
+        dev.upload_tree(self.root, up, c0, c1, self.dist, is_tip, self.id_lower, self.id_upRight, self.id_upLeft,
                         self.id_totUp, self.id_mut)
         return self
 
@@ -113,6 +137,7 @@ class HostTree:
             self.mutations = self.mutations + [[] for _ in range(grow)]
         self.root, self.up, self.children = root, list(up), [list(c) if c else [] for c in children]
         self.dist, self.n_minor, self.n = [float(x or 0.0) for x in dist], list(n_minor), n_new
+        self._cols = None
         return changed
 
 
@@ -235,7 +260,7 @@ def rebuild_genome_lists(dev: Device, tree: HostTree):
     return lower, up_right, up_left, tot_up
 
 
-def update_genome_lists(dev: Device, tree: HostTree, changed, changed_dist=None):
+def update_genome_lists(dev: Device, tree: HostTree, changed, changed_dist=None, native=True):
     """updatePartials (M:5479-5815) in its GPU-native form: instead of the reference's one-node-at-a-time LIFO work
     list, the lists invalidated by a set of local changes are repaired level by level, every level one batch of
     passGenomeListThroughBranch / mergeVectors / areVectorsDifferent / shorten launches -- so that any number of
@@ -249,7 +274,14 @@ def update_genome_lists(dev: Device, tree: HostTree, changed, changed_dist=None)
     only if its upper vector was replaced, i.e. areVectorsDifferent(old, new) (M:5645-5658) -- the reference's own stop
     rule, so the repaired region is the same up to that threshold.  A merge that comes out None between two zero-length
     branches re-estimates the branch above the changed child like updateBLen (M:5385-5414).
-    ``tree.id_*`` and ``tree.dist`` are updated in place; returns the number of lists replaced."""
+    ``tree.id_*`` and ``tree.dist`` are updated in place; returns the number of lists replaced.
+
+    ``native`` (default): the level loop runs inside the library (maple_update_partials, maple_amd/csrc/update_host.h) on
+    these same columns; the Python loop below is the same algorithm call for call and is kept as its cross-check."""
+    if native and changed_dist is None:
+        up_, c0_, c1_, tip_, depth_ = tree.columns()
+        return dev.update_partials(tree.root, up_, c0_, c1_, tip_, tree.id_mut, depth_, tree.dist, tree.id_lower, tree.id_upRight,
+                                   tree.id_upLeft, tree.id_totUp, changed)
     n = tree.n
     up = np.asarray([-1 if u is None else u for u in tree.up])
     c0 = np.asarray([c[0] if c else -1 for c in tree.children])

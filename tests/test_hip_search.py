@@ -475,8 +475,24 @@ def test_update_partials_matches_reference(uname):
             tree.dist[v] = ch["dist"]
         else:
             tree.id_lower[v] = dev.upload([tup(ch["probVect"])])[0]
+        # the same repair by the Python level loop on a second copy of the tree: the library's loop (maple_update_partials) is
+        # the same algorithm call for call, so the lists it leaves are identical entry for entry
+        twin = HostTree(t["root"], t["up"], t["children"], t["dist"], t["mutations"], t["nMinor"], None, None, None, None)
+        twin.id_mut = tree.id_mut
+        for _, attr in keys:
+            setattr(twin, attr, getattr(tree, attr).copy())
+        twin.dist[v] = tree.dist[v]
         replaced = update_genome_lists(dev, tree, [v])
         assert replaced >= 1
+        assert update_genome_lists(dev, twin, [v], native=False) == replaced
+        assert np.array_equal(twin.dist, tree.dist)
+        for _, attr in keys:
+            a, b = getattr(tree, attr), getattr(twin, attr)
+            assert np.array_equal(a >= 0, b >= 0), attr
+            moved = np.nonzero((a >= 0) & (a != b))[0]
+            if len(moved):
+                la, lb = dev.download(a[moved]), dev.download(b[moved])
+                assert la == lb, (attr, moved[:5])
         # every list of every node against the reference's tree after ITS updatePartials
         for key, attr in keys:
             ids = getattr(tree, attr)

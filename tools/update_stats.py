@@ -32,7 +32,17 @@ for k in (1, 10, 100, 1000):
     t0 = time.perf_counter()
     rep = update_genome_lists(dev, ht, pick.tolist())
     dt = time.perf_counter() - t0
-    print(f"{k} simultaneous branch-length changes: {rep} lists replaced in {dt * 1e3:.1f} ms ({dt / k * 1e3:.3f} ms per change)")
+    print(f"{k} simultaneous branch-length changes: {rep} lists replaced in {dt * 1e3:.2f} ms ({dt / k * 1e3:.3f} ms per change)")
+    if k == 1:                                          # the same kind of change again, both level loops, warm
+        for native in (True, False):
+            ts = []
+            for v in rng.choice(cand, size=20, replace=False):
+                ht.dist[v] = ht.dist[v] * 1.5
+                t0 = time.perf_counter()
+                update_genome_lists(dev, ht, [int(v)], native=native)
+                ts.append(time.perf_counter() - t0)
+            print(f"  single change, {'library' if native else 'Python'} level loop: median {np.median(ts) * 1e3:.2f} ms, "
+                  f"min {min(ts) * 1e3:.2f} ms over 20 changes")
 # findBestRoot's search + the fast branch-length pass on the same tree
 import math
 from maple_amd.tree_host import find_best_root, optimize_branch_lengths_fast_pass
