@@ -600,6 +600,43 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_shorten(const DevModel *__restr
     }
 }
 
+// One item of a level of updatePartials (update_host.h): mergeVectors, then what the reference does with the result, in
+// one go -- no trip to the host between the three.  mode 0 (a lower list, M:5760-5800): shorten(), then
+// areVectorsDifferent(new, old); mode 1 (probVectTotUp, M:5525-5557): shorten(); mode 2 (probVectUpRight / UpLeft,
+// M:5559-5660): areVectorsDifferent(old, new), and shorten() only if they differ.  The merged list goes to scratch slot A,
+// the shortened one to slot B (what is committed).  n_ent: entries of B, -1 = None, < -1 = fatal; flag: "different".
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_update_items(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *l1,
+                                                              const double *b1, const uint8_t *t1, const int32_t *l2,
+                                                              const double *b2, const uint8_t *t2, const uint8_t *ud,
+                                                              const uint8_t *mode, const int32_t *old, uint2 *words, double *aux,
+                                                              const int64_t *woff, const int64_t *cap, int32_t *res3)
+{
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Writer wa, wb;
+        wa.init(words + woff[i], aux + 5 * woff[i]);
+        wb.init(words + woff[i] + cap[i], aux + 5 * (woff[i] + cap[i]));
+        double lk = 0.0;
+        const int r = merge_walk(c, list_ref(av, l1[i]), b1[i], t1[i] != 0, list_ref(av, l2[i]), b2[i], t2[i] != 0, ud[i] != 0, false, 0,
+                                 0, wa, &lk);
+        int ne = r, na = 0, flag = 1;
+        if (r >= 0) {
+            const ListRef A{wa.w, wa.aux};
+            if (mode[i] == 2 && old[i] >= 0) flag = differ_walk(c, list_ref(av, old[i]), A) ? 1 : 0;
+            if (flag) {
+                ne = shorten_walk(c, A, r, wb);
+                na = wb.na;
+                if (mode[i] == 0 && old[i] >= 0) flag = differ_walk(c, ListRef{wb.w, wb.aux}, list_ref(av, old[i])) ? 1 : 0;
+            } else ne = 0;
+        }
+        res3[i] = ne; res3[n + i] = na; res3[2 * n + i] = flag;
+    }
+}
+
 // rootVector: frames up (node..root), root_walk, frames down (root..node), shorten.
 // Each item owns 3 scratch lists of `cap` entries: A, B (ping-pong) and the final output slot.
 template <bool RV, bool U, bool SS>
@@ -929,7 +966,7 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_commit(int n, const uint2 *sw, 
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int i = wave; i < n; i += nwaves) {
         if (n_ent[i] < 0) continue;
-        if (rowId && lane == 0) {                                          // the new list's row of the list table
+        if (rowId && lane == 0 && rowId[i] >= 0) {                         // the new list's row of the list table
             const int r = rowId[i];
             t_ent_off[r] = dst_w[i]; t_aux_off[r] = dst_a[i]; t_n_ent[r] = n_ent[i]; t_n_aux[r] = n_aux[i];
         }
@@ -1379,14 +1416,25 @@ static int need_model(maple_ctx *c)
 // Move freshly produced scratch lists into the arena and hand out ids (or -1 for None).  d_woff / d_aoff: the per-item
 // scratch offsets, already on the device.  One synchronisation (the sizes come back), then one staged copy (destinations and
 // list ids) and the copy kernel, which also writes the new rows of the device-side list table; nothing waits for it.
+static int commit_known(maple_ctx *c, int32_t n, const int64_t *d_woff, const int64_t *d_aoff, const int32_t *d_n_ent,
+                        const int32_t *d_n_aux, const std::vector<int32_t> &ne, const std::vector<int32_t> &na, int32_t *outList,
+                        const uint2 *srcW, const double *srcA);
 static int commit_lists(maple_ctx *c, int32_t n, const int64_t *d_woff, const int64_t *d_aoff, int32_t *d_n_ent, int32_t *d_n_aux,
                         int32_t *outList, const uint2 *srcW = nullptr, const double *srcA = nullptr)
 {
-    if (!srcW) { srcW = c->s_words.p; srcA = c->s_aux.p; }             // the batch operators' shared scratch
     std::vector<int32_t> ne(n), na(n);
     HIPCK(c, hipMemcpyAsync(ne.data(), d_n_ent, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(na.data(), d_n_aux, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    return commit_known(c, n, d_woff, d_aoff, d_n_ent, d_n_aux, ne, na, outList, srcW, srcA);
+}
+
+// ... with the sizes already on the host (ne[i] == -1: nothing to commit for item i)
+static int commit_known(maple_ctx *c, int32_t n, const int64_t *d_woff, const int64_t *d_aoff, const int32_t *d_n_ent,
+                        const int32_t *d_n_aux, const std::vector<int32_t> &ne, const std::vector<int32_t> &na, int32_t *outList,
+                        const uint2 *srcW, const double *srcA)
+{
+    if (!srcW) { srcW = c->s_words.p; srcA = c->s_aux.p; }             // the batch operators' shared scratch
     std::vector<int64_t> dw(n, -1), da(n, -1);
     std::vector<int32_t> rowId(n, -1);
     int64_t ue = c->used_ent, ua = c->used_aux;

@@ -58,6 +58,51 @@ static int upd_passed(maple_ctx *c, const int32_t *mut, std::vector<int32_t> &id
     return MAPLE_OK;
 }
 
+// One level's worth of items through k_update_items: merge, then shorten / compare as the item's mode says (see the
+// kernel).  outList[i]: the new list (-1: None from the merge, or mode 2 and not different: nothing to replace);
+// outNone[i] = 1 if the merge itself came out None; outDiff[i] = the areVectorsDifferent verdict (1 where none was asked).
+static int update_items(maple_ctx *c, int32_t n, const int32_t *l1, const double *b1, const uint8_t *t1, const int32_t *l2,
+                        const double *b2, const uint8_t *t2, const uint8_t *ud, const uint8_t *mode, const int32_t *old,
+                        int32_t *outList, uint8_t *outNone, uint8_t *outDiff)
+{
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(check_ids(c, n, l1, false, "list1"));
+    TRY(check_ids(c, n, l2, false, "list2"));
+    TRY(check_ids(c, n, old, true, "old list"));
+    std::vector<int64_t> woff(n), cap(n), woffB(n), aoffB(n);
+    int64_t tot = 0;
+    for (int i = 0; i < n; i++) {
+        cap[i] = (int64_t)c->h_n_ent[l1[i]] + c->h_n_ent[l2[i]];
+        woff[i] = tot; woffB[i] = tot + cap[i]; aoffB[i] = 5 * woffB[i];
+        tot += 2 * cap[i];
+    }
+    HIPCK(c, c->s_words.reserve((size_t)tot));
+    HIPCK(c, c->s_aux.reserve((size_t)(5 * tot)));
+    TRY(stage_begin(c, (size_t)n * 128 + 1024));
+    STAGE(dl1, c, l1, n); STAGE(dl2, c, l2, n); STAGE(db1, c, b1, n); STAGE(db2, c, b2, n);
+    STAGE(dt1, c, t1, n); STAGE(dt2, c, t2, n); STAGE(dud, c, ud, n); STAGE(dmode, c, mode, n); STAGE(dold, c, old, n);
+    STAGE(dwo, c, woff.data(), n); STAGE(dcap, c, cap.data(), n); STAGE(dwoB, c, woffB.data(), n); STAGE(daoB, c, aoffB.data(), n);
+    TRY(stage_flush(c));
+    HIPCK(c, c->s_i32[2].reserve((size_t)3 * n));
+    int32_t *res3 = c->s_i32[2].p;
+    DISPATCH3(c, k_update_items, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl1, db1, dt1, dl2, db2, dt2, dud,
+                                                                                dmode, dold, c->s_words.p, c->s_aux.p, dwo, dcap, res3));
+    HIPCK(c, hipGetLastError());
+    std::vector<int32_t> h3((size_t)3 * n);
+    HIPCK(c, hipMemcpyAsync(h3.data(), res3, (size_t)3 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    std::vector<int32_t> ne(n), na(n);
+    for (int i = 0; i < n; i++) {
+        const int r = h3[i], flag = h3[(size_t)2 * n + i];
+        outNone[i] = r == -1;
+        outDiff[i] = (uint8_t)(flag != 0);
+        ne[i] = (r >= 0 && !flag && mode[i] == 2) ? -1 : r;                // mode 2 and not different: nothing to commit
+        na[i] = h3[(size_t)n + i];
+    }
+    return commit_known(c, n, dwoB, daoB, res3, res3 + n, ne, na, outList, nullptr, nullptr);
+}
+
 extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, const int32_t *up, const int32_t *c0, const int32_t *c1,
                                      const uint8_t *tip, const int32_t *mut, const int32_t *depth, double *dist, int32_t *lower,
                                      int32_t *upRight, int32_t *upLeft, int32_t *totUp, int32_t nChanged, const int32_t *changed,
@@ -116,10 +161,13 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
         TRY(upd_passed(c, mut, pb, b, true));
         ud.assign(m, 0);
         out.resize(m);
-        TRY(maple_merge_batch(c, (int32_t)m, pa.data(), da.data(), ta.data(), pb.data(), db.data(), tb.data(), ud.data(), nullptr,
-                              nullptr, out.data(), nullptr));
+        std::vector<uint8_t> modeA(m, 0), none(m), diff(m);
+        std::vector<int32_t> oldA(m);
+        for (size_t k = 0; k < m; k++) oldA[k] = lower[nodes[k]];
+        TRY(update_items(c, (int32_t)m, pa.data(), da.data(), ta.data(), pb.data(), db.data(), tb.data(), ud.data(), modeA.data(),
+                         oldA.data(), out.data(), none.data(), diff.data()));
         for (size_t k = 0; k < m; k++) {
-            if (out[k] >= 0) continue;
+            if (!none[k]) continue;
             // None between two zero-length branches: re-estimate the branch above the changed child, like updateBLen
             // (M:5385-5414, 5689-5701)
             const int p = nodes[k];
@@ -129,37 +177,25 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
             for (int oi = 0; oi < 2; oi++) {
                 const int which = order[oi];
                 const int ch = which == 0 ? c0[p] : c1[p];
-                std::vector<int32_t> one{ch}, vu;
-                TRY(vectUpOf(one, vu));
+                std::vector<int32_t> one{ch}, vu1;
+                TRY(vectUpOf(one, vu1));
                 double t = 0.0;
                 uint8_t isFalse = 0;
                 const uint8_t tipc = tip[ch];
-                TRY(maple_blen_batch(c, 1, vu.data(), &lower[ch], &tipc, &t, &isFalse));
+                TRY(maple_blen_batch(c, 1, vu1.data(), &lower[ch], &tipc, &t, &isFalse));
                 dist[ch] = isFalse ? 0.0 : t;
                 S.dLow[ch] = 1; S.dDist[ch] = 1; S.touch(ch);
                 markChild(p, which);
                 if (dist[ch] != 0.0) break;
             }
             da[k] = dist[a[k]]; db[k] = dist[b[k]];
-            int32_t o2 = -1;
             const uint8_t z = 0;
-            TRY(maple_merge_batch(c, 1, &pa[k], &da[k], &ta[k], &pb[k], &db[k], &tb[k], &z, nullptr, nullptr, &o2, nullptr));
-            if (o2 < 0) return fail(c, MAPLE_ERR_FATAL, "None vector after updateBLen at node %d", p);
-            out[k] = o2;
+            TRY(update_items(c, 1, &pa[k], &da[k], &ta[k], &pb[k], &db[k], &tb[k], &z, &z, &oldA[k], &out[k], &none[k], &diff[k]));
+            if (none[k]) return fail(c, MAPLE_ERR_FATAL, "None vector after updateBLen at node %d", p);
         }
-        fresh.resize(m);
-        TRY(maple_shorten_batch(c, (int32_t)m, out.data(), fresh.data()));
-        ids1.clear(); ids2.clear();
-        std::vector<int32_t> whereOld;
-        for (size_t k = 0; k < m; k++)
-            if (lower[nodes[k]] >= 0) { ids1.push_back(fresh[k]); ids2.push_back(lower[nodes[k]]); whereOld.push_back((int32_t)k); }
-        flags.assign(ids1.size(), 1);
-        if (!ids1.empty()) TRY(maple_differ_batch(c, (int32_t)ids1.size(), ids1.data(), ids2.data(), flags.data()));   // (new, old), M:5793
-        std::vector<uint8_t> diff(m, 1);
-        for (size_t i = 0; i < whereOld.size(); i++) diff[whereOld[i]] = flags[i];
         for (size_t k = 0; k < m; k++) {
             const int v = nodes[k];
-            lower[v] = fresh[k];
+            lower[v] = out[k];
             replaced++;
             if (!diff[k]) continue;
             S.dLow[v] = 1; S.touch(v);
@@ -219,76 +255,56 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
             nodes.erase(nodes.begin());                                    // (only the root has depth 0)
         }
         TRY(vectUpOf(nodes, vu));
-        // probVectTotUp
-        sel.clear();
-        for (size_t k = 0; k < nodes.size(); k++) if (S.dUp[nodes[k]] || S.dLow[nodes[k]]) sel.push_back((int32_t)k);
-        if (!sel.empty()) {
-            ids1.clear(); ids2.clear(); da.clear(); db.clear(); ta.clear(); tb.clear();
-            std::vector<int32_t> who;
-            for (int32_t k : sel) {
-                const int v = nodes[k];
-                if (dist[v] == 0.0) { totUp[v] = -1; continue; }
-                who.push_back(v);
-                ids1.push_back(vu[k]); ids2.push_back(lower[v]); da.push_back(dist[v] / 2); db.push_back(dist[v] / 2);
-                ta.push_back(0); tb.push_back(tip[v]);
+        // One fused launch for the level: probVectTotUp where the node's lower list, length or upper vector changed,
+        // probVectUpRight (upper vector + child 1, for child 0) and probVectUpLeft (upper vector + child 0, for child 1) where
+        // the upper vector, the length or that child changed
+        std::vector<int32_t> iL1, iL2, iOld, iNode, iKid;
+        std::vector<double> iB1, iB2;
+        std::vector<uint8_t> iT2, iMode, iKind;                            // kind: 0 totUp, 1 upRight, 2 upLeft
+        for (size_t k = 0; k < nodes.size(); k++) {
+            const int v = nodes[k];
+            if (S.dUp[v] || S.dLow[v]) {
+                if (dist[v] == 0.0) totUp[v] = -1;
+                else {
+                    iL1.push_back(vu[k]); iB1.push_back(dist[v] / 2); iL2.push_back(lower[v]); iB2.push_back(dist[v] / 2);
+                    iT2.push_back(tip[v]); iMode.push_back(1); iOld.push_back(-1); iNode.push_back(v); iKid.push_back(-1); iKind.push_back(0);
+                }
             }
-            if (!who.empty()) {
-                ud.assign(who.size(), 1);
-                out.resize(who.size());
-                TRY(maple_merge_batch(c, (int32_t)who.size(), ids1.data(), da.data(), ta.data(), ids2.data(), db.data(), tb.data(),
-                                      ud.data(), nullptr, nullptr, out.data(), nullptr));
-                for (size_t i = 0; i < who.size(); i++)
-                    if (out[i] < 0) return fail(c, MAPLE_ERR_FATAL, "None probVectTotUp on a branch of non-zero length (node %d)", who[i]);
-                fresh.resize(who.size());
-                TRY(maple_shorten_batch(c, (int32_t)who.size(), out.data(), fresh.data()));
-                for (size_t i = 0; i < who.size(); i++) totUp[who[i]] = fresh[i];
-                replaced += (int)who.size();
+            if (c0[v] < 0) continue;
+            for (int which = 1; which >= 0; which--) {
+                if (!(S.dUp[v] || S.dDist[v] || (which == 0 ? S.dCh0[v] : S.dCh1[v]))) continue;
+                const int kd = which == 1 ? c1[v] : c0[v];
+                iL1.push_back(vu[k]); iB1.push_back(dist[v]); iL2.push_back(lower[kd]); iB2.push_back(dist[kd]); iT2.push_back(tip[kd]);
+                iMode.push_back(2); iOld.push_back(which == 1 ? upRight[v] : upLeft[v]); iNode.push_back(v); iKid.push_back(kd);
+                iKind.push_back(which == 1 ? 1 : 2);
             }
         }
-        // probVectUpRight (for child 0: upper vector + child 1) and probVectUpLeft (for child 1: upper vector + child 0)
-        for (int pass = 0; pass < 2; pass++) {
-            const int which = pass == 0 ? 1 : 0;
-            int32_t *store = pass == 0 ? upRight : upLeft;
-            std::vector<int32_t> who;
-            ids1.clear(); da.clear(); kid.clear();
-            for (size_t k = 0; k < nodes.size(); k++) {
-                const int v = nodes[k];
-                if (c0[v] < 0) continue;
-                if (!(S.dUp[v] || S.dDist[v] || (which == 0 ? S.dCh0[v] : S.dCh1[v]))) continue;
-                who.push_back(v); ids1.push_back(vu[k]); da.push_back(dist[v]);
-                kid.push_back(which == 1 ? c1[v] : c0[v]);
+        const size_t m = iL1.size();
+        if (m == 0) continue;
+        {   // the children's lower lists go through their own branches first where those carry mutations
+            std::vector<int32_t> kids, ids, where;
+            for (size_t i = 0; i < m; i++) if (iKid[i] >= 0 && mut[iKid[i]] >= 0) { kids.push_back(iKid[i]); ids.push_back(iL2[i]); where.push_back((int32_t)i); }
+            if (!kids.empty()) {
+                TRY(upd_passed(c, mut, ids, kids, true));
+                for (size_t i = 0; i < where.size(); i++) iL2[where[i]] = ids[i];
             }
-            if (who.empty()) continue;
-            const size_t m = who.size();
-            pk.resize(m); db.resize(m); ta.assign(m, 0); tb.resize(m);
-            for (size_t i = 0; i < m; i++) { pk[i] = lower[kid[i]]; db[i] = dist[kid[i]]; tb[i] = tip[kid[i]]; }
-            TRY(upd_passed(c, mut, pk, kid, true));
-            ud.assign(m, 1);
-            nv.resize(m);
-            TRY(maple_merge_batch(c, (int32_t)m, ids1.data(), da.data(), ta.data(), pk.data(), db.data(), tb.data(), ud.data(), nullptr,
-                                  nullptr, nv.data(), nullptr));
-            for (size_t i = 0; i < m; i++)
-                if (nv[i] < 0) return fail(c, MAPLE_ERR_FATAL, "None upper vector at node %d (the reference would call updateBLen here)", who[i]);
-            std::vector<int32_t> o1, o2, whereOld;
-            for (size_t i = 0; i < m; i++)
-                if (store[who[i]] >= 0) { o1.push_back(store[who[i]]); o2.push_back(nv[i]); whereOld.push_back((int32_t)i); }
-            flags.assign(o1.size(), 1);
-            if (!o1.empty()) TRY(maple_differ_batch(c, (int32_t)o1.size(), o1.data(), o2.data(), flags.data()));     // (old, new), M:5645
-            std::vector<uint8_t> diff(m, 1);
-            for (size_t i = 0; i < whereOld.size(); i++) diff[whereOld[i]] = flags[i];
-            std::vector<int32_t> keep, keepWho;
-            for (size_t i = 0; i < m; i++) if (diff[i]) { keep.push_back(nv[i]); keepWho.push_back(who[i]); }
-            if (keep.empty()) continue;
-            fresh.resize(keep.size());
-            TRY(maple_shorten_batch(c, (int32_t)keep.size(), keep.data(), fresh.data()));
-            for (size_t i = 0; i < keep.size(); i++) {
-                const int v = keepWho[i];
-                store[v] = fresh[i];
-                const int target = which == 1 ? c0[v] : c1[v];
-                S.dUp[target] = 1; S.touch(target);
-                addTodo(target);
-            }
-            replaced += (int)keep.size();
+        }
+        std::vector<uint8_t> iT1(m, 0), iUd(m, 1), none(m), diff(m);
+        out.resize(m);
+        TRY(update_items(c, (int32_t)m, iL1.data(), iB1.data(), iT1.data(), iL2.data(), iB2.data(), iT2.data(), iUd.data(), iMode.data(),
+                         iOld.data(), out.data(), none.data(), diff.data()));
+        for (size_t i = 0; i < m; i++) {
+            const int v = iNode[i];
+            if (none[i])
+                return fail(c, MAPLE_ERR_FATAL, iKind[i] == 0 ? "None probVectTotUp on a branch of non-zero length (node %d)"
+                                                              : "None upper vector at node %d (the reference would call updateBLen here)", v);
+            if (iKind[i] == 0) { totUp[v] = out[i]; replaced++; continue; }
+            if (!diff[i]) continue;
+            (iKind[i] == 1 ? upRight : upLeft)[v] = out[i];
+            replaced++;
+            const int target = iKind[i] == 1 ? c0[v] : c1[v];
+            S.dUp[target] = 1; S.touch(target);
+            addTodo(target);
         }
     }
     S.clear();
