@@ -352,11 +352,34 @@ def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_pl
     t0 = time.perf_counter()
     pres = dev.placement_search_batch(new_ids, **pkw)
     pwall = time.perf_counter() - t0
+    ts = []
+    for qid in new_ids[:32]:                                       # ... and one query at a time (the serial placement phase)
+        t0 = time.perf_counter()
+        dev.placement_search_batch(np.asarray([qid], dtype=np.int32), **pkw)
+        ts.append(time.perf_counter() - t0)
     dev.release(mark)
     out["placement_batch"] = {"queries": int(Q), "wall_ms": 1e3 * pwall, "queries_per_s": Q / pwall,
                               "reference_equivalent_placements_per_s": float(pres["nAppend"].sum() / pwall),
                               "branches_scored_per_s": float(Q * (Cn + 1) / pwall),
                               "minor_sequences": int((pres["status"] == 1).sum()), "failed": int((pres["status"] < 0).sum())}
+    # ---- the serial path of the placement phase (one sample, then one repair of the lists, M:11744-11752): one query at a
+    # time through the same entry point, and updatePartials for one changed branch through maple_update_partials
+    from maple_amd.tree_host import HostTree, update_genome_lists
+    mark = dev.mark()
+    ht1 = HostTree.from_mirror(mirror)
+    rng1 = np.random.default_rng(5)
+    cand1 = np.nonzero((mirror.parent >= 0) & (mirror.dist > 1e-5))[0]
+    tu, rep = [], 0
+    for v in rng1.choice(cand1, size=33, replace=False):
+        ht1.dist[v] = ht1.dist[v] * 1.5
+        t0 = time.perf_counter()
+        rep += update_genome_lists(dev, ht1, [int(v)])
+        tu.append(time.perf_counter() - t0)
+    dev.release(mark)
+    out["serial_path"] = {"single_query_placement_ms_median": 1e3 * float(np.median(ts[1:])),
+                          "single_change_update_partials_ms_median": 1e3 * float(np.median(tu[1:])),
+                          "lists_replaced_per_change": rep / len(tu),
+                          "note": "wall times through the Python binding; the reference's CPython updatePartials takes ~0.4 ms"}
     if args.local_refs or args.samples <= 20000:
         # ---- the same steps on the same tree after giving it MAT local references (setUpMAT's rule, 50 descendants per
         # reference node, M:166 / 6152-6164): the form real MAPLE trees have; lists are shorter, searches cross frames ----
