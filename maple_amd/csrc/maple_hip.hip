@@ -882,6 +882,10 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             o.bestNode = S.bestNode; o.bestScore = S.bestScore;
             o.blen[0] = S.bl0; o.blen[1] = S.bl1; o.blen[2] = S.bl2;
             o.nAppend = S.nAppend;
+#ifdef MAPLE_SPR_PROFILE
+            o.rprN = (int32_t)(S.tWalk / 100); o.rprNA = (int32_t)(S.tRefSetup / 100);   // (profile: microseconds inside append_walk / list lookup)
+            S.tWalk = S.tRefSetup = 0;
+#endif
             if (S.trI) *trN = S.trN;
             if (poolW) {                                             // hand bestRemovedPartials out through the pool
                 int hOut = S.hBestRpr;
@@ -2635,6 +2639,14 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 fprintf(stderr, "[maple] per-search time, %s (%zu): median %.2f ms, p90 %.2f, p99 %.2f, p99.9 %.2f, max %.2f\n",
                         pass ? "lane tier" : "dense tier", tot.size(), tot[tot.size() / 2], tot[tot.size() * 9 / 10],
                         tot[tot.size() * 99 / 100], tot[tot.size() * 999 / 1000], tot.back());
+        }
+        {
+            long long tw = 0, tl = 0;
+            for (int i = 0; i < n; i++) {
+                if (pass == 1 && !(ho[i].status == 0 && ho[i].nAppend <= wideBudget)) continue;
+                if (ho[i].rprWoff < 0) { tw += ho[i].rprN; tl += ho[i].rprNA; }
+            }
+            fprintf(stderr, "[maple]   of which inside append_walk %.1f ms, list lookup before it %.1f ms\n", tw * 1e-3, tl * 1e-3);
         }
         fprintf(stderr, "[maple] profile over %lld searches (%s; last launch each; %lld placements): updating steps %.1f ms total (max %.2f), "
                         "other visits %.1f (max %.2f), refine %.1f (max %.2f); %lld updating steps, %lld short-listed branches (max %lld)\n",

@@ -187,9 +187,14 @@ template <bool RV, bool U, bool SS> struct Search {
         if (listId < 0) return -1;
         return ws.newHandle(av.words + av.ent_off[listId], av.aux + av.aux_off[listId], av.n_ent[listId], av.n_aux[listId]);
     }
-    __device__ MAPLE_SEARCH_OP int opPass(int hid, int mutId, bool dirUp)
+    // (the test that nearly always says "nothing to do" stays inline: a real call costs a register spill to scratch)
+    __device__ __forceinline__ int opPass(int hid, int mutId, bool dirUp)
     {
         if (!valid(hid) || mutId < 0) return hid;
+        return opPassReal(hid, mutId, dirUp);
+    }
+    __device__ MAPLE_SEARCH_OP int opPassReal(int hid, int mutId, bool dirUp)
+    {
         int cnt = mv.cnt[mutId];
         if (cnt == 0) return hid;
         if (!ws.reserve(len(hid) + 2 * cnt)) return -2;
@@ -238,8 +243,20 @@ template <bool RV, bool U, bool SS> struct Search {
     __device__ MAPLE_SEARCH_OP double opAppend(int hP, int hC, bool isTipC, double bLen)
     {
         nAppend++;
+#ifdef MAPLE_SPR_PROFILE
+        const long long t0 = wall_clock64();
+        const ListRef rp = ref(hP), rc = ref(hC);
+        const long long t1 = wall_clock64();
+        const double v = append_walk(c, rp, rc, isTipC, bLen);
+        tRefSetup += t1 - t0; tWalk += wall_clock64() - t1;
+        return v;
+#else
         return append_walk(c, ref(hP), ref(hC), isTipC, bLen);
+#endif
     }
+#ifdef MAPLE_SPR_PROFILE
+    long long tWalk = 0, tRefSetup = 0;
+#endif
     __device__ MAPLE_SEARCH_OP double opBlen(int hP, int hC, bool fromTipC)
     {
         bool f;
