@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sub-blocks (all-pairs kernel, batched placement, local references)")
     ap.add_argument("--local-refs", action="store_true",
-                    help="also run the steps on the same tree after giving it MAT local references (default when samples <= 20000)")
+                    help="also run the steps on the same tree after giving it MAT local references (default when samples <= 200000)")
     args = ap.parse_args()
 
     import torch
@@ -141,7 +141,8 @@ def main():
     # genome-list arena: bigger trees get more of the 288 GB (the per-frame removed lists of the wide searches on trees
     # with local references are the big temporary)
     # (the tree's own lists take ~10 KB per sample; the sub-block with local references needs the large arena)
-    per_sample = (640 << 10) if (args.local_refs and not args.no_extras) else (64 << 10)
+    run_local_refs = (args.local_refs or args.samples <= 200000) and not args.no_extras
+    per_sample = (320 << 10) if run_local_refs else (64 << 10)
     dev = Device(ref_idx, root_freqs, device=local_rank, arena_bytes=min(128 << 30, max(4 << 30, args.samples * per_sample)))
     mkw = model_kwargs(args.model, len(ref_idx))
     dev.set_model(**mkw)
@@ -380,7 +381,7 @@ def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_pl
                           "single_change_update_partials_ms_median": 1e3 * float(np.median(tu[1:])),
                           "lists_replaced_per_change": rep / len(tu),
                           "note": "wall times through the Python binding; the reference's CPython updatePartials takes ~0.4 ms"}
-    if args.local_refs or args.samples <= 20000:
+    if args.local_refs or args.samples <= 200000:
         # ---- the same steps on the same tree after giving it MAT local references (setUpMAT's rule, 50 descendants per
         # reference node, M:166 / 6152-6164): the form real MAPLE trees have; lists are shorter, searches cross frames ----
         from maple_amd.mat import add_local_references
@@ -391,7 +392,7 @@ def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_pl
         mat_s = time.perf_counter() - t0
         dev.upload_tree(ht.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist, mirror.is_tip,
                         ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp, ht.id_mut)
-        nsteps = max(1, min(args.steps, 4))
+        nsteps = max(1, min(args.steps, 4 if args.samples <= 20000 else 1))
         dev.spr_search_batch(order[np.arange(nsteps * B, (nsteps + 1) * B) % len(order)], **kw)
         dev.timing_reset()
         t0 = time.perf_counter()

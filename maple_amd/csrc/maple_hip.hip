@@ -2604,13 +2604,16 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                     }
                     a = b;
                 }
+                if (dbgT) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] t=%.1f ms: removed lists in all %d frames\n", tms(tStart, tnow()), nF); }
                 TRY(h2d(c, c->s_i32[6], R.data(), R.size()));
                 double qBytes = 0.0;                                   // every frame's copy of the query that is read
                 for (size_t k = 0; k < R.size(); k++) if (R[k] >= 0) qBytes += 8.0 * c->h_n_ent[R[k]] + 8.0 * c->h_n_aux[R[k]];
                 TRY(launch_place_score(c, m, nF, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, c->t_scored_frame.p, 0, 0.0,
                                        c->s_cache.p, nT, c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p, MAPLE_K_SPR_SCORE,
                                        (double)m * c->scored_bytes_total + qBytes));
+                if (dbgT) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] t=%.1f ms: scored\n", tms(tStart, tnow())); }
                 TRY(run_queries(qn, sl, c->s_cache.p, 0, c->s_i32[6].p, nF));
+                if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: replayed\n", tms(tStart, tnow()));
                 TRY(maple_arena_release(c, mark));
             }
             w0 += (size_t)m;
@@ -2633,6 +2636,19 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 const bool laneTier = ho[i].status == 0 && ho[i].nAppend <= wideBudget;
                 if (ho[i].status != 0 || (pass == 1) != laneTier) continue;
                 tot.push_back((ho[i].tStep + ho[i].tReplay + ho[i].tRefine) * 1e-5);
+            }
+            if (pass == 1 && getenv("MAPLE_SPR_PROFILE_TOP")) {
+                std::vector<int> idx;
+                for (int i = 0; i < n; i++) if (ho[i].status == 0 && ho[i].nAppend <= wideBudget) idx.push_back(i);
+                std::sort(idx.begin(), idx.end(), [&](int a, int b) {
+                    return ho[a].tStep + ho[a].tReplay + ho[a].tRefine > ho[b].tStep + ho[b].tReplay + ho[b].tRefine; });
+                for (size_t k = 0; k < std::min<size_t>(12, idx.size()); k++) {
+                    const int i = idx[k];
+                    const int32_t l = c->h_tree_lower[nodes[i]];
+                    fprintf(stderr, "[maple]   slow search: node %d depth %d, %d placements, %d updating steps %.1f ms, visits %.1f ms, %d refinements %.1f ms, removed list %d entries\n",
+                            nodes[i], c->h_depth[nodes[i]], ho[i].nAppend, ho[i].nSteps, ho[i].tStep * 1e-5, ho[i].tReplay * 1e-5,
+                            ho[i].nShortList, ho[i].tRefine * 1e-5, l >= 0 ? c->h_n_ent[l] : -1);
+                }
             }
             std::sort(tot.begin(), tot.end());
             if (!tot.empty())
