@@ -156,6 +156,11 @@ def main():
         dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist, mirror.is_tip,
                         mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up, no_mut)
     upload_plain_tree()
+    t_up = time.perf_counter()
+    upload_plain_tree()                                  # (timed once more, warm: what a caller pays per change of the tree)
+    tree_upload_ms = 1e3 * (time.perf_counter() - t_up)
+    st_res = dev.stats()
+    n_lists_res, n_ent_res, n_aux_res = st_res["n_lists"], st_res["n_entries"], st_res["n_aux"]
     kw = search_kwargs(l_ref, args.spr_fast)
     order = preorder_nodes(mirror)
     B = min(args.batch, len(order)) if args.batch > 0 else len(order)
@@ -274,7 +279,11 @@ def main():
                        "candidate_placements_timed": int(total_placements),
                        "parallelism": f"each step's {B} pruned nodes dealt round-robin in pre-order (coreNum) over {world} GPU(s), "
                                       "tree mirror replicated, one all-gather of proposed moves per step",
-                       "setup_s": round(setup_s, 1)},
+                       "setup_s": round(setup_s, 1),
+                       "resident_inputs": {"genome_lists": int(n_lists_res), "list_bytes": int(8 * n_ent_res + 8 * n_aux_res),
+                                           "tree_upload_ms": round(tree_upload_ms, 1),
+                                           "note": "lists and tree tables are in HBM when the timed region starts; a step's own "
+                                                   "host traffic (node ids in, ~100 B of results per search out) is inside `value`"}},
             "roofline": dominant, "roofline_second_kernel": other,
             "spr_search": {"status_counts": status_counts, "proposed_moves_rank0": n_moves,
                            "kernel_ms_rank0": {"budgeted_lane_searches": ms_lane, "dense_scoring": ms_score,
