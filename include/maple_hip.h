@@ -85,6 +85,12 @@ int maple_get_model(maple_ctx *ctx, double *cumulativeRate /*[lRef+1]*/, double 
                     double *totError);
 
 /* ---- genome-list arena ------------------------------------------------------ */
+/* New contents for existing lists (re-upload of dirty lists): ids[i] keeps its number -- tree columns,
+ * candidate sets and an uploaded tree that refer to it stay valid -- and names the new words from now on.  A list that fits
+ * in the room of the old one is overwritten in place, otherwise it gets fresh room at the end of the arena.  Packed CSR
+ * input as for maple_lists_upload. */
+int maple_lists_update(maple_ctx *ctx, int32_t n, const int32_t *ids, const int64_t *ent_off, const int32_t *pos,
+                       const uint32_t *meta, const int64_t *aux_off, const double *aux);
 /* Upload n_lists packed lists; ids first_id .. first_id+n_lists-1 are assigned.
  * ent_off / aux_off are CSR offsets with n_lists+1 elements. */
 int maple_lists_upload(maple_ctx *ctx, int32_t n_lists, const int64_t *ent_off, const int32_t *pos,

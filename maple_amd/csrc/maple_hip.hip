@@ -1233,6 +1233,8 @@ extern "C" int maple_lists_upload(maple_ctx *c, int32_t n, const int64_t *ent_of
     return MAPLE_OK;
 }
 
+static int check_ids(maple_ctx *c, int32_t n, const int32_t *ids, bool allowNeg, const char *what);
+
 static int check_ids(maple_ctx *c, int32_t n, const int32_t *ids, bool allowNeg, const char *what)
 {
     const int32_t nl = (int32_t)c->h_n_ent.size();
@@ -1481,6 +1483,59 @@ static int commit_known(maple_ctx *c, int32_t n, const int64_t *d_woff, const in
 static int settle(maple_ctx *c)
 {
     if (c->commit_pending) { HIPCK(c, hipStreamSynchronize(c->stream)); c->commit_pending = false; }
+    return MAPLE_OK;
+}
+
+__global__ void k_set_rows(int n, const int32_t *ids, const int64_t *eo, const int64_t *ao, const int32_t *ne, const int32_t *na,
+                           int64_t *t_ent_off, int64_t *t_aux_off, int32_t *t_n_ent, int32_t *t_n_aux)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int r = ids[i]; t_ent_off[r] = eo[i]; t_aux_off[r] = ao[i]; t_n_ent[r] = ne[i]; t_n_aux[r] = na[i]; }
+}
+
+// New contents for EXISTING lists: ids[i] keeps its number (every table that refers to it -- tree columns, candidate sets,
+// an uploaded tree -- stays valid) and from now on names the new words.  A list that fits in the room of the old one is
+// overwritten in place; otherwise it gets fresh room at the end of the arena (the old room is given back by the next
+// maple_arena_release past it, like everything else in a bump arena).
+extern "C" int maple_lists_update(maple_ctx *c, int32_t n, const int32_t *ids, const int64_t *ent_off, const int32_t *pos,
+                                  const uint32_t *meta, const int64_t *aux_off, const double *aux)
+{
+    if (!c || n < 0 || !ids || !ent_off || !aux_off || (n && (!pos || !meta))) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(check_ids(c, n, ids, false, "list"));
+    std::vector<int64_t> eo(n), ao(n);
+    std::vector<int32_t> cnt(n), cna(n);
+    int64_t ue = c->used_ent, ua = c->used_aux;
+    for (int i = 0; i < n; i++) {
+        cnt[i] = (int32_t)(ent_off[i + 1] - ent_off[i]);
+        cna[i] = (int32_t)(aux_off[i + 1] - aux_off[i]);
+        if (cnt[i] <= 0) return fail(c, MAPLE_ERR_ARG, "list %d is empty", i);
+        const int32_t id = ids[i];
+        if (cnt[i] <= c->h_n_ent[id] && cna[i] <= c->h_n_aux[id]) { eo[i] = c->h_ent_off[id]; ao[i] = c->h_aux_off[id]; }
+        else { eo[i] = ue; ao[i] = ua; ue += cnt[i]; ua += cna[i]; }
+    }
+    if (ue > c->cap_ent || ua > c->cap_aux) return fail(c, MAPLE_ERR_NOMEM, "arena full while updating %d lists", n);
+    TRY(settle(c));
+    std::vector<uint2> w;
+    for (int i = 0; i < n; i++) {
+        w.resize((size_t)cnt[i]);
+        for (int k = 0; k < cnt[i]; k++) w[k] = make_uint2((uint32_t)pos[ent_off[i] + k], meta[ent_off[i] + k]);
+        HIPCK(c, hipMemcpyAsync(c->d_words + eo[i], w.data(), (size_t)cnt[i] * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+        if (cna[i]) HIPCK(c, hipMemcpyAsync(c->d_aux + ao[i], aux + aux_off[i], (size_t)cna[i] * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));                       // (w is reused)
+        const int32_t id = ids[i];
+        c->h_ent_off[id] = eo[i]; c->h_aux_off[id] = ao[i]; c->h_n_ent[id] = cnt[i]; c->h_n_aux[id] = cna[i];
+    }
+    TRY(stage_begin(c, (size_t)n * 32 + 256));
+    STAGE(dids, c, ids, n); STAGE(deo, c, eo.data(), n); STAGE(dao, c, ao.data(), n); STAGE(dne, c, cnt.data(), n); STAGE(dna, c, cna.data(), n);
+    TRY(stage_flush(c));
+    hipLaunchKernelGGL(k_set_rows, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dids, deo, dao, dne, dna, c->d_ent_off,
+                       c->d_aux_off, c->d_n_ent, c->d_n_aux);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->used_ent = ue;
+    c->used_aux = ua;
     return MAPLE_OK;
 }
 

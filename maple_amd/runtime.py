@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(HERE, "libmaple_hip.so")
 
 EXPORTS = [
     "maple_abi_version", "maple_create", "maple_destroy", "maple_last_error", "maple_set_model", "maple_get_model",
-    "maple_lists_upload", "maple_lists_sizes", "maple_lists_download", "maple_arena_mark", "maple_arena_release",
+    "maple_lists_upload", "maple_lists_update", "maple_lists_sizes", "maple_lists_download", "maple_arena_mark", "maple_arena_release",
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
     "maple_evaluate_placement_batch", "maple_update_partials", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
@@ -155,6 +155,14 @@ class Device:
         self._ck(self.lib.maple_lists_upload(self.h, len(pl), _ptr(pl.ent_off), _ptr(pl.pos), _ptr(pl.meta),
                                              _ptr(pl.aux_off), _ptr(pl.aux), C.byref(first)))
         return np.arange(first.value, first.value + len(pl), dtype=np.int32)
+
+    def update_lists(self, ids, lists):
+        """maple_lists_update: new contents (reference tuple form) for the existing list ids; the ids stay valid."""
+        pl = pack_lists(lists, self.u)
+        ids = _i32(ids)
+        assert len(ids) == len(pl)
+        self._ck(self.lib.maple_lists_update(self.h, len(pl), _ptr(ids), _ptr(pl.ent_off), _ptr(pl.pos), _ptr(pl.meta),
+                                             _ptr(pl.aux_off), _ptr(pl.aux)))
 
     def upload(self, lists):
         """Upload genome lists given in the reference's tuple form; returns their ids."""

@@ -84,6 +84,30 @@ def test_appendProbNode(env):
     assert total > 100
 
 
+def test_lists_update_keeps_ids_and_changes_contents(env):
+    """maple_lists_update: existing ids get new contents -- shorter ones in place, longer ones in fresh room --
+    and every operator sees the new words under the old id."""
+    f, dev, o = env
+    mid, recs = next(iter(by_model(f, "appendProbNode").items()))
+    recs = recs[:40]
+    dev.set_model(**model_args(f["models"][mid]))
+    o.set_model(**model_args(f["models"][mid]))
+    mark = dev.mark()
+    n = len(recs)
+    ids = dev.upload([tup(r["P"]) for r in recs] + [tup(r["C"]) for r in recs])
+    before = dev.stats()["n_lists"]
+    # the parent lists are replaced by the parent lists of the NEXT record (other lengths: some fit, some do not)
+    rolled = recs[1:] + recs[:1]
+    dev.update_lists(ids[:n], [tup(r["P"]) for r in rolled])
+    assert dev.stats()["n_lists"] == before
+    assert [len(x) for x in dev.download(ids[:n])] == [len(tup(r["P"])) for r in rolled]
+    got = dev.append_batch(ids[:n], ids[n:], [r["isTipC"] for r in recs], [r["bLen"] for r in recs])
+    for g, r, rp in zip(got, recs, rolled):
+        want = o.appendProbNode(tup(rp["P"]), tup(r["C"]), r["isTipC"], r["bLen"])
+        assert close(float(g), want, REL), (g, want)
+    dev.release(mark)
+
+
 def test_mergeVectors(env):
     f, dev, o = env
     total = 0
