@@ -195,6 +195,36 @@ def test_batched_placement_equals_single_query_search(world):
     assert 0 < n_minor < len(queries)
 
 
+def test_update_partials_on_a_tree_with_local_references(world):
+    """maple_update_partials at size, in every model mode, on the tree with MAT local references (lists cross reference
+    frames on their way up and down): 150 simultaneous branch-length changes repaired incrementally, then every list of
+    the tree against a full rebuild -- "not different" by the reference's own thresholds (areVectorsDifferent, both ways:
+    the repair stops where that function says so) -- and the tree log-likelihood of both."""
+    from maple_amd.mat import add_local_references
+    from maple_amd.tree_host import HostTree, rebuild_genome_lists, tree_log_likelihood, update_genome_lists
+    _, data, dev, orc, mirror = world
+    mark = dev.mark()
+    tree = HostTree.from_mirror(mirror)
+    assert add_local_references(dev, tree, 30) > 10
+    rng = np.random.default_rng(17)
+    cand = np.nonzero((mirror.parent >= 0) & (mirror.dist > 1e-5))[0]
+    pick = rng.choice(cand, size=150, replace=False)
+    for v in pick:
+        tree.dist[v] = tree.dist[v] * 2.5
+    replaced = update_genome_lists(dev, tree, pick.tolist())
+    assert replaced > 300
+    lk_upd, _ = tree_log_likelihood(dev, tree)
+    lo, ur, ul, tu = rebuild_genome_lists(dev, tree)
+    for a, b in ((tree.id_lower, lo), (tree.id_upRight, ur), (tree.id_upLeft, ul), (tree.id_totUp, tu)):
+        assert np.array_equal(a >= 0, b >= 0)
+        ok = a >= 0
+        assert not (dev.differ_batch(a[ok], b[ok]) | dev.differ_batch(b[ok], a[ok])).any()
+    tree.id_lower, tree.id_upRight, tree.id_upLeft, tree.id_totUp = lo, ur, ul, tu
+    lk_full, _ = tree_log_likelihood(dev, tree)
+    assert abs(lk_upd - lk_full) <= 1e-9 * abs(lk_full)
+    dev.release(mark)
+
+
 def test_batch_kernel_with_queries_longer_than_the_lds_stage():
     """k_append_queries keeps the tile's query words in LDS up to 192 entries and reads longer lists from memory: both
     paths against the oracle (samples with ~150 and ~400 differences give lists on either side of the limit)."""
