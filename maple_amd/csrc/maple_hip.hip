@@ -20,6 +20,7 @@ using namespace maple;
 
 // RCCL is used through dlopen only (maple_comm_*, below): types from the header, no link-time dependency
 #include <dlfcn.h>
+#include <hipcub/hipcub.hpp>
 #include <rccl/rccl.h>
 struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *);
@@ -142,6 +143,8 @@ struct maple_ctx {
     void *rccl_comm = nullptr;
     int rccl_world = 1, rccl_rank = 0;
     DevBuf<unsigned long long> s_comm_u64;
+    DevBuf<long long> s_fan[6];        // per (query, frame) item of a nesting level: capacities, offsets, sizes (k_fan_*)
+    DevBuf<uint8_t> s_fan_tmp;
     DevBuf<SScan> t_scan;              // the tree in the searches' depth-first order (search_dev.h), per effectivelyNon0BLen
     DevBuf<int32_t> t_scan_parent;
     bool scan_valid = false;
@@ -2309,6 +2312,129 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
 #ifndef MAPLE_WIDE_BUDGET_DEFAULT
 #define MAPLE_WIDE_BUDGET_DEFAULT 256
 #endif
+// ---- the removed lists of a batch of whole-tree searches in every MAT reference frame of one nesting level, on the device --
+// R[k * nF + f] = list id of query k's removed list expressed in frame f (-1: not yet).  One item per (query, frame of the
+// level): the list in the parent frame goes down through the mutations of the frame's node (passGenomeListThroughBranch,
+// M:7119 / 7342).  Sizes, scratch offsets, arena offsets and the rows of the list table are all produced here (two prefix
+// sums per level); the host only learns the totals.
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_fan_cap(long long nItems, int nF, int a, int nL, const int32_t *R,
+                                                         const int32_t *frameParent, const int32_t *frameMut, ArenaView av,
+                                                         MutView mv, long long *cap)
+{
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nItems; t += (long long)gridDim.x * blockDim.x) {
+        const long long k = t / nL;
+        const int f = a + (int)(t - k * nL);
+        long long cp = 0;
+        if (R[k * nF + f] < 0) {
+            const int src = R[k * nF + frameParent[f]];
+            if (src >= 0) cp = (long long)av.n_ent[src] + 2ll * mv.cnt[frameMut[f]];
+        }
+        cap[t] = cp;
+    }
+}
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_fan_pass(int lRef, ArenaView av, MutView mv, long long nItems, int nF, int a, int nL,
+                                                          const int32_t *R, const int32_t *frameParent, const int32_t *frameMut,
+                                                          const long long *cap, const long long *woff, uint2 *words, double *aux,
+                                                          long long *ne, long long *na)
+{
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nItems; t += (long long)gridDim.x * blockDim.x) {
+        long long e = 0, x = 0;
+        if (cap[t] > 0) {
+            const long long k = t / nL;
+            const int f = a + (int)(t - k * nL);
+            Writer w;
+            w.init(words + woff[t], aux + 5 * woff[t]);
+            const int id = frameMut[f];
+            e = pass_walk(lRef, list_ref(av, R[k * nF + frameParent[f]]), mv.mut3 + 3 * mv.off[id], mv.cnt[id], false, w);
+            x = w.na;
+        }
+        ne[t] = e; na[t] = x;
+    }
+}
+// one wavefront per item: scratch -> arena, the list's row of the list table, its id into R
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_fan_commit(long long nItems, int nF, int a, int nL, int32_t *R, const long long *woff,
+                                                            const long long *ne, const long long *na, const long long *de,
+                                                            const long long *da, long long baseE, long long baseA, int32_t firstId,
+                                                            const uint2 *sw, const double *sa, uint2 *words, double *aux,
+                                                            int64_t *t_ent_off, int64_t *t_aux_off, int32_t *t_n_ent, int32_t *t_n_aux)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long t = wave; t < nItems; t += nwaves) {
+        const long long e = ne[t], x = na[t];
+        if (lane == 0) {
+            t_ent_off[firstId + t] = baseE + de[t]; t_aux_off[firstId + t] = baseA + da[t];
+            t_n_ent[firstId + t] = (int32_t)e; t_n_aux[firstId + t] = (int32_t)x;
+            if (e > 0) { const long long k = t / nL; R[k * nF + a + (int)(t - k * nL)] = firstId + (int32_t)t; }
+        }
+        const uint2 *s1 = sw + woff[t];
+        uint2 *d1 = words + baseE + de[t];
+        for (long long i = lane; i < e; i += 64) d1[i] = s1[i];
+        const double *s2 = sa + 5 * woff[t];
+        double *d2 = aux + baseA + da[t];
+        for (long long i = lane; i < x; i += 64) d2[i] = s2[i];
+    }
+}
+
+static int fan_out_level(maple_ctx *c, int m, int nF, int a, int b, int32_t *dR, const int32_t *dFrameParent, const int32_t *dFrameMut,
+                         DevBuf<long long> *buf /* [6] */, DevBuf<uint8_t> &tmp, double *bytesRead)
+{
+    const int nL = b - a;
+    const long long nItems = (long long)m * nL;
+    if (nItems <= 0) return MAPLE_OK;
+    if (nItems > 0x7fffffffLL) return fail(c, MAPLE_ERR_ARG, "too many (query, frame) items in one level");
+    for (int i = 0; i < 6; i++) HIPCK(c, buf[i].reserve((size_t)nItems + 1));
+    long long *cap = buf[0].p, *woff = buf[1].p, *ne = buf[2].p, *na = buf[3].p, *de = buf[4].p, *da = buf[5].p;
+    const int grid = (int)std::min<long long>((nItems + MAPLE_BLOCK - 1) / MAPLE_BLOCK, 256 * 8);
+    hipLaunchKernelGGL(k_fan_cap, dim3(grid), dim3(MAPLE_BLOCK), 0, c->stream, nItems, nF, a, nL, dR, dFrameParent, dFrameMut, view(c),
+                       mview(c), cap);
+    size_t tb = 0;
+    HIPCK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cap, woff, (int)nItems, c->stream));
+    HIPCK(c, tmp.reserve(tb + 256));
+    HIPCK(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cap, woff, (int)nItems, c->stream));
+    long long lastOff = 0, lastCap = 0;
+    HIPCK(c, hipMemcpyAsync(&lastOff, woff + nItems - 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(&lastCap, cap + nItems - 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    const long long tot = lastOff + lastCap;
+    if (tot == 0) return MAPLE_OK;
+    HIPCK(c, c->s_words.reserve((size_t)tot));
+    HIPCK(c, c->s_aux.reserve((size_t)(5 * tot)));
+    hipLaunchKernelGGL(k_fan_pass, dim3(grid), dim3(MAPLE_BLOCK), 0, c->stream, c->lRef, view(c), mview(c), nItems, nF, a, nL, dR,
+                       dFrameParent, dFrameMut, cap, woff, c->s_words.p, c->s_aux.p, ne, na);
+    HIPCK(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, ne, de, (int)nItems, c->stream));
+    HIPCK(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, na, da, (int)nItems, c->stream));
+    long long tail[4] = {0, 0, 0, 0};
+    HIPCK(c, hipMemcpyAsync(&tail[0], de + nItems - 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(&tail[1], ne + nItems - 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(&tail[2], da + nItems - 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(&tail[3], na + nItems - 1, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    const long long totE = tail[0] + tail[1], totA = tail[2] + tail[3];
+    const int64_t first = (int64_t)c->h_n_ent.size();
+    if (c->used_ent + totE > c->cap_ent || c->used_aux + totA > c->cap_aux)
+        return fail(c, MAPLE_ERR_NOMEM, "arena full while expressing %d removed lists in %d reference frames", m, nL);
+    if (first + nItems > c->cap_lists) return fail(c, MAPLE_ERR_NOMEM, "list table full (%lld)", (long long)c->cap_lists);
+    const int gridW = (int)std::min<long long>((nItems + MAPLE_BLOCK / 64 - 1) / (MAPLE_BLOCK / 64), 256 * 8);
+    hipLaunchKernelGGL(k_fan_commit, dim3(gridW), dim3(MAPLE_BLOCK), 0, c->stream, nItems, nF, a, nL, dR, woff, ne, na, de, da,
+                       (long long)c->used_ent, (long long)c->used_aux, (int32_t)first, c->s_words.p, c->s_aux.p, c->d_words, c->d_aux,
+                       c->d_ent_off, c->d_aux_off, c->d_n_ent, c->d_n_aux);
+    HIPCK(c, hipGetLastError());
+    // the host's copy of the new rows
+    c->h_ent_off.resize((size_t)(first + nItems)); c->h_aux_off.resize((size_t)(first + nItems));
+    c->h_n_ent.resize((size_t)(first + nItems)); c->h_n_aux.resize((size_t)(first + nItems));
+    HIPCK(c, hipMemcpyAsync(c->h_ent_off.data() + first, c->d_ent_off + first, (size_t)nItems * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->h_aux_off.data() + first, c->d_aux_off + first, (size_t)nItems * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->h_n_ent.data() + first, c->d_n_ent + first, (size_t)nItems * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->h_n_aux.data() + first, c->d_n_aux + first, (size_t)nItems * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->used_ent += totE;
+    c->used_aux += totA;
+    *bytesRead += 8.0 * (double)totE + 8.0 * (double)totA;
+    return MAPLE_OK;
+}
+
 extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *nodes, const maple_search_params *sp,
                                       int32_t ws_entries_per_lane, int32_t *bestNode, double *bestScore, double *blen3,
                                       int32_t *placement, double *improvement, double *currentLK, int32_t *nAppend,
@@ -2639,30 +2765,24 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                         R[(size_t)k * nF + cur[k]] = out[i];
                     }
                 }
+                // down, one nesting level per round: on the device (k_fan_*), all (query, frame) items of the level at once
+                double qBytes = 0.0;                                   // every frame's copy of the query that is read
+                for (size_t k = 0; k < R.size(); k++) if (R[k] >= 0) qBytes += 8.0 * c->h_n_ent[R[k]] + 8.0 * c->h_n_aux[R[k]];
+                TRY(h2d(c, c->s_i32[6], R.data(), R.size()));
+                {
+                    std::vector<int32_t> fm((size_t)nF, 0);
+                    for (int f = 1; f < nF; f++) fm[f] = c->h_tree_mut[F.frameNode[f]];
+                    TRY(h2d(c, c->s_i32[4], F.frameParent.data(), (size_t)nF));
+                    TRY(h2d(c, c->s_i32[5], fm.data(), (size_t)nF));
+                    HIPCK(c, hipStreamSynchronize(c->stream));
+                }
                 int a = 1;
-                for (size_t l = 0; l < F.levelStart.size(); l++) {     // down, one nesting level per round
+                for (size_t l = 0; l < F.levelStart.size(); l++) {
                     const int b = F.levelStart[l];
-                    src.clear(); ml.clear();
-                    std::vector<size_t> where;
-                    for (int k = 0; k < m; k++)
-                        for (int f = a; f < b; f++)
-                            if (R[(size_t)k * nF + f] < 0) {
-                                where.push_back((size_t)k * nF + f);
-                                src.push_back(R[(size_t)k * nF + F.frameParent[f]]);
-                                ml.push_back(c->h_tree_mut[F.frameNode[f]]);
-                            }
-                    if (!where.empty()) {
-                        dir.assign(where.size(), 0);
-                        out.resize(where.size());
-                        TRY(maple_pass_branch_batch(c, (int32_t)where.size(), src.data(), ml.data(), dir.data(), out.data()));
-                        for (size_t i = 0; i < where.size(); i++) R[where[i]] = out[i];
-                    }
+                    TRY(fan_out_level(c, m, nF, a, b, c->s_i32[6].p, c->s_i32[4].p, c->s_i32[5].p, c->s_fan, c->s_fan_tmp, &qBytes));
                     a = b;
                 }
                 if (dbgT) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] t=%.1f ms: removed lists in all %d frames\n", tms(tStart, tnow()), nF); }
-                TRY(h2d(c, c->s_i32[6], R.data(), R.size()));
-                double qBytes = 0.0;                                   // every frame's copy of the query that is read
-                for (size_t k = 0; k < R.size(); k++) if (R[k] >= 0) qBytes += 8.0 * c->h_n_ent[R[k]] + 8.0 * c->h_n_aux[R[k]];
                 TRY(launch_place_score(c, m, nF, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, c->t_scored_frame.p, 0, 0.0,
                                        c->s_cache.p, nT, c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p, MAPLE_K_SPR_SCORE,
                                        (double)m * c->scored_bytes_total + qBytes));
