@@ -138,6 +138,8 @@ struct maple_ctx {
     int32_t tree_max_ent = 0;          // longest genome list of the uploaded tree (entries)
     int32_t n_scored = 0;              // nodes with a probVectTotUp, sorted by list length: t_i32[8] = list ids, t_scored_col = node ids
     DevBuf<int32_t> t_scored_col, t_scored_frame;
+    DevBuf<int4> t_frame_chunks;       // trees with local references: the scored candidates in chunks of <= 64 within one frame
+    int32_t n_frame_chunks = 0;
     DevBuf<uint8_t> s_tilebest;        // (query, 64-candidate tile) records of maple_append_queries_argmax_dev
     void *rccl_lib = nullptr;          // RCCL, loaded on first use (maple_comm_*)
     void *rccl_comm = nullptr;
@@ -334,8 +336,11 @@ template <bool RV, bool U, bool SS>
 __global__ __launch_bounds__(MAPLE_LDS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ, const int32_t *qList, int nC, const int32_t *cand,
                           int isTip, double bLen, double *out, long long ldOut, const int32_t *outCol, const uint8_t *qTip,
-                          const double *qBLen, int *counter, TileBest *tileBest, const int32_t *visitRank)
+                          const double *qBLen, int *counter, TileBest *tileBest, const int32_t *visitRank,
+                          const int4 *chunkTab, int nChunkTab, int nF)
 {
+    // chunkTab (trees with MAT local references): the chunks are given as {first candidate, candidates (<= 64), reference
+    // frame, -}, each within ONE frame, and query q's list is qList[q * nF + frame] -- the query expressed in that frame
     constexpr int NW = MAPLE_LDS_BLOCK / 64;
     __shared__ Lds lds;
     __shared__ int cwoff[65], caoff[65];
@@ -351,7 +356,7 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nChunks = (nC + 63) / 64, nQB = (nQ + MAPLE_LDS_QB - 1) / MAPLE_LDS_QB;
+    const int nChunks = chunkTab ? nChunkTab : (nC + 63) / 64, nQB = (nQ + MAPLE_LDS_QB - 1) / MAPLE_LDS_QB;
     const long long units = (long long)nChunks * nQB;
     unsigned long long *myq = qW + wave * MAPLE_QLDS;
     double *myqR = qR + wave * MAPLE_QLDS;
@@ -363,9 +368,11 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
         const int unit = sUnit;
         if (unit >= units) break;
         const int ch = unit / nQB, qb = unit - ch * nQB;
+        int c0 = ch * 64, nCk = min(64, nC - ch * 64), frame = 0;
+        if (chunkTab) { const int4 u = chunkTab[ch]; c0 = u.x; nCk = u.y; frame = u.z; }
         // this lane's candidate and where its list sits in the staged chunk
-        const int k = ch * 64 + lane;
-        const int cl = k < nC ? cand[k] : -1;
+        const int k = c0 + lane;
+        const int cl = lane < nCk ? cand[k] : -1;
         if (wave == 0) {
             int ne = cl >= 0 ? av.n_ent[cl] : 0, na = cl >= 0 ? av.n_aux[cl] : 0;
             int pw = ne, pa = na;                                          // inclusive prefix sums over the 64 lists
@@ -381,9 +388,8 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
         if (stagedC) {                                                     // 4 lists per wavefront, coalesced within a list
             constexpr int perWave = (64 + NW - 1) / NW;
             for (int i = wave * perWave; i < min(64, wave * perWave + perWave); i++) {
-                const int kk = ch * 64 + i;
-                if (kk >= nC) break;
-                const int li = cand[kk];
+                if (i >= nCk) break;
+                const int li = cand[c0 + i];
                 const unsigned long long *sw = (const unsigned long long *)(av.words + av.ent_off[li]);
                 const double *sa = av.aux + av.aux_off[li];
                 const int w0 = cwoff[i], nw = cwoff[i + 1] - w0, a0 = caoff[i], na2 = caoff[i + 1] - a0;
@@ -403,7 +409,7 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
             qi = __builtin_amdgcn_readfirstlane(qi);
             const int q = qb * MAPLE_LDS_QB + qi;
             if (qi >= MAPLE_LDS_QB || q >= nQ) break;
-            const int ql = qList[q];
+            const int ql = chunkTab ? qList[(long long)q * nF + frame] : qList[q];
             const int nq = av.n_ent[ql];
             const ListRef qref = list_ref(av, ql);
             const bool stagedQ = nq <= MAPLE_QLDS;                          // wave-uniform
@@ -1919,9 +1925,9 @@ static int ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b, int kind = 0, dou
 static int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int32_t *qList, int nC, const int32_t *cand,
                                  int isTip, double bLen, double *out, long long ldOut, const int32_t *outCol,
                                  const uint8_t *qTip, const double *qBLen, int kind, double algBytes, TileBest *tileBest = nullptr,
-                                 const int32_t *visitRank = nullptr)
+                                 const int32_t *visitRank = nullptr, const int4 *chunkTab = nullptr, int nChunkTab = 0, int nF = 1)
 {
-    const long long tiles = (long long)nQ * ((nC + 63) / 64);
+    const long long tiles = (long long)nQ * (chunkTab ? nChunkTab : (nC + 63) / 64);
     if (tiles > 0x7fffffffLL - (1 << 20)) return fail(c, MAPLE_ERR_ARG, "nQ x nC too large for one launch");
     if (!c->d_tile_counters) HIPCK(c, hipMalloc((void **)&c->d_tile_counters, 64 * sizeof(int32_t)));
     int32_t *counter = c->d_tile_counters + (c->tile_counter_next++ & 63);
@@ -1932,9 +1938,9 @@ static int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int3
     TRY(ev_pair(c, &e0, &e1, kind, (double)nQ * (double)nC, algBytes));
     HIPCK(c, hipEventRecord(e0, s));
     static const bool noLds = getenv("MAPLE_APPEND_GLOBAL") != nullptr;
-    if (nQ >= 32 && !noLds) {
+    if (chunkTab || (nQ >= 32 && !noLds)) {
         // enough queries to reuse a staged candidate chunk: the LDS kernel, one workgroup of 16 wavefronts per CU
-        const long long units = (long long)((nC + 63) / 64) * ((nQ + MAPLE_LDS_QB - 1) / MAPLE_LDS_QB);
+        const long long units = (long long)(chunkTab ? nChunkTab : (nC + 63) / 64) * ((nQ + MAPLE_LDS_QB - 1) / MAPLE_LDS_QB);
         const int gridL = units < 256 ? (int)units : 256;
         const bool rv_ = c->dm.useRateVariation;
         const size_t dyn = rv_ ? lds_kernel_dyn_bytes<true>() : lds_kernel_dyn_bytes<false>();
@@ -1948,7 +1954,8 @@ static int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int3
             attrSet = true;
         }
         DISPATCH3(c, k_append_queries_lds, <<<gridL, MAPLE_LDS_BLOCK, dyn, s>>>(c->d_model, view(c), nQ, qList, nC, cand, isTip, bLen, out,
-                                                                              ldOut, outCol, qTip, qBLen, counter, tileBest, visitRank));
+                                                                              ldOut, outCol, qTip, qBLen, counter, tileBest, visitRank,
+                                                                              chunkTab, nChunkTab, nF));
     } else
     DISPATCH3(c, k_append_queries, <<<grid, MAPLE_BLOCK, 0, s>>>(c->d_model, view(c), nQ, qList, nC, cand, isTip, bLen, out, ldOut,
                                                                   outCol, qTip, qBLen, counter, tileBest, visitRank));
@@ -2293,10 +2300,25 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         for (int i = 0; i < n; i++) if (totUp[i] >= 0) col.push_back(i);
         if (getenv("MAPLE_SCORED_ORDER_LENGTH"))
             std::stable_sort(col.begin(), col.end(), [&](int a, int b) { return c->h_n_ent[totUp[a]] < c->h_n_ent[totUp[b]]; });
+        else if (c->tree_has_mut)                                          // by reference frame, then depth-first: a chunk of 64
+            std::stable_sort(col.begin(), col.end(), [&](int a, int b) {     // candidates shares ONE copy of the query
+                return recs[a].frameOf != recs[b].frameOf ? recs[a].frameOf < recs[b].frameOf : recs[a].preRank < recs[b].preRank; });
         else
             std::stable_sort(col.begin(), col.end(), [&](int a, int b) { return recs[a].preRank < recs[b].preRank; });
         std::vector<int32_t> ids(col.size()), rank(col.size()), fr(col.size());
         for (size_t i = 0; i < col.size(); i++) { ids[i] = totUp[col[i]]; rank[i] = recs[col[i]].preRank; fr[i] = recs[col[i]].frameOf; }
+        c->n_frame_chunks = 0;
+        if (c->tree_has_mut && !getenv("MAPLE_SCORED_ORDER_LENGTH")) {
+            std::vector<int4> chunks;
+            for (size_t i = 0; i < col.size();) {
+                size_t j = i;
+                while (j < col.size() && j - i < 64 && fr[j] == fr[i]) j++;
+                chunks.push_back(make_int4((int)i, (int)(j - i), fr[i], 0));
+                i = j;
+            }
+            TRY(h2d(c, c->t_frame_chunks, chunks.data(), chunks.size()));
+            c->n_frame_chunks = (int32_t)chunks.size();
+        }
         c->n_scored = (int32_t)col.size();
         c->scored_bytes_total = 0.0;                                       // 8 E + 8 A + 8 (result) per candidate
         for (size_t i = 0; i < col.size(); i++) c->scored_bytes_total += 8.0 * c->h_n_ent[ids[i]] + 8.0 * c->h_n_aux[ids[i]] + 8.0;
@@ -2783,6 +2805,12 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                     a = b;
                 }
                 if (dbgT) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] t=%.1f ms: removed lists in all %d frames\n", tms(tStart, tnow()), nF); }
+                if (c->n_frame_chunks > 0 && m >= 32 && !getenv("MAPLE_APPEND_GLOBAL"))
+                    TRY(launch_append_queries(c, c->stream, m, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, 0, 0.0, c->s_cache.p, nT,
+                                              c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p, MAPLE_K_SPR_SCORE,
+                                              (double)m * c->scored_bytes_total + qBytes, nullptr, nullptr, c->t_frame_chunks.p,
+                                              c->n_frame_chunks, nF));
+                else
                 TRY(launch_place_score(c, m, nF, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, c->t_scored_frame.p, 0, 0.0,
                                        c->s_cache.p, nT, c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p, MAPLE_K_SPR_SCORE,
                                        (double)m * c->scored_bytes_total + qBytes));
