@@ -197,6 +197,16 @@ typedef struct {
                                                    (0 = default 256, < 0 = never); results do not depend on it */
 } maple_search_params;
 
+/* A local change of the uploaded tree -- what placeSampleOnTree (M:8300-8722) and the updatePartials after it leave behind:
+ * a few nodes with new relatives, branch lengths or list ids, one or two new nodes.  nodes[i] gets the record
+ * (up, child0, child1, dist, isTip, lower, upRight, upLeft, totUp)[i]; ids >= the old node count are new nodes (all of them
+ * listed; nTotal = the new count).  The root and the mutation lists (MAT reference nodes) do not change this way: re-upload
+ * the tree for that.  The single-query placement search (maple_placement_search_batch with <= 4 queries: the serial
+ * placement phase, M:11744-11752) then runs on the patched tree at once; the tables of the batched placement search and of
+ * the SPR search are rebuilt from the library's own copy of the tree before their next use. */
+int maple_tree_patch(maple_ctx *ctx, int32_t nTotal, int32_t nTouched, const int32_t *nodes, const int32_t *up,
+                     const int32_t *child0, const int32_t *child1, const double *dist, const uint8_t *isTip,
+                     const int32_t *lower, const int32_t *upRight, const int32_t *upLeft, const int32_t *totUp);
 /* The worker body of startTopologyUpdatesParallel (M:9615-9711) for n pruned nodes, each running
  * findBestParentTopology (M:6817-7724) entirely on the GPU (one lane per query).  Per query:
  *   bestNode/bestScore/blen3 = findBestParentTopology's (bestNode, bestScore, bestBranchLengths);

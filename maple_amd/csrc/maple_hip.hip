@@ -73,6 +73,8 @@ struct PlaceMeta {                     // derived from the uploaded tree, rebuil
     std::vector<int32_t> order;                    // nodes reachable from the root, depth-first
     int32_t rootVect = -1;                         // rootVector(probVect[root]) of the uploaded tree (list id), kept while it lives
     std::vector<int32_t> h_candIdx, h_leafIdx;     // per node: column in the score / minor matrix or -1
+    std::vector<int32_t> h_candList, h_candFrame, h_leafList, h_leafFrame;   // host copies of the column arrays (maple_tree_patch)
+    bool scanStale = false;                        // the tree changed through maple_tree_patch: h_scan / d_scan / order are old
     std::vector<ScanRec> h_scan;                   // the tree in traversal order (placement_dev.h)
     DevBuf<ScanRec> d_scan;
     DevBuf<int32_t> d_frameOf, d_candIdx, d_leafIdx, d_candList, d_candFrame, d_leafList, d_leafFrame;
@@ -171,6 +173,8 @@ struct maple_ctx {
     int32_t *d_tile_counters = nullptr;    // ring of tile counters for the dynamically scheduled kernels
     int tile_counter_next = 0;
     void *upd = nullptr;               // UpdateScratch of maple_update_partials (update_host.h)
+    bool tree_stale = false;           // maple_tree_patch changed the host copy of the tree; the device tables of the SPR search
+                                       // (and, for batches, of the placement search) are rebuilt from it before their next use
     // Staging of the small per-call argument columns of the batch operators: they are gathered in pinned host memory and go
     // to the device in ONE copy per call (a dozen separate copies from pageable memory cost ~0.2 ms per call, most of a
     // single-change updatePartials).  Two arenas used in turn: see stage_begin.
@@ -2120,6 +2124,7 @@ extern "C" int maple_argmax_allreduce_dev(maple_ctx *c, int32_t n, double *score
     return MAPLE_OK;
 }
 
+static int tree_rebuild_from_host(maple_ctx *c);
 #include "placement_host.h"
 #include "update_host.h"
 
@@ -2328,6 +2333,128 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         HIPCK(c, hipStreamSynchronize(c->stream));
     }
     c->tree_set = true;
+    c->tree_stale = false;
+    return MAPLE_OK;
+}
+
+// every device table rebuilt from the host's own copy of the tree (after maple_tree_patch, before a search that needs them)
+static int tree_rebuild_from_host(maple_ctx *c)
+{
+    const std::vector<int32_t> up = c->h_tree_up, c0 = c->h_tree_c0, c1 = c->h_tree_c1, lower = c->h_tree_lower,
+                               upRight = c->h_tree_upRight, upLeft = c->h_tree_upLeft, totUp = c->h_tree_totUp, mut = c->h_tree_mut;
+    const std::vector<double> dist = c->h_tree_dist;
+    const std::vector<uint8_t> tip = c->h_tree_tip;
+    return maple_tree_upload(c, (int32_t)up.size(), c->dtree.root, up.data(), c0.data(), c1.data(), dist.data(), tip.data(),
+                             lower.data(), upRight.data(), upLeft.data(), totUp.data(), mut.data());
+}
+
+// A local change of the uploaded tree -- what placeSampleOnTree (M:8300-8722) and the updatePartials after it leave behind:
+// a few nodes with new relatives, branch lengths or list ids, one or two new nodes.  nodes[i] gets the record
+// (up, child0, child1, dist, isTip, lower, upRight, upLeft, totUp)[i]; ids >= the old node count are new nodes (all of them
+// must be listed; nTotal = the new count).  Mutation lists (MAT reference nodes) and the root do not change this way:
+// re-upload the tree for that.  The host copy of the tree and the candidate / leaf columns of the placement search are
+// updated in place (a few 4-byte writes); the linearised tables of the batched placement search and of the SPR search are
+// only marked stale and are rebuilt from the host copy before their next use -- so the serial phase (one placement, one
+// patch, one placement, ...) never pays for the whole tree.
+extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, const int32_t *nodes, const int32_t *up,
+                                const int32_t *child0, const int32_t *child1, const double *dist, const uint8_t *isTip,
+                                const int32_t *lower, const int32_t *upRight, const int32_t *upLeft, const int32_t *totUp)
+{
+    if (!c || nTouched < 0 || (nTouched && (!nodes || !up || !child0 || !child1 || !dist || !isTip || !lower || !upRight || !upLeft || !totUp)))
+        return MAPLE_ERR_ARG;
+    if (!c->tree_set) return fail(c, MAPLE_ERR_STATE, "maple_tree_upload has not been called");
+    HIPCK(c, hipSetDevice(c->device));
+    const int32_t nOld = (int32_t)c->h_tree_up.size(), root = c->dtree.root;
+    if (nTotal < nOld) return fail(c, MAPLE_ERR_ARG, "a patch cannot remove nodes (%d < %d)", nTotal, nOld);
+    const int32_t nl = (int32_t)c->h_n_ent.size();
+    std::vector<uint8_t> seenNew((size_t)(nTotal - nOld), 0);
+    for (int i = 0; i < nTouched; i++) {
+        const int v = nodes[i];
+        if (v < 0 || v >= nTotal) return fail(c, MAPLE_ERR_ARG, "nodes[%d] = %d is not a node", i, v);
+        if (v >= nOld) seenNew[v - nOld] = 1;
+        if (up[i] < -1 || up[i] >= nTotal || child0[i] < -1 || child0[i] >= nTotal || child1[i] < -1 || child1[i] >= nTotal
+            || (child0[i] < 0) != (child1[i] < 0))
+            return fail(c, MAPLE_ERR_ARG, "node %d: relative out of range, or only one child", v);
+        if ((up[i] < 0) != (v == root)) return fail(c, MAPLE_ERR_ARG, "node %d: the root cannot change in a patch", v);
+        for (int32_t id : {lower[i], upRight[i], upLeft[i], totUp[i]})
+            if (id < -1 || id >= nl) return fail(c, MAPLE_ERR_ARG, "node %d: %d is not a list id", v, id);
+    }
+    for (size_t k = 0; k < seenNew.size(); k++)
+        if (!seenNew[k]) return fail(c, MAPLE_ERR_ARG, "new node %d is not in the patch", nOld + (int)k);
+    // ---- the host copy
+    for (auto *vec : {&c->h_tree_up, &c->h_tree_c0, &c->h_tree_c1, &c->h_tree_lower, &c->h_tree_upRight, &c->h_tree_upLeft,
+                      &c->h_tree_totUp, &c->h_tree_mut})
+        vec->resize((size_t)nTotal, -1);
+    c->h_tree_dist.resize((size_t)nTotal, 0.0);
+    c->h_tree_tip.resize((size_t)nTotal, 0);
+    for (int i = 0; i < nTouched; i++) {
+        const int v = nodes[i];
+        c->h_tree_up[v] = up[i]; c->h_tree_c0[v] = child0[i]; c->h_tree_c1[v] = child1[i];
+        c->h_tree_dist[v] = dist[i]; c->h_tree_tip[v] = isTip[i];
+        c->h_tree_lower[v] = lower[i]; c->h_tree_upRight[v] = upRight[i]; c->h_tree_upLeft[v] = upLeft[i]; c->h_tree_totUp[v] = totUp[i];
+    }
+    c->dtree.n = nTotal;
+    c->tree_stale = true;
+    c->scan_valid = false;
+    PlaceMeta &M = *c->place;
+    if (!M.valid) return MAPLE_OK;                                        // nothing of the placement search to keep up to date
+    // ---- the placement search's columns
+    M.scanStale = true;
+    M.frameOf.resize((size_t)nTotal, -1);
+    M.h_candIdx.resize((size_t)nTotal, -1);
+    M.h_leafIdx.resize((size_t)nTotal, -1);
+    for (bool again = true; again;) {                                     // a new node lives in its parent's reference frame
+        again = false;
+        for (int i = 0; i < nTouched; i++) {
+            const int v = nodes[i];
+            if (M.frameOf[v] >= 0) continue;
+            const int u = c->h_tree_up[v];
+            if (u >= 0 && M.frameOf[u] >= 0) { M.frameOf[v] = M.frameOf[u]; again = true; }
+        }
+    }
+    for (int i = 0; i < nTouched; i++)
+        if (M.frameOf[nodes[i]] < 0) return fail(c, MAPLE_ERR_ARG, "new node %d is not attached to the tree", nodes[i]);
+    auto poke = [&](DevBuf<int32_t> &b, size_t at, int32_t value) -> int {
+        if (at >= b.cap) { M.valid = false; return MAPLE_OK; }            // out of room: the next search rebuilds everything
+        HIPCK(c, hipMemcpyAsync(b.p + at, &value, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));                       // (`value` is a local)
+        return MAPLE_OK;
+    };
+    for (int i = 0; i < nTouched && M.valid; i++) {
+        const int v = nodes[i];
+        if (v == root && lower[i] != -1) M.rootVect = -1;                 // (recomputed by the next search if the root's list changed)
+        const bool cand = v != root && up[i] >= 0 && dist[i] > M.effNon0 && totUp[i] >= 0;        // M:8049
+        int col = M.h_candIdx[v];
+        if (col >= 0 && !cand) M.h_candIdx[v] = -1;                       // (the column stays and is scored for nothing)
+        else if (col >= 0) { if (M.h_candList[col] != totUp[i]) { M.h_candList[col] = totUp[i]; TRY(poke(M.d_candList, col, totUp[i])); } }
+        else if (cand) {
+            col = (int)M.cand.size();                                     // the column of the root vector moves up by one
+            M.cand.push_back(v);
+            M.h_candIdx[v] = col;
+            const int32_t rootFrame = M.h_candFrame.back();
+            M.h_candList.back() = totUp[i]; M.h_candFrame.back() = M.frameOf[v];
+            M.h_candList.push_back(-1); M.h_candFrame.push_back(rootFrame);
+            TRY(poke(M.d_candList, col, totUp[i]));
+            TRY(poke(M.d_candFrame, col, M.frameOf[v]));
+            TRY(poke(M.d_candFrame, col + 1, rootFrame));
+            if ((size_t)col + 1 >= M.d_candList.cap) M.valid = false;
+        }
+        const bool leaf = child0[i] < 0;
+        int lc = M.h_leafIdx[v];
+        if (lc >= 0 && !leaf) M.h_leafIdx[v] = -1;
+        else if (leaf) {
+            if (lower[i] < 0) return fail(c, MAPLE_ERR_STATE, "leaf %d has no lower genome list", v);
+            if (lc >= 0) { if (M.h_leafList[lc] != lower[i]) { M.h_leafList[lc] = lower[i]; TRY(poke(M.d_leafList, lc, lower[i])); } }
+            else {
+                lc = (int)M.leaves.size();
+                M.leaves.push_back(v);
+                M.h_leafIdx[v] = lc;
+                M.h_leafList.push_back(lower[i]); M.h_leafFrame.push_back(M.frameOf[v]);
+                TRY(poke(M.d_leafList, lc, lower[i]));
+                TRY(poke(M.d_leafFrame, lc, M.frameOf[v]));
+            }
+        }
+    }
     return MAPLE_OK;
 }
 
@@ -2469,6 +2596,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
     if (!c->tree_set) return fail(c, MAPLE_ERR_STATE, "maple_tree_upload has not been called");
+    if (c->tree_stale) TRY(tree_rebuild_from_host(c));                  // the tree was patched since its tables were built
     for (int i = 0; i < n; i++)
         if (nodes[i] < 0 || nodes[i] >= c->dtree.n) return fail(c, MAPLE_ERR_ARG, "nodes[%d] = %d is not a node", i, nodes[i]);
     const bool dbgT = getenv("MAPLE_DEBUG") != nullptr;

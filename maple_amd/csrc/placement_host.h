@@ -87,7 +87,8 @@ static int place_meta(maple_ctx *c, double effNon0)
     std::vector<int32_t> &candIdx = M.h_candIdx, &leafIdx = M.h_leafIdx;
     candIdx.assign(n, -1);
     leafIdx.assign(n, -1);
-    std::vector<int32_t> candList, candFrame, leafList, leafFrame;
+    std::vector<int32_t> &candList = M.h_candList, &candFrame = M.h_candFrame, &leafList = M.h_leafList, &leafFrame = M.h_leafFrame;
+    candList.clear(); candFrame.clear(); leafList.clear(); leafFrame.clear();
     for (int32_t v : order)
         if (v != root && up[v] >= 0 && c->h_tree_dist[v] > effNon0 && totUp[v] >= 0) M.cand.push_back(v);      // M:8049
     // columns sorted by list length: the 64 lanes of a scoring wavefront then finish together
@@ -135,7 +136,76 @@ static int place_meta(maple_ctx *c, double effNon0)
     HIPCK(c, hipStreamSynchronize(c->stream));
     M.effNon0 = effNon0;
     M.valid = true;
+    M.scanStale = false;
     return MAPLE_OK;
+}
+
+// The same traversal as place_replay_one (placement_dev.h), over the host's own tree columns instead of the scan array: the
+// single-query calls of the sequential placement phase use it, so that a tree changed through maple_tree_patch needs no
+// re-linearisation.  Children in the order of compute_frames' depth-first order: child 1's clade first.
+static void place_replay_ptr(const maple_ctx *c, const PlaceMeta &M, const PlaceParams &P, const double *sc, int rootCol,
+                             const uint8_t *mn, int nF, const PlaceOut &o)
+{
+    const int32_t root = c->dtree.root;
+    const auto &c0 = c->h_tree_c0, &c1 = c->h_tree_c1;
+    std::vector<uint32_t> frameBits((size_t)(nF + 31) >> 5, 0u);
+    int32_t *slN = o.slNode;
+    double *slL = o.slLK;
+    int nSl = 0, status = 0, minorNode = -1, missed = 0, nAppend = 1;
+    double bestLK = sc[rootCol];
+    const double originalLK = bestLK;
+    int bestNode = root;
+    struct It { int32_t node; int32_t fails; double parentLK; };
+    std::vector<It> st;
+    if (!P.supportOnly && M.h_leafIdx[root] >= 0 && mn[M.h_leafIdx[root]] == 1) { status = 1; minorNode = root; nAppend = 0; }
+    if (c0[root] >= 0) { st.push_back(It{c0[root], 0, bestLK}); st.push_back(It{c1[root], 0, bestLK}); }
+    while (!st.empty() && status == 0) {                                  // M:7972-8100
+        const It it = st.back();
+        st.pop_back();
+        const int t1 = it.node;
+        const int candCol = M.h_candIdx[t1], leafCol = M.h_leafIdx[t1];
+        int fails = it.fails;
+        if (leafCol >= 0) {
+            const int cmp = mn[leafCol];
+            if (cmp == 1) { if (!P.supportOnly) { status = 1; minorNode = t1; break; } }   // M:7986-8003
+            else if (cmp == 2) missed++;
+        }
+        double lk = it.parentLK;
+        if (candCol >= 0) {
+            lk = sc[candCol];
+            nAppend++;
+            bool keep = false;
+            if (lk >= bestLK) {                                           // M:8065-8073
+                const int f = M.frameOf[t1];
+                frameBits[f >> 5] |= 1u << (f & 31);
+                bestLK = lk; bestNode = t1; fails = 0; keep = true;
+            } else if (lk > bestLK - P.thrOpt) keep = true;               // M:8074-8075
+            if (keep) {
+                if (nSl == MAPLE_PLACE_SHORTLIST) {
+                    int k = 0;
+                    for (int i = 0; i < nSl; i++)
+                        if (slL[i] >= bestLK - P.thrFilter) { slN[k] = slN[i]; slL[k] = slL[i]; k++; }
+                    nSl = k;
+                }
+                if (nSl == MAPLE_PLACE_SHORTLIST) { status = -6; break; }
+                slN[nSl] = t1; slL[nSl] = lk; nSl++;
+            }
+            if (lk < it.parentLK - P.thrConsec) fails++;                  // M:8076-8077
+        }
+        const bool within = lk > bestLK - P.thrLK;
+        const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);   // M:8080-8093
+        if (go && c0[t1] >= 0) { st.push_back(It{c0[t1], fails, lk}); st.push_back(It{c1[t1], fails, lk}); }
+    }
+    int k = 0;
+    for (int i = 0; i < nSl; i++)
+        if (slL[i] >= bestLK - P.thrFilter) { slN[k] = slN[i]; slL[k] = slL[i]; k++; }
+    nSl = k;
+    for (int i = 0; i < nSl; i++) { const int f = M.frameOf[slN[i]]; o.slShort[i] = (frameBits[f >> 5] >> (f & 31)) & 1u; }
+    const int fb = M.frameOf[status == 1 ? minorNode : bestNode];
+    o.bestShort[0] = (frameBits[fb >> 5] >> (fb & 31)) & 1u;
+    o.status[0] = status; o.minorNode[0] = minorNode; o.bestNode[0] = bestNode;
+    o.bestLK[0] = bestLK; o.originalLK[0] = originalLK;
+    o.nAppend[0] = nAppend; o.missed[0] = missed; o.nShort[0] = nSl;
 }
 
 template <class T> static int d2h_vec(maple_ctx *c, std::vector<T> &dst, const T *src, size_t n)
@@ -151,6 +221,7 @@ extern "C" int maple_placement_prepare(maple_ctx *c, const maple_placement_param
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
     if (!c->tree_set) return fail(c, MAPLE_ERR_STATE, "maple_tree_upload has not been called");
+    if (c->tree_stale && (!c->place->valid || c->place->effNon0 != pp->effectivelyNon0BLen)) TRY(tree_rebuild_from_host(c));
     TRY(place_meta(c, pp->effectivelyNon0BLen));
     PlaceMeta &M = *c->place;
     if (M.rootVect < 0) {
@@ -211,6 +282,10 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
     TRY(need_model(c));
     if (!c->tree_set) return fail(c, MAPLE_ERR_STATE, "maple_tree_upload has not been called");
     TRY(check_ids(c, nQ, qLists, false, "qLists"));
+    // a tree changed through maple_tree_patch: single queries (the serial placement phase) run on the patched columns and the
+    // host's own tree; anything else rebuilds the tables first
+    if (c->tree_stale && (nQ > 4 || !c->place->valid || c->place->effNon0 != pp->effectivelyNon0BLen))
+        TRY(tree_rebuild_from_host(c));
     TRY(place_meta(c, pp->effectivelyNon0BLen));
     PlaceMeta &M = *c->place;
     const int32_t nF = M.nF, nC = (int32_t)M.cand.size(), nCols = nC + 1, nL = (int32_t)M.leaves.size();
@@ -331,9 +406,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                 oq.status += q; oq.minorNode += q; oq.bestNode += q; oq.nAppend += q; oq.missed += q; oq.nShort += q;
                 oq.bestLK += q; oq.originalLK += q; oq.bestShort += q;
                 oq.slNode += (size_t)q * SL; oq.slLK += (size_t)q * SL; oq.slShort += (size_t)q * SL;
-                place_replay_one(M.h_scan.data(), (int)M.h_scan.size(), P, 0, 1, hs.data() + (size_t)q * nCols, nC,
-                                 hm.data() + (size_t)q * std::max(nL, 1), M.frameOf.data(), nF, stackCap, stL.data(), stF.data(),
-                                 bits.data(), oq);
+                place_replay_ptr(c, M, P, hs.data() + (size_t)q * nCols, nC, hm.data() + (size_t)q * std::max(nL, 1), nF, oq);
             }
         } else {
             HIPCK(c, c->p_f64[0].reserve((size_t)nq * stackCap));         // per-depth lastLK

@@ -21,7 +21,7 @@ EXPORTS = [
     "maple_lists_upload", "maple_lists_update", "maple_lists_sizes", "maple_lists_download", "maple_arena_mark", "maple_arena_release",
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
-    "maple_evaluate_placement_batch", "maple_update_partials", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
+    "maple_evaluate_placement_batch", "maple_update_partials", "maple_tree_patch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
     "maple_timing_read_kind", "maple_placement_supports_batch", "maple_debug_gpv_batch", "maple_debug_simplify_batch",
@@ -331,6 +331,13 @@ class Device:
         self._ck(self.lib.maple_root_vector_batch(self.h, n, _ptr(lists), _ptr(bl), _ptr(tip), _ptr(off), _ptr(pm),
                                                   _ptr(out)))
         return out
+
+    def tree_patch(self, n_total, nodes, up, c0, c1, dist, tip, lower, up_right, up_left, tot_up):
+        """maple_tree_patch: the records of the touched (and new) nodes; see include/maple_hip.h."""
+        nodes = _i32(nodes)
+        cols = [_i32(x) for x in (up, c0, c1)] + [_f64(dist), _u8(tip)] + [_i32(x) for x in (lower, up_right, up_left, tot_up)]
+        assert all(len(x) == len(nodes) for x in cols)
+        self._ck(self.lib.maple_tree_patch(self.h, int(n_total), len(nodes), _ptr(nodes), *[_ptr(x) for x in cols]))
 
     def update_partials(self, root, up, c0, c1, tip, mut, depth, dist, lower, up_right, up_left, tot_up, changed):
         """maple_update_partials: the four list-id columns and ``dist`` are updated IN PLACE (they must be C-contiguous

@@ -116,7 +116,39 @@ class HostTree:
         up, c0, c1, is_tip, _ = self.columns()
         dev.upload_tree(self.root, up, c0, c1, self.dist, is_tip, self.id_lower, self.id_upRight, self.id_upLeft,
                         self.id_totUp, self.id_mut)
+        self._sent = dict(root=self.root, up=up.copy(), c0=c0.copy(), c1=c1.copy(), tip=is_tip.copy(), dist=self.dist.copy(),
+                          lower=self.id_lower.copy(), upRight=self.id_upRight.copy(), upLeft=self.id_upLeft.copy(),
+                          totUp=self.id_totUp.copy(), mut=self.id_mut.copy())
         return self
+
+    def sync(self, dev: Device):
+        """Bring the library's copy of the tree up to date after a LOCAL change (a placed sample, the repair of the lists
+        around it): the nodes whose record differs from what was last sent go through maple_tree_patch -- a few 4-byte
+        writes instead of the whole tree -- and the next single-query placement search runs on the patched tree.  Falls
+        back to the full upload when the root or a mutation list changed, or nothing was sent yet.  Returns the number of
+        patched nodes (-1: full upload)."""
+        sent = getattr(self, "_sent", None)
+        up, c0, c1, is_tip, _ = self.columns()
+        if sent is None or sent["root"] != self.root or len(sent["up"]) > self.n:
+            self.upload_topology(dev)
+            return -1
+        n_old = len(sent["up"])
+        if not np.array_equal(sent["mut"], self.id_mut[:n_old]) or (self.id_mut[n_old:] >= 0).any():
+            self.upload_topology(dev)
+            return -1
+        now = dict(up=up, c0=c0, c1=c1, tip=is_tip, dist=self.dist, lower=self.id_lower, upRight=self.id_upRight,
+                   upLeft=self.id_upLeft, totUp=self.id_totUp)
+        diff = np.zeros(n_old, dtype=bool)
+        for k, a in now.items():
+            diff |= a[:n_old] != sent[k]
+        touched = np.concatenate([np.nonzero(diff)[0], np.arange(n_old, self.n)]).astype(np.int32)
+        if len(touched):
+            dev.tree_patch(self.n, touched, up[touched], c0[touched], c1[touched], self.dist[touched], is_tip[touched],
+                           self.id_lower[touched], self.id_upRight[touched], self.id_upLeft[touched], self.id_totUp[touched])
+            for k, a in now.items():
+                sent[k] = a.copy()
+            sent["mut"] = self.id_mut.copy()
+        return len(touched)
 
     def apply_topology(self, root, up, children, dist, n_minor):
         """Tree surgery done by the host (placeSampleOnTree / cutAndPasteNode stay host code): take over the new arrays,

@@ -722,6 +722,61 @@ def test_applied_spr_moves_tree_likelihood(name):
 
 
 @pytest.mark.parametrize("name", E2E_NAMES)
+def test_online_sample_additions_through_tree_patch(name):
+    """The same sequence as test_online_sample_additions with the library's copy of the tree kept up to date by
+    maple_tree_patch (HostTree.sync: only the nodes a placement touched) instead of a full maple_tree_upload per sample:
+    every single-query placement search on the patched tree must still return the reference's node, score and branch
+    lengths, and the tables the batched search needs are rebuilt from the patched copy when it is asked for one."""
+    from maple_amd.tree_host import update_genome_lists
+    f, dev = _e2e_env(name)
+    ctx = f["context"]
+    dev.set_model(**model_args(f["model"]))
+    tree = _tree_from_topology(dev, f["online_start"], f["tips"])
+    pkw = dict(oneMutBLen=ctx["oneMutBLen"], effectivelyNon0BLen=ctx["effectivelyNon0BLen"], thresholdLogLK=ctx["thresholdLogLK"],
+               thresholdLogLKoptimization=ctx["thresholdLogLKoptimization"],
+               thresholdLogLKconsecutivePlacement=ctx["thresholdLogLKconsecutivePlacement"], allowedFails=ctx["allowedFails"],
+               strictStopRules=ctx["strictStopRules"])
+    tree.upload_topology(dev)
+    patched = []
+    last = None
+    for k, rec in enumerate(f["online"]):
+        patched.append(tree.sync(dev))
+        dev.placement_prepare(**pkw)                                  # (root vector, outside the mark)
+        mark = dev.mark()
+        qid = dev.upload([tup(rec["query"])])
+        out = dev.placement_search_batch(qid, **pkw)
+        want = rec["ret"]
+        assert out["status"][0] >= 0
+        assert int(out["bestNode"][0]) == want["bestNode"], (k, out["bestNode"][0], want["bestNode"])
+        assert close(float(out["bestScore"][0]), want["bestScore"], 1e-8), (k, out["bestScore"][0], want["bestScore"])
+        if want["bestBranchLengths"] is None:
+            assert out["status"][0] == 1
+        else:
+            assert all(close(float(g), w, 1e-7, 1e-15) for g, w in zip(out["blen"][0], want["bestBranchLengths"])), (k, out["blen"][0], want)
+        last = (qid.copy(), {kk: v.copy() for kk, v in out.items()})
+        dev.release(mark)
+        after = rec["after"]
+        changed = tree.apply_topology(after["root"], after["up"], after["children"], after["dist"], after["nMinor"])
+        for v, lst in rec["new_tips"].items():
+            tree.id_lower[int(v)] = dev.upload([tup(lst)])[0]
+        if changed:
+            update_genome_lists(dev, tree, changed)
+    print(f"{name}: nodes patched per added sample {patched}")
+    assert patched[0] == 0 and all(-1 <= p < tree.n // 4 for p in patched), patched   # a few nodes each, never the whole tree
+    assert sum(p > 0 for p in patched) >= len(patched) // 2, patched
+    # a batch on the patched tree: the linearised tables are rebuilt from the library's copy; the last query again, five times
+    tree.sync(dev)
+    dev.placement_prepare(**pkw)
+    mark = dev.mark()
+    rec = f["online"][-1]
+    qids = dev.upload([tup(rec["query"])] * 5)
+    out = dev.placement_search_batch(qids, **pkw)
+    assert (out["status"] >= 0).all() and len(set(out["bestNode"].tolist())) == 1
+    dev.release(mark)
+    dev.close()
+
+
+@pytest.mark.parametrize("name", E2E_NAMES)
 def test_online_sample_additions(name):
     """BASELINE configs[4] in small (online update of a frozen tree): new samples are added one after the other -- placement
     search on the GPU (must be the reference's node, score and branch lengths), the reference's tree edit applied from
