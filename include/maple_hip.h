@@ -168,6 +168,9 @@ int maple_update_partials(maple_ctx *ctx, int32_t n, int32_t root, const int32_t
                           const int32_t *child1, const uint8_t *isTip, const int32_t *mutList, const int32_t *depth,
                           double *dist, int32_t *lower, int32_t *upRight, int32_t *upLeft, int32_t *totUp, int32_t nChanged,
                           const int32_t *changed, int32_t *nReplaced);
+/* The nodes whose lists (or branch length) the last maple_update_partials replaced, each once, ascending (*n of them; an
+ * error if they do not fit in cap): with the nodes of the tree edit itself, what maple_tree_patch has to be told. */
+int maple_update_partials_touched(maple_ctx *ctx, int32_t cap, int32_t *nodes, int32_t *n);
 /* evaluatePlacement(midTot, downVect, upVect, distance, removedPartials, isRemovedTip, ..., fromTip1), M:6790-6806
  * out4[i*4..] = appendingCost, bestBottomLength, bestTopLength, bestAppendingLength (False -> 0.0) */
 int maple_evaluate_placement_batch(maple_ctx *ctx, int32_t n, const int32_t *midTot, const int32_t *downVect,

@@ -14,6 +14,7 @@ namespace {
 struct UpdateScratch {                 // per-context, persistent: flags per node, cleared through the touched list
     std::vector<uint8_t> dLow, dUp, dDist, dCh0, dCh1, inFrontier, inTodo;
     std::vector<int32_t> touched;
+    std::vector<int32_t> replacedNodes;   // nodes one of whose four lists (or whose branch length) the last call replaced
     void fit(size_t n)
     {
         if (dLow.size() < n) {
@@ -118,6 +119,7 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
     UpdateScratch &S = update_scratch(c);
     S.fit((size_t)n);
     S.clear();
+    S.replacedNodes.clear();
     int replaced = 0;
     auto whichChild = [&](int p, int v) { return c0[p] == v ? 0 : 1; };
     auto markChild = [&](int p, int which) { (which == 0 ? S.dCh0 : S.dCh1)[p] = 1; S.touch(p); };
@@ -184,6 +186,7 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
                 const uint8_t tipc = tip[ch];
                 TRY(maple_blen_batch(c, 1, vu1.data(), &lower[ch], &tipc, &t, &isFalse));
                 dist[ch] = isFalse ? 0.0 : t;
+                S.replacedNodes.push_back(ch);
                 S.dLow[ch] = 1; S.dDist[ch] = 1; S.touch(ch);
                 markChild(p, which);
                 if (dist[ch] != 0.0) break;
@@ -196,6 +199,7 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
         for (size_t k = 0; k < m; k++) {
             const int v = nodes[k];
             lower[v] = out[k];
+            S.replacedNodes.push_back(v);
             replaced++;
             if (!diff[k]) continue;
             S.dLow[v] = 1; S.touch(v);
@@ -245,6 +249,7 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
                     if (store[r] >= 0) TRY(maple_differ_batch(c, 1, &store[r], &res, &df));
                     if (df) {
                         store[r] = res;
+                        S.replacedNodes.push_back(r);
                         replaced++;
                         S.dUp[target] = 1; S.touch(target);
                         addTodo(target);
@@ -264,7 +269,7 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
         for (size_t k = 0; k < nodes.size(); k++) {
             const int v = nodes[k];
             if (S.dUp[v] || S.dLow[v]) {
-                if (dist[v] == 0.0) totUp[v] = -1;
+                if (dist[v] == 0.0) { if (totUp[v] != -1) S.replacedNodes.push_back(v); totUp[v] = -1; }
                 else {
                     iL1.push_back(vu[k]); iB1.push_back(dist[v] / 2); iL2.push_back(lower[v]); iB2.push_back(dist[v] / 2);
                     iT2.push_back(tip[v]); iMode.push_back(1); iOld.push_back(-1); iNode.push_back(v); iKid.push_back(-1); iKind.push_back(0);
@@ -298,9 +303,10 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
             if (none[i])
                 return fail(c, MAPLE_ERR_FATAL, iKind[i] == 0 ? "None probVectTotUp on a branch of non-zero length (node %d)"
                                                               : "None upper vector at node %d (the reference would call updateBLen here)", v);
-            if (iKind[i] == 0) { totUp[v] = out[i]; replaced++; continue; }
+            if (iKind[i] == 0) { totUp[v] = out[i]; S.replacedNodes.push_back(v); replaced++; continue; }
             if (!diff[i]) continue;
             (iKind[i] == 1 ? upRight : upLeft)[v] = out[i];
+            S.replacedNodes.push_back(v);
             replaced++;
             const int target = iKind[i] == 1 ? c0[v] : c1[v];
             S.dUp[target] = 1; S.touch(target);
@@ -309,5 +315,20 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
     }
     S.clear();
     *nReplaced = replaced;
+    return MAPLE_OK;
+}
+
+// the nodes whose lists (or branch length) the last maple_update_partials replaced, each once, ascending: what a caller
+// has to tell maple_tree_patch about besides its own tree edit
+extern "C" int maple_update_partials_touched(maple_ctx *c, int32_t cap, int32_t *nodes, int32_t *n)
+{
+    if (!c || cap < 0 || !n || (cap && !nodes)) return MAPLE_ERR_ARG;
+    UpdateScratch &S = update_scratch(c);
+    std::vector<int32_t> u(S.replacedNodes);
+    std::sort(u.begin(), u.end());
+    u.erase(std::unique(u.begin(), u.end()), u.end());
+    *n = (int32_t)u.size();
+    if ((int32_t)u.size() > cap) return fail(c, MAPLE_ERR_ARG, "%zu touched nodes do not fit in %d", u.size(), cap);
+    for (size_t i = 0; i < u.size(); i++) nodes[i] = u[i];
     return MAPLE_OK;
 }

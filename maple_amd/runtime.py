@@ -21,7 +21,7 @@ EXPORTS = [
     "maple_lists_upload", "maple_lists_update", "maple_lists_sizes", "maple_lists_download", "maple_arena_mark", "maple_arena_release",
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
-    "maple_evaluate_placement_batch", "maple_update_partials", "maple_tree_patch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
+    "maple_evaluate_placement_batch", "maple_update_partials", "maple_update_partials_touched", "maple_tree_patch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
     "maple_timing_read_kind", "maple_placement_supports_batch", "maple_debug_gpv_batch", "maple_debug_simplify_batch",
@@ -354,6 +354,13 @@ class Device:
                                                 _ptr(depth), _ptr(dist), _ptr(lower), _ptr(up_right), _ptr(up_left), _ptr(tot_up),
                                                 len(ch), _ptr(ch), C.byref(n_rep)))
         return int(n_rep.value)
+
+    def update_partials_touched(self, cap=65536):
+        """Nodes whose lists / branch length the last update_partials replaced (ascending)."""
+        out = np.zeros(cap, dtype=np.int32)
+        n = C.c_int32(0)
+        self._ck(self.lib.maple_update_partials_touched(self.h, cap, _ptr(out), C.byref(n)))
+        return out[:n.value].copy()
 
     def evaluate_placement_batch(self, midTot, down, up, distance, removed, isRemovedTip, fromTip1):
         midTot, down, up, removed = _i32(midTot), _i32(down), _i32(up), _i32(removed)

@@ -482,8 +482,13 @@ def test_update_partials_matches_reference(uname):
         for _, attr in keys:
             setattr(twin, attr, getattr(tree, attr).copy())
         twin.dist[v] = tree.dist[v]
+        pre = {attr: getattr(tree, attr).copy() for _, attr in keys}
         replaced = update_genome_lists(dev, tree, [v])
         assert replaced >= 1
+        moved_nodes = set()
+        for _, attr in keys:
+            moved_nodes.update(np.nonzero(getattr(tree, attr) != pre[attr])[0].tolist())
+        assert moved_nodes <= set(dev.update_partials_touched().tolist())      # what maple_tree_patch has to be told
         assert update_genome_lists(dev, twin, [v], native=False) == replaced
         assert np.array_equal(twin.dist, tree.dist)
         for _, attr in keys:

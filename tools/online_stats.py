@@ -9,7 +9,7 @@ internal node on the branch above the best node, with the three branch lengths t
 calls a minor sequence of a tip, or a placement at the root, is skipped).  It is good for timing -- the edits have the shape
 and the locality of the reference's -- not for parity: tests/test_hip_search.py::test_online_sample_additions_through_tree_patch
 applies the reference's own recorded edits.  The tree lives in plain numpy columns with room to grow; nothing in the loop
-touches all nodes except one vectorised comparison of the four list-id columns (which nodes did updatePartials touch).
+touches all nodes (which nodes updatePartials touched comes from maple_update_partials_touched).
 """
 import math
 import os
@@ -92,7 +92,6 @@ def main():
         if not (depth[g] < depth[p] < depth[b]):
             raise SystemExit("ran out of depth resolution on one branch (raise DEPTH_STEP)")
         n += 2
-        before = [lower[:n].copy(), up_right[:n].copy(), up_left[:n].copy(), tot_up[:n].copy()]
         # ---- updatePartials around the new nodes, inside the library, on these very columns
         t0 = time.perf_counter()
         dev.update_partials(m.root, up[:n], c0[:n], c1[:n], tip[:n], mut[:n], depth[:n], dist[:n], lower[:n], up_right[:n],
@@ -100,10 +99,7 @@ def main():
         t_update.append(time.perf_counter() - t0)
         # ---- the library's copy of the tree: only the nodes that changed
         t0 = time.perf_counter()
-        diff = np.zeros(n, dtype=bool)
-        for a, o in zip((lower, up_right, up_left, tot_up), before):
-            diff |= a[:n] != o
-        touched = np.unique(np.concatenate([np.nonzero(diff)[0], [g, b, p, s]])).astype(np.int32)
+        touched = np.unique(np.concatenate([dev.update_partials_touched(), [g, b, p, s]])).astype(np.int32)
         dev.tree_patch(n, touched, up[touched], c0[touched], c1[touched], dist[touched], tip[touched], lower[touched],
                        up_right[touched], up_left[touched], tot_up[touched])
         t_patch.append(time.perf_counter() - t0)
@@ -115,7 +111,7 @@ def main():
     total = med(t_upload) + med(t_search) + med(t_update) + med(t_patch)
     print(f"{n_tips}-tip tree, {n_add} samples one after the other: {placed} placed, {skipped} skipped (minor sequence / at the root)")
     print(f"  per sample (median, ms): upload of its list {med(t_upload):.2f}, placement search {med(t_search):.2f}, "
-          f"updatePartials {med(t_update):.2f}, tree patch incl. the comparison of the id columns {med(t_patch):.2f} "
+          f"updatePartials {med(t_update):.2f}, tree patch {med(t_patch):.2f} "
           f"-> {total:.2f} ms = {1e3 / total:.0f} samples/s; nodes patched per sample: median {int(np.median(patched))}, max {max(patched)}")
     # for comparison: what a full re-upload of the tree costs at this size
     t0 = time.perf_counter()
