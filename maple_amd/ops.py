@@ -130,13 +130,7 @@ class TreeOps:
 
     def upload_topology(self):
         """(Re)send the topology and list ids after the host changed the tree (maple_tree_upload)."""
-        t = self.tree
-        up = np.asarray([-1 if u is None else u for u in t.up], dtype=np.int32)
-        c0 = np.asarray([c[0] if c else -1 for c in t.children], dtype=np.int32)
-        c1 = np.asarray([c[1] if c else -1 for c in t.children], dtype=np.int32)
-        tip = np.asarray([(not c) and (m == 0) for c, m in zip(t.children, t.n_minor)], dtype=np.uint8)
-        dist = np.asarray([float(x or 0.0) for x in t.dist])
-        self.dev.upload_tree(t.root, up, c0, c1, dist, tip, t.id_lower, t.id_upRight, t.id_upLeft, t.id_totUp, t.id_mut)
+        self.tree.upload_topology(self.dev)
         self._searcher = None
 
     # M:7912 -- returns (bestNode, bestScore, bestBranchLengths, bestDiffs) like the reference; with
@@ -180,6 +174,17 @@ class TreeOps:
         from .tree_host import rebuild_genome_lists
         t = self.tree
         t.id_lower, t.id_upRight, t.id_upLeft, t.id_totUp = rebuild_genome_lists(self.dev, t)
+
+    def sync(self):
+        """After a LOCAL change (one placed sample + updatePartials): only the touched nodes go to the library
+        (maple_tree_patch); falls back to upload_topology when that is not possible.  Returns the number of patched nodes."""
+        n = self.tree.sync(self.dev)
+        if self._searcher is not None:
+            if n == -1 or self._searcher.world != 1:
+                self._searcher = None                                  # (its candidate shards describe the old tree)
+            else:
+                self._searcher._prepared = False                       # the root vector may have changed: prepare again
+        return n
 
     def updatePartials(self, changed_nodes):                               # M:5479 (level-synchronous, any number of changes)
         from .tree_host import update_genome_lists
