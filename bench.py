@@ -305,6 +305,88 @@ def main():
     dev.close()
 
 
+DEPTH_STEP = 1 << 12        # serial_phase keeps depths in units of 1/4096 of a level: a node put on a branch gets one in between
+
+
+def serial_phase(dev, m, new_lists, pkw):
+    """The serial placement phase on the tree of TreeMirror ``m``: the samples ``new_lists`` one after the other --
+    single-query placement search, tree edit, maple_update_partials around the new nodes, maple_tree_patch of the touched
+    records.  The tree edit is a STAND-IN for MAPLE's placeSampleOnTree (M:8300-8722), which stays host code of the
+    reference: a new internal node on the branch above the best node with the three branch lengths the search returned (a
+    sample the search calls a minor sequence, or a placement at the root, is skipped) -- good for timing (the edits have
+    the shape and the locality of the reference's), not for parity
+    (tests/test_hip_search.py::test_online_sample_additions_through_tree_patch applies the reference's own recorded edits).
+    The tree lives in plain numpy columns with room to grow; nothing in the loop touches all nodes.  Returns the per-step
+    times (s) and the columns of the final tree (which is also the tree uploaded to ``dev`` when it returns)."""
+    n_add = len(new_lists)
+    n0, cap = m.n_nodes, m.n_nodes + 2 * n_add
+
+    def grown(a, fill, dtype):
+        out = np.full(cap, fill, dtype=dtype)
+        out[:n0] = a
+        return out
+    up = grown(m.parent, -1, np.int32)
+    c0, c1 = grown(m.children[:, 0], -1, np.int32), grown(m.children[:, 1], -1, np.int32)
+    tip = grown(m.is_tip, 0, np.uint8)
+    dist = grown(m.dist, 0.0, np.float64)
+    mut = np.full(cap, -1, dtype=np.int32)
+    lower, up_right = grown(m.lower, -1, np.int32), grown(m.up_right, -1, np.int32)
+    up_left, tot_up = grown(m.up_left, -1, np.int32), grown(m.tot_up, -1, np.int32)
+    depth = np.zeros(cap, dtype=np.int32)                # (maple_update_partials only compares depths)
+    for v in preorder_nodes(m):
+        if up[v] >= 0:
+            depth[v] = depth[up[v]] + DEPTH_STEP
+    n = n0
+    dev.upload_tree(m.root, up[:n], c0[:n], c1[:n], dist[:n], tip[:n], lower[:n], up_right[:n], up_left[:n], tot_up[:n], mut[:n])
+    t = dict(upload=[], search=[], update=[], patch=[])
+    placed, skipped, patched = 0, 0, []
+    for lst in new_lists:
+        dev.placement_prepare(**pkw)
+        t0 = time.perf_counter()
+        qid = int(dev.upload([lst])[0])                  # the sample's list stays: it becomes the new tip's lower list
+        t["upload"].append(time.perf_counter() - t0)
+        mark = dev.mark()
+        t0 = time.perf_counter()
+        out = dev.placement_search_batch(np.asarray([qid], dtype=np.int32), **pkw)
+        t["search"].append(time.perf_counter() - t0)
+        dev.release(mark)
+        b = int(out["bestNode"][0])
+        if out["status"][0] != 0 or up[b] < 0:
+            skipped += 1
+            continue
+        top, bottom, app = (float(x) for x in out["blen"][0])
+        g, p, s = int(up[b]), n, n + 1
+        # ---- the stand-in tree edit: p on the branch above b, the sample s as p's other child
+        if c0[g] == b:
+            c0[g] = p
+        else:
+            c1[g] = p
+        up[p], c0[p], c1[p], dist[p], tip[p] = g, b, s, top, 0
+        up[b], dist[b] = p, bottom
+        up[s], dist[s], tip[s], lower[s] = p, app, 1, qid
+        depth[p] = (depth[g] + depth[b]) // 2
+        depth[s] = depth[p] + 1
+        if not (depth[g] < depth[p] < depth[b]):
+            raise SystemExit("serial_phase: ran out of depth resolution on one branch (raise DEPTH_STEP)")
+        n += 2
+        # ---- updatePartials around the new nodes, inside the library, on these very columns
+        t0 = time.perf_counter()
+        dev.update_partials(m.root, up[:n], c0[:n], c1[:n], tip[:n], mut[:n], depth[:n], dist[:n], lower[:n], up_right[:n],
+                            up_left[:n], tot_up[:n], [b, s, p])
+        t["update"].append(time.perf_counter() - t0)
+        # ---- the library's copy of the tree: only the nodes that changed
+        t0 = time.perf_counter()
+        touched = np.unique(np.concatenate([dev.update_partials_touched(), [g, b, p, s]])).astype(np.int32)
+        dev.tree_patch(n, touched, up[touched], c0[touched], c1[touched], dist[touched], tip[touched], lower[touched],
+                       up_right[touched], up_left[touched], tot_up[touched])
+        t["patch"].append(time.perf_counter() - t0)
+        patched.append(len(touched))
+        placed += 1
+    cols = dict(n=n, root=m.root, up=up, c0=c0, c1=c1, dist=dist, tip=tip, lower=lower, up_right=up_right, up_left=up_left,
+                tot_up=tot_up, mut=mut)
+    return dict(times=t, placed=placed, skipped=skipped, patched=patched, cols=cols)
+
+
 def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_plain_tree, torch, cu):
     """Secondary measurements next to the headline, never mixed into it (rank 0 only)."""
     from maple_amd.host import tip_genome_list
@@ -386,10 +468,25 @@ def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_pl
         rep += update_genome_lists(dev, ht1, [int(v)])
         tu.append(time.perf_counter() - t0)
     dev.release(mark)
+    # ... and the loop itself: 64 new samples placed one after the other (serial_phase above: search, stand-in tree edit,
+    # maple_update_partials, maple_tree_patch)
+    mark = dev.mark()
+    sp = serial_phase(dev, mirror, new_samples[:64], pkw)
+
+    def med_ms(x):
+        return 1e3 * float(np.median(x[len(x) // 8:])) if len(x) else float("nan")
+    per = {k: med_ms(v) for k, v in sp["times"].items()}
+    upload_plain_tree()                                  # (the original tree again; the loop's lists go with the mark)
+    dev.release(mark)
     out["serial_path"] = {"single_query_placement_ms_median": 1e3 * float(np.median(ts[1:])),
                           "single_change_update_partials_ms_median": 1e3 * float(np.median(tu[1:])),
                           "lists_replaced_per_change": rep / len(tu),
-                          "note": "wall times through the Python binding; the reference's CPython updatePartials takes ~0.4 ms"}
+                          "loop_ms_per_sample": {"upload_of_the_sample": per["upload"], "placement_search": per["search"],
+                                                 "update_partials": per["update"], "tree_patch": per["patch"],
+                                                 "total": sum(per.values())},
+                          "loop_samples": int(sp["placed"]), "nodes_patched_per_sample_median": float(np.median(sp["patched"])) if sp["patched"] else 0.0,
+                          "note": "wall times through the Python binding; the loop's tree edit is a stand-in for MAPLE's "
+                                  "placeSampleOnTree (bench.serial_phase); the reference's CPython updatePartials takes ~0.4 ms"}
     if args.local_refs or args.samples <= 200000:
         # ---- the same steps on the same tree after giving it MAT local references (setUpMAT's rule, 50 descendants per
         # reference node, M:166 / 6152-6164): the form real MAPLE trees have; lists are shorter, searches cross frames ----
