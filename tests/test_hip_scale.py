@@ -225,6 +225,66 @@ def test_update_partials_on_a_tree_with_local_references(world):
     dev.release(mark)
 
 
+def test_serial_placement_through_tree_patch_on_a_tree_with_local_references(world):
+    """The serial placement phase on a tree with MAT local references, in every model mode: 20 samples one after the other
+    (single-query search, a new internal node + tip at the best branch, maple_update_partials, HostTree.sync =
+    maple_tree_patch) must give, sample for sample, the same search results as the same sequence with a full
+    maple_tree_upload after every sample -- the patched copy of the tree, its reference frames and its candidate / leaf
+    columns are the rebuilt ones.  (The tree edit is a stand-in for placeSampleOnTree; the reference's own edits are
+    replayed by test_online_sample_additions_through_tree_patch on trees without local references.)"""
+    from maple_amd.host import tip_genome_list
+    from maple_amd.mat import add_local_references
+    from maple_amd.synth import perturb_diffs
+    from maple_amd.tree_host import HostTree, update_genome_lists
+    mode, data, dev, orc, mirror = world
+    l_ref = dev.lRef
+    ll = math.log(l_ref)
+    pkw = dict(oneMutBLen=1.0 / l_ref, effectivelyNon0BLen=1.0 / (10 * l_ref), thresholdLogLK=18.0 * ll,
+               thresholdLogLKoptimization=ll, thresholdLogLKconsecutivePlacement=1.0)
+    prng = np.random.default_rng(23)
+    from maple_amd.host import reference_tables
+    ref_idx, _ = reference_tables(data.ref)
+    new = [tip_genome_list(perturb_diffs(data.diffs[i], data.ref, prng), ref_idx) for i in range(20)]
+
+    def run(patching):
+        mark = dev.mark()
+        tree = HostTree.from_mirror(mirror)
+        assert add_local_references(dev, tree, 30) > 10
+        tree.upload_topology(dev)
+        results, patched = [], []
+        for lst in new:
+            patched.append(tree.sync(dev) if patching else (tree.upload_topology(dev), -1)[1])
+            dev.placement_prepare(**pkw)
+            qid = dev.upload([lst])
+            out = dev.placement_search_batch(qid, **pkw)
+            assert out["status"][0] >= 0
+            results.append((int(out["status"][0]), int(out["bestNode"][0]), float(out["bestScore"][0]), tuple(out["blen"][0].tolist())))
+            b = int(out["bestNode"][0])
+            if out["status"][0] != 0 or tree.up[b] is None:
+                continue
+            top, bottom, app = (float(x) for x in out["blen"][0])
+            n = tree.n
+            g, p, s = tree.up[b], n, n + 1
+            up = list(tree.up) + [g, p]
+            children = [list(c) for c in tree.children] + [[b, s], []]
+            children[g] = [p if c == b else c for c in children[g]]
+            up[b] = p
+            dist = list(tree.dist) + [top, app]
+            dist[b] = bottom
+            changed = tree.apply_topology(tree.root, up, children, dist, list(tree.n_minor) + [0, 0])
+            tree.id_lower[s] = int(out["bestDiffs"][0])                  # the sample in the frame of its new place
+            update_genome_lists(dev, tree, changed)
+        dev.release(mark)
+        return results, patched
+    a, patched = run(True)
+    b, _ = run(False)
+    assert patched[0] == 0 and all(0 <= p < 64 for p in patched), patched
+    assert len(a) == len(b) == 20
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert x[:2] == y[:2] and rel(x[2], y[2]) < 1e-12 and all(rel(u, v) < 1e-12 for u, v in zip(x[3], y[3])), (k, x, y)
+    assert sum(r[0] == 0 for r in a) >= 10
+
+
 def test_batch_kernel_with_queries_longer_than_the_lds_stage():
     """k_append_queries keeps the tile's query words in LDS up to 192 entries and reads longer lists from memory: both
     paths against the oracle (samples with ~150 and ~400 differences give lists on either side of the limit)."""
