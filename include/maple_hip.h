@@ -265,6 +265,11 @@ int maple_placement_supports_batch(maple_ctx *ctx, int32_t nQ, const int32_t *qL
                                    int64_t *outOff, int32_t *outNode, double *outSupport, double *outBlen3,
                                    int32_t *bestTotalLh, int32_t *status);
 
+/* appendProbNode for n (parent list, child list) pairs with ONE WAVEFRONT per pair (maple_amd/csrc/wave_dev.h: the walk cut
+ * along its merge path, the factors of all steps at once, the running product in walk order): the same results as
+ * maple_append_batch bit for bit; *ms (optional) = kernel time.  A test and timing aid. */
+int maple_debug_wave_append_batch(maple_ctx *ctx, int32_t n, const int32_t *parentList, const int32_t *childList,
+                                  const uint8_t *isTipC, const double *bLen, double *outLK, float *ms);
 /* Debugging aid: record the visit sequence of query index `query` of the next maple_spr_search_batch
  * (per visited item: t1, direction, needsUpdating, failedPasses | lastLK, midProb); -1 switches it off. */
 int maple_debug_trace_query(maple_ctx *ctx, int32_t query);

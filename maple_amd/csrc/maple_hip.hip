@@ -5,6 +5,7 @@
 #include "search_dev.h"
 #include "placement_dev.h"
 #include "append_lds.h"
+#include "wave_dev.h"
 
 #include <algorithm>
 #include <chrono>
@@ -3171,6 +3172,48 @@ extern "C" int maple_debug_simplify_batch(maple_ctx *c, int32_t n, const double 
 }
 
 // debugging aid: record the visit sequence (t1, direction, needsUpdating, failedPasses, lastLK, midProb) of one query
+// appendProbNode by a whole wavefront per pair (wave_dev.h), for parity tests against the one-lane walk and for timing
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(64) void k_wave_append(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *pl,
+                                                    const int32_t *cl, const uint8_t *tip, const double *bl, double *out)
+{
+    __shared__ Lds lds;
+    __shared__ WaveLds wl;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const double v = wave_append(c, list_ref(av, pl[i]), av.n_ent[pl[i]], list_ref(av, cl[i]), av.n_ent[cl[i]], tip[i] != 0, bl[i], wl);
+        if (threadIdx.x == 0) out[i] = v;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int maple_debug_wave_append_batch(maple_ctx *c, int32_t n, const int32_t *pl, const int32_t *cl, const uint8_t *tip,
+                                             const double *bl, double *out, float *ms)
+{
+    if (!c || n < 0 || !pl || !cl || !tip || !bl || !out) return MAPLE_ERR_ARG;
+    if (n == 0) return MAPLE_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    TRY(check_ids(c, n, pl, false, "parentList"));
+    TRY(check_ids(c, n, cl, false, "childList"));
+    TRY(stage_begin(c, (size_t)n * 32 + 256));
+    STAGE(dpl, c, pl, n); STAGE(dcl, c, cl, n); STAGE(dtip, c, tip, n); STAGE(dbl, c, bl, n);
+    TRY(stage_flush(c));
+    HIPCK(c, c->s_f64[1].reserve(n));
+    hipEvent_t e0, e1;
+    TRY(ev_pair(c, &e0, &e1, MAPLE_K_OTHER, (double)n, 0.0));
+    HIPCK(c, hipEventRecord(e0, c->stream));
+    DISPATCH3(c, k_wave_append, <<<std::min(n, 256 * 16), 64, 0, c->stream>>>(c->d_model, view(c), n, dpl, dcl, dtip, dbl, c->s_f64[1].p));
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipEventRecord(e1, c->stream));
+    HIPCK(c, hipMemcpyAsync(out, c->s_f64[1].p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (ms) HIPCK(c, hipEventElapsedTime(ms, e0, e1));
+    return MAPLE_OK;
+}
+
 extern "C" int maple_debug_trace_query(maple_ctx *c, int32_t query)
 {
     if (!c) return MAPLE_ERR_ARG;

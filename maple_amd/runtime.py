@@ -21,7 +21,7 @@ EXPORTS = [
     "maple_lists_upload", "maple_lists_update", "maple_lists_sizes", "maple_lists_download", "maple_arena_mark", "maple_arena_release",
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
-    "maple_evaluate_placement_batch", "maple_update_partials", "maple_update_partials_touched", "maple_tree_patch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
+    "maple_evaluate_placement_batch", "maple_update_partials", "maple_update_partials_touched", "maple_tree_patch", "maple_debug_wave_append_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
     "maple_timing_read_kind", "maple_placement_supports_batch", "maple_debug_gpv_batch", "maple_debug_simplify_batch",
@@ -354,6 +354,17 @@ class Device:
                                                 _ptr(depth), _ptr(dist), _ptr(lower), _ptr(up_right), _ptr(up_left), _ptr(tot_up),
                                                 len(ch), _ptr(ch), C.byref(n_rep)))
         return int(n_rep.value)
+
+    def debug_wave_append_batch(self, pl, cl, isTipC, bLen):
+        """appendProbNode with one wavefront per pair (maple_debug_wave_append_batch); returns (values, kernel ms)."""
+        pl, cl = _i32(pl), _i32(cl)
+        n = len(pl)
+        tip = _u8(np.broadcast_to(isTipC, n))
+        bl = _f64(np.broadcast_to(bLen, n))
+        out = np.zeros(n)
+        ms = C.c_float(0.0)
+        self._ck(self.lib.maple_debug_wave_append_batch(self.h, n, _ptr(pl), _ptr(cl), _ptr(tip), _ptr(bl), _ptr(out), C.byref(ms)))
+        return out, float(ms.value)
 
     def update_partials_touched(self, cap=65536):
         """Nodes whose lists / branch length the last update_partials replaced (ascending)."""

@@ -84,6 +84,30 @@ def test_appendProbNode(env):
     assert total > 100
 
 
+def test_wavefront_wide_appendProbNode_is_the_one_lane_walk_bit_for_bit(env):
+    """wave_append (maple_amd/csrc/wave_dev.h: the walk cut along its merge path, all steps' factors at once, the running
+    product in walk order) against the one-lane walk of maple_append_batch on every recorded appendProbNode call of the
+    fixture, in every model mode: identical doubles (including -inf), not just close ones."""
+    f, dev, o = env
+    total = 0
+    for mid, recs in by_model(f, "appendProbNode").items():
+        dev.set_model(**model_args(f["models"][mid]))
+        mark = dev.mark()
+        n = len(recs)
+        ids = dev.upload([tup(r["P"]) for r in recs] + [tup(r["C"]) for r in recs])
+        tips, bls = [r["isTipC"] for r in recs], [r["bLen"] for r in recs]
+        one = dev.append_batch(ids[:n], ids[n:], tips, bls)
+        wave, _ = dev.debug_wave_append_batch(ids[:n], ids[n:], tips, bls)
+        assert np.array_equal(one, wave), [(a, b) for a, b in zip(one, wave) if a != b][:3]
+        # ... and with the roles of the two lists exchanged (other merge paths, other ties)
+        one = dev.append_batch(ids[n:], ids[:n], tips, bls)
+        wave, _ = dev.debug_wave_append_batch(ids[n:], ids[:n], tips, bls)
+        assert np.array_equal(one, wave)
+        dev.release(mark)
+        total += n
+    assert total > 100
+
+
 def test_lists_update_keeps_ids_and_changes_contents(env):
     """maple_lists_update: existing ids get new contents -- shorter ones in place, longer ones in fresh room --
     and every operator sees the new words under the old id."""

@@ -285,6 +285,24 @@ def test_serial_placement_through_tree_patch_on_a_tree_with_local_references(wor
     assert sum(r[0] == 0 for r in a) >= 10
 
 
+def test_wavefront_wide_append_on_tree_lists(world):
+    """wave_append on the lists of a real tree (probVectTotUp of 4 000 branches against tip lists, every model mode; lists
+    near the root are longer than what the cooperative walk stages and take its one-lane fall-back): identical to
+    maple_append_batch in every bit."""
+    mode, data, dev, orc, mirror = world
+    rng = np.random.default_rng(41)
+    cand = np.nonzero(mirror.tot_up >= 0)[0]
+    tips = np.nonzero(mirror.is_tip.astype(bool))[0]
+    pl = mirror.tot_up[rng.choice(cand, size=4000)]
+    cl = mirror.lower[rng.choice(tips, size=4000)]
+    bl = np.where(rng.random(4000) < 0.2, 0.0, 1.0 / dev.lRef)          # some zero-length attachments: -inf results
+    one = dev.append_batch(pl, cl, True, bl)
+    wave, ms = dev.debug_wave_append_batch(pl, cl, True, bl)
+    assert np.array_equal(one, wave), int((one != wave).sum())
+    assert np.isfinite(one).any() and (mode == "siteerr" or np.isinf(one).any())   # (with an error model a zero-length mismatch is finite)
+    print(f"{mode}: 4000 wavefront-wide appendProbNode in {ms:.3f} ms")
+
+
 def test_batch_kernel_with_queries_longer_than_the_lds_stage():
     """k_append_queries keeps the tile's query words in LDS up to 192 entries and reads longer lists from memory: both
     paths against the oracle (samples with ~150 and ~400 differences give lists on either side of the limit)."""
