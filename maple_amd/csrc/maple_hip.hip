@@ -780,9 +780,10 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
                                                    unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
                                                    int traceQuery, int32_t *trI, double *trD, int trCap, int32_t *trN,
                                                    int activeLanes, const double *cacheS, int budget, const int32_t *rTable, int nF,
-                                                   const int32_t *cacheRow)
+                                                   const int32_t *cacheRow, int leanVisits)
 {
     __shared__ Lds lds;
+    __shared__ WaveLds wl;             // the wavefront-wide appendProbNode of the lane searches (wave_dev.h)
     const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
@@ -791,7 +792,11 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
     // Cached (whole-tree) launches run ONE search per wavefront (activeLanes == 1): lane 0 is the state machine, and all 64
     // lanes join it whenever the search descends into a clade in the cached regime (wave_scan_clade, search_dev.h).
     const bool coop = T.scan != nullptr;
-    if (!coop && (int)threadIdx.x >= activeLanes) return;
+    // lane searches on a tree without local references: the lanes that do not search stay and help -- every cached-regime
+    // placement score a searching lane needs is computed by all 64 (wave_append), one request after the other
+    const bool assist = !coop && leanVisits != 0 && cacheS == nullptr;
+    const int coopMax = leanVisits > 1 ? leanVisits - 1 : 0;                 // (leanVisits = 1 + the most requests served one by one)
+    if (!coop && !assist && (int)threadIdx.x >= activeLanes) return;
     const bool searcher = (int)threadIdx.x < activeLanes;
     const size_t lane = (size_t)blockIdx.x * activeLanes + (searcher ? threadIdx.x : 0);
     uint8_t *base = wsBase + lane * LB.total;
@@ -851,6 +856,8 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             // routing hint only: the dense tier runs the same search from the start.)
             S.budget = (!U && budget > MAPLE_ZERO_DIST_BUDGET && T.nd[node].dist == 0.0) ? MAPLE_ZERO_DIST_BUDGET : budget;
             S.overBudget = false;
+            S.lean = assist && q != traceQuery;                            // (a traced query keeps to step(), which records its visits)
+            S.wantApp = S.haveMail = false;
             S.trI = nullptr;
             if (q == traceQuery && trI) { S.trI = trI; S.trD = trD; S.trCap = trCap; S.trN = 0; }
             S.begin(parent, childIdx, curLK, T.nd[node].dist);
@@ -870,11 +877,11 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
 #ifdef MAPLE_SPR_PROFILE
             const long long t0 = wall_clock64();
             const bool notUpd = !ws.st[ws.sp - 1].upd;
-            const bool rep = S.cached && notUpd;
+            const bool rep = (S.cached || S.lean) && notUpd;
             if (rep) S.replayCached(); else { S.step(); if (!notUpd) out[q].nSteps++; }
             if (notUpd) out[q].tReplay += wall_clock64() - t0; else out[q].tStep += wall_clock64() - t0;
 #else
-            if (S.cached && !ws.st[ws.sp - 1].upd) S.replayCached();
+            if ((S.cached || S.lean) && !ws.st[ws.sp - 1].upd) S.replayCached();
             else S.step();
 #endif
         } else if (S.refineIdx < ws.nB) {
@@ -931,6 +938,39 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             active = false;
         }
         } while (0);
+        if (assist) {
+            // ---- every lane is here: the scores the searching lanes asked for, one wavefront-wide walk each ----
+            unsigned long long req = __ballot(searcher && !done && S.wantApp);
+            if (__popcll(req) > coopMax) {
+                // many lanes ask at once: each walks its own pair, all of them in lockstep (one walk's latency for all of
+                // them, a third of the instructions per score of the wavefront-wide form); the wavefront-wide form is for
+                // the few lanes still searching when the others are done
+                if (searcher && !done && S.wantApp) {
+                    const double v = append_walk(c, S.ref(S.treeList(T.nd[S.appT1].totUp)), S.ref(S.appHRpr), S.isRemovedTip, S.removedBLen);
+                    S.mailScore = v; S.mailNode = S.appT1; S.haveMail = true; S.wantApp = false;
+                }
+                req = 0;
+            }
+            while (req) {
+                const int r = (int)__ffsll((long long)req) - 1;
+                req &= req - 1;
+                TList tp{nullptr, nullptr, 0, 0}, tc{nullptr, nullptr, 0, 0};
+                if ((int)threadIdx.x == r) { tp = S.L(S.treeList(T.nd[S.appT1].totUp)); tc = S.L(S.appHRpr); }
+                auto bc64 = [&](unsigned long long x) {
+                    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(x >> 32), r) << 32)
+                           | (uint32_t)__builtin_amdgcn_readlane((int)x, r);
+                };
+                const ListRef P{(const uint2 *)bc64((unsigned long long)tp.w), (const double *)bc64((unsigned long long)tp.aux)};
+                const ListRef Cq{(const uint2 *)bc64((unsigned long long)tc.w), (const double *)bc64((unsigned long long)tc.aux)};
+                const int nP = __builtin_amdgcn_readlane(tp.n, r), nC = __builtin_amdgcn_readlane(tc.n, r);
+                const bool tipq = __builtin_amdgcn_readlane(S.isRemovedTip ? 1 : 0, r) != 0;
+                const double blq = __longlong_as_double((long long)bc64((unsigned long long)__double_as_longlong(S.removedBLen)));
+                const double v = wave_append(c, P, nP, Cq, nC, tipq, blq, wl);
+                if ((int)threadIdx.x == r) { S.mailScore = v; S.mailNode = S.appT1; S.haveMail = true; S.wantApp = false; }
+            }
+            if (!__ballot(!done)) break;
+            continue;
+        }
         if (!coop) {
             if (done) break;
             continue;
@@ -2639,6 +2679,11 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // Runs the searches `todo` (results into ho[slot[]]).  Queries whose per-lane workspace overflowed (status -3) are
     // re-run with 8x the workspace, twice at most.  cacheS (optional) = row-major (|todo| x T.n) cached scores.
     bool heavyQueries = false;
+    // Lane searches assisted by their wavefront (k_spr_search, wave_dev.h): on trees without local references, and without an
+    // error model -- with one, every search from a zero-length branch also runs to the budget here (no routing hint), the lane
+    // tier is then bound by its throughput, not by its longest search, and 24 lanes walking in lockstep do better (100 000
+    // tips, full model: 460 ms against 541).
+    const bool assistOK = !c->tree_has_mut && !c->dm.usingErrorRate && !getenv("MAPLE_NO_LEAN");
     auto run_queries = [&](std::vector<int32_t> todo, std::vector<int32_t> slot, const double *cacheS, int budgetNow,
                            const int32_t *rTable, int nF) -> int {
         // the few cached (whole-tree) searches get room up front; more when the budgeted pass already ran out of it
@@ -2690,6 +2735,10 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             int activeLanes = (lanesWanted + lanesDiv - 1) / lanesDiv;
             if (activeLanes < 1) activeLanes = 1;
             if (activeLanes > 64) activeLanes = 64;
+            // wave-assisted lane searches (below): the wavefront serves its lanes' score requests one after the other, so few
+            // searching lanes per wavefront (100 000 tips, budget 2 132: 2 / 4 / 6 / 8 / 16 / 24 lanes -> 298 / 281 / 279 / 289 /
+            // 394 / 345 ms; without the assistance 375)
+            if (!cacheS && assistOK && activeLanes > 4) activeLanes = 4;
             if (const char *e = getenv("MAPLE_SPR_LANES")) activeLanes = std::max(1, std::min(64, atoi(e)));   // (experiments)
             int nWaves = (lanesWanted + activeLanes - 1) / activeLanes;
             if (nWaves > 8192) nWaves = 8192;
@@ -2723,6 +2772,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 launchLanes = 1;                                         // one search per wavefront, 64 lanes per clade scan
                 launchWaves = lanes;                                     // (the workspace is sized for `lanes` searches at a time)
             } else { Tk.scan = nullptr; Tk.scanParent = nullptr; Tk.scanDepthCap = 0; }
+            int coopMaxHost = 8;                                            // (see k_spr_search: requests served one by one)
+            if (const char *e = getenv("MAPLE_COOP_MAX")) coopMaxHost = std::max(0, atoi(e));
             hipEvent_t e0, e1;
             TRY(ev_pair(c, &e0, &e1, cacheS ? MAPLE_K_SPR_REPLAY : MAPLE_K_SPR_SEARCH, (double)m, 0.0));
             HIPCK(c, hipEventRecord(e0, c->stream));
@@ -2732,7 +2783,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                                                                          attempt == 0 ? c->trace_query : -1, c->s_trace_i.p,
                                                                          c->s_trace_d.p, 4096, c->s_trace_i.p ? c->s_trace_i.p + 4 * 4096 : nullptr,
                                                                          launchLanes, cacheS, budgetNow, rTable, nF,
-                                                                         cacheS ? c->s_i32[1].p : nullptr));
+                                                                         cacheS ? c->s_i32[1].p : nullptr,
+                                                                         assistOK ? 1 + coopMaxHost : 0));
             HIPCK(c, hipGetLastError());
             HIPCK(c, hipEventRecord(e1, c->stream));
             std::vector<SearchOut> part(m);
@@ -2778,6 +2830,9 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // tips (256: 91 ms per round; 128: 100, 384: 97) and at 100 000 (2 048: 1.08 s; 256: 2.69, 1 024: 1.13, 4 096: 1.20)
     int wideBudget = sp->wideSearchBudget == 0 ? std::max(MAPLE_WIDE_BUDGET_DEFAULT, std::min(8192, c->n_scored / 64))
                                                : sp->wideSearchBudget;
+    // (a long search costs the wave-assisted lane tier a tenth of what it cost one lane: twice the budget pays -- 100 000 tips:
+    // 2 132 / 3 072 / 4 096 / 6 144 -> 693 / 688 / 668 / 692 ms per round; 10 000 tips: 256 / 384 / 512 -> 75 / 72 / 72)
+    if (sp->wideSearchBudget == 0 && !c->tree_has_mut && !c->dm.usingErrorRate && !getenv("MAPLE_NO_LEAN")) wideBudget *= 2;
     if (const char *e = getenv("MAPLE_WIDE_BUDGET")) wideBudget = atoi(e);        // (experiments)
     const bool hybrid = wideBudget > 0;
     if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !getenv("MAPLE_NO_SCAN")) {

@@ -155,6 +155,14 @@ template <bool RV, bool U, bool SS> struct Search {
     bool scanFirstScored = false, wantScan = false;
     int budget = 0;                    // > 0: give up (status -5) after this many traversal placements without a cache
     bool overBudget = false;
+    // lean: no score table, but the items that arrive with needsUpdating == False still go through the register-resident
+    // loop of replayCached().  The score of a branch is then ASKED FOR: the loop puts the item back, leaves (wantApp), the
+    // whole wavefront computes appendProbNode(probVectTotUp[appT1], removed list) (wave_append, wave_dev.h) and hands it over
+    // in the mailbox; the loop is entered again and carries on with that item.  (Trees without MAT local references: the
+    // removed list is one object for the whole search.)
+    bool lean = false, wantApp = false, haveMail = false;
+    int appT1 = -1, appHRpr = -1, mailNode = -1;
+    double mailScore = 0.0;
     // optional visit trace of ONE query (debugging / parity of the visit sequence)
     int32_t *trI = nullptr; double *trD = nullptr; int trN = 0, trCap = 0;
     __device__ inline void trace(int t1, int dir, int upd, int fails, double lastLK, double midProb)
@@ -496,6 +504,7 @@ template <bool RV, bool U, bool SS> struct Search {
         BestRec *br = ws.best;
         const NodeRec *nd = T.nd;
         const double *cs = cached;
+        const bool own = cs == nullptr;                                  // lean mode: scores are asked for, one at a time
         // the reference shortens the removed list in place at every improvement (M:7087); in the cached regime that has no
         // reader before the refinement, so the (few distinct) own handles are remembered and shortened on the way out
         int hShorten[4] = {-1, -1, -1, -1};
@@ -537,7 +546,17 @@ template <bool RV, bool U, bool SS> struct Search {
             if (it.dir == 0) {
                 if (!(upT == node || upT < 0) && (r1.dist > eff || rootChild)) {
                     if (r1.totUp < 0) continue;
-                    midProb = cs[r1.preRank]; nApp++;
+                    if (!own) midProb = cs[r1.preRank];
+                    else if (haveMail && mailNode == t1) { midProb = mailScore; haveMail = false; }
+                    else {
+                        // ask the wavefront for it -- after the shortenings the reference would have done by now (M:7087)
+                        for (int k = 0; k < 4; k++) if (hShorten[k] >= 0) { opShortenInPlace(hShorten[k]); hShorten[k] = -1; }
+                        top = it; haveTop = true;
+                        wantApp = true; appT1 = t1; appHRpr = it.hRpr;
+                        break;
+                    }
+                    nApp++;
+                    if (own && budget > 0 && nApp > budget) { overBudget = true; break; }
                     if (midProb > best - thrOpt) {
                         if (nB >= capB) { ws.overflow = 5; break; }
                         br[nB++] = BestRec{t1, -1, -1, -1, it.hRpr, midProb, 0.0};
@@ -566,7 +585,17 @@ template <bool RV, bool U, bool SS> struct Search {
                 const int other = (it.dir == 1) ? r1.c1 : r1.c0;
                 if (upT >= 0 && (r1.dist > eff || rootChild)) {
                     if (r1.totUp < 0) continue;
-                    midProb = cs[r1.preRank]; nApp++;
+                    if (!own) midProb = cs[r1.preRank];
+                    else if (haveMail && mailNode == t1) { midProb = mailScore; haveMail = false; }
+                    else {
+                        // ask the wavefront for it -- after the shortenings the reference would have done by now (M:7087)
+                        for (int k = 0; k < 4; k++) if (hShorten[k] >= 0) { opShortenInPlace(hShorten[k]); hShorten[k] = -1; }
+                        top = it; haveTop = true;
+                        wantApp = true; appT1 = t1; appHRpr = it.hRpr;
+                        break;
+                    }
+                    nApp++;
+                    if (own && budget > 0 && nApp > budget) { overBudget = true; break; }
                     if (midProb >= (best - thrOpt)) {
                         if (nB >= capB) { ws.overflow = 5; break; }
                         br[nB++] = BestRec{t1, -1, -1, -1, it.hRpr, midProb, 0.0};
