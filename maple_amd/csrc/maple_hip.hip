@@ -951,11 +951,12 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
                 }
                 req = 0;
             }
+            // (every asking lane looks its two lists up first, all of them at once: the look-ups are chains of dependent loads)
+            TList tp{nullptr, nullptr, 0, 0}, tc{nullptr, nullptr, 0, 0};
+            if (req && searcher && !done && S.wantApp) { tp = S.L(S.treeList(T.nd[S.appT1].totUp)); tc = S.L(S.appHRpr); }
             while (req) {
                 const int r = (int)__ffsll((long long)req) - 1;
                 req &= req - 1;
-                TList tp{nullptr, nullptr, 0, 0}, tc{nullptr, nullptr, 0, 0};
-                if ((int)threadIdx.x == r) { tp = S.L(S.treeList(T.nd[S.appT1].totUp)); tc = S.L(S.appHRpr); }
                 auto bc64 = [&](unsigned long long x) {
                     return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(x >> 32), r) << 32)
                            | (uint32_t)__builtin_amdgcn_readlane((int)x, r);
