@@ -783,7 +783,6 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
                                                    const int32_t *cacheRow, int leanVisits)
 {
     __shared__ Lds lds;
-    __shared__ WaveLds wl;             // the wavefront-wide appendProbNode of the lane searches (wave_dev.h)
     const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
@@ -794,7 +793,9 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
     const bool coop = T.scan != nullptr;
     // lane searches on a tree without local references: the lanes that do not search stay and help -- every cached-regime
     // placement score a searching lane needs is computed by all 64 (wave_append), one request after the other
-    const bool assist = !coop && leanVisits != 0 && cacheS == nullptr;
+    // (not compiled into the kernels of the error models, where it is not used: their site factors are large, and with the
+    // wavefront-wide walk inlined next to them the whole kernel spilled four times as many registers)
+    const bool assist = !U && !coop && leanVisits != 0 && cacheS == nullptr;
     const int coopMax = leanVisits > 1 ? leanVisits - 1 : 0;                 // (leanVisits = 1 + the most requests served one by one)
     if (!coop && !assist && (int)threadIdx.x >= activeLanes) return;
     const bool searcher = (int)threadIdx.x < activeLanes;
@@ -809,7 +810,8 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
     ws.ais = (double *)(base + LB.w + LB.aux + LB.h + LB.st + LB.best);
     ws.L = L;
     Search<RV, U, SS> S(c, av, mv, T, P, ws);
-    extern __shared__ double dynLds[];   // coop: per-depth (lastLK, failedPasses) slots of the clade scan
+    extern __shared__ double dynLds[];   // coop: per-depth (lastLK, failedPasses) slots of the clade scan; assisted lane searches:
+    WaveLds &wl = *(WaveLds *)dynLds;    // the staging area of the wavefront-wide appendProbNode (wave_dev.h)
     double *slotLK = dynLds;
     int *slotFails = (int *)(dynLds + T.scanDepthCap);
     unsigned *slotOwner = (unsigned *)(slotFails + T.scanDepthCap);
@@ -938,7 +940,7 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             active = false;
         }
         } while (0);
-        if (assist) {
+        if constexpr (!U) if (assist) {
             // ---- every lane is here: the scores the searching lanes asked for, one wavefront-wide walk each ----
             unsigned long long req = __ballot(searcher && !done && S.wantApp);
             if (__popcll(req) > coopMax) {
@@ -2684,7 +2686,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // error model -- with one, every search from a zero-length branch also runs to the budget here (no routing hint), the lane
     // tier is then bound by its throughput, not by its longest search, and 24 lanes walking in lockstep do better (100 000
     // tips, full model: 460 ms against 541).
-    const bool assistOK = !c->tree_has_mut && !c->dm.usingErrorRate && !getenv("MAPLE_NO_LEAN");
+    bool assistOK = !c->tree_has_mut && !c->dm.usingErrorRate && !getenv("MAPLE_NO_LEAN");
+    if (const char *e = getenv("MAPLE_LEAN")) assistOK = !c->tree_has_mut && !c->dm.usingErrorRate && atoi(e) != 0;   // (experiments)
     auto run_queries = [&](std::vector<int32_t> todo, std::vector<int32_t> slot, const double *cacheS, int budgetNow,
                            const int32_t *rTable, int nF) -> int {
         // the few cached (whole-tree) searches get room up front; more when the budgeted pass already ran out of it
@@ -2772,7 +2775,10 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 dynLds = ((size_t)Tk.scanDepthCap * 16 + 15) & ~(size_t)15;
                 launchLanes = 1;                                         // one search per wavefront, 64 lanes per clade scan
                 launchWaves = lanes;                                     // (the workspace is sized for `lanes` searches at a time)
-            } else { Tk.scan = nullptr; Tk.scanParent = nullptr; Tk.scanDepthCap = 0; }
+            } else {
+                Tk.scan = nullptr; Tk.scanParent = nullptr; Tk.scanDepthCap = 0;
+                if (!cacheS && assistOK) dynLds = sizeof(WaveLds);
+            }
             int coopMaxHost = 8;                                            // (see k_spr_search: requests served one by one)
             if (const char *e = getenv("MAPLE_COOP_MAX")) coopMaxHost = std::max(0, atoi(e));
             hipEvent_t e0, e1;

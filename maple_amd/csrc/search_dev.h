@@ -496,6 +496,13 @@ template <bool RV, bool U, bool SS> struct Search {
     // such trees, so the reference's in-place shorten() (M:7087) is done once, at the first improvement.
     __device__ __forceinline__ void replayCached()
     {
+        if constexpr (U) replayCachedT<false>();                         // (lean searches are not used with an error model)
+        else { if (cached) replayCachedT<false>(); else replayCachedT<true>(); }
+    }
+    // OWN: no score table -- a score is asked of the wavefront (lean lane searches); a template so that the replay over a
+    // table does not carry the other form's code and registers
+    template <bool OWN> __device__ __forceinline__ void replayCachedT()
+    {
         int sp = ws.sp, nB = ws.nB, nApp = nAppend;
         double best = bestLKdiff;
         const double thrOpt = P.thrOptTopo, thrCons = P.thrConsec, thrLK = P.thrLKtopology, eff = P.effNon0;
@@ -504,7 +511,7 @@ template <bool RV, bool U, bool SS> struct Search {
         BestRec *br = ws.best;
         const NodeRec *nd = T.nd;
         const double *cs = cached;
-        const bool own = cs == nullptr;                                  // lean mode: scores are asked for, one at a time
+        constexpr bool own = OWN;
         // the reference shortens the removed list in place at every improvement (M:7087); in the cached regime that has no
         // reader before the refinement, so the (few distinct) own handles are remembered and shortened on the way out
         int hShorten[4] = {-1, -1, -1, -1};
