@@ -2682,12 +2682,12 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // Runs the searches `todo` (results into ho[slot[]]).  Queries whose per-lane workspace overflowed (status -3) are
     // re-run with 8x the workspace, twice at most.  cacheS (optional) = row-major (|todo| x T.n) cached scores.
     bool heavyQueries = false;
-    // Lane searches assisted by their wavefront (k_spr_search, wave_dev.h): on trees without local references, and without an
+    // Lane searches assisted by their wavefront (k_spr_search, wave_dev.h): without an
     // error model -- with one, every search from a zero-length branch also runs to the budget here (no routing hint), the lane
     // tier is then bound by its throughput, not by its longest search, and 24 lanes walking in lockstep do better (100 000
     // tips, full model: 460 ms against 541).
-    bool assistOK = !c->tree_has_mut && !c->dm.usingErrorRate && !getenv("MAPLE_NO_LEAN");
-    if (const char *e = getenv("MAPLE_LEAN")) assistOK = !c->tree_has_mut && !c->dm.usingErrorRate && atoi(e) != 0;   // (experiments)
+    bool assistOK = !c->dm.usingErrorRate && !getenv("MAPLE_NO_LEAN");
+    if (getenv("MAPLE_NO_LEAN_MAT") && c->tree_has_mut) assistOK = false;                                              // (experiments)
     auto run_queries = [&](std::vector<int32_t> todo, std::vector<int32_t> slot, const double *cacheS, int budgetNow,
                            const int32_t *rTable, int nF) -> int {
         // the few cached (whole-tree) searches get room up front; more when the budgeted pass already ran out of it
@@ -2839,7 +2839,9 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                                                : sp->wideSearchBudget;
     // (a long search costs the wave-assisted lane tier a tenth of what it cost one lane: twice the budget pays -- 100 000 tips:
     // 2 132 / 3 072 / 4 096 / 6 144 -> 693 / 688 / 668 / 692 ms per round; 10 000 tips: 256 / 384 / 512 -> 75 / 72 / 72)
-    if (sp->wideSearchBudget == 0 && !c->tree_has_mut && !c->dm.usingErrorRate && !getenv("MAPLE_NO_LEAN")) wideBudget *= 2;
+    if (sp->wideSearchBudget == 0 && !c->dm.usingErrorRate && !getenv("MAPLE_NO_LEAN")
+        && !(getenv("MAPLE_NO_LEAN_MAT") && c->tree_has_mut))
+        wideBudget *= 2;
     if (const char *e = getenv("MAPLE_WIDE_BUDGET")) wideBudget = atoi(e);        // (experiments)
     const bool hybrid = wideBudget > 0;
     if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !getenv("MAPLE_NO_SCAN")) {

@@ -526,6 +526,13 @@ template <bool RV, bool U, bool SS> struct Search {
             top.distance = 0.0; top.lastLK = lastLK;
             haveTop = true;
         };
+        // the removed list for an item in another reference frame: from the per-frame table (replay over a score table), or
+        // passed through the branch that separates the frames right here, as step() does (M:7119 / 7342 / 7392)
+        auto hFor = [&](int hRpr, int frameFrom, int frameTo, int branchNode, bool dirUp) -> int {
+            if (frameTo == frameFrom) return hRpr;
+            if (!own) return rT ? treeList(rT[frameTo]) : hRpr;
+            return opPass(hRpr, nd[branchNode].mutId, dirUp);
+        };
         for (;;) {
             StackItem it;
             if (haveTop) { it = top; haveTop = false; }
@@ -585,8 +592,9 @@ template <bool RV, bool U, bool SS> struct Search {
                 else go = (fails <= allowed || midProb > (best - thrLK)) && r1.c0 >= 0;
                 if (go) {
                     if (sp + 3 > capS) { ws.overflow = 4; break; }
-                    if (r1.upRight >= 0) push(r1.c0, 0, fails, (rT && r1.c0Frame != r1.frameOf) ? treeList(rT[r1.c0Frame]) : it.hRpr, midProb);
-                    if (r1.upLeft >= 0) push(r1.c1, 0, fails, (rT && r1.c1Frame != r1.frameOf) ? treeList(rT[r1.c1Frame]) : it.hRpr, midProb);
+                    if (r1.upRight >= 0) push(r1.c0, 0, fails, hFor(it.hRpr, r1.frameOf, r1.c0Frame, r1.c0, false), midProb);
+                    if (r1.upLeft >= 0) push(r1.c1, 0, fails, hFor(it.hRpr, r1.frameOf, r1.c1Frame, r1.c1, false), midProb);
+                    if (own && ws.overflow) break;
                 }
             } else {
                 const int other = (it.dir == 1) ? r1.c1 : r1.c0;
@@ -618,12 +626,13 @@ template <bool RV, bool U, bool SS> struct Search {
                 if (upT >= 0) {
                     if (((it.dir == 1) ? r1.upLeft : r1.upRight) < 0) continue;
                     const int oFrame = (it.dir == 1) ? r1.c1Frame : r1.c0Frame;
-                    push(other, 0, fails, (rT && oFrame != r1.frameOf) ? treeList(rT[oFrame]) : it.hRpr, midProb);
-                    push(upT, (int)r1.whichChild + 1, fails, (rT && r1.upFrame != r1.frameOf) ? treeList(rT[r1.upFrame]) : it.hRpr, midProb);
+                    push(other, 0, fails, hFor(it.hRpr, r1.frameOf, oFrame, other, false), midProb);
+                    push(upT, (int)r1.whichChild + 1, fails, hFor(it.hRpr, r1.frameOf, r1.upFrame, t1, true), midProb);
                 } else {
                     const int oFrame = (it.dir == 1) ? r1.c1Frame : r1.c0Frame;
-                    push(other, 0, fails, (rT && oFrame != r1.frameOf) ? treeList(rT[oFrame]) : it.hRpr, midProb);
+                    push(other, 0, fails, hFor(it.hRpr, r1.frameOf, oFrame, other, false), midProb);
                 }
+                if (own && ws.overflow) break;
             }
         }
         if (haveTop) st[sp++] = top;
