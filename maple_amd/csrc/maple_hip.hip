@@ -859,7 +859,7 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             S.budget = (!U && budget > MAPLE_ZERO_DIST_BUDGET && T.nd[node].dist == 0.0) ? MAPLE_ZERO_DIST_BUDGET : budget;
             S.overBudget = false;
             S.lean = assist && q != traceQuery;                            // (a traced query keeps to step(), which records its visits)
-            S.wantApp = S.haveMail = false;
+            S.wantApp = S.haveMail = S.stepOnce = false;
             S.trI = nullptr;
             if (q == traceQuery && trI) { S.trI = trI; S.trD = trD; S.trCap = trCap; S.trN = 0; }
             S.begin(parent, childIdx, curLK, T.nd[node].dist);
@@ -879,12 +879,12 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
 #ifdef MAPLE_SPR_PROFILE
             const long long t0 = wall_clock64();
             const bool notUpd = !ws.st[ws.sp - 1].upd;
-            const bool rep = (S.cached || S.lean) && notUpd;
-            if (rep) S.replayCached(); else { S.step(); if (!notUpd) out[q].nSteps++; }
+            const bool rep = (S.cached || S.lean) && notUpd && !S.stepOnce;
+            if (rep) S.replayCached(); else { S.stepOnce = false; S.step(); if (!notUpd) out[q].nSteps++; }
             if (notUpd) out[q].tReplay += wall_clock64() - t0; else out[q].tStep += wall_clock64() - t0;
 #else
-            if ((S.cached || S.lean) && !ws.st[ws.sp - 1].upd) S.replayCached();
-            else S.step();
+            if ((S.cached || S.lean) && !ws.st[ws.sp - 1].upd && !S.stepOnce) S.replayCached();
+            else { S.stepOnce = false; S.step(); }
 #endif
         } else if (S.refineIdx < ws.nB) {
 #ifdef MAPLE_SPR_PROFILE

@@ -161,6 +161,8 @@ template <bool RV, bool U, bool SS> struct Search {
     // in the mailbox; the loop is entered again and carries on with that item.  (Trees without MAT local references: the
     // removed list is one object for the whole search.)
     bool lean = false, wantApp = false, haveMail = false;
+    bool stepOnce = false;             // the item on top crosses into another MAT reference frame: step() takes it (it passes the
+                                       // removed list through the branch, M:7119 / 7342 / 7392), the lean loop carries on after it
     int appT1 = -1, appHRpr = -1, mailNode = -1;
     double mailScore = 0.0;
     // optional visit trace of ONE query (debugging / parity of the visit sequence)
@@ -526,13 +528,6 @@ template <bool RV, bool U, bool SS> struct Search {
             top.distance = 0.0; top.lastLK = lastLK;
             haveTop = true;
         };
-        // the removed list for an item in another reference frame: from the per-frame table (replay over a score table), or
-        // passed through the branch that separates the frames right here, as step() does (M:7119 / 7342 / 7392)
-        auto hFor = [&](int hRpr, int frameFrom, int frameTo, int branchNode, bool dirUp) -> int {
-            if (frameTo == frameFrom) return hRpr;
-            if (!own) return rT ? treeList(rT[frameTo]) : hRpr;
-            return opPass(hRpr, nd[branchNode].mutId, dirUp);
-        };
         for (;;) {
             StackItem it;
             if (haveTop) { it = top; haveTop = false; }
@@ -546,6 +541,11 @@ template <bool RV, bool U, bool SS> struct Search {
             int fails = it.fails;
             double midProb = it.lastLK;
             const bool rootChild = r1.upIsRoot != 0;
+            if (own && (r1.c0Frame != r1.frameOf || r1.c1Frame != r1.frameOf || r1.upFrame != r1.frameOf)) {
+                top = it; haveTop = true;
+                stepOnce = true;
+                break;
+            }
             if (it.dir == 0 && T.scan) {
                 // The whole clade below this item goes to the wavefront (wave_scan_clade): this lane hands the item over
                 // and applies the outcome; what the LIFO stack would do with the item and everything it pushes happens
@@ -592,9 +592,8 @@ template <bool RV, bool U, bool SS> struct Search {
                 else go = (fails <= allowed || midProb > (best - thrLK)) && r1.c0 >= 0;
                 if (go) {
                     if (sp + 3 > capS) { ws.overflow = 4; break; }
-                    if (r1.upRight >= 0) push(r1.c0, 0, fails, hFor(it.hRpr, r1.frameOf, r1.c0Frame, r1.c0, false), midProb);
-                    if (r1.upLeft >= 0) push(r1.c1, 0, fails, hFor(it.hRpr, r1.frameOf, r1.c1Frame, r1.c1, false), midProb);
-                    if (own && ws.overflow) break;
+                    if (r1.upRight >= 0) push(r1.c0, 0, fails, (rT && r1.c0Frame != r1.frameOf) ? treeList(rT[r1.c0Frame]) : it.hRpr, midProb);
+                    if (r1.upLeft >= 0) push(r1.c1, 0, fails, (rT && r1.c1Frame != r1.frameOf) ? treeList(rT[r1.c1Frame]) : it.hRpr, midProb);
                 }
             } else {
                 const int other = (it.dir == 1) ? r1.c1 : r1.c0;
@@ -626,13 +625,12 @@ template <bool RV, bool U, bool SS> struct Search {
                 if (upT >= 0) {
                     if (((it.dir == 1) ? r1.upLeft : r1.upRight) < 0) continue;
                     const int oFrame = (it.dir == 1) ? r1.c1Frame : r1.c0Frame;
-                    push(other, 0, fails, hFor(it.hRpr, r1.frameOf, oFrame, other, false), midProb);
-                    push(upT, (int)r1.whichChild + 1, fails, hFor(it.hRpr, r1.frameOf, r1.upFrame, t1, true), midProb);
+                    push(other, 0, fails, (rT && oFrame != r1.frameOf) ? treeList(rT[oFrame]) : it.hRpr, midProb);
+                    push(upT, (int)r1.whichChild + 1, fails, (rT && r1.upFrame != r1.frameOf) ? treeList(rT[r1.upFrame]) : it.hRpr, midProb);
                 } else {
                     const int oFrame = (it.dir == 1) ? r1.c1Frame : r1.c0Frame;
-                    push(other, 0, fails, hFor(it.hRpr, r1.frameOf, oFrame, other, false), midProb);
+                    push(other, 0, fails, (rT && oFrame != r1.frameOf) ? treeList(rT[oFrame]) : it.hRpr, midProb);
                 }
-                if (own && ws.overflow) break;
             }
         }
         if (haveTop) st[sp++] = top;
