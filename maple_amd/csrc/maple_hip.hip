@@ -773,8 +773,11 @@ static LaneBytes lane_bytes(const WsLayout &L)
     return b;
 }
 
-template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel *__restrict__ mp, ArenaView av, MutView mv, DevTree T, SearchParams P, int n,
+// ASSIST: with the wave-assisted lane searches compiled in.  A kernel of its own (k_spr_search_assisted): inlined next to the
+// rest, that path costs every launch registers (with an error model the whole kernel spilled four times as many, and the
+// replay launches, which never use it, slowed by a quarter).
+template <bool RV, bool U, bool SS, bool ASSIST>
+__device__ __forceinline__ void spr_search_impl(const DevModel *__restrict__ mp, ArenaView av, MutView mv, DevTree T, SearchParams P, int n,
                                                    const int32_t *nodes, WsLayout L, LaneBytes LB, uint8_t *wsBase,
                                                    int32_t *counter, SearchOut *out, uint2 *poolW, double *poolA,
                                                    unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
@@ -795,7 +798,7 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
     // placement score a searching lane needs is computed by all 64 (wave_append), one request after the other
     // (not compiled into the kernels of the error models, where it is not used: their site factors are large, and with the
     // wavefront-wide walk inlined next to them the whole kernel spilled four times as many registers)
-    const bool assist = !U && !coop && leanVisits != 0 && cacheS == nullptr;
+    const bool assist = ASSIST && !coop && leanVisits != 0 && cacheS == nullptr;
     const int coopMax = leanVisits > 1 ? leanVisits - 1 : 0;                 // (leanVisits = 1 + the most requests served one by one)
     if (!coop && !assist && (int)threadIdx.x >= activeLanes) return;
     const bool searcher = (int)threadIdx.x < activeLanes;
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
     ws.best = (BestRec *)(base + LB.w + LB.aux + LB.h + LB.st);
     ws.ais = (double *)(base + LB.w + LB.aux + LB.h + LB.st + LB.best);
     ws.L = L;
-    Search<RV, U, SS> S(c, av, mv, T, P, ws);
+    Search<RV, U, SS, ASSIST> S(c, av, mv, T, P, ws);
     extern __shared__ double dynLds[];   // coop: per-depth (lastLK, failedPasses) slots of the clade scan; assisted lane searches:
     WaveLds &wl = *(WaveLds *)dynLds;    // the staging area of the wavefront-wide appendProbNode (wave_dev.h)
     double *slotLK = dynLds;
@@ -940,7 +943,7 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
             active = false;
         }
         } while (0);
-        if constexpr (!U) if (assist) {
+        if constexpr (ASSIST) if (assist) {
             // ---- every lane is here: the scores the searching lanes asked for, one wavefront-wide walk each ----
             unsigned long long req = __ballot(searcher && !done && S.wantApp);
             if (__popcll(req) > coopMax) {
@@ -1013,6 +1016,24 @@ __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(const DevModel
         }
         if (__builtin_amdgcn_readfirstlane(done ? 1 : 0)) break;
     }
+}
+
+#define MAPLE_SPR_KERNEL_ARGS const DevModel *__restrict__ mp, ArenaView av, MutView mv, DevTree T, SearchParams P, int n,            \
+    const int32_t *nodes, WsLayout L, LaneBytes LB, uint8_t *wsBase, int32_t *counter, SearchOut *out, uint2 *poolW, double *poolA, \
+    unsigned long long *poolUsed, long long poolCapW, long long poolCapA, int traceQuery, int32_t *trI, double *trD, int trCap,     \
+    int32_t *trN, int activeLanes, const double *cacheS, int budget, const int32_t *rTable, int nF, const int32_t *cacheRow,        \
+    int leanVisits
+#define MAPLE_SPR_KERNEL_PASS mp, av, mv, T, P, n, nodes, L, LB, wsBase, counter, out, poolW, poolA, poolUsed, poolCapW, poolCapA,   \
+    traceQuery, trI, trD, trCap, trN, activeLanes, cacheS, budget, rTable, nF, cacheRow, leanVisits
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(MAPLE_SPR_KERNEL_ARGS)
+{
+    spr_search_impl<RV, U, SS, false>(MAPLE_SPR_KERNEL_PASS);
+}
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search_assisted(MAPLE_SPR_KERNEL_ARGS)
+{
+    spr_search_impl<RV, U, SS, true>(MAPLE_SPR_KERNEL_PASS);
 }
 
 // compaction of scratch lists into the arena: one wavefront per list, coalesced copies
@@ -2686,7 +2707,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // error model -- with one, every search from a zero-length branch also runs to the budget here (no routing hint), the lane
     // tier is then bound by its throughput, not by its longest search, and 24 lanes walking in lockstep do better (100 000
     // tips, full model: 460 ms against 541).
-    bool assistOK = !c->dm.usingErrorRate && !getenv("MAPLE_NO_LEAN");
+    bool assistOK = !getenv("MAPLE_NO_LEAN") && (!c->dm.usingErrorRate || getenv("MAPLE_LEAN_ERR"));
+    const bool assistFew = !c->dm.usingErrorRate;      // few searching lanes per wavefront, every request served by all 64 lanes
     if (getenv("MAPLE_NO_LEAN_MAT") && c->tree_has_mut) assistOK = false;                                              // (experiments)
     auto run_queries = [&](std::vector<int32_t> todo, std::vector<int32_t> slot, const double *cacheS, int budgetNow,
                            const int32_t *rTable, int nF) -> int {
@@ -2742,7 +2764,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             // wave-assisted lane searches (below): the wavefront serves its lanes' score requests one after the other, so few
             // searching lanes per wavefront (100 000 tips, budget 2 132: 2 / 4 / 6 / 8 / 16 / 24 lanes -> 298 / 281 / 279 / 289 /
             // 394 / 345 ms; without the assistance 375)
-            if (!cacheS && assistOK && activeLanes > 4) activeLanes = 4;
+            if (!cacheS && assistOK && assistFew && activeLanes > 4) activeLanes = 4;
             if (const char *e = getenv("MAPLE_SPR_LANES")) activeLanes = std::max(1, std::min(64, atoi(e)));   // (experiments)
             int nWaves = (lanesWanted + activeLanes - 1) / activeLanes;
             if (nWaves > 8192) nWaves = 8192;
@@ -2784,14 +2806,17 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             hipEvent_t e0, e1;
             TRY(ev_pair(c, &e0, &e1, cacheS ? MAPLE_K_SPR_REPLAY : MAPLE_K_SPR_SEARCH, (double)m, 0.0));
             HIPCK(c, hipEventRecord(e0, c->stream));
-            DISPATCH3(c, k_spr_search, <<<launchWaves, 64, dynLds, c->stream>>>(c->d_model, view(c), mview(c), Tk, P, m, c->s_i32[0].p,
-                                                                         L, LB, c->s_search_ws.p, c->s_counter.p, dout, poolW,
-                                                                         poolA, poolUsed, poolCapW, poolCapA,
-                                                                         attempt == 0 ? c->trace_query : -1, c->s_trace_i.p,
-                                                                         c->s_trace_d.p, 4096, c->s_trace_i.p ? c->s_trace_i.p + 4 * 4096 : nullptr,
-                                                                         launchLanes, cacheS, budgetNow, rTable, nF,
-                                                                         cacheS ? c->s_i32[1].p : nullptr,
-                                                                         assistOK ? 1 + coopMaxHost : 0));
+#define MAPLE_SPR_LAUNCH_ARGS <<<launchWaves, 64, dynLds, c->stream>>>(c->d_model, view(c), mview(c), Tk, P, m, c->s_i32[0].p,          \
+                                                                         L, LB, c->s_search_ws.p, c->s_counter.p, dout, poolW,     \
+                                                                         poolA, poolUsed, poolCapW, poolCapA,                      \
+                                                                         attempt == 0 ? c->trace_query : -1, c->s_trace_i.p,       \
+                                                                         c->s_trace_d.p, 4096, c->s_trace_i.p ? c->s_trace_i.p + 4 * 4096 : nullptr, \
+                                                                         launchLanes, cacheS, budgetNow, rTable, nF,               \
+                                                                         cacheS ? c->s_i32[1].p : nullptr,                          \
+                                                                         assistOK ? 1 + coopMaxHost : 0)
+            if (!cacheS && assistOK) DISPATCH3(c, k_spr_search_assisted, MAPLE_SPR_LAUNCH_ARGS);
+            else DISPATCH3(c, k_spr_search, MAPLE_SPR_LAUNCH_ARGS);
+#undef MAPLE_SPR_LAUNCH_ARGS
             HIPCK(c, hipGetLastError());
             HIPCK(c, hipEventRecord(e1, c->stream));
             std::vector<SearchOut> part(m);

@@ -132,7 +132,8 @@ struct LaneWs {
     }
 };
 
-template <bool RV, bool U, bool SS> struct Search {
+// LEAN: the kernel this search runs in has the wave-assisted path (lean visits, wave_append) compiled in
+template <bool RV, bool U, bool SS, bool LEAN = false> struct Search {
     typedef Ctx<RV, U, SS> CT;
     const CT &c;
     const ArenaViewS &av;
@@ -498,7 +499,7 @@ template <bool RV, bool U, bool SS> struct Search {
     // such trees, so the reference's in-place shorten() (M:7087) is done once, at the first improvement.
     __device__ __forceinline__ void replayCached()
     {
-        if constexpr (U) replayCachedT<false>();                         // (lean searches are not used with an error model)
+        if constexpr (!LEAN) replayCachedT<false>();                     // (no lean visits in this kernel: none of their code)
         else { if (cached) replayCachedT<false>(); else replayCachedT<true>(); }
     }
     // OWN: no score table -- a score is asked of the wavefront (lean lane searches); a template so that the replay over a

@@ -93,10 +93,15 @@ if calib:
 # per kernel: HBM-side traffic per launch (calibrated), and for the scoring kernel the per-pair instruction counts
 traffic = {}
 for key in ("k_append_queries_lds", "k_append_queries", "k_spr_search"):
-    k = next((x for x in agg if x.startswith(key + "<") or x == key), None)
-    if not k:
+    # (k_spr_search: the plain kernel -- replay launches -- and k_spr_search_assisted -- the lane searches -- pooled: bench.py's
+    # roofline block averages over both kinds of launch)
+    ks = [x for x in agg if x.startswith(key + "<") or x == key or (key == "k_spr_search" and x.startswith("k_spr_search_assisted"))]
+    if not ks:
         continue
-    d = agg[k]
+    d = collections.defaultdict(list)
+    for k in ks:
+        for cn, vals in agg[k].items():
+            d[cn].extend(vals)
     fetch_b = avg(d, "FETCH_SIZE") * 1024 / (calib or 1.0)
     write_b = avg(d, "WRITE_SIZE") * 1024 / (wcal.get("stream") or 1.0)      # HBM-side bytes (partial-line stores included)
     traffic[key] = fetch_b + write_b
