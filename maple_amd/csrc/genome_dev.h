@@ -431,139 +431,7 @@ __device__ int merge_walk(const Ctx<RV, U, SS> &c, ListRef L1, double bLen1, boo
     for (;;) {
         const Ent &e1 = a.e, &e2 = b.e;
         int newPos;
-        if (e1.type == 5 || e2.type == 5) {
-            // one side carries no information: the other side is copied with its distance extended
-            const bool oneIsN = (e1.type == 5);
-            if (e1.type == 5 && e2.type == 5) {
-                newPos = min(e1.pos, e2.pos);
-                o.bare(5, newPos, 0);                                   // M:4498-4500
-            } else {
-                const Ent &e = oneIsN ? e2 : e1;
-                const double bl = oneIsN ? bLen2 : bLen1;
-                const bool tip = oneIsN ? tip2 : tip1;
-                if (e.type < 5) {
-                    newPos = (e.type < 4) ? pos + 1 : min(e1.pos, e2.pos);
-                    if (upDown && !oneIsN) {                            // upper list kept, M:4597-4619
-                        if (e.hasD1) o.put(e.type, newPos, e.ref, true, e.d0, true, e.d1 + bl, U && e.flag, nullptr);
-                        else if (e.hasD0) o.put(e.type, newPos, e.ref, true, e.d0 + bl, false, 0, U && e.flag, nullptr);
-                        else if (bl != 0.0) o.put(e.type, newPos, e.ref, true, bl, false, 0, false, nullptr);
-                        else o.bare(e.type, newPos, e.ref);
-                    } else if (upDown) {                                // lower list seen from above, M:4508-4526
-                        if (e.hasD0) o.put(e.type, newPos, e.ref, true, e.d0 + bl, true, 0.0, U && e.flag, nullptr);
-                        else if (bl != 0.0 || (U && tip)) o.put(e.type, newPos, e.ref, true, bl, true, 0.0, U && tip, nullptr);
-                        else o.bare(e.type, newPos, e.ref);
-                    } else {                                            // two lower lists, M:4527-4548, 4621-4643
-                        if (e.hasD0) o.put(e.type, newPos, e.ref, true, e.d0 + bl, false, 0, U && e.flag, nullptr);
-                        else if (bl != 0.0 || (U && tip)) o.put(e.type, newPos, e.ref, true, bl, false, 0, U && tip, nullptr);
-                        else o.bare(e.type, newPos, e.ref);
-                    }
-                } else {                                                // O against N
-                    newPos = pos + 1;
-                    bool propagate = upDown && (oneIsN || (e.hasD0 && e.d0 > 0) || bl != 0.0);
-                    if (propagate) {                                    // M:4552-4566, 4647-4660
-                        double nv[4];
-                        double tb = bl;
-                        if (e.hasD0) tb += e.d0;
-                        gpv_vec(c, c.rate(pos), e.vec, tb, !oneIsN, nv);
-                        if (oneIsN) for (int i = 0; i < 4; i++) nv[i] *= rf[i];
-                        double s = 0.0;
-                        for (int i = 0; i < 4; i++) s += nv[i];
-                        for (int i = 0; i < 4; i++) nv[i] /= s;
-                        o.put(6, newPos, e.ref, false, 0, false, 0, false, nv);
-                    } else {                                            // M:4568-4576, 4661-4668
-                        if (e.hasD0) o.put(6, newPos, e.ref, true, e.d0 + bl, false, 0, false, e.vec);
-                        else if (bl != 0.0) o.put(6, newPos, e.ref, true, bl, false, 0, false, e.vec);
-                        else o.put(6, newPos, e.ref, false, 0, false, 0, false, e.vec);
-                    }
-                }
-            }
-            if (wantLK) {                                               // M:4578-4587, 4670-4679
-                lk += (bLen1 + bLen2) * (cr[pos] - cr[newPos]);
-                if (U) {
-                    double ce = 0.0;
-                    if (tip1 || tip2) ce = SS ? cer[newPos] - cer[pos] : c.m.errorRate * (newPos - pos);
-                    if (tip1) lk += ce;
-                    if (tip2) lk += ce;
-                }
-            }
-        } else {
-            double totLen1 = bLen1, totLen2 = bLen2;                    // M:4683-4693
-            if (e1.hasD0) { totLen1 += e1.d0; if (e1.type != 6 && e1.hasD1) totLen1 += e1.d1; }
-            if (e2.hasD0) totLen2 += e2.d0;
-            const bool flag1 = U && e1.type != 6 && ((e1.hasD0 && e1.flag) || tip1);
-            const bool flag2 = U && e2.type != 6 && ((e2.hasD0 && e2.flag) || tip2);
-            const bool bothR = (e1.type == 4 && e2.type == 4);
-            newPos = bothR ? min(e1.pos, e2.pos) : pos + 1;
-            if (wantLK) {                                               // M:4703-4732
-                if (bothR) {
-                    if (totLen2 > bLen2 || totLen1 > bLen1) {
-                        lk += (totLen2 - bLen2 + totLen1 - bLen1) * (cr[newPos] - cr[pos]);
-                        if (U && ((!tip1 && flag1) || (!tip2 && flag2))) {
-                            double ce = SS ? cer[pos] - cer[newPos] : c.m.errorRate * (pos - newPos);
-                            if (!tip1 && flag1) lk += ce;
-                            if (!tip2 && flag2) lk += ce;
-                        }
-                    }
-                } else {
-                    int rn = (e1.type != 4) ? e1.ref : e2.ref;
-                    lk -= c.q(c.rate(pos), rn, rn) * (bLen2 + bLen1);
-                    if (U && ((e1.type != e2.type) || e1.type == 6) && (tip1 || tip2)) {
-                        double ce = c.err(pos);
-                        if (tip1) lk += ce;
-                        if (tip2) lk += ce;
-                    }
-                }
-            }
-            if (e1.type == e2.type && e1.type < 5) {                    // same state, M:4734-4755
-                if (e1.type == 4) o.bare(4, newPos, 0);
-                else {
-                    o.bare(e1.type, newPos, e1.ref);
-                    if (wantLK) {
-                        lk += c.q(c.rate(pos), e1.type, e1.type) * (totLen1 + totLen2);
-                        if (U && ((!tip1 && flag1) || (!tip2 && flag2))) {
-                            double ce = c.err(pos);
-                            if (!tip1 && flag1) lk -= ce;
-                            if (!tip2 && flag2) lk -= ce;
-                        }
-                    }
-                }
-            } else if (totLen1 == 0.0 && totLen2 == 0.0 && e1.type < 5 && e2.type < 5 && !flag1 && !flag2) {
-                return wantLK ? -2 : -1;                                // M:4757-4762
-            } else {                                                    // M:4763-4826
-                const double r = c.rate(pos);
-                const double er = c.err(pos);
-                const int refNuc = (e1.type == 4) ? e2.ref : e1.ref;
-                double v1[4], v2[4];
-                if (e1.type != 6) {
-                    int i1 = (e1.type == 4) ? refNuc : e1.type;
-                    if (totLen1 != 0.0 || flag1) {
-                        if (upDown && e1.hasD1) {                       // observation beyond the root, M:4777-4782
-                            gpv_nuc<CT, U>(c, r, i1, e1.d0, er, false, flag1, v1);
-                            for (int i = 0; i < 4; i++) v1[i] *= rf[i];
-                            double t = e1.d1 + bLen1;
-                            if (t != 0.0) { double tmp[4]; gpv_vec(c, r, v1, t, true, tmp); for (int i = 0; i < 4; i++) v1[i] = tmp[i]; }
-                        } else gpv_nuc<CT, U>(c, r, i1, totLen1, er, upDown, flag1, v1);
-                    } else for (int i = 0; i < 4; i++) v1[i] = (i == i1) ? 1.0 : 0.0;
-                } else gpv_vec(c, r, e1.vec, totLen1, upDown, v1);
-                if (e2.type == 6) gpv_vec(c, r, e2.vec, totLen2, false, v2);
-                else {
-                    int i2 = (e2.type == 4) ? refNuc : e2.type;
-                    if (totLen2 != 0.0 || flag2) gpv_nuc<CT, U>(c, r, i2, totLen2, er, false, flag2, v2);
-                    else for (int i = 0; i < 4; i++) v2[i] = (i == i2) ? 1.0 : 0.0;
-                }
-                for (int j = 0; j < 4; j++) v1[j] *= v2[j];
-                double s = 0.0;
-                for (int i = 0; i < 4; i++) s += v1[i];
-                if (s == 0.0) return wantLK ? -2 : -1;
-                for (int i = 0; i < 4; i++) v1[i] /= s;
-                int st = simplify(c, v1, refNuc);
-                if (st < 0) return -2;
-                if (st == 6) o.put(6, newPos, refNuc, false, 0, false, 0, false, v1);
-                else if (st == 4) o.bare(4, newPos, 0);
-                else o.bare(st, newPos, refNuc);
-                if (wantLK) totalFactor *= s;
-            }
-        }
+#include "merge_step_body.inc"
         pos = newPos;
         if (wantLK && totalFactor <= c.m.minimumCarryOver) {            // M:4830-4839
             if (totalFactor < 2.2250738585072014e-308) return -2;

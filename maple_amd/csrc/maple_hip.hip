@@ -6,6 +6,7 @@
 #include "placement_dev.h"
 #include "append_lds.h"
 #include "wave_dev.h"
+#include "wave_update.h"
 
 #include <algorithm>
 #include <chrono>
@@ -619,35 +620,84 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_shorten(const DevModel *__restr
 // areVectorsDifferent(new, old); mode 1 (probVectTotUp, M:5525-5557): shorten(); mode 2 (probVectUpRight / UpLeft,
 // M:5559-5660): areVectorsDifferent(old, new), and shorten() only if they differ.  The merged list goes to scratch slot A,
 // the shortened one to slot B (what is committed).  n_ent: entries of B, -1 = None, < -1 = fatal; flag: "different".
+#define MAPLE_UPDATE_ITEM_ARGS                                                                                                  \
+    const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *l1, const double *b1, const uint8_t *t1,               \
+        const int32_t *l2, const double *b2, const uint8_t *t2, const uint8_t *ud, const uint8_t *mode, const int32_t *old,     \
+        uint2 *words, double *aux, const int64_t *woff, const int64_t *cap, int32_t *res3
+
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(MAPLE_BLOCK) void k_update_items(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *l1,
-                                                              const double *b1, const uint8_t *t1, const int32_t *l2,
-                                                              const double *b2, const uint8_t *t2, const uint8_t *ud,
-                                                              const uint8_t *mode, const int32_t *old, uint2 *words, double *aux,
-                                                              const int64_t *woff, const int64_t *cap, int32_t *res3)
+__device__ inline void update_item_lane(const Ctx<RV, U, SS> &c, const ArenaView &av, int n, int i, const int32_t *l1, const double *b1,
+                                        const uint8_t *t1, const int32_t *l2, const double *b2, const uint8_t *t2, const uint8_t *ud,
+                                        const uint8_t *mode, const int32_t *old, uint2 *words, double *aux, const int64_t *woff,
+                                        const int64_t *cap, int32_t *res3)
+{
+    Writer wa, wb;
+    wa.init(words + woff[i], aux + 5 * woff[i]);
+    wb.init(words + woff[i] + cap[i], aux + 5 * (woff[i] + cap[i]));
+    double lk = 0.0;
+    const int r = merge_walk(c, list_ref(av, l1[i]), b1[i], t1[i] != 0, list_ref(av, l2[i]), b2[i], t2[i] != 0, ud[i] != 0, false, 0,
+                             0, wa, &lk);
+    int ne = r, na = 0, flag = 1;
+    if (r >= 0) {
+        const ListRef A{wa.w, wa.aux};
+        if (mode[i] == 2 && old[i] >= 0) flag = differ_walk(c, list_ref(av, old[i]), A) ? 1 : 0;
+        if (flag) {
+            ne = shorten_walk(c, A, r, wb);
+            na = wb.na;
+            if (mode[i] == 0 && old[i] >= 0) flag = differ_walk(c, ListRef{wb.w, wb.aux}, list_ref(av, old[i])) ? 1 : 0;
+        } else ne = 0;
+    }
+    res3[i] = ne; res3[n + i] = na; res3[2 * n + i] = flag;
+}
+
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_update_items(MAPLE_UPDATE_ITEM_ARGS)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        Writer wa, wb;
-        wa.init(words + woff[i], aux + 5 * woff[i]);
-        wb.init(words + woff[i] + cap[i], aux + 5 * (woff[i] + cap[i]));
-        double lk = 0.0;
-        const int r = merge_walk(c, list_ref(av, l1[i]), b1[i], t1[i] != 0, list_ref(av, l2[i]), b2[i], t2[i] != 0, ud[i] != 0, false, 0,
-                                 0, wa, &lk);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        update_item_lane(c, av, n, i, l1, b1, t1, l2, b2, t2, ud, mode, old, words, aux, woff, cap, res3);
+}
+
+// The same item by a whole wavefront (wave_update.h): what a level with a handful of items -- a single change walking up
+// and down the tree -- waits for is one item's latency, not throughput.  One wavefront per workgroup, one item at a time;
+// lists too long for the staged walk go through the one-lane code on lane 0.
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(64) void k_update_items_wave(MAPLE_UPDATE_ITEM_ARGS)
+{
+    __shared__ Lds lds;
+    __shared__ WaveUpdLds L;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const int lane = threadIdx.x;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int id1 = l1[i], id2 = l2[i], idOld = old[i];
+        const int n1 = av.n_ent[id1], n2 = av.n_ent[id2], nOld = idOld >= 0 ? av.n_ent[idOld] : 0;
+        if (n1 > MAPLE_WU_IN || n2 > MAPLE_WU_IN || nOld > MAPLE_WU_CAP) {
+            if (lane == 0) update_item_lane(c, av, n, i, l1, b1, t1, l2, b2, t2, ud, mode, old, words, aux, woff, cap, res3);
+            continue;
+        }
+        wave_sync();                                                       // the item before is done with the LDS
+        const ListRef Lo = idOld >= 0 ? list_ref(av, idOld) : ListRef{nullptr, nullptr};
+        if (idOld >= 0) {
+            const unsigned long long *wo = (const unsigned long long *)Lo.w;
+            for (int k = lane; k < nOld; k += 64) L.old[k] = wo[k];
+        }
+        int naA = 0;
+        const int r = wave_merge(c, list_ref(av, id1), n1, b1[i], t1[i] != 0, list_ref(av, id2), n2, b2[i], t2[i] != 0, ud[i] != 0, L, naA);
         int ne = r, na = 0, flag = 1;
         if (r >= 0) {
-            const ListRef A{wa.w, wa.aux};
-            if (mode[i] == 2 && old[i] >= 0) flag = differ_walk(c, list_ref(av, old[i]), A) ? 1 : 0;
+            const int md = mode[i];
+            if (md == 2 && idOld >= 0) flag = wave_differ(c, L.old, Lo.aux, nOld, L.m, L.maux, r) ? 1 : 0;
             if (flag) {
-                ne = shorten_walk(c, A, r, wb);
-                na = wb.na;
-                if (mode[i] == 0 && old[i] >= 0) flag = differ_walk(c, ListRef{wb.w, wb.aux}, list_ref(av, old[i])) ? 1 : 0;
+                ne = wave_shorten(c, L, r, words + woff[i] + cap[i], aux + 5 * (woff[i] + cap[i]), na);
+                if (md == 0 && idOld >= 0) flag = wave_differ(c, L.in, L.baux, ne, L.old, Lo.aux, nOld) ? 1 : 0;
             } else ne = 0;
         }
-        res3[i] = ne; res3[n + i] = na; res3[2 * n + i] = flag;
+        if (lane == 0) { res3[i] = ne; res3[n + i] = na; res3[2 * n + i] = flag; }
     }
 }
 

@@ -87,8 +87,14 @@ static int update_items(maple_ctx *c, int32_t n, const int32_t *l1, const double
     TRY(stage_flush(c));
     HIPCK(c, c->s_i32[2].reserve((size_t)3 * n));
     int32_t *res3 = c->s_i32[2].p;
-    DISPATCH3(c, k_update_items, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl1, db1, dt1, dl2, db2, dt2, dud,
-                                                                                dmode, dold, c->s_words.p, c->s_aux.p, dwo, dcap, res3));
+    // a level with few items waits for ONE item's latency: a wavefront per item (wave_update.h); many items: a lane each
+    static const int waveMax = getenv("MAPLE_WAVE_UPDATE_MAX") ? atoi(getenv("MAPLE_WAVE_UPDATE_MAX")) : 4096;
+    if (n <= waveMax && !getenv("MAPLE_NO_WAVE_UPDATE"))
+        DISPATCH3(c, k_update_items_wave, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dl1, db1, dt1, dl2, db2, dt2, dud, dmode, dold,
+                                                                     c->s_words.p, c->s_aux.p, dwo, dcap, res3));
+    else
+        DISPATCH3(c, k_update_items, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl1, db1, dt1, dl2, db2, dt2, dud,
+                                                                                    dmode, dold, c->s_words.p, c->s_aux.p, dwo, dcap, res3));
     HIPCK(c, hipGetLastError());
     std::vector<int32_t> h3((size_t)3 * n);
     HIPCK(c, hipMemcpyAsync(h3.data(), res3, (size_t)3 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

@@ -225,6 +225,48 @@ def test_update_partials_on_a_tree_with_local_references(world):
     dev.release(mark)
 
 
+def test_wavefront_wide_update_items_leave_the_one_lane_lists(world, monkeypatch):
+    """k_update_items_wave (one wavefront per item: mergeVectors, shorten and areVectorsDifferent cut along the merge path,
+    wave_update.h) against k_update_items (one lane per item), in every model mode: the same 60 changes -- one at a time,
+    the single-change chains the wavefront-wide kernel is for, then 40 at once -- repaired by both; every list either
+    leaves must be the other's entry for entry, bit for bit."""
+    from maple_amd.tree_host import HostTree, update_genome_lists
+    _, data, dev, orc, mirror = world
+    rng = np.random.default_rng(29)
+    cand = np.nonzero((mirror.parent >= 0) & (mirror.dist > 1e-5))[0]
+    pick = rng.choice(cand, size=60, replace=False)
+    scale = rng.choice([0.3, 2.5, 40.0], size=60)
+
+    def run():
+        tree = HostTree.from_mirror(mirror)
+        n = 0
+        for v, f in zip(pick[:20], scale[:20]):
+            tree.dist[v] = tree.dist[v] * f
+            n += update_genome_lists(dev, tree, [int(v)])
+        for v, f in zip(pick[20:], scale[20:]):
+            tree.dist[v] = tree.dist[v] * f
+        n += update_genome_lists(dev, tree, pick[20:].tolist())
+        return tree, n
+
+    mark = dev.mark()
+    wave, n_wave = run()
+    monkeypatch.setenv("MAPLE_NO_WAVE_UPDATE", "1")
+    lane, n_lane = run()
+    monkeypatch.delenv("MAPLE_NO_WAVE_UPDATE")
+    assert n_wave == n_lane and n_wave > 150
+    assert np.array_equal(wave.dist, lane.dist)
+    n_cmp = 0
+    for attr in ("id_lower", "id_upRight", "id_upLeft", "id_totUp"):
+        a, b = getattr(wave, attr), getattr(lane, attr)
+        assert np.array_equal(a >= 0, b >= 0), attr
+        moved = np.nonzero((a >= 0) & (a != getattr(HostTree.from_mirror(mirror), attr)))[0]
+        if len(moved):
+            assert dev.download(a[moved]) == dev.download(b[moved]), attr
+            n_cmp += len(moved)
+    assert n_cmp > 150
+    dev.release(mark)
+
+
 def test_serial_placement_through_tree_patch_on_a_tree_with_local_references(world):
     """The serial placement phase on a tree with MAT local references, in every model mode: 20 samples one after the other
     (single-query search, a new internal node + tip at the best branch, maple_update_partials, HostTree.sync =
