@@ -462,129 +462,21 @@ __device__ double blen_walk(const Ctx<RV, U, SS> &c, ListRef P, ListRef Cl, bool
     *isFalse = false;
     for (;;) {
         const Ent &e1 = a.e, &e2 = b.e;
-        if (e1.type == 5 || e2.type == 5) {                             // M:5077-5092
-            bool run1 = (e1.type == 4 || e1.type == 5), run2 = (e2.type == 4 || e2.type == 5);
-            int end = (run1 && run2) ? min(e1.pos, e2.pos) : pos + 1;
-            c1 += (cr[pos] - cr[end]);
-            pos = end;
-        } else if (e1.type == 4 && e2.type == 4) {
-            pos = min(e1.pos, e2.pos);
-        } else {
-            const double r = c.rate(pos);
-            const int rn = (e1.type == 4) ? e2.ref : e1.ref;
-            c1 -= c.q(r, rn, rn);                                       // M:5101-5104
-            const bool flag1 = U && e1.type != 6 && e1.hasD0 && e1.flag;
-            const bool flag2 = U && e2.type != 6 && (fromTipC || (e2.hasD0 && e2.flag));
-            const double er = c.err(pos);
-            double cl = 0.0;                                            // M:5109-5124
-            if (e1.type < 5) { if (e1.hasD1) cl = e1.d1; else if (e1.hasD0) cl = e1.d0; }
-            else if (e1.hasD0) cl = e1.d0;
-            if (e2.hasD0) cl += e2.d0;
-            double coeff0 = 0.0, coeff1 = 0.0;
-            int kind;   // 0: (coeff0, coeff1) pair rule ; 1: plain a_i rule ; 2: nothing
-            if (e1.type == 6) {                                         // M:5188-5212
-                if (e2.type == 6) {
-                    coeff0 = e1.vec[0] * e2.vec[0] + e1.vec[1] * e2.vec[1] + e1.vec[2] * e2.vec[2] + e1.vec[3] * e2.vec[3];
-                    for (int i = 0; i < 4; i++)
-                        for (int j = 0; j < 4; j++) coeff1 += e1.vec[i] * e2.vec[j] * c.q(r, i, j);
-                    if (cl != 0.0) coeff0 += coeff1 * cl;
-                } else {
-                    int i2 = (e2.type == 4) ? e1.ref : e2.type;
-                    coeff0 = e1.vec[i2];
-                    for (int i = 0; i < 4; i++) coeff1 += e1.vec[i] * c.q(r, i, i2);
-                    if (cl != 0.0) coeff0 += coeff1 * cl;
-                    if (flag2) coeff0 += er * 0.33333;
-                }
-                kind = 0;
-            } else if (e2.type == 6) {                                  // M:5128-5155, 5252-5276
-                int i1 = (e1.type == 4) ? e2.ref : e1.type;
-                if (e1.hasD1) {
-                    coeff0 = rf[i1] * e2.vec[i1];
-                    for (int i = 0; i < 4; i++) {
-                        coeff0 += rf[i] * c.q(r, i, i1) * e1.d0 * e2.vec[i];
-                        coeff1 += c.q(r, i1, i) * e2.vec[i];
-                    }
-                    coeff1 *= rf[i1];
-                    if (cl != 0.0) coeff0 += coeff1 * cl;
-                    if (flag1) {
-                        coeff0 -= 1.33333 * er * rf[i1] * e2.vec[i1];
-                        for (int i = 0; i < 4; i++) coeff0 += rf[i] * e2.vec[i] * 0.33333 * er;
-                    }
-                } else {
-                    coeff0 = e2.vec[i1];
-                    for (int j = 0; j < 4; j++) coeff1 += c.q(r, i1, j) * e2.vec[j];
-                    if (cl != 0.0) coeff0 += coeff1 * cl;
-                }
-                kind = 0;
-            } else if (e1.type == e2.type) {                            // same non-reference nucleotide, M:5217-5218
-                c1 += c.q(r, e1.type, e1.type);
-                kind = 2;
-            } else {                                                    // M:5157-5185, 5219-5250
-                int i1 = (e1.type == 4) ? e2.ref : e1.type;
-                int i2 = (e2.type == 4) ? e1.ref : e2.type;
-                kind = 1;
-                if (e1.hasD1) {
-                    coeff0 = rf[i2] * c.q(r, i2, i1) * e1.d0;
-                    if (cl != 0.0) coeff0 += rf[i1] * c.q(r, i1, i2) * cl;
-                    if (flag2) coeff0 += rf[i1] * 0.33333 * er;
-                    if (flag1) coeff0 += rf[i2] * 0.33333 * er;
-                    coeff1 = rf[i1] * c.q(r, i1, i2);
-                    if (coeff1 != 0.0) coeff0 = coeff0 / coeff1;
-                    else kind = 2;
-                } else {
-                    coeff0 = cl;
-                    if (flag2) {
-                        double qv = c.q(r, i1, i2);
-                        if (e1.type == 4 && qv == 0.0) kind = 2;        // M:5176-5180 guards only the R case
-                        else coeff0 += er * 0.33333 / qv;
-                    }
-                }
-            }
-            if (kind == 0) {
-                if (coeff1 < 0.0) c1 += coeff1 / coeff0;
-                else if (coeff1 != 0.0) { ais[(size_t)nA * stride] = coeff0 / coeff1; nA++; }
-            } else if (kind == 1) {
-                if (coeff0 != 0.0) { ais[(size_t)nA * stride] = coeff0; nA++; }
-                else nZeros++;
-            }
-            pos += 1;
-        }
+#define BLEN_C1_ADD(x) c1 += (x)
+#define BLEN_C1_SUB(x) c1 -= (x)
+#define BLEN_AIS(v) do { ais[(size_t)nA * stride] = (v); nA++; } while (0)
+#define BLEN_ZERO() nZeros++
+#include "blen_step_body.inc"
+#undef BLEN_C1_ADD
+#undef BLEN_C1_SUB
+#undef BLEN_AIS
+#undef BLEN_ZERO
         if (pos == lRef) break;
         a.step(pos);
         b.step(pos);
     }
     // bracket and bisect  sum 1/(a_i+t) + nZeros/t = c1   (M:5298-5358)
-    const double sens = c.m.minBLenSensitivity;
-    c1 = -c1;
-    const int n = nA + nZeros;
-    if (n == 0) { *isFalse = true; return 0.0; }
-    double minA = 0.0, maxA = 0.0;
-    if (nA) {
-        minA = maxA = ais[0];
-        for (int i = 1; i < nA; i++) { double v = ais[(size_t)i * stride]; if (v < minA) minA = v; if (v > maxA) maxA = v; }
-    }
-    if (nZeros) minA = fmin_py(0.0, minA);
-    if (minA < 0.0) return 0.1;
-    double tDown = fmin_py(0.1, n / c1 - minA);
-    if (tDown <= 0.0) { *isFalse = true; return 0.0; }
-    double vDown = nZeros ? nZeros / tDown : 0.0;
-    for (int i = 0; i < nA; i++) vDown += 1.0 / (ais[(size_t)i * stride] + tDown);
-    double tUp = fmin_py(0.1, n / c1 - maxA);
-    if (tUp >= 0.1) return 0.1;
-    if (tUp <= sens) tUp = (minA != 0.0) ? 0.0 : sens;
-    double vUp = nZeros ? nZeros / tUp : 0.0;
-    for (int i = 0; i < nA; i++) vUp += 1.0 / (ais[(size_t)i * stride] + tUp);
-    if (vDown > c1 + sens || vUp < c1 - sens) {
-        if (vUp < c1 - sens && tUp == 0.0) { *isFalse = true; return 0.0; }
-        if (vDown > c1 + sens && tDown >= 0.1) return 0.1;
-    }
-    while (tDown - tUp > sens) {
-        double tM = (tUp + tDown) / 2;
-        double vM = nZeros ? nZeros / tM : 0.0;
-        for (int i = 0; i < nA; i++) vM += 1.0 / (ais[(size_t)i * stride] + tM);
-        if (vM > c1) tUp = tM; else tDown = tM;
-    }
-    return tUp;
+#include "blen_solve_body.inc"
 }
 
 // ---- areVectorsDifferent (M:5419-5472) -------------------------------------------------------

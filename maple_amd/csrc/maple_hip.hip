@@ -63,6 +63,21 @@ template <class T> struct DevBuf {     // grow-only device scratch
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
+struct PinBuf {                          // grow-only page-locked host scratch (a D2H copy into pageable memory is staged
+    void *p = nullptr;                  // by the runtime at a few GB/s: 0.3 ms for the 1.6 MB of one query's scores)
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        const size_t want = bytes + bytes / 2 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        cap = (e == hipSuccess) ? want : 0;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
 
 struct PlaceMeta {                     // derived from the uploaded tree, rebuilt when it or effectivelyNon0BLen changes
     bool valid = false;
@@ -170,6 +185,7 @@ struct maple_ctx {
     std::vector<NodeRec> h_nodes;      // host copy of the node records (host-side traversal of tiny placement batches)
     DevBuf<int32_t> p_i32[4];
     DevBuf<double> p_f64[2], p_score;
+    PinBuf pin_place;                   // single-query placement: scores and minor-sequence flags on their way to the host
     DevBuf<int16_t> p_i16;
     DevBuf<uint8_t> p_u8, p_minor;
     int32_t *d_tile_counters = nullptr;    // ring of tile counters for the dynamically scheduled kernels
@@ -750,54 +766,130 @@ __global__ __launch_bounds__(MAPLE_BLOCK) void k_root_vector(const DevModel *__r
 
 // evaluatePlacement (M:6790-6806): three branch-length solves around three merges, then one append.
 // Each item owns 3 scratch lists (capacities capA/capB/capC packed back to back) and an `ais` strip.
+#define MAPLE_EVALPLACE_ARGS                                                                                                    \
+    const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *midTot, const int32_t *down, const int32_t *up,        \
+        const double *dist, const int32_t *rem, const uint8_t *remTip, const uint8_t *fromTip1, uint2 *sw, double *sa,          \
+        const int64_t *capOff, double *ais, const int64_t *aisOff, double *out4, int32_t *status, double *comp2
+
+// comp2 (optional): what the caller compares the optimised placement with (M:8101-8187) -- appendProbNode of the node's
+// lower list on its upper list at the branch's own length and at the sum of the two optimised halves.
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(MAPLE_BLOCK) void k_evalplace(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *midTot,
-                                                           const int32_t *down, const int32_t *up, const double *dist,
-                                                           const int32_t *rem, const uint8_t *remTip,
-                                                           const uint8_t *fromTip1, uint2 *sw, double *sa,
-                                                           const int64_t *capOff, double *ais, const int64_t *aisOff,
-                                                           double *out4, int32_t *status)
+__device__ inline void evalplace_item_lane(const Ctx<RV, U, SS> &c, const ArenaView &av, int i, const int32_t *midTot, const int32_t *down,
+                                           const int32_t *up, const double *dist, const int32_t *rem, const uint8_t *remTip,
+                                           const uint8_t *fromTip1, uint2 *sw, double *sa, const int64_t *capOff, double *ais,
+                                           const int64_t *aisOff, double *out4, int32_t *status, double *comp2)
+{
+    const DevModel &m = c.m;
+    ListRef Lmid = list_ref(av, midTot[i]), Ldown = list_ref(av, down[i]), Lup = list_ref(av, up[i]), Lrem = list_ref(av, rem[i]);
+    const int nDown = av.n_ent[down[i]], nUp = av.n_ent[up[i]], nRem = av.n_ent[rem[i]];
+    const int64_t base = capOff[i];
+    uint2 *wA = sw + base, *wB = wA + (nDown + nRem), *wC = wB + (nUp + nRem);
+    double *aA = sa + 5 * base, *aB = aA + 5 * (int64_t)(nDown + nRem), *aC = aB + 5 * (int64_t)(nUp + nRem);
+    double *myAis = ais + aisOff[i];
+    const bool rt = remTip[i] != 0, ft = fromTip1[i] != 0;
+    bool f;
+    Writer w;
+    status[i] = 0;
+    double bestApp = blen_walk(c, Lmid, Lrem, rt, myAis, 1, &f);
+    w.init(wA, aA);
+    int r = merge_walk(c, Ldown, dist[i] / 2, ft, Lrem, bestApp, rt, false, false, 0, 0, w, nullptr);
+    if (r < 0) { status[i] = -1; return; }
+    ListRef midLower{wA, aA};
+    double bestTop = blen_walk(c, Lup, midLower, false, myAis, 1, &f);
+    w.init(wB, aB);
+    r = merge_walk(c, Lup, bestTop, false, Lrem, bestApp, rt, true, false, 0, 0, w, nullptr);
+    if (r == -1) {
+        bestTop = m.defaultBLen * 0.1;
+        w.init(wB, aB);
+        r = merge_walk(c, Lup, bestTop, false, Lrem, bestApp, rt, true, false, 0, 0, w, nullptr);
+    }
+    if (r < 0) { status[i] = -1; return; }
+    ListRef midTop{wB, aB};
+    double bestBottom = blen_walk(c, midTop, Ldown, ft, myAis, 1, &f);
+    w.init(wC, aC);
+    r = merge_walk(c, Lup, bestTop, false, Ldown, bestBottom, ft, true, false, 0, 0, w, nullptr);
+    if (r < 0) { status[i] = -1; return; }
+    ListRef newMid{wC, aC};
+    out4[i * 4 + 0] = append_walk(c, newMid, Lrem, rt, bestApp);
+    out4[i * 4 + 1] = bestBottom;
+    out4[i * 4 + 2] = bestTop;
+    out4[i * 4 + 3] = bestApp;
+    if (comp2) {
+        comp2[2 * i] = append_walk(c, Lup, Ldown, ft, dist[i]);
+        comp2[2 * i + 1] = append_walk(c, Lup, Ldown, ft, bestBottom + bestTop);
+    }
+}
+
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(MAPLE_BLOCK) void k_evalplace(MAPLE_EVALPLACE_ARGS)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        ListRef Lmid = list_ref(av, midTot[i]), Ldown = list_ref(av, down[i]), Lup = list_ref(av, up[i]),
-                Lrem = list_ref(av, rem[i]);
-        const int nDown = av.n_ent[down[i]], nUp = av.n_ent[up[i]], nRem = av.n_ent[rem[i]];
-        const int64_t base = capOff[i];
-        uint2 *wA = sw + base, *wB = wA + (nDown + nRem), *wC = wB + (nUp + nRem);
-        double *aA = sa + 5 * base, *aB = aA + 5 * (int64_t)(nDown + nRem), *aC = aB + 5 * (int64_t)(nUp + nRem);
-        double *myAis = ais + aisOff[i];
-        const bool rt = remTip[i] != 0, ft = fromTip1[i] != 0;
-        bool f;
-        Writer w;
-        status[i] = 0;
-        double bestApp = blen_walk(c, Lmid, Lrem, rt, myAis, 1, &f);
-        w.init(wA, aA);
-        int r = merge_walk(c, Ldown, dist[i] / 2, ft, Lrem, bestApp, rt, false, false, 0, 0, w, nullptr);
-        if (r < 0) { status[i] = -1; continue; }
-        ListRef midLower{wA, aA};
-        double bestTop = blen_walk(c, Lup, midLower, false, myAis, 1, &f);
-        w.init(wB, aB);
-        r = merge_walk(c, Lup, bestTop, false, Lrem, bestApp, rt, true, false, 0, 0, w, nullptr);
-        if (r == -1) {
-            bestTop = m.defaultBLen * 0.1;
-            w.init(wB, aB);
-            r = merge_walk(c, Lup, bestTop, false, Lrem, bestApp, rt, true, false, 0, 0, w, nullptr);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        evalplace_item_lane(c, av, i, midTot, down, up, dist, rem, remTip, fromTip1, sw, sa, capOff, ais, aisOff, out4, status, comp2);
+}
+
+// The same by a whole wavefront: the chain of seven list walks (three branch-length solves around three merges, one
+// append) is what a single-query placement's refinement waits for -- 50 us per link for one lane, a few us for 64
+// (wave_blen / wave_merge, wave_update.h; wave_append, wave_dev.h; every list in LDS).  One wavefront per workgroup.
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(64) void k_evalplace_wave(MAPLE_EVALPLACE_ARGS)
+{
+    __shared__ Lds lds;
+    __shared__ WaveUpdLds L;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const int lane = threadIdx.x;
+    WaveLds &W = *reinterpret_cast<WaveLds *>(L.baux);                     // (baux and old are not used by the merges here)
+    double *terms = reinterpret_cast<double *>(L.old);
+    static_assert(sizeof(WaveLds) <= sizeof(L.baux) && 128 * sizeof(double) <= sizeof(L.old), "LDS aliases");
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int idM = midTot[i], idD = down[i], idU = up[i], idR = rem[i];
+        const int nMid = av.n_ent[idM], nDown = av.n_ent[idD], nUp = av.n_ent[idU], nRem = av.n_ent[idR];
+        if (nMid > MAPLE_WAVE_CAPW || nRem > MAPLE_WAVE_CAPW || nDown + nRem > MAPLE_WAVE_CAPW || nUp + nRem > MAPLE_WAVE_CAPW
+            || nUp + nDown > MAPLE_WAVE_CAPW) {
+            if (lane == 0)
+                evalplace_item_lane(c, av, i, midTot, down, up, dist, rem, remTip, fromTip1, sw, sa, capOff, ais, aisOff, out4, status,
+                                    comp2);
+            continue;
         }
-        if (r < 0) { status[i] = -1; continue; }
-        ListRef midTop{wB, aB};
-        double bestBottom = blen_walk(c, midTop, Ldown, ft, myAis, 1, &f);
-        w.init(wC, aC);
-        r = merge_walk(c, Lup, bestTop, false, Ldown, bestBottom, ft, true, false, 0, 0, w, nullptr);
-        if (r < 0) { status[i] = -1; continue; }
-        ListRef newMid{wC, aC};
-        out4[i * 4 + 0] = append_walk(c, newMid, Lrem, rt, bestApp);
-        out4[i * 4 + 1] = bestBottom;
-        out4[i * 4 + 2] = bestTop;
-        out4[i * 4 + 3] = bestApp;
+        wave_sync();
+        const ListRef Lmid = list_ref(av, idM), Ldown = list_ref(av, idD), Lup = list_ref(av, idU), Lrem = list_ref(av, idR);
+        const ListRef Lm{(const uint2 *)L.m, L.maux};                      // where the merges leave their result
+        const bool rt = remTip[i] != 0, ft = fromTip1[i] != 0;
+        const double d = dist[i];
+        bool f;
+        int na, st = 0;
+        double bestApp = wave_blen(c, Lmid, nMid, Lrem, nRem, rt, W, terms, &f), bestTop = 0.0, bestBottom = 0.0, lk = 0.0;
+        int r = wave_merge(c, Ldown, nDown, d / 2, ft, Lrem, nRem, bestApp, rt, false, L, na);
+        if (r < 0) st = -1;
+        if (!st) {
+            bestTop = wave_blen(c, Lup, nUp, Lm, r, false, W, terms, &f);
+            r = wave_merge(c, Lup, nUp, bestTop, false, Lrem, nRem, bestApp, rt, true, L, na);
+            if (r == -1) {
+                bestTop = m.defaultBLen * 0.1;
+                r = wave_merge(c, Lup, nUp, bestTop, false, Lrem, nRem, bestApp, rt, true, L, na);
+            }
+            if (r < 0) st = -1;
+        }
+        if (!st) {
+            bestBottom = wave_blen(c, Lm, r, Ldown, nDown, ft, W, terms, &f);
+            r = wave_merge(c, Lup, nUp, bestTop, false, Ldown, nDown, bestBottom, ft, true, L, na);
+            if (r < 0) st = -1;
+        }
+        if (!st) lk = wave_append(c, Lm, r, Lrem, nRem, rt, bestApp, W);
+        if (lane == 0) {
+            status[i] = st;
+            if (!st) { out4[i * 4 + 0] = lk; out4[i * 4 + 1] = bestBottom; out4[i * 4 + 2] = bestTop; out4[i * 4 + 3] = bestApp; }
+        }
+        if (!st && comp2) {
+            const double c0 = wave_append(c, Lup, nUp, Ldown, nDown, ft, d, W);
+            const double c1 = wave_append(c, Lup, nUp, Ldown, nDown, ft, bestBottom + bestTop, W);
+            if (lane == 0) { comp2[2 * i] = c0; comp2[2 * i + 1] = c1; }
+        }
     }
 }
 
@@ -1227,6 +1319,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     c->s_search_ws.release(); c->s_search_out.release(); c->s_counter.release(); c->s_cache.release();
     for (auto &b : c->p_i32) b.release();
     for (auto &b : c->p_f64) b.release();
+    c->pin_place.release();
     c->p_score.release(); c->p_i16.release(); c->p_u8.release(); c->p_minor.release();
     if (c->place) {
         PlaceMeta &M = *c->place;
@@ -1968,11 +2061,11 @@ extern "C" int maple_root_vector_batch(maple_ctx *c, int32_t n, const int32_t *l
     return commit_lists(c, n, dwo, dao, c->s_i32[2].p, c->s_i32[3].p, outList);
 }
 
-extern "C" int maple_evaluate_placement_batch(maple_ctx *c, int32_t n, const int32_t *midTot, const int32_t *down,
-                                              const int32_t *up, const double *dist, const int32_t *rem,
-                                              const uint8_t *remTip, const uint8_t *fromTip1, double *out4)
+// comp2 (optional, 2 doubles per item): see k_evalplace
+static int evaluate_placement_items(maple_ctx *c, int32_t n, const int32_t *midTot, const int32_t *down, const int32_t *up,
+                                    const double *dist, const int32_t *rem, const uint8_t *remTip, const uint8_t *fromTip1,
+                                    double *out4, double *comp2)
 {
-    if (!c || n < 0 || !midTot || !down || !up || !dist || !rem || !remTip || !fromTip1 || !out4) return MAPLE_ERR_ARG;
     if (n == 0) return MAPLE_OK;
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
@@ -1995,30 +2088,39 @@ extern "C" int maple_evaluate_placement_batch(maple_ctx *c, int32_t n, const int
     HIPCK(c, c->s_words.reserve((size_t)tot));
     HIPCK(c, c->s_aux.reserve((size_t)(5 * tot)));
     HIPCK(c, c->s_ais.reserve((size_t)totA));
-    TRY(h2d(c, c->s_i32[0], midTot, (size_t)n));
-    TRY(h2d(c, c->s_i32[1], down, (size_t)n));
-    TRY(h2d(c, c->s_i32[2], up, (size_t)n));
-    TRY(h2d(c, c->s_i32[3], rem, (size_t)n));
-    TRY(h2d(c, c->s_f64[0], dist, (size_t)n));
-    TRY(h2d(c, c->s_u8[0], remTip, (size_t)n));
-    TRY(h2d(c, c->s_u8[1], fromTip1, (size_t)n));
-    TRY(h2d(c, c->s_i64[0], capOff.data(), (size_t)n));
-    TRY(h2d(c, c->s_i64[1], aisOff.data(), (size_t)n));
-    HIPCK(c, c->s_f64[1].reserve((size_t)4 * n));
+    TRY(stage_begin(c, (size_t)n * 64 + 1024));
+    STAGE(dMid, c, midTot, n); STAGE(dDown, c, down, n); STAGE(dUp, c, up, n); STAGE(dRem, c, rem, n); STAGE(dDist, c, dist, n);
+    STAGE(dRt, c, remTip, n); STAGE(dFt, c, fromTip1, n); STAGE(dCap, c, capOff.data(), n); STAGE(dAis, c, aisOff.data(), n);
+    TRY(stage_flush(c));
+    HIPCK(c, c->s_f64[1].reserve((size_t)6 * n));
     HIPCK(c, c->s_i32[4].reserve(n));
-    DISPATCH3(c, k_evalplace, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
-                                                                             c->s_i32[2].p, c->s_f64[0].p, c->s_i32[3].p,
-                                                                             c->s_u8[0].p, c->s_u8[1].p, c->s_words.p,
-                                                                             c->s_aux.p, c->s_i64[0].p, c->s_ais.p,
-                                                                             c->s_i64[1].p, c->s_f64[1].p, c->s_i32[4].p));
+    double *d4 = c->s_f64[1].p, *d2 = comp2 ? d4 + (size_t)4 * n : nullptr;
+    // a handful of items (a single query's short list) wait for ONE item's chain of walks: a wavefront per item
+    static const int waveMax = getenv("MAPLE_WAVE_EVAL_MAX") ? atoi(getenv("MAPLE_WAVE_EVAL_MAX")) : 2048;
+    if (n <= waveMax && !getenv("MAPLE_NO_WAVE_EVAL"))
+        DISPATCH3(c, k_evalplace_wave, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dMid, dDown, dUp, dDist, dRem, dRt, dFt, c->s_words.p,
+                                                                  c->s_aux.p, dCap, c->s_ais.p, dAis, d4, c->s_i32[4].p, d2));
+    else
+        DISPATCH3(c, k_evalplace, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dMid, dDown, dUp, dDist, dRem, dRt, dFt,
+                                                                                 c->s_words.p, c->s_aux.p, dCap, c->s_ais.p, dAis, d4,
+                                                                                 c->s_i32[4].p, d2));
     HIPCK(c, hipGetLastError());
     std::vector<int32_t> st(n);
-    HIPCK(c, hipMemcpyAsync(out4, c->s_f64[1].p, (size_t)4 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(out4, d4, (size_t)4 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (comp2) HIPCK(c, hipMemcpyAsync(comp2, d2, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(st.data(), c->s_i32[4].p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; i++)
         if (st[i]) return fail(c, MAPLE_ERR_FATAL, "evaluatePlacement item %d: a merge returned None", i);
     return MAPLE_OK;
+}
+
+extern "C" int maple_evaluate_placement_batch(maple_ctx *c, int32_t n, const int32_t *midTot, const int32_t *down,
+                                              const int32_t *up, const double *dist, const int32_t *rem,
+                                              const uint8_t *remTip, const uint8_t *fromTip1, double *out4)
+{
+    if (!c || n < 0 || !midTot || !down || !up || !dist || !rem || !remTip || !fromTip1 || !out4) return MAPLE_ERR_ARG;
+    return evaluate_placement_items(c, n, midTot, down, up, dist, rem, remTip, fromTip1, out4, nullptr);
 }
 
 // ---- device-resident forms ---------------------------------------------------------------------------

@@ -277,6 +277,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                                  int32_t *nAppend, int32_t *status, SupportsOut *sup)
 {
     if (nQ == 0) return MAPLE_OK;
+    const auto tEntry = std::chrono::steady_clock::now();
     int32_t *const bestDiffs = bestDiffsOut;
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
@@ -383,11 +384,15 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
             // a handful of queries (the sequential placement loop hands over one at a time): one lane's ~1 us per visit
             // would dominate the call, so the scores come back (8 bytes per branch) and the SAME traversal function
             // runs on the host
-            std::vector<double> hs;
-            std::vector<uint8_t> hm;
-            TRY(d2h_vec(c, hs, c->p_score.p, (size_t)nq * nCols));
-            TRY(d2h_vec(c, hm, c->p_minor.p, (size_t)nq * std::max(nL, 1)));
+            const size_t nS = (size_t)nq * nCols, nM = (size_t)nq * std::max(nL, 1);
+            HIPCK(c, c->pin_place.reserve(nS * sizeof(double) + nM));
+            if (dbg) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple]   scoring kernels done after %lld us\n", tus(t2, tnow())); }
+            double *const hs = (double *)c->pin_place.p;
+            uint8_t *const hm = (uint8_t *)(hs + nS);
+            HIPCK(c, hipMemcpyAsync(hs, c->p_score.p, nS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            if (nL > 0) HIPCK(c, hipMemcpyAsync(hm, c->p_minor.p, nM, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
+            if (dbg) fprintf(stderr, "[maple]   scores on the host after %lld us\n", tus(t2, tnow()));
             hi.assign((size_t)nq * (6 + SL), 0);
             hf.assign((size_t)nq * (2 + SL), 0.0);
             hb.assign((size_t)nq * (1 + SL), 0);
@@ -406,7 +411,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                 oq.status += q; oq.minorNode += q; oq.bestNode += q; oq.nAppend += q; oq.missed += q; oq.nShort += q;
                 oq.bestLK += q; oq.originalLK += q; oq.bestShort += q;
                 oq.slNode += (size_t)q * SL; oq.slLK += (size_t)q * SL; oq.slShort += (size_t)q * SL;
-                place_replay_ptr(c, M, P, hs.data() + (size_t)q * nCols, nC, hm.data() + (size_t)q * std::max(nL, 1), nF, oq);
+                place_replay_ptr(c, M, P, hs + (size_t)q * nCols, nC, hm + (size_t)q * std::max(nL, 1), nF, oq);
             }
         } else {
             HIPCK(c, c->p_f64[0].reserve((size_t)nq * stackCap));         // per-depth lastLK
@@ -488,30 +493,26 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                 TRY(maple_pass_branch_batch(c, (int32_t)needNode.size(), needSrc.data(), needMut.data(), dn.data(), out.data()));
                 for (size_t i = 0; i < needNode.size(); i++) upOf[needNode[i]] = out[i];
             }
-            std::vector<int32_t> mid(nr), down(nr), upl(nr), ql(nr), ap(2 * nr), ac(2 * nr);
-            std::vector<double> dist(nr), abl(2 * nr);
-            std::vector<uint8_t> remTip(nr, 1), tip(nr), atip(2 * nr);
+            std::vector<int32_t> mid(nr), down(nr), upl(nr), ql(nr);
+            std::vector<double> dist(nr);
+            std::vector<uint8_t> remTip(nr, 1), tip(nr);
             for (size_t i = 0; i < nr; i++) {
                 const int32_t v = rnode[i];
                 mid[i] = c->h_tree_totUp[v]; down[i] = c->h_tree_lower[v]; upl[i] = upOf[v]; dist[i] = c->h_tree_dist[v];
                 tip[i] = c->h_tree_tip[v];
                 ql[i] = qlist(rq[i], v, hSlShort[(size_t)rq[i] * SL + ridx[i]] != 0);
             }
-            TRY(maple_evaluate_placement_batch(c, (int32_t)nr, mid.data(), down.data(), upl.data(), dist.data(), ql.data(),
-                                               remTip.data(), tip.data(), ev.data()));
+            // ... and, in the same launch, what the optimised placement is compared with (M:8101-8187): the node's lower list
+            // appended to its upper list at the branch's own length and at the sum of the two optimised halves
+            std::vector<double> c2(2 * nr);
+            TRY(evaluate_placement_items(c, (int32_t)nr, mid.data(), down.data(), upl.data(), dist.data(), ql.data(), remTip.data(),
+                                         tip.data(), ev.data(), c2.data()));
             refinedUp = upl;
-            for (size_t i = 0; i < nr; i++) {
-                ap[i] = ap[nr + i] = upl[i];
-                ac[i] = ac[nr + i] = down[i];
-                atip[i] = atip[nr + i] = tip[i];
-                abl[i] = dist[i];
-                abl[nr + i] = ev[4 * i + 1] + ev[4 * i + 2];
-            }
-            TRY(maple_append_batch(c, (int32_t)(2 * nr), ap.data(), ac.data(), atip.data(), abl.data(), comp.data()));
+            for (size_t i = 0; i < nr; i++) { comp[i] = c2[2 * i]; comp[nr + i] = c2[2 * i + 1]; }
         }
         auto t5 = tnow();
-        if (dbg) fprintf(stderr, "[maple] placement batch of %d: root vector %lld us, frames %lld, score+minor+traversal %lld, shorten %lld, refine %lld\n",
-                         nq, tus(t0, t1), tus(t1, t2), tus(t2, t3), tus(t3, t4), tus(t4, t5));
+        if (dbg) fprintf(stderr, "[maple] placement batch of %d: tables %lld us, root vector %lld, frames %lld, score+minor+traversal %lld, shorten %lld, refine %lld\n",
+                         nq, tus(tEntry, t0), tus(t0, t1), tus(t1, t2), tus(t2, t3), tus(t3, t4), tus(t4, t5));
         if (sup) {
             // ---- computePlacementSupportOnly=True, M:8101-8290: every refined branch is a possible placement; the mid-branch
             // vector of each (newMidVector, M:8131) is produced by one more merge batch from the optimised lengths
@@ -676,5 +677,6 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
             }
         }
     }
+    if (dbg) fprintf(stderr, "[maple] placement call of %d: %lld us in all\n", nQ, tus(tEntry, tnow()));
     return MAPLE_OK;
 }

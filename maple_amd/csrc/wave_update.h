@@ -11,6 +11,7 @@
 // Every lane of the wavefront calls these with the same arguments and gets the same result.
 #pragma once
 #include "genome_dev.h"
+#include "wave_dev.h"
 
 namespace maple {
 
@@ -245,6 +246,65 @@ __device__ inline bool wave_differ(const C &c, const unsigned long long *A, cons
         if (__ballot(diff)) return true;
     }
     return false;
+}
+
+// estimateBranchLengthWithDerivative (M:5040-5358) by the wavefront: lane d evaluates step d of the walk over the parent-side
+// list P and the child-side list Cl (blen_step_body.inc, the text the one-lane walk runs); what the steps add to the constant
+// c1 is added in walk order (the sum is rounded term by term), the 1/(a_i+t) terms are compacted in walk order into L.f, and
+// the bracketing and bisection (blen_solve_body.inc) then run on them as they do for one lane.  `terms`: 128 doubles of LDS.
+template <bool RV, bool U, bool SS>
+__device__ inline double wave_blen(const Ctx<RV, U, SS> &c, ListRef P, int nP, ListRef Cl, int nC, bool fromTipC, WaveLds &L,
+                                   double *terms, bool *isFalse)
+{
+    const int lane = threadIdx.x & 63;
+    const double *rf = c.rf;
+    const double *cr = c.m.cumulativeRate;
+    const unsigned long long *pw = (const unsigned long long *)P.w, *cw = (const unsigned long long *)Cl.w;
+    for (int i = lane; i < nP; i += 64) L.a[i] = pw[i];
+    for (int i = lane; i < nC; i += 64) L.b[i] = cw[i];
+    wave_sync();
+    const int nSteps = nP + nC;
+    int nA = 0, nZeros = 0;
+    double c1 = c.m.globalTotRate;
+    *isFalse = false;
+    for (int base = 0; base < nSteps; base += 64) {
+        const int d = base + lane;
+        int i = 0, k = 0;
+        const bool seg = d < nSteps && merge_path(L.a, nP, L.b, nC, d, i, k);
+        int nTerm = 0;
+        double t0 = 0.0, t1 = 0.0, aiv = 0.0;
+        bool hasAi = false, isZero = false;
+        if (seg) {
+            int pos = max(i > 0 ? (int)(uint32_t)L.a[i - 1] : 0, k > 0 ? (int)(uint32_t)L.b[k - 1] : 0);
+            Ent e1, e2;
+            decode_word(L.a[i], P.aux, e1);
+            decode_word(L.b[k], Cl.aux, e2);
+#define BLEN_C1_ADD(x) do { const double v_ = (x); if (nTerm == 0) t0 = v_; else t1 = v_; ++nTerm; } while (0)
+#define BLEN_C1_SUB(x) do { const double v_ = -(x); if (nTerm == 0) t0 = v_; else t1 = v_; ++nTerm; } while (0)
+#define BLEN_AIS(v) do { aiv = (v); hasAi = true; } while (0)
+#define BLEN_ZERO() isZero = true
+#include "blen_step_body.inc"
+#undef BLEN_C1_ADD
+#undef BLEN_C1_SUB
+#undef BLEN_AIS
+#undef BLEN_ZERO
+            (void)pos;
+        }
+        int total;
+        const int to = wave_excl_sum(nTerm, lane, total);
+        if (nTerm > 0) terms[to] = t0;
+        if (nTerm > 1) terms[to + 1] = t1;
+        const unsigned long long am = __ballot(hasAi);
+        if (hasAi) L.f[nA + __popcll(am & ((1ull << lane) - 1ull))] = aiv;
+        nA += __popcll(am);
+        nZeros += __popcll(__ballot(isZero));
+        wave_sync();
+        for (int j = 0; j < total; j++) c1 += terms[j];                    // (C - x is C + (-x), bit for bit)
+        wave_sync();
+    }
+    const double *ais = L.f;
+    constexpr int stride = 1;
+#include "blen_solve_body.inc"
 }
 
 }  // namespace maple

@@ -225,6 +225,58 @@ def test_update_partials_on_a_tree_with_local_references(world):
     dev.release(mark)
 
 
+def test_wavefront_wide_evaluate_placement_is_the_one_lane_chain_bit_for_bit(world, monkeypatch):
+    """k_evalplace_wave (one wavefront per item: the three branch-length solves, three merges and the append of
+    evaluatePlacement, M:6790-6806, each cut along its merge path) against k_evalplace (one lane per item), in every model
+    mode: 600 (branch, sample) pairs -- the sample's own neighbourhood and random branches -- must give the same four
+    numbers, bit for bit; and single-query placement searches (which also fold the refinement's two comparison scores into
+    that launch) the same results either way."""
+    mode, data, dev, orc, mirror = world
+    rng = np.random.default_rng(31)
+    l_ref = dev.lRef
+    nodes = rng.choice(np.nonzero(mirror.parent >= 0)[0], size=600, replace=False)
+    par = mirror.parent[nodes]
+    up_ids = np.where(mirror.children[par, 0] == nodes, mirror.up_right[par], mirror.up_left[par]).astype(np.int32)
+    tips = np.asarray(data.tip_node)
+    # half of the samples next to the branch (its own subtree's first tip), half anywhere
+    q_nodes = rng.choice(tips, size=600)
+    q_ids = mirror.lower[q_nodes].astype(np.int32)
+    args = (mirror.tot_up[nodes], mirror.lower[nodes], up_ids, mirror.dist[nodes], q_ids, True, mirror.is_tip[nodes])
+    ok = (mirror.tot_up[nodes] >= 0) & (up_ids >= 0)
+    args = tuple(a[ok] if isinstance(a, np.ndarray) else a for a in args)
+    wave = dev.evaluate_placement_batch(*args)
+    monkeypatch.setenv("MAPLE_NO_WAVE_EVAL", "1")
+    lane = dev.evaluate_placement_batch(*args)
+    monkeypatch.delenv("MAPLE_NO_WAVE_EVAL")
+    assert wave.shape == lane.shape and len(wave) > 300
+    assert np.array_equal(wave.view(np.uint64), lane.view(np.uint64)), np.nonzero((wave != lane).any(axis=1))[0][:5]
+    assert np.isfinite(wave[:, 1:]).all() and (wave[:, 1:] >= 0).all()
+    # the search around it
+    ll = math.log(l_ref)
+    pkw = dict(oneMutBLen=1.0 / l_ref, effectivelyNon0BLen=1.0 / (10 * l_ref), thresholdLogLK=18.0 * ll,
+               thresholdLogLKoptimization=ll, thresholdLogLKconsecutivePlacement=1.0)
+    from maple_amd.host import reference_tables, tip_genome_list
+    from maple_amd.synth import perturb_diffs
+    ref_idx, _ = reference_tables(data.ref)
+    mark = dev.mark()
+    dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist, mirror.is_tip,
+                    mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up, -np.ones(mirror.n_nodes, dtype=np.int32))
+    dev.placement_prepare(**pkw)
+    qs = dev.upload([tip_genome_list(perturb_diffs(data.diffs[i], data.ref, rng), ref_idx) for i in range(24)])
+    res = {}
+    for name in ("wave", "lane"):
+        if name == "lane":
+            monkeypatch.setenv("MAPLE_NO_WAVE_EVAL", "1")
+        res[name] = [dev.placement_search_batch(np.asarray([q], dtype=np.int32), **pkw) for q in qs]
+    monkeypatch.delenv("MAPLE_NO_WAVE_EVAL")
+    for a, b in zip(res["wave"], res["lane"]):
+        for k in ("bestNode", "nAppend", "status"):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a["bestScore"].view(np.uint64), b["bestScore"].view(np.uint64))
+        assert np.array_equal(a["blen"].view(np.uint64), b["blen"].view(np.uint64))
+    dev.release(mark)
+
+
 def test_wavefront_wide_update_items_leave_the_one_lane_lists(world, monkeypatch):
     """k_update_items_wave (one wavefront per item: mergeVectors, shorten and areVectorsDifferent cut along the merge path,
     wave_update.h) against k_update_items (one lane per item), in every model mode: the same 60 changes -- one at a time,
