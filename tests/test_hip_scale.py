@@ -319,6 +319,62 @@ def test_wavefront_wide_update_items_leave_the_one_lane_lists(world, monkeypatch
     dev.release(mark)
 
 
+def test_wavefront_wide_kernels_around_their_list_length_limit(monkeypatch):
+    """The wavefront-wide walks stage lists of up to 256 entries; longer ones go through the one-lane code on lane 0 of the
+    same launch.  A 400-tip tree of divergent samples (~80 differences each: lists on both sides of the limit) takes both routes in the same launches: updatePartials and evaluatePlacement must still be the one-lane
+    kernels', bit for bit."""
+    from maple_amd.host import reference_tables, tip_genome_list
+    from maple_amd.runtime import Device
+    from maple_amd.synth import make_dataset
+    from maple_amd.tree_host import HostTree, update_genome_lists
+    from maple_amd.tree_mirror import TreeMirror
+    data = make_dataset(n_samples=400, l_ref=29903, seed=9, mean_diffs=80.0, frac_with_n=0.1, frac_ambig=0.05)
+    ref_idx, rf = reference_tables(data.ref)
+    dev = Device(ref_idx, rf, arena_bytes=1 << 30)
+    dev.set_model(Q=Q)
+    tips = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
+    mirror = TreeMirror(dev, data.parent, data.blen, tips).build()
+    n_ent = dev.sizes(mirror.tot_up[mirror.tot_up >= 0])[0]
+    assert (n_ent > 256).sum() > 20 and (n_ent <= 200).sum() > 20, (n_ent.min(), int(np.median(n_ent)), n_ent.max())
+    rng = np.random.default_rng(37)
+    cand = np.nonzero((mirror.parent >= 0) & (mirror.dist > 1e-5))[0]
+    pick = rng.choice(cand, size=40, replace=False)
+
+    def run():
+        tree = HostTree.from_mirror(mirror)
+        n = 0
+        for v in pick:
+            tree.dist[v] = tree.dist[v] * 2.5
+            n += update_genome_lists(dev, tree, [int(v)])
+        return tree, n
+
+    wave, n_wave = run()
+    monkeypatch.setenv("MAPLE_NO_WAVE_UPDATE", "1")
+    lane, n_lane = run()
+    monkeypatch.delenv("MAPLE_NO_WAVE_UPDATE")
+    assert n_wave == n_lane and n_wave > 100
+    base = HostTree.from_mirror(mirror)
+    for attr in ("id_lower", "id_upRight", "id_upLeft", "id_totUp"):
+        a, b = getattr(wave, attr), getattr(lane, attr)
+        assert np.array_equal(a >= 0, b >= 0), attr
+        moved = np.nonzero((a >= 0) & (a != getattr(base, attr)))[0]
+        if len(moved):
+            assert dev.download(a[moved]) == dev.download(b[moved]), attr
+    nodes = np.nonzero(mirror.parent >= 0)[0]
+    par = mirror.parent[nodes]
+    up_ids = np.where(mirror.children[par, 0] == nodes, mirror.up_right[par], mirror.up_left[par]).astype(np.int32)
+    ok = (mirror.tot_up[nodes] >= 0) & (up_ids >= 0)
+    nodes, up_ids = nodes[ok], up_ids[ok]
+    q_ids = mirror.lower[rng.choice(np.asarray(data.tip_node), size=len(nodes))].astype(np.int32)
+    args = (mirror.tot_up[nodes], mirror.lower[nodes], up_ids, mirror.dist[nodes], q_ids, True, mirror.is_tip[nodes])
+    wave4 = dev.evaluate_placement_batch(*args)
+    monkeypatch.setenv("MAPLE_NO_WAVE_EVAL", "1")
+    lane4 = dev.evaluate_placement_batch(*args)
+    monkeypatch.delenv("MAPLE_NO_WAVE_EVAL")
+    assert len(wave4) > 500 and np.array_equal(wave4.view(np.uint64), lane4.view(np.uint64))
+    dev.close()
+
+
 def test_serial_placement_through_tree_patch_on_a_tree_with_local_references(world):
     """The serial placement phase on a tree with MAT local references, in every model mode: 20 samples one after the other
     (single-query search, a new internal node + tip at the best branch, maple_update_partials, HostTree.sync =
