@@ -186,6 +186,7 @@ struct maple_ctx {
     DevBuf<int32_t> p_i32[4];
     DevBuf<double> p_f64[2], p_score;
     PinBuf pin_place;                   // single-query placement: scores and minor-sequence flags on their way to the host
+    PinBuf pin_res;                     // small per-launch results (a copy into pageable memory costs an extra ~10 us)
     DevBuf<int16_t> p_i16;
     DevBuf<uint8_t> p_u8, p_minor;
     int32_t *d_tile_counters = nullptr;    // ring of tile counters for the dynamically scheduled kernels
@@ -714,6 +715,39 @@ __global__ __launch_bounds__(64) void k_update_items_wave(MAPLE_UPDATE_ITEM_ARGS
             } else ne = 0;
         }
         if (lane == 0) { res3[i] = ne; res3[n + i] = na; res3[2 * n + i] = flag; }
+    }
+}
+
+// shorten of ONE list per wavefront (wave_shorten, wave_update.h): for the handful of lists a single-query placement shortens
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(64) void k_shorten_wave(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *l, OutSpec o)
+{
+    __shared__ Lds lds;
+    __shared__ WaveUpdLds L;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const int lane = threadIdx.x;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int id = l[i], ne = av.n_ent[id], na = av.n_aux[id];
+        if (ne > MAPLE_WU_CAP || na > 5 * MAPLE_WU_CAP) {
+            if (lane == 0) {
+                Writer w;
+                w.init(o.words + o.woff[i], o.aux + o.aoff[i]);
+                o.n_ent[i] = shorten_walk(c, list_ref(av, id), ne, w);
+                o.n_aux[i] = w.na;
+            }
+            continue;
+        }
+        wave_sync();
+        const ListRef src = list_ref(av, id);
+        const unsigned long long *sw = (const unsigned long long *)src.w;
+        for (int k = lane; k < ne; k += 64) L.m[k] = sw[k];
+        for (int k = lane; k < na; k += 64) L.maux[k] = src.aux[k];
+        wave_sync();
+        int naOut = 0;
+        const int r = wave_shorten(c, L, ne, o.words + o.woff[i], o.aux + o.aoff[i], naOut);
+        if (lane == 0) { o.n_ent[i] = r; o.n_aux[i] = naOut; }
     }
 }
 
@@ -1319,7 +1353,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     c->s_search_ws.release(); c->s_search_out.release(); c->s_counter.release(); c->s_cache.release();
     for (auto &b : c->p_i32) b.release();
     for (auto &b : c->p_f64) b.release();
-    c->pin_place.release();
+    c->pin_place.release(); c->pin_res.release();
     c->p_score.release(); c->p_i16.release(); c->p_u8.release(); c->p_minor.release();
     if (c->place) {
         PlaceMeta &M = *c->place;
@@ -1649,10 +1683,12 @@ static int commit_known(maple_ctx *c, int32_t n, const int64_t *d_woff, const in
 static int commit_lists(maple_ctx *c, int32_t n, const int64_t *d_woff, const int64_t *d_aoff, int32_t *d_n_ent, int32_t *d_n_aux,
                         int32_t *outList, const uint2 *srcW = nullptr, const double *srcA = nullptr)
 {
-    std::vector<int32_t> ne(n), na(n);
-    HIPCK(c, hipMemcpyAsync(ne.data(), d_n_ent, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipMemcpyAsync(na.data(), d_n_aux, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, c->pin_res.reserve((size_t)2 * n * sizeof(int32_t)));
+    int32_t *h = (int32_t *)c->pin_res.p;
+    HIPCK(c, hipMemcpyAsync(h, d_n_ent, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(h + n, d_n_aux, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    const std::vector<int32_t> ne(h, h + n), na(h + n, h + 2 * (size_t)n);
     return commit_known(c, n, d_woff, d_aoff, d_n_ent, d_n_aux, ne, na, outList, srcW, srcA);
 }
 
@@ -2019,7 +2055,10 @@ extern "C" int maple_shorten_batch(maple_ctx *c, int32_t n, const int32_t *l, in
     HIPCK(c, c->s_i32[2].reserve(n));
     HIPCK(c, c->s_i32[3].reserve(n));
     OutSpec o{c->s_words.p, c->s_aux.p, dwo, dao, c->s_i32[2].p, c->s_i32[3].p};
-    DISPATCH3(c, k_shorten, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl, o));
+    if (n <= 1024 && !getenv("MAPLE_NO_WAVE_UPDATE"))
+        DISPATCH3(c, k_shorten_wave, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dl, o));
+    else
+        DISPATCH3(c, k_shorten, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl, o));
     HIPCK(c, hipGetLastError());
     return commit_lists(c, n, dwo, dao, c->s_i32[2].p, c->s_i32[3].p, outList);
 }
@@ -2105,11 +2144,15 @@ static int evaluate_placement_items(maple_ctx *c, int32_t n, const int32_t *midT
                                                                                  c->s_words.p, c->s_aux.p, dCap, c->s_ais.p, dAis, d4,
                                                                                  c->s_i32[4].p, d2));
     HIPCK(c, hipGetLastError());
-    std::vector<int32_t> st(n);
-    HIPCK(c, hipMemcpyAsync(out4, d4, (size_t)4 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (comp2) HIPCK(c, hipMemcpyAsync(comp2, d2, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipMemcpyAsync(st.data(), c->s_i32[4].p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    const size_t nD = (size_t)(comp2 ? 6 : 4) * n;
+    HIPCK(c, c->pin_res.reserve(nD * sizeof(double) + (size_t)n * sizeof(int32_t)));
+    double *hD = (double *)c->pin_res.p;
+    int32_t *st = (int32_t *)(hD + nD);
+    HIPCK(c, hipMemcpyAsync(hD, d4, nD * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(st, c->s_i32[4].p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    memcpy(out4, hD, (size_t)4 * n * sizeof(double));
+    if (comp2) memcpy(comp2, hD + (size_t)4 * n, (size_t)2 * n * sizeof(double));
     for (int i = 0; i < n; i++)
         if (st[i]) return fail(c, MAPLE_ERR_FATAL, "evaluatePlacement item %d: a merge returned None", i);
     return MAPLE_OK;

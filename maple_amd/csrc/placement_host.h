@@ -364,33 +364,49 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
         TRY(h2d(c, dU, U.data(), U.size()));
         HIPCK(c, c->p_score.reserve((size_t)nq * nCols));
         HIPCK(c, c->p_minor.reserve((size_t)nq * std::max(nL, 1)));
+        // a handful of queries: the traversal runs on the host (below), and the kernels write the scores it reads straight
+        // into page-locked host memory -- they cross PCIe while the kernel is still producing them instead of in a copy after it
+        const bool hostReplay = nq <= 4;
+        const size_t nS = (size_t)nq * nCols, nM = (size_t)nq * std::max(nL, 1);
+        double *hs = nullptr, *scoreOut = c->p_score.p;
+        uint8_t *hm = nullptr, *minorOut = c->p_minor.p;
+        bool zeroCopy = false;
+        if (hostReplay) {
+            HIPCK(c, c->pin_place.reserve(nS * sizeof(double) + nM));
+            hs = (double *)c->pin_place.p;
+            hm = (uint8_t *)(hs + nS);
+            void *dp = nullptr;
+            if (!getenv("MAPLE_NO_ZEROCOPY") && hipHostGetDevicePointer(&dp, hs, 0) == hipSuccess && dp) {
+                zeroCopy = true;
+                scoreOut = (double *)dp;
+                minorOut = (uint8_t *)((double *)dp + nS);
+            } else (void)hipGetLastError();
+        }
         if (nF == 1)   // one reference frame: the plain batch kernel (query words staged in LDS) does the same job faster
-            TRY(launch_append_queries(c, c->stream, nq, dU.p, nCols, M.d_candList.p, 1, pp->oneMutBLen, c->p_score.p, nCols,
+            TRY(launch_append_queries(c, c->stream, nq, dU.p, nCols, M.d_candList.p, 1, pp->oneMutBLen, scoreOut, nCols,
                                       nullptr, nullptr, nullptr, MAPLE_K_PLACE_SCORE, 0.0));
         else
-            TRY(launch_place_score(c, nq, nF, dU.p, nCols, M.d_candList.p, M.d_candFrame.p, 1, pp->oneMutBLen, c->p_score.p, nCols,
+            TRY(launch_place_score(c, nq, nF, dU.p, nCols, M.d_candList.p, M.d_candFrame.p, 1, pp->oneMutBLen, scoreOut, nCols,
                                    nullptr, nullptr, nullptr));
         if (nL > 0) {
             hipLaunchKernelGGL(k_place_minor, dim3(grid_for((int)std::min<long long>((long long)nq * nL, 1 << 30))), dim3(MAPLE_BLOCK), 0,
                                c->stream, c->lRef, view(c), nq, nF, dU.p, nL, M.d_leafList.p, M.d_leafFrame.p,
-                               pp->onlyFindIdentical, c->p_minor.p);
+                               pp->onlyFindIdentical, minorOut);
             HIPCK(c, hipGetLastError());
         }
         const size_t SL = MAPLE_PLACE_SHORTLIST;
         std::vector<int32_t> hi;
         std::vector<double> hf;
         std::vector<uint8_t> hb;
-        if (nq <= 4) {
+        if (hostReplay) {
             // a handful of queries (the sequential placement loop hands over one at a time): one lane's ~1 us per visit
             // would dominate the call, so the scores come back (8 bytes per branch) and the SAME traversal function
             // runs on the host
-            const size_t nS = (size_t)nq * nCols, nM = (size_t)nq * std::max(nL, 1);
-            HIPCK(c, c->pin_place.reserve(nS * sizeof(double) + nM));
             if (dbg) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple]   scoring kernels done after %lld us\n", tus(t2, tnow())); }
-            double *const hs = (double *)c->pin_place.p;
-            uint8_t *const hm = (uint8_t *)(hs + nS);
-            HIPCK(c, hipMemcpyAsync(hs, c->p_score.p, nS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            if (nL > 0) HIPCK(c, hipMemcpyAsync(hm, c->p_minor.p, nM, hipMemcpyDeviceToHost, c->stream));
+            if (!zeroCopy) {
+                HIPCK(c, hipMemcpyAsync(hs, c->p_score.p, nS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                if (nL > 0) HIPCK(c, hipMemcpyAsync(hm, c->p_minor.p, nM, hipMemcpyDeviceToHost, c->stream));
+            }
             HIPCK(c, hipStreamSynchronize(c->stream));
             if (dbg) fprintf(stderr, "[maple]   scores on the host after %lld us\n", tus(t2, tnow()));
             hi.assign((size_t)nq * (6 + SL), 0);

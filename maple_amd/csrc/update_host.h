@@ -96,8 +96,9 @@ static int update_items(maple_ctx *c, int32_t n, const int32_t *l1, const double
         DISPATCH3(c, k_update_items, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl1, db1, dt1, dl2, db2, dt2, dud,
                                                                                     dmode, dold, c->s_words.p, c->s_aux.p, dwo, dcap, res3));
     HIPCK(c, hipGetLastError());
-    std::vector<int32_t> h3((size_t)3 * n);
-    HIPCK(c, hipMemcpyAsync(h3.data(), res3, (size_t)3 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, c->pin_res.reserve((size_t)3 * n * sizeof(int32_t)));
+    const int32_t *h3 = (const int32_t *)c->pin_res.p;
+    HIPCK(c, hipMemcpyAsync(c->pin_res.p, res3, (size_t)3 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     std::vector<int32_t> ne(n), na(n);
     for (int i = 0; i < n; i++) {

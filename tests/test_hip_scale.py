@@ -372,6 +372,17 @@ def test_wavefront_wide_kernels_around_their_list_length_limit(monkeypatch):
     lane4 = dev.evaluate_placement_batch(*args)
     monkeypatch.delenv("MAPLE_NO_WAVE_EVAL")
     assert len(wave4) > 500 and np.array_equal(wave4.view(np.uint64), lane4.view(np.uint64))
+    # shorten() of single lists (k_shorten_wave for small batches): merged-but-unshortened lists are what it is for
+    half = mirror.dist[nodes][:500] / 2
+    merged = dev.merge_batch(up_ids[:500], half, False, mirror.lower[nodes][:500], half, mirror.is_tip[nodes][:500], True)
+    merged = merged[merged >= 0]
+    assert len(merged) > 300
+    sw = dev.shorten_batch(merged)
+    monkeypatch.setenv("MAPLE_NO_WAVE_UPDATE", "1")
+    sl = dev.shorten_batch(merged)
+    monkeypatch.delenv("MAPLE_NO_WAVE_UPDATE")
+    assert dev.download(sw) == dev.download(sl)
+    assert (dev.sizes(sw)[0] < dev.sizes(merged)[0]).sum() > 50           # (it did shorten something)
     dev.close()
 
 
