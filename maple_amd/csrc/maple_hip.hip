@@ -718,6 +718,77 @@ __global__ __launch_bounds__(64) void k_update_items_wave(MAPLE_UPDATE_ITEM_ARGS
     }
 }
 
+// The explicit-pair operators by one wavefront per pair, for the few pairs of a single reference call (mergeVectors without
+// the likelihood, estimateBranchLengthWithDerivative; appendProbNode: k_wave_append below): same results, a fifth of the wait.
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(64) void k_merge_wave(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *l1,
+                                                   const double *b1, const uint8_t *t1, const int32_t *l2, const double *b2,
+                                                   const uint8_t *t2, const uint8_t *ud, OutSpec o)
+{
+    __shared__ Lds lds;
+    __shared__ WaveUpdLds L;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const int lane = threadIdx.x;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int id1 = l1[i], id2 = l2[i];
+        const int n1 = av.n_ent[id1], n2 = av.n_ent[id2];
+        uint2 *gw = o.words + o.woff[i];
+        double *ga = o.aux + o.aoff[i];
+        if (n1 > MAPLE_WU_IN || n2 > MAPLE_WU_IN) {
+            if (lane == 0) {
+                Writer w;
+                w.init(gw, ga);
+                double lk = 0.0;
+                o.n_ent[i] = merge_walk(c, list_ref(av, id1), b1[i], t1[i] != 0, list_ref(av, id2), b2[i], t2[i] != 0, ud[i] != 0, false, 0, 0,
+                                        w, &lk);
+                o.n_aux[i] = w.na;
+            }
+            continue;
+        }
+        wave_sync();
+        int na = 0;
+        const int r = wave_merge(c, list_ref(av, id1), n1, b1[i], t1[i] != 0, list_ref(av, id2), n2, b2[i], t2[i] != 0, ud[i] != 0, L, na);
+        if (r >= 0) {
+            for (int k = lane; k < r; k += 64) { const unsigned long long w = L.m[k]; gw[k] = make_uint2((uint32_t)w, (uint32_t)(w >> 32)); }
+            for (int k = lane; k < na; k += 64) ga[k] = L.maux[k];
+        }
+        if (lane == 0) { o.n_ent[i] = r; o.n_aux[i] = r >= 0 ? na : 0; }
+    }
+}
+
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(64) void k_blen_wave(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *pl,
+                                                  const int32_t *cl, const uint8_t *tip, double *ais, const int64_t *aisOff,
+                                                  double *t, uint8_t *isFalse)
+{
+    __shared__ Lds lds;
+    __shared__ WaveLds W;
+    __shared__ double terms[128];
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int idP = pl[i], idC = cl[i];
+        const int nP = av.n_ent[idP], nC = av.n_ent[idC];
+        bool f = false;
+        double v = 0.0;
+        if (nP > MAPLE_WAVE_CAPW || nC > MAPLE_WAVE_CAPW) {
+            if (threadIdx.x == 0) v = blen_walk(c, list_ref(av, idP), list_ref(av, idC), tip[i] != 0, ais + aisOff[i], 1, &f);
+        } else {
+            wave_sync();
+            v = wave_blen(c, list_ref(av, idP), nP, list_ref(av, idC), nC, tip[i] != 0, W, terms, &f);
+        }
+        if (threadIdx.x == 0) { t[i] = v; isFalse[i] = f ? 1 : 0; }
+    }
+}
+
+template <bool RV, bool U, bool SS>
+__global__ void k_wave_append(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *pl, const int32_t *cl,
+                              const uint8_t *tip, const double *bl, double *out);
+#define MAPLE_WAVE_PAIRS_MAX 1024        // explicit-pair batches up to this size go one wavefront per pair
+
 // shorten of ONE list per wavefront (wave_shorten, wave_update.h): for the handful of lists a single-query placement shortens
 template <bool RV, bool U, bool SS>
 __global__ __launch_bounds__(64) void k_shorten_wave(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *l, OutSpec o)
@@ -1806,13 +1877,14 @@ extern "C" int maple_append_batch(maple_ctx *c, int32_t n, const int32_t *pl, co
     TRY(need_model(c));
     TRY(check_ids(c, n, pl, false, "parentList"));
     TRY(check_ids(c, n, cl, false, "childList"));
-    TRY(h2d(c, c->s_i32[0], pl, (size_t)n));
-    TRY(h2d(c, c->s_i32[1], cl, (size_t)n));
-    TRY(h2d(c, c->s_u8[0], tip, (size_t)n));
-    TRY(h2d(c, c->s_f64[0], bl, (size_t)n));
+    TRY(stage_begin(c, (size_t)n * 32 + 256));
+    STAGE(dpl, c, pl, n); STAGE(dcl, c, cl, n); STAGE(dtip, c, tip, n); STAGE(dbl, c, bl, n);
+    TRY(stage_flush(c));
     HIPCK(c, c->s_f64[1].reserve(n));
-    DISPATCH3(c, k_append, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, c->s_i32[0].p, c->s_i32[1].p,
-                                                                          c->s_u8[0].p, c->s_f64[0].p, c->s_f64[1].p));
+    if (n <= MAPLE_WAVE_PAIRS_MAX && !getenv("MAPLE_NO_WAVE_PAIRS"))
+        DISPATCH3(c, k_wave_append, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dpl, dcl, dtip, dbl, c->s_f64[1].p));
+    else
+        DISPATCH3(c, k_append, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dpl, dcl, dtip, dbl, c->s_f64[1].p));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(out, c->s_f64[1].p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -1850,8 +1922,11 @@ extern "C" int maple_merge_batch(maple_ctx *c, int32_t n, const int32_t *l1, con
     double *dlk = nullptr;
     if (outLK) { HIPCK(c, c->s_f64[2].reserve(n)); dlk = c->s_f64[2].p; }
     OutSpec o{c->s_words.p, c->s_aux.p, dwo, dao, c->s_i32[2].p, c->s_i32[3].p};
-    DISPATCH3(c, k_merge, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl1, db1, dt1, dl2, db2, dt2, dud, dnm1,
-                                                                         dnm2, o, dlk));
+    if (!outLK && n <= MAPLE_WAVE_PAIRS_MAX && !getenv("MAPLE_NO_WAVE_PAIRS"))
+        DISPATCH3(c, k_merge_wave, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dl1, db1, dt1, dl2, db2, dt2, dud, o));
+    else
+        DISPATCH3(c, k_merge, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl1, db1, dt1, dl2, db2, dt2, dud, dnm1,
+                                                                             dnm2, o, dlk));
     HIPCK(c, hipGetLastError());
     if (outLK) HIPCK(c, hipMemcpyAsync(outLK, dlk, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     return commit_lists(c, n, dwo, dao, c->s_i32[2].p, c->s_i32[3].p, outList);
@@ -1875,8 +1950,12 @@ extern "C" int maple_blen_batch(maple_ctx *c, int32_t n, const int32_t *pl, cons
     TRY(stage_flush(c));
     HIPCK(c, c->s_f64[0].reserve(n));
     HIPCK(c, c->s_u8[1].reserve(n));
-    DISPATCH3(c, k_blen, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dpl, dcl, dtip, c->s_ais.p, dao,
-                                                                        c->s_f64[0].p, c->s_u8[1].p));
+    if (n <= MAPLE_WAVE_PAIRS_MAX && !getenv("MAPLE_NO_WAVE_PAIRS"))
+        DISPATCH3(c, k_blen_wave, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dpl, dcl, dtip, c->s_ais.p, dao, c->s_f64[0].p,
+                                                             c->s_u8[1].p));
+    else
+        DISPATCH3(c, k_blen, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dpl, dcl, dtip, c->s_ais.p, dao,
+                                                                            c->s_f64[0].p, c->s_u8[1].p));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(t, c->s_f64[0].p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(isFalse, c->s_u8[1].p, n, hipMemcpyDeviceToHost, c->stream));

@@ -277,6 +277,44 @@ def test_wavefront_wide_evaluate_placement_is_the_one_lane_chain_bit_for_bit(wor
     dev.release(mark)
 
 
+def test_explicit_pair_operators_one_wavefront_per_pair_are_the_one_lane_kernels(world, monkeypatch):
+    """maple_append_batch, maple_merge_batch (without the likelihood) and maple_blen_batch send batches of up to 1 024 pairs --
+    a single reference call, a handful of calls -- through one wavefront per pair (k_wave_append, k_merge_wave, k_blen_wave);
+    in every model mode the scores, lists and lengths must be those of the one-lane kernels, bit for bit."""
+    mode, data, dev, orc, mirror = world
+    rng = np.random.default_rng(41)
+    nodes = rng.choice(np.nonzero(mirror.parent >= 0)[0], size=900, replace=False)
+    par = mirror.parent[nodes]
+    up_ids = np.where(mirror.children[par, 0] == nodes, mirror.up_right[par], mirror.up_left[par]).astype(np.int32)
+    ok = (up_ids >= 0) & (mirror.tot_up[nodes] >= 0)
+    nodes, up_ids = nodes[ok], up_ids[ok]
+    low, tip, dist = mirror.lower[nodes], mirror.is_tip[nodes], mirror.dist[nodes]
+    q = mirror.lower[rng.choice(np.asarray(data.tip_node), size=len(nodes))]
+    mark = dev.mark()
+
+    def run():
+        return dict(app=dev.append_batch(mirror.tot_up[nodes], q, True, 1.0 / dev.lRef),
+                    app2=dev.append_batch(up_ids, low, tip, dist),
+                    low=dev.merge_batch(low, dist, tip, q, 1.0 / dev.lRef, True, False),
+                    up=dev.merge_batch(up_ids, dist / 2, False, low, dist / 2, tip, True),
+                    blen=dev.blen_batch(mirror.tot_up[nodes], q, True), blen2=dev.blen_batch(up_ids, low, tip))
+
+    wave = run()
+    monkeypatch.setenv("MAPLE_NO_WAVE_PAIRS", "1")
+    lane = run()
+    monkeypatch.delenv("MAPLE_NO_WAVE_PAIRS")
+    assert len(nodes) > 500
+    for k in ("app", "app2"):
+        assert np.array_equal(wave[k].view(np.uint64), lane[k].view(np.uint64)), k
+    for k in ("blen", "blen2"):
+        assert np.array_equal(wave[k][0].view(np.uint64), lane[k][0].view(np.uint64)) and np.array_equal(wave[k][1], lane[k][1]), k
+    for k in ("low", "up"):
+        assert np.array_equal(wave[k] >= 0, lane[k] >= 0), k
+        good = wave[k] >= 0
+        assert good.sum() > 400 and dev.download(wave[k][good]) == dev.download(lane[k][good]), k
+    dev.release(mark)
+
+
 def test_wavefront_wide_update_items_leave_the_one_lane_lists(world, monkeypatch):
     """k_update_items_wave (one wavefront per item: mergeVectors, shorten and areVectorsDifferent cut along the merge path,
     wave_update.h) against k_update_items (one lane per item), in every model mode: the same 60 changes -- one at a time,
