@@ -785,6 +785,35 @@ __global__ __launch_bounds__(64) void k_blen_wave(const DevModel *__restrict__ m
 }
 
 template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(64) void k_differ_wave(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *l1, const int32_t *l2,
+                                                    uint8_t *out)
+{
+    __shared__ Lds lds;
+    __shared__ unsigned long long A[MAPLE_WU_CAP], B[MAPLE_WU_CAP];
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const int lane = threadIdx.x;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int id1 = l1[i], id2 = l2[i];
+        if (id2 < 0) { if (lane == 0) out[i] = 1; continue; }
+        const int n1 = av.n_ent[id1], n2 = av.n_ent[id2];
+        const ListRef L1 = list_ref(av, id1), L2 = list_ref(av, id2);
+        if (n1 > MAPLE_WU_CAP || n2 > MAPLE_WU_CAP) {
+            if (lane == 0) out[i] = differ_walk(c, L1, L2) ? 1 : 0;
+            continue;
+        }
+        wave_sync();
+        const unsigned long long *w1 = (const unsigned long long *)L1.w, *w2 = (const unsigned long long *)L2.w;
+        for (int k = lane; k < n1; k += 64) A[k] = w1[k];
+        for (int k = lane; k < n2; k += 64) B[k] = w2[k];
+        wave_sync();
+        const bool d = wave_differ(c, A, L1.aux, n1, B, L2.aux, n2);
+        if (lane == 0) out[i] = d ? 1 : 0;
+    }
+}
+
+template <bool RV, bool U, bool SS>
 __global__ void k_wave_append(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *pl, const int32_t *cl,
                               const uint8_t *tip, const double *bl, double *out);
 #define MAPLE_WAVE_PAIRS_MAX 1024        // explicit-pair batches up to this size go one wavefront per pair
@@ -1975,7 +2004,10 @@ extern "C" int maple_differ_batch(maple_ctx *c, int32_t n, const int32_t *l1, co
     STAGE(dl1, c, l1, n); STAGE(dl2, c, l2, n);
     TRY(stage_flush(c));
     HIPCK(c, c->s_u8[0].reserve(n));
-    DISPATCH3(c, k_differ, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl1, dl2, c->s_u8[0].p));
+    if (n <= MAPLE_WAVE_PAIRS_MAX && !getenv("MAPLE_NO_WAVE_PAIRS"))
+        DISPATCH3(c, k_differ_wave, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dl1, dl2, c->s_u8[0].p));
+    else
+        DISPATCH3(c, k_differ, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl1, dl2, c->s_u8[0].p));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(out, c->s_u8[0].p, n, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));

@@ -278,8 +278,8 @@ def test_wavefront_wide_evaluate_placement_is_the_one_lane_chain_bit_for_bit(wor
 
 
 def test_explicit_pair_operators_one_wavefront_per_pair_are_the_one_lane_kernels(world, monkeypatch):
-    """maple_append_batch, maple_merge_batch (without the likelihood) and maple_blen_batch send batches of up to 1 024 pairs --
-    a single reference call, a handful of calls -- through one wavefront per pair (k_wave_append, k_merge_wave, k_blen_wave);
+    """maple_append_batch, maple_merge_batch (without the likelihood), maple_blen_batch and maple_differ_batch send batches of up to 1 024 pairs --
+    a single reference call, a handful of calls -- through one wavefront per pair (k_wave_append, k_merge_wave, k_blen_wave, k_differ_wave);
     in every model mode the scores, lists and lengths must be those of the one-lane kernels, bit for bit."""
     mode, data, dev, orc, mirror = world
     rng = np.random.default_rng(41)
@@ -297,7 +297,8 @@ def test_explicit_pair_operators_one_wavefront_per_pair_are_the_one_lane_kernels
                     app2=dev.append_batch(up_ids, low, tip, dist),
                     low=dev.merge_batch(low, dist, tip, q, 1.0 / dev.lRef, True, False),
                     up=dev.merge_batch(up_ids, dist / 2, False, low, dist / 2, tip, True),
-                    blen=dev.blen_batch(mirror.tot_up[nodes], q, True), blen2=dev.blen_batch(up_ids, low, tip))
+                    blen=dev.blen_batch(mirror.tot_up[nodes], q, True), blen2=dev.blen_batch(up_ids, low, tip),
+                    dif=dev.differ_batch(low, np.roll(low, 1)), dif2=dev.differ_batch(mirror.tot_up[nodes], mirror.tot_up[nodes]))
 
     wave = run()
     monkeypatch.setenv("MAPLE_NO_WAVE_PAIRS", "1")
@@ -308,6 +309,7 @@ def test_explicit_pair_operators_one_wavefront_per_pair_are_the_one_lane_kernels
         assert np.array_equal(wave[k].view(np.uint64), lane[k].view(np.uint64)), k
     for k in ("blen", "blen2"):
         assert np.array_equal(wave[k][0].view(np.uint64), lane[k][0].view(np.uint64)) and np.array_equal(wave[k][1], lane[k][1]), k
+    assert np.array_equal(wave["dif"], lane["dif"]) and wave["dif"].sum() > 400 and not wave["dif2"].any() and not lane["dif2"].any()
     for k in ("low", "up"):
         assert np.array_equal(wave[k] >= 0, lane[k] >= 0), k
         good = wave[k] >= 0
