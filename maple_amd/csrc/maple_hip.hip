@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -100,6 +101,11 @@ struct PlaceMeta {                     // derived from the uploaded tree, rebuil
 struct maple_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;     // side stream: the dense scoring of the searches known to be whole-tree ones runs next to
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the lane searches of the others (maple_spr_search_batch)
+    DevBuf<int32_t> z_ql;
+    DevBuf<uint8_t> z_qt;
+    DevBuf<double> z_qb;
     std::vector<hipEvent_t> evs;       // pairs (start, stop) of timed *_dev launches since the last reset
     size_t ev_used = 0;
     // what each timed launch was: kind (MAPLE_K_*), units of work (pairs scored / searches run) and the algorithmic
@@ -1464,6 +1470,10 @@ extern "C" int maple_destroy(maple_ctx *c)
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     for (auto &cs : c->candsets) { if (cs.lists) (void)hipFree(cs.lists); if (cs.frame) (void)hipFree(cs.frame); }
     if (c->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->rccl_comm);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    c->z_ql.release(); c->z_qt.release(); c->z_qb.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return MAPLE_OK;
@@ -3016,12 +3026,14 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     bool assistOK = !getenv("MAPLE_NO_LEAN") && (!c->dm.usingErrorRate || getenv("MAPLE_LEAN_ERR"));
     const bool assistFew = !c->dm.usingErrorRate;      // few searching lanes per wavefront, every request served by all 64 lanes
     if (getenv("MAPLE_NO_LEAN_MAT") && c->tree_has_mut) assistOK = false;                                              // (experiments)
+    const std::vector<int32_t> *rowOverride = nullptr;                 // rows of the score table the next cached launch reads
+    std::function<int()> afterLaunch;                                  // called once, right after the next search kernel is queued
     auto run_queries = [&](std::vector<int32_t> todo, std::vector<int32_t> slot, const double *cacheS, int budgetNow,
                            const int32_t *rTable, int nF) -> int {
         // the few cached (whole-tree) searches get room up front; more when the budgeted pass already ran out of it
         int capW = cacheS ? (heavyQueries ? 8 : 4) * capW0 : capW0;
         std::vector<int32_t> rows(todo.size());                        // row of each query in the cache / frame tables
-        for (size_t k = 0; k < rows.size(); k++) rows[k] = (int32_t)k;
+        for (size_t k = 0; k < rows.size(); k++) rows[k] = rowOverride ? (*rowOverride)[k] : (int32_t)k;
         if (!getenv("MAPLE_NO_LPT")) {
             // Lanes pull searches from a counter, so a launch ends one search after the last one is pulled: the expensive
             // searches go first.  The expensive ones are those near the root (long lists: an updating step there merges
@@ -3125,6 +3137,11 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
 #undef MAPLE_SPR_LAUNCH_ARGS
             HIPCK(c, hipGetLastError());
             HIPCK(c, hipEventRecord(e1, c->stream));
+            if (afterLaunch) {                                             // (work for the side stream, queued behind this launch)
+                std::function<int()> f;
+                f.swap(afterLaunch);
+                TRY(f());
+            }
             std::vector<SearchOut> part(m);
             HIPCK(c, hipMemcpyAsync(part.data(), dout, (size_t)m * sizeof(SearchOut), hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
@@ -3214,12 +3231,120 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         c->scan_eff = P.effNon0;
         c->scan_valid = true;
     }
+    // Without an error model the whole-tree searches are known before anything runs: they are the ones that start from a
+    // zero-length branch (the routing hint in the kernel gives those 16 placements and sends them on).  Their dense scoring
+    // needs nothing from the lane searches, so it is launched first, on a side stream, and shares the GPU with them -- the
+    // lane launch is latency-bound and spends its second half on a thinning tail.  Rows of the score table: the predicted
+    // searches in order, then up to `preSpare` searches that run over their budget unannounced.
+    std::vector<int32_t> preIdx, preRowOf;
+    int preSpare = 0;
+    const int nTpre = c->dtree.n;
+    if (hybrid && !c->tree_has_mut && !c->dm.usingErrorRate && wideBudget > 16 && !getenv("MAPLE_NO_PRESCORE")) {
+        {   // a node on a zero-length branch is searched at all only if its current placement is bad enough (M:9674): the
+            // kernel's own test, on the same appendProbNode, for all of them at once
+            std::vector<int32_t> zi, pl, cl;
+            std::vector<uint8_t> tp;
+            for (int i = 0; i < n; i++) {
+                const int v = nodes[i], u = c->h_tree_up[v];
+                if (c->h_tree_dist[v] != 0.0 || u < 0) continue;
+                const int32_t vu = c->h_tree_c0[u] == v ? c->h_tree_upRight[u] : c->h_tree_upLeft[u];
+                if (vu < 0 || c->h_tree_lower[v] < 0) continue;
+                zi.push_back(i); pl.push_back(vu); cl.push_back(c->h_tree_lower[v]); tp.push_back(c->h_tree_tip[v]);
+            }
+            if (zi.size() >= 64) {
+                std::vector<double> bl(zi.size(), 0.0), cur(zi.size());
+                const int rc = maple_append_batch(c, (int32_t)zi.size(), pl.data(), cl.data(), tp.data(), bl.data(), cur.data());
+                if (rc != MAPLE_OK) return rc;
+                for (size_t k = 0; k < zi.size(); k++) if (cur[k] < P.thrPlacement) preIdx.push_back(zi[k]);
+            }
+        }
+        size_t freeB = 0, totalB = 0;
+        size_t budgetB = (size_t)4ull << 30;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess)
+            budgetB = std::max(budgetB, std::min((freeB + c->s_cache.cap * sizeof(double)) / 2, (size_t)96ull << 30));
+        const size_t rowsMax = budgetB / ((size_t)nTpre * sizeof(double));
+        if (preIdx.size() < 64 || preIdx.size() > rowsMax) preIdx.clear();
+        else {
+            preSpare = (int)std::min<size_t>(4096, rowsMax - preIdx.size());
+            const int mZ = (int)preIdx.size();
+            HIPCK(c, c->s_cache.reserve_exact((size_t)(mZ + preSpare) * nTpre));
+            if (!c->stream2) {
+                HIPCK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+                HIPCK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                HIPCK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            std::vector<int32_t> ql(mZ);
+            std::vector<uint8_t> qt(mZ);
+            std::vector<double> qb(mZ);
+            preRowOf.assign(n, -1);
+            double qBytes = 0.0;
+            for (int k = 0; k < mZ; k++) {
+                const int node = nodes[preIdx[k]];
+                ql[k] = c->h_tree_lower[node]; qt[k] = c->h_tree_tip[node]; qb[k] = c->h_tree_dist[node];
+                preRowOf[preIdx[k]] = k;
+                qBytes += 8.0 * c->h_n_ent[ql[k]] + 8.0 * c->h_n_aux[ql[k]];
+            }
+            HIPCK(c, c->z_ql.reserve(mZ)); HIPCK(c, c->z_qt.reserve(mZ)); HIPCK(c, c->z_qb.reserve(mZ));
+            HIPCK(c, hipEventRecord(c->ev_fork, c->stream));               // (everything the tree tables wait for)
+            HIPCK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            HIPCK(c, hipMemcpyAsync(c->z_ql.p, ql.data(), (size_t)mZ * sizeof(int32_t), hipMemcpyHostToDevice, c->stream2));
+            HIPCK(c, hipMemcpyAsync(c->z_qt.p, qt.data(), (size_t)mZ, hipMemcpyHostToDevice, c->stream2));
+            HIPCK(c, hipMemcpyAsync(c->z_qb.p, qb.data(), (size_t)mZ * sizeof(double), hipMemcpyHostToDevice, c->stream2));
+            HIPCK(c, hipStreamSynchronize(c->stream2));                     // (the three vectors are locals)
+            // queued BEHIND the lane launch: a workgroup of the dense kernel wants most of a compute unit's LDS, so it starts
+            // where the lane searches have thinned out -- launched first it would hold them off instead (measured: no overlap)
+            afterLaunch = [c, mZ, nTpre, qBytes]() -> int {
+                TRY(launch_append_queries(c, c->stream2, mZ, c->z_ql.p, c->n_scored, c->t_i32[8].p, 0, 0.0, c->s_cache.p, nTpre,
+                                          c->t_scored_col.p, c->z_qt.p, c->z_qb.p, MAPLE_K_SPR_SCORE,
+                                          (double)mZ * c->scored_bytes_total + qBytes));
+                HIPCK(c, hipEventRecord(c->ev_join, c->stream2));
+                return MAPLE_OK;
+            };
+            if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: %d searches from zero-length branches to be scored on the side stream\n", tms(tStart, tnow()), mZ);
+        }
+    }
     TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
     if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: budgeted pass done\n", tms(tStart, tnow()));
     if (hybrid) {
         std::vector<int32_t> wide;
         for (int i = 0; i < n; i++)
             if (ho[i].status == -5) { wide.push_back(i); if (ho[i].bestNode == -2) heavyQueries = true; }
+        if (!preIdx.empty()) {
+            // replay what was scored on the side, together with as many unannounced ones as the spare rows take
+            const int mZ = (int)preIdx.size();
+            std::vector<int32_t> qn, sl, rowsNow, rest, ql2;
+            std::vector<uint8_t> qt2;
+            std::vector<double> qb2;
+            for (int32_t i : wide) {
+                const int node = nodes[i];
+                if (preRowOf[i] >= 0) { qn.push_back(node); sl.push_back(i); rowsNow.push_back(preRowOf[i]); }
+                else if ((int)ql2.size() < preSpare) {
+                    qn.push_back(node); sl.push_back(i); rowsNow.push_back(mZ + (int)ql2.size());
+                    ql2.push_back(c->h_tree_lower[node]); qt2.push_back(c->h_tree_tip[node]); qb2.push_back(c->h_tree_dist[node]);
+                } else rest.push_back(i);
+            }
+            if (!ql2.empty()) {
+                const int m2 = (int)ql2.size();
+                TRY(h2d(c, c->s_i32[6], ql2.data(), (size_t)m2));
+                TRY(h2d(c, c->s_u8[3], qt2.data(), (size_t)m2));
+                TRY(h2d(c, c->s_f64[3], qb2.data(), (size_t)m2));
+                double qBytes = 0.0;
+                for (int k = 0; k < m2; k++) qBytes += 8.0 * c->h_n_ent[ql2[k]] + 8.0 * c->h_n_aux[ql2[k]];
+                TRY(launch_append_queries(c, c->stream, m2, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, 0, 0.0,
+                                          c->s_cache.p + (size_t)mZ * nTpre, nTpre, c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p,
+                                          MAPLE_K_SPR_SCORE, (double)m2 * c->scored_bytes_total + qBytes));
+            }
+            if (afterLaunch) { std::function<int()> f; f.swap(afterLaunch); TRY(f()); }   // (no lane launch took it)
+            HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            if (!qn.empty()) {
+                rowOverride = &rowsNow;
+                const int rc = run_queries(qn, sl, c->s_cache.p, 0, nullptr, 0);
+                rowOverride = nullptr;
+                if (rc != MAPLE_OK) return rc;
+            }
+            if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: %zu pre-scored and %zu other wide searches replayed, %zu left\n", tms(tStart, tnow()), qn.size() - ql2.size(), ql2.size(), rest.size());
+            wide.swap(rest);
+        }
         const PlaceMeta &F = *c->place;
         const int nT = c->dtree.n, nF = c->tree_has_mut ? F.nF : 1;
         const size_t rowBytes = (size_t)nT * sizeof(double);
