@@ -3123,6 +3123,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             if (const char *e = getenv("MAPLE_COOP_MAX")) coopMaxHost = std::max(0, atoi(e));
             hipEvent_t e0, e1;
             TRY(ev_pair(c, &e0, &e1, cacheS ? MAPLE_K_SPR_REPLAY : MAPLE_K_SPR_SEARCH, (double)m, 0.0));
+            const size_t slotEv = c->ev_used / 2 - 1;                       // (this launch's timing record: filled in below)
             HIPCK(c, hipEventRecord(e0, c->stream));
 #define MAPLE_SPR_LAUNCH_ARGS <<<launchWaves, 64, dynLds, c->stream>>>(c->d_model, view(c), mview(c), Tk, P, m, c->s_i32[0].p,          \
                                                                          L, LB, c->s_search_ws.p, c->s_counter.p, dout, poolW,     \
@@ -3158,7 +3159,6 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                     const double qb = l >= 0 ? 8.0 * c->h_n_ent[l] + 8.0 * c->h_n_aux[l] : 0.0;
                     bytes += cacheS ? 8.0 * part[k].nAppend + qb : meanCand * part[k].nAppend + qb;
                 }
-                const size_t slotEv = c->ev_used / 2 - 1;
                 c->ev_units[slotEv] = units; c->ev_bytes[slotEv] = bytes;
             }
             for (int k = 0; k < m; k++) {
