@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MAPLE_ABI_VERSION 1
+#define MAPLE_ABI_VERSION 2
 
 enum {
     MAPLE_OK = 0,
@@ -198,6 +198,9 @@ typedef struct {
     double effectivelyNon0BLen;                 /* M:3614 */
     int32_t wideSearchBudget;                   /* searches scoring more branches than this are batch-scored first
                                                    (0 = default 256, < 0 = never); results do not depend on it */
+    int32_t searchTier;                         /* 0 = automatic (the frontier tier where it applies: trees without MAT local
+                                                   references); 1 = one lane per search (k_spr_search) for every search;
+                                                   results do not depend on it */
 } maple_search_params;
 
 /* A local change of the uploaded tree -- what placeSampleOnTree (M:8300-8722) and the updatePartials after it leave behind:

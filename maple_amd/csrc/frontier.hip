@@ -1,0 +1,758 @@
+// maple_amd/csrc/frontier.hip -- the FRONTIER TIER of the SPR regraft search (findBestParentTopology, M:6817-7724, and the
+// worker body of startTopologyUpdatesParallel, M:9615-9711), for trees without MAT local references.
+//
+// The reference's search is a depth-first walk with order-dependent pruning: the running best (bestLKdiff) and the
+// failedPasses counter decide which branches are descended into (M:7090-7103, 7311-7323).  What an item of its stack
+// COMPUTES, however -- the lists merged along the path while needsUpdating holds, the placement score
+// appendProbNode(midTot, removed list) -- depends only on the path from the pruned node to that item, never on the order in
+// which the stack is emptied.  So the search is split in two:
+//
+//  1. EXPANSION (order-free, data-parallel over every item of every search of the batch, level by level).  Each item is
+//     scored by one lane and pushes its children under a PERMISSIVE form of the reference's rules that needs nothing but the
+//     path: the running best is replaced by pathBest = max(current placement cost, scores of the item's ancestors on its
+//     path) <= the running best the reference would hold when it reaches the item (ancestors are visited before it), and
+//     failedPasses is reset whenever a score beats pathBest (a superset of the reference's resets).  Both rules are
+//     monotone in the running best, so the set of expanded items is a SUPERSET of the items the reference visits, and
+//     every expanded item carries exactly the score, lists and flags the reference would compute for it.
+//  2. REPLAY (exact, one lane per search, integer and compare work only).  The reference's LIFO walk is run over the item
+//     tree of step 1 with the real running best and failedPasses: same visiting order, same short list (M:7071, 7293), same
+//     candidate count.  Short-listed branches of all searches are then refined in one batch (evaluatePlacement,
+//     M:6790-6806; one lane per record), and a last pass per search applies the reference's final selection (M:7635) and the
+//     worker's accept rule and vetoes (M:9681-9700).
+//
+// Results are those of the one-lane-per-search kernel (k_spr_search, search_dev.h) bit for bit; what changes is the shape
+// of the work: ~10^7 independent (search, branch) items per launch sequence instead of 10^5 chains of dependent list walks.
+//
+// The reference shortens the removed list in place at every improvement (M:7087).  Without local references the removed
+// list is the pruned node's own lower list, which is stored shortened, so that is a no-op; a search whose removed list
+// WOULD change is handed back (status FR_FALLBACK), as are searches that touch the root while still updating lists
+// (rootVector, M:6916-6960 / 7406-7432), run out of scratch, or exceed the pools.  Searches that expand more than `budget`
+// items are whole-tree searches and go to the dense tier (status -5), as before.
+#include "ctx_host.h"
+#include "frontier.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace {
+
+#define FR_BLOCK 256
+
+enum { FI_UPD_IN = 1, FI_UPD_OUT = 2, FI_SCORED = 4, FI_DEAD = 8, FI_REC_UPD = 16 };
+enum { FS_ACTIVE = 0, FS_FINAL = 1, FS_OVER = 2, FS_FALLBACK = 3 };
+#define FR_NONE (-1)
+
+struct alignas(16) FItem {
+    // in (written by the parent item's lane)
+    int32_t q, t1;
+    int8_t dir;                        // 0 = moving from a parent to its child, 1 / 2 = crawling up from child 0 / 1
+    uint8_t flags;
+    int16_t failsP;                    // failedPasses under the permissive rules
+    int32_t hPassed, hRpr;             // list handles: >= 0 temporary list, <= -10 tree list -(id + 10), -1 None
+    double distance, lastLK, pathBest;
+    // out (written by the item's own lane)
+    double midProb, recDist;
+    int32_t child0, child1;            // item refs in push order: >= 0 cached pool, <= -2 updating pool -(i + 2), -1 none
+    int32_t hA, hB, hMid;              // short-list record of an item that was still updating (M:7073 / 7295)
+    // replay
+    int32_t next;                      // stack link, then short-list link
+    int16_t failsA, pad;
+};
+
+struct FSearch {
+    int32_t node, parent, sibling;     // pruned node, its parent (`node` of findBestParentTopology), its sibling
+    int32_t hRpr0;
+    int32_t seed0, seed1;
+    int32_t nItems;                    // expanded so far (atomic)
+    int32_t state;
+    int32_t slHead, nApp, recBase, recCount;
+    int32_t isRemovedTip, pad;
+    double removedBLen, curLK;
+};
+
+struct FRec { int32_t q, ref; double optimized, top, bottom, app; int32_t ok, pad; };
+
+struct FCtr {                          // device-side bookkeeping of the level loop
+    unsigned long long usedU, usedC;   // items allocated in the two pools
+    unsigned long long loU, hiU, loC, hiC;   // the current level
+    unsigned long long nLists, usedW, usedA; // temporary lists
+    unsigned long long nRecs;
+    int32_t overflow, pad;
+};
+
+struct FPools {
+    FItem *U, *C;
+    long long capU, capC;
+    // temporary lists
+    uint2 *tw; double *ta;
+    long long *toffW, *toffA;
+    int32_t *tn, *tna;
+    long long capW, capA, capL;
+    // per-lane scratch
+    uint2 *sw; double *sa; double *sais;
+    int32_t capE;                      // entries one scratch list takes (aux: 5 per entry; ais: 2 per entry)
+    FCtr *ctr;
+    FSearch *S;
+    FRec *recs;
+    long long capRecs;
+};
+
+__device__ __forceinline__ FItem &item_of(const FPools &fp, int ref) { return ref >= 0 ? fp.C[ref] : fp.U[-(ref + 2)]; }
+
+struct FList { const uint2 *w; const double *aux; int32_t n, na; };
+
+__device__ __forceinline__ bool fvalid(int h) { return h >= 0 || h <= -10; }
+__device__ __forceinline__ int ftree(int listId) { return listId < 0 ? -1 : -(listId + 10); }
+__device__ __forceinline__ FList flist(const ArenaViewS &av, const FPools &fp, int h)
+{
+    if (h >= 0) return FList{fp.tw + fp.toffW[h], fp.ta + fp.toffA[h], fp.tn[h], fp.tna[h]};
+    const int id = -h - 10;
+    return FList{av.words + av.ent_off[id], av.aux + av.aux_off[id], av.n_ent[id], av.n_aux[id]};
+}
+__device__ __forceinline__ ListRef fref(const FList &l) { return ListRef{l.w, l.aux}; }
+
+// a scratch list becomes a temporary list of the batch: exact room, one copy; -2 when the pools are full
+__device__ inline int fstore(const FPools &fp, const Writer &wr)
+{
+    const unsigned long long id = atomicAdd(&fp.ctr->nLists, 1ull);
+    const unsigned long long ow = atomicAdd(&fp.ctr->usedW, (unsigned long long)wr.n);
+    const unsigned long long oa = atomicAdd(&fp.ctr->usedA, (unsigned long long)wr.na);
+    if ((long long)id >= fp.capL || (long long)(ow + wr.n) > fp.capW || (long long)(oa + wr.na) > fp.capA) {
+        fp.ctr->overflow = 1;
+        return -2;
+    }
+    uint2 *dw = fp.tw + ow;
+    double *da = fp.ta + oa;
+    for (int k = 0; k < wr.n; k++) dw[k] = wr.w[k];
+    for (int k = 0; k < wr.na; k++) da[k] = wr.aux[k];
+    fp.toffW[id] = (long long)ow; fp.toffA[id] = (long long)oa; fp.tn[id] = wr.n; fp.tna[id] = wr.na;
+    return (int)id;
+}
+
+// would shorten() (M:3721-3745) change this list?  (the absorb test of shorten_walk, genome_dev.h)
+template <class C> __device__ inline bool shorten_would_merge(const C &c, ListRef L, int nEnt)
+{
+    const double thr = c.m.thresholdProb;
+    Cursor a;
+    a.init(L);
+    Ent head = a.e;
+    for (int k = 1; k < nEnt; k++) {
+        a.next();
+        const Ent &nw = a.e;
+        if (nw.type == 4 && head.type == 4 && nw.hasD0 == head.hasD0 && nw.hasD1 == head.hasD1) {
+            if (!nw.hasD0) return true;
+            if (!(fabs(nw.d0 - head.d0) > thr) && !(nw.hasD1 && fabs(nw.d1 - head.d1) > thr) && nw.flag == head.flag) return true;
+        }
+        head = nw;
+    }
+    return false;
+}
+
+// one more expanded item of search q; false when the search is over its budget (it becomes a dense-tier search) or the pool
+// is full (the search is handed back)
+__device__ inline int fpush(const FPools &fp, const int budget, const int q, const bool upd, const int t1, const int dir,
+                            const int hPassed, const double distance, const double lastLK, const int fails, const int hRpr,
+                            const double pathBest)
+{
+    FSearch &S = fp.S[q];
+    if (atomicAdd(&S.nItems, 1) >= budget) { S.state = FS_OVER; return FR_NONE; }
+    FItem *it;
+    int ref;
+    if (upd) {
+        const unsigned long long i = atomicAdd(&fp.ctr->usedU, 1ull);
+        if ((long long)i >= fp.capU) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; return FR_NONE; }
+        it = &fp.U[i]; ref = -((int)i + 2);
+    } else {
+        const unsigned long long i = atomicAdd(&fp.ctr->usedC, 1ull);
+        if ((long long)i >= fp.capC) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; return FR_NONE; }
+        it = &fp.C[i]; ref = (int)i;
+    }
+    it->q = q; it->t1 = t1; it->dir = (int8_t)dir; it->flags = upd ? FI_UPD_IN : 0; it->failsP = (int16_t)fails;
+    it->hPassed = hPassed; it->hRpr = hRpr; it->distance = distance; it->lastLK = lastLK; it->pathBest = pathBest;
+    it->child0 = it->child1 = FR_NONE; it->hA = it->hB = it->hMid = -1; it->next = FR_NONE; it->failsA = 0;
+    it->midProb = lastLK; it->recDist = 0.0;
+    return ref;
+}
+
+// ---- the worker's prologue (M:9626-9674) and the seeding of nodesToVisit (M:6855-6914) ----------------------------------
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, int n,
+                                                       const int32_t *nodes, FPools fp, SearchOut *out, int budget, int zeroBudget)
+{
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        const int node = nodes[q];
+        SearchOut &o = out[q];
+        o.bestNode = -1; o.placement = -1; o.status = 0; o.nAppend = 0;
+        o.bestScore = 0.0; o.improvement = 0.0; o.currentLK = 0.0;
+        o.blen[0] = o.blen[1] = o.blen[2] = 0.0;
+        o.rprWoff = o.rprAoff = -1; o.rprN = o.rprNA = 0;
+        o.nShortList = o.nSteps = 0; o.tStep = o.tReplay = o.tRefine = 0;
+        FSearch &S = fp.S[q];
+        S.node = node; S.parent = -1; S.sibling = -1; S.hRpr0 = -1; S.seed0 = S.seed1 = FR_NONE; S.nItems = 0; S.state = FS_FINAL;
+        S.slHead = FR_NONE; S.nApp = 0; S.recBase = 0; S.recCount = 0; S.isRemovedTip = 0; S.removedBLen = 0.0; S.curLK = 0.0;
+        const NodeRec rn = T.nd[node];
+        const int parent = rn.up;
+        if (parent < 0) { o.status = 1; continue; }                          // the root cannot be re-placed (M:9626)
+        const NodeRec rp = T.nd[parent];
+        const int childIdx = (rp.c0 == node) ? 0 : 1;
+        const int vectUp = ftree(childIdx == 0 ? rp.upRight : rp.upLeft);
+        if (!fvalid(vectUp) || rn.lower < 0) { o.status = -1; continue; }
+        const FList lu = flist(av, fp, vectUp), ll = flist(av, fp, ftree(rn.lower));
+        const double curLK = append_walk(c, fref(lu), fref(ll), rn.isTip != 0, rn.dist);   // M:9646
+        o.currentLK = curLK;
+        if (!(curLK < P.thrPlacement || rn.dist != 0.0)) { o.status = 2; continue; }        // M:9674
+        S.parent = parent; S.sibling = childIdx == 0 ? rp.c1 : rp.c0;
+        S.isRemovedTip = rn.isTip; S.removedBLen = rn.dist; S.curLK = curLK;
+        S.hRpr0 = ftree(rn.lower);
+        // a search from a zero-length branch without an error model is a whole-tree search (see k_spr_search): dense tier
+        if (!U && budget > zeroBudget && rn.dist == 0.0) { S.state = FS_OVER; o.status = -5; continue; }
+        if (rp.up < 0) { S.state = FS_FALLBACK; continue; }                  // the parent is the root: rootVector (M:6916-6960)
+        if (shorten_would_merge(c, fref(ll), ll.n)) { S.state = FS_FALLBACK; continue; }   // M:7087 would edit the removed list
+        S.state = FS_ACTIVE;
+        const int pp = rp.up;
+        const NodeRec rpp = T.nd[pp];
+        const bool first = rpp.c0 == parent;
+        const NodeRec rs = T.nd[S.sibling];
+        const double d = rs.dist + rp.dist;
+        S.seed0 = fpush(fp, budget, q, true, pp, first ? 1 : 2, ftree(rs.lower), d, curLK, 0, S.hRpr0, curLK);
+        S.seed1 = fpush(fp, budget, q, true, S.sibling, 0, ftree(first ? rpp.upRight : rpp.upLeft), d, curLK, 0, S.hRpr0, curLK);
+    }
+}
+
+__global__ void k_fr_snap(FCtr *ctr)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ctr->loU = ctr->hiU; ctr->hiU = ctr->usedU;
+        ctr->loC = ctr->hiC; ctr->hiC = ctr->usedC;
+    }
+}
+
+// The permissive form of the reference's rules after an item was scored (M:7083-7103 / 7306-7323): failedPasses under
+// pathBest, the new pathBest, and whether the item's relatives are pushed.
+struct PRule { int fails; double pathBest; bool go; };
+__device__ __forceinline__ PRule p_rule(const SearchParams &P, bool scored, double midProb, double lastLK, int fails, double pathBest)
+{
+    PRule r;
+    r.fails = fails; r.pathBest = pathBest;
+    if (scored) {
+        if (midProb > pathBest) { r.pathBest = midProb; r.fails = 0; }
+        else if (midProb < (lastLK - P.thrConsec)) r.fails = fails + 1;
+    }
+    // (the reference tests against the running best AFTER it took this score into account: pathBest is updated first, too)
+    const bool within = midProb > (r.pathBest - P.thrLKtopology);
+    r.go = P.strict ? (r.fails <= P.allowedFails && within) : (r.fails <= P.allowedFails || within);
+    return r;
+}
+
+// ---- items that arrived with needsUpdating == True (M:6982-7091, 7182-7304): lists merged along the path ----------------
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, FPools fp, int budget)
+{
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    uint2 *sw = fp.sw + laneId * fp.capE;
+    double *sa = fp.sa + laneId * 5ll * fp.capE;
+    const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
+    for (long long i = lo + laneId; i < hi; i += (long long)gridDim.x * blockDim.x) {
+        FItem &it = fp.U[i];
+        FSearch &S = fp.S[it.q];
+        if (S.state != FS_ACTIVE) { it.flags |= FI_DEAD; continue; }
+        const int q = it.q, t1 = it.t1;
+        const NodeRec r1 = T.nd[t1];
+        const int hPassed = it.hPassed, hRpr = it.hRpr;
+        const double distance = it.distance, lastLK = it.lastLK;
+        const bool rt = S.isRemovedTip != 0;
+        const double rbl = S.removedBLen;
+        bool upd = true;
+        double midProb = lastLK;
+        Writer wr;
+        // merge two lists into the lane's scratch; -1 None, -2 fatal / no room
+        auto merge = [&](int h1, double b1, bool tp1, int h2, double b2, bool tp2, bool upDown) -> int {
+            if (!fvalid(h1) || !fvalid(h2)) return -2;
+            const FList l1 = flist(av, fp, h1), l2 = flist(av, fp, h2);
+            if (l1.n + l2.n > fp.capE) { S.state = FS_FALLBACK; return -2; }
+            wr.init(sw, sa);
+            const int r = merge_walk(c, fref(l1), b1, tp1, fref(l2), b2, tp2, upDown, false, 0, 0, wr, nullptr);
+            return r == -1 ? -1 : (r < 0 ? -2 : 0);
+        };
+        if (it.dir == 0) {                                                  // moving from a parent to its child, M:6982-7160
+            const int upT = r1.up;
+            const bool scored = !(upT == S.parent || upT < 0) && (r1.dist > P.effNon0 || r1.upIsRoot);
+            if (scored) {
+                if (merge(hPassed, distance / 2, false, ftree(r1.lower), distance / 2, r1.isTip != 0, true) != 0) { it.flags |= FI_DEAD; continue; }
+                const ListRef mid{sw, sa};
+                if (r1.totUp >= 0) { const FList tu = flist(av, fp, ftree(r1.totUp)); if (!differ_walk(c, mid, fref(tu))) upd = false; }
+                const FList lr = flist(av, fp, hRpr);
+                midProb = append_walk(c, mid, fref(lr), rt, rbl);
+                it.flags |= FI_SCORED;
+                if (upd && midProb >= it.pathBest - P.thrOptTopo) {          // may be short-listed (M:7071): keep the record's lists
+                    const int hm = fstore(fp, wr);
+                    if (hm < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; continue; }
+                    it.hA = hPassed; it.hB = ftree(r1.lower); it.hMid = hm; it.recDist = distance; it.flags |= FI_REC_UPD;
+                }
+            }
+            it.midProb = midProb;
+            if (upd) it.flags |= FI_UPD_OUT;
+            const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
+            if (pr.go && r1.c0 >= 0) {
+                for (int k = 0; k < 2; k++) {                               // child 0 uses vectUpRight, child 1 vectUpLeft
+                    const int ch = k == 0 ? r1.c0 : r1.c1, other = k == 0 ? r1.c1 : r1.c0;
+                    int ref = FR_NONE;
+                    if (upd) {
+                        const NodeRec ro = T.nd[other];
+                        const int r = merge(hPassed, distance, false, ftree(ro.lower), ro.dist, ro.isTip != 0, true);
+                        if (r == -2) { S.state = FS_FALLBACK; break; }
+                        if (r == 0) {
+                            const int hv = fstore(fp, wr);
+                            if (hv < 0) { S.state = FS_FALLBACK; break; }
+                            ref = fpush(fp, budget, q, true, ch, 0, hv, T.nd[ch].dist, midProb, pr.fails, hRpr, pr.pathBest);
+                        }
+                    } else if ((k == 0 ? r1.upRight : r1.upLeft) >= 0)
+                        ref = fpush(fp, budget, q, false, ch, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
+                    if (k == 0) it.child0 = ref; else it.child1 = ref;
+                }
+            }
+        } else {                                                             // crawling up from a child to its parent t1, M:7162-7434
+            const int other = (it.dir == 1) ? r1.c1 : r1.c0;
+            const int upT = r1.up;
+            const NodeRec ro = T.nd[other];
+            int hBottom = -1;
+            const int vectUp = upT >= 0 ? ftree(r1.whichChild ? T.nd[upT].upLeft : T.nd[upT].upRight) : -1;
+            const bool scored = upT >= 0 && (r1.dist > P.effNon0 || r1.upIsRoot);
+            if (scored) {
+                int r = merge(hPassed, distance, false, ftree(ro.lower), ro.dist, ro.isTip != 0, false);
+                if (r != 0) { it.flags |= FI_DEAD; continue; }
+                hBottom = fstore(fp, wr);
+                if (hBottom < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; continue; }
+                r = merge(vectUp, r1.dist / 2, false, hBottom, r1.dist / 2, false, true);
+                if (r != 0) { it.flags |= FI_DEAD; continue; }
+                const ListRef mid{sw, sa};
+                if (r1.totUp >= 0) { const FList tu = flist(av, fp, ftree(r1.totUp)); if (!differ_walk(c, mid, fref(tu))) upd = false; }
+                else {
+                    // "Node has no probVectTotUp ... calculating new one", M:7198-7200: compared with a list merged on the spot
+                    // (into the arena: the scratch holds midTot)
+                    S.state = FS_FALLBACK; it.flags |= FI_DEAD; continue;
+                }
+                const FList lr = flist(av, fp, hRpr);
+                midProb = append_walk(c, mid, fref(lr), rt, rbl);
+                it.flags |= FI_SCORED;
+                if (upd && midProb >= it.pathBest - P.thrOptTopo) {          // M:7293
+                    const int hm = fstore(fp, wr);
+                    if (hm < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; continue; }
+                    it.hA = vectUp; it.hB = hBottom; it.hMid = hm; it.recDist = r1.dist; it.flags |= FI_REC_UPD;
+                }
+            }
+            it.midProb = midProb;
+            if (upd) it.flags |= FI_UPD_OUT;
+            const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
+            if (!pr.go) continue;
+            if (upT >= 0) {
+                int hUp = -1;
+                if (upd) {
+                    const int r = merge(vectUp, r1.dist, false, hPassed, distance, false, true);
+                    if (r == -2) { S.state = FS_FALLBACK; continue; }
+                    if (r == 0) { hUp = fstore(fp, wr); if (hUp < 0) { S.state = FS_FALLBACK; continue; } }
+                } else hUp = ftree(it.dir == 1 ? r1.upLeft : r1.upRight);
+                if (!fvalid(hUp)) continue;
+                it.child0 = upd ? fpush(fp, budget, q, true, other, 0, hUp, ro.dist, midProb, pr.fails, hRpr, pr.pathBest)
+                                : fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
+                if (upd && hBottom < 0) {                                    // M:7376-7384
+                    const int r = merge(hPassed, distance, false, ftree(ro.lower), ro.dist, ro.isTip != 0, false);
+                    if (r != 0) continue;
+                    hBottom = fstore(fp, wr);
+                    if (hBottom < 0) { S.state = FS_FALLBACK; continue; }
+                }
+                it.child1 = upd ? fpush(fp, budget, q, true, upT, (int)r1.whichChild + 1, hBottom, r1.dist, midProb, pr.fails, hRpr, pr.pathBest)
+                                : fpush(fp, budget, q, false, upT, (int)r1.whichChild + 1, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
+            } else {                                                         // t1 is the root, M:7406-7432
+                if (upd) { S.state = FS_FALLBACK; continue; }               // rootVector of the passed list: one-lane search
+                it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
+            }
+        }
+    }
+}
+
+// ---- items in the cached regime (needsUpdating == False): appendProbNode(probVectTotUp[t1], removed list) ---------------
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, FPools fp, int budget)
+{
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const long long lo = (long long)fp.ctr->loC, hi = (long long)fp.ctr->hiC;
+    for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long long)gridDim.x * blockDim.x) {
+        FItem &it = fp.C[i];
+        FSearch &S = fp.S[it.q];
+        if (S.state != FS_ACTIVE) { it.flags |= FI_DEAD; continue; }
+        const int q = it.q, t1 = it.t1, hRpr = it.hRpr;
+        const NodeRec r1 = T.nd[t1];
+        const double lastLK = it.lastLK;
+        const int upT = r1.up;
+        double midProb = lastLK;
+        const bool scored = (it.dir == 0) ? (!(upT == S.parent || upT < 0) && (r1.dist > P.effNon0 || r1.upIsRoot))
+                                          : (upT >= 0 && (r1.dist > P.effNon0 || r1.upIsRoot));
+        if (scored) {
+            if (r1.totUp < 0) { it.flags |= FI_DEAD; continue; }
+            const FList lp = flist(av, fp, ftree(r1.totUp)), lr = flist(av, fp, hRpr);
+            midProb = append_walk(c, fref(lp), fref(lr), S.isRemovedTip != 0, S.removedBLen);
+            it.flags |= FI_SCORED;
+        }
+        it.midProb = midProb;
+        const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
+        if (!pr.go) continue;
+        if (it.dir == 0) {
+            if (r1.c0 < 0) continue;
+            if (r1.upRight >= 0) it.child0 = fpush(fp, budget, q, false, r1.c0, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
+            if (r1.upLeft >= 0) it.child1 = fpush(fp, budget, q, false, r1.c1, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
+        } else {
+            const int other = (it.dir == 1) ? r1.c1 : r1.c0;
+            if (upT >= 0) {
+                if (((it.dir == 1) ? r1.upLeft : r1.upRight) < 0) continue;
+                it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
+                it.child1 = fpush(fp, budget, q, false, upT, (int)r1.whichChild + 1, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
+            } else
+                it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
+        }
+    }
+}
+
+// ---- the reference's own walk over the expanded items: "while nodesToVisit", M:6964-7434, with the real running best ------
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, FPools fp, SearchOut *out)
+{
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        FSearch &S = fp.S[q];
+        if (S.state == FS_OVER) { out[q].status = -5; continue; }
+        if (S.state == FS_FALLBACK) { out[q].status = FR_STATUS_FALLBACK; continue; }
+        if (S.state != FS_ACTIVE) continue;
+        int top = FR_NONE;
+        auto push = [&](int ref, int fails) {
+            if (ref == FR_NONE) return;
+            FItem &x = item_of(fp, ref);
+            x.next = top; x.failsA = (int16_t)fails; top = ref;
+        };
+        push(S.seed0, 0);
+        push(S.seed1, 0);
+        double best = S.curLK;
+        int nApp = 0, slHead = FR_NONE, slTail = FR_NONE;
+        while (top != FR_NONE) {
+            const int ref = top;
+            FItem &it = item_of(fp, ref);
+            top = it.next;
+            if (it.flags & FI_DEAD) continue;
+            int fails = it.failsA;
+            const double mp = it.midProb;
+            if (it.flags & FI_SCORED) {
+                nApp++;
+                const bool list = (it.dir == 0) ? (mp > best - P.thrOptTopo) : (mp >= best - P.thrOptTopo);   // M:7071 / 7293
+                if (list) {
+                    it.next = FR_NONE;
+                    if (slTail == FR_NONE) slHead = ref; else item_of(fp, slTail).next = ref;
+                    slTail = ref;
+                }
+                if (mp > best) { best = mp; fails = 0; }
+                else if (mp < (it.lastLK - P.thrConsec)) fails++;
+            }
+            const bool within = mp > (best - P.thrLKtopology);
+            const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);
+            if (!go) continue;
+            push(it.child0, fails);
+            push(it.child1, fails);
+        }
+        S.slHead = slHead; S.nApp = nApp;
+        // the short-listed branches that are refined (M:7465: within thresholdLogLKoptimizationTopology of the ORIGINAL cost)
+        int cnt = 0;
+        for (int r = slHead; r != FR_NONE; r = item_of(fp, r).next)
+            if (item_of(fp, r).midProb >= S.curLK - P.thrOptTopo) cnt++;
+        const unsigned long long base = atomicAdd(&fp.ctr->nRecs, (unsigned long long)cnt);
+        if ((long long)(base + cnt) > fp.capRecs) { S.state = FS_FALLBACK; out[q].status = FR_STATUS_FALLBACK; fp.ctr->overflow = 1; continue; }
+        S.recBase = (int32_t)base; S.recCount = cnt;
+        int k = 0;
+        for (int r = slHead; r != FR_NONE; r = item_of(fp, r).next)
+            if (item_of(fp, r).midProb >= S.curLK - P.thrOptTopo) { FRec &x = fp.recs[base + k++]; x.q = q; x.ref = r; x.ok = 0; }
+    }
+}
+
+// ---- refinement of one short-listed branch, M:7460-7639 (evaluatePlacement M:6790-6806 and the two compensation appends) --
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_fr_refine(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, FPools fp)
+{
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    uint2 *sw = fp.sw + laneId * fp.capE;
+    double *sa = fp.sa + laneId * 5ll * fp.capE;
+    double *ais = fp.sais + laneId * 2ll * fp.capE;
+    const long long nRecs = (long long)fp.ctr->nRecs;
+    for (long long i = laneId; i < nRecs; i += (long long)gridDim.x * blockDim.x) {
+        FRec &R = fp.recs[i];
+        const FItem &it = item_of(fp, R.ref);
+        FSearch &S = fp.S[R.q];
+        R.ok = 0;
+        if (S.state != FS_ACTIVE) continue;
+        const int t1 = it.t1;
+        const NodeRec r1 = T.nd[t1];
+        int hUp, hDown, hMid;
+        double distance;
+        if (it.flags & FI_REC_UPD) { hUp = it.hA; hDown = it.hB; hMid = it.hMid; distance = it.recDist; }
+        else {
+            hUp = r1.up >= 0 ? ftree(r1.whichChild ? T.nd[r1.up].upLeft : T.nd[r1.up].upRight) : -1;
+            hDown = ftree(r1.lower); hMid = ftree(r1.totUp); distance = r1.dist;
+        }
+        if (!fvalid(hUp) || !fvalid(hDown) || !fvalid(hMid)) { R.ok = -1; continue; }
+        const FList lUp = flist(av, fp, hUp), lDown = flist(av, fp, hDown), lMid = flist(av, fp, hMid), lRem = flist(av, fp, it.hRpr);
+        const bool ft = r1.isTip != 0, rt = S.isRemovedTip != 0;
+        if (lMid.n + lRem.n > 2 * fp.capE || lUp.n + lDown.n + lRem.n > fp.capE) { S.state = FS_FALLBACK; continue; }
+        bool f;
+        Writer w;
+        const double app = blen_walk(c, fref(lMid), fref(lRem), rt, ais, 1, &f);
+        w.init(sw, sa);
+        int r = merge_walk(c, fref(lDown), distance / 2, ft, fref(lRem), app, rt, false, false, 0, 0, w, nullptr);
+        if (r < 0) { R.ok = -1; continue; }                                 // the reference fails here (caught by the worker)
+        const ListRef scr{sw, sa};
+        double top = blen_walk(c, fref(lUp), scr, false, ais, 1, &f);
+        w.init(sw, sa);
+        r = merge_walk(c, fref(lUp), top, false, fref(lRem), app, rt, true, false, 0, 0, w, nullptr);
+        if (r == -1) {
+            top = m.defaultBLen * 0.1;
+            w.init(sw, sa);
+            r = merge_walk(c, fref(lUp), top, false, fref(lRem), app, rt, true, false, 0, 0, w, nullptr);
+        }
+        if (r < 0) { R.ok = -1; continue; }
+        const double bottom = blen_walk(c, scr, fref(lDown), ft, ais, 1, &f);
+        w.init(sw, sa);
+        r = merge_walk(c, fref(lUp), top, false, fref(lDown), bottom, ft, true, false, 0, 0, w, nullptr);
+        if (r < 0) { R.ok = -1; continue; }
+        const double cost = append_walk(c, scr, fref(lRem), rt, app);
+        const double initialCost = append_walk(c, fref(lUp), fref(lDown), ft, distance);
+        const double newPartialCost = append_walk(c, fref(lUp), fref(lDown), ft, bottom + top);
+        R.optimized = cost + newPartialCost - initialCost;
+        R.top = top; R.bottom = bottom; R.app = app;
+        R.ok = 1;
+    }
+}
+
+// ---- final selection (M:7635), the worker's accept rule and vetoes (M:9681-9700), bestRemovedPartials --------------------
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_finish(ArenaViewS av, DevTree T, SearchParams P, int n, FPools fp, SearchOut *out,
+                                                        uint2 *poolW, double *poolA, unsigned long long *poolUsed, long long poolCapW,
+                                                        long long poolCapA)
+{
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        FSearch &S = fp.S[q];
+        SearchOut &o = out[q];
+        if (S.state == FS_FALLBACK) { o.status = FR_STATUS_FALLBACK; continue; }
+        if (S.state != FS_ACTIVE) continue;
+        const int node = S.node;
+        const NodeRec rp = T.nd[S.parent];
+        double bestScore = S.curLK;
+        int bestNode = S.sibling, hBestRpr = S.hRpr0, nApp = S.nApp;
+        double bl0 = rp.dist, bl1 = T.nd[S.sibling].dist, bl2 = S.removedBLen;
+        bool failed = false;
+        for (int k = 0; k < S.recCount; k++) {
+            const FRec &R = fp.recs[S.recBase + k];
+            if (R.ok != 1) { failed = true; break; }
+            nApp += 3;
+            if (R.optimized >= bestScore) {
+                const FItem &it = item_of(fp, R.ref);
+                bestNode = it.t1; bestScore = R.optimized; bl0 = R.top; bl1 = R.bottom; bl2 = R.app; hBestRpr = it.hRpr;
+            }
+        }
+        o.nAppend = nApp;
+        o.nShortList = S.recCount;
+        if (failed) { o.status = -1; continue; }                            // the reference raises here; its worker swallows it (M:9703)
+        o.bestNode = bestNode; o.bestScore = bestScore;
+        o.blen[0] = bl0; o.blen[1] = bl1; o.blen[2] = bl2;
+        if (poolW) {
+            const FList rp2 = flist(av, fp, hBestRpr);
+            const long long ow = (long long)atomicAdd(&poolUsed[0], (unsigned long long)rp2.n);
+            const long long oa = (long long)atomicAdd(&poolUsed[1], (unsigned long long)rp2.na);
+            if (ow + rp2.n <= poolCapW && oa + rp2.na <= poolCapA) {
+                for (int k = 0; k < rp2.n; k++) poolW[ow + k] = rp2.w[k];
+                for (int k = 0; k < rp2.na; k++) poolA[oa + k] = rp2.aux[k];
+                o.rprWoff = ow; o.rprAoff = oa; o.rprN = rp2.n; o.rprNA = rp2.na;
+            } else o.status = -4;
+        }
+        const double curLK = S.curLK;
+        if (bestScore + P.thrPlacement > curLK) {
+            bool updated = true;
+            int topNode = T.nd[node].up;
+            if (bestNode == topNode) updated = false;
+            while (T.nd[topNode].dist == 0.0 && T.nd[topNode].up >= 0) topNode = T.nd[topNode].up;
+            if (bestNode == topNode && bl1 == 0.0) updated = false;
+            if (bestNode == S.sibling) updated = false;
+            if (T.nd[bestNode].up == S.sibling && bl0 == 0.0) updated = false;
+            if (updated) { o.improvement = bestScore - curLK; o.placement = bestNode; }
+        }
+    }
+}
+
+struct FrontierScratch {
+    DevBuf<uint8_t> itemsU, itemsC, srch, recs, ctr;
+    DevBuf<uint2> tw, sw;
+    DevBuf<double> ta, sa, sais;
+    DevBuf<long long> toffW, toffA;
+    DevBuf<int32_t> tn, tna, nodes;
+    DevBuf<uint8_t> out;
+};
+
+}  // namespace
+
+void frontier_scratch_free(maple_ctx *c)
+{
+    FrontierScratch *F = (FrontierScratch *)c->frontier;
+    if (!F) return;
+    F->itemsU.release(); F->itemsC.release(); F->srch.release(); F->recs.release(); F->ctr.release();
+    F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release();
+    F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
+    delete F;
+    c->frontier = nullptr;
+}
+
+#define FR_DISPATCH3(c, KERNEL, ...)                                                                       \
+    do {                                                                                                  \
+        const bool rv_ = (c)->dm.useRateVariation, u_ = (c)->dm.usingErrorRate, ss_ = (c)->dm.errorRateSiteSpecific; \
+        if (!rv_ && !u_) KERNEL<false, false, false> __VA_ARGS__;                                          \
+        else if (rv_ && !u_) KERNEL<true, false, false> __VA_ARGS__;                                       \
+        else if (!rv_ && u_ && !ss_) KERNEL<false, true, false> __VA_ARGS__;                               \
+        else if (!rv_ && u_ && ss_) KERNEL<false, true, true> __VA_ARGS__;                                 \
+        else if (rv_ && u_ && !ss_) KERNEL<true, true, false> __VA_ARGS__;                                 \
+        else KERNEL<true, true, true> __VA_ARGS__;                                                         \
+    } while (0)
+
+// Runs the searches nodes[0..m) through the frontier tier; out[k] as k_spr_search leaves it: status 0 / 1 / 2 / -1 final,
+// -5 = over `budget` expanded items (dense tier), FR_STATUS_FALLBACK = hand to the one-lane-per-search kernel.
+int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *nodes, int budget, int zeroBudget, SearchOut *hostOut,
+                    uint2 *poolW, double *poolA, unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
+                    FrontierStats *stats)
+{
+    if (!c->frontier) c->frontier = new FrontierScratch();
+    FrontierScratch &F = *(FrontierScratch *)c->frontier;
+    if (budget < 1) budget = 1 << 30;
+    // pools, sized for the batch and bounded by what the device has free
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t)8 << 30;
+    const size_t held = F.itemsU.cap + F.itemsC.cap + F.tw.cap * sizeof(uint2) + F.ta.cap * sizeof(double)
+                        + F.sw.cap * sizeof(uint2) + F.sa.cap * sizeof(double) + F.sais.cap * sizeof(double);
+    const double room = 0.5 * (double)(freeB + held);
+    const long long perSearchC = std::min<long long>(budget, 512);
+    long long capC = std::max<long long>(1 << 16, (long long)m * perSearchC);
+    long long capU = std::max<long long>(1 << 14, (long long)m * std::min<long long>(budget, 24));
+    const long long meanEnt = std::max(16, c->tree_max_ent / 4);
+    long long capL = 3 * capU;
+    long long capW = capL * meanEnt, capA = 2 * capW;
+    const int capE = std::max(1024, 4 * c->tree_max_ent);
+    const int gridUpd = 256;                                              // lanes with scratch: 256 x 256
+    const long long scratchLanes = (long long)gridUpd * FR_BLOCK;
+    {   // shrink the pools proportionally if they would not fit
+        const double need = (double)capC * sizeof(FItem) + (double)capU * sizeof(FItem) + (double)capW * 8 + (double)capA * 8
+                            + (double)capL * 24 + (double)scratchLanes * capE * (8 + 40 + 16);
+        if (need > room) {
+            const double f = std::max(0.05, (room - (double)scratchLanes * capE * 64) / (need - (double)scratchLanes * capE * 64));
+            capC = std::max<long long>(1 << 16, (long long)(capC * f)); capU = std::max<long long>(1 << 14, (long long)(capU * f));
+            capL = 3 * capU; capW = capL * meanEnt; capA = 2 * capW;
+        }
+    }
+    const long long capRecs = std::max<long long>(1 << 14, (long long)m * 16);
+    auto grow = [](size_t want, size_t cap) { return want <= cap ? cap : std::max(want, cap + cap / 2); };
+    HIPCK(c, F.itemsU.reserve_exact(grow((size_t)capU * sizeof(FItem), F.itemsU.cap)));
+    HIPCK(c, F.itemsC.reserve_exact(grow((size_t)capC * sizeof(FItem), F.itemsC.cap)));
+    HIPCK(c, F.srch.reserve((size_t)m * sizeof(FSearch)));
+    HIPCK(c, F.recs.reserve_exact(grow((size_t)capRecs * sizeof(FRec), F.recs.cap)));
+    HIPCK(c, F.ctr.reserve(sizeof(FCtr)));
+    HIPCK(c, F.tw.reserve_exact(grow((size_t)capW, F.tw.cap)));
+    HIPCK(c, F.ta.reserve_exact(grow((size_t)capA, F.ta.cap)));
+    HIPCK(c, F.toffW.reserve_exact(grow((size_t)capL, F.toffW.cap)));
+    HIPCK(c, F.toffA.reserve_exact(grow((size_t)capL, F.toffA.cap)));
+    HIPCK(c, F.tn.reserve_exact(grow((size_t)capL, F.tn.cap)));
+    HIPCK(c, F.tna.reserve_exact(grow((size_t)capL, F.tna.cap)));
+    HIPCK(c, F.sw.reserve_exact((size_t)scratchLanes * capE));
+    HIPCK(c, F.sa.reserve_exact((size_t)scratchLanes * capE * 5));
+    HIPCK(c, F.sais.reserve_exact((size_t)scratchLanes * capE * 2));
+    HIPCK(c, F.nodes.reserve((size_t)m));
+    HIPCK(c, F.out.reserve((size_t)m * sizeof(SearchOut)));
+    FPools fp;
+    fp.U = (FItem *)F.itemsU.p; fp.C = (FItem *)F.itemsC.p;
+    fp.capU = (long long)(F.itemsU.cap / sizeof(FItem)); fp.capC = (long long)(F.itemsC.cap / sizeof(FItem));
+    fp.tw = F.tw.p; fp.ta = F.ta.p; fp.toffW = F.toffW.p; fp.toffA = F.toffA.p; fp.tn = F.tn.p; fp.tna = F.tna.p;
+    fp.capW = (long long)F.tw.cap; fp.capA = (long long)F.ta.cap;
+    fp.capL = (long long)std::min(std::min(F.toffW.cap, F.toffA.cap), std::min(F.tn.cap, F.tna.cap));
+    fp.sw = F.sw.p; fp.sa = F.sa.p; fp.sais = F.sais.p; fp.capE = capE;
+    fp.ctr = (FCtr *)F.ctr.p; fp.S = (FSearch *)F.srch.p; fp.recs = (FRec *)F.recs.p;
+    fp.capRecs = (long long)(F.recs.cap / sizeof(FRec));
+    hipStream_t s = c->stream;
+    HIPCK(c, hipMemsetAsync(fp.ctr, 0, sizeof(FCtr), s));
+    HIPCK(c, hipMemcpyAsync(F.nodes.p, nodes, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    SearchOut *dout = (SearchOut *)F.out.p;
+    DevTree T = c->dtree;
+    const ArenaViewS av = view(c);
+    const int gridN = std::max(1, std::min(2048, (m + FR_BLOCK - 1) / FR_BLOCK));
+    hipEvent_t e0, e1, er0, er1;
+    TRY(maple_internal_ev_pair(c, &e0, &e1, MAPLE_K_SPR_SEARCH, (double)m, 0.0));
+    const size_t slotEv = c->ev_used / 2 - 1;
+    HIPCK(c, hipEventRecord(e0, s));
+    FR_DISPATCH3(c, k_fr_begin, <<<gridN, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, m, F.nodes.p, fp, dout, budget, zeroBudget));
+    HIPCK(c, hipGetLastError());
+    // level loop: the counters stay on the device; the host looks at them every few levels
+    FCtr hc;
+    std::memset(&hc, 0, sizeof hc);
+    int levels = 0;
+    const int gridCached = 2048;
+    for (;;) {
+        for (int g = 0; g < 8; g++) {
+            k_fr_snap<<<1, 64, 0, s>>>(fp.ctr);
+            FR_DISPATCH3(c, k_fr_updating, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget));
+            FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget));
+            levels++;
+        }
+        k_fr_snap<<<1, 64, 0, s>>>(fp.ctr);
+        HIPCK(c, hipGetLastError());
+        HIPCK(c, hipMemcpyAsync(&hc, fp.ctr, sizeof(FCtr), hipMemcpyDeviceToHost, s));
+        HIPCK(c, hipStreamSynchronize(s));
+        if (hc.hiU == hc.loU && hc.hiC == hc.loC) break;
+        // (the snap above opened the next level: the loop's first snap would skip it -- undo by running its kernels first)
+        FR_DISPATCH3(c, k_fr_updating, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget));
+        FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget));
+        levels++;
+        if (levels > 100000) return fail(c, MAPLE_ERR_FATAL, "frontier search did not terminate");
+    }
+    TRY(maple_internal_ev_pair(c, &er0, &er1, MAPLE_K_OTHER, 0.0, 0.0));
+    HIPCK(c, hipEventRecord(er0, s));
+    k_fr_replay<<<gridN, FR_BLOCK, 0, s>>>(P, m, fp, dout);
+    FR_DISPATCH3(c, k_fr_refine, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, fp));
+    k_fr_finish<<<gridN, FR_BLOCK, 0, s>>>(av, T, P, m, fp, dout, poolW, poolA, poolUsed, poolCapW, poolCapA);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipEventRecord(er1, s));
+    HIPCK(c, hipEventRecord(e1, s));
+    HIPCK(c, hipMemcpyAsync(hostOut, dout, (size_t)m * sizeof(SearchOut), hipMemcpyDeviceToHost, s));
+    HIPCK(c, hipMemcpyAsync(&hc, fp.ctr, sizeof(FCtr), hipMemcpyDeviceToHost, s));
+    HIPCK(c, hipStreamSynchronize(s));
+    {   // what this tier did, for maple_timing_read_kind: candidate placements of the searches it finished (SURVEY 8d bytes)
+        const double meanCand = c->n_scored ? c->scored_bytes_total / c->n_scored : 0.0;
+        double units = 0.0, bytes = 0.0;
+        for (int k = 0; k < m; k++) {
+            if (hostOut[k].status != 0 && hostOut[k].status != -1) continue;
+            units += hostOut[k].nAppend;
+            const int32_t l = c->h_tree_lower[nodes[k]];
+            bytes += meanCand * hostOut[k].nAppend + (l >= 0 ? 8.0 * c->h_n_ent[l] + 8.0 * c->h_n_aux[l] : 0.0);
+        }
+        c->ev_units[slotEv] = units; c->ev_bytes[slotEv] = bytes;
+    }
+    if (stats) {
+        stats->levels = levels; stats->itemsUpdating = (long long)hc.usedU; stats->itemsCached = (long long)hc.usedC;
+        stats->tempLists = (long long)hc.nLists; stats->tempWords = (long long)hc.usedW; stats->tempAux = (long long)hc.usedA;
+        stats->records = (long long)hc.nRecs; stats->overflow = hc.overflow;
+    }
+    return MAPLE_OK;
+}

@@ -34,213 +34,8 @@ struct RcclApi {
 };
 static RcclApi g_rccl{};
 
-// =================================================================================================
-// context
-// =================================================================================================
-typedef maple::ArenaViewS ArenaView;   // {words, aux, ent_off[], aux_off[], n_ent[], n_aux[]} per list
-typedef maple::MutViewS MutView;       // {mut3, off[], cnt[]} per mutation list
-
-template <class T> struct DevBuf {     // grow-only device scratch
-    T *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t n)
-    {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        size_t want = n + n / 2 + 64;
-        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
-        cap = (e == hipSuccess) ? want : 0;
-        return e;
-    }
-    hipError_t reserve_exact(size_t n)     // for the very large buffers: no growth margin
-    {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
-        cap = (e == hipSuccess) ? n : 0;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-struct PinBuf {                          // grow-only page-locked host scratch (a D2H copy into pageable memory is staged
-    void *p = nullptr;                  // by the runtime at a few GB/s: 0.3 ms for the 1.6 MB of one query's scores)
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        const size_t want = bytes + bytes / 2 + 4096;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-        cap = (e == hipSuccess) ? want : 0;
-        return e;
-    }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-};
-
-struct PlaceMeta {                     // derived from the uploaded tree, rebuilt when it or effectivelyNon0BLen changes
-    bool valid = false;
-    double effNon0 = -1.0;
-    int32_t nF = 0, maxDepth = 0;
-    std::vector<int32_t> frameOf;                  // per node
-    std::vector<int32_t> frameNode, frameParent;   // per frame (frame 0 = the root's reference, node -1)
-    std::vector<int32_t> levelStart;               // frames 1.. sorted by nesting depth; level l = [levelStart[l], levelStart[l+1])
-    std::vector<int32_t> cand, leaves;             // node ids
-    std::vector<int32_t> order;                    // nodes reachable from the root, depth-first
-    int32_t rootVect = -1;                         // rootVector(probVect[root]) of the uploaded tree (list id), kept while it lives
-    std::vector<int32_t> h_candIdx, h_leafIdx;     // per node: column in the score / minor matrix or -1
-    std::vector<int32_t> h_candList, h_candFrame, h_leafList, h_leafFrame;   // host copies of the column arrays (maple_tree_patch)
-    bool scanStale = false;                        // the tree changed through maple_tree_patch: h_scan / d_scan / order are old
-    std::vector<ScanRec> h_scan;                   // the tree in traversal order (placement_dev.h)
-    DevBuf<ScanRec> d_scan;
-    DevBuf<int32_t> d_frameOf, d_candIdx, d_leafIdx, d_candList, d_candFrame, d_leafList, d_leafFrame;
-};
-
-struct maple_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;     // side stream: the dense scoring of the searches known to be whole-tree ones runs next to
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the lane searches of the others (maple_spr_search_batch)
-    DevBuf<int32_t> z_ql;
-    DevBuf<uint8_t> z_qt;
-    DevBuf<double> z_qb;
-    std::vector<hipEvent_t> evs;       // pairs (start, stop) of timed *_dev launches since the last reset
-    size_t ev_used = 0;
-    // what each timed launch was: kind (MAPLE_K_*), units of work (pairs scored / searches run) and the algorithmic
-    // bytes of SURVEY 8d for the scoring kernels
-    std::vector<int32_t> ev_kind;
-    std::vector<double> ev_units, ev_bytes;
-    std::vector<double> cand_bytes_prefix;       // per scored column of the uploaded tree: 8E + 8A + 8, summed (host)
-    double scored_bytes_total = 0.0;
-    std::string err;
-    maple_params params{};
-    int32_t lRef = 0;
-    std::vector<uint8_t> refIdx;
-    DevModel dm{};                     // device pointers inside
-    DevModel *d_model = nullptr;       // the same struct in device memory: what the kernels read
-    bool model_set = false;
-    double *d_siteRates = nullptr, *d_errorRates = nullptr, *d_cumRate = nullptr, *d_cumErr = nullptr;
-    int32_t *d_cumBases = nullptr;
-    double *d_rflec = nullptr;
-    std::vector<double> h_cumRate, h_cumErr;
-    // list arena
-    uint2 *d_words = nullptr;
-    double *d_aux = nullptr;
-    int64_t cap_ent = 0, cap_aux = 0, cap_lists = 0;
-    int64_t used_ent = 0, used_aux = 0;
-    int64_t *d_ent_off = nullptr, *d_aux_off = nullptr;
-    int32_t *d_n_ent = nullptr, *d_n_aux = nullptr;
-    std::vector<int64_t> h_ent_off, h_aux_off;
-    std::vector<int32_t> h_n_ent, h_n_aux;
-    // mutation lists
-    int32_t *d_mut3 = nullptr;
-    int64_t *d_mut_off = nullptr;
-    int32_t *d_mut_cnt = nullptr;
-    int64_t cap_mut = 0, used_mut = 0, cap_mut_lists = 0;
-    std::vector<int64_t> h_mut_off;
-    std::vector<int32_t> h_mut_cnt;
-    // staging / scratch
-    DevBuf<int32_t> s_i32[8];
-    DevBuf<double> s_f64[4];
-    DevBuf<uint8_t> s_u8[4];
-    DevBuf<int64_t> s_i64[6];
-    DevBuf<uint2> s_words, s_pool_w;
-    DevBuf<double> s_aux, s_pool_a;
-    DevBuf<double> s_ais;
-    // tree mirror (topology + list ids), maple_tree_upload
-    DevTree dtree{};
-    bool tree_set = false;
-    DevBuf<int32_t> t_i32[9];
-    DevBuf<double> t_dist;
-    DevBuf<uint8_t> t_tip;
-    DevBuf<uint8_t> t_nodes;           // NodeRec[n], 64-byte aligned
-    std::vector<int32_t> h_tree_up, h_tree_lower;
-    std::vector<double> h_tree_dist;
-    std::vector<uint8_t> h_tree_tip;
-    bool tree_has_mut = false;
-    int32_t tree_max_ent = 0;          // longest genome list of the uploaded tree (entries)
-    int32_t n_scored = 0;              // nodes with a probVectTotUp, sorted by list length: t_i32[8] = list ids, t_scored_col = node ids
-    DevBuf<int32_t> t_scored_col, t_scored_frame;
-    DevBuf<int4> t_frame_chunks;       // trees with local references: the scored candidates in chunks of <= 64 within one frame
-    int32_t n_frame_chunks = 0;
-    DevBuf<uint8_t> s_tilebest;        // (query, 64-candidate tile) records of maple_append_queries_argmax_dev
-    void *rccl_lib = nullptr;          // RCCL, loaded on first use (maple_comm_*)
-    void *rccl_comm = nullptr;
-    int rccl_world = 1, rccl_rank = 0;
-    DevBuf<unsigned long long> s_comm_u64;
-    DevBuf<long long> s_fan[6];        // per (query, frame) item of a nesting level: capacities, offsets, sizes (k_fan_*)
-    DevBuf<uint8_t> s_fan_tmp;
-    DevBuf<SScan> t_scan;              // the tree in the searches' depth-first order (search_dev.h), per effectivelyNon0BLen
-    DevBuf<int32_t> t_scan_parent;
-    bool scan_valid = false;
-    double scan_eff = -1.0;
-    std::vector<int32_t> h_depth;      // per node: distance from the root in branches
-    int32_t tree_max_depth = 0;
-    // SPR search workspace
-    DevBuf<uint8_t> s_search_ws;
-    DevBuf<uint8_t> s_search_out;
-    DevBuf<int32_t> s_counter;
-    DevBuf<double> s_cache;            // cached (query x node) scores of wide searches
-    struct CandSet { int32_t n = 0, nFrames = 0; int32_t *lists = nullptr, *frame = nullptr; };
-    std::vector<CandSet> candsets;     // resident candidate sets (maple_candset_create)
-    // batched placement (maple_placement_search_batch)
-    PlaceMeta *place = nullptr;
-    std::vector<int32_t> h_tree_c0, h_tree_c1, h_tree_mut, h_tree_totUp, h_tree_upRight, h_tree_upLeft;
-    std::vector<NodeRec> h_nodes;      // host copy of the node records (host-side traversal of tiny placement batches)
-    DevBuf<int32_t> p_i32[4];
-    DevBuf<double> p_f64[2], p_score;
-    PinBuf pin_place;                   // single-query placement: scores and minor-sequence flags on their way to the host
-    PinBuf pin_res;                     // small per-launch results (a copy into pageable memory costs an extra ~10 us)
-    DevBuf<int16_t> p_i16;
-    DevBuf<uint8_t> p_u8, p_minor;
-    int32_t *d_tile_counters = nullptr;    // ring of tile counters for the dynamically scheduled kernels
-    int tile_counter_next = 0;
-    void *upd = nullptr;               // UpdateScratch of maple_update_partials (update_host.h)
-    bool tree_stale = false;           // maple_tree_patch changed the host copy of the tree; the device tables of the SPR search
-                                       // (and, for batches, of the placement search) are rebuilt from it before their next use
-    // Staging of the small per-call argument columns of the batch operators: they are gathered in pinned host memory and go
-    // to the device in ONE copy per call (a dozen separate copies from pageable memory cost ~0.2 ms per call, most of a
-    // single-change updatePartials).  Two arenas used in turn: see stage_begin.
-    uint8_t *stg_h[2] = {nullptr, nullptr}, *stg_d[2] = {nullptr, nullptr};
-    size_t stg_cap[2] = {0, 0}, stg_used = 0, stg_flushed = 0;
-    int stg_cur = 0;
-    bool commit_pending = false;       // commit_lists left its copy kernel running on `stream`: entry points that launch on a
-                                       // caller's stream wait for it first (settle)
-    bool tolerate_fatal = false;       // maple_set_fatal_policy
-    int trace_query = -1;
-    DevBuf<int32_t> s_trace_i;
-    DevBuf<double> s_trace_d;
-};
-
-enum { MAPLE_K_OTHER = 0, MAPLE_K_SPR_SCORE = 1, MAPLE_K_SPR_SEARCH = 2, MAPLE_K_SPR_REPLAY = 3, MAPLE_K_APPEND_QUERIES = 4,
-       MAPLE_K_APPEND_PAIRS = 5, MAPLE_K_PLACE_SCORE = 6 };
-
-static int fail(maple_ctx *c, int code, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (c) c->err = buf;
-    return code;
-}
-#define HIPCK(c, call)                                                                       \
-    do {                                                                                     \
-        hipError_t e_ = (call);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            return fail((c), MAPLE_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
-    } while (0)
-
-static ArenaView view(const maple_ctx *c) { return ArenaView{c->d_words, c->d_aux, c->d_ent_off, c->d_aux_off, c->d_n_ent, c->d_n_aux}; }
-static MutView mview(const maple_ctx *c) { return MutView{c->d_mut3, c->d_mut_off, c->d_mut_cnt}; }
-
-__device__ inline ListRef list_ref(const ArenaView &a, int id)
-{
-    return ListRef{a.words + a.ent_off[id], a.aux + a.aux_off[id]};
-}
+#include "ctx_host.h"
+#include "frontier.h"
 
 // =================================================================================================
 // kernels
@@ -1442,6 +1237,7 @@ extern "C" int maple_destroy(maple_ctx *c)
 {
     if (!c) return MAPLE_OK;
     update_scratch_free(c);
+    frontier_scratch_free(c);
     for (int k = 0; k < 2; k++) { if (c->stg_h[k]) (void)hipHostFree(c->stg_h[k]); if (c->stg_d[k]) (void)hipFree(c->stg_d[k]); }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -1725,7 +1521,10 @@ extern "C" int maple_mutations_upload(maple_ctx *c, int32_t n, const int64_t *of
 }
 
 // ---- helpers for batch calls -----------------------------------------------------------------------
-static int ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b, int kind, double units, double bytes);
+static inline int ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b, int kind = 0, double units = 0.0, double bytes = 0.0)
+{
+    return maple_internal_ev_pair(c, a, b, kind, units, bytes);
+}
 
 template <class T> static int h2d(maple_ctx *c, DevBuf<T> &b, const T *src, size_t n)
 {
@@ -1733,7 +1532,6 @@ template <class T> static int h2d(maple_ctx *c, DevBuf<T> &b, const T *src, size
     if (n) HIPCK(c, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
     return MAPLE_OK;
 }
-#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
 // Start staging the arguments of one batch call (at most `bytes` of them).  The two arenas alternate from call to call:
 // every batch operator synchronises its stream at least once after its first stage_flush, so by the time an arena comes
@@ -2288,7 +2086,7 @@ extern "C" int maple_evaluate_placement_batch(maple_ctx *c, int32_t n, const int
 }
 
 // ---- device-resident forms ---------------------------------------------------------------------------
-static int ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b, int kind = 0, double units = 0.0, double bytes = 0.0)
+int maple_internal_ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b, int kind, double units, double bytes)
 {
     if (c->ev_used >= 8192) c->ev_used = 0;       // nobody is reading these timings: recycle the event pairs
     const size_t slot = c->ev_used / 2;
@@ -3200,17 +2998,30 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         for (int i = 0; i < nT; i++) byRank[c->h_nodes[i].preRank] = i;
         std::vector<SScan> sc((size_t)nT);
         std::vector<int32_t> size(nT, 1), depth(nT, 0);
+        // Node slots the root does not reach (a tree read from a file keeps the slots of collapsed nodes, their `up` still
+        // naming a live node) rank behind every reachable node and belong to no clade: counted into their stale parent's
+        // clade they made the scan of that parent -- and of every ancestor -- run past the clade's end.
+        std::vector<uint8_t> reach(nT, 0);
+        {
+            std::vector<int32_t> stk{c->dtree.root};
+            while (!stk.empty()) {
+                const int v = stk.back();
+                stk.pop_back();
+                reach[v] = 1;
+                if (c->h_tree_c0[v] >= 0) { stk.push_back(c->h_tree_c0[v]); stk.push_back(c->h_tree_c1[v]); }
+            }
+        }
         int32_t maxDepth = 0;
         for (int r = 0; r < nT; r++) {                                      // parents precede their clades in rank order
             const int v = byRank[r];
             const int u = c->h_tree_up[v];
-            if (u >= 0 && v != c->dtree.root && c->h_nodes[u].preRank < r) depth[v] = depth[u] + 1;
+            if (reach[v] && u >= 0 && v != c->dtree.root && c->h_nodes[u].preRank < r) depth[v] = depth[u] + 1;
             maxDepth = std::max(maxDepth, depth[v]);
         }
         for (int r = nT - 1; r >= 0; r--) {
             const int v = byRank[r];
             const int u = c->h_tree_up[v];
-            if (u >= 0 && v != c->dtree.root && c->h_nodes[u].preRank < r) size[u] += size[v];
+            if (reach[v] && u >= 0 && v != c->dtree.root && c->h_nodes[u].preRank < r) size[u] += size[v];
         }
         for (int r = 0; r < nT; r++) {
             const int v = byRank[r];
@@ -3303,7 +3114,29 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: %d searches from zero-length branches to be scored on the side stream\n", tms(tStart, tnow()), mZ);
         }
     }
-    TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
+    // Frontier tier (frontier.hip): every search of the batch expanded level by level, one lane per (search, branch) item,
+    // then replayed exactly -- for trees without MAT local references.  What it hands back (a search that would edit its
+    // removed list in place, touches the root while still updating lists, or overflows a pool) runs one lane per search.
+    const bool useFrontier = sp->searchTier == 0 && !c->tree_has_mut && c->trace_query < 0;
+    if (useFrontier) {
+        if (afterLaunch) { std::function<int()> f; f.swap(afterLaunch); TRY(f()); }   // (the side-stream scoring starts alongside)
+        std::vector<SearchOut> part(n);
+        FrontierStats fs;
+        TRY(frontier_search(c, P, n, todo.data(), hybrid ? wideBudget : 0, (hybrid && wideBudget > MAPLE_ZERO_DIST_BUDGET) ? MAPLE_ZERO_DIST_BUDGET : (1 << 30),
+                            part.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs));
+        std::vector<int32_t> todoFb, slotFb;
+        for (int i = 0; i < n; i++) {
+            ho[i] = part[i];
+            if (part[i].status == FR_STATUS_FALLBACK) { todoFb.push_back(todo[i]); slotFb.push_back(i); }
+        }
+        if (dbgT)
+            fprintf(stderr, "[maple] t=%.1f ms: frontier tier done: %d levels, %lld updating + %lld cached items, %lld temporary lists "
+                            "(%lld words, %lld aux), %lld refined records, %zu searches handed back%s\n", tms(tStart, tnow()), fs.levels,
+                    fs.itemsUpdating, fs.itemsCached, fs.tempLists, fs.tempWords, fs.tempAux, fs.records, todoFb.size(),
+                    fs.overflow ? " (a pool overflowed)" : "");
+        if (!todoFb.empty()) TRY(run_queries(todoFb, slotFb, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
+    } else
+        TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
     if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: budgeted pass done\n", tms(tStart, tnow()));
     if (hybrid) {
         std::vector<int32_t> wide;

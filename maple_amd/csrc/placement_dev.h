@@ -140,7 +140,7 @@ __host__ __device__ inline void place_replay_one(const ScanRec *R, int nReach, c
     o.nAppend[q] = nAppend; o.missed[q] = missed; o.nShort[q] = nSl;
 }
 
-__global__ __launch_bounds__(64) void k_place_replay(const ScanRec *__restrict__ R, int nReach, PlaceParams P, int nQ, int nCols,
+static __global__ __launch_bounds__(64) void k_place_replay(const ScanRec *__restrict__ R, int nReach, PlaceParams P, int nQ, int nCols,
                                                      int rootCol, const double *__restrict__ score, int nLeaf,
                                                      const uint8_t *__restrict__ minor, const int32_t *__restrict__ frameOf,
                                                      int nF, int stateCap, double *stLK, int16_t *stFails, uint32_t *frameBits,

@@ -39,7 +39,7 @@ class MapleSearchParams(C.Structure):
     _fields_ = [("strictTopologyStopRules", C.c_int32), ("allowedFailsTopology", C.c_int32),
                 ("thresholdLogLKtopology", C.c_double), ("thresholdTopologyPlacement", C.c_double),
                 ("thresholdLogLKoptimizationTopology", C.c_double), ("thresholdLogLKconsecutivePlacement", C.c_double),
-                ("effectivelyNon0BLen", C.c_double), ("wideSearchBudget", C.c_int32)]
+                ("effectivelyNon0BLen", C.c_double), ("wideSearchBudget", C.c_int32), ("searchTier", C.c_int32)]
 
 
 class MaplePlacementParams(C.Structure):
@@ -395,13 +395,13 @@ class Device:
 
     def spr_search_batch(self, nodes, *, strict, allowedFails, thresholdLogLKtopology, thresholdTopologyPlacement,
                          thresholdLogLKoptimizationTopology, thresholdLogLKconsecutivePlacement, effectivelyNon0BLen,
-                         ws_entries_per_lane=0, want_removed_partials=False, wide_search_budget=0):
+                         ws_entries_per_lane=0, want_removed_partials=False, wide_search_budget=0, search_tier=0):
         """startTopologyUpdatesParallel's worker body (M:9615-9711) for `nodes`, searches run on the GPU."""
         nodes = _i32(nodes)
         n = len(nodes)
         sp = MapleSearchParams(int(bool(strict)), int(allowedFails), thresholdLogLKtopology, thresholdTopologyPlacement,
                                thresholdLogLKoptimizationTopology, thresholdLogLKconsecutivePlacement,
-                               effectivelyNon0BLen, int(wide_search_budget))
+                               effectivelyNon0BLen, int(wide_search_budget), int(search_tier))
         out = dict(bestNode=np.zeros(n, np.int32), bestScore=np.zeros(n), blen=np.zeros((n, 3)),
                    placement=np.zeros(n, np.int32), improvement=np.zeros(n), currentLK=np.zeros(n),
                    nAppend=np.zeros(n, np.int32), status=np.zeros(n, np.int32))

@@ -125,6 +125,10 @@ int omo_findBestParentTopology(const OModel *m, const OTree *t, const OSearchPar
 int omo_sprWorker(const OModel *m, const OTree *t, const OSearchParams *p, int n, const int *nodes, OSearchResult *out,
                   void *arenaMem, size_t arenaBytes);
 
+/* ... dealt to OpenMP threads (every thread owns arenaBytesPerThread bytes of arenaMem); same results */
+int omo_sprWorker_mt(const OModel *m, const OTree *t, const OSearchParams *p, int n, const int *nodes, OSearchResult *out,
+                     void *arenaMem, size_t arenaBytesPerThread, int threads);
+
 /* batch driver (lists concatenated, off[] = CSR offsets by list index) used to time the CPU baseline */
 int   omo_appendProbNode_batch(const OModel *m, const OEntry *all, const long long *off, int n, const int *pl,
                                const int *cl, const unsigned char *tip, const double *bl, double *out);

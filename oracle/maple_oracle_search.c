@@ -399,3 +399,24 @@ int omo_sprWorker(const OModel *m, const OTree *t, const OSearchParams *p, int n
     }
     return 0;
 }
+
+/* The same worker dealt to `threads` OpenMP threads (searches are independent given the frozen tree -- the reference's own
+ * Pool.map over numCores, M:12283-12293); every thread owns arenaBytesPerThread bytes of arenaMem.  threads <= 1: the
+ * scalar loop above.  Results are those of omo_sprWorker whatever the thread count. */
+int omo_sprWorker_mt(const OModel *m, const OTree *t, const OSearchParams *p, int n, const int *nodes, OSearchResult *out,
+                     void *arenaMem, size_t arenaBytesPerThread, int threads)
+{
+    if (threads <= 1) return omo_sprWorker(m, t, p, n, nodes, out, arenaMem, arenaBytesPerThread);
+#pragma omp parallel num_threads(threads)
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        extern int omp_get_thread_num(void);
+        tid = omp_get_thread_num();
+#endif
+        char *mine = (char *)arenaMem + (size_t)tid * arenaBytesPerThread;
+#pragma omp for schedule(dynamic, 4)
+        for (int i = 0; i < n; i++) omo_sprWorker(m, t, p, 1, nodes + i, out + i, mine, arenaBytesPerThread);
+    }
+    return 0;
+}

@@ -423,7 +423,7 @@ class Oracle:
     # ---- SPR search -----------------------------------------------------------------------------
     def spr_worker(self, tree, nodes, *, strict, allowedFails, thresholdLogLKtopology, thresholdTopologyPlacement,
                    thresholdLogLKoptimizationTopology, thresholdLogLKconsecutivePlacement, effectivelyNon0BLen,
-                   arena_mb=256, want_removed_partials=False):
+                   arena_mb=256, want_removed_partials=False, threads=1):
         """startTopologyUpdatesParallel's worker body (M:9615-9711) for the pruned nodes `nodes`."""
         nodes = np.ascontiguousarray(nodes, dtype=np.int32)
         n = len(nodes)
@@ -438,9 +438,10 @@ class Oracle:
                 bufs.append(b)
                 res[i].rpr = b.ctypes.data
                 res[i].rprCap = 4096
-        arena = np.zeros(arena_mb << 20, dtype=np.uint8)
-        self.lib.omo_sprWorker(C.byref(self.m), C.byref(tree.c), C.byref(sp), n, _p(nodes), res, _p(arena),
-                               C.c_size_t(arena.nbytes))
+        threads = max(1, int(threads))
+        arena = np.empty((arena_mb << 20) * threads, dtype=np.uint8)
+        self.lib.omo_sprWorker_mt(C.byref(self.m), C.byref(tree.c), C.byref(sp), n, _p(nodes), res, _p(arena),
+                                  C.c_size_t(arena_mb << 20), threads)
         out = dict(bestNode=np.array([r.bestNode for r in res]), placement=np.array([r.placement for r in res]),
                    status=np.array([r.status for r in res]), nAppend=np.array([r.nAppend for r in res]),
                    bestScore=np.array([r.bestScore for r in res]), improvement=np.array([r.improvement for r in res]),

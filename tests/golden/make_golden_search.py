@@ -41,13 +41,23 @@ RUNS = {
     "example_jc": ["--model", "JC"],
     # real SARS-CoV-2 data: the first 600 samples of example_files/sameRef_B.1.429.maple.gz
     "b1429_unrest": ["--model", "UNREST", "--numTopologyImprovements", "0", "--noFastTopologyInitialSearch"],
+    # Trees with MANY improvable placements (the accept rule and the four vetoes of M:9681-9700 need proposed moves to
+    # bite on; a tree the reference built itself proposes 0-3): the reference builds its tree, the names of SCRAMBLE tips
+    # are permuted among themselves in its Newick output, and the reference reads that tree back (--inputTree
+    # --largeUpdate, M:3648 / 12247) without running any SPR round -- the tree frozen here is the one its first parallel
+    # SPR round would search.
+    "synth_scrambled": ["--model", "UNREST", "--maxNumDescendantsForMATClade", "12", "--numTopologyImprovements", "0",
+                        "--noFastTopologyInitialSearch"],
+    "b1429_scrambled": ["--model", "UNREST", "--numTopologyImprovements", "0", "--noFastTopologyInitialSearch"],
 }
+SCRAMBLE = {"synth_scrambled": 30, "b1429_scrambled": 40}
 EXAMPLE_DIR = "/root/reference/example_files"
 INPUTS = {                                   # default: tests/golden/synth_small.maple.txt
     "example_unrest": os.path.join(EXAMPLE_DIR, "MAPLE_alignment_example.txt"),
     "example_siteerr": os.path.join(EXAMPLE_DIR, "MAPLE_alignment_example.txt"),
     "example_jc": os.path.join(EXAMPLE_DIR, "MAPLE_alignment_example.txt"),
     "b1429_unrest": ("prefix", os.path.join(EXAMPLE_DIR, "sameRef_B.1.429.maple.gz"), 600),
+    "b1429_scrambled": ("prefix", os.path.join(EXAMPLE_DIR, "sameRef_B.1.429.maple.gz"), 600),
 }
 
 
@@ -73,9 +83,9 @@ def input_path(name, tmp_dir):
 def snapshot_tree(tree, root):
     n = len(tree.up)
     return dict(
-        root=root, up=list(tree.up), children=[list(c) for c in tree.children], dist=list(tree.dist),
-        mutations=[[list(m) for m in ml] for ml in tree.mutations],
-        nMinor=[len(m) for m in tree.minorSequences],
+        root=root, up=list(tree.up), children=[list(c) if c else [] for c in tree.children], dist=list(tree.dist),
+        mutations=[[list(m) for m in ml] if ml else [] for ml in tree.mutations],
+        nMinor=[len(m) if m else 0 for m in tree.minorSequences],
         probVect=[ser_list(x) for x in tree.probVect],
         probVectUpRight=[ser_list(x) for x in tree.probVectUpRight],
         probVectUpLeft=[ser_list(x) for x in tree.probVectUpLeft],
@@ -113,6 +123,26 @@ def frozen_reference_tree(name, flags):
     out_dir = tempfile.mkdtemp(prefix="maple_golden_search_")
     inp = input_path(name, out_dir)
     argv = ["MAPLE", "--input", inp, "--output", os.path.join(out_dir, "out"), "--overwrite"] + flags
+    if name in SCRAMBLE:
+        old = sys.argv
+        sys.argv = argv
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                runpy.run_path(REF, run_name="__main__")
+        except SystemExit:
+            pass
+        finally:
+            sys.argv = old
+        newick = open(os.path.join(out_dir, "out_tree.tree")).read()
+        tip_names = sorted(set(re.findall(r"[(,]([A-Za-z][^:,()]*):", newick)))
+        rng0 = random.Random(99)
+        chosen = rng0.sample(tip_names, min(SCRAMBLE[name], len(tip_names)))
+        swap = dict(zip(chosen, chosen[1:] + chosen[:1]))
+        scrambled = re.sub(r"([(,])([A-Za-z][^:,()]*):", lambda m: m.group(1) + swap.get(m.group(2), m.group(2)) + ":", newick)
+        tree_path = os.path.join(out_dir, "scrambled.tree")
+        open(tree_path, "w").write(scrambled)
+        argv = ["MAPLE", "--input", inp, "--output", os.path.join(out_dir, "out2"), "--overwrite", "--inputTree", tree_path,
+                "--largeUpdate"] + flags
     holder = {}
 
     def grab(frame, event, arg):
