@@ -79,6 +79,52 @@ def preorder_nodes(mirror):
             stack.append(int(ch[v, 0]))
     return np.asarray(order, dtype=np.int64)
 
+def optimise_branch_lengths(dev, mirror, tip_ids, mark_tree, eff_non0, max_passes=8):
+    """The branch-length optimisation MAPLE runs before its SPR rounds (M:11899-11906: traverseTreeToOptimizeBranchLengths
+    until nothing moves) on the bench tree, in the form of the reference's fastPass=True (M:8727-8893): every branch
+    re-estimated from the same frozen lists (estimateBranchLengthWithDerivative(upper vector, lower list), ONE launch for
+    the whole tree), a length replaced when it moves by more than 1 % (M:8873), then all genome lists rebuilt on the GPU;
+    repeated until a pass moves nothing.  (The two branches below the root keep their lengths: the reference splits their
+    sum by a grid search, M:8743-8810.)  Returns what it did; mirror.dist and the lists are updated in place."""
+    nodes = np.nonzero(mirror.parent >= 0)[0]
+    nodes = nodes[mirror.parent[nodes] != mirror.root]
+    out = {"form": "fastPass (every branch from the same frozen lists) + full rebuild of the genome lists, until no length moves by > 1 %",
+           "branches": int(len(nodes)), "updates_per_pass": [], "estimate_ms_per_pass": [], "rebuild_ms_per_pass": []}
+
+    def impossible():
+        p = mirror.parent[nodes]
+        upv = np.where(mirror.children[p, 0] == nodes, mirror.up_right[p], mirror.up_left[p]).astype(np.int32)
+        cur = dev.append_batch(upv, mirror.lower[nodes], mirror.is_tip[nodes], mirror.dist[nodes])
+        return upv, int(np.isinf(cur).sum())
+    upv, out["current_placement_impossible_before"] = impossible()
+    out["zero_length_branches_before"] = int((mirror.dist[nodes] == 0).sum())
+    for _ in range(max_passes):
+        t0 = time.perf_counter()
+        t, isf = dev.blen_batch(upv, mirror.lower[nodes], mirror.is_tip[nodes])
+        out["estimate_ms_per_pass"].append(round(1e3 * (time.perf_counter() - t0), 2))
+        best = np.where(isf.astype(bool), 0.0, t)
+        d = mirror.dist[nodes]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ratio = d / best
+        upd = ~((best == 0) & (d == 0)) & ((best == 0) | (d == 0) | (ratio > 1.01) | (ratio < 0.99))          # M:8873
+        out["updates_per_pass"].append(int(upd.sum()))
+        if not upd.any():
+            break
+        mirror.dist[nodes[upd]] = best[upd]
+        t0 = time.perf_counter()
+        dev.release(mark_tree)
+        mirror.lower = tip_ids.copy()
+        mirror.up_right[:] = -1
+        mirror.up_left[:] = -1
+        mirror.tot_up[:] = -1
+        mirror.build()
+        out["rebuild_ms_per_pass"].append(round(1e3 * (time.perf_counter() - t0), 1))
+        upv, _ = impossible()
+    _, out["current_placement_impossible_after"] = impossible()
+    out["zero_length_branches_after"] = int((mirror.dist[nodes] == 0).sum())
+    out["passes"] = len(out["updates_per_pass"])
+    return out
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -94,6 +140,10 @@ def main():
                          "search round per step, what the reference does per round, M:12283-12316)")
     ap.add_argument("--spr-fast", action="store_true",
                     help="the reference's fast initial round (strict, 2 fails, 6 log lRef) instead of the deep round")
+    ap.add_argument("--tree", choices=["optimised", "truth"], default="optimised",
+                    help="optimised (default): the simulated tree after the branch-length passes MAPLE runs before its SPR rounds "
+                         "(traverseTreeToOptimizeBranchLengths, M:11899-11906), until no length moves; truth: the simulated tree "
+                         "with branch lengths = mutations / lRef (rounds 1-2)")
     ap.add_argument("--queries", type=int, default=256, help="query lists of the all-pairs scoring sub-block")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate host time spent on cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,8 +198,17 @@ def main():
     dev.set_model(**mkw)
     tip_kw = dict(error_rates=mkw["errorRates"]) if args.model == "siteerr" else {}
     tip_lists = {int(v): tip_genome_list(dl, ref_idx, **tip_kw) for v, dl in zip(data.tip_node, data.diffs)}
-    mirror = TreeMirror(dev, data.parent, data.blen, tip_lists).build()
+    mirror = TreeMirror(dev, data.parent, data.blen, tip_lists)
+    tip_ids = mirror.lower.copy()
+    mark_tree = dev.mark()
+    t_b = time.perf_counter()
+    mirror.build()
+    build_ms = 1e3 * (time.perf_counter() - t_b)
     l_ref = dev.lRef
+    blen_opt = None
+    if args.tree == "optimised":
+        blen_opt = optimise_branch_lengths(dev, mirror, tip_ids, mark_tree, 1.0 / (10 * l_ref))
+        blen_opt["tree_build_ms"] = round(build_ms, 1)
     no_mut = -np.ones(mirror.n_nodes, dtype=np.int32)
 
     def upload_plain_tree():
@@ -209,10 +268,8 @@ def main():
         distd.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    n_score, ms_score, pairs_score, bytes_score = dev.timing_read_kind(Device.KIND_SPR_SCORE)
-    n_s, ms_s, u_s, b_s = dev.timing_read_kind(Device.KIND_SPR_SEARCH)
-    n_r, ms_r, u_r, b_r = dev.timing_read_kind(Device.KIND_SPR_REPLAY)
-    n_lane, ms_lane, n_rep, ms_rep = n_s, ms_s, n_r, ms_r
+    K = {name: dev.timing_read_kind(getattr(Device, "KIND_" + name)) for name in
+         ("SPR_SCORE", "SPR_SEARCH", "SPR_REPLAY", "FR_UPDATING", "FR_CACHED", "FR_REPLAY")}     # (launches, ms, units, bytes)
     for res in kept:
         for k, v in zip(*np.unique(res["status"], return_counts=True)):
             status_counts[str(int(k))] = status_counts.get(str(int(k)), 0) + int(v)
@@ -249,34 +306,67 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_placements / elapsed
+        steps = args.steps
 
-        def roof(kernel, n, ms, bytes_, units, what):
+        def roof(kernel, kind, what, bytes_override=None):
+            n, ms, units, bytes_ = K[kind]
+            if bytes_override is not None:
+                bytes_ = bytes_override
             ach = (bytes_ / (ms * 1e-3) / 1e9) if ms else 0.0
             return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(kernel.split()[0]),
                     "algorithmic_bytes_per_launch": bytes_ / max(1, n), "kernel_ms": ms / max(1, n), "launches_timed": n,
-                    "units_per_launch": units / max(1, n), "note": what}
-        roof_search = roof("k_spr_search (the search state machine: budgeted lane searches + replay / refinement launches)",
-                           n_s + n_r, ms_s + ms_r, b_s + b_r, u_s + u_r,
-                           "rank 0's launches; algorithmic bytes = SURVEY 8d per candidate placement the launch scored itself "
-                           "(mean candidate list: 8E + 8A + 8, the removed list once per search), 8 B per placement replayed "
-                           "from the score table; a latency-bound kernel: see DESIGN.md section 3")
-        roof_score = roof("k_append_queries_lds (dense scoring of the whole-tree searches)", n_score, ms_score, bytes_score,
-                          pairs_score,
-                          "rank 0's launches; algorithmic bytes = SURVEY 8d (8E + 8A + 8 per candidate branch per query, each "
-                          "query list once per launch); the 64 candidate lists of a tile are staged in LDS once per 512 "
-                          "queries, so the algorithmic rate can exceed the HBM peak -- `traffic` is what really moves")
-        dominant, other = (roof_search, roof_score) if ms_s + ms_r >= ms_score else (roof_score, roof_search)
+                    "kernel_ms_per_step": ms / steps, "units_per_step": units / steps, "note": what}
+        # every kernel of a step that matters, each timed by its own HIP events on the stream it is launched on
+        roofs = [
+            roof("k_fr_cached (frontier tier: one lane scores one (search, branch) item, appendProbNode of the branch's "
+                 "probVectTotUp and the removed list)", "FR_CACHED",
+                 "rank 0; units = placements scored, algorithmic bytes = SURVEY 8d (8E + 8A + 8 per candidate list, counted on the "
+                 "device per scored item); one launch per level of the expansion"),
+            roof("k_fr_updating (frontier tier: items that still update genome lists -- mergeVectors x 1-4, areVectorsDifferent, "
+                 "appendProbNode per item)", "FR_UPDATING",
+                 "rank 0; no SURVEY 8d byte count is defined for these items (their lists are made on the spot): time only"),
+            roof("k_append_queries_lds (dense scoring of the whole-tree searches: every branch of the tree per search)", "SPR_SCORE",
+                 "rank 0; algorithmic bytes = SURVEY 8d (8E + 8A + 8 per candidate branch per query, each query list once per launch). "
+                 "The 64 candidate lists of a tile are staged in LDS once per 512 queries, so this count is NOT a bound for the "
+                 "kernel (frac can exceed 1): `traffic` is what moves, and profiles/ holds its issue / LDS counters"),
+            roof("k_spr_search (exact replay of the whole-tree searches over their score rows: wave-cooperative clade scan, "
+                 "refinement)", "SPR_REPLAY",
+                 "rank 0; algorithmic bytes = 8 B per placement replayed from the score table + the removed list once per search"),
+        ]
+        roofs = [r for r in roofs if r["launches_timed"]]
+        dominant = max(roofs, key=lambda r: r["kernel_ms_per_step"]) if roofs else None
+        # ---- the two kinds of candidate placement of a step
+        n_fr, ms_fr, u_fr, b_fr = K["SPR_SEARCH"]                       # the frontier tier as a whole (or the lane searches)
+        n_rp, ms_rp, u_rp, b_rp = K["SPR_REPLAY"]
+        ms_dense = K["SPR_SCORE"][1]
+        split = {
+            "full_walk": {"what": "candidate placements of searches finished by the frontier tier: each scored by walking the "
+                                  "candidate branch's genome list against the removed subtree's list (M:7011 / 7223)",
+                          "placements_per_step": u_fr / steps, "kernel_ms_per_step": ms_fr / steps,
+                          "placements_per_s_of_its_kernels": (u_fr / (ms_fr * 1e-3)) if ms_fr else 0.0,
+                          "algorithmic_GBps": (b_fr / (ms_fr * 1e-3) / 1e9) if ms_fr else 0.0,
+                          "frac_of_hbm_peak": (b_fr / (ms_fr * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_fr else 0.0},
+            "replayed": {"what": "candidate placements of whole-tree searches (searches from zero-length branches without an error "
+                                 "model: a mismatch over zero length is impossible, M:6663, -inf never counts as a failed pass, the "
+                                 "non-strict rule M:7095 descends everywhere): every branch scored by the dense kernel -- most walks "
+                                 "end at the first mismatch -- then the traversal replayed over the score row",
+                         "placements_per_step": u_rp / steps, "kernel_ms_per_step": (ms_rp + ms_dense) / steps,
+                         "placements_per_s_of_its_kernels": (u_rp / ((ms_rp + ms_dense) * 1e-3)) if (ms_rp + ms_dense) else 0.0},
+        }
         out = {
             "metric": "candidate SPR placements/sec", "value": value, "unit": "placements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.samples} synthetic SARS-CoV-2 diff-lists (lRef 29903, ~30 diffs/sample), "
                                    f"{MODEL_TEXT[args.model]}; SPR search (findBestParentTopology + worker, "
-                                   f"{'fast initial' if args.spr_fast else 'deep'}-round parameters) for {B} pruned nodes per step",
-                       "samples": args.samples, "model": args.model, "tree_nodes": int(mirror.n_nodes),
+                                   f"{'fast initial' if args.spr_fast else 'deep'}-round parameters) for {B} pruned nodes per step; "
+                                   f"tree: {'branch lengths optimised as MAPLE does before its SPR rounds' if args.tree == 'optimised' else 'simulated tree, lengths = mutations / lRef'}",
+                       "samples": args.samples, "model": args.model, "tree": args.tree, "tree_nodes": int(mirror.n_nodes),
                        "searches_per_step": int(B), "searches_timed": int(total_searches),
                        "candidate_placements_timed": int(total_placements),
+                       "placements_split": split,
+                       "branch_length_optimisation": blen_opt,
                        "parallelism": f"each step's {B} pruned nodes dealt round-robin in pre-order (coreNum) over {world} GPU(s), "
                                       "tree mirror replicated, one all-gather of proposed moves per step",
                        "setup_s": round(setup_s, 1),
@@ -284,12 +374,14 @@ def main():
                                            "tree_upload_ms": round(tree_upload_ms, 1),
                                            "note": "lists and tree tables are in HBM when the timed region starts; a step's own "
                                                    "host traffic (node ids in, ~100 B of results per search out) is inside `value`"}},
-            "roofline": dominant, "roofline_second_kernel": other,
+            "roofline": dominant, "roofline_by_kernel": roofs,
             "spr_search": {"status_counts": status_counts, "proposed_moves_rank0": n_moves,
-                           "kernel_ms_rank0": {"budgeted_lane_searches": ms_lane, "dense_scoring": ms_score,
-                                               "replay_and_refinement": ms_rep},
-                           "launches_rank0": {"budgeted_lane_searches": n_lane, "dense_scoring": n_score,
-                                              "replay_and_refinement": n_rep},
+                           "kernel_ms_rank0_per_step": {"frontier_tier": ms_fr / steps, "of_which_k_fr_updating": K["FR_UPDATING"][1] / steps,
+                                                        "of_which_k_fr_cached": K["FR_CACHED"][1] / steps,
+                                                        "of_which_replay_refine_finish": K["FR_REPLAY"][1] / steps,
+                                                        "dense_scoring": ms_dense / steps, "replay_of_whole_tree_searches": ms_rp / steps},
+                           "launches_rank0_per_step": {"frontier_levels": K["FR_CACHED"][0] / steps, "dense_scoring": K["SPR_SCORE"][0] / steps,
+                                                       "replay": n_rp / steps},
                            "params": ("fast round: strict, allowedFailsTopology 2, thresholdLogLKtopology 6 log(lRef)"
                                       if args.spr_fast else
                                       "deep round: non-strict, allowedFailsTopology 4, thresholdLogLKtopology 14 log(lRef)")},
@@ -517,8 +609,8 @@ def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_pl
 
 def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, batch_of, gpu_results, kw, cpu_seconds, mkw, steps):
     """The C oracle's SPR search (a port of findBestParentTopology + the worker body, oracle/maple_oracle_search.c,
-    pinned to the reference's recorded searches) on ONE host core over a bounded, evenly spread sample of the timed
-    searches; also cross-checks the GPU's node ids, moves and candidate counts."""
+    pinned to the reference's recorded searches) on one host core and on all of them (OpenMP over searches) over bounded,
+    evenly spread samples of the timed searches; also cross-checks the GPU's node ids, moves and candidate counts."""
     from oracle.oracle_py import Oracle, OracleTree
     orc = Oracle(ref_idx, root_freqs)
     orc.set_model(**mkw)
@@ -533,33 +625,44 @@ def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, batch_of, gpu_results, kw
     otree = OracleTree(orc, mirror.root, up, children, mirror.dist, [[] for _ in range(n)], [0] * n, lists4)
     nodes = np.concatenate([batch_of(i) for i in range(steps)])
     gpu = {k: np.concatenate([r[k] for r in gpu_results]) for k in ("status", "bestNode", "placement", "nAppend")}
-    # grow the sample until the time budget is used: every 997th search, then every 499th, ...
-    t_used, placements, checked = 0.0, 0, 0
-    stride = 997
+    cores = usable_host_threads()
+
+    def timed_sample(threads, budget_s, stride0, seen):
+        """Grow an evenly spread sample of the timed searches (every stride0-th, then every (stride0 / 2)-th, ...) until the
+        time budget is used; every result is checked against the GPU's."""
+        t_used, placements, checked = 0.0, 0, 0
+        stride = stride0
+        while t_used < budget_s and stride >= 1:
+            sel = np.asarray([i for i in range(0, len(nodes), stride) if i not in seen], dtype=np.int64)
+            if len(sel) == 0:
+                break
+            # bound one call by what is left of the budget (a whole-tree search costs ~10 ms on one core)
+            est = max(1e-9, t_used / max(1, placements)) if placements else 6e-8 / threads
+            budget_pl = max(1.0, (budget_s - t_used) / est)
+            cum = np.cumsum(gpu["nAppend"][sel].astype(np.float64))
+            sel = sel[: max(1, int(np.searchsorted(cum, budget_pl)) + 1)]
+            t0 = time.perf_counter()
+            o = orc.spr_worker(otree, nodes[sel], threads=threads, **kw)
+            t_used += time.perf_counter() - t0
+            placements += int(o["nAppend"].sum())
+            for k in ("status", "bestNode", "placement", "nAppend"):
+                if not np.array_equal(o[k], gpu[k][sel]):
+                    raise SystemExit(f"GPU SPR search disagrees with the oracle on {k}")
+            checked += len(sel)
+            seen.update(sel.tolist())
+            stride //= 2
+        return t_used, placements, checked
     seen = set()
-    while t_used < cpu_seconds and stride >= 1:
-        sel = np.asarray([i for i in range(0, len(nodes), stride) if i not in seen], dtype=np.int64)
-        if len(sel) == 0:
-            break
-        # bound one call by what is left of the budget (a whole-tree search costs ~10 ms on this core)
-        est = max(1e-9, t_used / max(1, placements)) if placements else 6e-8
-        budget_pl = max(1.0, (cpu_seconds - t_used) / est)
-        cum = np.cumsum(gpu["nAppend"][sel].astype(np.float64))
-        sel = sel[: max(1, int(np.searchsorted(cum, budget_pl)) + 1)]
-        t0 = time.perf_counter()
-        o = orc.spr_worker(otree, nodes[sel], **kw)
-        t_used += time.perf_counter() - t0
-        placements += int(o["nAppend"].sum())
-        for k in ("status", "bestNode", "placement", "nAppend"):
-            if not np.array_equal(o[k], gpu[k][sel]):
-                raise SystemExit(f"GPU SPR search disagrees with the oracle on {k}")
-        checked += len(sel)
-        seen.update(sel.tolist())
-        stride //= 2
-    return {"value": placements / t_used, "unit": "placements/s", "cores": 1, "kind": "port",
-            "sample": f"{checked} of the {len(nodes)} timed searches (evenly spread), {placements} candidate placements, "
-                      f"C oracle search (oracle/maple_oracle_search.c) on one host core, {t_used:.1f} s; node ids, moves "
-                      "and candidate counts identical to the GPU's"}
+    t1, p1, c1 = timed_sample(1, cpu_seconds / 3.0, 997, seen)
+    tn, pn, cn = timed_sample(cores, 2.0 * cpu_seconds / 3.0, 499, seen) if cores > 1 else (t1, p1, c1)
+    full = float(gpu["nAppend"][gpu["status"] >= -1].sum())
+    return {"value": pn / tn, "unit": "placements/s", "cores": cores, "kind": "port",
+            "sample": f"{cn} of the {len(nodes)} timed searches (evenly spread), {pn} candidate placements, C oracle search "
+                      f"(oracle/maple_oracle_search.c, OpenMP over searches like the reference's Pool.map over --numCores, M:12283-12293) "
+                      f"on {cores} host threads, {tn:.1f} s; node ids, moves and candidate counts identical to the GPU's",
+            "one_core": {"value": p1 / t1, "unit": "placements/s", "cores": 1,
+                         "sample": f"{c1} searches, {p1} candidate placements, {t1:.1f} s"},
+            "whole_workload_estimate_s": {"one_core": full / (p1 / t1), f"{cores}_cores": full / (pn / tn)}}
 
 
 def usable_host_threads():

@@ -327,7 +327,10 @@ int maple_timing_read_each(maple_ctx *ctx, int32_t cap, float *ms, int32_t *n_la
  *   1 = dense scoring inside maple_spr_search_batch (k_append_queries / k_place_score: units = (query, branch) pairs,
  *       alg_bytes = SURVEY 8d bytes: 8 E + 8 A + 8 per candidate branch per query, each query list once per launch),
  *   2 = budgeted lane searches, 3 = searches replayed over cached scores (units = searches),
- *   4 = maple_append_queries_dev, 5 = maple_append_batch_dev, 6 = scoring inside maple_placement_search_batch (units = pairs). */
+ *   4 = maple_append_queries_dev, 5 = maple_append_batch_dev, 6 = scoring inside maple_placement_search_batch (units = pairs),
+ *   the frontier tier of the SPR search (kind 2 = the tier as a whole; its kernels, one record per launch):
+ *   7 = k_fr_updating (items that still update genome lists), 8 = k_fr_cached (units = cached-regime placements scored,
+ *   alg_bytes = their SURVEY 8d bytes, counted on the device), 9 = exact replay + refinement + final selection. */
 int maple_timing_read_kind(maple_ctx *ctx, int32_t kind, int32_t *n_launches, double *total_ms, double *units,
                            double *alg_bytes);
 /* algorithmic bytes (8*E + 8*B + 32*O + 8 per candidate, child list once per query) */

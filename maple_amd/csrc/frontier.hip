@@ -77,6 +77,8 @@ struct FCtr {                          // device-side bookkeeping of the level l
     unsigned long long loU, hiU, loC, hiC;   // the current level
     unsigned long long nLists, usedW, usedA; // temporary lists
     unsigned long long nRecs;
+    unsigned long long bigUsed;        // entries taken from the shared scratch of over-long lists (reset every level)
+    unsigned long long scoredC, bytesC;  // cached-regime items scored by k_fr_cached and their SURVEY 8d bytes (8 E + 8 A + 8)
     int32_t overflow, pad;
 };
 
@@ -90,7 +92,9 @@ struct FPools {
     long long capW, capA, capL;
     // per-lane scratch
     uint2 *sw; double *sa; double *sais;
-    int32_t capE;                      // entries one scratch list takes (aux: 5 per entry; ais: 2 per entry)
+    int32_t capE;                      // entries one lane's scratch list takes (aux: 5 per entry; ais: 2 per entry)
+    uint2 *bw; double *ba;             // shared scratch for the few lists longer than that (bump-allocated, reset every level)
+    long long capBig;
     FCtr *ctr;
     FSearch *S;
     FRec *recs;
@@ -110,6 +114,18 @@ __device__ __forceinline__ FList flist(const ArenaViewS &av, const FPools &fp, i
     return FList{av.words + av.ent_off[id], av.aux + av.aux_off[id], av.n_ent[id], av.n_aux[id]};
 }
 __device__ __forceinline__ ListRef fref(const FList &l) { return ListRef{l.w, l.aux}; }
+
+// room for one list of up to `need` entries: the lane's own slab, or -- for the few lists near the root that are longer --
+// a piece of the shared scratch (false: none left)
+struct FScr { uint2 *w; double *a; };
+__device__ inline bool fscratch(const FPools &fp, long long laneId, int need, FScr &o)
+{
+    if (need <= fp.capE) { o.w = fp.sw + laneId * fp.capE; o.a = fp.sa + laneId * 5ll * fp.capE; return true; }
+    const unsigned long long off = atomicAdd(&fp.ctr->bigUsed, (unsigned long long)need);
+    if ((long long)(off + need) > fp.capBig) return false;
+    o.w = fp.bw + off; o.a = fp.ba + 5ull * off;
+    return true;
+}
 
 // a scratch list becomes a temporary list of the batch: exact room, one copy; -2 when the pools are full
 __device__ inline int fstore(const FPools &fp, const Writer &wr)
@@ -158,12 +174,22 @@ __device__ inline int fpush(const FPools &fp, const int budget, const int q, con
     if (atomicAdd(&S.nItems, 1) >= budget) { S.state = FS_OVER; return FR_NONE; }
     FItem *it;
     int ref;
+    // one atomic per wavefront and pool: the lanes that are here together take consecutive items
+    unsigned long long *ctrp = upd ? &fp.ctr->usedU : &fp.ctr->usedC;
+    const unsigned long long act = __ballot(1);
+    const int lane = threadIdx.x & 63, leader = (int)__ffsll((long long)act) - 1;
+    const unsigned long long same = __ballot(upd);                           // (lanes pushing into the updating pool)
+    const unsigned long long mine = upd ? (act & same) : (act & ~same);
+    const int lead2 = (int)__ffsll((long long)mine) - 1;
+    unsigned long long base = 0;
+    if (lane == lead2) base = atomicAdd(ctrp, (unsigned long long)__popcll(mine));
+    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), lead2, 64) << 32) | (uint32_t)__shfl((int)base, lead2, 64);
+    (void)leader;
+    const unsigned long long i = base + (unsigned long long)__popcll(mine & ((1ull << lane) - 1ull));
     if (upd) {
-        const unsigned long long i = atomicAdd(&fp.ctr->usedU, 1ull);
         if ((long long)i >= fp.capU) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; return FR_NONE; }
         it = &fp.U[i]; ref = -((int)i + 2);
     } else {
-        const unsigned long long i = atomicAdd(&fp.ctr->usedC, 1ull);
         if ((long long)i >= fp.capC) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; return FR_NONE; }
         it = &fp.C[i]; ref = (int)i;
     }
@@ -210,9 +236,12 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
         S.hRpr0 = ftree(rn.lower);
         // a search from a zero-length branch without an error model is a whole-tree search (see k_spr_search): dense tier
         if (!U && budget > zeroBudget && rn.dist == 0.0) { S.state = FS_OVER; o.status = -5; continue; }
-        if (rp.up < 0) { S.state = FS_FALLBACK; continue; }                  // the parent is the root: rootVector (M:6916-6960)
         if (shorten_would_merge(c, fref(ll), ll.n)) { S.state = FS_FALLBACK; continue; }   // M:7087 would edit the removed list
         S.state = FS_ACTIVE;
+        if (rp.up < 0) {                                                    // the parent is the root (M:6916-6960): seeded by an item
+            S.seed0 = fpush(fp, budget, q, true, S.sibling, 3, -1, 0.0, curLK, 0, S.hRpr0, curLK);   // of its own (k_fr_updating)
+            continue;
+        }
         const int pp = rp.up;
         const NodeRec rpp = T.nd[pp];
         const bool first = rpp.c0 == parent;
@@ -228,6 +257,7 @@ __global__ void k_fr_snap(FCtr *ctr)
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         ctr->loU = ctr->hiU; ctr->hiU = ctr->usedU;
         ctr->loC = ctr->hiC; ctr->hiC = ctr->usedC;
+        ctr->bigUsed = 0;
     }
 }
 
@@ -249,6 +279,7 @@ __device__ __forceinline__ PRule p_rule(const SearchParams &P, bool scored, doub
 }
 
 // ---- items that arrived with needsUpdating == True (M:6982-7091, 7182-7304): lists merged along the path ----------------
+// (dir 3: the seeding of a search whose pruned node hangs off the root, M:6916-6960 -- two rootVector calls)
 template <bool RV, bool U, bool SS>
 __global__ __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, FPools fp, int budget)
@@ -258,8 +289,6 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    uint2 *sw = fp.sw + laneId * fp.capE;
-    double *sa = fp.sa + laneId * 5ll * fp.capE;
     const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
     for (long long i = lo + laneId; i < hi; i += (long long)gridDim.x * blockDim.x) {
         FItem &it = fp.U[i];
@@ -274,21 +303,52 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
         bool upd = true;
         double midProb = lastLK;
         Writer wr;
-        // merge two lists into the lane's scratch; -1 None, -2 fatal / no room
+        FScr scr{nullptr, nullptr};
+        // merge two lists into scratch (wr / scr); 0 ok, -1 None, -2 fatal / no room (then the search is handed back)
         auto merge = [&](int h1, double b1, bool tp1, int h2, double b2, bool tp2, bool upDown) -> int {
             if (!fvalid(h1) || !fvalid(h2)) return -2;
             const FList l1 = flist(av, fp, h1), l2 = flist(av, fp, h2);
-            if (l1.n + l2.n > fp.capE) { S.state = FS_FALLBACK; return -2; }
-            wr.init(sw, sa);
+            if (!fscratch(fp, laneId, l1.n + l2.n, scr)) { S.state = FS_FALLBACK; return -2; }
+            wr.init(scr.w, scr.a);
             const int r = merge_walk(c, fref(l1), b1, tp1, fref(l2), b2, tp2, upDown, false, 0, 0, wr, nullptr);
             return r == -1 ? -1 : (r < 0 ? -2 : 0);
         };
+        // rootVector(list, bLen, isFromTip) without local references (M:4916-4996): the walk, then shorten; a stored handle,
+        // -2 when out of room
+        auto rootVector = [&](int h, double bLen, bool fromTip) -> int {
+            if (!fvalid(h)) return -2;
+            const FList l = flist(av, fp, h);
+            if (!fscratch(fp, laneId, l.n, scr)) return -2;
+            wr.init(scr.w, scr.a);
+            root_walk(c, fref(l), bLen, fromTip, wr);
+            const int hr = fstore(fp, wr);
+            if (hr < 0) return -2;
+            const FList lr = flist(av, fp, hr);
+            wr.init(scr.w, scr.a);
+            shorten_walk(c, fref(lr), lr.n, wr);
+            if (wr.n == lr.n) return hr;                                   // nothing merged: the list as it is
+            return fstore(fp, wr);
+        };
+        if (it.dir == 3) {                                                  // the pruned node's parent is the root; t1 = its sibling
+            it.midProb = lastLK;
+            it.flags |= FI_UPD_OUT;
+            if (r1.c0 >= 0) {
+                const int ch1 = r1.c0, ch2 = r1.c1;
+                const NodeRec rc1 = T.nd[ch1], rc2 = T.nd[ch2];
+                const int v1 = rootVector(ftree(rc2.lower), rc2.dist, rc2.isTip != 0);
+                const int v2 = v1 < 0 ? -2 : rootVector(ftree(rc1.lower), rc1.dist, rc1.isTip != 0);
+                if (v1 < 0 || v2 < 0) { S.state = FS_FALLBACK; continue; }
+                it.child0 = fpush(fp, budget, q, true, ch1, 0, v1, rc1.dist, lastLK, 0, hRpr, it.pathBest);
+                it.child1 = fpush(fp, budget, q, true, ch2, 0, v2, rc2.dist, lastLK, 0, hRpr, it.pathBest);
+            }
+            continue;
+        }
         if (it.dir == 0) {                                                  // moving from a parent to its child, M:6982-7160
             const int upT = r1.up;
             const bool scored = !(upT == S.parent || upT < 0) && (r1.dist > P.effNon0 || r1.upIsRoot);
             if (scored) {
                 if (merge(hPassed, distance / 2, false, ftree(r1.lower), distance / 2, r1.isTip != 0, true) != 0) { it.flags |= FI_DEAD; continue; }
-                const ListRef mid{sw, sa};
+                const ListRef mid{scr.w, scr.a};
                 if (r1.totUp >= 0) { const FList tu = flist(av, fp, ftree(r1.totUp)); if (!differ_walk(c, mid, fref(tu))) upd = false; }
                 const FList lr = flist(av, fp, hRpr);
                 midProb = append_walk(c, mid, fref(lr), rt, rbl);
@@ -334,18 +394,26 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
                 if (hBottom < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; continue; }
                 r = merge(vectUp, r1.dist / 2, false, hBottom, r1.dist / 2, false, true);
                 if (r != 0) { it.flags |= FI_DEAD; continue; }
-                const ListRef mid{sw, sa};
-                if (r1.totUp >= 0) { const FList tu = flist(av, fp, ftree(r1.totUp)); if (!differ_walk(c, mid, fref(tu))) upd = false; }
-                else {
-                    // "Node has no probVectTotUp ... calculating new one", M:7198-7200: compared with a list merged on the spot
-                    // (into the arena: the scratch holds midTot)
-                    S.state = FS_FALLBACK; it.flags |= FI_DEAD; continue;
+                int hm = -1;
+                if (r1.totUp >= 0) {
+                    const ListRef mid{scr.w, scr.a};
+                    const FList tu = flist(av, fp, ftree(r1.totUp));
+                    if (!differ_walk(c, mid, fref(tu))) upd = false;
+                } else {
+                    // "Node has no probVectTotUp ... calculating new one", M:7198-7200: midTot is compared with a list merged on
+                    // the spot (midTot moves to the arena first: the scratch is needed for that merge)
+                    hm = fstore(fp, wr);
+                    if (hm < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; continue; }
+                    const int rc = merge(vectUp, r1.dist / 2, false, ftree(r1.lower), r1.dist / 2, false, true);
+                    if (rc == 0) { const FList lm = flist(av, fp, hm); if (!differ_walk(c, fref(lm), ListRef{scr.w, scr.a})) upd = false; }
+                    else if (S.state == FS_FALLBACK) { it.flags |= FI_DEAD; continue; }
                 }
                 const FList lr = flist(av, fp, hRpr);
-                midProb = append_walk(c, mid, fref(lr), rt, rbl);
+                if (hm >= 0) { const FList lm = flist(av, fp, hm); midProb = append_walk(c, fref(lm), fref(lr), rt, rbl); }
+                else midProb = append_walk(c, ListRef{scr.w, scr.a}, fref(lr), rt, rbl);
                 it.flags |= FI_SCORED;
                 if (upd && midProb >= it.pathBest - P.thrOptTopo) {          // M:7293
-                    const int hm = fstore(fp, wr);
+                    if (hm < 0) hm = fstore(fp, wr);
                     if (hm < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; continue; }
                     it.hA = vectUp; it.hB = hBottom; it.hMid = hm; it.recDist = r1.dist; it.flags |= FI_REC_UPD;
                 }
@@ -373,8 +441,12 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
                 it.child1 = upd ? fpush(fp, budget, q, true, upT, (int)r1.whichChild + 1, hBottom, r1.dist, midProb, pr.fails, hRpr, pr.pathBest)
                                 : fpush(fp, budget, q, false, upT, (int)r1.whichChild + 1, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
             } else {                                                         // t1 is the root, M:7406-7432
-                if (upd) { S.state = FS_FALLBACK; continue; }               // rootVector of the passed list: one-lane search
-                it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
+                if (upd) {
+                    const int hv = rootVector(hPassed, distance, false);
+                    if (hv < 0) { S.state = FS_FALLBACK; continue; }
+                    it.child0 = fpush(fp, budget, q, true, other, 0, hv, ro.dist, midProb, pr.fails, hRpr, pr.pathBest);
+                } else
+                    it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
             }
         }
     }
@@ -390,6 +462,7 @@ void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Sear
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     const long long lo = (long long)fp.ctr->loC, hi = (long long)fp.ctr->hiC;
+    unsigned long long nSc = 0, bSc = 0;
     for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long long)gridDim.x * blockDim.x) {
         FItem &it = fp.C[i];
         FSearch &S = fp.S[it.q];
@@ -406,6 +479,7 @@ void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Sear
             const FList lp = flist(av, fp, ftree(r1.totUp)), lr = flist(av, fp, hRpr);
             midProb = append_walk(c, fref(lp), fref(lr), S.isRemovedTip != 0, S.removedBLen);
             it.flags |= FI_SCORED;
+            nSc++; bSc += 8ull * (unsigned long long)(lp.n + lp.na) + 8ull;
         }
         it.midProb = midProb;
         const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
@@ -424,6 +498,12 @@ void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Sear
                 it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
         }
     }
+    // (what the launch scored, for the roofline of the bench line: one atomic per wavefront)
+    for (int off = 32; off > 0; off >>= 1) {
+        nSc += ((unsigned long long)(uint32_t)__shfl_down((int)(nSc >> 32), off, 64) << 32) | (uint32_t)__shfl_down((int)nSc, off, 64);
+        bSc += ((unsigned long long)(uint32_t)__shfl_down((int)(bSc >> 32), off, 64) << 32) | (uint32_t)__shfl_down((int)bSc, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && nSc) { atomicAdd(&fp.ctr->scoredC, nSc); atomicAdd(&fp.ctr->bytesC, bSc); }
 }
 
 // ---- the reference's own walk over the expanded items: "while nodesToVisit", M:6964-7434, with the real running best ------
@@ -492,8 +572,6 @@ void k_fr_refine(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, FPoo
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    uint2 *sw = fp.sw + laneId * fp.capE;
-    double *sa = fp.sa + laneId * 5ll * fp.capE;
     double *ais = fp.sais + laneId * 2ll * fp.capE;
     const long long nRecs = (long long)fp.ctr->nRecs;
     for (long long i = laneId; i < nRecs; i += (long long)gridDim.x * blockDim.x) {
@@ -514,7 +592,11 @@ void k_fr_refine(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, FPoo
         if (!fvalid(hUp) || !fvalid(hDown) || !fvalid(hMid)) { R.ok = -1; continue; }
         const FList lUp = flist(av, fp, hUp), lDown = flist(av, fp, hDown), lMid = flist(av, fp, hMid), lRem = flist(av, fp, it.hRpr);
         const bool ft = r1.isTip != 0, rt = S.isRemovedTip != 0;
-        if (lMid.n + lRem.n > 2 * fp.capE || lUp.n + lDown.n + lRem.n > fp.capE) { S.state = FS_FALLBACK; continue; }
+        const int need = max(lDown.n + lRem.n, max(lUp.n + lRem.n, lUp.n + lDown.n));
+        FScr scr0;
+        if (lMid.n + lRem.n > 2 * fp.capE || lUp.n + need > 2 * fp.capE || !fscratch(fp, laneId, need, scr0)) { S.state = FS_FALLBACK; continue; }
+        uint2 *sw = scr0.w;
+        double *sa = scr0.a;
         bool f;
         Writer w;
         const double app = blen_walk(c, fref(lMid), fref(lRem), rt, ais, 1, &f);
@@ -558,7 +640,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_finish(ArenaViewS av, DevTree T
         const NodeRec rp = T.nd[S.parent];
         double bestScore = S.curLK;
         int bestNode = S.sibling, hBestRpr = S.hRpr0, nApp = S.nApp;
-        double bl0 = rp.dist, bl1 = T.nd[S.sibling].dist, bl2 = S.removedBLen;
+        double bl0 = rp.up >= 0 ? rp.dist : 0.0, bl1 = T.nd[S.sibling].dist, bl2 = S.removedBLen;
         bool failed = false;
         for (int k = 0; k < S.recCount; k++) {
             const FRec &R = fp.recs[S.recBase + k];
@@ -600,8 +682,8 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_finish(ArenaViewS av, DevTree T
 
 struct FrontierScratch {
     DevBuf<uint8_t> itemsU, itemsC, srch, recs, ctr;
-    DevBuf<uint2> tw, sw;
-    DevBuf<double> ta, sa, sais;
+    DevBuf<uint2> tw, sw, bw;
+    DevBuf<double> ta, sa, sais, ba;
     DevBuf<long long> toffW, toffA;
     DevBuf<int32_t> tn, tna, nodes;
     DevBuf<uint8_t> out;
@@ -614,7 +696,7 @@ void frontier_scratch_free(maple_ctx *c)
     FrontierScratch *F = (FrontierScratch *)c->frontier;
     if (!F) return;
     F->itemsU.release(); F->itemsC.release(); F->srch.release(); F->recs.release(); F->ctr.release();
-    F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release();
+    F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
     F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
     delete F;
     c->frontier = nullptr;
@@ -644,24 +726,29 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t)8 << 30;
     const size_t held = F.itemsU.cap + F.itemsC.cap + F.tw.cap * sizeof(uint2) + F.ta.cap * sizeof(double)
-                        + F.sw.cap * sizeof(uint2) + F.sa.cap * sizeof(double) + F.sais.cap * sizeof(double);
+                        + F.sw.cap * sizeof(uint2) + F.sa.cap * sizeof(double) + F.sais.cap * sizeof(double) + F.bw.cap * 48;
     const double room = 0.5 * (double)(freeB + held);
-    const long long perSearchC = std::min<long long>(budget, 512);
+    const long long perSearchC = std::min<long long>(budget, 768);
     long long capC = std::max<long long>(1 << 16, (long long)m * perSearchC);
-    long long capU = std::max<long long>(1 << 14, (long long)m * std::min<long long>(budget, 24));
-    const long long meanEnt = std::max(16, c->tree_max_ent / 4);
-    long long capL = 3 * capU;
-    long long capW = capL * meanEnt, capA = 2 * capW;
-    const int capE = std::max(1024, 4 * c->tree_max_ent);
-    const int gridUpd = 256;                                              // lanes with scratch: 256 x 256
-    const long long scratchLanes = (long long)gridUpd * FR_BLOCK;
+    long long capU = std::max<long long>(1 << 14, (long long)m * std::min<long long>(budget, 12));
+    const long long meanEnt = std::max<long long>(16, c->h_n_ent.empty() ? 64 : c->used_ent / (long long)c->h_n_ent.size());   // entries per list in the arena
+    long long capL = 2 * capU;
+    long long capW = 2 * capL * meanEnt, capA = capW;
+    // per-lane scratch for lists of up to capE entries (two average lists merged, with room); the few longer ones -- near the
+    // root -- take pieces of a shared region.  As many lanes as the GPU holds at once at this kernel's occupancy.
+    const int capE = std::max(256, std::min(1024, 6 * (int)meanEnt));
+    long long scratchLanes = 256ll * 4 * 4 * 64;                           // 256 CUs x 4 SIMDs x 4 wavefronts
+    while (scratchLanes > 16384 && (double)scratchLanes * capE * 64 > 0.25 * room) scratchLanes /= 2;
+    const int gridUpd = (int)(scratchLanes / FR_BLOCK);
+    const long long capBig = std::max<long long>(1 << 20, 64ll * 1024 * std::max(1, c->tree_max_ent));
     {   // shrink the pools proportionally if they would not fit
+        const double fixed = (double)scratchLanes * capE * 64 + (double)capBig * 48;
         const double need = (double)capC * sizeof(FItem) + (double)capU * sizeof(FItem) + (double)capW * 8 + (double)capA * 8
-                            + (double)capL * 24 + (double)scratchLanes * capE * (8 + 40 + 16);
+                            + (double)capL * 24 + fixed;
         if (need > room) {
-            const double f = std::max(0.05, (room - (double)scratchLanes * capE * 64) / (need - (double)scratchLanes * capE * 64));
+            const double f = std::max(0.05, (room - fixed) / (need - fixed));
             capC = std::max<long long>(1 << 16, (long long)(capC * f)); capU = std::max<long long>(1 << 14, (long long)(capU * f));
-            capL = 3 * capU; capW = capL * meanEnt; capA = 2 * capW;
+            capL = 2 * capU; capW = 2 * capL * meanEnt; capA = capW;
         }
     }
     const long long capRecs = std::max<long long>(1 << 14, (long long)m * 16);
@@ -680,6 +767,8 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, F.sw.reserve_exact((size_t)scratchLanes * capE));
     HIPCK(c, F.sa.reserve_exact((size_t)scratchLanes * capE * 5));
     HIPCK(c, F.sais.reserve_exact((size_t)scratchLanes * capE * 2));
+    HIPCK(c, F.bw.reserve_exact((size_t)capBig));
+    HIPCK(c, F.ba.reserve_exact((size_t)capBig * 5));
     HIPCK(c, F.nodes.reserve((size_t)m));
     HIPCK(c, F.out.reserve((size_t)m * sizeof(SearchOut)));
     FPools fp;
@@ -689,6 +778,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     fp.capW = (long long)F.tw.cap; fp.capA = (long long)F.ta.cap;
     fp.capL = (long long)std::min(std::min(F.toffW.cap, F.toffA.cap), std::min(F.tn.cap, F.tna.cap));
     fp.sw = F.sw.p; fp.sa = F.sa.p; fp.sais = F.sais.p; fp.capE = capE;
+    fp.bw = F.bw.p; fp.ba = F.ba.p; fp.capBig = (long long)F.bw.cap;
     fp.ctr = (FCtr *)F.ctr.p; fp.S = (FSearch *)F.srch.p; fp.recs = (FRec *)F.recs.p;
     fp.capRecs = (long long)(F.recs.cap / sizeof(FRec));
     hipStream_t s = c->stream;
@@ -709,12 +799,25 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     std::memset(&hc, 0, sizeof hc);
     int levels = 0;
     const int gridCached = 2048;
+    std::vector<size_t> slotsC;
+    auto level = [&]() -> int {                                            // the kernels of one level, each between its own events
+        hipEvent_t a0, a1, b0, b1;
+        TRY(maple_internal_ev_pair(c, &a0, &a1, MAPLE_K_FR_UPDATING, 0.0, 0.0));
+        HIPCK(c, hipEventRecord(a0, s));
+        FR_DISPATCH3(c, k_fr_updating, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget));
+        HIPCK(c, hipEventRecord(a1, s));
+        TRY(maple_internal_ev_pair(c, &b0, &b1, MAPLE_K_FR_CACHED, 0.0, 0.0));
+        slotsC.push_back(c->ev_used / 2 - 1);
+        HIPCK(c, hipEventRecord(b0, s));
+        FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget));
+        HIPCK(c, hipEventRecord(b1, s));
+        levels++;
+        return MAPLE_OK;
+    };
     for (;;) {
         for (int g = 0; g < 8; g++) {
             k_fr_snap<<<1, 64, 0, s>>>(fp.ctr);
-            FR_DISPATCH3(c, k_fr_updating, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget));
-            FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget));
-            levels++;
+            TRY(level());
         }
         k_fr_snap<<<1, 64, 0, s>>>(fp.ctr);
         HIPCK(c, hipGetLastError());
@@ -722,12 +825,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, hipStreamSynchronize(s));
         if (hc.hiU == hc.loU && hc.hiC == hc.loC) break;
         // (the snap above opened the next level: the loop's first snap would skip it -- undo by running its kernels first)
-        FR_DISPATCH3(c, k_fr_updating, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget));
-        FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget));
-        levels++;
+        TRY(level());
         if (levels > 100000) return fail(c, MAPLE_ERR_FATAL, "frontier search did not terminate");
     }
-    TRY(maple_internal_ev_pair(c, &er0, &er1, MAPLE_K_OTHER, 0.0, 0.0));
+    TRY(maple_internal_ev_pair(c, &er0, &er1, MAPLE_K_FR_REPLAY, (double)m, 0.0));
     HIPCK(c, hipEventRecord(er0, s));
     k_fr_replay<<<gridN, FR_BLOCK, 0, s>>>(P, m, fp, dout);
     FR_DISPATCH3(c, k_fr_refine, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, fp));
@@ -748,6 +849,8 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
             bytes += meanCand * hostOut[k].nAppend + (l >= 0 ? 8.0 * c->h_n_ent[l] + 8.0 * c->h_n_aux[l] : 0.0);
         }
         c->ev_units[slotEv] = units; c->ev_bytes[slotEv] = bytes;
+        // the cached-regime kernel's own share: what its launches scored (counted on the device), booked on the first launch
+        if (!slotsC.empty()) { c->ev_units[slotsC[0]] = (double)hc.scoredC; c->ev_bytes[slotsC[0]] = (double)hc.bytesC; }
     }
     if (stats) {
         stats->levels = levels; stats->itemsUpdating = (long long)hc.usedU; stats->itemsCached = (long long)hc.usedC;

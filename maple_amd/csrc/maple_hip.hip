@@ -2088,7 +2088,7 @@ extern "C" int maple_evaluate_placement_batch(maple_ctx *c, int32_t n, const int
 // ---- device-resident forms ---------------------------------------------------------------------------
 int maple_internal_ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b, int kind, double units, double bytes)
 {
-    if (c->ev_used >= 8192) c->ev_used = 0;       // nobody is reading these timings: recycle the event pairs
+    if (c->ev_used >= 65536) c->ev_used = 0;      // nobody is reading these timings: recycle the event pairs
     const size_t slot = c->ev_used / 2;
     if (c->ev_kind.size() <= slot) { c->ev_kind.resize(slot + 1); c->ev_units.resize(slot + 1); c->ev_bytes.resize(slot + 1); }
     c->ev_kind[slot] = kind; c->ev_units[slot] = units; c->ev_bytes[slot] = bytes;
@@ -3122,7 +3122,11 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         if (afterLaunch) { std::function<int()> f; f.swap(afterLaunch); TRY(f()); }   // (the side-stream scoring starts alongside)
         std::vector<SearchOut> part(n);
         FrontierStats fs;
-        TRY(frontier_search(c, P, n, todo.data(), hybrid ? wideBudget : 0, (hybrid && wideBudget > MAPLE_ZERO_DIST_BUDGET) ? MAPLE_ZERO_DIST_BUDGET : (1 << 30),
+        // An item of the frontier tier costs about what half a (search, branch) pair costs the dense tier on full walks (1.1e9
+        // items/s against 2.3e9 pairs/s), so a search only pays for a row of the whole tree once it has expanded half a tree's
+        // worth of items; the searches from zero-length branches (whole-tree searches without an error model) never start here.
+        const int frontierBudget = hybrid ? std::max(wideBudget, sp->wideSearchBudget == 0 ? c->n_scored / 2 : 0) : 0;
+        TRY(frontier_search(c, P, n, todo.data(), frontierBudget, (hybrid && wideBudget > MAPLE_ZERO_DIST_BUDGET) ? MAPLE_ZERO_DIST_BUDGET : (1 << 30),
                             part.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs));
         std::vector<int32_t> todoFb, slotFb;
         for (int i = 0; i < n; i++) {

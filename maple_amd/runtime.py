@@ -545,6 +545,7 @@ class Device:
         return n.value, ms.value
 
     KIND_SPR_SCORE, KIND_SPR_SEARCH, KIND_SPR_REPLAY, KIND_APPEND_QUERIES, KIND_APPEND_PAIRS, KIND_PLACE_SCORE = 1, 2, 3, 4, 5, 6
+    KIND_FR_UPDATING, KIND_FR_CACHED, KIND_FR_REPLAY = 7, 8, 9
 
     def timing_read_kind(self, kind):
         """(launches, summed HIP-event ms, units of work, algorithmic bytes) of one kind of timed launch since the reset."""
