@@ -175,6 +175,7 @@ struct maple_ctx {
     PinBuf pin_res;                     // small per-launch results (a copy into pageable memory costs an extra ~10 us)
     DevBuf<int16_t> p_i16;
     DevBuf<uint8_t> p_u8, p_minor;
+    DevBuf<uint32_t> p_from;
     int32_t *d_tile_counters = nullptr;    // ring of tile counters for the dynamically scheduled kernels
     int tile_counter_next = 0;
     void *upd = nullptr;               // UpdateScratch of maple_update_partials (update_host.h)

@@ -12,5 +12,5 @@ struct FrontierStats {
 __attribute__((visibility("hidden")))
 int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *nodes, int budget, int zeroBudget, SearchOut *hostOut,
                     uint2 *poolW, double *poolA, unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
-                    FrontierStats *stats);
+                    FrontierStats *stats, long long itemsHint);   // itemsHint: expected expanded items (0 = by the budget)
 __attribute__((visibility("hidden"))) void frontier_scratch_free(maple_ctx *c);

@@ -717,7 +717,7 @@ void frontier_scratch_free(maple_ctx *c)
 // -5 = over `budget` expanded items (dense tier), FR_STATUS_FALLBACK = hand to the one-lane-per-search kernel.
 int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *nodes, int budget, int zeroBudget, SearchOut *hostOut,
                     uint2 *poolW, double *poolA, unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
-                    FrontierStats *stats)
+                    FrontierStats *stats, long long itemsHint)
 {
     if (!c->frontier) c->frontier = new FrontierScratch();
     FrontierScratch &F = *(FrontierScratch *)c->frontier;
@@ -729,7 +729,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
                         + F.sw.cap * sizeof(uint2) + F.sa.cap * sizeof(double) + F.sais.cap * sizeof(double) + F.bw.cap * 48;
     const double room = 0.5 * (double)(freeB + held);
     const long long perSearchC = std::min<long long>(budget, 768);
-    long long capC = std::max<long long>(1 << 16, (long long)m * perSearchC);
+    long long capC = std::max<long long>(1 << 16, std::max((long long)m * perSearchC, itemsHint));
     long long capU = std::max<long long>(1 << 14, (long long)m * std::min<long long>(budget, 12));
     const long long meanEnt = std::max<long long>(16, c->h_n_ent.empty() ? 64 : c->used_ent / (long long)c->h_n_ent.size());   // entries per list in the arena
     long long capL = 2 * capU;

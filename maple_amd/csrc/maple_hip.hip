@@ -1256,7 +1256,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     for (auto &b : c->p_i32) b.release();
     for (auto &b : c->p_f64) b.release();
     c->pin_place.release(); c->pin_res.release();
-    c->p_score.release(); c->p_i16.release(); c->p_u8.release(); c->p_minor.release();
+    c->p_score.release(); c->p_i16.release(); c->p_u8.release(); c->p_minor.release(); c->p_from.release();
     if (c->place) {
         PlaceMeta &M = *c->place;
         M.d_scan.release(); M.d_frameOf.release(); M.d_candIdx.release(); M.d_leafIdx.release(); M.d_candList.release(); M.d_candFrame.release();
@@ -2824,6 +2824,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     bool assistOK = !getenv("MAPLE_NO_LEAN") && (!c->dm.usingErrorRate || getenv("MAPLE_LEAN_ERR"));
     const bool assistFew = !c->dm.usingErrorRate;      // few searching lanes per wavefront, every request served by all 64 lanes
     if (getenv("MAPLE_NO_LEAN_MAT") && c->tree_has_mut) assistOK = false;                                              // (experiments)
+    // (the frontier tier, frontier.hip, takes the searches of trees without MAT local references)
+    const bool useFrontier = sp->searchTier == 0 && !c->tree_has_mut && c->trace_query < 0;
     const std::vector<int32_t> *rowOverride = nullptr;                 // rows of the score table the next cached launch reads
     std::function<int()> afterLaunch;                                  // called once, right after the next search kernel is queued
     auto run_queries = [&](std::vector<int32_t> todo, std::vector<int32_t> slot, const double *cacheS, int budgetNow,
@@ -2970,6 +2972,23 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             todo.swap(todo2);
             slot.swap(slot2);
             rows.swap(rows2);
+            if (cacheS && useFrontier && !todo.empty()) {
+                // Whole-tree searches that ran out of per-lane workspace (near the root, where an updating step merges lists of
+                // several hundred entries): a retry with more room is a 100 ms tail of a handful of one-lane searches.  The
+                // frontier tier expands them over the whole tree instead -- a million items, a few ms.
+                const int mF = (int)todo.size();
+                std::vector<SearchOut> part2(mF);
+                FrontierStats fs2;
+                TRY(frontier_search(c, P, mF, todo.data(), 0, 1 << 30, part2.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs2,
+                                    (long long)mF * (c->dtree.n + 64)));
+                std::vector<int32_t> t3, s3, r3;
+                for (int k = 0; k < mF; k++) {
+                    if (part2[k].status == FR_STATUS_FALLBACK) { t3.push_back(todo[k]); s3.push_back(slot[k]); r3.push_back(rows[k]); }
+                    else ho[slot[k]] = part2[k];
+                }
+                if (getenv("MAPLE_DEBUG")) fprintf(stderr, "[maple]   %d of them through the frontier tier (%lld items), %zu left\n", mF, fs2.itemsCached, t3.size());
+                todo.swap(t3); slot.swap(s3); rows.swap(r3);
+            }
             // (the budget stays: a retried search that turns out to be wide still goes to the batch path)
         }
         return MAPLE_OK;
@@ -3117,7 +3136,6 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // Frontier tier (frontier.hip): every search of the batch expanded level by level, one lane per (search, branch) item,
     // then replayed exactly -- for trees without MAT local references.  What it hands back (a search that would edit its
     // removed list in place, touches the root while still updating lists, or overflows a pool) runs one lane per search.
-    const bool useFrontier = sp->searchTier == 0 && !c->tree_has_mut && c->trace_query < 0;
     if (useFrontier) {
         if (afterLaunch) { std::function<int()> f; f.swap(afterLaunch); TRY(f()); }   // (the side-stream scoring starts alongside)
         std::vector<SearchOut> part(n);
@@ -3127,7 +3145,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         // worth of items; the searches from zero-length branches (whole-tree searches without an error model) never start here.
         const int frontierBudget = hybrid ? std::max(wideBudget, sp->wideSearchBudget == 0 ? c->n_scored / 2 : 0) : 0;
         TRY(frontier_search(c, P, n, todo.data(), frontierBudget, (hybrid && wideBudget > MAPLE_ZERO_DIST_BUDGET) ? MAPLE_ZERO_DIST_BUDGET : (1 << 30),
-                            part.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs));
+                            part.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs, 0));
         std::vector<int32_t> todoFb, slotFb;
         for (int i = 0; i < n; i++) {
             ho[i] = part[i];

@@ -33,6 +33,9 @@ struct PlaceOut {
     double *slLK;
     uint8_t *slShort;                  // was the query list of that node's frame shortened (M:8066) by the end of the walk
     uint8_t *bestShort;
+    uint32_t *fromBits;                // one bit per MAT frame: the frame's query list was made (passGenomeListThroughBranch at the
+                                       // push of the frame's node, M:8084-8092) from a parent-frame list that HAD been shortened
+                                       // by then -- laid out like the frame bits; may be null
 };
 
 // The tree in the traversal's own depth-first order (the child pushed last, child 1, first): rank r+1 is the first child
@@ -46,7 +49,7 @@ struct alignas(32) ScanRec {
     int32_t candCol;                   // column in the score matrix or -1 (M:8049: dist > effectivelyNon0BLen, up != None)
     int32_t leafCol;                   // column in the minor-sequence matrix; >= 0 exactly for leaves
     int32_t frame;                     // MAT reference frame of the node
-    int32_t pad[2];
+    int32_t childFrame[2];             // frames of the two children where they differ from the node's own, else -1
 };
 
 // The traversal of ONE query over the scan array.  Lane q of nQ keeps element i of its per-depth state / frame bits at
@@ -59,6 +62,7 @@ __host__ __device__ inline void place_replay_one(const ScanRec *R, int nReach, c
 {
     const int words = (nF + 31) >> 5;
     for (int i = 0; i < words; i++) frameBits[(long long)i * nQ + q] = 0u;
+    if (o.fromBits) for (int i = 0; i < words; i++) o.fromBits[(long long)i * nQ + q] = 0u;
     int32_t *slN = o.slNode + (long long)q * MAPLE_PLACE_SHORTLIST;
     double *slL = o.slLK + (long long)q * MAPLE_PLACE_SHORTLIST;
     int nSl = 0, status = 0, minorNode = -1, missed = 0, nAppend = 1;
@@ -120,6 +124,13 @@ __host__ __device__ inline void place_replay_one(const ScanRec *R, int nReach, c
         const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);   // M:8080-8093
         stLK[(long long)d * nQ + q] = lk; stFails[(long long)d * nQ + q] = (int16_t)fails;
         curLK = lk; curFails = fails; prevDepth = d;
+        if (go && o.fromBits && (rec.childFrame[0] >= 0 || rec.childFrame[1] >= 0)) {
+            // the children are pushed now: a child in a frame of its own gets its list from this frame's list as it is NOW
+            const int f = rec.frame;
+            if ((frameBits[(long long)(f >> 5) * nQ + q] >> (f & 31)) & 1u)
+                for (int k = 0; k < 2; k++)
+                    if (rec.childFrame[k] >= 0) o.fromBits[(long long)(rec.childFrame[k] >> 5) * nQ + q] |= 1u << (rec.childFrame[k] & 31);
+        }
         if ((go && rec.leafCol < 0) || rec.size == 1) { r += 1; rec = ahead; }   // into the clade, or past a leaf
         else { r += rec.size; if (r < nReach) rec = R[r]; }               // past a pruned clade
     }

@@ -119,7 +119,8 @@ static int place_meta(maple_ctx *c, double effNon0)
             ScanRec &r = M.h_scan[i];
             r.node = v; r.size = size[v]; r.depth = depth[v];
             r.candCol = candIdx[v]; r.leafCol = leafIdx[v]; r.frame = M.frameOf[v];
-            r.pad[0] = r.pad[1] = 0;
+            r.childFrame[0] = (c0[v] >= 0 && M.frameOf[c0[v]] != M.frameOf[v]) ? M.frameOf[c0[v]] : -1;
+            r.childFrame[1] = (c0[v] >= 0 && M.frameOf[c->h_tree_c1[v]] != M.frameOf[v]) ? M.frameOf[c->h_tree_c1[v]] : -1;
         }
         TRY(h2d(c, M.d_scan, M.h_scan.data(), nr));
     }
@@ -149,6 +150,7 @@ static void place_replay_ptr(const maple_ctx *c, const PlaceMeta &M, const Place
     const int32_t root = c->dtree.root;
     const auto &c0 = c->h_tree_c0, &c1 = c->h_tree_c1;
     std::vector<uint32_t> frameBits((size_t)(nF + 31) >> 5, 0u);
+    if (o.fromBits) for (int i = 0; i < (nF + 31) >> 5; i++) o.fromBits[i] = 0u;
     int32_t *slN = o.slNode;
     double *slL = o.slLK;
     int nSl = 0, status = 0, minorNode = -1, missed = 0, nAppend = 1;
@@ -194,7 +196,13 @@ static void place_replay_ptr(const maple_ctx *c, const PlaceMeta &M, const Place
         }
         const bool within = lk > bestLK - P.thrLK;
         const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);   // M:8080-8093
-        if (go && c0[t1] >= 0) { st.push_back(It{c0[t1], fails, lk}); st.push_back(It{c1[t1], fails, lk}); }
+        if (go && c0[t1] >= 0) {
+            st.push_back(It{c0[t1], fails, lk}); st.push_back(It{c1[t1], fails, lk});
+            const int f = M.frameOf[t1];
+            if (o.fromBits && ((frameBits[f >> 5] >> (f & 31)) & 1u))       // (see place_replay_one)
+                for (int32_t ch : {c0[t1], c1[t1]})
+                    if (M.frameOf[ch] != f) o.fromBits[M.frameOf[ch] >> 5] |= 1u << (M.frameOf[ch] & 31);
+        }
     }
     int k = 0;
     for (int i = 0; i < nSl; i++)
@@ -398,6 +406,8 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
         std::vector<int32_t> hi;
         std::vector<double> hf;
         std::vector<uint8_t> hb;
+        std::vector<uint32_t> hFrom;                                       // per query: the "made from a shortened list" bit of every frame
+        bool fromLaneMajor = false;                                        // (device replay: word i of query q at [i * nq + q])
         if (hostReplay) {
             // a handful of queries (the sequential placement loop hands over one at a time): one lane's ~1 us per visit
             // would dominate the call, so the scores come back (8 bytes per branch) and the SAME traversal function
@@ -418,6 +428,8 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
             o.missed = ib + 4 * (size_t)nq; o.nShort = ib + 5 * (size_t)nq; o.slNode = ib + 6 * (size_t)nq;
             o.bestLK = hf.data(); o.originalLK = hf.data() + nq; o.slLK = hf.data() + 2 * (size_t)nq;
             o.bestShort = hb.data(); o.slShort = hb.data() + nq;
+            hFrom.assign((size_t)nq * words, 0u);
+            o.fromBits = nF > 1 ? hFrom.data() : nullptr;
             std::vector<double> stL(stackCap);
             std::vector<int16_t> stF(stackCap);
             std::vector<uint32_t> bits(words);
@@ -427,6 +439,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                 oq.status += q; oq.minorNode += q; oq.bestNode += q; oq.nAppend += q; oq.missed += q; oq.nShort += q;
                 oq.bestLK += q; oq.originalLK += q; oq.bestShort += q;
                 oq.slNode += (size_t)q * SL; oq.slLK += (size_t)q * SL; oq.slShort += (size_t)q * SL;
+                if (oq.fromBits) oq.fromBits += (size_t)q * words;
                 place_replay_ptr(c, M, P, hs + (size_t)q * nCols, nC, hm + (size_t)q * std::max(nL, 1), nF, oq);
             }
         } else {
@@ -443,6 +456,9 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
             double *fb = c->p_f64[1].p;
             o.bestLK = fb; o.originalLK = fb + nq; o.slLK = fb + 2 * (size_t)nq;
             o.bestShort = c->p_u8.p; o.slShort = c->p_u8.p + nq;
+            HIPCK(c, c->p_from.reserve((size_t)nq * words));
+            o.fromBits = nF > 1 ? (uint32_t *)c->p_from.p : nullptr;
+            fromLaneMajor = true;
             hipLaunchKernelGGL(k_place_replay, dim3((nq + 63) / 64), dim3(64), 0, c->stream, M.d_scan.p, (int)M.h_scan.size(), P, nq,
                                nCols, nC, c->p_score.p, std::max(nL, 1), c->p_minor.p, M.d_frameOf.p, nF, stackCap, c->p_f64[0].p,
                                c->p_i16.p, (uint32_t *)c->p_i32[2].p, o);
@@ -450,6 +466,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
             TRY(d2h_vec(c, hi, ib, (size_t)nq * (6 + SL)));
             TRY(d2h_vec(c, hf, fb, (size_t)nq * (2 + SL)));
             TRY(d2h_vec(c, hb, c->p_u8.p, (size_t)nq * (1 + SL)));
+            if (nF > 1) TRY(d2h_vec(c, hFrom, (const uint32_t *)c->p_from.p, (size_t)nq * words));
             HIPCK(c, hipStreamSynchronize(c->stream));
         }
         auto t3 = tnow();
@@ -481,6 +498,36 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
         auto qlist = [&](int q, int node, bool shortened) {
             const size_t key = (size_t)q * nF + M.frameOf[node];
             return shortened ? S[key] : U[key];
+        };
+        // The list OBJECT the reference hands back as bestDiffs (M:8071 / 8186 / 8003).  A frame's query list is made once, when
+        // the frame's node is pushed, from the parent frame's list as it is THEN: if that one had already been shortened in
+        // place (M:8066), the child's list descends from the shortened form and differs -- in how reference runs are cut, not
+        // in what it says -- from passing the original list down (U) and shortening that (S).  Rare; rebuilt along the chain
+        // of frames when it happens.  *out = list id.
+        auto from_bit = [&](int q, int f) -> bool {
+            if (hFrom.empty()) return false;
+            const uint32_t w = fromLaneMajor ? hFrom[(size_t)(f >> 5) * nq + q] : hFrom[(size_t)q * words + (f >> 5)];
+            return (w >> (f & 31)) & 1u;
+        };
+        auto exact_qlist = [&](int q, int node, bool shortened, int32_t *outId) -> int {
+            std::vector<int> chain;                                        // frames from the node's up to the top one
+            for (int f = M.frameOf[node]; f > 0; f = M.frameParent[f]) chain.push_back(f);
+            int first = -1;                                                // the outermost frame made from a shortened list
+            for (int i = (int)chain.size() - 1; i >= 0; i--) if (from_bit(q, chain[i])) { first = i; break; }
+            if (first < 0) { *outId = qlist(q, node, shortened); return MAPLE_OK; }
+            int32_t cur = U[(size_t)q * nF + (first + 1 < (int)chain.size() ? chain[first + 1] : 0)];
+            for (int i = first; i >= 0; i--) {
+                const int f = chain[i];
+                if (from_bit(q, f)) { int32_t sh; TRY(maple_shorten_batch(c, 1, &cur, &sh)); cur = sh; }
+                const int32_t ml = c->h_tree_mut[M.frameNode[f]];
+                const uint8_t down = 0;
+                int32_t nx;
+                TRY(maple_pass_branch_batch(c, 1, &cur, &ml, &down, &nx));
+                cur = nx;
+            }
+            if (shortened) { int32_t sh; TRY(maple_shorten_batch(c, 1, &cur, &sh)); cur = sh; }
+            *outId = cur;
+            return MAPLE_OK;
         };
         auto t4 = tnow();
         // ---- short-list refinement, M:8101-8187: one batch over every (query, short-listed node)
@@ -643,7 +690,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
             if (hStatus[q] < 0) { bestNode[g] = -1; bestScore[g] = 0.0; bestDiffs[g] = -1; continue; }
             if (hStatus[q] == 1) {                                        // M:7986-8003: placed as a minor sequence
                 bestNode[g] = hMinor[q]; bestScore[g] = 1.0;
-                bestDiffs[g] = qlist(q, hMinor[q], hBestShort[q] != 0);
+                TRY(exact_qlist(q, hMinor[q], hBestShort[q] != 0, &bestDiffs[g]));
                 continue;
             }
             int32_t bn = hBest[q];
@@ -664,7 +711,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
             if (bs == -INFINITY) bs = hOrig[q];
             nAppend[g] += 3 * hNShort[q];
             bestNode[g] = bn; bestScore[g] = bs;
-            bestDiffs[g] = qlist(q, bn, bshort);
+            TRY(exact_qlist(q, bn, bshort, &bestDiffs[g]));
         }
         }
         if (manyChunks) {

@@ -136,9 +136,12 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
         for (size_t i = 0; i < nodes.size(); i++) { const int p = up[nodes[i]]; out[i] = c0[p] == nodes[i] ? upRight[p] : upLeft[p]; }
         return upd_passed(c, mut, out, nodes, false);
     };
+    int roundNo = 0;
+    std::vector<int32_t> redoNow, redoNext;                                // nodes whose upper vectors an earlier round left undone
+    auto repair = [&](const std::vector<int32_t> &chg, std::vector<int32_t> &next) -> int {
     std::vector<int32_t> frontier;
-    for (int i = 0; i < nChanged; i++) {
-        const int v = changed[i];
+    for (size_t i = 0; i < chg.size(); i++) {
+        const int v = chg[i];
         S.dLow[v] = 1; S.dDist[v] = 1; S.touch(v);
         if (up[v] >= 0) {
             markChild(up[v], whichChild(up[v], v));
@@ -226,6 +229,7 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
             if ((S.dLow[v] || S.dCh0[v] || S.dCh1[v]) && !S.inTodo[v]) { S.inTodo[v] = 1; todo.push_back(v); }
     }
     auto addTodo = [&](int v) { if (!S.inTodo[v]) { S.inTodo[v] = 1; S.touch(v); todo.push_back(v); } };
+    for (int v : redoNow) { S.dUp[v] = 1; S.touch(v); addTodo(v); }
     std::vector<int32_t> vu, sel, kid, nv, pk;
     while (!todo.empty()) {
         int dmin = 1 << 30;
@@ -305,11 +309,49 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
         out.resize(m);
         TRY(update_items(c, (int32_t)m, iL1.data(), iB1.data(), iT1.data(), iL2.data(), iB2.data(), iT2.data(), iUd.data(), iMode.data(),
                          iOld.data(), out.data(), none.data(), diff.data()));
+        std::vector<int32_t> deferred;                                     // nodes of this level that met an inconsistency
         for (size_t i = 0; i < m; i++) {
             const int v = iNode[i];
-            if (none[i])
-                return fail(c, MAPLE_ERR_FATAL, iKind[i] == 0 ? "None probVectTotUp on a branch of non-zero length (node %d)"
-                                                              : "None upper vector at node %d (the reference would call updateBLen here)", v);
+            if (none[i]) {
+                // An inconsistency between zero-length branches (M:5522-5528, 5568-5600): the reference re-estimates the branch
+                // above the node (updateBLen, M:5385-5414) and, if that stays at zero, the branch above the child that was being
+                // merged, then repairs from there.  Here: the same estimates, and the node whose length changed starts another
+                // round of the level loops.
+                const int kd = iKid[i];
+                if (getenv("MAPLE_DEBUG"))
+                    fprintf(stderr, "[maple] updatePartials round %d: None %s at node %d (length %.3g), child %d (length %.3g), merged with b1 %.3g b2 %.3g\n",
+                            roundNo, iKind[i] == 0 ? "probVectTotUp" : (iKind[i] == 1 ? "probVectUpRight" : "probVectUpLeft"), v, dist[v], kd,
+                            kd >= 0 ? dist[kd] : -1.0, iB1[i], iB2[i]);
+                bool done = false;
+                for (int32_t w : deferred) if (w == v) done = true;          // (its other merge already dealt with it)
+                if (done) continue;
+                if (iKind[i] != 0 && (dist[v] != 0.0 || dist[kd] != 0.0))
+                    return fail(c, MAPLE_ERR_FATAL, "None upper vector from non-zero distances at node %d (the reference raises too)", v);
+                deferred.push_back(v);
+                redoNext.push_back(v);
+                const int cand[2] = {v, kd};
+                for (int ci = 0; ci < 2 && !done; ci++) {
+                    const int w = cand[ci];
+                    if (w < 0 || up[w] < 0) continue;
+                    std::vector<int32_t> one{w}, vu1;
+                    TRY(vectUpOf(one, vu1));
+                    double t = 0.0;
+                    uint8_t isFalse = 0;
+                    const uint8_t tipc = tip[w];
+                    TRY(maple_blen_batch(c, 1, vu1.data(), &lower[w], &tipc, &t, &isFalse));
+                    dist[w] = isFalse ? 0.0 : t;
+                    S.replacedNodes.push_back(w);
+                    if (dist[w] != 0.0) { next.push_back(w); done = true; }
+                }
+                if (!done) return fail(c, MAPLE_ERR_FATAL, "None upper vector at node %d and no branch length to lengthen", v);
+                continue;
+            }
+        }
+        // (the reference recomputes ALL of such a node's vectors with the new length before anything goes on to its children,
+        // M:5575-5600: none of what this level computed for it with the old length is used; the next round redoes the node)
+        for (size_t i = 0; i < m; i++) {
+            const int v = iNode[i];
+            if (none[i] || std::find(deferred.begin(), deferred.end(), v) != deferred.end()) continue;
             if (iKind[i] == 0) { totUp[v] = out[i]; S.replacedNodes.push_back(v); replaced++; continue; }
             if (!diff[i]) continue;
             (iKind[i] == 1 ? upRight : upLeft)[v] = out[i];
@@ -319,6 +361,19 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
             S.dUp[target] = 1; S.touch(target);
             addTodo(target);
         }
+    }
+    return MAPLE_OK;
+    };
+    std::vector<int32_t> chg(changed, changed + nChanged), next;
+    for (int round = 0; !chg.empty() || !redoNext.empty(); round++) {
+        if (round >= 64) return fail(c, MAPLE_ERR_FATAL, "updatePartials keeps finding inconsistent zero-length branches");
+        next.clear();
+        roundNo = round;
+        redoNow.swap(redoNext);
+        redoNext.clear();
+        TRY(repair(chg, next));
+        S.clear();
+        chg.swap(next);
     }
     S.clear();
     *nReplaced = replaced;
