@@ -157,9 +157,10 @@ struct maple_ctx {
     bool scan_valid = false;
     double scan_eff = -1.0;
     std::vector<int32_t> h_depth;      // per node: distance from the root in branches
+    std::vector<int32_t> h_clade;      // per node: nodes in its clade (itself included); filled on first use, dropped with the tree
     int32_t tree_max_depth = 0;
     // SPR search workspace
-    DevBuf<uint8_t> s_search_ws;
+    DevBuf<uint8_t> s_search_ws, s_search_ws_big;
     DevBuf<uint8_t> s_search_out;
     DevBuf<int32_t> s_counter;
     DevBuf<double> s_cache;            // cached (query x node) scores of wide searches

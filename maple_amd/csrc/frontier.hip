@@ -30,6 +30,12 @@
 // items are whole-tree searches and go to the dense tier (status -5), as before.
 #include "ctx_host.h"
 #include "frontier.h"
+// (this translation unit's wavefront-wide walks serve the FEW items with the longest lists, one wavefront per compute unit:
+// staging areas for lists of 512 entries, 110 KB of LDS)
+#define MAPLE_WAVE_CAPW 512
+#define MAPLE_WU_IN 512
+#include "wave_dev.h"
+#include "wave_update.h"
 
 #include <algorithm>
 #include <cstring>
@@ -280,20 +286,14 @@ __device__ __forceinline__ PRule p_rule(const SearchParams &P, bool scored, doub
 
 // ---- items that arrived with needsUpdating == True (M:6982-7091, 7182-7304): lists merged along the path ----------------
 // (dir 3: the seeding of a search whose pruned node hangs off the root, M:6916-6960 -- two rootVector calls)
+// one such item by one lane (the one-lane list walks of genome_dev.h)
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, FPools fp, int budget)
+__device__ __forceinline__ void fr_upd_item_lane(const Ctx<RV, U, SS> &c, const ArenaViewS &av, const DevTree &T, const SearchParams &P, const FPools &fp,
+                                 const int budget, const long long laneId, const long long i)
 {
-    __shared__ Lds lds;
-    const DevModel &m = *mp;
-    stage_model(m, lds);
-    Ctx<RV, U, SS> c(m, lds);
-    const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
-    for (long long i = lo + laneId; i < hi; i += (long long)gridDim.x * blockDim.x) {
         FItem &it = fp.U[i];
         FSearch &S = fp.S[it.q];
-        if (S.state != FS_ACTIVE) { it.flags |= FI_DEAD; continue; }
+        if (S.state != FS_ACTIVE) { it.flags |= FI_DEAD; return; }
         const int q = it.q, t1 = it.t1;
         const NodeRec r1 = T.nd[t1];
         const int hPassed = it.hPassed, hRpr = it.hRpr;
@@ -337,17 +337,17 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
                 const NodeRec rc1 = T.nd[ch1], rc2 = T.nd[ch2];
                 const int v1 = rootVector(ftree(rc2.lower), rc2.dist, rc2.isTip != 0);
                 const int v2 = v1 < 0 ? -2 : rootVector(ftree(rc1.lower), rc1.dist, rc1.isTip != 0);
-                if (v1 < 0 || v2 < 0) { S.state = FS_FALLBACK; continue; }
+                if (v1 < 0 || v2 < 0) { S.state = FS_FALLBACK; return; }
                 it.child0 = fpush(fp, budget, q, true, ch1, 0, v1, rc1.dist, lastLK, 0, hRpr, it.pathBest);
                 it.child1 = fpush(fp, budget, q, true, ch2, 0, v2, rc2.dist, lastLK, 0, hRpr, it.pathBest);
             }
-            continue;
+            return;
         }
         if (it.dir == 0) {                                                  // moving from a parent to its child, M:6982-7160
             const int upT = r1.up;
             const bool scored = !(upT == S.parent || upT < 0) && (r1.dist > P.effNon0 || r1.upIsRoot);
             if (scored) {
-                if (merge(hPassed, distance / 2, false, ftree(r1.lower), distance / 2, r1.isTip != 0, true) != 0) { it.flags |= FI_DEAD; continue; }
+                if (merge(hPassed, distance / 2, false, ftree(r1.lower), distance / 2, r1.isTip != 0, true) != 0) { it.flags |= FI_DEAD; return; }
                 const ListRef mid{scr.w, scr.a};
                 if (r1.totUp >= 0) { const FList tu = flist(av, fp, ftree(r1.totUp)); if (!differ_walk(c, mid, fref(tu))) upd = false; }
                 const FList lr = flist(av, fp, hRpr);
@@ -355,7 +355,7 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
                 it.flags |= FI_SCORED;
                 if (upd && midProb >= it.pathBest - P.thrOptTopo) {          // may be short-listed (M:7071): keep the record's lists
                     const int hm = fstore(fp, wr);
-                    if (hm < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; continue; }
+                    if (hm < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; return; }
                     it.hA = hPassed; it.hB = ftree(r1.lower); it.hMid = hm; it.recDist = distance; it.flags |= FI_REC_UPD;
                 }
             }
@@ -389,11 +389,11 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
             const bool scored = upT >= 0 && (r1.dist > P.effNon0 || r1.upIsRoot);
             if (scored) {
                 int r = merge(hPassed, distance, false, ftree(ro.lower), ro.dist, ro.isTip != 0, false);
-                if (r != 0) { it.flags |= FI_DEAD; continue; }
+                if (r != 0) { it.flags |= FI_DEAD; return; }
                 hBottom = fstore(fp, wr);
-                if (hBottom < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; continue; }
+                if (hBottom < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; return; }
                 r = merge(vectUp, r1.dist / 2, false, hBottom, r1.dist / 2, false, true);
-                if (r != 0) { it.flags |= FI_DEAD; continue; }
+                if (r != 0) { it.flags |= FI_DEAD; return; }
                 int hm = -1;
                 if (r1.totUp >= 0) {
                     const ListRef mid{scr.w, scr.a};
@@ -403,10 +403,10 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
                     // "Node has no probVectTotUp ... calculating new one", M:7198-7200: midTot is compared with a list merged on
                     // the spot (midTot moves to the arena first: the scratch is needed for that merge)
                     hm = fstore(fp, wr);
-                    if (hm < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; continue; }
+                    if (hm < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; return; }
                     const int rc = merge(vectUp, r1.dist / 2, false, ftree(r1.lower), r1.dist / 2, false, true);
                     if (rc == 0) { const FList lm = flist(av, fp, hm); if (!differ_walk(c, fref(lm), ListRef{scr.w, scr.a})) upd = false; }
-                    else if (S.state == FS_FALLBACK) { it.flags |= FI_DEAD; continue; }
+                    else if (S.state == FS_FALLBACK) { it.flags |= FI_DEAD; return; }
                 }
                 const FList lr = flist(av, fp, hRpr);
                 if (hm >= 0) { const FList lm = flist(av, fp, hm); midProb = append_walk(c, fref(lm), fref(lr), rt, rbl); }
@@ -414,40 +414,308 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
                 it.flags |= FI_SCORED;
                 if (upd && midProb >= it.pathBest - P.thrOptTopo) {          // M:7293
                     if (hm < 0) hm = fstore(fp, wr);
-                    if (hm < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; continue; }
+                    if (hm < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; return; }
                     it.hA = vectUp; it.hB = hBottom; it.hMid = hm; it.recDist = r1.dist; it.flags |= FI_REC_UPD;
                 }
             }
             it.midProb = midProb;
             if (upd) it.flags |= FI_UPD_OUT;
             const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
-            if (!pr.go) continue;
+            if (!pr.go) return;
             if (upT >= 0) {
                 int hUp = -1;
                 if (upd) {
                     const int r = merge(vectUp, r1.dist, false, hPassed, distance, false, true);
-                    if (r == -2) { S.state = FS_FALLBACK; continue; }
-                    if (r == 0) { hUp = fstore(fp, wr); if (hUp < 0) { S.state = FS_FALLBACK; continue; } }
+                    if (r == -2) { S.state = FS_FALLBACK; return; }
+                    if (r == 0) { hUp = fstore(fp, wr); if (hUp < 0) { S.state = FS_FALLBACK; return; } }
                 } else hUp = ftree(it.dir == 1 ? r1.upLeft : r1.upRight);
-                if (!fvalid(hUp)) continue;
+                if (!fvalid(hUp)) return;
                 it.child0 = upd ? fpush(fp, budget, q, true, other, 0, hUp, ro.dist, midProb, pr.fails, hRpr, pr.pathBest)
                                 : fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
                 if (upd && hBottom < 0) {                                    // M:7376-7384
                     const int r = merge(hPassed, distance, false, ftree(ro.lower), ro.dist, ro.isTip != 0, false);
-                    if (r != 0) continue;
+                    if (r != 0) return;
                     hBottom = fstore(fp, wr);
-                    if (hBottom < 0) { S.state = FS_FALLBACK; continue; }
+                    if (hBottom < 0) { S.state = FS_FALLBACK; return; }
                 }
                 it.child1 = upd ? fpush(fp, budget, q, true, upT, (int)r1.whichChild + 1, hBottom, r1.dist, midProb, pr.fails, hRpr, pr.pathBest)
                                 : fpush(fp, budget, q, false, upT, (int)r1.whichChild + 1, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
             } else {                                                         // t1 is the root, M:7406-7432
                 if (upd) {
                     const int hv = rootVector(hPassed, distance, false);
-                    if (hv < 0) { S.state = FS_FALLBACK; continue; }
+                    if (hv < 0) { S.state = FS_FALLBACK; return; }
                     it.child0 = fpush(fp, budget, q, true, other, 0, hv, ro.dist, midProb, pr.fails, hRpr, pr.pathBest);
                 } else
                     it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
             }
+        }
+}
+
+// (a real call: k_fr_updating_wave falls back to it from three places and is bound by its LDS, not its registers)
+template <bool RV, bool U, bool SS>
+__device__ __noinline__ void fr_upd_item_lane_call(const Ctx<RV, U, SS> &c, const ArenaViewS &av, const DevTree &T, const SearchParams &P,
+                                                   const FPools &fp, const int budget, const long long laneId, const long long i)
+{
+    fr_upd_item_lane(c, av, T, P, fp, budget, laneId, i);
+}
+
+// Is this item one of the few with long lists (near the root)?  One lane walking two lists of several hundred entries takes
+// milliseconds, and a level of the expansion lasts as long as its slowest item: those go to k_fr_updating_wave, a wavefront
+// per item.
+__device__ __forceinline__ bool fr_upd_heavy(const ArenaViewS &av, const DevTree &T, const FPools &fp, const FItem &it, int heavyMin)
+{
+    if (it.dir == 3 || heavyMin <= 0) return false;
+    const NodeRec &r1 = T.nd[it.t1];
+    const int other = it.dir == 0 ? it.t1 : (it.dir == 1 ? r1.c1 : r1.c0);
+    const int lw = T.nd[other].lower;
+    const int nTree = lw >= 0 ? av.n_ent[lw] : 0;
+    const int nPass = it.hPassed >= 0 ? fp.tn[it.hPassed] : (it.hPassed <= -10 ? av.n_ent[-it.hPassed - 10] : 0);
+    return nPass + nTree >= heavyMin;
+}
+
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, FPools fp, int budget, int heavyMin)
+{
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
+    for (long long i = lo + laneId; i < hi; i += (long long)gridDim.x * blockDim.x) {
+        if (fr_upd_heavy(av, T, fp, fp.U[i], heavyMin)) continue;          // (k_fr_updating_wave takes it)
+        fr_upd_item_lane(c, av, T, P, fp, budget, laneId, i);
+    }
+}
+
+// ---- the same items by a whole wavefront: the few whose lists are long -------------------------------------------------------
+// mergeVectors, areVectorsDifferent and appendProbNode cut along the merge path of the two lists (wave_update.h, wave_dev.h:
+// lane d does step d of the walk; bit for bit the one-lane walks), every list of the item in LDS.  An item with a list beyond
+// the staging limit is walked by lane 0 alone.
+__device__ inline int fstore_wave(const FPools &fp, const unsigned long long *w, const double *a, int n, int na)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long id = 0, ow = 0, oa = 0;
+    if (lane == 0) {
+        id = atomicAdd(&fp.ctr->nLists, 1ull);
+        ow = atomicAdd(&fp.ctr->usedW, (unsigned long long)n);
+        oa = atomicAdd(&fp.ctr->usedA, (unsigned long long)na);
+    }
+    auto bc = [](unsigned long long x) {
+        return ((unsigned long long)(uint32_t)__shfl((int)(x >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)x, 0, 64);
+    };
+    id = bc(id); ow = bc(ow); oa = bc(oa);
+    if ((long long)id >= fp.capL || (long long)(ow + n) > fp.capW || (long long)(oa + na) > fp.capA) {
+        if (lane == 0) fp.ctr->overflow = 1;
+        return -2;
+    }
+    unsigned long long *dw = (unsigned long long *)(fp.tw + ow);
+    double *da = fp.ta + oa;
+    for (int k = lane; k < n; k += 64) dw[k] = w[k];
+    for (int k = lane; k < na; k += 64) da[k] = a[k];
+    if (lane == 0) { fp.toffW[id] = (long long)ow; fp.toffA[id] = (long long)oa; fp.tn[id] = n; fp.tna[id] = na; }
+    __threadfence();
+    wave_sync();
+    return (int)id;
+}
+
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(64) void k_fr_updating_wave(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, FPools fp,
+                                                         int budget, int heavyMin, long long laneBase)
+{
+    __shared__ Lds lds;
+    __shared__ WaveUpdLds L;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const int lane = threadIdx.x;
+    WaveLds &W = *reinterpret_cast<WaveLds *>(L.baux);                     // (appendProbNode's staging: baux is free by then)
+    static_assert(sizeof(WaveLds) <= sizeof(L.baux), "LDS alias");
+    const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
+    for (long long base = lo + (long long)blockIdx.x * 64; base < hi; base += (long long)gridDim.x * 64) {
+        const long long mine = base + lane;
+        const bool heavy = mine < hi && fr_upd_heavy(av, T, fp, fp.U[mine], heavyMin);
+        unsigned long long todo = __ballot(heavy);
+        while (todo) {
+            const int j = (int)__ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const long long i = base + j;
+            FItem &it = fp.U[i];
+            FSearch &S = fp.S[it.q];
+            if (S.state != FS_ACTIVE) { if (lane == 0) it.flags |= FI_DEAD; continue; }
+            const int q = it.q, t1 = it.t1, dir = it.dir;
+            const NodeRec r1 = T.nd[t1];
+            const int hPassed = it.hPassed, hRpr = it.hRpr;
+            const double distance = it.distance, lastLK = it.lastLK;
+            const bool rt = S.isRemovedTip != 0;
+            const double rbl = S.removedBLen;
+            const int other = dir == 0 ? -1 : (dir == 1 ? r1.c1 : r1.c0);
+            const int upT = r1.up;
+            // every list the item touches must fit the staging areas; else lane 0 walks the item alone
+            const FList lp = fvalid(hPassed) ? flist(av, fp, hPassed) : FList{nullptr, nullptr, 0, 0};
+            const FList lr = flist(av, fp, hRpr);
+            bool fits = fvalid(hPassed) && lp.n <= MAPLE_WU_IN && lr.n <= MAPLE_WAVE_CAPW;
+            {
+                const int ids[6] = {r1.lower, r1.totUp, dir == 0 && r1.c0 >= 0 ? T.nd[r1.c0].lower : -1, dir == 0 && r1.c1 >= 0 ? T.nd[r1.c1].lower : -1,
+                                    other >= 0 ? T.nd[other].lower : -1,
+                                    (dir != 0 && upT >= 0) ? (r1.whichChild ? T.nd[upT].upLeft : T.nd[upT].upRight) : -1};
+                for (int k = 0; k < 6; k++) if (ids[k] >= 0 && av.n_ent[ids[k]] > MAPLE_WU_IN) fits = false;
+                // (crawling up, the merged lower list is an input of the next merge)
+                if (dir != 0 && other >= 0 && T.nd[other].lower >= 0 && lp.n + av.n_ent[T.nd[other].lower] > MAPLE_WU_IN) fits = false;
+            }
+            if (!fits) {
+                if (lane == 0) fr_upd_item_lane_call(c, av, T, P, fp, budget, laneBase + blockIdx.x, i);
+                wave_sync();
+                continue;
+            }
+            bool upd = true;
+            double midProb = lastLK;
+            int flagsAdd = 0;
+            int nM = 0, naM = 0;
+            // mergeVectors into L.m / L.maux: 0 ok, -1 None, -2 fatal
+            auto merge = [&](const FList &l1, double b1, bool tp1, const FList &l2, double b2, bool tp2, bool upDown) -> int {
+                wave_sync();
+                const int r = wave_merge(c, fref(l1), l1.n, b1, tp1, fref(l2), l2.n, b2, tp2, upDown, L, naM);
+                if (r < 0) return r == -1 ? -1 : -2;
+                nM = r;
+                return 0;
+            };
+            auto differs = [&](int listId) -> bool {                        // areVectorsDifferent(L.m, tree list)
+                const FList tu = flist(av, fp, ftree(listId));
+                const unsigned long long *tw = (const unsigned long long *)tu.w;
+                for (int k = lane; k < tu.n; k += 64) L.old[k] = tw[k];
+                wave_sync();
+                return wave_differ(c, L.m, L.maux, nM, L.old, tu.aux, tu.n);
+            };
+            auto score = [&]() -> double {                                  // appendProbNode(L.m, removed list)
+                wave_sync();
+                return wave_append(c, ListRef{(const uint2 *)L.m, L.maux}, nM, fref(lr), lr.n, rt, rbl, W);
+            };
+            auto push1 = [&](bool u, int node, int d, int h, double dst, double mp, int fails, double pb) -> int {
+                int ref = FR_NONE;
+                if (lane == 0) ref = fpush(fp, budget, q, u, node, d, h, dst, mp, fails, hRpr, pb);
+                return __shfl(ref, 0, 64);
+            };
+            bool dead = false, fallback = false;
+            int child0 = FR_NONE, child1 = FR_NONE, hA = -1, hB = -1, hMid = -1;
+            double recDist = 0.0;
+            if (dir == 0) {
+                const bool scored = !(upT == S.parent || upT < 0) && (r1.dist > P.effNon0 || r1.upIsRoot);
+                if (scored) {
+                    const FList ll = flist(av, fp, ftree(r1.lower));
+                    if (merge(lp, distance / 2, false, ll, distance / 2, r1.isTip != 0, true) != 0) dead = true;
+                    else {
+                        if (r1.totUp >= 0 && !differs(r1.totUp)) upd = false;
+                        midProb = score();
+                        flagsAdd |= FI_SCORED;
+                        if (upd && midProb >= it.pathBest - P.thrOptTopo) {
+                            wave_sync();
+                            hMid = fstore_wave(fp, L.m, L.maux, nM, naM);
+                            if (hMid < 0) { fallback = true; dead = true; }
+                            else { hA = hPassed; hB = ftree(r1.lower); recDist = distance; flagsAdd |= FI_REC_UPD; }
+                        }
+                    }
+                }
+                if (!dead) {
+                    const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
+                    if (pr.go && r1.c0 >= 0) {
+                        for (int k = 0; k < 2 && !fallback; k++) {
+                            const int ch = k == 0 ? r1.c0 : r1.c1, oth = k == 0 ? r1.c1 : r1.c0;
+                            int ref = FR_NONE;
+                            if (upd) {
+                                const NodeRec ro = T.nd[oth];
+                                const FList lo2 = flist(av, fp, ftree(ro.lower));
+                                const int r = ro.lower >= 0 ? merge(lp, distance, false, lo2, ro.dist, ro.isTip != 0, true) : -2;
+                                if (r == -2) { fallback = true; break; }
+                                if (r == 0) {
+                                    wave_sync();
+                                    const int hv = fstore_wave(fp, L.m, L.maux, nM, naM);
+                                    if (hv < 0) { fallback = true; break; }
+                                    ref = push1(true, ch, 0, hv, T.nd[ch].dist, midProb, pr.fails, pr.pathBest);
+                                }
+                            } else if ((k == 0 ? r1.upRight : r1.upLeft) >= 0)
+                                ref = push1(false, ch, 0, -1, 0.0, midProb, pr.fails, pr.pathBest);
+                            if (k == 0) child0 = ref; else child1 = ref;
+                        }
+                    }
+                }
+            } else {
+                const NodeRec ro = T.nd[other];
+                const int vectUp = upT >= 0 ? ftree(r1.whichChild ? T.nd[upT].upLeft : T.nd[upT].upRight) : -1;
+                const bool scored = upT >= 0 && (r1.dist > P.effNon0 || r1.upIsRoot);
+                int hBottom = -1;
+                const FList lo2 = flist(av, fp, ftree(ro.lower));
+                const FList lvu = fvalid(vectUp) ? flist(av, fp, vectUp) : FList{nullptr, nullptr, 0, 0};
+                if (scored) {
+                    if (!fvalid(vectUp) || r1.totUp < 0) {                  // (the on-the-spot probVectTotUp of M:7198-7200: one lane)
+                        if (lane == 0) fr_upd_item_lane_call(c, av, T, P, fp, budget, laneBase + blockIdx.x, i);
+                        wave_sync();
+                        continue;
+                    }
+                    int r = merge(lp, distance, false, lo2, ro.dist, ro.isTip != 0, false);
+                    if (r != 0) dead = true;
+                    else {
+                        wave_sync();
+                        hBottom = fstore_wave(fp, L.m, L.maux, nM, naM);
+                        if (hBottom < 0) { fallback = true; dead = true; }
+                        else {
+                            const FList lb = flist(av, fp, hBottom);            // (written by this wavefront, fenced in fstore_wave)
+                            r = merge(lvu, r1.dist / 2, false, lb, r1.dist / 2, false, true);
+                            if (r != 0) dead = true;
+                            else {
+                                if (!differs(r1.totUp)) upd = false;
+                                midProb = score();
+                                flagsAdd |= FI_SCORED;
+                                if (upd && midProb >= it.pathBest - P.thrOptTopo) {
+                                    wave_sync();
+                                    hMid = fstore_wave(fp, L.m, L.maux, nM, naM);
+                                    if (hMid < 0) { fallback = true; dead = true; }
+                                    else { hA = vectUp; hB = hBottom; recDist = r1.dist; flagsAdd |= FI_REC_UPD; }
+                                }
+                            }
+                        }
+                    }
+                }
+                if (!dead) {
+                    const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
+                    if (pr.go) {
+                        if (upT >= 0) {
+                            int hUp = -1;
+                            bool stop = false;
+                            if (upd) {
+                                const int r = fvalid(vectUp) ? merge(lvu, r1.dist, false, lp, distance, false, true) : -2;
+                                if (r == -2) { fallback = true; stop = true; }
+                                else if (r == 0) { wave_sync(); hUp = fstore_wave(fp, L.m, L.maux, nM, naM); if (hUp < 0) { fallback = true; stop = true; } }
+                            } else hUp = ftree(dir == 1 ? r1.upLeft : r1.upRight);
+                            if (!stop && fvalid(hUp)) {
+                                child0 = upd ? push1(true, other, 0, hUp, ro.dist, midProb, pr.fails, pr.pathBest)
+                                             : push1(false, other, 0, -1, 0.0, midProb, pr.fails, pr.pathBest);
+                                if (upd && hBottom < 0) {
+                                    const int r = merge(lp, distance, false, lo2, ro.dist, ro.isTip != 0, false);
+                                    if (r == 0) { wave_sync(); hBottom = fstore_wave(fp, L.m, L.maux, nM, naM); if (hBottom < 0) fallback = true; }
+                                    else stop = true;
+                                }
+                                if (!stop && !fallback)
+                                    child1 = upd ? push1(true, upT, (int)r1.whichChild + 1, hBottom, r1.dist, midProb, pr.fails, pr.pathBest)
+                                                 : push1(false, upT, (int)r1.whichChild + 1, -1, 0.0, midProb, pr.fails, pr.pathBest);
+                            }
+                        } else if (upd) {                                   // t1 is the root and the item still updates: rootVector, one lane
+                            // (nothing was pushed or stored yet that the one-lane walk would not redo)
+                            if (lane == 0) fr_upd_item_lane_call(c, av, T, P, fp, budget, laneBase + blockIdx.x, i);
+                            wave_sync();
+                            continue;
+                        } else
+                            child0 = push1(false, other, 0, -1, 0.0, midProb, pr.fails, pr.pathBest);
+                    }
+                }
+            }
+            if (lane == 0) {
+                if (fallback) S.state = FS_FALLBACK;
+                it.midProb = midProb; it.recDist = recDist; it.child0 = child0; it.child1 = child1; it.hA = hA; it.hB = hB; it.hMid = hMid;
+                it.flags |= (uint8_t)(flagsAdd | (upd ? FI_UPD_OUT : 0) | (dead ? FI_DEAD : 0));
+            }
+            wave_sync();
         }
     }
 }
@@ -764,9 +1032,9 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, F.toffA.reserve_exact(grow((size_t)capL, F.toffA.cap)));
     HIPCK(c, F.tn.reserve_exact(grow((size_t)capL, F.tn.cap)));
     HIPCK(c, F.tna.reserve_exact(grow((size_t)capL, F.tna.cap)));
-    HIPCK(c, F.sw.reserve_exact((size_t)scratchLanes * capE));
-    HIPCK(c, F.sa.reserve_exact((size_t)scratchLanes * capE * 5));
-    HIPCK(c, F.sais.reserve_exact((size_t)scratchLanes * capE * 2));
+    HIPCK(c, F.sw.reserve_exact((size_t)(scratchLanes + 512) * capE));     // (+ one slab per wavefront of k_fr_updating_wave)
+    HIPCK(c, F.sa.reserve_exact((size_t)(scratchLanes + 512) * capE * 5));
+    HIPCK(c, F.sais.reserve_exact((size_t)(scratchLanes + 512) * capE * 2));
     HIPCK(c, F.bw.reserve_exact((size_t)capBig));
     HIPCK(c, F.ba.reserve_exact((size_t)capBig * 5));
     HIPCK(c, F.nodes.reserve((size_t)m));
@@ -799,12 +1067,17 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     std::memset(&hc, 0, sizeof hc);
     int levels = 0;
     const int gridCached = 2048;
+    // items whose two lists add up to this many entries are walked by a wavefront each (k_fr_updating_wave: 54 KB of LDS per
+    // wavefront, two per compute unit)
+    const int heavyMin = std::max(256, 6 * (int)meanEnt), gridWave = 256;
     std::vector<size_t> slotsC;
     auto level = [&]() -> int {                                            // the kernels of one level, each between its own events
         hipEvent_t a0, a1, b0, b1;
         TRY(maple_internal_ev_pair(c, &a0, &a1, MAPLE_K_FR_UPDATING, 0.0, 0.0));
         HIPCK(c, hipEventRecord(a0, s));
-        FR_DISPATCH3(c, k_fr_updating, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget));
+        FR_DISPATCH3(c, k_fr_updating, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget, heavyMin));
+        if (heavyMin > 0)
+            FR_DISPATCH3(c, k_fr_updating_wave, <<<gridWave, 64, 0, s>>>(c->d_model, av, T, P, fp, budget, heavyMin, scratchLanes));
         HIPCK(c, hipEventRecord(a1, s));
         TRY(maple_internal_ev_pair(c, &b0, &b1, MAPLE_K_FR_CACHED, 0.0, 0.0));
         slotsC.push_back(c->ev_used / 2 - 1);

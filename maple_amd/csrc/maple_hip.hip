@@ -860,7 +860,8 @@ __device__ __forceinline__ void spr_search_impl(const DevModel *__restrict__ mp,
                                                    unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
                                                    int traceQuery, int32_t *trI, double *trD, int trCap, int32_t *trN,
                                                    int activeLanes, const double *cacheS, int budget, const int32_t *rTable, int nF,
-                                                   const int32_t *cacheRow, int leanVisits)
+                                                   const int32_t *cacheRow, int leanVisits, unsigned long long *ovfUsed, uint8_t *ovfBase,
+                                                   long long ovfChunks)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
@@ -880,15 +881,22 @@ __device__ __forceinline__ void spr_search_impl(const DevModel *__restrict__ mp,
     if (!coop && !assist && (int)threadIdx.x >= activeLanes) return;
     const bool searcher = (int)threadIdx.x < activeLanes;
     const size_t lane = (size_t)blockIdx.x * activeLanes + (searcher ? threadIdx.x : 0);
-    uint8_t *base = wsBase + lane * LB.total;
     LaneWs ws;
-    ws.w = (uint2 *)base;
-    ws.aux = (double *)(base + LB.w);
-    ws.h = (TList *)(base + LB.w + LB.aux);
-    ws.st = (StackItem *)(base + LB.w + LB.aux + LB.h);
-    ws.best = (BestRec *)(base + LB.w + LB.aux + LB.h + LB.st);
-    ws.ais = (double *)(base + LB.w + LB.aux + LB.h + LB.st + LB.best);
-    ws.L = L;
+    // the lane's own workspace (a search that outgrows its list room carries on in chunks of a shared pool: LaneWs::reserve)
+    auto setWs = [&](uint8_t *base, const LaneBytes &B, const WsLayout &Lx) {
+        ws.w = (uint2 *)base;
+        ws.aux = (double *)(base + B.w);
+        ws.h = (TList *)(base + B.w + B.aux);
+        ws.st = (StackItem *)(base + B.w + B.aux + B.h);
+        ws.best = (BestRec *)(base + B.w + B.aux + B.h + B.st);
+        ws.ais = (double *)(base + B.w + B.aux + B.h + B.st + B.best);
+        ws.L = Lx;
+    };
+    setWs(wsBase + lane * LB.total, LB, L);
+    if (ovfBase && ovfChunks > 0) {
+        ws.ovfUsed = ovfUsed; ws.ovfChunks = ovfChunks;
+        ws.ovfW = (uint2 *)ovfBase; ws.ovfA = (double *)(ovfBase + (size_t)ovfChunks * L.capW * sizeof(uint2));
+    }
     Search<RV, U, SS, ASSIST> S(c, av, mv, T, P, ws);
     extern __shared__ double dynLds[];   // coop: per-depth (lastLK, failedPasses) slots of the clade scan; assisted lane searches:
     WaveLds &wl = *(WaveLds *)dynLds;    // the staging area of the wavefront-wide appendProbNode (wave_dev.h)
@@ -905,6 +913,7 @@ __device__ __forceinline__ void spr_search_impl(const DevModel *__restrict__ mp,
             q = atomicAdd(counter, 1);
             if (q >= n) { done = true; break; }
             node = nodes[q];
+            setWs(wsBase + lane * LB.total, LB, L);                           // (the last search may have moved into the shared pool)
             ws.usedW = ws.usedA = ws.nH = ws.sp = ws.nB = 0;
             ws.overflow = 0;
             S.nAppend = 0;
@@ -1071,14 +1080,17 @@ __device__ __forceinline__ void spr_search_impl(const DevModel *__restrict__ mp,
             st.shortenSeed = false;
             for (int k = 0; k < 4; k++) st.fShort[k] = __builtin_amdgcn_readfirstlane(S.fShort[k]);
             const int hSeed = __builtin_amdgcn_readfirstlane(S.scanItem.hRpr);
-            BestRec *br = (BestRec *)(wsBase + (size_t)blockIdx.x * activeLanes * LB.total + LB.w + LB.aux + LB.h + LB.st);
+            const unsigned long long brBits = (unsigned long long)ws.best;  // (lane 0's short list)
+            BestRec *br = (BestRec *)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(brBits >> 32)) << 32)
+                                      | (uint32_t)__builtin_amdgcn_readfirstlane((int)brBits));
+            const int capBnow = __builtin_amdgcn_readfirstlane(ws.L.capB);
 #ifdef MAPLE_SPR_PROFILE
             const long long tScan0 = wall_clock64();
 #endif
             wave_scan_clade(T.scan, T.scanParent, cs, rT, __builtin_amdgcn_readfirstlane(S.scanRank),
                             __builtin_amdgcn_readfirstlane(S.scanFirstScored ? 1 : 0) != 0,
                             __builtin_amdgcn_readfirstlane(S.scanSeedFrame), hSeed, readfirst_f64(S.scanItem.lastLK),
-                            __builtin_amdgcn_readfirstlane((int)S.scanItem.fails), P, br, L.capB, slotLK, slotFails,
+                            __builtin_amdgcn_readfirstlane((int)S.scanItem.fails), P, br, capBnow, slotLK, slotFails,
                             slotOwner, T.scanDepthCap, st);
 #ifdef MAPLE_SPR_PROFILE
             if (searcher) out[q].tReplay += wall_clock64() - tScan0;
@@ -1099,9 +1111,9 @@ __device__ __forceinline__ void spr_search_impl(const DevModel *__restrict__ mp,
     const int32_t *nodes, WsLayout L, LaneBytes LB, uint8_t *wsBase, int32_t *counter, SearchOut *out, uint2 *poolW, double *poolA, \
     unsigned long long *poolUsed, long long poolCapW, long long poolCapA, int traceQuery, int32_t *trI, double *trD, int trCap,     \
     int32_t *trN, int activeLanes, const double *cacheS, int budget, const int32_t *rTable, int nF, const int32_t *cacheRow,        \
-    int leanVisits
+    int leanVisits, unsigned long long *ovfUsed, uint8_t *ovfBase, long long ovfChunks
 #define MAPLE_SPR_KERNEL_PASS mp, av, mv, T, P, n, nodes, L, LB, wsBase, counter, out, poolW, poolA, poolUsed, poolCapW, poolCapA,   \
-    traceQuery, trI, trD, trCap, trN, activeLanes, cacheS, budget, rTable, nF, cacheRow, leanVisits
+    traceQuery, trI, trD, trCap, trN, activeLanes, cacheS, budget, rTable, nF, cacheRow, leanVisits, ovfUsed, ovfBase, ovfChunks
 template <bool RV, bool U, bool SS>
 __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(MAPLE_SPR_KERNEL_ARGS)
 {
@@ -1252,7 +1264,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     for (auto &b : c->t_i32) b.release();
     c->t_dist.release(); c->t_tip.release(); c->t_nodes.release(); c->t_scored_col.release(); c->t_scored_frame.release(); c->t_scan.release(); c->t_scan_parent.release(); c->s_tilebest.release(); c->s_comm_u64.release();
     if (c->d_tile_counters) (void)hipFree(c->d_tile_counters);
-    c->s_search_ws.release(); c->s_search_out.release(); c->s_counter.release(); c->s_cache.release();
+    c->s_search_ws.release(); c->s_search_ws_big.release(); c->s_search_out.release(); c->s_counter.release(); c->s_cache.release();
     for (auto &b : c->p_i32) b.release();
     for (auto &b : c->p_f64) b.release();
     c->pin_place.release(); c->pin_res.release();
@@ -2454,6 +2466,7 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         std::vector<int32_t> byRank((size_t)n, 0);
         for (int i = 0; i < n; i++) byRank[recs[i].preRank] = i;
         c->h_depth.assign((size_t)n, 0);
+        c->h_clade.clear();
         for (int r = 0; r < n; r++) {                                          // parents precede their children in rank order
             const int v = byRank[r], u = up[v];
             if (u >= 0 && seen[v] && recs[u].preRank < r) c->h_depth[v] = c->h_depth[u] + 1;
@@ -2841,6 +2854,24 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             // against 4 ms on average) -- nodes in order of depth.
             std::vector<int32_t> ord(todo.size());
             for (size_t k = 0; k < ord.size(); k++) ord[k] = (int32_t)k;
+            if (cacheS) {
+                // ... for whole-tree searches, those that take a large clade out of the tree: what its removal changes reaches far,
+                // the search updates lists for hundreds of steps (measured: the 11 searches of the 100 000-tip tree that used to
+                // come back for more workspace sit at depths 17-22, with removed lists of ordinary length)
+                if ((int)c->h_clade.size() != c->dtree.n) {
+                    const int nT = c->dtree.n;
+                    c->h_clade.assign((size_t)nT, 1);
+                    std::vector<int32_t> order, stk{c->dtree.root};
+                    while (!stk.empty()) {
+                        const int v = stk.back();
+                        stk.pop_back();
+                        order.push_back(v);
+                        if (c->h_tree_c0[v] >= 0) { stk.push_back(c->h_tree_c0[v]); stk.push_back(c->h_tree_c1[v]); }
+                    }
+                    for (size_t k = order.size(); k-- > 1;) c->h_clade[c->h_tree_up[order[k]]] += c->h_clade[order[k]];
+                }
+                std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return c->h_clade[todo[a]] > c->h_clade[todo[b]]; });
+            } else
             std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return c->h_depth[todo[a]] < c->h_depth[todo[b]]; });
             std::vector<int32_t> t2(todo.size()), s2(todo.size()), r2(todo.size());
             for (size_t k = 0; k < ord.size(); k++) { t2[k] = todo[ord[k]]; s2[k] = slot[ord[k]]; r2[k] = rows[ord[k]]; }
@@ -2919,6 +2950,14 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 Tk.scan = nullptr; Tk.scanParent = nullptr; Tk.scanDepthCap = 0;
                 if (!cacheS && assistOK) dynLds = sizeof(WaveLds);
             }
+            // searches that update lists for hundreds of steps outgrow the per-lane list room; they carry on in chunks (one lane's
+            // worth each) of a pool the launch shares instead of coming back for a second launch with 8x the room
+            long long ovfChunks = 0;
+            if (cacheS && attempt == 0) {
+                ovfChunks = std::min<long long>(1024, std::max<long long>(64, m / 16));
+                HIPCK(c, c->s_search_ws_big.reserve_exact((size_t)ovfChunks * ((size_t)L.capW * sizeof(uint2) + (size_t)L.capA * sizeof(double))));
+                HIPCK(c, hipMemsetAsync(c->s_counter.p + 6, 0, 2 * sizeof(int32_t), c->stream));
+            }
             int coopMaxHost = 8;                                            // (see k_spr_search: requests served one by one)
             if (const char *e = getenv("MAPLE_COOP_MAX")) coopMaxHost = std::max(0, atoi(e));
             hipEvent_t e0, e1;
@@ -2932,7 +2971,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                                                                          c->s_trace_d.p, 4096, c->s_trace_i.p ? c->s_trace_i.p + 4 * 4096 : nullptr, \
                                                                          launchLanes, cacheS, budgetNow, rTable, nF,               \
                                                                          cacheS ? c->s_i32[1].p : nullptr,                          \
-                                                                         assistOK ? 1 + coopMaxHost : 0)
+                                                                         assistOK ? 1 + coopMaxHost : 0, (unsigned long long *)(c->s_counter.p + 6),          \
+                                                                         ovfChunks ? c->s_search_ws_big.p : nullptr, ovfChunks)
             if (!cacheS && assistOK) DISPATCH3(c, k_spr_search_assisted, MAPLE_SPR_LAUNCH_ARGS);
             else DISPATCH3(c, k_spr_search, MAPLE_SPR_LAUNCH_ARGS);
 #undef MAPLE_SPR_LAUNCH_ARGS
@@ -2965,30 +3005,13 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 ho[slot[k]] = part[k];
                 if (part[k].status == -3 && attempt < 2) {
                     todo2.push_back(todo[k]); slot2.push_back(slot[k]); rows2.push_back(rows[k]);
-                    if (getenv("MAPLE_DEBUG")) fprintf(stderr, "[maple]   node %d ran out of workspace (capacity kind %d)\n", todo[k], part[k].nAppend);
+                    if (getenv("MAPLE_DEBUG")) fprintf(stderr, "[maple]   node %d ran out of workspace (capacity kind %d): position %d of the launch, depth %d, lower list %d entries\n", todo[k], part[k].nAppend, k, c->h_depth[todo[k]], c->h_tree_lower[todo[k]] >= 0 ? c->h_n_ent[c->h_tree_lower[todo[k]]] : -1);
                 }
             }
             if (getenv("MAPLE_DEBUG")) fprintf(stderr, "[maple] search launch: %d queries, %zu retried with more workspace\n", m, todo2.size());
             todo.swap(todo2);
             slot.swap(slot2);
             rows.swap(rows2);
-            if (cacheS && useFrontier && !todo.empty()) {
-                // Whole-tree searches that ran out of per-lane workspace (near the root, where an updating step merges lists of
-                // several hundred entries): a retry with more room is a 100 ms tail of a handful of one-lane searches.  The
-                // frontier tier expands them over the whole tree instead -- a million items, a few ms.
-                const int mF = (int)todo.size();
-                std::vector<SearchOut> part2(mF);
-                FrontierStats fs2;
-                TRY(frontier_search(c, P, mF, todo.data(), 0, 1 << 30, part2.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs2,
-                                    (long long)mF * (c->dtree.n + 64)));
-                std::vector<int32_t> t3, s3, r3;
-                for (int k = 0; k < mF; k++) {
-                    if (part2[k].status == FR_STATUS_FALLBACK) { t3.push_back(todo[k]); s3.push_back(slot[k]); r3.push_back(rows[k]); }
-                    else ho[slot[k]] = part2[k];
-                }
-                if (getenv("MAPLE_DEBUG")) fprintf(stderr, "[maple]   %d of them through the frontier tier (%lld items), %zu left\n", mF, fs2.itemsCached, t3.size());
-                todo.swap(t3); slot.swap(s3); rows.swap(r3);
-            }
             // (the budget stays: a retried search that turns out to be wide still goes to the batch path)
         }
         return MAPLE_OK;

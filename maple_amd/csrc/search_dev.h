@@ -117,13 +117,32 @@ struct LaneWs {
     int32_t usedW, usedA, nH, sp, nB;
     WsLayout L;
     int overflow;                      // 0, or which capacity ran out: 1 handles, 2 list words/aux, 3 coefficients, 4 stack, 5 short list, 6 other
+    // When the lane's own room for lists is used up it carries on in a chunk of a pool the whole launch shares (lists are
+    // referred to by pointer, so they stay where they are): the few searches that update lists for hundreds of steps no longer
+    // come back for a second launch with a larger workspace.
+    unsigned long long *ovfUsed = nullptr;
+    uint2 *ovfW = nullptr;
+    double *ovfA = nullptr;
+    long long ovfChunks = 0;
+    int chunkSerial = 0;
     __device__ inline int newHandle(const uint2 *w_, const double *a_, int n, int na)
     {
         if (nH >= L.capH) { overflow = 1; return -2; }
         h[nH] = TList{w_, a_, n, na};
         return nH++;
     }
-    __device__ inline bool reserve(int nw) { if (usedW + nw > L.capW || usedA + 5 * nw > L.capA) { overflow = 2; return false; } return true; }
+    __device__ inline bool reserve(int nw)
+    {
+        if (usedW + nw > L.capW || usedA + 5 * nw > L.capA) {
+            if (!ovfW || nw > L.capW || 5 * nw > L.capA) { overflow = 2; return false; }
+            const unsigned long long k = atomicAdd(ovfUsed, 1ull);
+            if ((long long)k >= ovfChunks) { overflow = 2; return false; }
+            w = ovfW + k * (size_t)L.capW; aux = ovfA + k * (size_t)L.capA;
+            usedW = usedA = 0;
+            chunkSerial++;
+        }
+        return true;
+    }
     __device__ inline int commit(const Writer &wr)
     {
         int hid = newHandle(w + usedW, aux + usedA, wr.n, wr.na);
@@ -655,7 +674,7 @@ template <bool RV, bool U, bool SS, bool LEAN = false> struct Search {
         if (!valid(upV) || !valid(downV) || !valid(midTot)) return -1;
         const int rem = r.hRpr;
         const bool ft = T.nd[t1].isTip;
-        const int saveW = ws.usedW, saveA = ws.usedA, saveH = ws.nH;
+        const int saveW = ws.usedW, saveA = ws.usedA, saveH = ws.nH, saveSerial = ws.chunkSerial;
         double app = opBlen(midTot, rem, isRemovedTip);
         int midLower = opMerge(downV, distance / 2, ft, rem, app, isRemovedTip, false);
         if (midLower < 0) return -1;                                  // the reference fails here (caught by the worker)
@@ -670,7 +689,9 @@ template <bool RV, bool U, bool SS, bool LEAN = false> struct Search {
         double initialCost = opAppend(upV, downV, ft, distance);
         double newPartialCost = opAppend(upV, downV, ft, bottom + top);
         double optimized = cost + newPartialCost - initialCost;
-        ws.usedW = saveW; ws.usedA = saveA; ws.nH = saveH;            // temporaries of this record are dead
+        // temporaries of this record are dead (after a move to a new chunk in between: everything in that chunk)
+        if (ws.chunkSerial == saveSerial) { ws.usedW = saveW; ws.usedA = saveA; } else ws.usedW = ws.usedA = 0;
+        ws.nH = saveH;
         if (optimized >= bestScore) {
             bestNode = t1; bestScore = optimized; bl0 = top; bl1 = bottom; bl2 = app; hBestRpr = rem;
         }

@@ -13,7 +13,9 @@
 
 namespace maple {
 
+#ifndef MAPLE_WAVE_CAPW
 #define MAPLE_WAVE_CAPW 256            // entries per list the cooperative walk stages (longer lists: one lane's walk)
+#endif
 
 struct WaveLds {                       // per wavefront
     unsigned long long a[MAPLE_WAVE_CAPW], b[MAPLE_WAVE_CAPW];

@@ -15,7 +15,9 @@
 
 namespace maple {
 
+#ifndef MAPLE_WU_IN
 #define MAPLE_WU_IN 256                // entries per input list the cooperative walks stage (longer: one lane's walk)
+#endif
 #define MAPLE_WU_CAP (2 * MAPLE_WU_IN)
 
 struct WaveUpdLds {                    // per wavefront
