@@ -289,7 +289,8 @@ def main():
 
     extras = {}
     if not args.no_extras and rank == 0:
-        extras = sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_plain_tree, torch, cu)
+        extras = sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_plain_tree, torch, cu,
+                            first_step=kept[0] if kept else None, first_nodes=batch_of(0))
 
     # HBM-side bytes per launch come from separate rocprofv3 PMC passes over this same command (a running process cannot
     # read its own PMCs); they are recorded under profiles/ and only reported for the workload they were measured on.
@@ -479,7 +480,7 @@ def serial_phase(dev, m, new_lists, pkw):
     return dict(times=t, placed=placed, skipped=skipped, patched=patched, cols=cols)
 
 
-def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_plain_tree, torch, cu):
+def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_plain_tree, torch, cu, first_step=None, first_nodes=None):
     """Secondary measurements next to the headline, never mixed into it (rank 0 only)."""
     from maple_amd.host import tip_genome_list
     from maple_amd.runtime import Device
@@ -579,6 +580,42 @@ def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_pl
                           "loop_samples": int(sp["placed"]), "nodes_patched_per_sample_median": float(np.median(sp["patched"])) if sp["patched"] else 0.0,
                           "note": "wall times through the Python binding; the loop's tree edit is a stand-in for MAPLE's "
                                   "placeSampleOnTree (bench.serial_phase); the reference's CPython updatePartials takes ~0.4 ms"}
+    # ---- the apply phase of the round: the proposed moves of the first timed step, best first, re-searched one at a time on the
+    # current tree and applied (bench.apply_phase)
+    if first_step is not None:
+        from maple_amd.spr_apply import SprApplier
+        res0 = first_step
+        prop = np.nonzero(res0["placement"] >= 0)[0]
+        prop = prop[np.argsort(-res0["improvement"][prop], kind="stable")]
+        moves = first_nodes[prop][:96]
+
+        def med(x):
+            return 1e3 * float(np.median(x)) if len(x) else float("nan")
+        rep = {}
+        for mode in ("sequential", "batched"):
+            mark = dev.mark()
+            ap = SprApplier.from_mirror(dev, mirror)
+            t0 = time.perf_counter()
+            (ap.apply_sequential if mode == "sequential" else ap.apply_batched)(moves, kw)
+            wall = time.perf_counter() - t0
+            rep[mode] = ap
+            out_ap = {"moves": int(len(moves)), "applied": len(ap.applied), "no_longer_proposed": int(ap.no_longer_proposed),
+                      "skipped_by_the_stand_in_edit": int(ap.skipped), "wall_ms_per_move": 1e3 * wall / max(1, len(moves)),
+                      "ms_median": {"search_call": med(ap.times["search"]), "update_partials": med(ap.times["update"]),
+                                    "tree_patch": med(ap.times["patch"])},
+                      "search_calls": len(ap.times["search"]),
+                      "nodes_patched_per_move_median": float(np.median(ap.patched)) if ap.patched else 0.0}
+            if mode == "batched":
+                out_ap["batches_searched_kept"] = [list(x) for x in ap.batches]
+            out["serial_path"].setdefault("apply_phase", {})[mode] = out_ap
+            upload_plain_tree()
+            dev.release(mark)
+        out["serial_path"]["apply_phase"]["same_applied_sequence"] = rep["sequential"].applied == rep["batched"].applied
+        out["serial_path"]["apply_phase"]["note"] = (
+            "applySPRMovesParallel (M:9470-9484) over the proposed moves of the first timed step, best first, with a stand-in "
+            "tree edit (maple_amd/spr_apply.py); sequential = one re-search per move (frontier tier on the patched node records); "
+            "batched = 32 moves re-searched per call, a speculative result kept while nothing its search may have read was "
+            "touched by the moves applied before it")
     if args.local_refs or args.samples <= 200000:
         # ---- the same steps on the same tree after giving it MAT local references (setUpMAT's rule, 50 descendants per
         # reference node, M:166 / 6152-6164): the form real MAPLE trees have; lists are shorter, searches cross frames ----

@@ -227,6 +227,15 @@ int maple_spr_search_batch(maple_ctx *ctx, int32_t n, const int32_t *nodes, cons
                            int32_t *placement, double *improvement, double *currentLK, int32_t *nAppend,
                            int32_t *status, int32_t *outRprList);
 
+/* What the searches of the last maple_spr_search_batch may have READ: (index into that call's nodes[], tree node) for every
+ * branch a search visited or could have visited under any outcome of its order-dependent rules (the frontier tier's expanded
+ * items) -- a superset of the visited branches.  A caller that applies proposed moves one after the other (applySPRMovesParallel,
+ * M:9470-9484: every move is re-searched on the tree the earlier ones left) can re-search a BATCH of moves speculatively and
+ * keep the result of a later one as long as no node these lists name for it, nor a relative of one, was touched by the moves
+ * applied before it.  Only after a call that ran wholly in the frontier tier (wideSearchBudget < 0, a tree without MAT local
+ * references); *n pairs, MAPLE_ERR_ARG if they do not fit in cap. */
+int maple_spr_search_visited(maple_ctx *ctx, int64_t cap, int32_t *query, int32_t *node, int64_t *n);
+
 typedef struct {
     double oneMutBLen;                          /* M:3606 */
     double effectivelyNon0BLen;                 /* M:3607 */

@@ -181,6 +181,8 @@ struct maple_ctx {
     int tile_counter_next = 0;
     void *upd = nullptr;               // UpdateScratch of maple_update_partials (update_host.h)
     void *frontier = nullptr;          // FrontierScratch of the frontier tier of the SPR search (frontier.hip)
+    bool last_search_frontier_only = false;   // maple_spr_search_visited can report on the last maple_spr_search_batch
+    bool nodes_current = false;        // the node records of the SPR search on the device follow every maple_tree_patch
     bool tree_stale = false;           // maple_tree_patch changed the host copy of the tree; the device tables of the SPR search
                                        // (and, for batches, of the placement search) are rebuilt from it before their next use
     // Staging of the small per-call argument columns of the batch operators: they are gathered in pinned host memory and go

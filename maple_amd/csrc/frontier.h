@@ -14,3 +14,4 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
                     uint2 *poolW, double *poolA, unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
                     FrontierStats *stats, long long itemsHint);   // itemsHint: expected expanded items (0 = by the budget)
 __attribute__((visibility("hidden"))) void frontier_scratch_free(maple_ctx *c);
+__attribute__((visibility("hidden"))) int frontier_export(maple_ctx *c, long long cap, int32_t *q, int32_t *node, long long *n);

@@ -948,13 +948,25 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_finish(ArenaViewS av, DevTree T
     }
 }
 
+// (query index, node) of every expanded item of the last call: a superset of what each search visited
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_export(FPools fp, long long nU, long long nC, int32_t *outQ, int32_t *outNode)
+{
+    const long long n = nU + nC;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const FItem &it = i < nU ? fp.U[i] : fp.C[i - nU];
+        outQ[i] = it.q; outNode[i] = it.t1;
+    }
+}
+
 struct FrontierScratch {
     DevBuf<uint8_t> itemsU, itemsC, srch, recs, ctr;
     DevBuf<uint2> tw, sw, bw;
     DevBuf<double> ta, sa, sais, ba;
     DevBuf<long long> toffW, toffA;
-    DevBuf<int32_t> tn, tna, nodes;
+    DevBuf<int32_t> tn, tna, nodes, expQ, expNode;
     DevBuf<uint8_t> out;
+    long long lastU = -1, lastC = -1;     // items of the last call (for frontier_export), -1: none
+    FPools lastPools{};
 };
 
 }  // namespace
@@ -966,6 +978,7 @@ void frontier_scratch_free(maple_ctx *c)
     F->itemsU.release(); F->itemsC.release(); F->srch.release(); F->recs.release(); F->ctr.release();
     F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
     F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
+    F->expQ.release(); F->expNode.release();
     delete F;
     c->frontier = nullptr;
 }
@@ -1069,7 +1082,8 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     const int gridCached = 2048;
     // items whose two lists add up to this many entries are walked by a wavefront each (k_fr_updating_wave: 54 KB of LDS per
     // wavefront, two per compute unit)
-    const int heavyMin = std::max(256, 6 * (int)meanEnt), gridWave = 256;
+    // (a handful of searches -- the re-search of a proposed move -- wait for every single item: all of them by wavefronts)
+    const int heavyMin = m <= 64 ? 1 : std::max(256, 6 * (int)meanEnt), gridWave = 256;
     std::vector<size_t> slotsC;
     auto level = [&]() -> int {                                            // the kernels of one level, each between its own events
         hipEvent_t a0, a1, b0, b1;
@@ -1125,10 +1139,33 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         // the cached-regime kernel's own share: what its launches scored (counted on the device), booked on the first launch
         if (!slotsC.empty()) { c->ev_units[slotsC[0]] = (double)hc.scoredC; c->ev_bytes[slotsC[0]] = (double)hc.bytesC; }
     }
+    F.lastU = (long long)hc.usedU; F.lastC = (long long)hc.usedC; F.lastPools = fp;
+    if (hc.overflow) F.lastU = F.lastC = -1;                              // (a pool overflowed: the item lists are not complete)
     if (stats) {
         stats->levels = levels; stats->itemsUpdating = (long long)hc.usedU; stats->itemsCached = (long long)hc.usedC;
         stats->tempLists = (long long)hc.nLists; stats->tempWords = (long long)hc.usedW; stats->tempAux = (long long)hc.usedA;
         stats->records = (long long)hc.nRecs; stats->overflow = hc.overflow;
     }
+    return MAPLE_OK;
+}
+
+// (query index, node) of every item the last frontier_search expanded: *n pairs (MAPLE_ERR_STATE if that call did not run or
+// overflowed, MAPLE_ERR_ARG if they do not fit in cap)
+int frontier_export(maple_ctx *c, long long cap, int32_t *q, int32_t *node, long long *n)
+{
+    FrontierScratch *F = (FrontierScratch *)c->frontier;
+    if (!F || F->lastU < 0) return fail(c, MAPLE_ERR_STATE, "no complete frontier search to export");
+    const long long tot = F->lastU + F->lastC;
+    *n = tot;
+    if (tot > cap) return fail(c, MAPLE_ERR_ARG, "%lld expanded items do not fit in %lld", tot, cap);
+    if (tot == 0) return MAPLE_OK;
+    HIPCK(c, F->expQ.reserve((size_t)tot));
+    HIPCK(c, F->expNode.reserve((size_t)tot));
+    k_fr_export<<<(int)std::min<long long>(1024, (tot + FR_BLOCK - 1) / FR_BLOCK), FR_BLOCK, 0, c->stream>>>(F->lastPools, F->lastU, F->lastC,
+                                                                                                          F->expQ.p, F->expNode.p);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(q, F->expQ.p, (size_t)tot * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(node, F->expNode.p, (size_t)tot * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
     return MAPLE_OK;
 }

@@ -2472,10 +2472,11 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
             if (u >= 0 && seen[v] && recs[u].preRank < r) c->h_depth[v] = c->h_depth[u] + 1;
         }
     }
-    HIPCK(c, c->t_nodes.reserve((size_t)n * sizeof(NodeRec) + 64));
+    HIPCK(c, c->t_nodes.reserve(((size_t)n + (size_t)n / 8 + 1024) * sizeof(NodeRec) + 64));   // (room for the nodes patches add)
     uint8_t *aligned = (uint8_t *)(((uintptr_t)c->t_nodes.p + 63) & ~(uintptr_t)63);
     HIPCK(c, hipMemcpy(aligned, recs.data(), (size_t)n * sizeof(NodeRec), hipMemcpyHostToDevice));
     c->h_nodes = recs;
+    c->nodes_current = true;
     DevTree &T = c->dtree;
     T.n = n; T.root = root;
     T.nd = (const NodeRec *)aligned;
@@ -2588,6 +2589,40 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
     c->dtree.n = nTotal;
     c->tree_stale = true;
     c->scan_valid = false;
+    c->h_clade.clear();
+    // ---- the node records of the SPR search (search_dev.h): the touched nodes and their relatives are rewritten in place, so
+    // that a small batch of searches -- the re-search of a proposed move before it is applied, M:9470-9484 -- can run on the
+    // patched tree at once (frontier tier, no tree-sized table); everything tree-sized (depth-first orders, score columns)
+    // waits for the rebuild
+    if (c->nodes_current && !c->tree_has_mut && c->dtree.nd) {
+        const size_t capNodes = (c->t_nodes.cap - 64) / sizeof(NodeRec);
+        if ((size_t)nTotal > capNodes) c->nodes_current = false;
+        else {
+            c->h_nodes.resize((size_t)nTotal);
+            std::vector<int32_t> redo;
+            for (int i = 0; i < nTouched; i++) {
+                const int v = nodes[i];
+                redo.push_back(v);
+                for (int32_t w : {c->h_tree_up[v], c->h_tree_c0[v], c->h_tree_c1[v]}) if (w >= 0) redo.push_back(w);
+            }
+            std::sort(redo.begin(), redo.end());
+            redo.erase(std::unique(redo.begin(), redo.end()), redo.end());
+            NodeRec *dn = const_cast<NodeRec *>(c->dtree.nd);
+            for (int32_t v : redo) {
+                NodeRec &r = c->h_nodes[v];
+                const int32_t keepRank = v < nOld ? r.preRank : 0;
+                memset(&r, 0, sizeof r);
+                r.up = c->h_tree_up[v]; r.c0 = c->h_tree_c0[v]; r.c1 = c->h_tree_c1[v];
+                r.lower = c->h_tree_lower[v]; r.upRight = c->h_tree_upRight[v]; r.upLeft = c->h_tree_upLeft[v]; r.totUp = c->h_tree_totUp[v];
+                r.mutId = -1; r.dist = c->h_tree_dist[v]; r.isTip = c->h_tree_tip[v];
+                r.upIsRoot = (r.up >= 0 && c->h_tree_up[r.up] < 0) ? 1 : 0;
+                r.whichChild = (r.up >= 0 && c->h_tree_c1[r.up] == v) ? 1 : 0;
+                r.preRank = keepRank;                                          // (stale: only the tree-sized tables use it)
+                HIPCK(c, hipMemcpyAsync(dn + v, &r, sizeof(NodeRec), hipMemcpyHostToDevice, c->stream));
+            }
+            HIPCK(c, hipStreamSynchronize(c->stream));
+        }
+    } else c->nodes_current = false;
     PlaceMeta &M = *c->place;
     if (!M.valid) return MAPLE_OK;                                        // nothing of the placement search to keep up to date
     // ---- the placement search's columns
@@ -2788,9 +2823,20 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     HIPCK(c, hipSetDevice(c->device));
     TRY(need_model(c));
     if (!c->tree_set) return fail(c, MAPLE_ERR_STATE, "maple_tree_upload has not been called");
-    if (c->tree_stale) TRY(tree_rebuild_from_host(c));                  // the tree was patched since its tables were built
     for (int i = 0; i < n; i++)
         if (nodes[i] < 0 || nodes[i] >= c->dtree.n) return fail(c, MAPLE_ERR_ARG, "nodes[%d] = %d is not a node", i, nodes[i]);
+    // The tree was patched since its tables were built.  A small batch (the re-search of proposed moves before they are
+    // applied) runs on the patched node records alone, through the frontier tier with no hand-over to the dense tier -- unless
+    // one of its searches is a whole-tree search by construction (a zero-length branch without an error model); everything
+    // else rebuilds the tables first.
+    bool patchedOnly = false;
+    c->last_search_frontier_only = false;
+    if (c->tree_stale) {
+        patchedOnly = c->nodes_current && !c->tree_has_mut && n <= 64 && sp->searchTier == 0 && c->trace_query < 0 && !outRprList;
+        for (int i = 0; i < n && patchedOnly; i++)
+            if (sp->wideSearchBudget >= 0 && !c->dm.usingErrorRate && c->h_tree_dist[nodes[i]] == 0.0) patchedOnly = false;
+        if (!patchedOnly) TRY(tree_rebuild_from_host(c));
+    }
     const bool dbgT = getenv("MAPLE_DEBUG") != nullptr;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -2847,7 +2893,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         int capW = cacheS ? (heavyQueries ? 8 : 4) * capW0 : capW0;
         std::vector<int32_t> rows(todo.size());                        // row of each query in the cache / frame tables
         for (size_t k = 0; k < rows.size(); k++) rows[k] = rowOverride ? (*rowOverride)[k] : (int32_t)k;
-        if (!getenv("MAPLE_NO_LPT")) {
+        if (!getenv("MAPLE_NO_LPT") && (int)c->h_depth.size() >= c->dtree.n) {
             // Lanes pull searches from a counter, so a launch ends one search after the last one is pulled: the expensive
             // searches go first.  The expensive ones are those near the root (long lists: an updating step there merges
             // several hundred entries; measured up to 100 ms of updating steps in one search of the 100 000-tip tree
@@ -3025,6 +3071,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // tips (256: 91 ms per round; 128: 100, 384: 97) and at 100 000 (2 048: 1.08 s; 256: 2.69, 1 024: 1.13, 4 096: 1.20)
     int wideBudget = sp->wideSearchBudget == 0 ? std::max(MAPLE_WIDE_BUDGET_DEFAULT, std::min(8192, c->n_scored / 64))
                                                : sp->wideSearchBudget;
+    if (patchedOnly) wideBudget = -1;                                   // (no tree-sized table is current)
     // (a long search costs the wave-assisted lane tier a tenth of what it cost one lane: twice the budget pays -- 100 000 tips:
     // 2 132 / 3 072 / 4 096 / 6 144 -> 693 / 688 / 668 / 692 ms per round; 10 000 tips: 256 / 384 / 512 -> 75 / 72 / 72)
     if (sp->wideSearchBudget == 0 && !c->dm.usingErrorRate && !getenv("MAPLE_NO_LEAN")
@@ -3179,6 +3226,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                             "(%lld words, %lld aux), %lld refined records, %zu searches handed back%s\n", tms(tStart, tnow()), fs.levels,
                     fs.itemsUpdating, fs.itemsCached, fs.tempLists, fs.tempWords, fs.tempAux, fs.records, todoFb.size(),
                     fs.overflow ? " (a pool overflowed)" : "");
+        c->last_search_frontier_only = todoFb.empty() && !hybrid;
         if (!todoFb.empty()) TRY(run_queries(todoFb, slotFb, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
     } else
         TRY(run_queries(todo, slot, nullptr, hybrid ? wideBudget : 0, nullptr, 0));
@@ -3422,6 +3470,18 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         TRY(commit_lists(c, n, dwo, dao, c->s_i32[2].p, c->s_i32[3].p, outRprList, poolW, poolA));
     }
     return MAPLE_OK;
+}
+
+extern "C" int maple_spr_search_visited(maple_ctx *c, int64_t cap, int32_t *query, int32_t *node, int64_t *n)
+{
+    if (!c || cap < 0 || !n || (cap && (!query || !node))) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    if (!c->last_search_frontier_only)
+        return fail(c, MAPLE_ERR_STATE, "the last maple_spr_search_batch did not run wholly in the frontier tier (use wideSearchBudget < 0)");
+    long long nn = 0;
+    const int rc = frontier_export(c, cap, query, node, &nn);
+    *n = nn;
+    return rc;
 }
 
 // Calibration of the FETCH_SIZE counter for THIS library's access pattern (MI355X_MICROARCH.md, HBM section: the

@@ -25,7 +25,7 @@ EXPORTS = [
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
     "maple_timing_read_kind", "maple_placement_supports_batch", "maple_debug_gpv_batch", "maple_debug_simplify_batch",
-    "maple_candset_destroy", "maple_debug_calib_write", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev",
+    "maple_candset_destroy", "maple_debug_calib_write", "maple_spr_search_visited", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev",
 ]
 
 
@@ -414,6 +414,14 @@ class Device:
         if want_removed_partials:
             out["removedPartials"] = rpr
         return out
+
+    def spr_search_visited(self, cap=1 << 22):
+        """(query index, node) pairs of every branch the searches of the last spr_search_batch may have read (see the header)."""
+        q = np.zeros(cap, np.int32)
+        v = np.zeros(cap, np.int32)
+        n = C.c_int64()
+        self._ck(self.lib.maple_spr_search_visited(self.h, C.c_int64(cap), _ptr(q), _ptr(v), C.byref(n)))
+        return q[: n.value], v[: n.value]
 
     def placement_prepare(self, *, oneMutBLen, effectivelyNon0BLen, thresholdLogLK, thresholdLogLKoptimization,
                           thresholdLogLKconsecutivePlacement, allowedFails=5, strictStopRules=True, onlyFindIdentical=False):

@@ -579,3 +579,49 @@ def test_bench_two_ranks_plumbing():
     assert line2["config"]["searches_timed"] == line1["config"]["searches_timed"] == 2 * 600
     assert line2["config"]["candidate_placements_timed"] == line1["config"]["candidate_placements_timed"]
     assert line2["value"] > 0 and line2["roofline"]["frac"] >= 0
+
+
+def test_apply_phase_batched_equals_sequential(world):
+    """applySPRMovesParallel (M:9470-9484) in its two drivers (maple_amd/spr_apply.py): the proposed moves of a deep round on a
+    tree with misplaced tips, re-searched one at a time on the current tree and applied -- against the same moves re-searched
+    32 at a time, a speculative result kept only while nothing its search may have read was touched.  Same applied sequence,
+    same topology, same branch lengths, and every genome list the same entry for entry."""
+    import bench
+    from maple_amd.spr_apply import SprApplier
+    mode, data, dev, orc, mirror = world
+    kw = bench.search_kwargs(dev.lRef)
+    m = mirror
+    # misplace 60 tips: swap the lower lists of pairs of tips far apart in the tree, then rebuild the lists
+    from maple_amd.tree_mirror import TreeMirror
+    rng = np.random.default_rng(17)
+    tips = np.asarray(data.tip_node)
+    pick = rng.choice(tips, size=120, replace=False)
+    mark = dev.mark()
+    tip_lists = {int(v): dev.download([m.lower[v]])[0] for v in tips}
+    for a, b in zip(pick[:60], pick[60:]):
+        tip_lists[int(a)], tip_lists[int(b)] = tip_lists[int(b)], tip_lists[int(a)]
+    m2 = TreeMirror(dev, m.parent, m.dist.copy(), tip_lists).build()
+    no_mut = -np.ones(m2.n_nodes, dtype=np.int32)
+    dev.upload_tree(m2.root, m2.parent, m2.children[:, 0], m2.children[:, 1], m2.dist, m2.is_tip, m2.lower, m2.up_right, m2.up_left,
+                    m2.tot_up, no_mut)
+    order = bench.preorder_nodes(m2)
+    r = dev.spr_search_batch(order, **kw)
+    prop = np.nonzero(r["placement"] >= 0)[0]
+    prop = prop[np.argsort(-r["improvement"][prop], kind="stable")]
+    moves = order[prop][:80]
+    assert len(moves) >= 40
+    seq = SprApplier.from_mirror(dev, m2).apply_sequential(moves, kw)
+    bat = SprApplier.from_mirror(dev, m2).apply_batched(moves, kw, batch=32)
+    assert len(seq.applied) >= 20
+    assert seq.applied == bat.applied
+    # (searches from misplaced tips expand wide regions, so speculative results are often dropped here; on the bench tree the
+    # searches are local and a batch of 32 is mostly kept -- bench.py's apply_phase block)
+    assert len(bat.times["search"]) < len(seq.times["search"]) and max(k for _, k in bat.batches) >= 2
+    for a in ("up", "c0", "c1", "dist"):
+        assert np.array_equal(getattr(seq, a), getattr(bat, a)), a
+    for a in ("lower", "up_right", "up_left", "tot_up"):
+        ia, ib = getattr(seq, a), getattr(bat, a)
+        assert np.array_equal(ia >= 0, ib >= 0), a
+        have = np.nonzero(ia >= 0)[0]
+        assert dev.download(ia[have]) == dev.download(ib[have]), a
+    dev.release(mark)
