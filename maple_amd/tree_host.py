@@ -150,10 +150,12 @@ class HostTree:
             sent["mut"] = self.id_mut.copy()
         return len(touched)
 
-    def apply_topology(self, root, up, children, dist, n_minor):
+    def apply_topology(self, root, up, children, dist, n_minor, mutations=None, dev: Device = None):
         """Tree surgery done by the host (placeSampleOnTree / cutAndPasteNode stay host code): take over the new arrays,
         growing the per-node tables for nodes that did not exist (their lists are missing: id -1).  Returns the nodes
-        whose parent, children or branch length changed -- what update_genome_lists needs to be told."""
+        whose parent, children, branch length or MAT mutation list changed -- what update_genome_lists needs to be told.
+        ``mutations`` (with ``dev``): the tree's MAT mutation lists after the edit (a placement above a reference node hands
+        that node's list to the new internal node); changed ones are uploaded."""
         n_new = len(up)
         changed = []
         for v in range(n_new):
@@ -162,6 +164,8 @@ class HostTree:
             elif self.up[v] != up[v] or list(self.children[v]) != list(children[v] or []) \
                     or float(self.dist[v] or 0.0) != float(dist[v] or 0.0):
                 changed.append(v)
+            elif mutations is not None and [list(m) for m in (mutations[v] or [])] != [list(m) for m in self.mutations[v]]:
+                changed.append(v)
         grow = n_new - self.n
         if grow > 0:
             for name in ("id_lower", "id_upRight", "id_upLeft", "id_totUp", "id_mut"):
@@ -169,6 +173,12 @@ class HostTree:
             self.mutations = self.mutations + [[] for _ in range(grow)]
         self.root, self.up, self.children = root, list(up), [list(c) if c else [] for c in children]
         self.dist, self.n_minor, self.n = [float(x or 0.0) for x in dist], list(n_minor), n_new
+        if mutations is not None:
+            new_mut = [[list(m) for m in (ml or [])] for ml in mutations]
+            for v in range(n_new):
+                if new_mut[v] != [list(m) for m in self.mutations[v]]:
+                    self.mutations[v] = new_mut[v]
+                    self.id_mut[v] = dev.upload_mutations([new_mut[v]])[0] if new_mut[v] else -1
         self._cols = None
         return changed
 

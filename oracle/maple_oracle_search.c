@@ -328,19 +328,19 @@ int omo_findBestParentTopology(const OModel *m, const OTree *t, const OSearchPar
             distance = t->dist[t1];
             midTot = tree_list(&S, 3, t1);
         } else { upV = r->up; downV = r->down; distance = r->distance; midTot = r->mid; }
-        if (!upV || !downV || !midTot) return -1;
+        if (!upV || !downV || !midTot) { res->nAppend = S.nAppend; return -1; }
         const int ft = is_tip(t, t1);
         const size_t save = A.used;
         const double app = blen(&S, midTot, r->rpr, isRemovedTip);
         OL *midLower = merge(&S, downV, distance / 2, ft, r->rpr, app, isRemovedTip, 0);
-        if (!midLower) return -1;                                     /* the reference raises; its worker swallows it */
+        if (!midLower) { res->nAppend = S.nAppend; return -1; }                                     /* the reference raises; its worker swallows it */
         double top = blen(&S, upV, midLower, 0);
         OL *midTop = merge(&S, upV, top, 0, r->rpr, app, isRemovedTip, 1);
         if (!midTop) { top = p->defaultBLen * 0.1; midTop = merge(&S, upV, top, 0, r->rpr, app, isRemovedTip, 1); }
-        if (!midTop) return -1;
+        if (!midTop) { res->nAppend = S.nAppend; return -1; }
         const double bottom = blen(&S, midTop, downV, ft);
         OL *newMid = merge(&S, upV, top, 0, downV, bottom, ft, 1);
-        if (!newMid) return -1;
+        if (!newMid) { res->nAppend = S.nAppend; return -1; }
         const double cost = append(&S, newMid, r->rpr, isRemovedTip, app);
         const double initialCost = append(&S, upV, downV, ft, distance);
         const double newPartialCost = append(&S, upV, downV, ft, bottom + top);
@@ -384,7 +384,7 @@ int omo_sprWorker(const OModel *m, const OTree *t, const OSearchParams *p, int n
         r->currentLK = cur;
         if (!(cur < p->thrPlacement || t->dist[node] != 0.0)) { r->status = 2; continue; }
         int rc = omo_findBestParentTopology(m, t, p, parent, child, cur, t->dist[node], r, arenaMem, arenaBytes);
-        if (rc != 0) { r->status = rc; continue; }
+        if (rc != 0) { r->status = rc; continue; }                    /* (-1: nAppend = the calls issued before the reference raises) */
         if (r->bestScore + p->thrPlacement > cur) {                   /* M:9681-9700 */
             int updated = 1;
             int topNode = t->up[node];

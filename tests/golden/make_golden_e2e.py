@@ -37,6 +37,15 @@ from make_golden_search import input_path, perturb  # noqa: E402
 # no MAT reference frames: --noLocalRef only covers input trees (M:6219); new clades become references once they hold
 # --maxNumDescendantsForMATClade branches (M:8543), so that is set out of reach as well
 FLAGS = ["--model", "UNREST", "--noLocalRef", "--maxNumDescendantsForMATClade", "1000000"]
+# variants: name -> (input of make_golden_search.input_path, flags, record the SPR moves?)
+#   *_fullmodel_mat: BASELINE configs[4]'s model (per-site rates + per-site error rates) on a tree WITH MAT local references
+#   (the reference's default); only the online additions are recorded (the model changes between SPR rounds there)
+VARIANTS = {
+    "synth_unrest": ("synth_unrest", FLAGS, True),
+    "b1429_unrest": ("b1429_unrest", FLAGS, True),
+    "synth_fullmodel_mat": ("synth_unrest", ["--model", "UNREST", "--rateVariation", "--estimateSiteSpecificErrorRate",
+                                             "--maxNumDescendantsForMATClade", "40"], False),
+}
 MAX_MOVES = 40
 SCRAMBLE = 30          # tips whose names are permuted in the starting tree of the SPR-move run
 N_ONLINE = 30
@@ -44,12 +53,14 @@ N_ONLINE = 30
 
 def topo(tree, root):
     return dict(root=root, up=list(tree.up), children=[list(c) if c else [] for c in tree.children],
-                dist=[float(x or 0.0) for x in tree.dist], nMinor=[len(m) for m in tree.minorSequences])
+                dist=[float(x or 0.0) for x in tree.dist], nMinor=[len(m) for m in tree.minorSequences],
+                mutations=[[list(m) for m in ml] if ml else [] for ml in tree.mutations])
 
 
 def main(name="synth_unrest"):
     out_dir = tempfile.mkdtemp(prefix="maple_golden_e2e_")
-    inp = input_path(name, out_dir)
+    in_name, FLAGS, with_moves = VARIANTS[name]
+    inp = input_path(in_name, out_dir)
     argv = ["MAPLE", "--input", inp, "--output", os.path.join(out_dir, "out"), "--overwrite"] + FLAGS
     st = {"g": None, "busy": False, "pending": None}
     moves = []
@@ -66,7 +77,7 @@ def main(name="synth_unrest"):
             return
         if st["g"] is None:
             st["g"] = frame.f_globals
-        if st["busy"] or co.co_name != "traverseTreeForTopologyUpdate" or len(moves) >= MAX_MOVES:
+        if st["busy"] or co.co_name != "traverseTreeForTopologyUpdate" or len(moves) >= MAX_MOVES or not with_moves:
             return
         g = st["g"]
         if event == "call":
@@ -140,7 +151,8 @@ def main(name="synth_unrest"):
     reference_run(argv2, prof)
     g = st["g"]
     tree, t1 = g["tree"], g["t1"]
-    assert not any(tree.mutations[v] for v in range(len(tree.up))), "--noLocalRef run has MAT mutations"
+    if "--noLocalRef" in FLAGS:
+        assert not any(tree.mutations[v] for v in range(len(tree.up))), "--noLocalRef run has MAT mutations"
     # every tip list of the final tree (tips never change without local references; minor-sequence bookkeeping aside)
     tips = {}
     for v in range(len(tree.up)):
@@ -153,8 +165,16 @@ def main(name="synth_unrest"):
     ctx = {k: g[k] for k in keys}
     ctx["rootFreqs"] = list(g["rootFreqs"])
     ctx["ref"] = g["ref"]
-    model = dict(useRateVariation=False, usingErrorRate=False, errorRateSiteSpecific=False,
-                 Q=[list(r) for r in g["mutMatrixGlobal"]], siteRates=None, errorRateGlobal=0.0, errorRates=None)
+    model = dict(useRateVariation=bool(g["useRateVariation"]), usingErrorRate=bool(g["usingErrorRate"]),
+                 errorRateSiteSpecific=bool(g["errorRateSiteSpecific"]), Q=[list(r) for r in g["mutMatrixGlobal"]],
+                 siteRates=list(g["siteRates"]) if g["useRateVariation"] else None,
+                 errorRateGlobal=g["errorRateGlobal"] if g["usingErrorRate"] else 0.0,
+                 errorRates=list(g["errorRates"]) if (g["usingErrorRate"] and g["errorRateSiteSpecific"]) else None)
+    # (with an error model the reference's tips share one ambiguity vector object per IUPAC code and rewrite it in place,
+    # M:3966: de-alias them before the lists are recomputed, as make_golden_search.py does)
+    for v in range(len(tree.up)):
+        if tree.probVect[v] is not None and not tree.children[v]:
+            tree.probVect[v] = copy.deepcopy(tree.probVect[v])
 
     # ---- online additions on the frozen final tree (model frozen) ----
     with contextlib.redirect_stdout(io.StringIO()):
@@ -162,6 +182,10 @@ def main(name="synth_unrest"):
         g["reCalculateAllGenomeLists"](tree, t1)
         lk0 = g["calculateTreeLikelihood"](tree, t1)
     start = topo(tree, t1)
+    tips = {}                                   # (the lists of the de-aliased tips, as the online phase starts)
+    for v in range(len(tree.up)):
+        if tree.probVect[v] is not None and not tree.children[v]:
+            tips[str(v)] = ser_list(tree.probVect[v])
     from maple_amd.host import read_maple_file
     _, data = read_maple_file(inp)
     names = sorted(data)
@@ -174,6 +198,8 @@ def main(name="synth_unrest"):
         names_in_tree.append(sample_name)
         idx = len(names_in_tree) - 1
         n_before = len(tree.up)
+        tips_before = {v: ser_list(tree.probVect[v]) for v in range(n_before) if tree.probVect[v] is not None and not tree.children[v]}
+        muts_before = [[list(m) for m in ml] if ml else [] for ml in tree.mutations]
         with contextlib.redirect_stdout(io.StringIO()):
             q = g["probVectTerminalNode"](diffs, None, None)
             q_ser = ser_list(q)
@@ -188,6 +214,12 @@ def main(name="synth_unrest"):
             lk = g["calculateTreeLikelihood"](tree, t1)
         new_nodes = list(range(n_before, len(tree.up)))
         new_tips = {str(v): ser_list(tree.probVect[v]) for v in new_nodes if not tree.children[v]}
+        # existing tips whose list the placement rewrote (a minor sequence with an error model, M:7951 / 3966)
+        for v, before in tips_before.items():
+            if not tree.children[v] and ser_list(tree.probVect[v]) != before:
+                new_tips[str(v)] = ser_list(tree.probVect[v])
+        # (a placement above a MAT reference node moves that node's mutation list to the new internal node, M:8300-8722:
+        # `after` carries the mutation lists of every node)
         online.append(dict(diffs=[list(e) for e in diffs], query=q_ser,
                            ret=dict(bestNode=best_node, bestScore=best_score,
                                     bestBranchLengths=None if blens is None else [0.0 if b is False else b for b in blens]),

@@ -317,7 +317,22 @@ def test_hybrid_search_with_local_references_matches_reference(env):
         assert np.allclose(plain[key], out[key], rtol=1e-11, atol=1e-15), key
 
 
-def test_hybrid_search_on_big_tree_with_local_references():
+def _model_for(mode, l_ref, seed=31):
+    """Model tables of BASELINE's configs[1..3]: UNREST; + per-site rates; + per-site error rates."""
+    import math
+    Qm = [[-0.55, 0.06, 0.37, 0.12], [0.17, -2.6, 0.04, 2.39], [0.84, 0.13, -2.4, 1.43], [0.07, 0.48, 0.05, -0.6]]
+    kw = dict(Q=Qm)
+    rng = np.random.default_rng(seed)
+    if mode != "unrest":
+        kw["siteRates"] = np.clip(rng.gamma(0.5, 2.0, size=l_ref), 0.001, 0.005 * l_ref)
+    if mode == "siteerr":
+        er = np.exp(rng.uniform(math.log(1e-10), math.log(1e-3), size=l_ref))
+        kw.update(usingErrorRate=True, errorRates=er, errorRateGlobal=float(er.mean()))
+    return kw
+
+
+@pytest.mark.parametrize("mode", ["unrest", "ratevar", "siteerr"])
+def test_hybrid_search_on_big_tree_with_local_references(mode):
     """A 1500-tip tree given MAT local references the way setUpMAT does (maple_amd.mat, 30 descendants per clade):
     lane-only search, hybrid search and the C oracle's search agree on every node id, move and candidate count."""
     import math
@@ -328,14 +343,16 @@ def test_hybrid_search_on_big_tree_with_local_references():
     from maple_amd.tree_host import HostTree
     from maple_amd.tree_mirror import TreeMirror
     from oracle.oracle_py import Oracle, OracleTree
-    data = make_dataset(n_samples=1500, l_ref=29903, seed=6, mean_diffs=30.0, frac_with_n=0.05, frac_ambig=0.05)
+    data = make_dataset(n_samples=1500, l_ref=29903, seed=6, mean_diffs=30.0, frac_with_n=0.05, frac_ambig=0.05,
+                        rate_variation=(mode != "unrest"))
     ref_idx, rf = reference_tables(data.ref)
-    Qm = [[-0.55, 0.06, 0.37, 0.12], [0.17, -2.6, 0.04, 2.39], [0.84, 0.13, -2.4, 1.43], [0.07, 0.48, 0.05, -0.6]]
+    mkw = _model_for(mode, len(ref_idx))
     dev = Device(ref_idx, rf, arena_bytes=2 << 30)
-    dev.set_model(Qm)
+    dev.set_model(**mkw)
     orc = Oracle(ref_idx, rf)
-    orc.set_model(Qm)
-    tips = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
+    orc.set_model(**mkw)
+    tip_kw = dict(error_rates=mkw["errorRates"]) if mode == "siteerr" else {}
+    tips = {int(v): tip_genome_list(dl, ref_idx, **tip_kw) for v, dl in zip(data.tip_node, data.diffs)}
     m = TreeMirror(dev, data.parent, data.blen, tips).build()
     ht = HostTree.from_mirror(m)
     n_ref = add_local_references(dev, ht, 30)
@@ -368,7 +385,8 @@ def test_hybrid_search_on_big_tree_with_local_references():
     dev.close()
 
 
-def test_device_search_vs_oracle_search_on_gpu_built_tree():
+@pytest.mark.parametrize("mode", ["unrest", "ratevar", "siteerr"])
+def test_device_search_vs_oracle_search_on_gpu_built_tree(mode):
     """Beyond the reference's small recorded trees: every node of a 1500-tip synthetic tree (mirror built on the GPU)
     searched by the device state machine and by the C oracle (itself pinned to the reference's records): node ids,
     proposed moves and candidate counts bit-exact, scores to 1e-12."""
@@ -378,14 +396,16 @@ def test_device_search_vs_oracle_search_on_gpu_built_tree():
     from maple_amd.synth import make_dataset
     from maple_amd.tree_mirror import TreeMirror
     from oracle.oracle_py import Oracle, OracleTree
-    data = make_dataset(n_samples=1500, l_ref=29903, seed=4, mean_diffs=30.0, frac_with_n=0.05, frac_ambig=0.05)
+    data = make_dataset(n_samples=1500, l_ref=29903, seed=4, mean_diffs=30.0, frac_with_n=0.05, frac_ambig=0.05,
+                        rate_variation=(mode != "unrest"))
     ref_idx, rf = reference_tables(data.ref)
-    Qm = [[-0.55, 0.06, 0.37, 0.12], [0.17, -2.6, 0.04, 2.39], [0.84, 0.13, -2.4, 1.43], [0.07, 0.48, 0.05, -0.6]]
+    mkw = _model_for(mode, len(ref_idx))
     dev = Device(ref_idx, rf, arena_bytes=1 << 30)
-    dev.set_model(Qm)
+    dev.set_model(**mkw)
     orc = Oracle(ref_idx, rf)
-    orc.set_model(Qm)
-    tips = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
+    orc.set_model(**mkw)
+    tip_kw = dict(error_rates=mkw["errorRates"]) if mode == "siteerr" else {}
+    tips = {int(v): tip_genome_list(dl, ref_idx, **tip_kw) for v, dl in zip(data.tip_node, data.diffs)}
     m = TreeMirror(dev, data.parent, data.blen, tips).build()
     n = m.n_nodes
     dev.upload_tree(m.root, m.parent, m.children[:, 0], m.children[:, 1], m.dist, m.is_tip, m.lower, m.up_right, m.up_left,
@@ -406,8 +426,11 @@ def test_device_search_vs_oracle_search_on_gpu_built_tree():
         sel = nodes if kw["strict"] else nodes[::7]                   # the deep round is ~100x the work on the CPU
         g = dev.spr_search_batch(sel, **kw)
         o = orc.spr_worker(otree, sel, **kw)
+        lane = dev.spr_search_batch(sel, search_tier=1, **kw)            # one lane per search instead of the frontier tier
         for k in ("status", "bestNode", "placement", "nAppend"):
             assert np.array_equal(g[k], o[k]), k
+            assert np.array_equal(g[k], lane[k]), k
+        assert np.array_equal(g["bestScore"], lane["bestScore"]) and np.array_equal(g["blen"], lane["blen"])
         for k in ("bestScore", "currentLK", "improvement", "blen"):
             assert np.allclose(g[k], o[k], rtol=1e-11, atol=1e-15), k
         assert g["nAppend"].sum() > 10000
@@ -699,13 +722,19 @@ def _tree_from_topology(dev, topo, tips):
     for v, lst in tips.items():
         if int(v) < n and not topo["children"][int(v)]:
             pv[int(v)] = lst
-    tree = HostTree(topo["root"], topo["up"], topo["children"], topo["dist"], [[] for _ in range(n)], topo["nMinor"], pv,
-                    [None] * n, [None] * n, [None] * n).upload(dev)
+    tree = HostTree(topo["root"], topo["up"], topo["children"], topo["dist"], topo.get("mutations") or [[] for _ in range(n)],
+                    topo["nMinor"], pv, [None] * n, [None] * n, [None] * n).upload(dev)
     tree.id_lower, tree.id_upRight, tree.id_upLeft, tree.id_totUp = rebuild_genome_lists(dev, tree)
     return tree
 
 
-@pytest.mark.parametrize("name", E2E_NAMES)
+def _has_moves(name):
+    with gzip.open(os.path.join(GOLDEN, f"e2e_{name}.json.gz"), "rt") as fh:
+        return bool(json.load(fh)["spr_moves"])
+
+
+# (e2e_b1429_unrest: the reference applied no move on that tree; e2e_synth_fullmodel_mat records online additions only)
+@pytest.mark.parametrize("name", [n for n in E2E_NAMES if _has_moves(n)])
 def test_applied_spr_moves_tree_likelihood(name):
     """Metric part 2 on the reference's own SPR rounds: for every move the reference APPLIED (40 in a row, starting from a
     tree with 30 tips misplaced), the tree it produced is rebuilt on the GPU from the tips alone and its log-likelihood
@@ -767,13 +796,18 @@ def test_online_sample_additions_through_tree_patch(name):
         if want["bestBranchLengths"] is None:
             assert out["status"][0] == 1
         else:
-            assert all(close(float(g), w, 1e-7, 1e-15) for g, w in zip(out["blen"][0], want["bestBranchLengths"])), (k, out["blen"][0], want)
+            # (branch lengths come out of a bisection that stops at minBLenSensitivity, on lists the two sides repaired in a
+            # different order after 27 additions: 1e-6, the tolerance north_star states for floating point)
+            assert all(close(float(g), w, 1e-6, 1e-15) for g, w in zip(out["blen"][0], want["bestBranchLengths"])), (k, out["blen"][0], want)
         last = (qid.copy(), {kk: v.copy() for kk, v in out.items()})
         dev.release(mark)
         after = rec["after"]
-        changed = tree.apply_topology(after["root"], after["up"], after["children"], after["dist"], after["nMinor"])
+        changed = tree.apply_topology(after["root"], after["up"], after["children"], after["dist"], after["nMinor"],
+                                      after.get("mutations"), dev)
         for v, lst in rec["new_tips"].items():
             tree.id_lower[int(v)] = dev.upload([tup(lst)])[0]
+            if int(v) not in changed:
+                changed.append(int(v))
         if changed:
             update_genome_lists(dev, tree, changed)
     print(f"{name}: nodes patched per added sample {patched}")
@@ -820,11 +854,14 @@ def test_online_sample_additions(name):
         if want["bestBranchLengths"] is None:
             assert blens is None
         else:
-            assert all(close(float(g or 0.0), w, 1e-7, 1e-15) for g, w in zip(blens, want["bestBranchLengths"])), (k, blens, want)
+            assert all(close(float(g or 0.0), w, 1e-6, 1e-15) for g, w in zip(blens, want["bestBranchLengths"])), (k, blens, want)
         after = rec["after"]
-        changed = tree.apply_topology(after["root"], after["up"], after["children"], after["dist"], after["nMinor"])
+        changed = tree.apply_topology(after["root"], after["up"], after["children"], after["dist"], after["nMinor"],
+                                      after.get("mutations"), dev)
         for v, lst in rec["new_tips"].items():
             tree.id_lower[int(v)] = dev.upload([tup(lst)])[0]
+            if int(v) not in changed:
+                changed.append(int(v))                   # (an existing tip the placement rewrote: a minor sequence, M:3966)
         if changed:
             update_genome_lists(dev, tree, changed)
         lk, _ = tree_log_likelihood(dev, tree)
