@@ -104,6 +104,11 @@ int maple_lists_download(maple_ctx *ctx, int32_t n, const int32_t *ids, const in
 int maple_arena_mark(maple_ctx *ctx, int64_t *mark);
 int maple_arena_release(maple_ctx *ctx, int64_t mark);
 int maple_arena_stats(maple_ctx *ctx, int64_t *n_lists, int64_t *n_entries, int64_t *n_aux, int64_t *cap_entries);
+/* Compaction: keep only the lists live[0 .. nLive) (no duplicates; -1 entries stay -1), copied to the bottom of the arena in
+ * that order and renumbered 0, 1, 2, ...: newIds[i] = the new id of live[i].  Every other list id, every arena mark, resident
+ * candidate sets and the uploaded tree are gone (upload the tree again with the new ids).  maple_update_partials and the
+ * single-sample placement loop bump-allocate every replaced list; this is how a long run gives the room back. */
+int maple_arena_compact(maple_ctx *ctx, int64_t nLive, const int32_t *live, int32_t *newIds);
 
 /* MAT branch mutation lists (tree.mutations[node], M:336): triples (pos, from, to). CSR upload. */
 int maple_mutations_upload(maple_ctx *ctx, int32_t n_lists, const int64_t *off, const int32_t *mut3,

@@ -113,6 +113,7 @@ struct maple_ctx {
     int64_t *d_ent_off = nullptr, *d_aux_off = nullptr;
     int32_t *d_n_ent = nullptr, *d_n_aux = nullptr;
     std::vector<int64_t> h_ent_off, h_aux_off;
+    std::vector<int32_t> relocated;    // lists maple_lists_update moved to the end of the arena (maple_arena_release keeps their room)
     std::vector<int32_t> h_n_ent, h_n_aux;
     // mutation lists
     int32_t *d_mut3 = nullptr;

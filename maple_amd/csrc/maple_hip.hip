@@ -1492,10 +1492,94 @@ extern "C" int maple_arena_release(maple_ctx *c, int64_t markBoth)
         c->h_mut_off.resize(mmark); c->h_mut_cnt.resize(mmark);
     }
     if (mark == (int64_t)c->h_n_ent.size()) return MAPLE_OK;
-    c->used_ent = c->h_ent_off[mark];
-    c->used_aux = c->h_aux_off[mark];
+    int64_t ue = c->h_ent_off[mark], ua = c->h_aux_off[mark];
+    {   // a list below the mark that maple_lists_update moved to the end of the arena keeps its (new) room
+        size_t k = 0;
+        for (int32_t id : c->relocated) {
+            if (id >= mark) continue;
+            ue = std::max<int64_t>(ue, c->h_ent_off[id] + c->h_n_ent[id]);
+            ua = std::max<int64_t>(ua, c->h_aux_off[id] + c->h_n_aux[id]);
+            c->relocated[k++] = id;
+        }
+        c->relocated.resize(k);
+    }
+    c->used_ent = ue;
+    c->used_aux = ua;
     c->h_ent_off.resize(mark); c->h_aux_off.resize(mark); c->h_n_ent.resize(mark); c->h_n_aux.resize(mark);
     if (c->place && c->place->rootVect >= mark) c->place->rootVect = -1;     // the cached root vector went with the release
+    return MAPLE_OK;
+}
+
+static int settle(maple_ctx *c);
+static int grid_for(int n);
+// Keep only the lists `live` (ids in any order, no duplicates, -1 entries allowed and kept as -1): they are copied to the
+// bottom of the arena in the order given and renumbered 0, 1, 2, ...; newIds[i] = the new id of live[i].  Everything else
+// -- every other list id, every arena mark, resident candidate sets and the uploaded tree -- is gone: upload the tree again
+// with the new ids.  What a long run of maple_update_partials / single-sample placements needs from time to time: every
+// replaced list keeps its room until then.
+extern "C" int maple_arena_compact(maple_ctx *c, int64_t nLive, const int32_t *live, int32_t *newIds)
+{
+    if (!c || nLive < 0 || (nLive && (!live || !newIds))) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(settle(c));
+    const int64_t nl = (int64_t)c->h_n_ent.size();
+    std::vector<uint8_t> seen((size_t)nl, 0);
+    int64_t totE = 0, totA = 0, m = 0;
+    for (int64_t i = 0; i < nLive; i++) {
+        if (live[i] == -1) continue;
+        if (live[i] < 0 || live[i] >= nl) return fail(c, MAPLE_ERR_ARG, "live[%lld] = %d is not a list id", (long long)i, live[i]);
+        if (seen[live[i]]) return fail(c, MAPLE_ERR_ARG, "list %d is named twice", live[i]);
+        seen[live[i]] = 1;
+        totE += c->h_n_ent[live[i]]; totA += c->h_n_aux[live[i]];
+        m++;
+    }
+    // gather into scratch (one wavefront per list), then one straight copy back to the bottom of the arena
+    std::vector<int64_t> srcW((size_t)m), srcA((size_t)m), dstW((size_t)m), dstA((size_t)m);
+    std::vector<int32_t> ne((size_t)m), na((size_t)m);
+    int64_t e = 0, a = 0, k = 0;
+    for (int64_t i = 0; i < nLive; i++) {
+        if (live[i] == -1) { newIds[i] = -1; continue; }
+        const int32_t id = live[i];
+        srcW[k] = c->h_ent_off[id]; srcA[k] = c->h_aux_off[id]; dstW[k] = e; dstA[k] = a; ne[k] = c->h_n_ent[id]; na[k] = c->h_n_aux[id];
+        e += ne[k]; a += na[k];
+        newIds[i] = (int32_t)k++;
+    }
+    if (m) {
+        HIPCK(c, c->s_words.reserve((size_t)totE));
+        HIPCK(c, c->s_aux.reserve((size_t)std::max<int64_t>(totA, 1)));
+        for (int b = 0; b < 6; b++) HIPCK(c, c->s_i64[b].reserve((size_t)m));
+        HIPCK(c, c->s_i32[2].reserve((size_t)m));
+        HIPCK(c, c->s_i32[3].reserve((size_t)m));
+        HIPCK(c, hipMemcpyAsync(c->s_i64[0].p, srcW.data(), (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->s_i64[1].p, srcA.data(), (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->s_i64[2].p, dstW.data(), (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->s_i64[3].p, dstA.data(), (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->s_i32[2].p, ne.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->s_i32[3].p, na.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+        // (k_commit: list i of the source (words, aux) at swoff / saoff -> destination arrays at dst_w / dst_a)
+        hipLaunchKernelGGL(k_commit, dim3(grid_for((int)std::min<int64_t>(m, 1 << 20) * 64)), dim3(MAPLE_BLOCK), 0, c->stream, (int)m, c->d_words,
+                           c->d_aux, c->s_i64[0].p, c->s_i64[1].p, c->s_i32[2].p, c->s_i32[3].p, c->s_i64[2].p, c->s_i64[3].p, c->s_words.p,
+                           c->s_aux.p, (const int32_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+        HIPCK(c, hipGetLastError());
+        HIPCK(c, hipMemcpyAsync(c->d_words, c->s_words.p, (size_t)totE * sizeof(uint2), hipMemcpyDeviceToDevice, c->stream));
+        if (totA) HIPCK(c, hipMemcpyAsync(c->d_aux, c->s_aux.p, (size_t)totA * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->d_ent_off, dstW.data(), (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->d_aux_off, dstA.data(), (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->d_n_ent, ne.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipMemcpyAsync(c->d_n_aux, na.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+    }
+    c->h_ent_off.assign(dstW.begin(), dstW.end()); c->h_aux_off.assign(dstA.begin(), dstA.end());
+    c->h_n_ent.assign(ne.begin(), ne.end()); c->h_n_aux.assign(na.begin(), na.end());
+    c->used_ent = totE; c->used_aux = totA;
+    c->relocated.clear();
+    c->tree_set = false; c->tree_stale = false; c->nodes_current = false; c->scan_valid = false;
+    if (c->place) { c->place->valid = false; c->place->rootVect = -1; }
+    for (auto &cs : c->candsets) {
+        if (cs.lists) (void)hipFree(cs.lists);
+        if (cs.frame) (void)hipFree(cs.frame);
+        cs = maple_ctx::CandSet{};
+    }
     return MAPLE_OK;
 }
 
@@ -1693,6 +1777,7 @@ extern "C" int maple_lists_update(maple_ctx *c, int32_t n, const int32_t *ids, c
         else { eo[i] = ue; ao[i] = ua; ue += cnt[i]; ua += cna[i]; }
     }
     if (ue > c->cap_ent || ua > c->cap_aux) return fail(c, MAPLE_ERR_NOMEM, "arena full while updating %d lists", n);
+    for (int i = 0; i < n; i++) if (eo[i] >= c->used_ent) c->relocated.push_back(ids[i]);   // (maple_arena_release must not free their room)
     TRY(settle(c));
     std::vector<uint2> w;
     for (int i = 0; i < n; i++) {
@@ -2574,6 +2659,22 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
     }
     for (size_t k = 0; k < seenNew.size(); k++)
         if (!seenNew[k]) return fail(c, MAPLE_ERR_ARG, "new node %d is not in the patch", nOld + (int)k);
+    {   // relatives must point back at each other in the tree AS PATCHED -- checked before anything changes, so that a
+        // malformed patch leaves the library's copy as it was (the traversals trust these columns)
+        std::vector<int32_t> at((size_t)nTotal, -1);
+        for (int i = 0; i < nTouched; i++) at[nodes[i]] = i;
+        auto upOf = [&](int v) { return at[v] >= 0 ? up[at[v]] : c->h_tree_up[v]; };
+        auto c0Of = [&](int v) { return at[v] >= 0 ? child0[at[v]] : c->h_tree_c0[v]; };
+        auto c1Of = [&](int v) { return at[v] >= 0 ? child1[at[v]] : c->h_tree_c1[v]; };
+        for (int i = 0; i < nTouched; i++) {
+            const int v = nodes[i];
+            for (int32_t ch : {child0[i], child1[i]})
+                if (ch >= 0 && (ch == v || upOf(ch) != v)) return fail(c, MAPLE_ERR_ARG, "node %d: child %d does not point back to it", v, ch);
+            if (child0[i] >= 0 && child0[i] == child1[i]) return fail(c, MAPLE_ERR_ARG, "node %d: the same child twice", v);
+            if (up[i] >= 0 && c0Of(up[i]) != v && c1Of(up[i]) != v)
+                return fail(c, MAPLE_ERR_ARG, "node %d is not a child of its parent %d", v, up[i]);
+        }
+    }
     // ---- the host copy
     for (auto *vec : {&c->h_tree_up, &c->h_tree_c0, &c->h_tree_c1, &c->h_tree_lower, &c->h_tree_upRight, &c->h_tree_upLeft,
                       &c->h_tree_totUp, &c->h_tree_mut})

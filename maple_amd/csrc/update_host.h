@@ -128,6 +128,9 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
     S.clear();
     S.replacedNodes.clear();
     int replaced = 0;
+    // (the caller's columns are trusted only as far as they are read: every relative that enters the work lists is range-checked)
+    bool badNode = false;
+    auto okNode = [&](int v) { if (v < -1 || v >= n) { badNode = true; return false; } return v >= 0; };
     auto whichChild = [&](int p, int v) { return c0[p] == v ? 0 : 1; };
     auto markChild = [&](int p, int which) { (which == 0 ? S.dCh0 : S.dCh1)[p] = 1; S.touch(p); };
     // the upper vector seen by each node, in the node's own reference frame (M:5503-5513)
@@ -143,7 +146,7 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
     for (size_t i = 0; i < chg.size(); i++) {
         const int v = chg[i];
         S.dLow[v] = 1; S.dDist[v] = 1; S.touch(v);
-        if (up[v] >= 0) {
+        if (okNode(up[v])) {
             markChild(up[v], whichChild(up[v], v));
             if (!S.inFrontier[up[v]]) { S.inFrontier[up[v]] = 1; frontier.push_back(up[v]); }
         }
@@ -165,7 +168,7 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
         a.resize(m); b.resize(m); pa.resize(m); pb.resize(m); da.resize(m); db.resize(m); ta.resize(m); tb.resize(m);
         for (size_t k = 0; k < m; k++) {
             a[k] = c0[nodes[k]]; b[k] = c1[nodes[k]];
-            if (a[k] < 0 || b[k] < 0) return fail(c, MAPLE_ERR_ARG, "node %d has a changed child but no two children", nodes[k]);
+            if (a[k] < 0 || b[k] < 0 || a[k] >= n || b[k] >= n) return fail(c, MAPLE_ERR_ARG, "node %d has a changed child but no two (valid) children", nodes[k]);
             pa[k] = lower[a[k]]; pb[k] = lower[b[k]];
             da[k] = dist[a[k]]; db[k] = dist[b[k]]; ta[k] = tip[a[k]]; tb[k] = tip[b[k]];
         }
@@ -213,7 +216,7 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
             replaced++;
             if (!diff[k]) continue;
             S.dLow[v] = 1; S.touch(v);
-            if (up[v] >= 0) {
+            if (okNode(up[v])) {
                 markChild(up[v], whichChild(up[v], v));
                 if (!S.inFrontier[up[v]]) { S.inFrontier[up[v]] = 1; frontier.push_back(up[v]); }
             }
@@ -270,6 +273,7 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
             if (nodes.size() == 1) continue;
             nodes.erase(nodes.begin());                                    // (only the root has depth 0)
         }
+        for (int v : nodes) if (up[v] < 0 || up[v] >= n) return fail(c, MAPLE_ERR_ARG, "node %d: parent index out of range", v);
         TRY(vectUpOf(nodes, vu));
         // One fused launch for the level: probVectTotUp where the node's lower list, length or upper vector changed,
         // probVectUpRight (upper vector + child 1, for child 0) and probVectUpLeft (upper vector + child 0, for child 1) where
@@ -287,6 +291,7 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
                 }
             }
             if (c0[v] < 0) continue;
+            if (c0[v] >= n || c1[v] < 0 || c1[v] >= n) return fail(c, MAPLE_ERR_ARG, "node %d: child index out of range", v);
             for (int which = 1; which >= 0; which--) {
                 if (!(S.dUp[v] || S.dDist[v] || (which == 0 ? S.dCh0[v] : S.dCh1[v]))) continue;
                 const int kd = which == 1 ? c1[v] : c0[v];
@@ -362,6 +367,7 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
             addTodo(target);
         }
     }
+    if (badNode) return fail(c, MAPLE_ERR_ARG, "a relative index of a touched node is out of range");
     return MAPLE_OK;
     };
     std::vector<int32_t> chg(changed, changed + nChanged), next;

@@ -25,7 +25,7 @@ EXPORTS = [
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
     "maple_timing_read_kind", "maple_placement_supports_batch", "maple_debug_gpv_batch", "maple_debug_simplify_batch",
-    "maple_candset_destroy", "maple_debug_calib_write", "maple_spr_search_visited", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev",
+    "maple_candset_destroy", "maple_debug_calib_write", "maple_spr_search_visited", "maple_arena_compact", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev",
 ]
 
 
@@ -61,7 +61,7 @@ def load_library():
     if _lib is None:
         lib_path = os.environ.get("MAPLE_HIP_LIB", LIB_PATH)         # (kernel-variant experiments: another build of the library)
         if not os.path.exists(lib_path):
-            raise MapleError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`; "
+            raise MapleError(f"{lib_path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`; "
                              "there is no CPU fallback for the placement path")
         # PyTorch-ROCm ships its own HIP runtime; whichever copy of libamdhip64 is loaded first serves the whole
         # process, and torch cannot see the GPU if the system copy got there before it.  Load torch's first.
@@ -222,6 +222,14 @@ class Device:
         a, b, c_, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         self._ck(self.lib.maple_arena_stats(self.h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d)))
         return dict(n_lists=a.value, n_entries=b.value, n_aux=c_.value, cap_entries=d.value)
+
+    def arena_compact(self, live):
+        """Keep only the lists `live` (-1 entries stay -1): returns their new ids.  Every other id, mark, candidate set and the
+        uploaded tree are gone afterwards (maple_arena_compact)."""
+        live = _i32(live)
+        new = np.zeros(len(live), np.int32)
+        self._ck(self.lib.maple_arena_compact(self.h, C.c_int64(len(live)), _ptr(live), _ptr(new)))
+        return new
 
     def upload_mutations(self, mut_lists):
         off, mut3 = pack_mutations(mut_lists)

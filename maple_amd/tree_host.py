@@ -43,7 +43,11 @@ class HostTree:
     def columns(self):
         """The topology as plain columns (up, child0, child1, isTip, depth: int32 / uint8 arrays, -1 = none) -- what the
         C ABI takes; cached until apply_topology changes the tree."""
+        sig = (self.n, sum(self.n_minor))                 # (a sample placed as a minor sequence turns a tip into a non-tip)
+        if self._cols is not None and getattr(self, "_cols_sig", None) != sig:
+            self._cols = None
         if self._cols is None:
+            self._cols_sig = sig
             up = np.asarray([-1 if u is None else u for u in self.up], dtype=np.int32)
             c0 = np.asarray([c[0] if c else -1 for c in self.children], dtype=np.int32)
             c1 = np.asarray([c[1] if c else -1 for c in self.children], dtype=np.int32)
@@ -181,6 +185,24 @@ class HostTree:
                     self.id_mut[v] = dev.upload_mutations([new_mut[v]])[0] if new_mut[v] else -1
         self._cols = None
         return changed
+
+
+def compact_arena(dev: Device, tree: HostTree, keep=()):
+    """Give the room of every replaced genome list back (maple_arena_compact): the four lists of every node of ``tree`` --
+    and the extra ids ``keep`` -- survive, renumbered; the tree is uploaded again.  For long runs of update_genome_lists /
+    single-sample placements, whose every replaced list is bump-allocated (call it when Device.stats() shows the arena
+    filling up).  Returns the new ids of ``keep``."""
+    cols = [tree.id_lower, tree.id_upRight, tree.id_upLeft, tree.id_totUp]
+    live = np.concatenate(cols + [np.asarray(keep, dtype=np.int32)])
+    # (a list may be shared by two columns -- never in trees built here, but an id must not be named twice)
+    uniq, first = np.unique(live[live >= 0], return_index=False), None
+    new_of = dict(zip(uniq.tolist(), dev.arena_compact(uniq).tolist()))
+    remap = np.vectorize(lambda i: new_of.get(int(i), -1) if i >= 0 else -1, otypes=[np.int32])
+    n = tree.n
+    tree.id_lower, tree.id_upRight = remap(cols[0]), remap(cols[1])
+    tree.id_upLeft, tree.id_totUp = remap(cols[2]), remap(cols[3])
+    tree.upload_topology(dev)
+    return remap(np.asarray(keep, dtype=np.int32)) if len(keep) else np.zeros(0, np.int32)
 
 
 def tree_log_likelihood(dev: Device, tree: HostTree):
