@@ -154,7 +154,9 @@ struct maple_ctx {
     DevBuf<long long> s_fan[6];        // per (query, frame) item of a nesting level: capacities, offsets, sizes (k_fan_*)
     DevBuf<uint8_t> s_fan_tmp;
     DevBuf<SScan> t_scan;              // the tree in the searches' depth-first order (search_dev.h), per effectivelyNon0BLen
-    DevBuf<int32_t> t_scan_parent;
+    DevBuf<int32_t> t_scan_parent, t_cand_before, t_clade_visits;
+    DevBuf<unsigned long long> s_fin_mask;    // bitmaps of the finite scores of the whole-tree searches' rows (FiniteRows, search_dev.h)
+    DevBuf<int32_t> s_fin_prefix;
     bool scan_valid = false;
     double scan_eff = -1.0;
     std::vector<int32_t> h_depth;      // per node: distance from the root in branches

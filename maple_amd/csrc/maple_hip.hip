@@ -77,7 +77,7 @@ __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ 
                                                    const int32_t *qList, int nC, const int32_t *cand, int isTip,
                                                    double bLen, double *out, long long ldOut, const int32_t *outCol,
                                                    const uint8_t *qTip, const double *qBLen, int *counter,
-                                                   TileBest *tileBest, const int32_t *visitRank)
+                                                   TileBest *tileBest, const int32_t *visitRank, unsigned long long *finMask)
 {
     __shared__ Lds lds;
     __shared__ unsigned long long qlds[MAPLE_BLOCK / 64][MAPLE_QLDS];   // the tile's query list, one copy per wavefront
@@ -111,6 +111,7 @@ __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         const int cl = k < nC ? cand[k] : -1;                             // -1: this column has no list (score unused)
+        bool finite = false;
         if (cl >= 0) {
             const bool tipq = qTip ? qTip[q] != 0 : isTip != 0;
             const double blq = qBLen ? qBLen[q] : bLen;
@@ -121,8 +122,13 @@ __global__ MAPLE_APPEND_ATTR void k_append_queries(const DevModel *__restrict__ 
                 while (!w.step()) {}
                 lk = w.finish();
             } else lk = append_walk(c, list_ref(av, cl), qref, tipq, blq);
-            if (!tileBest) out[(long long)q * ldOut + (outCol ? outCol[k] : k)] = lk;
+            if (!tileBest) { if (!finMask || lk > -INFINITY) out[(long long)q * ldOut + (outCol ? outCol[k] : k)] = lk; }   // (see the LDS kernel)
             else { tbScore = lk; tbRank = visitRank ? visitRank[k] : k; tbIdx = k; }
+            finite = lk > -INFINITY;
+        }
+        if (finMask) {
+            const unsigned long long fm = __ballot(finite);
+            if (lane == 0) finMask[(long long)q * nChunks + ch] = fm;
         }
         if (tileBest) {
             // the wavefront reduction of north_star: best score of the tile's 64 candidates, exact ties to the EARLIEST visit
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(MAPLE_LDS_BLOCK) __attribute__((amdgpu_waves_per_eu
 void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ, const int32_t *qList, int nC, const int32_t *cand,
                           int isTip, double bLen, double *out, long long ldOut, const int32_t *outCol, const uint8_t *qTip,
                           const double *qBLen, int *counter, TileBest *tileBest, const int32_t *visitRank,
-                          const int4 *chunkTab, int nChunkTab, int nF)
+                          const int4 *chunkTab, int nChunkTab, int nF, unsigned long long *finMask)
 {
     // chunkTab (trees with MAT local references): the chunks are given as {first candidate, candidates (<= 64), reference
     // frame, -}, each within ONE frame, and query q's list is qList[q * nF + frame] -- the query expressed in that frame
@@ -247,6 +253,7 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+            bool finite = false;
             if (cl >= 0) {
                 const bool tipq = qTip ? qTip[q] != 0 : isTip != 0;
                 const double blq = qBLen ? qBLen[q] : bLen;
@@ -261,8 +268,16 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
                     const MemG pG{(const unsigned long long *)pr.w, pr.aux};
                     lk = stagedQ ? append_walk_m(c, pG, qL, tipq, blq) : append_walk_m(c, pG, qG, tipq, blq);
                 }
-                if (!tileBest) out[(long long)q * ldOut + (outCol ? outCol[k] : k)] = lk;
+                // finMask: which of the tile's 64 scores are finite goes out as ONE word per (query, tile) and only the finite
+                // scores are stored -- the searches these rows are for are the ones whose scores are nearly all -inf (a mismatch
+                // over a zero-length branch), and an 8-byte store into every line of a row was most of the kernel's HBM traffic
+                if (!tileBest) { if (!finMask || lk > -INFINITY) out[(long long)q * ldOut + (outCol ? outCol[k] : k)] = lk; }
                 else { tbScore = lk; tbRank = visitRank ? visitRank[k] : k; tbIdx = k; }
+                finite = lk > -INFINITY;
+            }
+            if (finMask) {
+                const unsigned long long fm = __ballot(finite);
+                if (lane == 0) finMask[(long long)q * nChunks + ch] = fm;
             }
             if (tileBest) {
                 for (int m2 = 32; m2 >= 1; m2 >>= 1) {
@@ -861,7 +876,7 @@ __device__ __forceinline__ void spr_search_impl(const DevModel *__restrict__ mp,
                                                    int traceQuery, int32_t *trI, double *trD, int trCap, int32_t *trN,
                                                    int activeLanes, const double *cacheS, int budget, const int32_t *rTable, int nF,
                                                    const int32_t *cacheRow, int leanVisits, unsigned long long *ovfUsed, uint8_t *ovfBase,
-                                                   long long ovfChunks)
+                                                   long long ovfChunks, FiniteRows fin)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
@@ -936,6 +951,7 @@ __device__ __forceinline__ void spr_search_impl(const DevModel *__restrict__ mp,
             const size_t row = cacheRow ? (size_t)cacheRow[q] : (size_t)q;
             curRow = (int)row;
             S.cached = cacheS ? cacheS + row * T.n : nullptr;             // this query's row of the (queries x nodes) score table
+            S.finMask = (cacheS && fin.mask) ? fin.mask + row * fin.nWords : nullptr;
             S.rTable = (cacheS && rTable) ? rTable + row * nF : nullptr;  // and of the (queries x frames) removed lists
             S.fShort[0] = S.fShort[1] = S.fShort[2] = S.fShort[3] = -1;
             // A pruned node on a zero-length branch is searched with removedBLen = 0 (M:9644).  Without an error model a
@@ -1091,7 +1107,8 @@ __device__ __forceinline__ void spr_search_impl(const DevModel *__restrict__ mp,
                             __builtin_amdgcn_readfirstlane(S.scanFirstScored ? 1 : 0) != 0,
                             __builtin_amdgcn_readfirstlane(S.scanSeedFrame), hSeed, readfirst_f64(S.scanItem.lastLK),
                             __builtin_amdgcn_readfirstlane((int)S.scanItem.fails), P, br, capBnow, slotLK, slotFails,
-                            slotOwner, T.scanDepthCap, st);
+                            slotOwner, T.scanDepthCap, st, fin.mask ? fin.mask + (size_t)rowU * fin.nWords : nullptr,
+                            fin.mask ? fin.prefix + (size_t)rowU * (fin.nWords + 1) : nullptr, T.candBefore, T.cladeVisits);
 #ifdef MAPLE_SPR_PROFILE
             if (searcher) out[q].tReplay += wall_clock64() - tScan0;
 #endif
@@ -1111,9 +1128,9 @@ __device__ __forceinline__ void spr_search_impl(const DevModel *__restrict__ mp,
     const int32_t *nodes, WsLayout L, LaneBytes LB, uint8_t *wsBase, int32_t *counter, SearchOut *out, uint2 *poolW, double *poolA, \
     unsigned long long *poolUsed, long long poolCapW, long long poolCapA, int traceQuery, int32_t *trI, double *trD, int trCap,     \
     int32_t *trN, int activeLanes, const double *cacheS, int budget, const int32_t *rTable, int nF, const int32_t *cacheRow,        \
-    int leanVisits, unsigned long long *ovfUsed, uint8_t *ovfBase, long long ovfChunks
+    int leanVisits, unsigned long long *ovfUsed, uint8_t *ovfBase, long long ovfChunks, FiniteRows fin
 #define MAPLE_SPR_KERNEL_PASS mp, av, mv, T, P, n, nodes, L, LB, wsBase, counter, out, poolW, poolA, poolUsed, poolCapW, poolCapA,   \
-    traceQuery, trI, trD, trCap, trN, activeLanes, cacheS, budget, rTable, nF, cacheRow, leanVisits, ovfUsed, ovfBase, ovfChunks
+    traceQuery, trI, trD, trCap, trN, activeLanes, cacheS, budget, rTable, nF, cacheRow, leanVisits, ovfUsed, ovfBase, ovfChunks, fin
 template <bool RV, bool U, bool SS>
 __global__ __launch_bounds__(64) MAPLE_SPR_ATTR void k_spr_search(MAPLE_SPR_KERNEL_ARGS)
 {
@@ -1262,7 +1279,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     for (auto &b : c->s_i64) b.release();
     c->s_words.release(); c->s_aux.release(); c->s_ais.release(); c->s_pool_w.release(); c->s_pool_a.release();
     for (auto &b : c->t_i32) b.release();
-    c->t_dist.release(); c->t_tip.release(); c->t_nodes.release(); c->t_scored_col.release(); c->t_scored_frame.release(); c->t_scan.release(); c->t_scan_parent.release(); c->s_tilebest.release(); c->s_comm_u64.release();
+    c->t_dist.release(); c->t_tip.release(); c->t_nodes.release(); c->t_scored_col.release(); c->t_scored_frame.release(); c->t_scan.release(); c->t_scan_parent.release(); c->t_cand_before.release(); c->t_clade_visits.release(); c->s_fin_mask.release(); c->s_fin_prefix.release(); c->s_tilebest.release(); c->s_comm_u64.release();
     if (c->d_tile_counters) (void)hipFree(c->d_tile_counters);
     c->s_search_ws.release(); c->s_search_ws_big.release(); c->s_search_out.release(); c->s_counter.release(); c->s_cache.release();
     for (auto &b : c->p_i32) b.release();
@@ -2205,7 +2222,8 @@ int maple_internal_ev_pair(maple_ctx *c, hipEvent_t *a, hipEvent_t *b, int kind,
 static int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int32_t *qList, int nC, const int32_t *cand,
                                  int isTip, double bLen, double *out, long long ldOut, const int32_t *outCol,
                                  const uint8_t *qTip, const double *qBLen, int kind, double algBytes, TileBest *tileBest = nullptr,
-                                 const int32_t *visitRank = nullptr, const int4 *chunkTab = nullptr, int nChunkTab = 0, int nF = 1)
+                                 const int32_t *visitRank = nullptr, const int4 *chunkTab = nullptr, int nChunkTab = 0, int nF = 1,
+                                 unsigned long long *finMask = nullptr)
 {
     const long long tiles = (long long)nQ * (chunkTab ? nChunkTab : (nC + 63) / 64);
     if (tiles > 0x7fffffffLL - (1 << 20)) return fail(c, MAPLE_ERR_ARG, "nQ x nC too large for one launch");
@@ -2235,10 +2253,10 @@ static int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int3
         }
         DISPATCH3(c, k_append_queries_lds, <<<gridL, MAPLE_LDS_BLOCK, dyn, s>>>(c->d_model, view(c), nQ, qList, nC, cand, isTip, bLen, out,
                                                                               ldOut, outCol, qTip, qBLen, counter, tileBest, visitRank,
-                                                                              chunkTab, nChunkTab, nF));
+                                                                              chunkTab, nChunkTab, nF, finMask));
     } else
     DISPATCH3(c, k_append_queries, <<<grid, MAPLE_BLOCK, 0, s>>>(c->d_model, view(c), nQ, qList, nC, cand, isTip, bLen, out, ldOut,
-                                                                  outCol, qTip, qBLen, counter, tileBest, visitRank));
+                                                                  outCol, qTip, qBLen, counter, tileBest, visitRank, finMask));
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipEventRecord(e1, s));
     return MAPLE_OK;
@@ -2912,6 +2930,25 @@ static int fan_out_level(maple_ctx *c, int m, int nF, int a, int b, int32_t *dR,
     return MAPLE_OK;
 }
 
+// finite scores before each word of every row's bitmap (FiniteRows, search_dev.h): one wavefront per row
+__global__ __launch_bounds__(64) void k_finite_prefix(int nRows, int nWords, const unsigned long long *mask, int32_t *prefix)
+{
+    const int lane = threadIdx.x;
+    for (int row = blockIdx.x; row < nRows; row += gridDim.x) {
+        const unsigned long long *m = mask + (size_t)row * nWords;
+        int32_t *p = prefix + (size_t)row * (nWords + 1);
+        int run = 0;
+        for (int base = 0; base <= nWords; base += 64) {
+            const int w = base + lane;
+            const int cnt = w < nWords ? __popcll(m[w]) : 0;
+            int incl = cnt;
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+            if (w <= nWords) p[w] = run + incl - cnt;
+            run += __shfl(incl, 63, 64);
+        }
+    }
+}
+
 extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *nodes, const maple_search_params *sp,
                                       int32_t ws_entries_per_lane, int32_t *bestNode, double *bestScore, double *blen3,
                                       int32_t *placement, double *improvement, double *currentLK, int32_t *nAppend,
@@ -2987,6 +3024,20 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // (the frontier tier, frontier.hip, takes the searches of trees without MAT local references)
     const bool useFrontier = sp->searchTier == 0 && !c->tree_has_mut && c->trace_query < 0;
     const std::vector<int32_t> *rowOverride = nullptr;                 // rows of the score table the next cached launch reads
+    FiniteRows finRows{nullptr, nullptr, 0};                           // ... and, where the rows come with one, the bitmap of their finite scores
+    const int finWords = (c->n_scored + 63) / 64;                      // (words per row: one per tile of 64 candidates of the dense kernel)
+    auto fin_reserve = [&](size_t rows) -> int {
+        HIPCK(c, c->s_fin_mask.reserve_exact(std::max(rows * (size_t)finWords, c->s_fin_mask.cap)));
+        HIPCK(c, c->s_fin_prefix.reserve_exact(std::max(rows * (size_t)(finWords + 1), c->s_fin_prefix.cap)));
+        return MAPLE_OK;
+    };
+    auto fin_prefix = [&](hipStream_t st, size_t row0, size_t rows) -> int {   // (after the dense launch that wrote those rows' bitmaps)
+        if (!rows) return MAPLE_OK;
+        k_finite_prefix<<<(int)std::min<size_t>(rows, 4096), 64, 0, st>>>((int)rows, finWords, c->s_fin_mask.p + row0 * finWords,
+                                                                          c->s_fin_prefix.p + row0 * (finWords + 1));
+        HIPCK(c, hipGetLastError());
+        return MAPLE_OK;
+    };
     std::function<int()> afterLaunch;                                  // called once, right after the next search kernel is queued
     auto run_queries = [&](std::vector<int32_t> todo, std::vector<int32_t> slot, const double *cacheS, int budgetNow,
                            const int32_t *rTable, int nF) -> int {
@@ -3084,11 +3135,14 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             // cached (whole-tree) searches descend by scanning the tree in their own depth-first order; the per-depth slots
             // of every searching lane live in LDS (deeper trees fall back to popping one node at a time)
             DevTree Tk = c->dtree;
+            Tk.candBefore = c->t_cand_before.p;
+            Tk.cladeVisits = c->t_clade_visits.p;
             size_t dynLds = 0;
             int launchLanes = activeLanes, launchWaves = nWaves;
             if (cacheS && c->scan_valid && (size_t)(c->tree_max_depth + 2) * 16 <= (48u << 10)) {
                 Tk.scan = c->t_scan.p;
                 Tk.scanParent = c->t_scan_parent.p;
+
                 Tk.scanDepthCap = c->tree_max_depth + 2;
                 dynLds = ((size_t)Tk.scanDepthCap * 16 + 15) & ~(size_t)15;
                 launchLanes = 1;                                         // one search per wavefront, 64 lanes per clade scan
@@ -3119,7 +3173,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                                                                          launchLanes, cacheS, budgetNow, rTable, nF,               \
                                                                          cacheS ? c->s_i32[1].p : nullptr,                          \
                                                                          assistOK ? 1 + coopMaxHost : 0, (unsigned long long *)(c->s_counter.p + 6),          \
-                                                                         ovfChunks ? c->s_search_ws_big.p : nullptr, ovfChunks)
+                                                                         ovfChunks ? c->s_search_ws_big.p : nullptr, ovfChunks, cacheS ? finRows : FiniteRows{nullptr, nullptr, 0})
             if (!cacheS && assistOK) DISPATCH3(c, k_spr_search_assisted, MAPLE_SPR_LAUNCH_ARGS);
             else DISPATCH3(c, k_spr_search, MAPLE_SPR_LAUNCH_ARGS);
 #undef MAPLE_SPR_LAUNCH_ARGS
@@ -3225,6 +3279,22 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         }
         std::vector<int32_t> prank((size_t)nT, 0);
         for (int r = 0; r < nT; r++) { const int u = c->h_tree_up[byRank[r]]; prank[r] = u >= 0 ? c->h_nodes[u].preRank : 0; }
+        // for rows that come with a bitmap of their finite scores (FiniteRows, search_dev.h): candidates before each rank, and
+        // what a clade adds to the count of candidate placements when it is walked with every score -inf
+        std::vector<int32_t> candBefore((size_t)nT + 1, 0), cladeVisits((size_t)nT, 0);
+        for (int r = 0; r < nT; r++)
+            candBefore[r + 1] = candBefore[r] + ((sc[r].ff & SS_TOTUP) ? 1 : 0);   // (the order of the dense kernel's candidates)
+        for (int r = nT - 1; r >= 1; r--) {
+            const int v = byRank[r];
+            if (!reach[v]) continue;
+            const uint32_t fl = sc[r].ff & 15u;
+            if (!(fl & SS_ENTER)) continue;                                 // never pushed: neither it nor its clade is visited
+            const bool scored = fl & SS_SCORED, counts = scored && (fl & SS_TOTUP), dropped = scored && !(fl & SS_TOTUP);
+            const int add = (counts ? 1 : 0) + ((!dropped && (fl & SS_INNER)) ? cladeVisits[r] : 0);
+            cladeVisits[prank[r]] += add;
+        }
+        TRY(h2d(c, c->t_cand_before, candBefore.data(), candBefore.size()));
+        TRY(h2d(c, c->t_clade_visits, cladeVisits.data(), cladeVisits.size()));
         TRY(h2d(c, c->t_scan, sc.data(), sc.size()));
         TRY(h2d(c, c->t_scan_parent, prank.data(), prank.size()));
         HIPCK(c, hipStreamSynchronize(c->stream));
@@ -3232,6 +3302,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         c->scan_eff = P.effNon0;
         c->scan_valid = true;
     }
+    // rows of the score table come with the bitmap of their finite scores (FiniteRows) when the tables that go with it exist
+    const bool useFin = hybrid && c->scan_valid && !c->tree_has_mut;
     // Without an error model the whole-tree searches are known before anything runs: they are the ones that start from a
     // zero-length branch (the routing hint in the kernel gives those 16 placements and sends them on).  Their dense scoring
     // needs nothing from the lane searches, so it is launched first, on a side stream, and shares the GPU with them -- the
@@ -3269,6 +3341,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             preSpare = (int)std::min<size_t>(4096, rowsMax - preIdx.size());
             const int mZ = (int)preIdx.size();
             HIPCK(c, c->s_cache.reserve_exact((size_t)(mZ + preSpare) * nTpre));
+            TRY(fin_reserve((size_t)mZ + preSpare));
             if (!c->stream2) {
                 HIPCK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
                 HIPCK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -3294,10 +3367,11 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             HIPCK(c, hipStreamSynchronize(c->stream2));                     // (the three vectors are locals)
             // queued BEHIND the lane launch: a workgroup of the dense kernel wants most of a compute unit's LDS, so it starts
             // where the lane searches have thinned out -- launched first it would hold them off instead (measured: no overlap)
-            afterLaunch = [c, mZ, nTpre, qBytes]() -> int {
+            afterLaunch = [c, mZ, nTpre, qBytes, fin_prefix, useFin]() -> int {
                 TRY(launch_append_queries(c, c->stream2, mZ, c->z_ql.p, c->n_scored, c->t_i32[8].p, 0, 0.0, c->s_cache.p, nTpre,
                                           c->t_scored_col.p, c->z_qt.p, c->z_qb.p, MAPLE_K_SPR_SCORE,
-                                          (double)mZ * c->scored_bytes_total + qBytes));
+                                          (double)mZ * c->scored_bytes_total + qBytes, nullptr, nullptr, nullptr, 0, 1, useFin ? c->s_fin_mask.p : nullptr));
+                if (useFin) TRY(fin_prefix(c->stream2, 0, (size_t)mZ));
                 HIPCK(c, hipEventRecord(c->ev_join, c->stream2));
                 return MAPLE_OK;
             };
@@ -3359,13 +3433,17 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 for (int k = 0; k < m2; k++) qBytes += 8.0 * c->h_n_ent[ql2[k]] + 8.0 * c->h_n_aux[ql2[k]];
                 TRY(launch_append_queries(c, c->stream, m2, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, 0, 0.0,
                                           c->s_cache.p + (size_t)mZ * nTpre, nTpre, c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p,
-                                          MAPLE_K_SPR_SCORE, (double)m2 * c->scored_bytes_total + qBytes));
+                                          MAPLE_K_SPR_SCORE, (double)m2 * c->scored_bytes_total + qBytes, nullptr, nullptr, nullptr, 0, 1,
+                                          useFin ? c->s_fin_mask.p + (size_t)mZ * finWords : nullptr));
+                if (useFin) TRY(fin_prefix(c->stream, (size_t)mZ, (size_t)m2));
             }
             if (afterLaunch) { std::function<int()> f; f.swap(afterLaunch); TRY(f()); }   // (no lane launch took it)
             HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
             if (!qn.empty()) {
                 rowOverride = &rowsNow;
+                if (useFin) finRows = FiniteRows{c->s_fin_mask.p, c->s_fin_prefix.p, finWords};
                 const int rc = run_queries(qn, sl, c->s_cache.p, 0, nullptr, 0);
+                finRows = FiniteRows{nullptr, nullptr, 0};
                 rowOverride = nullptr;
                 if (rc != MAPLE_OK) return rc;
             }
@@ -3433,11 +3511,16 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 TRY(h2d(c, c->s_i32[6], ql.data(), (size_t)m));
                 double qBytes = 0.0;                                   // each query list once per launch
                 for (int k = 0; k < m; k++) qBytes += 8.0 * c->h_n_ent[ql[k]] + 8.0 * c->h_n_aux[ql[k]];
+                TRY(fin_reserve((size_t)m));
                 TRY(launch_append_queries(c, c->stream, m, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, 0, 0.0, c->s_cache.p, nT,
                                           c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p, MAPLE_K_SPR_SCORE,
-                                          (double)m * c->scored_bytes_total + qBytes));
+                                          (double)m * c->scored_bytes_total + qBytes, nullptr, nullptr, nullptr, 0, 1, useFin ? c->s_fin_mask.p : nullptr));
+                if (useFin) TRY(fin_prefix(c->stream, 0, (size_t)m));
                 if (dbgT) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] t=%.1f ms: scored\n", tms(tStart, tnow())); }
-                TRY(run_queries(qn, sl, c->s_cache.p, 0, nullptr, 0));
+                if (useFin) finRows = FiniteRows{c->s_fin_mask.p, c->s_fin_prefix.p, finWords};
+                const int rcW = run_queries(qn, sl, c->s_cache.p, 0, nullptr, 0);
+                finRows = FiniteRows{nullptr, nullptr, 0};
+                TRY(rcW);
                 if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: replayed\n", tms(tStart, tnow()));
             } else {
                 // the removed list in every MAT reference frame, along the paths the traversal itself takes

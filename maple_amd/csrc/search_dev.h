@@ -74,7 +74,26 @@ struct DevTree {
     const SScan *scan;                 // [n] by preRank, or null (then the cached regime pops one node at a time)
     const int32_t *scanParent;         // [n] by preRank: the rank of the parent
     int32_t scanDepthCap;              // per-depth slots a searching lane owns in LDS
+    // for score rows that come with a bitmap of their finite scores (whole-tree searches, FiniteRows below):
+    const int32_t *candBefore;         // [n + 1] by preRank: scored candidates (nodes with a probVectTotUp) of smaller rank
+    const int32_t *cladeVisits;        // [n] by preRank: candidate placements counted below the node when its whole clade is
+                                       // walked with every score -inf (the non-strict rule descends everywhere, M:7095)
 };
+
+// A search's row of the score table together with the bitmap of its finite scores (one bit per scored candidate, in rank
+// order; one word per tile of 64 candidates of the dense kernel) and the number of finite scores before each word: only the
+// finite scores are stored in the row, and a clade without a single finite score is counted, not walked.
+struct FiniteRows {
+    const unsigned long long *mask;    // [rows][nWords] or null (then every score of the row is stored)
+    const int32_t *prefix;             // [rows][nWords + 1]
+    int32_t nWords;
+};
+__device__ __forceinline__ bool fin_bit(const unsigned long long *m, int cb) { return (m[cb >> 6] >> (cb & 63)) & 1ull; }
+__device__ __forceinline__ int fin_count_before(const unsigned long long *m, const int32_t *pf, int cb)
+{
+    const int w = cb >> 6, b = cb & 63;
+    return pf[w] + (b ? __popcll(m[w] & ((1ull << b) - 1ull)) : 0);
+}
 
 struct SearchParams {
     int32_t strict;                    // strictTopologyStopRules
@@ -165,6 +184,12 @@ template <bool RV, bool U, bool SS, bool LEAN = false> struct Search {
     // appendProbNode(probVectTotUp[t1], removed list, ...) -- a pure function of (query, branch) that a batch kernel
     // computes ~50x faster per placement.  `cached` (if set) is this query's row of such scores, indexed by node.
     const double *cached = nullptr;
+    const unsigned long long *finMask = nullptr;   // this row's bitmap of finite scores (only those are stored), or null
+    __device__ __forceinline__ double cachedAt(int rank) const
+    {
+        if (finMask && !fin_bit(finMask, T.candBefore[rank])) return -INFINITY;
+        return cached[rank];
+    }
     // with MAT local references: this query's removed list in every reference frame (arena list ids, one per frame),
     // prepared by the host along the same up-then-down paths the traversal takes
     const int32_t *rTable = nullptr;
@@ -415,7 +440,7 @@ template <bool RV, bool U, bool SS, bool LEAN = false> struct Search {
                     distance = T.nd[t1].dist;
                 }
                 if (!valid(midTot)) return;
-                if (cached && !it.upd) { midProb = cached[T.nd[t1].preRank]; nAppend++; }   // only items that ARRIVED in the cached regime
+                if (cached && !it.upd) { midProb = cachedAt(T.nd[t1].preRank); nAppend++; }   // only items that ARRIVED in the cached regime
                 else midProb = opAppend(midTot, hRpr, isRemovedTip, removedBLen);
                 if (budget > 0 && !cached && nAppend > budget) { overBudget = true; return; }
                 if (midProb > bestLKdiff - P.thrOptTopo) {            // M:7071-7082
@@ -464,7 +489,7 @@ template <bool RV, bool U, bool SS, bool LEAN = false> struct Search {
                     if (!opDiffer(midTot, cached)) upd = false;
                 } else midTot = treeList(T.nd[t1].totUp);
                 if (!valid(midTot)) return;
-                if (cached && !it.upd) { midProb = cached[T.nd[t1].preRank]; nAppend++; }   // only items that ARRIVED in the cached regime
+                if (cached && !it.upd) { midProb = cachedAt(T.nd[t1].preRank); nAppend++; }   // only items that ARRIVED in the cached regime
                 else midProb = opAppend(midTot, hRpr, isRemovedTip, removedBLen);
                 if (budget > 0 && !cached && nAppend > budget) { overBudget = true; return; }
                 if (midProb >= (bestLKdiff - P.thrOptTopo)) {         // M:7293-7304 (>= here, > on the way down)
@@ -580,7 +605,7 @@ template <bool RV, bool U, bool SS, bool LEAN = false> struct Search {
             if (it.dir == 0) {
                 if (!(upT == node || upT < 0) && (r1.dist > eff || rootChild)) {
                     if (r1.totUp < 0) continue;
-                    if (!own) midProb = cs[r1.preRank];
+                    if (!own) midProb = cachedAt(r1.preRank);
                     else if (haveMail && mailNode == t1) { midProb = mailScore; haveMail = false; }
                     else {
                         // ask the wavefront for it -- after the shortenings the reference would have done by now (M:7087)
@@ -619,7 +644,7 @@ template <bool RV, bool U, bool SS, bool LEAN = false> struct Search {
                 const int other = (it.dir == 1) ? r1.c1 : r1.c0;
                 if (upT >= 0 && (r1.dist > eff || rootChild)) {
                     if (r1.totUp < 0) continue;
-                    if (!own) midProb = cs[r1.preRank];
+                    if (!own) midProb = cachedAt(r1.preRank);
                     else if (haveMail && mailNode == t1) { midProb = mailScore; haveMail = false; }
                     else {
                         // ask the wavefront for it -- after the shortenings the reference would have done by now (M:7087)
@@ -727,7 +752,9 @@ __device__ __forceinline__ double readfirst_f64(double v)
 __device__ inline void wave_scan_clade(const SScan *__restrict__ SC, const int32_t *__restrict__ PR, const double *__restrict__ cs,
                                        const int32_t *__restrict__ rT, int r, bool firstScored, int seedFrame, int hSeed,
                                        double lastLK, int fails0, const SearchParams &P, BestRec *br, int capB, double *slotLK,
-                                       int *slotFails, unsigned *slotOwner, int cap, ScanState &S)
+                                       int *slotFails, unsigned *slotOwner, int cap, ScanState &S,
+                                       const unsigned long long *fm = nullptr, const int32_t *fp = nullptr, const int32_t *CB = nullptr,
+                                       const int32_t *DV = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const double thrOpt = P.thrOptTopo, thrCons = P.thrConsec, thrLK = P.thrLKtopology;
@@ -752,12 +779,18 @@ __device__ inline void wave_scan_clade(const SScan *__restrict__ SC, const int32
         SScan rec;
         double scv;
         int prk;
+        // (fm: only the finite scores of the row are stored; which ones they are is in the bitmap)
+        auto scoreAt = [&](int at, const SScan &rc) -> double {
+            if (!fm) return cs[at];
+            if ((rc.ff & (SS_SCORED | SS_TOTUP)) != (SS_SCORED | SS_TOTUP)) return 0.0;   // (not a candidate: nothing is read)
+            return fin_bit(fm, CB[at]) ? cs[at] : -INFINITY;
+        };
         if (r == rAhead) { rec = recAhead; scv = scvAhead; prk = prAhead; }
-        else { rec = SC[idx]; scv = cs[idx]; prk = PR[idx]; }
+        else { rec = SC[idx]; scv = scoreAt(idx, rec); prk = PR[idx]; }
         if (r + 64 < end) {
             rAhead = r + 64;
             const int idx2 = min(rAhead + lane, end - 1);
-            recAhead = SC[idx2]; scvAhead = cs[idx2]; prAhead = PR[idx2];
+            recAhead = SC[idx2]; scvAhead = scoreAt(idx2, recAhead); prAhead = PR[idx2];
         }
         const int pl = prk - r;                                             // lane of the parent; < 0: an earlier chunk
         const int d = rec.depth, f = (int)(rec.ff >> 4);
@@ -808,7 +841,16 @@ __device__ inline void wave_scan_clade(const SScan *__restrict__ SC, const int32
         // (3) descended into: the record's own rule and every ancestor's
         const bool within = myMp > (best - thrLK);
         const bool rule = strict ? (myFails <= allowed && within) : (myFails <= allowed || within);
-        const bool ownGo = valid && enter && !dropped && (fl & SS_INNER) && rule;   // descended into, if it is visited at all
+        bool ownGo = valid && enter && !dropped && (fl & SS_INNER) && rule;   // descended into, if it is visited at all
+        // A record that is descended into with the score -inf and no finite score anywhere below it: every record of its clade
+        // hands on (-inf, the same failedPasses), nothing is short-listed, the running best does not move, and the non-strict
+        // rule keeps descending -- its clade is COUNTED (cladeVisits, static) instead of walked.
+        bool skipClade = false;
+        if (fm && !strict && ownGo && myMp == -INFINITY && rec.size > 1) {
+            const int lo = CB[idx + 1], hi = CB[idx + rec.size];
+            skipClade = fin_count_before(fm, fp, hi) == fin_count_before(fm, fp, lo);
+            if (skipClade) ownGo = false;
+        }
         bool go = ownGo;
         {
             int ptr = rootLane ? -1 : pl;
@@ -827,6 +869,11 @@ __device__ inline void wave_scan_clade(const SScan *__restrict__ SC, const int32
         const bool fin = lane < nFinal;
         const unsigned long long cntM = __ballot(fin && vis && counts);
         nApp += __popcll(cntM);
+        if (fm) {                                                           // the clades counted instead of walked
+            int add = (fin && vis && skipClade) ? DV[idx] : 0;
+            for (int off = 32; off > 0; off >>= 1) add += __shfl_xor(add, off, 64);
+            nApp += add;
+        }
         const bool rec1 = fin && vis && counts && myMp > (best - thrOpt);   // M:7071: the short list (on the way down: >)
         const unsigned long long recM = __ballot(rec1);
         const int nRec = __popcll(recM);
