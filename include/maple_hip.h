@@ -71,6 +71,18 @@ int maple_abi_version(void);
 int maple_create(maple_ctx **out, int device, int32_t lRef, const uint8_t *refIdx,
                  const double *rootFreqs4, const maple_params *params, uint64_t arena_bytes);
 int maple_destroy(maple_ctx *ctx);
+/* How the library schedules its work -- never WHAT it computes (every setting gives bit-identical results; the tests flip
+ * them to compare kernels).  Zero-initialise, set what is wanted, the rest keeps the library's choice. */
+typedef struct {
+    int32_t wavePerItemMax;     /* the explicit-pair operators (append / merge / blen / differ / shorten), maple_update_partials'
+                                   levels and evaluatePlacement batches of at most this many items run one WAVEFRONT per item
+                                   (lowest latency), larger ones one lane per item; 0 = the library's own thresholds, -1 = never */
+    int32_t placementChunkMax;  /* queries per chunk of maple_placement_search_batch (0 = by free memory) */
+    int32_t noCladeScan;        /* 1: whole-tree SPR searches are replayed one branch at a time instead of by the
+                                   wavefront-wide clade scan */
+    int32_t verbose;            /* 1: progress lines on stderr (also switched on by the environment variable MAPLE_DEBUG) */
+} maple_tuning;
+int maple_set_tuning(maple_ctx *ctx, const maple_tuning *t);
 const char *maple_last_error(maple_ctx *ctx);
 
 /* Model tables: replaces the *Passed / *Global keyword arguments of the

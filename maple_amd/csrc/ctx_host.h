@@ -95,6 +95,7 @@ struct maple_ctx {
     std::vector<double> cand_bytes_prefix;       // per scored column of the uploaded tree: 8E + 8A + 8, summed (host)
     double scored_bytes_total = 0.0;
     std::string err;
+    maple_tuning tuning{};             // maple_set_tuning
     maple_params params{};
     int32_t lRef = 0;
     std::vector<uint8_t> refIdx;
@@ -230,6 +231,12 @@ __device__ inline ListRef list_ref(const ArenaView &a, int id)
     return ListRef{a.words + a.ent_off[id], a.aux + a.aux_off[id]};
 }
 
+
+// batches of at most this many items run one wavefront per item (maple_tuning.wavePerItemMax over the operator's own default)
+static inline int wave_item_max(const maple_ctx *c, int dflt)
+{
+    return c->tuning.wavePerItemMax < 0 ? 0 : (c->tuning.wavePerItemMax > 0 ? c->tuning.wavePerItemMax : dflt);
+}
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 

@@ -1199,6 +1199,7 @@ extern "C" int maple_create(maple_ctx **out, int device, int32_t lRef, const uin
     if (!out || !refIdx || !rootFreqs4 || !params || lRef <= 0) return MAPLE_ERR_ARG;
     *out = nullptr;
     maple_ctx *c = new maple_ctx();
+    if (const char *e = getenv("MAPLE_DEBUG")) c->tuning.verbose = atoi(e) > 1 ? atoi(e) : 1;   // (the one environment variable: progress lines)
     c->device = device;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1261,6 +1262,15 @@ extern "C" int maple_create(maple_ctx **out, int device, int32_t lRef, const uin
 }
 
 static void update_scratch_free(maple_ctx *c);   // update_host.h
+
+extern "C" int maple_set_tuning(maple_ctx *c, const maple_tuning *t)
+{
+    if (!c || !t) return MAPLE_ERR_ARG;
+    const int32_t verbose = c->tuning.verbose;
+    c->tuning = *t;
+    if (!t->verbose && getenv("MAPLE_DEBUG")) c->tuning.verbose = verbose;   // (the environment variable keeps it on)
+    return MAPLE_OK;
+}
 
 extern "C" int maple_destroy(maple_ctx *c)
 {
@@ -1832,7 +1842,7 @@ extern "C" int maple_append_batch(maple_ctx *c, int32_t n, const int32_t *pl, co
     STAGE(dpl, c, pl, n); STAGE(dcl, c, cl, n); STAGE(dtip, c, tip, n); STAGE(dbl, c, bl, n);
     TRY(stage_flush(c));
     HIPCK(c, c->s_f64[1].reserve(n));
-    if (n <= MAPLE_WAVE_PAIRS_MAX && !getenv("MAPLE_NO_WAVE_PAIRS"))
+    if (n <= wave_item_max(c, MAPLE_WAVE_PAIRS_MAX))
         DISPATCH3(c, k_wave_append, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dpl, dcl, dtip, dbl, c->s_f64[1].p));
     else
         DISPATCH3(c, k_append, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dpl, dcl, dtip, dbl, c->s_f64[1].p));
@@ -1873,7 +1883,7 @@ extern "C" int maple_merge_batch(maple_ctx *c, int32_t n, const int32_t *l1, con
     double *dlk = nullptr;
     if (outLK) { HIPCK(c, c->s_f64[2].reserve(n)); dlk = c->s_f64[2].p; }
     OutSpec o{c->s_words.p, c->s_aux.p, dwo, dao, c->s_i32[2].p, c->s_i32[3].p};
-    if (!outLK && n <= MAPLE_WAVE_PAIRS_MAX && !getenv("MAPLE_NO_WAVE_PAIRS"))
+    if (!outLK && n <= wave_item_max(c, MAPLE_WAVE_PAIRS_MAX))
         DISPATCH3(c, k_merge_wave, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dl1, db1, dt1, dl2, db2, dt2, dud, o));
     else
         DISPATCH3(c, k_merge, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl1, db1, dt1, dl2, db2, dt2, dud, dnm1,
@@ -1901,7 +1911,7 @@ extern "C" int maple_blen_batch(maple_ctx *c, int32_t n, const int32_t *pl, cons
     TRY(stage_flush(c));
     HIPCK(c, c->s_f64[0].reserve(n));
     HIPCK(c, c->s_u8[1].reserve(n));
-    if (n <= MAPLE_WAVE_PAIRS_MAX && !getenv("MAPLE_NO_WAVE_PAIRS"))
+    if (n <= wave_item_max(c, MAPLE_WAVE_PAIRS_MAX))
         DISPATCH3(c, k_blen_wave, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dpl, dcl, dtip, c->s_ais.p, dao, c->s_f64[0].p,
                                                              c->s_u8[1].p));
     else
@@ -1926,7 +1936,7 @@ extern "C" int maple_differ_batch(maple_ctx *c, int32_t n, const int32_t *l1, co
     STAGE(dl1, c, l1, n); STAGE(dl2, c, l2, n);
     TRY(stage_flush(c));
     HIPCK(c, c->s_u8[0].reserve(n));
-    if (n <= MAPLE_WAVE_PAIRS_MAX && !getenv("MAPLE_NO_WAVE_PAIRS"))
+    if (n <= wave_item_max(c, MAPLE_WAVE_PAIRS_MAX))
         DISPATCH3(c, k_differ_wave, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dl1, dl2, c->s_u8[0].p));
     else
         DISPATCH3(c, k_differ, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl1, dl2, c->s_u8[0].p));
@@ -2088,7 +2098,7 @@ extern "C" int maple_shorten_batch(maple_ctx *c, int32_t n, const int32_t *l, in
     HIPCK(c, c->s_i32[2].reserve(n));
     HIPCK(c, c->s_i32[3].reserve(n));
     OutSpec o{c->s_words.p, c->s_aux.p, dwo, dao, c->s_i32[2].p, c->s_i32[3].p};
-    if (n <= 1024 && !getenv("MAPLE_NO_WAVE_UPDATE"))
+    if (n <= wave_item_max(c, 1024))
         DISPATCH3(c, k_shorten_wave, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dl, o));
     else
         DISPATCH3(c, k_shorten, <<<grid_for(n), MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), n, dl, o));
@@ -2168,8 +2178,7 @@ static int evaluate_placement_items(maple_ctx *c, int32_t n, const int32_t *midT
     HIPCK(c, c->s_i32[4].reserve(n));
     double *d4 = c->s_f64[1].p, *d2 = comp2 ? d4 + (size_t)4 * n : nullptr;
     // a handful of items (a single query's short list) wait for ONE item's chain of walks: a wavefront per item
-    static const int waveMax = getenv("MAPLE_WAVE_EVAL_MAX") ? atoi(getenv("MAPLE_WAVE_EVAL_MAX")) : 2048;
-    if (n <= waveMax && !getenv("MAPLE_NO_WAVE_EVAL"))
+    if (n <= wave_item_max(c, 2048))
         DISPATCH3(c, k_evalplace_wave, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dMid, dDown, dUp, dDist, dRem, dRt, dFt, c->s_words.p,
                                                                   c->s_aux.p, dCap, c->s_ais.p, dAis, d4, c->s_i32[4].p, d2));
     else
@@ -2235,8 +2244,7 @@ static int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int3
     hipEvent_t e0, e1;
     TRY(ev_pair(c, &e0, &e1, kind, (double)nQ * (double)nC, algBytes));
     HIPCK(c, hipEventRecord(e0, s));
-    static const bool noLds = getenv("MAPLE_APPEND_GLOBAL") != nullptr;
-    if (chunkTab || (nQ >= 32 && !noLds)) {
+    if (chunkTab || nQ >= 32) {
         // enough queries to reuse a staged candidate chunk: the LDS kernel, one workgroup of 16 wavefronts per CU
         const long long units = (long long)(chunkTab ? nChunkTab : (nC + 63) / 64) * ((nQ + MAPLE_LDS_QB - 1) / MAPLE_LDS_QB);
         const int gridL = units < 256 ? (int)units : 256;
@@ -2599,9 +2607,7 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         // similar length anyway.  Measured at 100 000 tips: 1 017 -> 940 ms per round against candidates sorted by length.
         std::vector<int32_t> col;
         for (int i = 0; i < n; i++) if (totUp[i] >= 0) col.push_back(i);
-        if (getenv("MAPLE_SCORED_ORDER_LENGTH"))
-            std::stable_sort(col.begin(), col.end(), [&](int a, int b) { return c->h_n_ent[totUp[a]] < c->h_n_ent[totUp[b]]; });
-        else if (c->tree_has_mut)                                          // by reference frame, then depth-first: a chunk of 64
+        if (c->tree_has_mut)                                          // by reference frame, then depth-first: a chunk of 64
             std::stable_sort(col.begin(), col.end(), [&](int a, int b) {     // candidates shares ONE copy of the query
                 return recs[a].frameOf != recs[b].frameOf ? recs[a].frameOf < recs[b].frameOf : recs[a].preRank < recs[b].preRank; });
         else
@@ -2609,7 +2615,7 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         std::vector<int32_t> ids(col.size()), rank(col.size()), fr(col.size());
         for (size_t i = 0; i < col.size(); i++) { ids[i] = totUp[col[i]]; rank[i] = recs[col[i]].preRank; fr[i] = recs[col[i]].frameOf; }
         c->n_frame_chunks = 0;
-        if (c->tree_has_mut && !getenv("MAPLE_SCORED_ORDER_LENGTH")) {
+        if (c->tree_has_mut) {
             std::vector<int4> chunks;
             for (size_t i = 0; i < col.size();) {
                 size_t j = i;
@@ -2975,7 +2981,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             if (sp->wideSearchBudget >= 0 && !c->dm.usingErrorRate && c->h_tree_dist[nodes[i]] == 0.0) patchedOnly = false;
         if (!patchedOnly) TRY(tree_rebuild_from_host(c));
     }
-    const bool dbgT = getenv("MAPLE_DEBUG") != nullptr;
+    const bool dbgT = c->tuning.verbose != 0;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration_cast<std::chrono::microseconds>(b - a).count() * 1e-3;
@@ -3018,9 +3024,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // error model -- with one, every search from a zero-length branch also runs to the budget here (no routing hint), the lane
     // tier is then bound by its throughput, not by its longest search, and 24 lanes walking in lockstep do better (100 000
     // tips, full model: 460 ms against 541).
-    bool assistOK = !getenv("MAPLE_NO_LEAN") && (!c->dm.usingErrorRate || getenv("MAPLE_LEAN_ERR"));
+    bool assistOK = !c->dm.usingErrorRate;
     const bool assistFew = !c->dm.usingErrorRate;      // few searching lanes per wavefront, every request served by all 64 lanes
-    if (getenv("MAPLE_NO_LEAN_MAT") && c->tree_has_mut) assistOK = false;                                              // (experiments)
     // (the frontier tier, frontier.hip, takes the searches of trees without MAT local references)
     const bool useFrontier = sp->searchTier == 0 && !c->tree_has_mut && c->trace_query < 0;
     const std::vector<int32_t> *rowOverride = nullptr;                 // rows of the score table the next cached launch reads
@@ -3045,7 +3050,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         int capW = cacheS ? (heavyQueries ? 8 : 4) * capW0 : capW0;
         std::vector<int32_t> rows(todo.size());                        // row of each query in the cache / frame tables
         for (size_t k = 0; k < rows.size(); k++) rows[k] = rowOverride ? (*rowOverride)[k] : (int32_t)k;
-        if (!getenv("MAPLE_NO_LPT") && (int)c->h_depth.size() >= c->dtree.n) {
+        if ((int)c->h_depth.size() >= c->dtree.n) {
             // Lanes pull searches from a counter, so a launch ends one search after the last one is pulled: the expensive
             // searches go first.  The expensive ones are those near the root (long lists: an updating step there merges
             // several hundred entries; measured up to 100 ms of updating steps in one search of the 100 000-tip tree
@@ -3112,7 +3117,6 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             // searching lanes per wavefront (100 000 tips, budget 2 132: 2 / 4 / 6 / 8 / 16 / 24 lanes -> 298 / 281 / 279 / 289 /
             // 394 / 345 ms; without the assistance 375)
             if (!cacheS && assistOK && assistFew && activeLanes > 4) activeLanes = 4;
-            if (const char *e = getenv("MAPLE_SPR_LANES")) activeLanes = std::max(1, std::min(64, atoi(e)));   // (experiments)
             int nWaves = (lanesWanted + activeLanes - 1) / activeLanes;
             if (nWaves > 8192) nWaves = 8192;
             const int lanes = nWaves * activeLanes;
@@ -3139,7 +3143,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             Tk.cladeVisits = c->t_clade_visits.p;
             size_t dynLds = 0;
             int launchLanes = activeLanes, launchWaves = nWaves;
-            if (cacheS && c->scan_valid && (size_t)(c->tree_max_depth + 2) * 16 <= (48u << 10)) {
+            if (cacheS && c->scan_valid && !c->tuning.noCladeScan && (size_t)(c->tree_max_depth + 2) * 16 <= (48u << 10)) {
                 Tk.scan = c->t_scan.p;
                 Tk.scanParent = c->t_scan_parent.p;
 
@@ -3159,8 +3163,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 HIPCK(c, c->s_search_ws_big.reserve_exact((size_t)ovfChunks * ((size_t)L.capW * sizeof(uint2) + (size_t)L.capA * sizeof(double))));
                 HIPCK(c, hipMemsetAsync(c->s_counter.p + 6, 0, 2 * sizeof(int32_t), c->stream));
             }
-            int coopMaxHost = 8;                                            // (see k_spr_search: requests served one by one)
-            if (const char *e = getenv("MAPLE_COOP_MAX")) coopMaxHost = std::max(0, atoi(e));
+            const int coopMaxHost = 8;                                      // (see k_spr_search: requests served one by one)
             hipEvent_t e0, e1;
             TRY(ev_pair(c, &e0, &e1, cacheS ? MAPLE_K_SPR_REPLAY : MAPLE_K_SPR_SEARCH, (double)m, 0.0));
             const size_t slotEv = c->ev_used / 2 - 1;                       // (this launch's timing record: filled in below)
@@ -3206,10 +3209,10 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 ho[slot[k]] = part[k];
                 if (part[k].status == -3 && attempt < 2) {
                     todo2.push_back(todo[k]); slot2.push_back(slot[k]); rows2.push_back(rows[k]);
-                    if (getenv("MAPLE_DEBUG")) fprintf(stderr, "[maple]   node %d ran out of workspace (capacity kind %d): position %d of the launch, depth %d, lower list %d entries\n", todo[k], part[k].nAppend, k, c->h_depth[todo[k]], c->h_tree_lower[todo[k]] >= 0 ? c->h_n_ent[c->h_tree_lower[todo[k]]] : -1);
+                    if (dbgT) fprintf(stderr, "[maple]   node %d ran out of workspace (capacity kind %d): position %d of the launch, depth %d, lower list %d entries\n", todo[k], part[k].nAppend, k, c->h_depth[todo[k]], c->h_tree_lower[todo[k]] >= 0 ? c->h_n_ent[c->h_tree_lower[todo[k]]] : -1);
                 }
             }
-            if (getenv("MAPLE_DEBUG")) fprintf(stderr, "[maple] search launch: %d queries, %zu retried with more workspace\n", m, todo2.size());
+            if (dbgT) fprintf(stderr, "[maple] search launch: %d queries, %zu retried with more workspace\n", m, todo2.size());
             todo.swap(todo2);
             slot.swap(slot2);
             rows.swap(rows2);
@@ -3229,12 +3232,9 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     if (patchedOnly) wideBudget = -1;                                   // (no tree-sized table is current)
     // (a long search costs the wave-assisted lane tier a tenth of what it cost one lane: twice the budget pays -- 100 000 tips:
     // 2 132 / 3 072 / 4 096 / 6 144 -> 693 / 688 / 668 / 692 ms per round; 10 000 tips: 256 / 384 / 512 -> 75 / 72 / 72)
-    if (sp->wideSearchBudget == 0 && !c->dm.usingErrorRate && !getenv("MAPLE_NO_LEAN")
-        && !(getenv("MAPLE_NO_LEAN_MAT") && c->tree_has_mut))
-        wideBudget *= 2;
-    if (const char *e = getenv("MAPLE_WIDE_BUDGET")) wideBudget = atoi(e);        // (experiments)
+    if (sp->wideSearchBudget == 0 && !c->dm.usingErrorRate) wideBudget *= 2;
     const bool hybrid = wideBudget > 0;
-    if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !getenv("MAPLE_NO_SCAN")) {
+    if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !c->tuning.noCladeScan) {
         // the tree in the searches' own depth-first order (SScan, search_dev.h): clade sizes, depths and the per-node facts
         // the cached-regime descent tests
         const int32_t nT = c->dtree.n;
@@ -3312,7 +3312,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     std::vector<int32_t> preIdx, preRowOf;
     int preSpare = 0;
     const int nTpre = c->dtree.n;
-    if (hybrid && !c->tree_has_mut && !c->dm.usingErrorRate && wideBudget > 16 && !getenv("MAPLE_NO_PRESCORE")) {
+    if (hybrid && !c->tree_has_mut && !c->dm.usingErrorRate && wideBudget > 16) {
         {   // a node on a zero-length branch is searched at all only if its current placement is bad enough (M:9674): the
             // kernel's own test, on the same appendProbNode, for all of them at once
             std::vector<int32_t> zi, pl, cl;
@@ -3564,7 +3564,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                     a = b;
                 }
                 if (dbgT) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] t=%.1f ms: removed lists in all %d frames\n", tms(tStart, tnow()), nF); }
-                if (c->n_frame_chunks > 0 && m >= 32 && !getenv("MAPLE_APPEND_GLOBAL"))
+                if (c->n_frame_chunks > 0 && m >= 32)
                     TRY(launch_append_queries(c, c->stream, m, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, 0, 0.0, c->s_cache.p, nT,
                                               c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p, MAPLE_K_SPR_SCORE,
                                               (double)m * c->scored_bytes_total + qBytes, nullptr, nullptr, c->t_frame_chunks.p,
@@ -3599,7 +3599,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 if (ho[i].status != 0 || (pass == 1) != laneTier) continue;
                 tot.push_back((ho[i].tStep + ho[i].tReplay + ho[i].tRefine) * 1e-5);
             }
-            if (pass == 1 && getenv("MAPLE_SPR_PROFILE_TOP")) {
+            if (pass == 1 && c->tuning.verbose > 1) {
                 std::vector<int> idx;
                 for (int i = 0; i < n; i++) if (ho[i].status == 0 && ho[i].nAppend <= wideBudget) idx.push_back(i);
                 std::sort(idx.begin(), idx.end(), [&](int a, int b) {

@@ -300,7 +300,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
     const int32_t nF = M.nF, nC = (int32_t)M.cand.size(), nCols = nC + 1, nL = (int32_t)M.leaves.size();
     const int32_t root = c->dtree.root;
     const auto &mut = c->h_tree_mut;
-    const bool dbg = getenv("MAPLE_DEBUG_PLACE") != nullptr;
+    const bool dbg = c->tuning.verbose > 1;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tus = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return (long long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count();
@@ -336,7 +336,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
         const int64_t byLists = (c->cap_lists - (int64_t)c->h_n_ent.size()) / 3 / (2 * (int64_t)nF + 8);
         const int64_t byArena = std::max<int64_t>(1, std::min(std::min(byEnt, byAux), byLists));
         if (byArena < chunk) chunk = (int32_t)byArena;
-        if (const char *e = getenv("MAPLE_PLACE_MAX_CHUNK")) chunk = std::max(1, std::min(chunk, atoi(e)));   // (tests: force chunking)
+        if (c->tuning.placementChunkMax > 0) chunk = std::max(1, std::min(chunk, (int)c->tuning.placementChunkMax));
     }
     const bool manyChunks = chunk < nQ;
     const int stackCap = M.maxDepth + 4, words = (nF + 31) / 32;
@@ -384,7 +384,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
             hs = (double *)c->pin_place.p;
             hm = (uint8_t *)(hs + nS);
             void *dp = nullptr;
-            if (!getenv("MAPLE_NO_ZEROCOPY") && hipHostGetDevicePointer(&dp, hs, 0) == hipSuccess && dp) {
+            if (hipHostGetDevicePointer(&dp, hs, 0) == hipSuccess && dp) {
                 zeroCopy = true;
                 scoreOut = (double *)dp;
                 minorOut = (uint8_t *)((double *)dp + nS);

@@ -88,8 +88,7 @@ static int update_items(maple_ctx *c, int32_t n, const int32_t *l1, const double
     HIPCK(c, c->s_i32[2].reserve((size_t)3 * n));
     int32_t *res3 = c->s_i32[2].p;
     // a level with few items waits for ONE item's latency: a wavefront per item (wave_update.h); many items: a lane each
-    static const int waveMax = getenv("MAPLE_WAVE_UPDATE_MAX") ? atoi(getenv("MAPLE_WAVE_UPDATE_MAX")) : 4096;
-    if (n <= waveMax && !getenv("MAPLE_NO_WAVE_UPDATE"))
+    if (n <= wave_item_max(c, 4096))
         DISPATCH3(c, k_update_items_wave, <<<n, 64, 0, c->stream>>>(c->d_model, view(c), n, dl1, db1, dt1, dl2, db2, dt2, dud, dmode, dold,
                                                                      c->s_words.p, c->s_aux.p, dwo, dcap, res3));
     else
@@ -323,7 +322,7 @@ extern "C" int maple_update_partials(maple_ctx *c, int32_t n, int32_t root, cons
                 // merged, then repairs from there.  Here: the same estimates, and the node whose length changed starts another
                 // round of the level loops.
                 const int kd = iKid[i];
-                if (getenv("MAPLE_DEBUG"))
+                if (c->tuning.verbose)
                     fprintf(stderr, "[maple] updatePartials round %d: None %s at node %d (length %.3g), child %d (length %.3g), merged with b1 %.3g b2 %.3g\n",
                             roundNo, iKind[i] == 0 ? "probVectTotUp" : (iKind[i] == 1 ? "probVectUpRight" : "probVectUpLeft"), v, dist[v], kd,
                             kd >= 0 ? dist[kd] : -1.0, iB1[i], iB2[i]);

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmaple_hip.so")
 
 EXPORTS = [
-    "maple_abi_version", "maple_create", "maple_destroy", "maple_last_error", "maple_set_model", "maple_get_model",
+    "maple_abi_version", "maple_create", "maple_destroy", "maple_set_tuning", "maple_last_error", "maple_set_model", "maple_get_model",
     "maple_lists_upload", "maple_lists_update", "maple_lists_sizes", "maple_lists_download", "maple_arena_mark", "maple_arena_release",
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
@@ -40,6 +40,10 @@ class MapleSearchParams(C.Structure):
                 ("thresholdLogLKtopology", C.c_double), ("thresholdTopologyPlacement", C.c_double),
                 ("thresholdLogLKoptimizationTopology", C.c_double), ("thresholdLogLKconsecutivePlacement", C.c_double),
                 ("effectivelyNon0BLen", C.c_double), ("wideSearchBudget", C.c_int32), ("searchTier", C.c_int32)]
+
+
+class MapleTuning(C.Structure):
+    _fields_ = [("wavePerItemMax", C.c_int32), ("placementChunkMax", C.c_int32), ("noCladeScan", C.c_int32), ("verbose", C.c_int32)]
 
 
 class MaplePlacementParams(C.Structure):
@@ -134,6 +138,11 @@ class Device:
             pass
 
     # -- model -------------------------------------------------------------------------------
+    def set_tuning(self, *, wave_per_item_max=0, placement_chunk_max=0, no_clade_scan=False, verbose=0):
+        """How the library schedules its work (never what it computes): see maple_tuning in include/maple_hip.h."""
+        t = MapleTuning(int(wave_per_item_max), int(placement_chunk_max), int(bool(no_clade_scan)), int(verbose))
+        self._ck(self.lib.maple_set_tuning(self.h, C.byref(t)))
+
     def set_model(self, Q, siteRates=None, usingErrorRate=False, errorRateGlobal=0.0, errorRates=None):
         Qf = _f64(np.asarray(Q, dtype=np.float64).reshape(16))
         sr = None if siteRates is None else _f64(siteRates)

@@ -245,9 +245,9 @@ def test_wavefront_wide_evaluate_placement_is_the_one_lane_chain_bit_for_bit(wor
     ok = (mirror.tot_up[nodes] >= 0) & (up_ids >= 0)
     args = tuple(a[ok] if isinstance(a, np.ndarray) else a for a in args)
     wave = dev.evaluate_placement_batch(*args)
-    monkeypatch.setenv("MAPLE_NO_WAVE_EVAL", "1")
+    dev.set_tuning(wave_per_item_max=-1)
     lane = dev.evaluate_placement_batch(*args)
-    monkeypatch.delenv("MAPLE_NO_WAVE_EVAL")
+    dev.set_tuning()
     assert wave.shape == lane.shape and len(wave) > 300
     assert np.array_equal(wave.view(np.uint64), lane.view(np.uint64)), np.nonzero((wave != lane).any(axis=1))[0][:5]
     assert np.isfinite(wave[:, 1:]).all() and (wave[:, 1:] >= 0).all()
@@ -266,9 +266,9 @@ def test_wavefront_wide_evaluate_placement_is_the_one_lane_chain_bit_for_bit(wor
     res = {}
     for name in ("wave", "lane"):
         if name == "lane":
-            monkeypatch.setenv("MAPLE_NO_WAVE_EVAL", "1")
+            dev.set_tuning(wave_per_item_max=-1)
         res[name] = [dev.placement_search_batch(np.asarray([q], dtype=np.int32), **pkw) for q in qs]
-    monkeypatch.delenv("MAPLE_NO_WAVE_EVAL")
+    dev.set_tuning()
     for a, b in zip(res["wave"], res["lane"]):
         for k in ("bestNode", "nAppend", "status"):
             assert np.array_equal(a[k], b[k]), k
@@ -301,9 +301,9 @@ def test_explicit_pair_operators_one_wavefront_per_pair_are_the_one_lane_kernels
                     dif=dev.differ_batch(low, np.roll(low, 1)), dif2=dev.differ_batch(mirror.tot_up[nodes], mirror.tot_up[nodes]))
 
     wave = run()
-    monkeypatch.setenv("MAPLE_NO_WAVE_PAIRS", "1")
+    dev.set_tuning(wave_per_item_max=-1)
     lane = run()
-    monkeypatch.delenv("MAPLE_NO_WAVE_PAIRS")
+    dev.set_tuning()
     assert len(nodes) > 500
     for k in ("app", "app2"):
         assert np.array_equal(wave[k].view(np.uint64), lane[k].view(np.uint64)), k
@@ -342,9 +342,9 @@ def test_wavefront_wide_update_items_leave_the_one_lane_lists(world, monkeypatch
 
     mark = dev.mark()
     wave, n_wave = run()
-    monkeypatch.setenv("MAPLE_NO_WAVE_UPDATE", "1")
+    dev.set_tuning(wave_per_item_max=-1)
     lane, n_lane = run()
-    monkeypatch.delenv("MAPLE_NO_WAVE_UPDATE")
+    dev.set_tuning()
     assert n_wave == n_lane and n_wave > 150
     assert np.array_equal(wave.dist, lane.dist)
     n_cmp = 0
@@ -389,9 +389,9 @@ def test_wavefront_wide_kernels_around_their_list_length_limit(monkeypatch):
         return tree, n
 
     wave, n_wave = run()
-    monkeypatch.setenv("MAPLE_NO_WAVE_UPDATE", "1")
+    dev.set_tuning(wave_per_item_max=-1)
     lane, n_lane = run()
-    monkeypatch.delenv("MAPLE_NO_WAVE_UPDATE")
+    dev.set_tuning()
     assert n_wave == n_lane and n_wave > 100
     base = HostTree.from_mirror(mirror)
     for attr in ("id_lower", "id_upRight", "id_upLeft", "id_totUp"):
@@ -408,9 +408,9 @@ def test_wavefront_wide_kernels_around_their_list_length_limit(monkeypatch):
     q_ids = mirror.lower[rng.choice(np.asarray(data.tip_node), size=len(nodes))].astype(np.int32)
     args = (mirror.tot_up[nodes], mirror.lower[nodes], up_ids, mirror.dist[nodes], q_ids, True, mirror.is_tip[nodes])
     wave4 = dev.evaluate_placement_batch(*args)
-    monkeypatch.setenv("MAPLE_NO_WAVE_EVAL", "1")
+    dev.set_tuning(wave_per_item_max=-1)
     lane4 = dev.evaluate_placement_batch(*args)
-    monkeypatch.delenv("MAPLE_NO_WAVE_EVAL")
+    dev.set_tuning()
     assert len(wave4) > 500 and np.array_equal(wave4.view(np.uint64), lane4.view(np.uint64))
     # shorten() of single lists (k_shorten_wave for small batches): merged-but-unshortened lists are what it is for
     half = mirror.dist[nodes][:500] / 2
@@ -418,9 +418,9 @@ def test_wavefront_wide_kernels_around_their_list_length_limit(monkeypatch):
     merged = merged[merged >= 0]
     assert len(merged) > 300
     sw = dev.shorten_batch(merged)
-    monkeypatch.setenv("MAPLE_NO_WAVE_UPDATE", "1")
+    dev.set_tuning(wave_per_item_max=-1)
     sl = dev.shorten_batch(merged)
-    monkeypatch.delenv("MAPLE_NO_WAVE_UPDATE")
+    dev.set_tuning()
     assert dev.download(sw) == dev.download(sl)
     assert (dev.sizes(sw)[0] < dev.sizes(merged)[0]).sum() > 50           # (it did shorten something)
     dev.close()

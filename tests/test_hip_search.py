@@ -223,10 +223,11 @@ def test_batched_placement_in_chunks_is_the_same(env, monkeypatch):
     whole_lists = dev.download(whole["bestDiffs"])
     used_whole = dev.stats()["n_entries"]
     dev.release(mark)
-    monkeypatch.setenv("MAPLE_PLACE_MAX_CHUNK", "7")
+    dev.set_tuning(placement_chunk_max=7)
     mark = dev.mark()
     q_ids = dev.upload([tup(r["query"]) for r in recs])
     parts = dev.placement_search_batch(q_ids, **kw)
+    dev.set_tuning()
     part_lists = dev.download(parts["bestDiffs"])
     used_parts = dev.stats()["n_entries"]
     dev.release(mark)
