@@ -268,6 +268,7 @@ def main():
         distd.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     K = {name: dev.timing_read_kind(getattr(Device, "KIND_" + name)) for name in
          ("SPR_SCORE", "SPR_SEARCH", "SPR_REPLAY", "FR_UPDATING", "FR_CACHED", "FR_REPLAY")}     # (launches, ms, units, bytes)
     for res in kept:
@@ -287,6 +288,15 @@ def main():
     else:
         total_placements, total_searches = float(placements), float(searches)
 
+    # per-rank kernel times of the timed steps (what a scaling run is read with: the ranks search disjoint shares of a step)
+    mine_ms = {"rank": rank, "wall_ms_per_step": 1e3 * elapsed_local / args.steps,
+               "frontier_tier": K["SPR_SEARCH"][1] / args.steps, "dense_scoring": K["SPR_SCORE"][1] / args.steps,
+               "replay_of_whole_tree_searches": K["SPR_REPLAY"][1] / args.steps,
+               "searches_per_step": len(batch_of(0)), "placements_per_step": placements / args.steps}
+    per_rank = [mine_ms]
+    if distd is not None:
+        per_rank = [None] * world
+        distd.all_gather_object(per_rank, mine_ms)
     extras = {}
     if not args.no_extras and rank == 0:
         extras = sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_plain_tree, torch, cu,
@@ -375,7 +385,7 @@ def main():
                                            "tree_upload_ms": round(tree_upload_ms, 1),
                                            "note": "lists and tree tables are in HBM when the timed region starts; a step's own "
                                                    "host traffic (node ids in, ~100 B of results per search out) is inside `value`"}},
-            "roofline": dominant, "roofline_by_kernel": roofs,
+            "roofline": dominant, "roofline_by_kernel": roofs, "per_rank": per_rank,
             "spr_search": {"status_counts": status_counts, "proposed_moves_rank0": n_moves,
                            "kernel_ms_rank0_per_step": {"frontier_tier": ms_fr / steps, "of_which_k_fr_updating": K["FR_UPDATING"][1] / steps,
                                                         "of_which_k_fr_cached": K["FR_CACHED"][1] / steps,

@@ -2936,6 +2936,81 @@ static int fan_out_level(maple_ctx *c, int m, int nF, int a, int b, int32_t *dR,
     return MAPLE_OK;
 }
 
+// The tree in the searches' own depth-first order (SScan, search_dev.h) -- clade sizes, depths and the per-node facts the
+// cached-regime descent tests -- plus what rows with a bitmap of their finite scores need (FiniteRows).  Per uploaded tree and
+// effectivelyNon0BLen.
+static int build_scan_tables(maple_ctx *c, const SearchParams &P)
+{
+
+    // the tree in the searches' own depth-first order (SScan, search_dev.h): clade sizes, depths and the per-node facts
+    // the cached-regime descent tests
+    const int32_t nT = c->dtree.n;
+    std::vector<int32_t> byRank(nT, -1);
+    for (int i = 0; i < nT; i++) byRank[c->h_nodes[i].preRank] = i;
+    std::vector<SScan> sc((size_t)nT);
+    std::vector<int32_t> size(nT, 1), depth(nT, 0);
+    // Node slots the root does not reach (a tree read from a file keeps the slots of collapsed nodes, their `up` still
+    // naming a live node) rank behind every reachable node and belong to no clade: counted into their stale parent's
+    // clade they made the scan of that parent -- and of every ancestor -- run past the clade's end.
+    std::vector<uint8_t> reach(nT, 0);
+    {
+        std::vector<int32_t> stk{c->dtree.root};
+        while (!stk.empty()) {
+            const int v = stk.back();
+            stk.pop_back();
+            reach[v] = 1;
+            if (c->h_tree_c0[v] >= 0) { stk.push_back(c->h_tree_c0[v]); stk.push_back(c->h_tree_c1[v]); }
+        }
+    }
+    int32_t maxDepth = 0;
+    for (int r = 0; r < nT; r++) {                                      // parents precede their clades in rank order
+        const int v = byRank[r];
+        const int u = c->h_tree_up[v];
+        if (reach[v] && u >= 0 && v != c->dtree.root && c->h_nodes[u].preRank < r) depth[v] = depth[u] + 1;
+        maxDepth = std::max(maxDepth, depth[v]);
+    }
+    for (int r = nT - 1; r >= 0; r--) {
+        const int v = byRank[r];
+        const int u = c->h_tree_up[v];
+        if (reach[v] && u >= 0 && v != c->dtree.root && c->h_nodes[u].preRank < r) size[u] += size[v];
+    }
+    for (int r = 0; r < nT; r++) {
+        const int v = byRank[r];
+        const NodeRec &nr = c->h_nodes[v];
+        uint32_t fl = 0;
+        if (nr.up >= 0 && (nr.dist > P.effNon0 || nr.upIsRoot)) fl |= SS_SCORED;
+        if (nr.totUp >= 0) fl |= SS_TOTUP;
+        if (nr.c0 >= 0) fl |= SS_INNER;
+        if (nr.up >= 0 && (nr.whichChild ? c->h_nodes[nr.up].upLeft : c->h_nodes[nr.up].upRight) >= 0) fl |= SS_ENTER;
+        sc[r] = SScan{v, size[v], depth[v], ((uint32_t)nr.frameOf << 4) | fl};
+    }
+    std::vector<int32_t> prank((size_t)nT, 0);
+    for (int r = 0; r < nT; r++) { const int u = c->h_tree_up[byRank[r]]; prank[r] = u >= 0 ? c->h_nodes[u].preRank : 0; }
+    // for rows that come with a bitmap of their finite scores (FiniteRows, search_dev.h): candidates before each rank, and
+    // what a clade adds to the count of candidate placements when it is walked with every score -inf
+    std::vector<int32_t> candBefore((size_t)nT + 1, 0), cladeVisits((size_t)nT, 0);
+    for (int r = 0; r < nT; r++)
+        candBefore[r + 1] = candBefore[r] + ((sc[r].ff & SS_TOTUP) ? 1 : 0);   // (the order of the dense kernel's candidates)
+    for (int r = nT - 1; r >= 1; r--) {
+        const int v = byRank[r];
+        if (!reach[v]) continue;
+        const uint32_t fl = sc[r].ff & 15u;
+        if (!(fl & SS_ENTER)) continue;                                 // never pushed: neither it nor its clade is visited
+        const bool scored = fl & SS_SCORED, counts = scored && (fl & SS_TOTUP), dropped = scored && !(fl & SS_TOTUP);
+        const int add = (counts ? 1 : 0) + ((!dropped && (fl & SS_INNER)) ? cladeVisits[r] : 0);
+        cladeVisits[prank[r]] += add;
+    }
+    TRY(h2d(c, c->t_cand_before, candBefore.data(), candBefore.size()));
+    TRY(h2d(c, c->t_clade_visits, cladeVisits.data(), cladeVisits.size()));
+    TRY(h2d(c, c->t_scan, sc.data(), sc.size()));
+    TRY(h2d(c, c->t_scan_parent, prank.data(), prank.size()));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->tree_max_depth = maxDepth;
+    c->scan_eff = P.effNon0;
+    c->scan_valid = true;
+    return MAPLE_OK;
+}
+
 // finite scores before each word of every row's bitmap (FiniteRows, search_dev.h): one wavefront per row
 __global__ __launch_bounds__(64) void k_finite_prefix(int nRows, int nWords, const unsigned long long *mask, int32_t *prefix)
 {
@@ -3234,74 +3309,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // 2 132 / 3 072 / 4 096 / 6 144 -> 693 / 688 / 668 / 692 ms per round; 10 000 tips: 256 / 384 / 512 -> 75 / 72 / 72)
     if (sp->wideSearchBudget == 0 && !c->dm.usingErrorRate) wideBudget *= 2;
     const bool hybrid = wideBudget > 0;
-    if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !c->tuning.noCladeScan) {
-        // the tree in the searches' own depth-first order (SScan, search_dev.h): clade sizes, depths and the per-node facts
-        // the cached-regime descent tests
-        const int32_t nT = c->dtree.n;
-        std::vector<int32_t> byRank(nT, -1);
-        for (int i = 0; i < nT; i++) byRank[c->h_nodes[i].preRank] = i;
-        std::vector<SScan> sc((size_t)nT);
-        std::vector<int32_t> size(nT, 1), depth(nT, 0);
-        // Node slots the root does not reach (a tree read from a file keeps the slots of collapsed nodes, their `up` still
-        // naming a live node) rank behind every reachable node and belong to no clade: counted into their stale parent's
-        // clade they made the scan of that parent -- and of every ancestor -- run past the clade's end.
-        std::vector<uint8_t> reach(nT, 0);
-        {
-            std::vector<int32_t> stk{c->dtree.root};
-            while (!stk.empty()) {
-                const int v = stk.back();
-                stk.pop_back();
-                reach[v] = 1;
-                if (c->h_tree_c0[v] >= 0) { stk.push_back(c->h_tree_c0[v]); stk.push_back(c->h_tree_c1[v]); }
-            }
-        }
-        int32_t maxDepth = 0;
-        for (int r = 0; r < nT; r++) {                                      // parents precede their clades in rank order
-            const int v = byRank[r];
-            const int u = c->h_tree_up[v];
-            if (reach[v] && u >= 0 && v != c->dtree.root && c->h_nodes[u].preRank < r) depth[v] = depth[u] + 1;
-            maxDepth = std::max(maxDepth, depth[v]);
-        }
-        for (int r = nT - 1; r >= 0; r--) {
-            const int v = byRank[r];
-            const int u = c->h_tree_up[v];
-            if (reach[v] && u >= 0 && v != c->dtree.root && c->h_nodes[u].preRank < r) size[u] += size[v];
-        }
-        for (int r = 0; r < nT; r++) {
-            const int v = byRank[r];
-            const NodeRec &nr = c->h_nodes[v];
-            uint32_t fl = 0;
-            if (nr.up >= 0 && (nr.dist > P.effNon0 || nr.upIsRoot)) fl |= SS_SCORED;
-            if (nr.totUp >= 0) fl |= SS_TOTUP;
-            if (nr.c0 >= 0) fl |= SS_INNER;
-            if (nr.up >= 0 && (nr.whichChild ? c->h_nodes[nr.up].upLeft : c->h_nodes[nr.up].upRight) >= 0) fl |= SS_ENTER;
-            sc[r] = SScan{v, size[v], depth[v], ((uint32_t)nr.frameOf << 4) | fl};
-        }
-        std::vector<int32_t> prank((size_t)nT, 0);
-        for (int r = 0; r < nT; r++) { const int u = c->h_tree_up[byRank[r]]; prank[r] = u >= 0 ? c->h_nodes[u].preRank : 0; }
-        // for rows that come with a bitmap of their finite scores (FiniteRows, search_dev.h): candidates before each rank, and
-        // what a clade adds to the count of candidate placements when it is walked with every score -inf
-        std::vector<int32_t> candBefore((size_t)nT + 1, 0), cladeVisits((size_t)nT, 0);
-        for (int r = 0; r < nT; r++)
-            candBefore[r + 1] = candBefore[r] + ((sc[r].ff & SS_TOTUP) ? 1 : 0);   // (the order of the dense kernel's candidates)
-        for (int r = nT - 1; r >= 1; r--) {
-            const int v = byRank[r];
-            if (!reach[v]) continue;
-            const uint32_t fl = sc[r].ff & 15u;
-            if (!(fl & SS_ENTER)) continue;                                 // never pushed: neither it nor its clade is visited
-            const bool scored = fl & SS_SCORED, counts = scored && (fl & SS_TOTUP), dropped = scored && !(fl & SS_TOTUP);
-            const int add = (counts ? 1 : 0) + ((!dropped && (fl & SS_INNER)) ? cladeVisits[r] : 0);
-            cladeVisits[prank[r]] += add;
-        }
-        TRY(h2d(c, c->t_cand_before, candBefore.data(), candBefore.size()));
-        TRY(h2d(c, c->t_clade_visits, cladeVisits.data(), cladeVisits.size()));
-        TRY(h2d(c, c->t_scan, sc.data(), sc.size()));
-        TRY(h2d(c, c->t_scan_parent, prank.data(), prank.size()));
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        c->tree_max_depth = maxDepth;
-        c->scan_eff = P.effNon0;
-        c->scan_valid = true;
-    }
+    if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !c->tuning.noCladeScan) TRY(build_scan_tables(c, P));
     // rows of the score table come with the bitmap of their finite scores (FiniteRows) when the tables that go with it exist
     const bool useFin = hybrid && c->scan_valid && !c->tree_has_mut;
     // Without an error model the whole-tree searches are known before anything runs: they are the ones that start from a

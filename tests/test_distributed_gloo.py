@@ -112,3 +112,73 @@ def test_two_rank_candidate_sharding_level2():
         assert full == scores.tolist()
         assert full_flags == flags.tolist()
         assert best == (float(scores[want_k]), int(visit[want_k]))
+
+
+class _StubDevice:
+    """Stands in for runtime.Device in argmax_allreduce_native: the two ncclAllReduce of maple_argmax_allreduce_dev
+    (maple_hip.hip: max of order-preserving 64-bit keys, then min of the offered indices among the ranks that hold the
+    maximum) done over gloo on host memory, with the kernels' own key packing."""
+
+    def __init__(self):
+        self.inits = []
+
+    def comm_unique_id(self):
+        return np.arange(128, dtype=np.uint8)
+
+    def comm_init(self, world, rank, uid):
+        self.inits.append((world, rank, bytes(uid.tolist())))
+
+    def argmax_allreduce_dev(self, n, score_ptr, idx_ptr, stream=0):
+        import ctypes
+        score = np.ctypeslib.as_array((ctypes.c_double * n).from_address(score_ptr))
+        idx = np.ctypeslib.as_array((ctypes.c_int32 * n).from_address(idx_ptr))
+        bits = score.view(np.uint64)
+        key = np.where(bits >> np.uint64(63), ~bits, bits | np.uint64(1 << 63))        # k_argmax_pack: order-preserving
+        k = torch.from_numpy(key.astype(np.int64) ^ np.int64(-(1 << 63)))              # (as a signed tensor with the same order)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+        offer = torch.from_numpy(np.where((key.astype(np.int64) ^ np.int64(-(1 << 63))) == k.numpy(), idx.astype(np.int64),
+                                          np.iinfo(np.int64).max))                      # k_argmax_offer
+        dist.all_reduce(offer, op=dist.ReduceOp.MIN)
+        best = (k.numpy() ^ np.int64(-(1 << 63))).astype(np.uint64)                      # k_argmax_unpack
+        out_bits = np.where(best >> np.uint64(63), best & ~np.uint64(1 << 63), ~best)
+        score[:] = out_bits.view(np.float64)
+        idx[:] = offer.numpy().astype(np.int32)
+
+
+def _argmax_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from maple_amd.parallel import argmax_allreduce_native
+    # 6 queries; each rank holds its shard's best score and the depth-first visit index of the branch that has it
+    score = np.array([[-3.0, -1.0, -2.0, float("-inf"), -5.5, -0.0],
+                      [-3.0, -4.0, -2.0, float("-inf"), -5.25, 0.0]])[rank].copy()
+    idx = np.array([[40, 7, 9, 3, 11, 5], [12, 8, 90, 1, 2, 6]], dtype=np.int32)[rank].copy()
+    dev = _StubDevice()
+    argmax_allreduce_native(dev, torch.from_numpy(score), torch.from_numpy(idx))
+    q.put((rank, score.tolist(), idx.tolist(), dev.inits))
+    dist.destroy_process_group()
+
+
+def test_argmax_allreduce_control_flow_and_tie_break_two_ranks():
+    """Level 2 of the multi-GPU design through parallel.argmax_allreduce_native's own control flow (unique id from rank 0,
+    broadcast, comm_init on every rank, one in-place reduction) with the RCCL calls replaced by gloo: the maximum score per
+    query, exact ties to the SMALLEST visit index (the reference's strict >, M:7083 / 8065), -inf and -0.0 / 0.0 ordered as
+    the 64-bit keys order them."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_argmax_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_score = [-3.0, -1.0, -2.0, float("-inf"), -5.25, 0.0]
+    want_idx = [12, 7, 9, 1, 2, 6]
+    for rank, score, idx, inits in got:
+        assert score == want_score and idx == want_idx, (rank, score, idx)
+        assert len(inits) == 1 and inits[0][0] == world and inits[0][1] == rank
+        assert inits[0][2] == bytes(range(128))                     # rank 0's unique id reached every rank
