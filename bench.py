@@ -304,13 +304,15 @@ def main():
 
     # HBM-side bytes per launch come from separate rocprofv3 PMC passes over this same command (a running process cannot
     # read its own PMCs); they are recorded under profiles/ and only reported for the workload they were measured on.
-    traffic = {}
+    traffic, pmc_issue = {}, {}
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_spr_*.json"))):
         try:
             pmc = json.load(open(path))
             w = pmc["workload"]
-            if (w["samples"], w["model"], w["batch"], w["n_gpus"]) == (args.samples, args.model, B, world):
-                traffic = pmc["traffic_bytes_per_launch"]
+            if (w["samples"], w["model"], w["batch"], w["n_gpus"], w.get("tree", "truth")) == (args.samples, args.model, B, world, args.tree) \
+                    and "traffic_bytes_per_step" in pmc:
+                traffic = {k: v / max(1.0, pmc["launches_per_step"][k]) for k, v in pmc["traffic_bytes_per_step"].items()}
+                pmc_issue = pmc.get("issue", {})
         except (OSError, KeyError, ValueError):
             pass
 
@@ -326,6 +328,7 @@ def main():
             ach = (bytes_ / (ms * 1e-3) / 1e9) if ms else 0.0
             return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(kernel.split()[0]),
+                    "pmc_per_step": pmc_issue.get(kernel.split()[0]),
                     "algorithmic_bytes_per_launch": bytes_ / max(1, n), "kernel_ms": ms / max(1, n), "launches_timed": n,
                     "kernel_ms_per_step": ms / steps, "units_per_step": units / steps, "note": what}
         # every kernel of a step that matters, each timed by its own HIP events on the stream it is launched on

@@ -81,6 +81,8 @@ typedef struct {
     int32_t noCladeScan;        /* 1: whole-tree SPR searches are replayed one branch at a time instead of by the
                                    wavefront-wide clade scan */
     int32_t verbose;            /* 1: progress lines on stderr (also switched on by the environment variable MAPLE_DEBUG) */
+    int32_t wideOutsideFrontier; /* 1: whole-tree SPR searches leave the frontier tier at once and run one wavefront per search
+                                   from their first step (k_spr_search), instead of sharing its batched updating steps */
 } maple_tuning;
 int maple_set_tuning(maple_ctx *ctx, const maple_tuning *t);
 const char *maple_last_error(maple_ctx *ctx);
@@ -356,7 +358,8 @@ int maple_timing_read_each(maple_ctx *ctx, int32_t cap, float *ms, int32_t *n_la
  *   4 = maple_append_queries_dev, 5 = maple_append_batch_dev, 6 = scoring inside maple_placement_search_batch (units = pairs),
  *   the frontier tier of the SPR search (kind 2 = the tier as a whole; its kernels, one record per launch):
  *   7 = k_fr_updating (items that still update genome lists), 8 = k_fr_cached (units = cached-regime placements scored,
- *   alg_bytes = their SURVEY 8d bytes, counted on the device), 9 = exact replay + refinement + final selection. */
+ *   alg_bytes = their SURVEY 8d bytes, counted on the device), 9 = exact replay + refinement + final selection,
+ *   10 = k_fr_replay_wide (the whole-tree searches replayed over their rows of the dense score table: units = placements). */
 int maple_timing_read_kind(maple_ctx *ctx, int32_t kind, int32_t *n_launches, double *total_ms, double *units,
                            double *alg_bytes);
 /* algorithmic bytes (8*E + 8*B + 32*O + 8 per candidate, child list once per query) */

@@ -204,7 +204,8 @@ struct maple_ctx {
 };
 
 enum { MAPLE_K_OTHER = 0, MAPLE_K_SPR_SCORE = 1, MAPLE_K_SPR_SEARCH = 2, MAPLE_K_SPR_REPLAY = 3, MAPLE_K_APPEND_QUERIES = 4,
-       MAPLE_K_APPEND_PAIRS = 5, MAPLE_K_PLACE_SCORE = 6, MAPLE_K_FR_UPDATING = 7, MAPLE_K_FR_CACHED = 8, MAPLE_K_FR_REPLAY = 9 };
+       MAPLE_K_APPEND_PAIRS = 5, MAPLE_K_PLACE_SCORE = 6, MAPLE_K_FR_UPDATING = 7, MAPLE_K_FR_CACHED = 8, MAPLE_K_FR_REPLAY = 9,
+       MAPLE_K_FR_WIDE = 10 };
 
 static inline int fail(maple_ctx *c, int code, const char *fmt, ...)
 {

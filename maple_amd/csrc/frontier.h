@@ -9,9 +9,18 @@ struct FrontierStats {
     long long itemsUpdating = 0, itemsCached = 0, tempLists = 0, tempWords = 0, tempAux = 0, records = 0;
 };
 
+// whole-tree searches whose rows of the dense (query x branch) score table are made next to the tier: their cached-regime
+// clades are scanned over those rows inside the tier (k_fr_replay_wide) instead of being handed back with status -5
+struct FrontierWide {
+    const int32_t *rowOf;              // host, per search of the batch: its row of the table, or -1
+    const double *cacheS;              // device: the table, rows of dtree.n scores by preRank
+    FiniteRows fin;                    // bitmap form of the rows (or nulls)
+    hipEvent_t rowsReady;              // recorded behind the launches that write the rows (or null: same stream)
+};
+
 __attribute__((visibility("hidden")))
 int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *nodes, int budget, int zeroBudget, SearchOut *hostOut,
                     uint2 *poolW, double *poolA, unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
-                    FrontierStats *stats, long long itemsHint);   // itemsHint: expected expanded items (0 = by the budget)
+                    FrontierStats *stats, long long itemsHint, const FrontierWide *wide = nullptr);   // itemsHint: expected expanded items (0 = by the budget)
 __attribute__((visibility("hidden"))) void frontier_scratch_free(maple_ctx *c);
 __attribute__((visibility("hidden"))) int frontier_export(maple_ctx *c, long long cap, int32_t *q, int32_t *node, long long *n);

@@ -44,8 +44,13 @@ namespace {
 
 #define FR_BLOCK 256
 
-enum { FI_UPD_IN = 1, FI_UPD_OUT = 2, FI_SCORED = 4, FI_DEAD = 8, FI_REC_UPD = 16 };
-enum { FS_ACTIVE = 0, FS_FINAL = 1, FS_OVER = 2, FS_FALLBACK = 3 };
+enum { FI_UPD_IN = 1, FI_UPD_OUT = 2, FI_SCORED = 4, FI_DEAD = 8, FI_REC_UPD = 16, FI_SEED = 32 };
+// FS_WIDE: a whole-tree search whose row of the dense score table is being made next to this tier.  Its items that still
+// update genome lists are expanded here like any other's (they are what made such a search slow for one lane: up to 200
+// updating steps in a row); an item that arrives in the cached regime on the way DOWN is left as a seed (FI_SEED) -- the clade
+// below it is scanned over the score row by k_fr_replay_wide (wave_scan_clade, search_dev.h) when the exact walk gets there.
+enum { FS_ACTIVE = 0, FS_FINAL = 1, FS_OVER = 2, FS_FALLBACK = 3, FS_WIDE = 4 };
+__device__ __forceinline__ bool fs_live(int st) { return st == FS_ACTIVE || st == FS_WIDE; }
 #define FR_NONE (-1)
 
 struct alignas(16) FItem {
@@ -177,7 +182,7 @@ __device__ inline int fpush(const FPools &fp, const int budget, const int q, con
                             const double pathBest)
 {
     FSearch &S = fp.S[q];
-    if (atomicAdd(&S.nItems, 1) >= budget) { S.state = FS_OVER; return FR_NONE; }
+    if (S.state != FS_WIDE && atomicAdd(&S.nItems, 1) >= budget) { S.state = FS_OVER; return FR_NONE; }
     FItem *it;
     int ref;
     // one atomic per wavefront and pool: the lanes that are here together take consecutive items
@@ -209,7 +214,8 @@ __device__ inline int fpush(const FPools &fp, const int budget, const int q, con
 // ---- the worker's prologue (M:9626-9674) and the seeding of nodesToVisit (M:6855-6914) ----------------------------------
 template <bool RV, bool U, bool SS>
 __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, int n,
-                                                       const int32_t *nodes, FPools fp, SearchOut *out, int budget, int zeroBudget)
+                                                       const int32_t *nodes, FPools fp, SearchOut *out, int budget, int zeroBudget,
+                                                       const int32_t *rowOf)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
@@ -241,9 +247,14 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
         S.isRemovedTip = rn.isTip; S.removedBLen = rn.dist; S.curLK = curLK;
         S.hRpr0 = ftree(rn.lower);
         // a search from a zero-length branch without an error model is a whole-tree search (see k_spr_search): dense tier
-        if (!U && budget > zeroBudget && rn.dist == 0.0) { S.state = FS_OVER; o.status = -5; continue; }
-        if (shorten_would_merge(c, fref(ll), ll.n)) { S.state = FS_FALLBACK; continue; }   // M:7087 would edit the removed list
-        S.state = FS_ACTIVE;
+        const bool wouldMerge = shorten_would_merge(c, fref(ll), ll.n);     // M:7087 would edit the removed list
+        bool wide = false;
+        if (!U && budget > zeroBudget && rn.dist == 0.0) {
+            wide = rowOf && rowOf[q] >= 0 && !wouldMerge;
+            if (!wide) { S.state = FS_OVER; o.status = -5; continue; }
+        }
+        if (wouldMerge) { S.state = FS_FALLBACK; continue; }
+        S.state = wide ? FS_WIDE : FS_ACTIVE;
         if (rp.up < 0) {                                                    // the parent is the root (M:6916-6960): seeded by an item
             S.seed0 = fpush(fp, budget, q, true, S.sibling, 3, -1, 0.0, curLK, 0, S.hRpr0, curLK);   // of its own (k_fr_updating)
             continue;
@@ -293,7 +304,7 @@ __device__ __forceinline__ void fr_upd_item_lane(const Ctx<RV, U, SS> &c, const 
 {
         FItem &it = fp.U[i];
         FSearch &S = fp.S[it.q];
-        if (S.state != FS_ACTIVE) { it.flags |= FI_DEAD; return; }
+        if (!fs_live(S.state)) { it.flags |= FI_DEAD; return; }
         const int q = it.q, t1 = it.t1;
         const NodeRec r1 = T.nd[t1];
         const int hPassed = it.hPassed, hRpr = it.hRpr;
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(64) void k_fr_updating_wave(const DevModel *__restr
             const long long i = base + j;
             FItem &it = fp.U[i];
             FSearch &S = fp.S[it.q];
-            if (S.state != FS_ACTIVE) { if (lane == 0) it.flags |= FI_DEAD; continue; }
+            if (!fs_live(S.state)) { if (lane == 0) it.flags |= FI_DEAD; continue; }
             const int q = it.q, t1 = it.t1, dir = it.dir;
             const NodeRec r1 = T.nd[t1];
             const int hPassed = it.hPassed, hRpr = it.hRpr;
@@ -734,7 +745,9 @@ void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Sear
     for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long long)gridDim.x * blockDim.x) {
         FItem &it = fp.C[i];
         FSearch &S = fp.S[it.q];
-        if (S.state != FS_ACTIVE) { it.flags |= FI_DEAD; continue; }
+        const int st = S.state;
+        if (!fs_live(st)) { it.flags |= FI_DEAD; continue; }
+        if (st == FS_WIDE && it.dir == 0) { it.flags |= FI_SEED; continue; }   // (the clade below it: k_fr_replay_wide)
         const int q = it.q, t1 = it.t1, hRpr = it.hRpr;
         const NodeRec r1 = T.nd[t1];
         const double lastLK = it.lastLK;
@@ -822,11 +835,145 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
         for (int r = slHead; r != FR_NONE; r = item_of(fp, r).next)
             if (item_of(fp, r).midProb >= S.curLK - P.thrOptTopo) cnt++;
         const unsigned long long base = atomicAdd(&fp.ctr->nRecs, (unsigned long long)cnt);
-        if ((long long)(base + cnt) > fp.capRecs) { S.state = FS_FALLBACK; out[q].status = FR_STATUS_FALLBACK; fp.ctr->overflow = 1; continue; }
+        if ((long long)(base + cnt) > fp.capRecs) {
+            S.state = FS_FALLBACK; out[q].status = FR_STATUS_FALLBACK; fp.ctr->overflow = 1;
+            for (long long k2 = (long long)base; k2 < fp.capRecs; k2++) { fp.recs[k2].q = q; fp.recs[k2].ref = FR_NONE; }   // (skipped by its state)
+            continue;
+        }
         S.recBase = (int32_t)base; S.recCount = cnt;
         int k = 0;
         for (int r = slHead; r != FR_NONE; r = item_of(fp, r).next)
             if (item_of(fp, r).midProb >= S.curLK - P.thrOptTopo) { FRec &x = fp.recs[base + k++]; x.q = q; x.ref = r; x.ok = 0; }
+    }
+}
+
+// ---- the same walk for a whole-tree search (FS_WIDE), one wavefront per search ------------------------------------------
+// Lane 0 pops items like k_fr_replay; a seed (an item that arrived in the cached regime on the way down) hands the clade below
+// it to all 64 lanes: wave_scan_clade (search_dev.h) applies the reference's rules to the clade in pop order over the search's
+// row of the dense score table -- what the LIFO stack would do with the item and everything it pushes, a pushed clade being
+// finished before anything older is popped.  The short list is kept in visiting order in `br` (items: hUp = item ref, hDown =
+// WR_ITEM; scan entries: the node); the scan's entries that are refined become items of the cached pool so that k_fr_refine
+// and k_fr_finish treat them like any other.
+#define WR_ITEM (-77)
+__global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P, int nWide, const int32_t *wideQ, const int32_t *rowOf,
+                                                       const double *cacheS, FiniteRows fin, FPools fp, SearchOut *out,
+                                                       BestRec *brAll, int capB, int *counter)
+{
+    extern __shared__ double dynW[];
+    double *slotLK = dynW;
+    int *slotFails = (int *)(dynW + T.scanDepthCap);
+    unsigned *slotOwner = (unsigned *)(slotFails + T.scanDepthCap);
+    const int lane = threadIdx.x;
+    BestRec *br = brAll + (size_t)blockIdx.x * capB;
+    for (;;) {
+        int k = 0;
+        if (lane == 0) k = atomicAdd(counter, 1);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (k >= nWide) break;
+        const int q = wideQ[k];
+        FSearch &S = fp.S[q];
+        if (S.state != FS_WIDE) continue;
+        const size_t row = (size_t)rowOf[q];
+        const double *cs = cacheS + row * (size_t)T.n;
+        const unsigned long long *fm = fin.mask ? fin.mask + row * fin.nWords : nullptr;
+        const int32_t *fpx = fin.mask ? fin.prefix + row * (fin.nWords + 1) : nullptr;
+        int top = FR_NONE;
+        auto push = [&](int ref, int fails) {
+            if (ref == FR_NONE) return;
+            FItem &x = item_of(fp, ref);
+            x.next = top; x.failsA = (int16_t)fails; top = ref;
+        };
+        double best = S.curLK;
+        int nApp = 0, nB = 0, bad = 0;
+        if (lane == 0) { push(S.seed0, 0); push(S.seed1, 0); }
+        for (;;) {
+            int seed = FR_NONE, seedFails = 0;
+            if (lane == 0) {
+                while (top != FR_NONE) {
+                    const int ref = top;
+                    FItem &it = item_of(fp, ref);
+                    top = it.next;
+                    if (it.flags & FI_DEAD) continue;
+                    int fails = it.failsA;
+                    if (it.flags & FI_SEED) { seed = ref; seedFails = fails; break; }
+                    const double mp = it.midProb;
+                    if (it.flags & FI_SCORED) {
+                        nApp++;
+                        const bool list = (it.dir == 0) ? (mp > best - P.thrOptTopo) : (mp >= best - P.thrOptTopo);   // M:7071 / 7293
+                        if (list) {
+                            if (nB >= capB) { bad = 1; break; }
+                            br[nB++] = BestRec{it.t1, ref, WR_ITEM, -1, it.hRpr, mp, 0.0};
+                        }
+                        if (mp > best) { best = mp; fails = 0; }
+                        else if (mp < (it.lastLK - P.thrConsec)) fails++;
+                    }
+                    const bool within = mp > (best - P.thrLKtopology);
+                    const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);
+                    if (!go) continue;
+                    push(it.child0, fails);
+                    push(it.child1, fails);
+                }
+            }
+            seed = __builtin_amdgcn_readfirstlane(seed);
+            bad = __builtin_amdgcn_readfirstlane(bad);
+            if (seed == FR_NONE || bad) break;
+            seedFails = __builtin_amdgcn_readfirstlane(seedFails);
+            const FItem &it = fp.C[seed];
+            const NodeRec r1 = T.nd[it.t1];
+            const bool firstScored = !(r1.up == S.parent || r1.up < 0) && (r1.dist > P.effNon0 || r1.upIsRoot);
+            ScanState st;
+            st.best = readfirst_f64(best);
+            st.nB = __builtin_amdgcn_readfirstlane(nB);
+            st.nApp = __builtin_amdgcn_readfirstlane(nApp);
+            st.overflow = 0;
+            st.shortenSeed = false;
+            st.fShort[0] = st.fShort[1] = st.fShort[2] = st.fShort[3] = -1;
+            __threadfence();                                                // (lane 0's short-list entries before the scan's)
+            wave_scan_clade(T.scan, T.scanParent, cs, nullptr, r1.preRank, firstScored, r1.frameOf, it.hRpr, it.lastLK, seedFails, P, br, capB,
+                            slotLK, slotFails, slotOwner, T.scanDepthCap, st, fm, fpx, T.candBefore, T.cladeVisits);
+            if (st.overflow) { bad = 1; break; }
+            best = st.best; nB = st.nB; nApp = st.nApp;
+            __threadfence();
+        }
+        nB = __builtin_amdgcn_readfirstlane(nB);
+        nApp = __builtin_amdgcn_readfirstlane(nApp);
+        __builtin_amdgcn_wave_barrier();
+        __threadfence();                                                    // (the scan's short-list entries, written by other lanes)
+        if (lane == 0) {
+            // the short-listed branches that are refined (M:7465), in visiting order; the scan's become cached-pool items
+            int cnt = 0, cntScan = 0;
+            for (int i = 0; i < nB && !bad; i++)
+                if (br[i].score >= S.curLK - P.thrOptTopo) { cnt++; if (br[i].hDown != WR_ITEM) cntScan++; }
+            unsigned long long base = 0ull, ibase = 0ull;
+            if (!bad) {
+                base = atomicAdd(&fp.ctr->nRecs, (unsigned long long)cnt);
+                ibase = cntScan ? atomicAdd(&fp.ctr->usedC, (unsigned long long)cntScan) : 0ull;
+                if ((long long)(base + cnt) > fp.capRecs || (long long)(ibase + cntScan) > fp.capC) {
+                    bad = 1; fp.ctr->overflow = 1;
+                    for (long long k2 = (long long)base; k2 < min((long long)(base + cnt), fp.capRecs); k2++) { fp.recs[k2].q = q; fp.recs[k2].ref = FR_NONE; }
+                }
+            }
+            if (bad) S.state = FS_FALLBACK;                                  // (short list, depth slots or pools too small: the one-lane kernel)
+            else {
+                S.recBase = (int32_t)base; S.recCount = cnt; S.nApp = nApp;
+                int kk = 0, ks = 0;
+                for (int i = 0; i < nB; i++) {
+                    const BestRec b = br[i];
+                    if (!(b.score >= S.curLK - P.thrOptTopo)) continue;
+                    int ref = b.hUp;
+                    if (b.hDown != WR_ITEM) {
+                        ref = (int)(ibase + ks++);
+                        FItem &x = fp.C[ref];
+                        x.q = q; x.t1 = b.t1; x.dir = 0; x.flags = FI_SCORED; x.failsP = 0; x.hPassed = -1; x.hRpr = b.hRpr;
+                        x.distance = 0.0; x.lastLK = b.score; x.pathBest = b.score; x.midProb = b.score; x.recDist = 0.0;
+                        x.child0 = x.child1 = FR_NONE; x.hA = x.hB = x.hMid = -1; x.next = FR_NONE; x.failsA = 0;
+                    }
+                    FRec &x = fp.recs[base + kk++];
+                    x.q = q; x.ref = ref; x.ok = 0;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -841,13 +988,13 @@ void k_fr_refine(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, FPoo
     Ctx<RV, U, SS> c(m, lds);
     const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     double *ais = fp.sais + laneId * 2ll * fp.capE;
-    const long long nRecs = (long long)fp.ctr->nRecs;
+    const long long nRecs = min((long long)fp.ctr->nRecs, fp.capRecs);
     for (long long i = laneId; i < nRecs; i += (long long)gridDim.x * blockDim.x) {
         FRec &R = fp.recs[i];
         const FItem &it = item_of(fp, R.ref);
         FSearch &S = fp.S[R.q];
         R.ok = 0;
-        if (S.state != FS_ACTIVE) continue;
+        if (!fs_live(S.state)) continue;
         const int t1 = it.t1;
         const NodeRec r1 = T.nd[t1];
         int hUp, hDown, hMid;
@@ -903,7 +1050,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_finish(ArenaViewS av, DevTree T
         FSearch &S = fp.S[q];
         SearchOut &o = out[q];
         if (S.state == FS_FALLBACK) { o.status = FR_STATUS_FALLBACK; continue; }
-        if (S.state != FS_ACTIVE) continue;
+        if (!fs_live(S.state)) continue;
         const int node = S.node;
         const NodeRec rp = T.nd[S.parent];
         double bestScore = S.curLK;
@@ -964,9 +1111,14 @@ struct FrontierScratch {
     DevBuf<double> ta, sa, sais, ba;
     DevBuf<long long> toffW, toffA;
     DevBuf<int32_t> tn, tna, nodes, expQ, expNode;
-    DevBuf<uint8_t> out;
+    DevBuf<uint8_t> out, wideBr;
+    DevBuf<int32_t> wideRow, wideQ, wideCtr;
     long long lastU = -1, lastC = -1;     // items of the last call (for frontier_export), -1: none
     FPools lastPools{};
+    // the two kernels of a level read disjoint items (they only meet in the pools' atomic counters): the cached-regime one runs
+    // on a stream of its own next to the updating one -- a level of the latter lasts as long as its slowest item, on a few lanes
+    hipStream_t side = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
 };
 
 }  // namespace
@@ -979,6 +1131,10 @@ void frontier_scratch_free(maple_ctx *c)
     F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
     F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
     F->expQ.release(); F->expNode.release();
+    F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release();
+    if (F->evFork) (void)hipEventDestroy(F->evFork);
+    if (F->evJoin) (void)hipEventDestroy(F->evJoin);
+    if (F->side) (void)hipStreamDestroy(F->side);
     delete F;
     c->frontier = nullptr;
 }
@@ -998,7 +1154,7 @@ void frontier_scratch_free(maple_ctx *c)
 // -5 = over `budget` expanded items (dense tier), FR_STATUS_FALLBACK = hand to the one-lane-per-search kernel.
 int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *nodes, int budget, int zeroBudget, SearchOut *hostOut,
                     uint2 *poolW, double *poolA, unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
-                    FrontierStats *stats, long long itemsHint)
+                    FrontierStats *stats, long long itemsHint, const FrontierWide *wide)
 {
     if (!c->frontier) c->frontier = new FrontierScratch();
     FrontierScratch &F = *(FrontierScratch *)c->frontier;
@@ -1011,7 +1167,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     const double room = 0.5 * (double)(freeB + held);
     const long long perSearchC = std::min<long long>(budget, 768);
     long long capC = std::max<long long>(1 << 16, std::max((long long)m * perSearchC, itemsHint));
-    long long capU = std::max<long long>(1 << 14, (long long)m * std::min<long long>(budget, 12));
+    long long capU = std::max<long long>(1 << 14, (long long)m * std::min<long long>(budget, 16));
     const long long meanEnt = std::max<long long>(16, c->h_n_ent.empty() ? 64 : c->used_ent / (long long)c->h_n_ent.size());   // entries per list in the arena
     long long capL = 2 * capU;
     long long capW = 2 * capL * meanEnt, capA = capW;
@@ -1073,7 +1229,32 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     TRY(maple_internal_ev_pair(c, &e0, &e1, MAPLE_K_SPR_SEARCH, (double)m, 0.0));
     const size_t slotEv = c->ev_used / 2 - 1;
     HIPCK(c, hipEventRecord(e0, s));
-    FR_DISPATCH3(c, k_fr_begin, <<<gridN, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, m, F.nodes.p, fp, dout, budget, zeroBudget));
+    // whole-tree searches whose rows of the dense score table are being made on another stream (FS_WIDE)
+    std::vector<int32_t> wideIdx;
+    const bool useWide = wide && wide->rowOf && wide->cacheS && budget > zeroBudget && c->scan_valid && !c->tuning.noCladeScan
+                         && (size_t)(c->tree_max_depth + 2) * 16 <= (48u << 10);
+    DevTree Tw = T;                                                         // (with the tables of the clade scan, as k_spr_search gets them)
+    if (useWide) {
+        Tw.scan = c->t_scan.p; Tw.scanParent = c->t_scan_parent.p; Tw.scanDepthCap = c->tree_max_depth + 2;
+        Tw.candBefore = c->t_cand_before.p; Tw.cladeVisits = c->t_clade_visits.p;
+    }
+    if (useWide) {
+        for (int k = 0; k < m; k++) if (wide->rowOf[k] >= 0) wideIdx.push_back(k);
+        // (the searches with the largest clades to scan first)
+        if ((int)c->h_clade.size() == T.n)
+            std::stable_sort(wideIdx.begin(), wideIdx.end(), [&](int a, int b) { return c->h_clade[nodes[a]] > c->h_clade[nodes[b]]; });
+        HIPCK(c, F.wideRow.reserve((size_t)m));
+        HIPCK(c, F.wideQ.reserve(std::max<size_t>(1, wideIdx.size())));
+        HIPCK(c, F.wideCtr.reserve(4));
+        HIPCK(c, hipMemcpyAsync(F.wideRow.p, wide->rowOf, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        if (!wideIdx.empty())
+            HIPCK(c, hipMemcpyAsync(F.wideQ.p, wideIdx.data(), wideIdx.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIPCK(c, hipMemsetAsync(F.wideCtr.p, 0, 4 * sizeof(int32_t), s));
+        HIPCK(c, hipStreamSynchronize(s));                                  // (wideIdx is a local)
+    }
+    const bool anyWide = useWide && !wideIdx.empty();
+    FR_DISPATCH3(c, k_fr_begin, <<<gridN, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, m, F.nodes.p, fp, dout, budget, zeroBudget,
+                                                            anyWide ? F.wideRow.p : nullptr));
     HIPCK(c, hipGetLastError());
     // level loop: the counters stay on the device; the host looks at them every few levels
     FCtr hc;
@@ -1085,19 +1266,29 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     // (a handful of searches -- the re-search of a proposed move -- wait for every single item: all of them by wavefronts)
     const int heavyMin = m <= 64 ? 1 : std::max(256, 6 * (int)meanEnt), gridWave = 256;
     std::vector<size_t> slotsC;
+    if (!F.side) {
+        HIPCK(c, hipStreamCreateWithFlags(&F.side, hipStreamNonBlocking));
+        HIPCK(c, hipEventCreateWithFlags(&F.evFork, hipEventDisableTiming));
+        HIPCK(c, hipEventCreateWithFlags(&F.evJoin, hipEventDisableTiming));
+    }
+    const hipStream_t s2 = F.side;
     auto level = [&]() -> int {                                            // the kernels of one level, each between its own events
         hipEvent_t a0, a1, b0, b1;
+        HIPCK(c, hipEventRecord(F.evFork, s));                             // (after the level's snap)
+        HIPCK(c, hipStreamWaitEvent(s2, F.evFork, 0));
+        TRY(maple_internal_ev_pair(c, &b0, &b1, MAPLE_K_FR_CACHED, 0.0, 0.0));
+        slotsC.push_back(c->ev_used / 2 - 1);
+        HIPCK(c, hipEventRecord(b0, s2));
+        FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s2>>>(c->d_model, av, T, P, fp, budget));
+        HIPCK(c, hipEventRecord(b1, s2));
+        HIPCK(c, hipEventRecord(F.evJoin, s2));
         TRY(maple_internal_ev_pair(c, &a0, &a1, MAPLE_K_FR_UPDATING, 0.0, 0.0));
         HIPCK(c, hipEventRecord(a0, s));
         FR_DISPATCH3(c, k_fr_updating, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget, heavyMin));
         if (heavyMin > 0)
             FR_DISPATCH3(c, k_fr_updating_wave, <<<gridWave, 64, 0, s>>>(c->d_model, av, T, P, fp, budget, heavyMin, scratchLanes));
         HIPCK(c, hipEventRecord(a1, s));
-        TRY(maple_internal_ev_pair(c, &b0, &b1, MAPLE_K_FR_CACHED, 0.0, 0.0));
-        slotsC.push_back(c->ev_used / 2 - 1);
-        HIPCK(c, hipEventRecord(b0, s));
-        FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget));
-        HIPCK(c, hipEventRecord(b1, s));
+        HIPCK(c, hipStreamWaitEvent(s, F.evJoin, 0));
         levels++;
         return MAPLE_OK;
     };
@@ -1118,6 +1309,26 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     TRY(maple_internal_ev_pair(c, &er0, &er1, MAPLE_K_FR_REPLAY, (double)m, 0.0));
     HIPCK(c, hipEventRecord(er0, s));
     k_fr_replay<<<gridN, FR_BLOCK, 0, s>>>(P, m, fp, dout);
+    size_t slotWide = (size_t)-1;
+    if (anyWide) {
+        // the whole-tree searches: the same exact walk, a wavefront each, the clades in the cached regime scanned over the rows
+        // of the dense score table (made on wide->rowsReady's stream while the levels above ran)
+        HIPCK(c, hipEventRecord(er1, s));
+        hipEvent_t w0, w1;
+        TRY(maple_internal_ev_pair(c, &w0, &w1, MAPLE_K_FR_WIDE, 0.0, 0.0));
+        slotWide = c->ev_used / 2 - 1;
+        const int capB = 512, gridW = (int)std::min<size_t>(4096, wideIdx.size());
+        HIPCK(c, F.wideBr.reserve_exact(std::max(F.wideBr.cap, (size_t)gridW * capB * sizeof(BestRec))));
+        if (wide->rowsReady) HIPCK(c, hipStreamWaitEvent(s, wide->rowsReady, 0));
+        HIPCK(c, hipEventRecord(w0, s));
+        const size_t dyn = (size_t)Tw.scanDepthCap * (sizeof(double) + sizeof(int) + sizeof(unsigned));
+        k_fr_replay_wide<<<gridW, 64, dyn, s>>>(Tw, P, (int)wideIdx.size(), F.wideQ.p, F.wideRow.p, wide->cacheS, wide->fin, fp, dout,
+                                                 (BestRec *)F.wideBr.p, capB, F.wideCtr.p);
+        HIPCK(c, hipGetLastError());
+        HIPCK(c, hipEventRecord(w1, s));
+        TRY(maple_internal_ev_pair(c, &er0, &er1, MAPLE_K_FR_REPLAY, 0.0, 0.0));
+        HIPCK(c, hipEventRecord(er0, s));
+    }
     FR_DISPATCH3(c, k_fr_refine, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, fp));
     k_fr_finish<<<gridN, FR_BLOCK, 0, s>>>(av, T, P, m, fp, dout, poolW, poolA, poolUsed, poolCapW, poolCapA);
     HIPCK(c, hipGetLastError());
@@ -1129,13 +1340,21 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     {   // what this tier did, for maple_timing_read_kind: candidate placements of the searches it finished (SURVEY 8d bytes)
         const double meanCand = c->n_scored ? c->scored_bytes_total / c->n_scored : 0.0;
         double units = 0.0, bytes = 0.0;
+        double unitsW = 0.0, bytesW = 0.0;
         for (int k = 0; k < m; k++) {
             if (hostOut[k].status != 0 && hostOut[k].status != -1) continue;
+            if (anyWide && wide->rowOf[k] >= 0) {                           // replayed over its score row: 8 B per placement + its list
+                const int32_t l = c->h_tree_lower[nodes[k]];
+                unitsW += hostOut[k].nAppend;
+                bytesW += 8.0 * hostOut[k].nAppend + (l >= 0 ? 8.0 * c->h_n_ent[l] + 8.0 * c->h_n_aux[l] : 0.0);
+                continue;
+            }
             units += hostOut[k].nAppend;
             const int32_t l = c->h_tree_lower[nodes[k]];
             bytes += meanCand * hostOut[k].nAppend + (l >= 0 ? 8.0 * c->h_n_ent[l] + 8.0 * c->h_n_aux[l] : 0.0);
         }
         c->ev_units[slotEv] = units; c->ev_bytes[slotEv] = bytes;
+        if (slotWide != (size_t)-1) { c->ev_units[slotWide] = unitsW; c->ev_bytes[slotWide] = bytesW; }
         // the cached-regime kernel's own share: what its launches scored (counted on the device), booked on the first launch
         if (!slotsC.empty()) { c->ev_units[slotsC[0]] = (double)hc.scoredC; c->ev_bytes[slotsC[0]] = (double)hc.bytesC; }
     }

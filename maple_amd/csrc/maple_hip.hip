@@ -3397,8 +3397,15 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         // items/s against 2.3e9 pairs/s), so a search only pays for a row of the whole tree once it has expanded half a tree's
         // worth of items; the searches from zero-length branches (whole-tree searches without an error model) never start here.
         const int frontierBudget = hybrid ? std::max(wideBudget, sp->wideSearchBudget == 0 ? c->n_scored / 2 : 0) : 0;
+        // the searches scored on the side stream stay in the tier: their updating steps run with everybody else's, their clades
+        // in the cached regime are scanned over the rows (k_fr_replay_wide)
+        FrontierWide fw{nullptr, nullptr, FiniteRows{nullptr, nullptr, 0}, nullptr};
+        if (!preIdx.empty() && !c->tuning.wideOutsideFrontier) {
+            fw.rowOf = preRowOf.data(); fw.cacheS = c->s_cache.p; fw.rowsReady = c->ev_join;
+            if (useFin) fw.fin = FiniteRows{c->s_fin_mask.p, c->s_fin_prefix.p, finWords};
+        }
         TRY(frontier_search(c, P, n, todo.data(), frontierBudget, (hybrid && wideBudget > MAPLE_ZERO_DIST_BUDGET) ? MAPLE_ZERO_DIST_BUDGET : (1 << 30),
-                            part.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs, 0));
+                            part.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs, 0, fw.rowOf ? &fw : nullptr));
         std::vector<int32_t> todoFb, slotFb;
         for (int i = 0; i < n; i++) {
             ho[i] = part[i];
@@ -3607,9 +3614,9 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 if (ho[i].status != 0 || (pass == 1) != laneTier) continue;
                 tot.push_back((ho[i].tStep + ho[i].tReplay + ho[i].tRefine) * 1e-5);
             }
-            if (pass == 1 && c->tuning.verbose > 1) {
+            if (c->tuning.verbose > 1) {
                 std::vector<int> idx;
-                for (int i = 0; i < n; i++) if (ho[i].status == 0 && ho[i].nAppend <= wideBudget) idx.push_back(i);
+                for (int i = 0; i < n; i++) if (ho[i].status == 0 && (ho[i].nAppend <= wideBudget) == (pass == 1)) idx.push_back(i);
                 std::sort(idx.begin(), idx.end(), [&](int a, int b) {
                     return ho[a].tStep + ho[a].tReplay + ho[a].tRefine > ho[b].tStep + ho[b].tReplay + ho[b].tRefine; });
                 for (size_t k = 0; k < std::min<size_t>(12, idx.size()); k++) {

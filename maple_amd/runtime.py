@@ -43,7 +43,8 @@ class MapleSearchParams(C.Structure):
 
 
 class MapleTuning(C.Structure):
-    _fields_ = [("wavePerItemMax", C.c_int32), ("placementChunkMax", C.c_int32), ("noCladeScan", C.c_int32), ("verbose", C.c_int32)]
+    _fields_ = [("wavePerItemMax", C.c_int32), ("placementChunkMax", C.c_int32), ("noCladeScan", C.c_int32), ("verbose", C.c_int32),
+                ("wideOutsideFrontier", C.c_int32)]
 
 
 class MaplePlacementParams(C.Structure):
@@ -138,9 +139,10 @@ class Device:
             pass
 
     # -- model -------------------------------------------------------------------------------
-    def set_tuning(self, *, wave_per_item_max=0, placement_chunk_max=0, no_clade_scan=False, verbose=0):
+    def set_tuning(self, *, wave_per_item_max=0, placement_chunk_max=0, no_clade_scan=False, verbose=0, wide_outside_frontier=False):
         """How the library schedules its work (never what it computes): see maple_tuning in include/maple_hip.h."""
-        t = MapleTuning(int(wave_per_item_max), int(placement_chunk_max), int(bool(no_clade_scan)), int(verbose))
+        t = MapleTuning(int(wave_per_item_max), int(placement_chunk_max), int(bool(no_clade_scan)), int(verbose),
+                        int(bool(wide_outside_frontier)))
         self._ck(self.lib.maple_set_tuning(self.h, C.byref(t)))
 
     def set_model(self, Q, siteRates=None, usingErrorRate=False, errorRateGlobal=0.0, errorRates=None):
@@ -570,7 +572,7 @@ class Device:
         return n.value, ms.value
 
     KIND_SPR_SCORE, KIND_SPR_SEARCH, KIND_SPR_REPLAY, KIND_APPEND_QUERIES, KIND_APPEND_PAIRS, KIND_PLACE_SCORE = 1, 2, 3, 4, 5, 6
-    KIND_FR_UPDATING, KIND_FR_CACHED, KIND_FR_REPLAY = 7, 8, 9
+    KIND_FR_UPDATING, KIND_FR_CACHED, KIND_FR_REPLAY, KIND_FR_WIDE = 7, 8, 9, 10
 
     def timing_read_kind(self, kind):
         """(launches, summed HIP-event ms, units of work, algorithmic bytes) of one kind of timed launch since the reset."""
