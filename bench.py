@@ -270,7 +270,7 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed_local = elapsed
     K = {name: dev.timing_read_kind(getattr(Device, "KIND_" + name)) for name in
-         ("SPR_SCORE", "SPR_SEARCH", "SPR_REPLAY", "FR_UPDATING", "FR_CACHED", "FR_REPLAY")}     # (launches, ms, units, bytes)
+         ("SPR_SCORE", "SPR_SEARCH", "SPR_REPLAY", "FR_UPDATING", "FR_CACHED", "FR_REPLAY", "FR_WIDE")}     # (launches, ms, units, bytes)
     for res in kept:
         for k, v in zip(*np.unique(res["status"], return_counts=True)):
             status_counts[str(int(k))] = status_counts.get(str(int(k)), 0) + int(v)
@@ -290,8 +290,8 @@ def main():
 
     # per-rank kernel times of the timed steps (what a scaling run is read with: the ranks search disjoint shares of a step)
     mine_ms = {"rank": rank, "wall_ms_per_step": 1e3 * elapsed_local / args.steps,
-               "frontier_tier": K["SPR_SEARCH"][1] / args.steps, "dense_scoring": K["SPR_SCORE"][1] / args.steps,
-               "replay_of_whole_tree_searches": K["SPR_REPLAY"][1] / args.steps,
+               "frontier_tier_without_wide_replay": (K["SPR_SEARCH"][1] - K["FR_WIDE"][1]) / args.steps, "dense_scoring": K["SPR_SCORE"][1] / args.steps,
+               "replay_of_whole_tree_searches": (K["SPR_REPLAY"][1] + K["FR_WIDE"][1]) / args.steps,
                "searches_per_step": len(batch_of(0)), "placements_per_step": placements / args.steps}
     per_rank = [mine_ms]
     if distd is not None:
@@ -344,19 +344,26 @@ def main():
                  "rank 0; algorithmic bytes = SURVEY 8d (8E + 8A + 8 per candidate branch per query, each query list once per launch). "
                  "The 64 candidate lists of a tile are staged in LDS once per 512 queries, so this count is NOT a bound for the "
                  "kernel (frac can exceed 1): `traffic` is what moves, and profiles/ holds its issue / LDS counters"),
-            roof("k_spr_search (exact replay of the whole-tree searches over their score rows: wave-cooperative clade scan, "
-                 "refinement)", "SPR_REPLAY",
+            roof("k_fr_replay_wide (exact replay of the whole-tree searches: a wavefront per search walks the search's expanded "
+                 "items and scans the clades in the cached regime over the search's row of the dense score table)", "FR_WIDE",
+                 "rank 0; algorithmic bytes = 8 B per placement replayed from the score table + the removed list once per search; the "
+                 "rows are bitmaps of their finite scores, and a clade without one is counted instead of walked"),
+            roof("k_spr_search (one wavefront per search from its first step: whole-tree searches the frontier tier handed back)",
+                 "SPR_REPLAY",
                  "rank 0; algorithmic bytes = 8 B per placement replayed from the score table + the removed list once per search"),
         ]
         roofs = [r for r in roofs if r["launches_timed"]]
         dominant = max(roofs, key=lambda r: r["kernel_ms_per_step"]) if roofs else None
         # ---- the two kinds of candidate placement of a step
         n_fr, ms_fr, u_fr, b_fr = K["SPR_SEARCH"]                       # the frontier tier as a whole (or the lane searches)
-        n_rp, ms_rp, u_rp, b_rp = K["SPR_REPLAY"]
+        ms_fr -= K["FR_WIDE"][1]                                        # (the replay of the whole-tree searches runs inside it)
+        n_rp, ms_rp, u_rp, b_rp = (K["SPR_REPLAY"][i] + K["FR_WIDE"][i] for i in range(4))
         ms_dense = K["SPR_SCORE"][1]
         split = {
-            "full_walk": {"what": "candidate placements of searches finished by the frontier tier: each scored by walking the "
-                                  "candidate branch's genome list against the removed subtree's list (M:7011 / 7223)",
+            "full_walk": {"what": "candidate placements of the searches that are not whole-tree searches: each scored by walking the "
+                                  "candidate branch's genome list against the removed subtree's list (M:7011 / 7223); kernel time = "
+                                  "the frontier tier without k_fr_replay_wide (the updating steps of the whole-tree searches, ~10 "
+                                  "per search, run in its level kernels and are counted here)",
                           "placements_per_step": u_fr / steps, "kernel_ms_per_step": ms_fr / steps,
                           "placements_per_s_of_its_kernels": (u_fr / (ms_fr * 1e-3)) if ms_fr else 0.0,
                           "algorithmic_GBps": (b_fr / (ms_fr * 1e-3) / 1e9) if ms_fr else 0.0,
@@ -390,10 +397,11 @@ def main():
                                                    "host traffic (node ids in, ~100 B of results per search out) is inside `value`"}},
             "roofline": dominant, "roofline_by_kernel": roofs, "per_rank": per_rank,
             "spr_search": {"status_counts": status_counts, "proposed_moves_rank0": n_moves,
-                           "kernel_ms_rank0_per_step": {"frontier_tier": ms_fr / steps, "of_which_k_fr_updating": K["FR_UPDATING"][1] / steps,
+                           "kernel_ms_rank0_per_step": {"frontier_tier": K["SPR_SEARCH"][1] / steps, "of_which_k_fr_updating": K["FR_UPDATING"][1] / steps,
                                                         "of_which_k_fr_cached": K["FR_CACHED"][1] / steps,
                                                         "of_which_replay_refine_finish": K["FR_REPLAY"][1] / steps,
-                                                        "dense_scoring": ms_dense / steps, "replay_of_whole_tree_searches": ms_rp / steps},
+                                                        "of_which_k_fr_replay_wide": K["FR_WIDE"][1] / steps,
+                                                        "dense_scoring": ms_dense / steps, "replay_outside_the_tier": K["SPR_REPLAY"][1] / steps},
                            "launches_rank0_per_step": {"frontier_levels": K["FR_CACHED"][0] / steps, "dense_scoring": K["SPR_SCORE"][0] / steps,
                                                        "replay": n_rp / steps},
                            "params": ("fast round: strict, allowedFailsTopology 2, thresholdLogLKtopology 6 log(lRef)"

@@ -83,6 +83,8 @@ typedef struct {
     int32_t verbose;            /* 1: progress lines on stderr (also switched on by the environment variable MAPLE_DEBUG) */
     int32_t wideOutsideFrontier; /* 1: whole-tree SPR searches leave the frontier tier at once and run one wavefront per search
                                    from their first step (k_spr_search), instead of sharing its batched updating steps */
+    int32_t denseWideScoring;   /* 1: the whole-tree SPR searches known beforehand are scored against EVERY branch by the dense kernel
+                                   instead of only against the branches their witness filter cannot rule out (witness.hip) */
 } maple_tuning;
 int maple_set_tuning(maple_ctx *ctx, const maple_tuning *t);
 const char *maple_last_error(maple_ctx *ctx);

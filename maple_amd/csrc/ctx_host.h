@@ -185,6 +185,7 @@ struct maple_ctx {
     int tile_counter_next = 0;
     void *upd = nullptr;               // UpdateScratch of maple_update_partials (update_host.h)
     void *frontier = nullptr;          // FrontierScratch of the frontier tier of the SPR search (frontier.hip)
+    void *witness = nullptr;           // WitnessScratch of the whole-tree searches' candidate filter (witness.hip)
     bool last_search_frontier_only = false;   // maple_spr_search_visited can report on the last maple_spr_search_batch
     bool nodes_current = false;        // the node records of the SPR search on the device follow every maple_tree_patch
     bool tree_stale = false;           // maple_tree_patch changed the host copy of the tree; the device tables of the SPR search

@@ -36,6 +36,7 @@ static RcclApi g_rccl{};
 
 #include "ctx_host.h"
 #include "frontier.h"
+#include "witness.h"
 
 // =================================================================================================
 // kernels
@@ -1277,6 +1278,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     if (!c) return MAPLE_OK;
     update_scratch_free(c);
     frontier_scratch_free(c);
+    witness_scratch_free(c);
     for (int k = 0; k < 2; k++) { if (c->stg_h[k]) (void)hipHostFree(c->stg_h[k]); if (c->stg_d[k]) (void)hipFree(c->stg_d[k]); }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -3375,7 +3377,19 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             HIPCK(c, hipStreamSynchronize(c->stream2));                     // (the three vectors are locals)
             // queued BEHIND the lane launch: a workgroup of the dense kernel wants most of a compute unit's LDS, so it starts
             // where the lane searches have thinned out -- launched first it would hold them off instead (measured: no overlap)
-            afterLaunch = [c, mZ, nTpre, qBytes, fin_prefix, useFin]() -> int {
+            afterLaunch = [c, mZ, nTpre, qBytes, fin_prefix, useFin, finWords, dbgT]() -> int {
+                // (every one of these searches has removedBLen = 0 and there is no error model: only the pairs the witness
+                // filter cannot rule out are walked -- witness.hip)
+                if (useFin && !c->tuning.denseWideScoring) {
+                    long long pairs = 0;
+                    TRY(witness_score(c, c->stream2, mZ, c->z_ql.p, c->z_qt.p, c->z_qb.p, c->n_scored, c->t_i32[8].p, c->t_scored_col.p,
+                                      c->s_cache.p, nTpre, c->s_fin_mask.p, finWords,
+                                      c->n_scored ? c->scored_bytes_total / c->n_scored : 0.0, qBytes, &pairs));
+                    if (dbgT) fprintf(stderr, "[maple] witness filter: %lld of %lld (search, branch) pairs walked\n", pairs, (long long)mZ * c->n_scored);
+                    TRY(fin_prefix(c->stream2, 0, (size_t)mZ));
+                    HIPCK(c, hipEventRecord(c->ev_join, c->stream2));
+                    return MAPLE_OK;
+                }
                 TRY(launch_append_queries(c, c->stream2, mZ, c->z_ql.p, c->n_scored, c->t_i32[8].p, 0, 0.0, c->s_cache.p, nTpre,
                                           c->t_scored_col.p, c->z_qt.p, c->z_qb.p, MAPLE_K_SPR_SCORE,
                                           (double)mZ * c->scored_bytes_total + qBytes, nullptr, nullptr, nullptr, 0, 1, useFin ? c->s_fin_mask.p : nullptr));

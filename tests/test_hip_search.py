@@ -435,6 +435,23 @@ def test_device_search_vs_oracle_search_on_gpu_built_tree(mode):
         for k in ("bestScore", "currentLK", "improvement", "blen"):
             assert np.allclose(g[k], o[k], rtol=1e-11, atol=1e-15), k
         assert g["nAppend"].sum() > 10000
+        if not kw["strict"]:
+            # the whole-tree searches of the full round, replayed inside the frontier tier (k_fr_replay_wide) and one wavefront
+            # per search from their first step (k_spr_search): the same results, bit for bit
+            dev.timing_reset()
+            a = dev.spr_search_batch(nodes, **kw)
+            inside = dev.timing_read_kind(Device.KIND_FR_WIDE)[0]
+            dev.set_tuning(wide_outside_frontier=True)
+            b = dev.spr_search_batch(nodes, **kw)
+            dev.set_tuning(dense_wide_scoring=True)                      # every branch scored instead of the witness filter's survivors
+            d = dev.spr_search_batch(nodes, **kw)
+            dev.set_tuning()
+            for k in ("status", "bestNode", "placement", "nAppend", "bestScore", "currentLK", "improvement", "blen"):
+                assert np.array_equal(a[k], b[k]), k
+                assert np.array_equal(a[k], d[k]), k
+            assert np.array_equal(a["nAppend"][::7], g["nAppend"])
+            if mode != "siteerr":                                        # (without an error model such searches are known beforehand)
+                assert inside > 0
     dev.close()
 
 

@@ -31,5 +31,7 @@ for i in range(rounds + 1):
     r = dev.spr_search_batch(order, **kw, search_tier=tier)
     wall = time.perf_counter() - t0
     print(f"round {i}: {1e3 * wall:.1f} ms, placements {int(r['nAppend'][r['status'] >= -1].sum()):.4e}, moves {(r['placement'] >= 0).sum()}", flush=True)
-ks = {k: dev.timing_read_kind(k) for k in (Device.KIND_SPR_SCORE, Device.KIND_SPR_SEARCH, Device.KIND_SPR_REPLAY)}
-print("kernel ms per round score/lane/replay:", [round(ks[k][1] / rounds, 1) for k in ks], flush=True)
+names = ("SPR_SCORE", "SPR_SEARCH", "SPR_REPLAY", "FR_UPDATING", "FR_CACHED", "FR_REPLAY", "FR_WIDE")
+ks = {k: dev.timing_read_kind(getattr(Device, "KIND_" + k)) for k in names}
+print("kernel ms per round:", {k: round(ks[k][1] / rounds, 1) for k in names}, flush=True)
+print("launches per round:", {k: round(ks[k][0] / rounds, 1) for k in names}, flush=True)
