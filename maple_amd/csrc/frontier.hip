@@ -44,7 +44,7 @@ namespace {
 
 #define FR_BLOCK 256
 
-enum { FI_UPD_IN = 1, FI_UPD_OUT = 2, FI_SCORED = 4, FI_DEAD = 8, FI_REC_UPD = 16, FI_SEED = 32 };
+enum { FI_UPD_IN = 1, FI_UPD_OUT = 2, FI_SCORED = 4, FI_DEAD = 8, FI_REC_UPD = 16, FI_SEED = 32, FI_SEED_EMPTY = 64 };
 // FS_WIDE: a whole-tree search whose row of the dense score table is being made next to this tier.  Its items that still
 // update genome lists are expanded here like any other's (they are what made such a search slow for one lane: up to 200
 // updating steps in a row); an item that arrives in the cached regime on the way DOWN is left as a seed (FI_SEED) -- the clade
@@ -734,7 +734,8 @@ __global__ __launch_bounds__(64) void k_fr_updating_wave(const DevModel *__restr
 // ---- items in the cached regime (needsUpdating == False): appendProbNode(probVectTotUp[t1], removed list) ---------------
 template <bool RV, bool U, bool SS>
 __global__ __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, FPools fp, int budget)
+void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, FPools fp, int budget,
+                 const int32_t *rowOf, FiniteRows fin)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
@@ -747,7 +748,29 @@ void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Sear
         FSearch &S = fp.S[it.q];
         const int st = S.state;
         if (!fs_live(st)) { it.flags |= FI_DEAD; continue; }
-        if (st == FS_WIDE && it.dir == 0) { it.flags |= FI_SEED; continue; }   // (the clade below it: k_fr_replay_wide)
+        if (st == FS_WIDE && it.dir == 0) {                                 // (the clade below it: k_fr_replay_wide)
+            // Most such clades hold no finite score at all for this search.  What the scan does with one of those only
+            // depends on the state the walk arrives with: noted here, applied by the walk itself without a scan.
+            int fl = FI_SEED;
+            if (fin.mask && rowOf) {
+                const NodeRec r1s = T.nd[it.t1];
+                const SScan rec = T.scan[r1s.preRank];
+                const size_t row = (size_t)rowOf[it.q];
+                const unsigned long long *fm = fin.mask + row * fin.nWords;
+                const int32_t *fpx = fin.prefix + row * (fin.nWords + 1);
+                const int lo = T.candBefore[r1s.preRank], hi = T.candBefore[r1s.preRank + rec.size];
+                if (fin_count_before(fm, fpx, hi) == fin_count_before(fm, fpx, lo)) {
+                    const bool firstScored = !(r1s.up == S.parent || r1s.up < 0) && (r1s.dist > P.effNon0 || r1s.upIsRoot);
+                    const bool dropped = firstScored && !(rec.ff & SS_TOTUP);
+                    fl |= FI_SEED_EMPTY;
+                    it.hA = (firstScored && !dropped) ? 1 : 0;               // the clade's root counts as one placement
+                    it.hB = T.cladeVisits[r1s.preRank];                      // placements below it when it is descended into
+                    it.hMid = ((rec.ff & SS_INNER) && !dropped) ? 1 : 0;
+                }
+            }
+            it.flags |= (uint8_t)fl;
+            continue;
+        }
         const int q = it.q, t1 = it.t1, hRpr = it.hRpr;
         const NodeRec r1 = T.nd[t1];
         const double lastLK = it.lastLK;
@@ -886,8 +909,14 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
         double best = S.curLK;
         int nApp = 0, nB = 0, bad = 0;
         if (lane == 0) { push(S.seed0, 0); push(S.seed1, 0); }
+#ifdef MAPLE_SPR_PROFILE
+        long long tWalk = 0, tScan = 0, nScan = 0, tw0 = wall_clock64();
+#endif
         for (;;) {
             int seed = FR_NONE, seedFails = 0;
+#ifdef MAPLE_SPR_PROFILE
+            tw0 = wall_clock64();
+#endif
             if (lane == 0) {
                 while (top != FR_NONE) {
                     const int ref = top;
@@ -895,7 +924,17 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
                     top = it.next;
                     if (it.flags & FI_DEAD) continue;
                     int fails = it.failsA;
-                    if (it.flags & FI_SEED) { seed = ref; seedFails = fails; break; }
+                    if (it.flags & FI_SEED) {
+                        const double hMp = it.hA ? -INFINITY : it.lastLK;       // what the clade's root hands on
+                        if ((it.flags & FI_SEED_EMPTY) && hMp == -INFINITY) {
+                            // a clade without a finite score, entered with -inf: counted, not walked (wave_scan_clade's skipClade)
+                            nApp += it.hA;
+                            if (it.hA && hMp < (it.lastLK - P.thrConsec)) fails++;
+                            if (!P.strict && fails <= P.allowedFails && it.hMid) nApp += it.hB;
+                            continue;
+                        }
+                        seed = ref; seedFails = fails; break;
+                    }
                     const double mp = it.midProb;
                     if (it.flags & FI_SCORED) {
                         nApp++;
@@ -916,6 +955,9 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
             }
             seed = __builtin_amdgcn_readfirstlane(seed);
             bad = __builtin_amdgcn_readfirstlane(bad);
+#ifdef MAPLE_SPR_PROFILE
+            tWalk += wall_clock64() - tw0; tw0 = wall_clock64(); nScan++;
+#endif
             if (seed == FR_NONE || bad) break;
             seedFails = __builtin_amdgcn_readfirstlane(seedFails);
             const FItem &it = fp.C[seed];
@@ -934,11 +976,17 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
             if (st.overflow) { bad = 1; break; }
             best = st.best; nB = st.nB; nApp = st.nApp;
             __threadfence();
+#ifdef MAPLE_SPR_PROFILE
+            tScan += wall_clock64() - tw0;
+#endif
         }
         nB = __builtin_amdgcn_readfirstlane(nB);
         nApp = __builtin_amdgcn_readfirstlane(nApp);
         __builtin_amdgcn_wave_barrier();
         __threadfence();                                                    // (the scan's short-list entries, written by other lanes)
+#ifdef MAPLE_SPR_PROFILE
+        if (lane == 0) { out[q].tStep = tWalk; out[q].tReplay = tScan; out[q].nSteps = (int32_t)nScan; }
+#endif
         if (lane == 0) {
             // the short-listed branches that are refined (M:7465), in visiting order; the scan's become cached-pool items
             int cnt = 0, cntScan = 0;
@@ -1256,6 +1304,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     FR_DISPATCH3(c, k_fr_begin, <<<gridN, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, m, F.nodes.p, fp, dout, budget, zeroBudget,
                                                             anyWide ? F.wideRow.p : nullptr));
     HIPCK(c, hipGetLastError());
+    if (anyWide && wide->rowsReady) HIPCK(c, hipStreamWaitEvent(s, wide->rowsReady, 0));   // (k_fr_cached reads the rows' bitmaps)
     // level loop: the counters stay on the device; the host looks at them every few levels
     FCtr hc;
     std::memset(&hc, 0, sizeof hc);
@@ -1279,7 +1328,9 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         TRY(maple_internal_ev_pair(c, &b0, &b1, MAPLE_K_FR_CACHED, 0.0, 0.0));
         slotsC.push_back(c->ev_used / 2 - 1);
         HIPCK(c, hipEventRecord(b0, s2));
-        FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s2>>>(c->d_model, av, T, P, fp, budget));
+        FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s2>>>(c->d_model, av, anyWide ? Tw : T, P, fp, budget,
+                                                                        anyWide ? F.wideRow.p : nullptr,
+                                                                        anyWide ? wide->fin : FiniteRows{nullptr, nullptr, 0}));
         HIPCK(c, hipEventRecord(b1, s2));
         HIPCK(c, hipEventRecord(F.evJoin, s2));
         TRY(maple_internal_ev_pair(c, &a0, &a1, MAPLE_K_FR_UPDATING, 0.0, 0.0));
@@ -1306,29 +1357,29 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         TRY(level());
         if (levels > 100000) return fail(c, MAPLE_ERR_FATAL, "frontier search did not terminate");
     }
-    TRY(maple_internal_ev_pair(c, &er0, &er1, MAPLE_K_FR_REPLAY, (double)m, 0.0));
-    HIPCK(c, hipEventRecord(er0, s));
-    k_fr_replay<<<gridN, FR_BLOCK, 0, s>>>(P, m, fp, dout);
     size_t slotWide = (size_t)-1;
     if (anyWide) {
         // the whole-tree searches: the same exact walk, a wavefront each, the clades in the cached regime scanned over the rows
-        // of the dense score table (made on wide->rowsReady's stream while the levels above ran)
-        HIPCK(c, hipEventRecord(er1, s));
+        // of the dense score table -- next to the other searches' walk (k_fr_replay: one lane each, as long as its longest search)
         hipEvent_t w0, w1;
         TRY(maple_internal_ev_pair(c, &w0, &w1, MAPLE_K_FR_WIDE, 0.0, 0.0));
         slotWide = c->ev_used / 2 - 1;
-        const int capB = 512, gridW = (int)std::min<size_t>(4096, wideIdx.size());
+        const int capB = 512, gridW = (int)std::min<size_t>(8192, wideIdx.size());
         HIPCK(c, F.wideBr.reserve_exact(std::max(F.wideBr.cap, (size_t)gridW * capB * sizeof(BestRec))));
-        if (wide->rowsReady) HIPCK(c, hipStreamWaitEvent(s, wide->rowsReady, 0));
-        HIPCK(c, hipEventRecord(w0, s));
+        HIPCK(c, hipEventRecord(F.evFork, s));
+        HIPCK(c, hipStreamWaitEvent(s2, F.evFork, 0));
+        HIPCK(c, hipEventRecord(w0, s2));
         const size_t dyn = (size_t)Tw.scanDepthCap * (sizeof(double) + sizeof(int) + sizeof(unsigned));
-        k_fr_replay_wide<<<gridW, 64, dyn, s>>>(Tw, P, (int)wideIdx.size(), F.wideQ.p, F.wideRow.p, wide->cacheS, wide->fin, fp, dout,
-                                                 (BestRec *)F.wideBr.p, capB, F.wideCtr.p);
+        k_fr_replay_wide<<<gridW, 64, dyn, s2>>>(Tw, P, (int)wideIdx.size(), F.wideQ.p, F.wideRow.p, wide->cacheS, wide->fin, fp, dout,
+                                                  (BestRec *)F.wideBr.p, capB, F.wideCtr.p);
         HIPCK(c, hipGetLastError());
-        HIPCK(c, hipEventRecord(w1, s));
-        TRY(maple_internal_ev_pair(c, &er0, &er1, MAPLE_K_FR_REPLAY, 0.0, 0.0));
-        HIPCK(c, hipEventRecord(er0, s));
+        HIPCK(c, hipEventRecord(w1, s2));
+        HIPCK(c, hipEventRecord(F.evJoin, s2));
     }
+    TRY(maple_internal_ev_pair(c, &er0, &er1, MAPLE_K_FR_REPLAY, (double)m, 0.0));
+    HIPCK(c, hipEventRecord(er0, s));
+    k_fr_replay<<<gridN, FR_BLOCK, 0, s>>>(P, m, fp, dout);
+    if (anyWide) HIPCK(c, hipStreamWaitEvent(s, F.evJoin, 0));
     FR_DISPATCH3(c, k_fr_refine, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, fp));
     k_fr_finish<<<gridN, FR_BLOCK, 0, s>>>(av, T, P, m, fp, dout, poolW, poolA, poolUsed, poolCapW, poolCapA);
     HIPCK(c, hipGetLastError());
@@ -1358,6 +1409,17 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         // the cached-regime kernel's own share: what its launches scored (counted on the device), booked on the first launch
         if (!slotsC.empty()) { c->ev_units[slotsC[0]] = (double)hc.scoredC; c->ev_bytes[slotsC[0]] = (double)hc.bytesC; }
     }
+#ifdef MAPLE_SPR_PROFILE
+    if (anyWide) {
+        double tw = 0, ts = 0, mw = 0, ms = 0; long long ns = 0, mxn = 0;
+        for (int k : wideIdx) {
+            tw += hostOut[k].tStep * 1e-5; ts += hostOut[k].tReplay * 1e-5; ns += hostOut[k].nSteps;
+            mw = std::max(mw, hostOut[k].tStep * 1e-5); ms = std::max(ms, hostOut[k].tReplay * 1e-5); mxn = std::max<long long>(mxn, hostOut[k].nSteps);
+        }
+        fprintf(stderr, "[maple] wide replay profile over %zu searches: item walk %.1f ms total (max %.2f), scans %.1f ms total (max %.2f), %lld scans (max %lld)\n",
+                wideIdx.size(), tw, mw, ts, ms, ns, mxn);
+    }
+#endif
     F.lastU = (long long)hc.usedU; F.lastC = (long long)hc.usedC; F.lastPools = fp;
     if (hc.overflow) F.lastU = F.lastC = -1;                              // (a pool overflowed: the item lists are not complete)
     if (stats) {
