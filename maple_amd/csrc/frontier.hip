@@ -84,13 +84,24 @@ struct FSearch {
 struct FRec { int32_t q, ref; double optimized, top, bottom, app; int32_t ok, pad; };
 
 struct FCtr {                          // device-side bookkeeping of the level loop
-    unsigned long long usedU, usedC;   // items allocated in the two pools
-    unsigned long long loU, hiU, loC, hiC;   // the current level
-    unsigned long long nLists, usedW, usedA; // temporary lists
-    unsigned long long nRecs;
+    // (what every lane READS at the start of a kernel, and each counter the lanes bump, on cache lines of their own)
+    alignas(128) unsigned long long loU;
+    unsigned long long hiU, loC, hiC;  // the current level
+    alignas(128) unsigned long long usedU;   // items allocated in the two pools
+    alignas(128) unsigned long long usedC;
+    alignas(128) unsigned long long permDown;     // the level's one-lane updating items by direction (k_fr_sort_level)
+    alignas(128) unsigned long long permUp;
+    alignas(128) unsigned long long nLists;       // temporary lists
+    alignas(128) unsigned long long usedW;
+    alignas(128) unsigned long long usedA;
+    alignas(128) unsigned long long nRecs;
     unsigned long long bigUsed;        // entries taken from the shared scratch of over-long lists (reset every level)
-    unsigned long long scoredC, bytesC;  // cached-regime items scored by k_fr_cached and their SURVEY 8d bytes (8 E + 8 A + 8)
+    alignas(128) unsigned long long scoredC;
+    unsigned long long bytesC;         // cached-regime items scored by k_fr_cached and their SURVEY 8d bytes (8 E + 8 A + 8)
     int32_t overflow, pad;
+#ifdef MAPLE_SPR_PROFILE
+    unsigned long long dbgCnt[8], dbgT[8], dbgMax[8];   // k_fr_updating's one-lane items by size (entries of the two lists): count, ticks, slowest
+#endif
 };
 
 struct FPools {
@@ -101,6 +112,7 @@ struct FPools {
     long long *toffW, *toffA;
     int32_t *tn, *tna;
     long long capW, capA, capL;
+    int32_t *perm;                     // the level's one-lane updating items: moving down from the front, crawling up from the back
     // per-lane scratch
     uint2 *sw; double *sa; double *sais;
     int32_t capE;                      // entries one lane's scratch list takes (aux: 5 per entry; ais: 2 per entry)
@@ -141,9 +153,30 @@ __device__ inline bool fscratch(const FPools &fp, long long laneId, int need, FS
 // a scratch list becomes a temporary list of the batch: exact room, one copy; -2 when the pools are full
 __device__ inline int fstore(const FPools &fp, const Writer &wr)
 {
-    const unsigned long long id = atomicAdd(&fp.ctr->nLists, 1ull);
-    const unsigned long long ow = atomicAdd(&fp.ctr->usedW, (unsigned long long)wr.n);
-    const unsigned long long oa = atomicAdd(&fp.ctr->usedA, (unsigned long long)wr.na);
+    // The lanes of a wavefront that are here together take their room with ONE atomic per counter: the three counters share a
+    // cache line with everything else the level loop counts, and a million single-lane atomics per level on it were what a
+    // level of k_fr_updating waited for.
+    const unsigned long long act = __ballot(1);
+    const int lane = threadIdx.x & 63, leader = (int)__ffsll((long long)act) - 1;
+    int preN = 0, preA = 0, totN = 0, totA = 0, rank = 0, cnt = 0;
+    for (unsigned long long mm = act; mm; mm &= mm - 1) {
+        const int j = (int)__ffsll((long long)mm) - 1;
+        const int nj = __builtin_amdgcn_readlane(wr.n, j), aj = __builtin_amdgcn_readlane(wr.na, j);
+        if (j < lane) { preN += nj; preA += aj; rank++; }
+        totN += nj; totA += aj; cnt++;
+    }
+    unsigned long long id0 = 0, ow0 = 0, oa0 = 0;
+    if (lane == leader) {
+        id0 = atomicAdd(&fp.ctr->nLists, (unsigned long long)cnt);
+        ow0 = atomicAdd(&fp.ctr->usedW, (unsigned long long)totN);
+        oa0 = atomicAdd(&fp.ctr->usedA, (unsigned long long)totA);
+    }
+    auto bc = [&](unsigned long long x) {
+        return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(x >> 32), leader) << 32)
+               | (uint32_t)__builtin_amdgcn_readlane((int)x, leader);
+    };
+    const unsigned long long id = bc(id0) + (unsigned long long)rank, ow = bc(ow0) + (unsigned long long)preN,
+                             oa = bc(oa0) + (unsigned long long)preA;
     if ((long long)id >= fp.capL || (long long)(ow + wr.n) > fp.capW || (long long)(oa + wr.na) > fp.capA) {
         fp.ctr->overflow = 1;
         return -2;
@@ -275,6 +308,7 @@ __global__ void k_fr_snap(FCtr *ctr)
         ctr->loU = ctr->hiU; ctr->hiU = ctr->usedU;
         ctr->loC = ctr->hiC; ctr->hiC = ctr->usedC;
         ctr->bigUsed = 0;
+        ctr->permDown = ctr->permUp = 0;
     }
 }
 
@@ -484,6 +518,35 @@ __device__ __forceinline__ bool fr_upd_heavy(const ArenaViewS &av, const DevTree
     return nPass + nTree >= heavyMin;
 }
 
+// The one-lane updating items of the level, by direction: an item that moves down (M:6982-7160) and one that crawls up
+// (M:7162-7434) share no code, and a wavefront that holds both runs the two paths one after the other -- a level lasts as long
+// as its slowest wavefront.  Items moving down are listed from the front of `perm`, the others from its back.
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_sort_level(ArenaViewS av, DevTree T, FPools fp, int heavyMin)
+{
+    const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
+    const long long n = hi - lo;
+    const int lane = threadIdx.x & 63;
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < n; base += (long long)gridDim.x * blockDim.x) {
+        const long long i = base + threadIdx.x;
+        int kind = -1;                                                      // 0 down, 1 up, -1 none / a wavefront's item
+        if (i < n) {
+            const FItem &it = fp.U[lo + i];
+            if (!fr_upd_heavy(av, T, fp, it, heavyMin)) kind = it.dir == 0 ? 0 : 1;
+        }
+        const unsigned long long md = __ballot(kind == 0), mu = __ballot(kind == 1);
+        unsigned long long bd = 0, bu = 0;
+        if (lane == 0) {
+            if (md) bd = atomicAdd(&fp.ctr->permDown, (unsigned long long)__popcll(md));
+            if (mu) bu = atomicAdd(&fp.ctr->permUp, (unsigned long long)__popcll(mu));
+        }
+        bd = ((unsigned long long)(uint32_t)__shfl((int)(bd >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)bd, 0, 64);
+        bu = ((unsigned long long)(uint32_t)__shfl((int)(bu >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)bu, 0, 64);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (kind == 0) fp.perm[bd + __popcll(md & below)] = (int32_t)i;
+        else if (kind == 1) fp.perm[n - 1 - (long long)(bu + __popcll(mu & below))] = (int32_t)i;
+    }
+}
+
 template <bool RV, bool U, bool SS>
 __global__ __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, FPools fp, int budget, int heavyMin)
@@ -494,9 +557,33 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
     Ctx<RV, U, SS> c(m, lds);
     const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
-    for (long long i = lo + laneId; i < hi; i += (long long)gridDim.x * blockDim.x) {
-        if (fr_upd_heavy(av, T, fp, fp.U[i], heavyMin)) continue;          // (k_fr_updating_wave takes it)
+    // wavefronts of items moving down first, then wavefronts of items crawling up (k_fr_sort_level; heavy items are not listed)
+    const long long nDown = (long long)fp.ctr->permDown, nUp = (long long)fp.ctr->permUp, padDown = (nDown + 63) & ~63ll;
+    (void)heavyMin;
+    for (long long v = laneId; v < padDown + nUp; v += (long long)gridDim.x * blockDim.x) {
+        if (v >= nDown && v < padDown) continue;
+        const long long i = lo + (v < nDown ? fp.perm[v] : fp.perm[(hi - lo) - 1 - (v - padDown)]);
+#ifdef MAPLE_SPR_PROFILE
+        const long long t0 = wall_clock64();
+        int sz = 0;
+        {
+            const FItem &it = fp.U[i];
+            if (it.dir != 3) {
+                const NodeRec &r1 = T.nd[it.t1];
+                const int other = it.dir == 0 ? it.t1 : (it.dir == 1 ? r1.c1 : r1.c0);
+                const int lw = T.nd[other].lower;
+                sz = (lw >= 0 ? av.n_ent[lw] : 0) + (it.hPassed >= 0 ? fp.tn[it.hPassed] : (it.hPassed <= -10 ? av.n_ent[-it.hPassed - 10] : 0));
+            }
+        }
+#endif
         fr_upd_item_lane(c, av, T, P, fp, budget, laneId, i);
+#ifdef MAPLE_SPR_PROFILE
+        {
+            const unsigned long long dt = (unsigned long long)(wall_clock64() - t0);
+            const int b = sz < 64 ? 0 : sz < 96 ? 1 : sz < 128 ? 2 : sz < 192 ? 3 : sz < 256 ? 4 : sz < 384 ? 5 : sz < 512 ? 6 : 7;
+            atomicAdd(&fp.ctr->dbgCnt[b], 1ull); atomicAdd(&fp.ctr->dbgT[b], dt); atomicMax(&fp.ctr->dbgMax[b], dt);
+        }
+#endif
     }
 }
 
@@ -1160,7 +1247,7 @@ struct FrontierScratch {
     DevBuf<long long> toffW, toffA;
     DevBuf<int32_t> tn, tna, nodes, expQ, expNode;
     DevBuf<uint8_t> out, wideBr;
-    DevBuf<int32_t> wideRow, wideQ, wideCtr;
+    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm;
     long long lastU = -1, lastC = -1;     // items of the last call (for frontier_export), -1: none
     FPools lastPools{};
     // the two kernels of a level read disjoint items (they only meet in the pools' atomic counters): the cached-regime one runs
@@ -1179,7 +1266,7 @@ void frontier_scratch_free(maple_ctx *c)
     F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
     F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
     F->expQ.release(); F->expNode.release();
-    F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release();
+    F->perm.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release();
     if (F->evFork) (void)hipEventDestroy(F->evFork);
     if (F->evJoin) (void)hipEventDestroy(F->evJoin);
     if (F->side) (void)hipStreamDestroy(F->side);
@@ -1262,6 +1349,8 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     fp.tw = F.tw.p; fp.ta = F.ta.p; fp.toffW = F.toffW.p; fp.toffA = F.toffA.p; fp.tn = F.tn.p; fp.tna = F.tna.p;
     fp.capW = (long long)F.tw.cap; fp.capA = (long long)F.ta.cap;
     fp.capL = (long long)std::min(std::min(F.toffW.cap, F.toffA.cap), std::min(F.tn.cap, F.tna.cap));
+    HIPCK(c, F.perm.reserve_exact(std::max(F.perm.cap, (size_t)fp.capU)));
+    fp.perm = F.perm.p;
     fp.sw = F.sw.p; fp.sa = F.sa.p; fp.sais = F.sais.p; fp.capE = capE;
     fp.bw = F.bw.p; fp.ba = F.ba.p; fp.capBig = (long long)F.bw.cap;
     fp.ctr = (FCtr *)F.ctr.p; fp.S = (FSearch *)F.srch.p; fp.recs = (FRec *)F.recs.p;
@@ -1335,6 +1424,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, hipEventRecord(F.evJoin, s2));
         TRY(maple_internal_ev_pair(c, &a0, &a1, MAPLE_K_FR_UPDATING, 0.0, 0.0));
         HIPCK(c, hipEventRecord(a0, s));
+        k_fr_sort_level<<<512, FR_BLOCK, 0, s>>>(av, T, fp, heavyMin);
         FR_DISPATCH3(c, k_fr_updating, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget, heavyMin));
         if (heavyMin > 0)
             FR_DISPATCH3(c, k_fr_updating_wave, <<<gridWave, 64, 0, s>>>(c->d_model, av, T, P, fp, budget, heavyMin, scratchLanes));
@@ -1410,6 +1500,12 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         if (!slotsC.empty()) { c->ev_units[slotsC[0]] = (double)hc.scoredC; c->ev_bytes[slotsC[0]] = (double)hc.bytesC; }
     }
 #ifdef MAPLE_SPR_PROFILE
+    {
+        const char *nm[8] = {"<64", "<96", "<128", "<192", "<256", "<384", "<512", ">=512"};
+        for (int b = 0; b < 8; b++)
+            if (hc.dbgCnt[b]) fprintf(stderr, "[maple] one-lane updating items, lists of %s entries: %llu items, mean %.3f ms, slowest %.3f ms\n", nm[b],
+                                      hc.dbgCnt[b], hc.dbgT[b] * 1e-5 / hc.dbgCnt[b], hc.dbgMax[b] * 1e-5);
+    }
     if (anyWide) {
         double tw = 0, ts = 0, mw = 0, ms = 0; long long ns = 0, mxn = 0;
         for (int k : wideIdx) {
