@@ -290,7 +290,7 @@ def main():
 
     # per-rank kernel times of the timed steps (what a scaling run is read with: the ranks search disjoint shares of a step)
     mine_ms = {"rank": rank, "wall_ms_per_step": 1e3 * elapsed_local / args.steps,
-               "frontier_tier_without_wide_replay": (K["SPR_SEARCH"][1] - K["FR_WIDE"][1]) / args.steps, "dense_scoring": K["SPR_SCORE"][1] / args.steps,
+               "frontier_tier": K["SPR_SEARCH"][1] / args.steps, "witness_filter_and_scoring": K["SPR_SCORE"][1] / args.steps,
                "replay_of_whole_tree_searches": (K["SPR_REPLAY"][1] + K["FR_WIDE"][1]) / args.steps,
                "searches_per_step": len(batch_of(0)), "placements_per_step": placements / args.steps}
     per_rank = [mine_ms]
@@ -339,11 +339,16 @@ def main():
                  "device per scored item); one launch per level of the expansion"),
             roof("k_fr_updating (frontier tier: items that still update genome lists -- mergeVectors x 1-4, areVectorsDifferent, "
                  "appendProbNode per item)", "FR_UPDATING",
-                 "rank 0; no SURVEY 8d byte count is defined for these items (their lists are made on the spot): time only"),
-            roof("k_append_queries_lds (dense scoring of the whole-tree searches: every branch of the tree per search)", "SPR_SCORE",
-                 "rank 0; algorithmic bytes = SURVEY 8d (8E + 8A + 8 per candidate branch per query, each query list once per launch). "
-                 "The 64 candidate lists of a tile are staged in LDS once per 512 queries, so this count is NOT a bound for the "
-                 "kernel (frac can exceed 1): `traffic` is what moves, and profiles/ holds its issue / LDS counters"),
+                 "rank 0; units = items one lane each walked (the few with very long lists go to k_fr_updating_wave, inside the same "
+                 "events); algorithmic bytes, counted on the device = the two lists every mergeVectors of an item reads and the one it "
+                 "writes (8E + 8A each).  A level lasts as long as its slowest wavefront (64 items, ~1000 dependent list steps): "
+                 "latency-bound, see DESIGN.md"),
+            roof("k_wit_score (whole-tree searches: the witness filter rules out the branches that score -inf by appendProbNode's own "
+                 "rule, the pairs that are left are walked)", "SPR_SCORE",
+                 "rank 0; units = (search, branch) pairs walked, algorithmic bytes = SURVEY 8d for those pairs (8E + 8A + 8 per candidate "
+                 "list, each removed list once); the time is the whole stage: witnesses, buckets, pair list, walks, bitmap prefix "
+                 "(when the dense kernel k_append_queries_lds runs instead -- error model, local references, searches that were not "
+                 "announced -- its launches are booked here too)"),
             roof("k_fr_replay_wide (exact replay of the whole-tree searches: a wavefront per search walks the search's expanded "
                  "items and scans the clades in the cached regime over the search's row of the dense score table)", "FR_WIDE",
                  "rank 0; algorithmic bytes = 8 B per placement replayed from the score table + the removed list once per search; the "
@@ -356,23 +361,26 @@ def main():
         dominant = max(roofs, key=lambda r: r["kernel_ms_per_step"]) if roofs else None
         # ---- the two kinds of candidate placement of a step
         n_fr, ms_fr, u_fr, b_fr = K["SPR_SEARCH"]                       # the frontier tier as a whole (or the lane searches)
-        ms_fr -= K["FR_WIDE"][1]                                        # (the replay of the whole-tree searches runs inside it)
+        # (k_fr_replay_wide runs inside the tier, next to k_fr_replay: its time is not taken out of the tier's)
         n_rp, ms_rp, u_rp, b_rp = (K["SPR_REPLAY"][i] + K["FR_WIDE"][i] for i in range(4))
         ms_dense = K["SPR_SCORE"][1]
         split = {
             "full_walk": {"what": "candidate placements of the searches that are not whole-tree searches: each scored by walking the "
                                   "candidate branch's genome list against the removed subtree's list (M:7011 / 7223); kernel time = "
-                                  "the frontier tier without k_fr_replay_wide (the updating steps of the whole-tree searches, ~10 "
-                                  "per search, run in its level kernels and are counted here)",
+                                  "the frontier tier as a whole (the updating steps of the whole-tree searches, ~10 per search, run "
+                                  "in its level kernels, and their replay runs next to the other searches' replay: both are in it)",
                           "placements_per_step": u_fr / steps, "kernel_ms_per_step": ms_fr / steps,
                           "placements_per_s_of_its_kernels": (u_fr / (ms_fr * 1e-3)) if ms_fr else 0.0,
                           "algorithmic_GBps": (b_fr / (ms_fr * 1e-3) / 1e9) if ms_fr else 0.0,
                           "frac_of_hbm_peak": (b_fr / (ms_fr * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_fr else 0.0},
             "replayed": {"what": "candidate placements of whole-tree searches (searches from zero-length branches without an error "
                                  "model: a mismatch over zero length is impossible, M:6663, -inf never counts as a failed pass, the "
-                                 "non-strict rule M:7095 descends everywhere): every branch scored by the dense kernel -- most walks "
-                                 "end at the first mismatch -- then the traversal replayed over the score row",
+                                 "non-strict rule M:7095 descends everywhere): the branches that can score above -inf are found by "
+                                 "the witness filter (witness.hip) and walked, the traversal is replayed over the search's row of "
+                                 "scores; a clade without a finite score is counted, not walked -- so these placements are "
+                                 "candidate placements the reference's search evaluates, not list walks this library performs",
                          "placements_per_step": u_rp / steps, "kernel_ms_per_step": (ms_rp + ms_dense) / steps,
+                         "pairs_walked_per_step": K["SPR_SCORE"][2] / steps,
                          "placements_per_s_of_its_kernels": (u_rp / ((ms_rp + ms_dense) * 1e-3)) if (ms_rp + ms_dense) else 0.0},
         }
         out = {
@@ -401,8 +409,8 @@ def main():
                                                         "of_which_k_fr_cached": K["FR_CACHED"][1] / steps,
                                                         "of_which_replay_refine_finish": K["FR_REPLAY"][1] / steps,
                                                         "of_which_k_fr_replay_wide": K["FR_WIDE"][1] / steps,
-                                                        "dense_scoring": ms_dense / steps, "replay_outside_the_tier": K["SPR_REPLAY"][1] / steps},
-                           "launches_rank0_per_step": {"frontier_levels": K["FR_CACHED"][0] / steps, "dense_scoring": K["SPR_SCORE"][0] / steps,
+                                                        "witness_filter_and_scoring": ms_dense / steps, "replay_outside_the_tier": K["SPR_REPLAY"][1] / steps},
+                           "launches_rank0_per_step": {"frontier_levels": K["FR_CACHED"][0] / steps, "witness_filter_and_scoring": K["SPR_SCORE"][0] / steps,
                                                        "replay": n_rp / steps},
                            "params": ("fast round: strict, allowedFailsTopology 2, thresholdLogLKtopology 6 log(lRef)"
                                       if args.spr_fast else

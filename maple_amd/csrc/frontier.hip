@@ -96,6 +96,8 @@ struct FCtr {                          // device-side bookkeeping of the level l
     alignas(128) unsigned long long usedA;
     alignas(128) unsigned long long nRecs;
     unsigned long long bigUsed;        // entries taken from the shared scratch of over-long lists (reset every level)
+    alignas(128) unsigned long long itemsU;
+    unsigned long long bytesU;         // items k_fr_updating walked and the bytes of the lists their mergeVectors read and wrote
     alignas(128) unsigned long long scoredC;
     unsigned long long bytesC;         // cached-regime items scored by k_fr_cached and their SURVEY 8d bytes (8 E + 8 A + 8)
     int32_t overflow, pad;
@@ -334,7 +336,7 @@ __device__ __forceinline__ PRule p_rule(const SearchParams &P, bool scored, doub
 // one such item by one lane (the one-lane list walks of genome_dev.h)
 template <bool RV, bool U, bool SS>
 __device__ __forceinline__ void fr_upd_item_lane(const Ctx<RV, U, SS> &c, const ArenaViewS &av, const DevTree &T, const SearchParams &P, const FPools &fp,
-                                 const int budget, const long long laneId, const long long i)
+                                 const int budget, const long long laneId, const long long i, unsigned long long *algBytes = nullptr)
 {
         FItem &it = fp.U[i];
         FSearch &S = fp.S[it.q];
@@ -356,6 +358,9 @@ __device__ __forceinline__ void fr_upd_item_lane(const Ctx<RV, U, SS> &c, const 
             if (!fscratch(fp, laneId, l1.n + l2.n, scr)) { S.state = FS_FALLBACK; return -2; }
             wr.init(scr.w, scr.a);
             const int r = merge_walk(c, fref(l1), b1, tp1, fref(l2), b2, tp2, upDown, false, 0, 0, wr, nullptr);
+            // (the item's algorithmic bytes: the two lists a mergeVectors reads and the one it writes; the lists of the item's
+            // areVectorsDifferent and appendProbNode are among them or of the same size)
+            if (algBytes) *algBytes += 8ull * (unsigned long long)(l1.n + l1.na + l2.n + l2.na + (r > 0 ? wr.n + wr.na : 0));
             return r == -1 ? -1 : (r < 0 ? -2 : 0);
         };
         // rootVector(list, bLen, isFromTip) without local references (M:4916-4996): the walk, then shorten; a stored handle,
@@ -559,6 +564,7 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
     const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
     // wavefronts of items moving down first, then wavefronts of items crawling up (k_fr_sort_level; heavy items are not listed)
     const long long nDown = (long long)fp.ctr->permDown, nUp = (long long)fp.ctr->permUp, padDown = (nDown + 63) & ~63ll;
+    unsigned long long nU = 0, bU = 0;
     (void)heavyMin;
     for (long long v = laneId; v < padDown + nUp; v += (long long)gridDim.x * blockDim.x) {
         if (v >= nDown && v < padDown) continue;
@@ -576,7 +582,8 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
             }
         }
 #endif
-        fr_upd_item_lane(c, av, T, P, fp, budget, laneId, i);
+        fr_upd_item_lane(c, av, T, P, fp, budget, laneId, i, &bU);
+        nU++;
 #ifdef MAPLE_SPR_PROFILE
         {
             const unsigned long long dt = (unsigned long long)(wall_clock64() - t0);
@@ -585,6 +592,12 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
         }
 #endif
     }
+    // (what the launch did, for the roofline of the bench line: one atomic per wavefront)
+    for (int off = 32; off > 0; off >>= 1) {
+        nU += ((unsigned long long)(uint32_t)__shfl_down((int)(nU >> 32), off, 64) << 32) | (uint32_t)__shfl_down((int)nU, off, 64);
+        bU += ((unsigned long long)(uint32_t)__shfl_down((int)(bU >> 32), off, 64) << 32) | (uint32_t)__shfl_down((int)bU, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && nU) { atomicAdd(&fp.ctr->itemsU, nU); atomicAdd(&fp.ctr->bytesU, bU); }
 }
 
 // ---- the same items by a whole wavefront: the few whose lists are long -------------------------------------------------------
@@ -1403,7 +1416,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     // wavefront, two per compute unit)
     // (a handful of searches -- the re-search of a proposed move -- wait for every single item: all of them by wavefronts)
     const int heavyMin = m <= 64 ? 1 : std::max(256, 6 * (int)meanEnt), gridWave = 256;
-    std::vector<size_t> slotsC;
+    std::vector<size_t> slotsC, slotsU;
     if (!F.side) {
         HIPCK(c, hipStreamCreateWithFlags(&F.side, hipStreamNonBlocking));
         HIPCK(c, hipEventCreateWithFlags(&F.evFork, hipEventDisableTiming));
@@ -1423,6 +1436,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, hipEventRecord(b1, s2));
         HIPCK(c, hipEventRecord(F.evJoin, s2));
         TRY(maple_internal_ev_pair(c, &a0, &a1, MAPLE_K_FR_UPDATING, 0.0, 0.0));
+        slotsU.push_back(c->ev_used / 2 - 1);
         HIPCK(c, hipEventRecord(a0, s));
         k_fr_sort_level<<<512, FR_BLOCK, 0, s>>>(av, T, fp, heavyMin);
         FR_DISPATCH3(c, k_fr_updating, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget, heavyMin));
@@ -1498,6 +1512,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         if (slotWide != (size_t)-1) { c->ev_units[slotWide] = unitsW; c->ev_bytes[slotWide] = bytesW; }
         // the cached-regime kernel's own share: what its launches scored (counted on the device), booked on the first launch
         if (!slotsC.empty()) { c->ev_units[slotsC[0]] = (double)hc.scoredC; c->ev_bytes[slotsC[0]] = (double)hc.bytesC; }
+        if (!slotsU.empty()) { c->ev_units[slotsU[0]] = (double)hc.itemsU; c->ev_bytes[slotsU[0]] = (double)hc.bytesU; }
     }
 #ifdef MAPLE_SPR_PROFILE
     {
