@@ -304,11 +304,12 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
     }
 }
 
-__global__ void k_fr_snap(FCtr *ctr)
+__global__ void k_fr_snap(FCtr *ctr, long long capU, long long capC)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        ctr->loU = ctr->hiU; ctr->hiU = ctr->usedU;
-        ctr->loC = ctr->hiC; ctr->hiC = ctr->usedC;
+        // (a pool that overflowed keeps counting what was asked of it: the items themselves end at its capacity)
+        ctr->loU = ctr->hiU; ctr->hiU = min(ctr->usedU, (unsigned long long)capU);
+        ctr->loC = ctr->hiC; ctr->hiC = min(ctr->usedC, (unsigned long long)capC);
         ctr->bigUsed = 0;
         ctr->permDown = ctr->permUp = 0;
     }
@@ -1262,6 +1263,7 @@ struct FrontierScratch {
     DevBuf<uint8_t> out, wideBr;
     DevBuf<int32_t> wideRow, wideQ, wideCtr, perm;
     long long lastU = -1, lastC = -1;     // items of the last call (for frontier_export), -1: none
+    long long needU = 0, needC = 0, needL = 0, needW = 0, needA = 0, needM = 0;   // what the last call asked of the pools, and its searches
     FPools lastPools{};
     // the two kernels of a level read disjoint items (they only meet in the pools' atomic counters): the cached-regime one runs
     // on a stream of its own next to the updating one -- a level of the latter lasts as long as its slowest item, on a few lanes
@@ -1319,6 +1321,13 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     const long long meanEnt = std::max<long long>(16, c->h_n_ent.empty() ? 64 : c->used_ent / (long long)c->h_n_ent.size());   // entries per list in the arena
     long long capL = 2 * capU;
     long long capW = 2 * capL * meanEnt, capA = capW;
+    if (F.needM > 0) {
+        // what the last batch asked for, scaled to this one: with an error model the searches are several times as long as the
+        // first guess, and a pool that runs over hands its searches back
+        const double f = 1.25 * (double)m / (double)F.needM;
+        capU = std::max(capU, (long long)(f * F.needU)); capC = std::max(capC, (long long)(f * F.needC));
+        capL = std::max(capL, (long long)(f * F.needL)); capW = std::max(capW, (long long)(f * F.needW)); capA = std::max(capA, (long long)(f * F.needA));
+    }
     // per-lane scratch for lists of up to capE entries (two average lists merged, with room); the few longer ones -- near the
     // root -- take pieces of a shared region.  As many lanes as the GPU holds at once at this kernel's occupancy.
     const int capE = std::max(256, std::min(1024, 6 * (int)meanEnt));
@@ -1369,6 +1378,13 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     fp.ctr = (FCtr *)F.ctr.p; fp.S = (FSearch *)F.srch.p; fp.recs = (FRec *)F.recs.p;
     fp.capRecs = (long long)(F.recs.cap / sizeof(FRec));
     hipStream_t s = c->stream;
+    const bool dbgSync = c->tuning.verbose > 2;                            // (MAPLE_DEBUG=3: every launch awaited and named)
+    auto stage = [&](const char *what) -> int {
+        if (!dbgSync) return MAPLE_OK;
+        HIPCK(c, hipDeviceSynchronize());
+        fprintf(stderr, "[maple] frontier: %s done\n", what);
+        return MAPLE_OK;
+    };
     HIPCK(c, hipMemsetAsync(fp.ctr, 0, sizeof(FCtr), s));
     HIPCK(c, hipMemcpyAsync(F.nodes.p, nodes, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s));
     SearchOut *dout = (SearchOut *)F.out.p;
@@ -1435,13 +1451,17 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
                                                                         anyWide ? wide->fin : FiniteRows{nullptr, nullptr, 0}));
         HIPCK(c, hipEventRecord(b1, s2));
         HIPCK(c, hipEventRecord(F.evJoin, s2));
+        TRY(stage("k_fr_cached"));
         TRY(maple_internal_ev_pair(c, &a0, &a1, MAPLE_K_FR_UPDATING, 0.0, 0.0));
         slotsU.push_back(c->ev_used / 2 - 1);
         HIPCK(c, hipEventRecord(a0, s));
         k_fr_sort_level<<<512, FR_BLOCK, 0, s>>>(av, T, fp, heavyMin);
+        TRY(stage("k_fr_sort_level"));
         FR_DISPATCH3(c, k_fr_updating, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget, heavyMin));
+        TRY(stage("k_fr_updating"));
         if (heavyMin > 0)
             FR_DISPATCH3(c, k_fr_updating_wave, <<<gridWave, 64, 0, s>>>(c->d_model, av, T, P, fp, budget, heavyMin, scratchLanes));
+        TRY(stage("k_fr_updating_wave"));
         HIPCK(c, hipEventRecord(a1, s));
         HIPCK(c, hipStreamWaitEvent(s, F.evJoin, 0));
         levels++;
@@ -1449,10 +1469,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     };
     for (;;) {
         for (int g = 0; g < 8; g++) {
-            k_fr_snap<<<1, 64, 0, s>>>(fp.ctr);
+            k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC);
             TRY(level());
         }
-        k_fr_snap<<<1, 64, 0, s>>>(fp.ctr);
+        k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC);
         HIPCK(c, hipGetLastError());
         HIPCK(c, hipMemcpyAsync(&hc, fp.ctr, sizeof(FCtr), hipMemcpyDeviceToHost, s));
         HIPCK(c, hipStreamSynchronize(s));
@@ -1483,8 +1503,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     TRY(maple_internal_ev_pair(c, &er0, &er1, MAPLE_K_FR_REPLAY, (double)m, 0.0));
     HIPCK(c, hipEventRecord(er0, s));
     k_fr_replay<<<gridN, FR_BLOCK, 0, s>>>(P, m, fp, dout);
+    TRY(stage("k_fr_replay"));
     if (anyWide) HIPCK(c, hipStreamWaitEvent(s, F.evJoin, 0));
     FR_DISPATCH3(c, k_fr_refine, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, fp));
+    TRY(stage("k_fr_refine"));
     k_fr_finish<<<gridN, FR_BLOCK, 0, s>>>(av, T, P, m, fp, dout, poolW, poolA, poolUsed, poolCapW, poolCapA);
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipEventRecord(er1, s));
@@ -1531,7 +1553,9 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
                 wideIdx.size(), tw, mw, ts, ms, ns, mxn);
     }
 #endif
-    F.lastU = (long long)hc.usedU; F.lastC = (long long)hc.usedC; F.lastPools = fp;
+    F.needU = (long long)hc.usedU; F.needC = (long long)hc.usedC; F.needL = (long long)hc.nLists; F.needW = (long long)hc.usedW;
+    F.needA = (long long)hc.usedA; F.needM = m;
+    F.lastU = std::min((long long)hc.usedU, fp.capU); F.lastC = std::min((long long)hc.usedC, fp.capC); F.lastPools = fp;
     if (hc.overflow) F.lastU = F.lastC = -1;                              // (a pool overflowed: the item lists are not complete)
     if (stats) {
         stats->levels = levels; stats->itemsUpdating = (long long)hc.usedU; stats->itemsCached = (long long)hc.usedC;

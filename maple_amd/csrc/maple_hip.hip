@@ -3410,7 +3410,11 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         // An item of the frontier tier costs about what half a (search, branch) pair costs the dense tier on full walks (1.1e9
         // items/s against 2.3e9 pairs/s), so a search only pays for a row of the whole tree once it has expanded half a tree's
         // worth of items; the searches from zero-length branches (whole-tree searches without an error model) never start here.
-        const int frontierBudget = hybrid ? std::max(wideBudget, sp->wideSearchBudget == 0 ? c->n_scored / 2 : 0) : 0;
+        // (With an error model there are no searches known to be whole-tree ones beforehand, a fifth of all searches is long, and
+        // half a tree's worth of items each does not fit any pool -- 5e8 items at 100 000 tips and counting: those searches
+        // leave at the lane tiers' budget.)
+        const int frontierBudget = !hybrid ? 0 : (c->dm.usingErrorRate ? wideBudget
+                                                                       : std::max(wideBudget, sp->wideSearchBudget == 0 ? c->n_scored / 2 : 0));
         // the searches scored on the side stream stay in the tier: their updating steps run with everybody else's, their clades
         // in the cached regime are scanned over the rows (k_fr_replay_wide)
         FrontierWide fw{nullptr, nullptr, FiniteRows{nullptr, nullptr, 0}, nullptr};

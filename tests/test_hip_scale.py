@@ -625,3 +625,25 @@ def test_apply_phase_batched_equals_sequential(world):
         have = np.nonzero(ia >= 0)[0]
         assert dev.download(ia[have]) == dev.download(ib[have]), a
     dev.release(mark)
+
+
+def test_deep_round_with_error_model_at_20k_tips_frontier_tier_equals_lane_tier():
+    """A deep SPR round with the error model on a 20 000-tip tree: a fifth of the searches is long, the frontier tier's pools run
+    over on the first call (searches handed back, the level ranges end at the pools' capacity) and the long searches leave at
+    the lane tiers' budget.  Status, node ids, candidate counts, scores and branch lengths equal those of the
+    one-lane-per-search kernels, bit for bit -- on the first call and on the next one, whose pools are sized by what the
+    first asked for."""
+    import bench
+    data, dev, orc, m = build(20000, "siteerr", seed=1)
+    dev.upload_tree(m.root, m.parent, m.children[:, 0], m.children[:, 1], m.dist, m.is_tip, m.lower, m.up_right, m.up_left,
+                    m.tot_up, -np.ones(m.n_nodes, dtype=np.int32))
+    kw = bench.search_kwargs(dev.lRef)
+    nodes = bench.preorder_nodes(m)
+    lane = dev.spr_search_batch(nodes, search_tier=1, **kw)
+    # (wide_search_budget = 20 000 items per search: more than the pools of a first call hold -- they run over, then grow)
+    for budget in (20000, 20000, 0, 0):
+        g = dev.spr_search_batch(nodes, wide_search_budget=budget, **kw)
+        for k in ("status", "bestNode", "placement", "nAppend", "bestScore", "currentLK", "improvement", "blen"):
+            assert np.array_equal(g[k], lane[k]), (budget, k)
+    assert (g["status"] == 0).sum() > 30000 and g["nAppend"].sum() > 1e7
+    dev.close()
