@@ -690,7 +690,8 @@ def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, batch_of, gpu_results, kw
     children = [[] if mirror.children[v, 0] < 0 else [int(mirror.children[v, 0]), int(mirror.children[v, 1])] for v in range(n)]
     otree = OracleTree(orc, mirror.root, up, children, mirror.dist, [[] for _ in range(n)], [0] * n, lists4)
     nodes = np.concatenate([batch_of(i) for i in range(steps)])
-    gpu = {k: np.concatenate([r[k] for r in gpu_results]) for k in ("status", "bestNode", "placement", "nAppend")}
+    gpu = {k: np.concatenate([r[k] for r in gpu_results]) for k in ("status", "bestNode", "placement", "nAppend", "bestScore")}
+    ties = [0]
     cores = usable_host_threads()
 
     def timed_sample(threads, budget_s, stride0, seen):
@@ -711,9 +712,20 @@ def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, batch_of, gpu_results, kw
             o = orc.spr_worker(otree, nodes[sel], threads=threads, **kw)
             t_used += time.perf_counter() - t0
             placements += int(o["nAppend"].sum())
+            # node ids, moves and candidate counts are compared exactly -- except where two branches tie: the final selection
+            # (M:7635) takes the later of two equal optimised scores, and the device's log() and the host's differ in the last
+            # bit, so a tie to 1e-11 may go either way (counted and reported)
+            tie = np.abs(o["bestScore"] - gpu["bestScore"][sel]) <= 1e-11 * np.maximum(1.0, np.abs(o["bestScore"]))
             for k in ("status", "bestNode", "placement", "nAppend"):
-                if not np.array_equal(o[k], gpu[k][sel]):
-                    raise SystemExit(f"GPU SPR search disagrees with the oracle on {k}")
+                diff = o[k] != gpu[k][sel]
+                if k in ("bestNode", "placement"):
+                    ties[0] += int((diff & tie).sum()) if k == "bestNode" else 0
+                    diff &= ~tie
+                if diff.any():
+                    j = int(np.nonzero(diff)[0][0])
+                    raise SystemExit(f"GPU SPR search disagrees with the oracle on {k}: timed search {int(sel[j])} (node {int(nodes[sel[j]])}, "
+                                     f"{threads} oracle thread(s)): oracle " + str({q: o[q][j].tolist() for q in ("status", "bestNode", "placement", "nAppend", "bestScore")})
+                                     + " GPU " + str({q: gpu[q][sel[j]].tolist() for q in ("status", "bestNode", "placement", "nAppend", "bestScore")}))
             checked += len(sel)
             seen.update(sel.tolist())
             stride //= 2
@@ -725,7 +737,8 @@ def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, batch_of, gpu_results, kw
     return {"value": pn / tn, "unit": "placements/s", "cores": cores, "kind": "port",
             "sample": f"{cn} of the {len(nodes)} timed searches (evenly spread), {pn} candidate placements, C oracle search "
                       f"(oracle/maple_oracle_search.c, OpenMP over searches like the reference's Pool.map over --numCores, M:12283-12293) "
-                      f"on {cores} host threads, {tn:.1f} s; node ids, moves and candidate counts identical to the GPU's",
+                      f"on {cores} host threads, {tn:.1f} s; node ids, moves and candidate counts identical to the GPU's"
+                      + (f" ({ties[0]} searches whose two best branches tie to 1e-11 end on the other one)" if ties[0] else ""),
             "one_core": {"value": p1 / t1, "unit": "placements/s", "cores": 1,
                          "sample": f"{c1} searches, {p1} candidate placements, {t1:.1f} s"},
             "whole_workload_estimate_s": {"one_core": full / (p1 / t1), f"{cores}_cores": full / (pn / tn)}}
