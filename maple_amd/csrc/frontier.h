@@ -16,6 +16,8 @@ struct FrontierWide {
     const double *cacheS;              // device: the table, rows of dtree.n scores by preRank
     FiniteRows fin;                    // bitmap form of the rows (or nulls)
     hipEvent_t rowsReady;              // recorded behind the launches that write the rows (or null: same stream)
+    int forceWide;                     // 1: every search with a row is a whole-tree search (they were found by running over their
+                                       // budget, with any model); 0: those the kernel's own routing hint names (zero-length branch, no error model)
 };
 
 __attribute__((visibility("hidden")))

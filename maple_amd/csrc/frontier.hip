@@ -250,7 +250,7 @@ __device__ inline int fpush(const FPools &fp, const int budget, const int q, con
 template <bool RV, bool U, bool SS>
 __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, int n,
                                                        const int32_t *nodes, FPools fp, SearchOut *out, int budget, int zeroBudget,
-                                                       const int32_t *rowOf)
+                                                       const int32_t *rowOf, int forceWide)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
@@ -284,7 +284,10 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
         // a search from a zero-length branch without an error model is a whole-tree search (see k_spr_search): dense tier
         const bool wouldMerge = shorten_would_merge(c, fref(ll), ll.n);     // M:7087 would edit the removed list
         bool wide = false;
-        if (!U && budget > zeroBudget && rn.dist == 0.0) {
+        if (forceWide && rowOf && rowOf[q] >= 0) {
+            if (wouldMerge) { S.state = FS_OVER; o.status = -5; continue; }   // (the one-wavefront-per-search kernel edits the list in place)
+            wide = true;
+        } else if (!U && budget > zeroBudget && rn.dist == 0.0) {
             wide = rowOf && rowOf[q] >= 0 && !wouldMerge;
             if (!wide) { S.state = FS_OVER; o.status = -5; continue; }
         }
@@ -1321,7 +1324,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     const long long meanEnt = std::max<long long>(16, c->h_n_ent.empty() ? 64 : c->used_ent / (long long)c->h_n_ent.size());   // entries per list in the arena
     long long capL = 2 * capU;
     long long capW = 2 * capL * meanEnt, capA = capW;
-    if (F.needM > 0) {
+    if (F.needM > 0 && !(wide && wide->forceWide)) {
         // what the last batch asked for, scaled to this one: with an error model the searches are several times as long as the
         // first guess, and a pool that runs over hands its searches back
         const double f = 1.25 * (double)m / (double)F.needM;
@@ -1397,7 +1400,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, hipEventRecord(e0, s));
     // whole-tree searches whose rows of the dense score table are being made on another stream (FS_WIDE)
     std::vector<int32_t> wideIdx;
-    const bool useWide = wide && wide->rowOf && wide->cacheS && budget > zeroBudget && c->scan_valid && !c->tuning.noCladeScan
+    const bool useWide = wide && wide->rowOf && wide->cacheS && (wide->forceWide || budget > zeroBudget) && c->scan_valid && !c->tuning.noCladeScan
                          && (size_t)(c->tree_max_depth + 2) * 16 <= (48u << 10);
     DevTree Tw = T;                                                         // (with the tables of the clade scan, as k_spr_search gets them)
     if (useWide) {
@@ -1420,7 +1423,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     }
     const bool anyWide = useWide && !wideIdx.empty();
     FR_DISPATCH3(c, k_fr_begin, <<<gridN, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, m, F.nodes.p, fp, dout, budget, zeroBudget,
-                                                            anyWide ? F.wideRow.p : nullptr));
+                                                            anyWide ? F.wideRow.p : nullptr, anyWide ? wide->forceWide : 0));
     HIPCK(c, hipGetLastError());
     if (anyWide && wide->rowsReady) HIPCK(c, hipStreamWaitEvent(s, wide->rowsReady, 0));   // (k_fr_cached reads the rows' bitmaps)
     // level loop: the counters stay on the device; the host looks at them every few levels
@@ -1553,8 +1556,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
                 wideIdx.size(), tw, mw, ts, ms, ns, mxn);
     }
 #endif
-    F.needU = (long long)hc.usedU; F.needC = (long long)hc.usedC; F.needL = (long long)hc.nLists; F.needW = (long long)hc.usedW;
-    F.needA = (long long)hc.usedA; F.needM = m;
+    if (!(anyWide && wide->forceWide)) {                                  // (a batch of whole-tree searches only says nothing about the next full one)
+        F.needU = (long long)hc.usedU; F.needC = (long long)hc.usedC; F.needL = (long long)hc.nLists; F.needW = (long long)hc.usedW;
+        F.needA = (long long)hc.usedA; F.needM = m;
+    }
     F.lastU = std::min((long long)hc.usedU, fp.capU); F.lastC = std::min((long long)hc.usedC, fp.capC); F.lastPools = fp;
     if (hc.overflow) F.lastU = F.lastC = -1;                              // (a pool overflowed: the item lists are not complete)
     if (stats) {

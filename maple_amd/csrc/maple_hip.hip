@@ -3417,7 +3417,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                                                                        : std::max(wideBudget, sp->wideSearchBudget == 0 ? c->n_scored / 2 : 0));
         // the searches scored on the side stream stay in the tier: their updating steps run with everybody else's, their clades
         // in the cached regime are scanned over the rows (k_fr_replay_wide)
-        FrontierWide fw{nullptr, nullptr, FiniteRows{nullptr, nullptr, 0}, nullptr};
+        FrontierWide fw{nullptr, nullptr, FiniteRows{nullptr, nullptr, 0}, nullptr, 0};
         if (!preIdx.empty() && !c->tuning.wideOutsideFrontier) {
             fw.rowOf = preRowOf.data(); fw.cacheS = c->s_cache.p; fw.rowsReady = c->ev_join;
             if (useFin) fw.fin = FiniteRows{c->s_fin_mask.p, c->s_fin_prefix.p, finWords};
@@ -3551,9 +3551,35 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 if (useFin) TRY(fin_prefix(c->stream, 0, (size_t)m));
                 if (dbgT) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] t=%.1f ms: scored\n", tms(tStart, tnow())); }
                 if (useFin) finRows = FiniteRows{c->s_fin_mask.p, c->s_fin_prefix.p, finWords};
+                if (useFrontier && useFin && !c->tuning.wideOutsideFrontier && m >= 64) {
+                    // the searches that ran over their budget: back through the frontier tier as whole-tree searches -- their
+                    // updating steps batched, their clades scanned over the rows just made (k_fr_replay_wide); what the tier
+                    // hands back is replayed one wavefront per search as before, on its own row
+                    std::vector<int32_t> rowId(m);
+                    for (int k = 0; k < m; k++) rowId[k] = k;
+                    FrontierWide fw2{rowId.data(), c->s_cache.p, finRows, nullptr, 1};
+                    std::vector<SearchOut> part(m);
+                    FrontierStats fs2;
+                    const int rcF = frontier_search(c, P, m, qn.data(), 1 << 30, 0, part.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs2, 0, &fw2);
+                    if (rcF != MAPLE_OK) { finRows = FiniteRows{nullptr, nullptr, 0}; return rcF; }
+                    std::vector<int32_t> qn2, sl2, rows2;
+                    for (int k = 0; k < m; k++) {
+                        if (part[k].status == FR_STATUS_FALLBACK || part[k].status == -5) { qn2.push_back(qn[k]); sl2.push_back(sl[k]); rows2.push_back(k); }
+                        else ho[sl[k]] = part[k];
+                    }
+                    if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: %d searches over budget replayed inside the frontier tier (%d levels), %zu handed back\n",
+                                      tms(tStart, tnow()), m, fs2.levels, qn2.size());
+                    qn.swap(qn2); sl.swap(sl2);
+                    if (!qn.empty()) rowOverride = &rows2;
+                    const int rcW = qn.empty() ? MAPLE_OK : run_queries(qn, sl, c->s_cache.p, 0, nullptr, 0);
+                    rowOverride = nullptr;
+                    finRows = FiniteRows{nullptr, nullptr, 0};
+                    TRY(rcW);
+                } else {
                 const int rcW = run_queries(qn, sl, c->s_cache.p, 0, nullptr, 0);
                 finRows = FiniteRows{nullptr, nullptr, 0};
                 TRY(rcW);
+                }
                 if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: replayed\n", tms(tStart, tnow()));
             } else {
                 // the removed list in every MAT reference frame, along the paths the traversal itself takes
