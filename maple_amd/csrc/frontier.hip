@@ -43,6 +43,9 @@
 namespace {
 
 #define FR_BLOCK 256
+#ifndef FR_BIG_MIN
+#define FR_BIG_MIN 176
+#endif
 
 enum { FI_UPD_IN = 1, FI_UPD_OUT = 2, FI_SCORED = 4, FI_DEAD = 8, FI_REC_UPD = 16, FI_SEED = 32, FI_SEED_EMPTY = 64 };
 // FS_WIDE: a whole-tree search whose row of the dense score table is being made next to this tier.  Its items that still
@@ -53,22 +56,25 @@ enum { FS_ACTIVE = 0, FS_FINAL = 1, FS_OVER = 2, FS_FALLBACK = 3, FS_WIDE = 4 };
 __device__ __forceinline__ bool fs_live(int st) { return st == FS_ACTIVE || st == FS_WIDE; }
 #define FR_NONE (-1)
 
-struct alignas(16) FItem {
-    // in (written by the parent item's lane)
-    int32_t q, t1;
+struct alignas(32) FItem {
+    // what the exact replay reads and writes per pop, in one 32-byte sector (the walk of the longest search is a chain of
+    // dependent misses on these)
     int8_t dir;                        // 0 = moving from a parent to its child, 1 / 2 = crawling up from child 0 / 1
     uint8_t flags;
-    int16_t failsP;                    // failedPasses under the permissive rules
-    int32_t hPassed, hRpr;             // list handles: >= 0 temporary list, <= -10 tree list -(id + 10), -1 None
-    double distance, lastLK, pathBest;
-    // out (written by the item's own lane)
-    double midProb, recDist;
-    int32_t child0, child1;            // item refs in push order: >= 0 cached pool, <= -2 updating pool -(i + 2), -1 none
-    int32_t hA, hB, hMid;              // short-list record of an item that was still updating (M:7073 / 7295)
-    // replay
+    int16_t failsA;                    // failedPasses the replay arrives with
     int32_t next;                      // stack link, then short-list link
-    int16_t failsA, pad;
+    int32_t child0, child1;            // item refs in push order: >= 0 cached pool, <= -2 updating pool -(i + 2), -1 none
+    double midProb, lastLK;
+    // in (written by the parent item's lane)
+    int32_t q, t1;
+    int32_t hPassed, hRpr;             // list handles: >= 0 temporary list, <= -10 tree list -(id + 10), -1 None
+    double distance, pathBest;
+    int16_t failsP, pad;               // failedPasses under the permissive rules
+    // out (written by the item's own lane)
+    int32_t hA, hB, hMid;              // short-list record of an item that was still updating (M:7073 / 7295)
+    double recDist;
 };
+static_assert(sizeof(FItem) == 96, "FItem");
 
 struct FSearch {
     int32_t node, parent, sibling;     // pruned node, its parent (`node` of findBestParentTopology), its sibling
@@ -91,6 +97,8 @@ struct FCtr {                          // device-side bookkeeping of the level l
     alignas(128) unsigned long long usedC;
     alignas(128) unsigned long long permDown;     // the level's one-lane updating items by direction (k_fr_sort_level)
     alignas(128) unsigned long long permUp;
+    alignas(128) unsigned long long permDownB;    // ... those with long lists (16 to a wavefront)
+    alignas(128) unsigned long long permUpB;
     alignas(128) unsigned long long nLists;       // temporary lists
     alignas(128) unsigned long long usedW;
     alignas(128) unsigned long long usedA;
@@ -114,7 +122,8 @@ struct FPools {
     long long *toffW, *toffA;
     int32_t *tn, *tna;
     long long capW, capA, capL;
-    int32_t *perm;                     // the level's one-lane updating items: moving down from the front, crawling up from the back
+    int32_t *perm, *perm2;             // the level's one-lane updating items: moving down from the front, crawling up from the back
+                                       // (perm2: those with long lists)
     // per-lane scratch
     uint2 *sw; double *sa; double *sais;
     int32_t capE;                      // entries one lane's scratch list takes (aux: 5 per entry; ais: 2 per entry)
@@ -314,7 +323,7 @@ __global__ void k_fr_snap(FCtr *ctr, long long capU, long long capC)
         ctr->loU = ctr->hiU; ctr->hiU = min(ctr->usedU, (unsigned long long)capU);
         ctr->loC = ctr->hiC; ctr->hiC = min(ctr->usedC, (unsigned long long)capC);
         ctr->bigUsed = 0;
-        ctr->permDown = ctr->permUp = 0;
+        ctr->permDown = ctr->permUp = ctr->permDownB = ctr->permUpB = 0;
     }
 }
 
@@ -516,43 +525,57 @@ __device__ __noinline__ void fr_upd_item_lane_call(const Ctx<RV, U, SS> &c, cons
 // Is this item one of the few with long lists (near the root)?  One lane walking two lists of several hundred entries takes
 // milliseconds, and a level of the expansion lasts as long as its slowest item: those go to k_fr_updating_wave, a wavefront
 // per item.
-__device__ __forceinline__ bool fr_upd_heavy(const ArenaViewS &av, const DevTree &T, const FPools &fp, const FItem &it, int heavyMin)
+__device__ __forceinline__ int fr_upd_size(const ArenaViewS &av, const DevTree &T, const FPools &fp, const FItem &it)
 {
-    if (it.dir == 3 || heavyMin <= 0) return false;
+    if (it.dir == 3) return 0;
     const NodeRec &r1 = T.nd[it.t1];
     const int other = it.dir == 0 ? it.t1 : (it.dir == 1 ? r1.c1 : r1.c0);
     const int lw = T.nd[other].lower;
     const int nTree = lw >= 0 ? av.n_ent[lw] : 0;
     const int nPass = it.hPassed >= 0 ? fp.tn[it.hPassed] : (it.hPassed <= -10 ? av.n_ent[-it.hPassed - 10] : 0);
-    return nPass + nTree >= heavyMin;
+    return nPass + nTree;
+}
+__device__ __forceinline__ bool fr_upd_heavy(const ArenaViewS &av, const DevTree &T, const FPools &fp, const FItem &it, int heavyMin)
+{
+    return heavyMin > 0 && it.dir != 3 && fr_upd_size(av, T, fp, it) >= heavyMin;
 }
 
 // The one-lane updating items of the level, by direction: an item that moves down (M:6982-7160) and one that crawls up
 // (M:7162-7434) share no code, and a wavefront that holds both runs the two paths one after the other -- a level lasts as long
 // as its slowest wavefront.  Items moving down are listed from the front of `perm`, the others from its back.
-__global__ __launch_bounds__(FR_BLOCK) void k_fr_sort_level(ArenaViewS av, DevTree T, FPools fp, int heavyMin)
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_sort_level(ArenaViewS av, DevTree T, FPools fp, int heavyMin, int bigMin)
 {
+    // (and by size: the items with the longest lists of the level -- the ones its slowest wavefront is made of -- are listed
+    // apart, in perm2, and walked 16 to a wavefront: a wavefront runs the union of its lanes' paths for as many steps as its
+    // longest list has, and a quarter of the lanes is a good deal less than the whole of that union)
     const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
     const long long n = hi - lo;
     const int lane = threadIdx.x & 63;
+    auto bc = [](unsigned long long x) {
+        return ((unsigned long long)(uint32_t)__shfl((int)(x >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)x, 0, 64);
+    };
     for (long long base = (long long)blockIdx.x * blockDim.x; base < n; base += (long long)gridDim.x * blockDim.x) {
         const long long i = base + threadIdx.x;
-        int kind = -1;                                                      // 0 down, 1 up, -1 none / a wavefront's item
+        int kind = -1;                                                      // 0 down, 1 up, 2 / 3 the same with long lists, -1 a wavefront's item
         if (i < n) {
             const FItem &it = fp.U[lo + i];
-            if (!fr_upd_heavy(av, T, fp, it, heavyMin)) kind = it.dir == 0 ? 0 : 1;
+            const int sz = fr_upd_size(av, T, fp, it);
+            if (!(heavyMin > 0 && it.dir != 3 && sz >= heavyMin)) kind = (it.dir == 0 ? 0 : 1) + (sz >= bigMin ? 2 : 0);
         }
-        const unsigned long long md = __ballot(kind == 0), mu = __ballot(kind == 1);
-        unsigned long long bd = 0, bu = 0;
-        if (lane == 0) {
-            if (md) bd = atomicAdd(&fp.ctr->permDown, (unsigned long long)__popcll(md));
-            if (mu) bu = atomicAdd(&fp.ctr->permUp, (unsigned long long)__popcll(mu));
-        }
-        bd = ((unsigned long long)(uint32_t)__shfl((int)(bd >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)bd, 0, 64);
-        bu = ((unsigned long long)(uint32_t)__shfl((int)(bu >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)bu, 0, 64);
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (kind == 0) fp.perm[bd + __popcll(md & below)] = (int32_t)i;
-        else if (kind == 1) fp.perm[n - 1 - (long long)(bu + __popcll(mu & below))] = (int32_t)i;
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long mk = __ballot(kind == k);
+            if (!mk) continue;
+            unsigned long long *ctr = k == 0 ? &fp.ctr->permDown : (k == 1 ? &fp.ctr->permUp : (k == 2 ? &fp.ctr->permDownB : &fp.ctr->permUpB));
+            unsigned long long b0 = 0;
+            if (lane == 0) b0 = atomicAdd(ctr, (unsigned long long)__popcll(mk));
+            b0 = bc(b0);
+            if (kind == k) {
+                int32_t *pm = k < 2 ? fp.perm : fp.perm2;
+                const long long at = (long long)(b0 + __popcll(mk & below));
+                pm[(k & 1) ? n - 1 - at : at] = (int32_t)i;
+            }
+        }
     }
 }
 
@@ -568,11 +591,25 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
     const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
     // wavefronts of items moving down first, then wavefronts of items crawling up (k_fr_sort_level; heavy items are not listed)
     const long long nDown = (long long)fp.ctr->permDown, nUp = (long long)fp.ctr->permUp, padDown = (nDown + 63) & ~63ll;
+    // the items with long lists first, 16 to a wavefront (lanes 0-15), then wavefronts of 64 moving down, then of 64 crawling up
+    const long long nDownB = (long long)fp.ctr->permDownB, nUpB = (long long)fp.ctr->permUpB;
+    const long long vDownB = ((nDownB + 15) >> 4) << 6, vUpB = ((nUpB + 15) >> 4) << 6, vBig = vDownB + vUpB;
     unsigned long long nU = 0, bU = 0;
     (void)heavyMin;
-    for (long long v = laneId; v < padDown + nUp; v += (long long)gridDim.x * blockDim.x) {
-        if (v >= nDown && v < padDown) continue;
-        const long long i = lo + (v < nDown ? fp.perm[v] : fp.perm[(hi - lo) - 1 - (v - padDown)]);
+    for (long long v0 = laneId; v0 < vBig + padDown + nUp; v0 += (long long)gridDim.x * blockDim.x) {
+        long long i;
+        if (v0 < vBig) {
+            const bool up = v0 >= vDownB;
+            const long long w = up ? v0 - vDownB : v0;
+            const int l = (int)(w & 63);
+            const long long j = (w >> 6) * 16 + l;
+            if (l >= 16 || j >= (up ? nUpB : nDownB)) continue;
+            i = lo + (up ? fp.perm2[(hi - lo) - 1 - j] : fp.perm2[j]);
+        } else {
+            const long long v = v0 - vBig;
+            if (v >= nDown && v < padDown) continue;
+            i = lo + (v < nDown ? fp.perm[v] : fp.perm[(hi - lo) - 1 - (v - padDown)]);
+        }
 #ifdef MAPLE_SPR_PROFILE
         const long long t0 = wall_clock64();
         int sz = 0;
@@ -1264,7 +1301,7 @@ struct FrontierScratch {
     DevBuf<long long> toffW, toffA;
     DevBuf<int32_t> tn, tna, nodes, expQ, expNode;
     DevBuf<uint8_t> out, wideBr;
-    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm;
+    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2;
     long long lastU = -1, lastC = -1;     // items of the last call (for frontier_export), -1: none
     long long needU = 0, needC = 0, needL = 0, needW = 0, needA = 0, needM = 0;   // what the last call asked of the pools, and its searches
     FPools lastPools{};
@@ -1284,7 +1321,7 @@ void frontier_scratch_free(maple_ctx *c)
     F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
     F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
     F->expQ.release(); F->expNode.release();
-    F->perm.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release();
+    F->perm.release(); F->perm2.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release();
     if (F->evFork) (void)hipEventDestroy(F->evFork);
     if (F->evJoin) (void)hipEventDestroy(F->evJoin);
     if (F->side) (void)hipStreamDestroy(F->side);
@@ -1375,7 +1412,8 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     fp.capW = (long long)F.tw.cap; fp.capA = (long long)F.ta.cap;
     fp.capL = (long long)std::min(std::min(F.toffW.cap, F.toffA.cap), std::min(F.tn.cap, F.tna.cap));
     HIPCK(c, F.perm.reserve_exact(std::max(F.perm.cap, (size_t)fp.capU)));
-    fp.perm = F.perm.p;
+    HIPCK(c, F.perm2.reserve_exact(std::max(F.perm2.cap, (size_t)fp.capU)));
+    fp.perm = F.perm.p; fp.perm2 = F.perm2.p;
     fp.sw = F.sw.p; fp.sa = F.sa.p; fp.sais = F.sais.p; fp.capE = capE;
     fp.bw = F.bw.p; fp.ba = F.ba.p; fp.capBig = (long long)F.bw.cap;
     fp.ctr = (FCtr *)F.ctr.p; fp.S = (FSearch *)F.srch.p; fp.recs = (FRec *)F.recs.p;
@@ -1435,6 +1473,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     // wavefront, two per compute unit)
     // (a handful of searches -- the re-search of a proposed move -- wait for every single item: all of them by wavefronts)
     const int heavyMin = m <= 64 ? 1 : std::max(256, 6 * (int)meanEnt), gridWave = 256;
+    const int bigMin = m <= 64 ? (1 << 30) : FR_BIG_MIN;                  // (lists of this many entries together: 16 items to a wavefront)
     std::vector<size_t> slotsC, slotsU;
     if (!F.side) {
         HIPCK(c, hipStreamCreateWithFlags(&F.side, hipStreamNonBlocking));
@@ -1458,7 +1497,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         TRY(maple_internal_ev_pair(c, &a0, &a1, MAPLE_K_FR_UPDATING, 0.0, 0.0));
         slotsU.push_back(c->ev_used / 2 - 1);
         HIPCK(c, hipEventRecord(a0, s));
-        k_fr_sort_level<<<512, FR_BLOCK, 0, s>>>(av, T, fp, heavyMin);
+        k_fr_sort_level<<<512, FR_BLOCK, 0, s>>>(av, T, fp, heavyMin, bigMin);
         TRY(stage("k_fr_sort_level"));
         FR_DISPATCH3(c, k_fr_updating, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget, heavyMin));
         TRY(stage("k_fr_updating"));
