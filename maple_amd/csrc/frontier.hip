@@ -43,6 +43,9 @@
 namespace {
 
 #define FR_BLOCK 256
+#ifndef FR_HEAVY_MULT
+#define FR_HEAVY_MULT 24               // (quarters of the mean list length: lists of this many entries together go one wavefront per item)
+#endif
 #ifndef FR_BIG_MIN
 #define FR_BIG_MIN 176
 #endif
@@ -1472,7 +1475,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     // items whose two lists add up to this many entries are walked by a wavefront each (k_fr_updating_wave: 54 KB of LDS per
     // wavefront, two per compute unit)
     // (a handful of searches -- the re-search of a proposed move -- wait for every single item: all of them by wavefronts)
-    const int heavyMin = m <= 64 ? 1 : std::max(256, 6 * (int)meanEnt), gridWave = 256;
+    const int heavyMin = m <= 64 ? 1 : std::max(256, FR_HEAVY_MULT * (int)meanEnt / 4), gridWave = 256;
     const int bigMin = m <= 64 ? (1 << 30) : FR_BIG_MIN;                  // (lists of this many entries together: 16 items to a wavefront)
     std::vector<size_t> slotsC, slotsU;
     if (!F.side) {
