@@ -28,7 +28,7 @@ for i in range(rounds + 1):
     if i == 1:
         dev.timing_reset()
     t0 = time.perf_counter()
-    r = dev.spr_search_batch(order, **kw, search_tier=tier)
+    r = dev.spr_search_batch(order, **kw, search_tier=tier, wide_search_budget=int(os.environ.get("WIDE_BUDGET", "0")))
     wall = time.perf_counter() - t0
     print(f"round {i}: {1e3 * wall:.1f} ms, placements {int(r['nAppend'][r['status'] >= -1].sum()):.4e}, moves {(r['placement'] >= 0).sum()}", flush=True)
 names = ("SPR_SCORE", "SPR_SEARCH", "SPR_REPLAY", "FR_UPDATING", "FR_CACHED", "FR_REPLAY", "FR_WIDE")
