@@ -184,6 +184,8 @@ struct maple_ctx {
     int32_t *d_tile_counters = nullptr;    // ring of tile counters for the dynamically scheduled kernels
     int tile_counter_next = 0;
     void *upd = nullptr;               // UpdateScratch of maple_update_partials (update_host.h)
+    std::vector<SearchOut> h_search_out;   // per-search results of the last maple_spr_search_batch on the host (kept: 24 MB of fresh
+                                       // pages per call cost 5 ms at 200 000 searches)
     void *frontier = nullptr;          // FrontierScratch of the frontier tier of the SPR search (frontier.hip)
     void *witness = nullptr;           // WitnessScratch of the whole-tree searches' candidate filter (witness.hip)
     bool last_search_frontier_only = false;   // maple_spr_search_visited can report on the last maple_spr_search_batch

@@ -3071,7 +3071,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     P.effNon0 = sp->effectivelyNon0BLen;
     HIPCK(c, c->s_search_out.reserve((size_t)n * sizeof(SearchOut)));
     HIPCK(c, c->s_counter.reserve(8));
-    std::vector<SearchOut> ho(n);
+    std::vector<SearchOut> &ho = c->h_search_out;
+    ho.assign((size_t)n, SearchOut{});
     std::vector<int32_t> todo(nodes, nodes + n), slot(n);
     for (int i = 0; i < n; i++) slot[i] = i;
     // output pool for bestRemovedPartials: a list re-expressed in another frame stays close to its original size
@@ -3405,7 +3406,6 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // removed list in place, touches the root while still updating lists, or overflows a pool) runs one lane per search.
     if (useFrontier) {
         if (afterLaunch) { std::function<int()> f; f.swap(afterLaunch); TRY(f()); }   // (the side-stream scoring starts alongside)
-        std::vector<SearchOut> part(n);
         FrontierStats fs;
         // An item of the frontier tier costs about what half a (search, branch) pair costs the dense tier on full walks (1.1e9
         // items/s against 2.3e9 pairs/s), so a search only pays for a row of the whole tree once it has expanded half a tree's
@@ -3423,12 +3423,10 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             if (useFin) fw.fin = FiniteRows{c->s_fin_mask.p, c->s_fin_prefix.p, finWords};
         }
         TRY(frontier_search(c, P, n, todo.data(), frontierBudget, (hybrid && wideBudget > MAPLE_ZERO_DIST_BUDGET) ? MAPLE_ZERO_DIST_BUDGET : (1 << 30),
-                            part.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs, 0, fw.rowOf ? &fw : nullptr));
+                            ho.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs, 0, fw.rowOf ? &fw : nullptr));
         std::vector<int32_t> todoFb, slotFb;
-        for (int i = 0; i < n; i++) {
-            ho[i] = part[i];
-            if (part[i].status == FR_STATUS_FALLBACK) { todoFb.push_back(todo[i]); slotFb.push_back(i); }
-        }
+        for (int i = 0; i < n; i++)
+            if (ho[i].status == FR_STATUS_FALLBACK) { todoFb.push_back(todo[i]); slotFb.push_back(i); }
         if (dbgT)
             fprintf(stderr, "[maple] t=%.1f ms: frontier tier done: %d levels, %lld updating + %lld cached items, %lld temporary lists "
                             "(%lld words, %lld aux), %lld refined records, %zu searches handed back%s\n", tms(tStart, tnow()), fs.levels,
