@@ -76,8 +76,20 @@ struct alignas(32) FItem {
     // out (written by the item's own lane)
     int32_t hA, hB, hMid;              // short-list record of an item that was still updating (M:7073 / 7295)
     double recDist;
+    int32_t size, pos;                 // items in the subtree the item heads, and its place in its search's visiting order (layout)
 };
 static_assert(sizeof(FItem) == 96, "FItem");
+
+// The items of a search once more, in the order the exact walk visits them (the child pushed last first): rank p + 1 is the first
+// item visited after rank p, p + size skips the subtree -- the walk of k_fr_replay is a forward scan over these 32-byte records
+// instead of a chase through 96-byte items scattered over gigabytes (one miss to HBM per pop).
+struct alignas(32) FVisit {
+    double midProb, lastLK;
+    int32_t ref, size;
+    int32_t parent;                    // rank of the item that pushed it (its failedPasses are handed on), -1 for a seed
+    uint8_t flags; int8_t dir; int16_t failsOut;
+};
+static_assert(sizeof(FVisit) == 32, "FVisit");
 
 struct FSearch {
     int32_t node, parent, sibling;     // pruned node, its parent (`node` of findBestParentTopology), its sibling
@@ -111,7 +123,7 @@ struct FCtr {                          // device-side bookkeeping of the level l
     unsigned long long bytesU;         // items k_fr_updating walked and the bytes of the lists their mergeVectors read and wrote
     alignas(128) unsigned long long scoredC;
     unsigned long long bytesC;         // cached-regime items scored by k_fr_cached and their SURVEY 8d bytes (8 E + 8 A + 8)
-    int32_t overflow, pad;
+    int32_t overflow, nLevels;
 #ifdef MAPLE_SPR_PROFILE
     unsigned long long dbgCnt[8], dbgT[8], dbgMax[8];   // k_fr_updating's one-lane items by size (entries of the two lists): count, ticks, slowest
 #endif
@@ -125,6 +137,10 @@ struct FPools {
     long long *toffW, *toffA;
     int32_t *tn, *tna;
     long long capW, capA, capL;
+    FVisit *visit; long long capVisit;   // the layout of k_fr_layout_* (null: k_fr_replay chases the items)
+    unsigned long long *lvl;           // [maxLevels][4]: loU, hiU, loC, hiC of every level
+    int32_t maxLevels;
+    int32_t *tot; long long *vbase;    // per search: items in its two seed subtrees, and where its visiting order starts
     int32_t *perm, *perm2;             // the level's one-lane updating items: moving down from the front, crawling up from the back
                                        // (perm2: those with long lists)
     // per-lane scratch
@@ -254,7 +270,7 @@ __device__ inline int fpush(const FPools &fp, const int budget, const int q, con
     it->q = q; it->t1 = t1; it->dir = (int8_t)dir; it->flags = upd ? FI_UPD_IN : 0; it->failsP = (int16_t)fails;
     it->hPassed = hPassed; it->hRpr = hRpr; it->distance = distance; it->lastLK = lastLK; it->pathBest = pathBest;
     it->child0 = it->child1 = FR_NONE; it->hA = it->hB = it->hMid = -1; it->next = FR_NONE; it->failsA = 0;
-    it->midProb = lastLK; it->recDist = 0.0;
+    it->midProb = lastLK; it->recDist = 0.0; it->size = 1; it->pos = -1;
     return ref;
 }
 
@@ -319,7 +335,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
     }
 }
 
-__global__ void k_fr_snap(FCtr *ctr, long long capU, long long capC)
+__global__ void k_fr_snap(FCtr *ctr, long long capU, long long capC, unsigned long long *lvl, int maxLevels)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         // (a pool that overflowed keeps counting what was asked of it: the items themselves end at its capacity)
@@ -327,6 +343,10 @@ __global__ void k_fr_snap(FCtr *ctr, long long capU, long long capC)
         ctr->loC = ctr->hiC; ctr->hiC = min(ctr->usedC, (unsigned long long)capC);
         ctr->bigUsed = 0;
         ctr->permDown = ctr->permUp = ctr->permDownB = ctr->permUpB = 0;
+        if (lvl) {
+            const int l = ctr->nLevels++;
+            if (l < maxLevels) { lvl[4 * l] = ctr->loU; lvl[4 * l + 1] = ctr->hiU; lvl[4 * l + 2] = ctr->loC; lvl[4 * l + 3] = ctr->hiC; }
+        }
     }
 }
 
@@ -955,6 +975,79 @@ void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Sear
 }
 
 // ---- the reference's own walk over the expanded items: "while nodesToVisit", M:6964-7434, with the real running best ------
+// ---- the visiting-order layout ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fsize(const FPools &fp, int ref) { return ref == FR_NONE ? 0 : item_of(fp, ref).size; }
+
+// subtree sizes, one level at a time from the last to the first (a child is one level below its parent)
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_sizes(FPools fp, int level)
+{
+    const long long loU = (long long)fp.lvl[4 * level], hiU = (long long)fp.lvl[4 * level + 1];
+    const long long loC = (long long)fp.lvl[4 * level + 2], hiC = (long long)fp.lvl[4 * level + 3];
+    const long long n = (hiU - loU) + (hiC - loC);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        FItem &it = i < hiU - loU ? fp.U[loU + i] : fp.C[loC + (i - (hiU - loU))];
+        it.size = 1 + fsize(fp, it.child0) + fsize(fp, it.child1);
+    }
+}
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_totals(int n, FPools fp)
+{
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        const FSearch &S = fp.S[q];
+        fp.tot[q] = S.state == FS_ACTIVE ? fsize(fp, S.seed0) + fsize(fp, S.seed1) : 0;
+    }
+}
+// exclusive prefix sums of n counts by ONE workgroup: out[0 .. n], out[n] = the total
+__global__ __launch_bounds__(1024) void k_fr_layout_scan(int n, const int32_t *in, long long *out)
+{
+    __shared__ long long part[1024];
+    const int t = threadIdx.x, per = (n + 1023) / 1024;
+    const int lo = min(n, t * per), hi = min(n, lo + per);
+    long long s = 0;
+    for (int i = lo; i < hi; i++) s += in[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        long long run = 0;
+        for (int i = 0; i < 1024; i++) { const long long v = part[i]; part[i] = run; run += v; }
+        out[n] = run;
+    }
+    __syncthreads();
+    long long run = part[t];
+    for (int i = lo; i < hi; i++) { out[i] = run; run += in[i]; }
+}
+// the seeds' ranks (the one pushed last, seed1, is visited first)
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_seeds(int n, FPools fp)
+{
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        const FSearch &S = fp.S[q];
+        if (S.state != FS_ACTIVE || fp.vbase[q + 1] > fp.capVisit) continue;
+        long long p = fp.vbase[q];
+        if (S.seed1 != FR_NONE) { FItem &x = item_of(fp, S.seed1); x.pos = (int32_t)p; x.next = -1; p += x.size; }
+        if (S.seed0 != FR_NONE) { FItem &x = item_of(fp, S.seed0); x.pos = (int32_t)p; x.next = -1; }
+    }
+}
+// ranks of the children and the item's own record, one level at a time from the first to the last
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_place(FPools fp, int level)
+{
+    const long long loU = (long long)fp.lvl[4 * level], hiU = (long long)fp.lvl[4 * level + 1];
+    const long long loC = (long long)fp.lvl[4 * level + 2], hiC = (long long)fp.lvl[4 * level + 3];
+    const long long n = (hiU - loU) + (hiC - loC);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const bool isU = i < hiU - loU;
+        const long long at = isU ? loU + i : loC + (i - (hiU - loU));
+        FItem &it = isU ? fp.U[at] : fp.C[at];
+        const int p = it.pos;
+        if (p < 0) continue;                                                // (its search is not laid out)
+        FVisit v;
+        v.midProb = it.midProb; v.lastLK = it.lastLK; v.ref = isU ? -((int)at + 2) : (int)at; v.size = it.size;
+        v.parent = it.next; v.flags = it.flags; v.dir = it.dir; v.failsOut = 0;
+        fp.visit[p] = v;
+        int q = p + 1;
+        if (it.child1 != FR_NONE) { FItem &x = item_of(fp, it.child1); x.pos = q; x.next = p; q += x.size; }
+        if (it.child0 != FR_NONE) { FItem &x = item_of(fp, it.child0); x.pos = q; x.next = p; }
+    }
+}
+
 __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, FPools fp, SearchOut *out)
 {
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
@@ -962,6 +1055,36 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
         if (S.state == FS_OVER) { out[q].status = -5; continue; }
         if (S.state == FS_FALLBACK) { out[q].status = FR_STATUS_FALLBACK; continue; }
         if (S.state != FS_ACTIVE) continue;
+        double best = S.curLK;
+        int nApp = 0, slHead = FR_NONE, slTail = FR_NONE;
+        if (fp.visit && fp.vbase[q + 1] <= fp.capVisit) {
+            // the same walk as a forward scan over the search's items in visiting order
+            const long long end = fp.vbase[q + 1];
+            long long i = fp.vbase[q];
+            while (i < end) {
+                FVisit &rec = fp.visit[i];
+                const int size = rec.size;
+                if (rec.flags & FI_DEAD) { i += size; continue; }
+                int fails = rec.parent < 0 ? 0 : fp.visit[rec.parent].failsOut;
+                const double mp = rec.midProb;
+                if (rec.flags & FI_SCORED) {
+                    nApp++;
+                    const bool list = (rec.dir == 0) ? (mp > best - P.thrOptTopo) : (mp >= best - P.thrOptTopo);   // M:7071 / 7293
+                    if (list) {
+                        const int ref = rec.ref;
+                        item_of(fp, ref).next = FR_NONE;
+                        if (slTail == FR_NONE) slHead = ref; else item_of(fp, slTail).next = ref;
+                        slTail = ref;
+                    }
+                    if (mp > best) { best = mp; fails = 0; }
+                    else if (mp < (rec.lastLK - P.thrConsec)) fails++;
+                }
+                const bool within = mp > (best - P.thrLKtopology);
+                const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);
+                rec.failsOut = (int16_t)fails;
+                i += go ? 1 : size;
+            }
+        } else {
         int top = FR_NONE;
         auto push = [&](int ref, int fails) {
             if (ref == FR_NONE) return;
@@ -970,8 +1093,6 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
         };
         push(S.seed0, 0);
         push(S.seed1, 0);
-        double best = S.curLK;
-        int nApp = 0, slHead = FR_NONE, slTail = FR_NONE;
         while (top != FR_NONE) {
             const int ref = top;
             FItem &it = item_of(fp, ref);
@@ -995,6 +1116,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
             if (!go) continue;
             push(it.child0, fails);
             push(it.child1, fails);
+        }
         }
         S.slHead = slHead; S.nApp = nApp;
         // the short-listed branches that are refined (M:7465: within thresholdLogLKoptimizationTopology of the ORIGINAL cost)
@@ -1304,7 +1426,10 @@ struct FrontierScratch {
     DevBuf<long long> toffW, toffA;
     DevBuf<int32_t> tn, tna, nodes, expQ, expNode;
     DevBuf<uint8_t> out, wideBr;
-    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2;
+    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, tot;
+    DevBuf<uint8_t> visit;
+    DevBuf<unsigned long long> lvl;
+    DevBuf<long long> vbase;
     long long lastU = -1, lastC = -1;     // items of the last call (for frontier_export), -1: none
     long long needU = 0, needC = 0, needL = 0, needW = 0, needA = 0, needM = 0;   // what the last call asked of the pools, and its searches
     FPools lastPools{};
@@ -1324,7 +1449,7 @@ void frontier_scratch_free(maple_ctx *c)
     F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
     F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
     F->expQ.release(); F->expNode.release();
-    F->perm.release(); F->perm2.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release();
+    F->perm.release(); F->perm2.release(); F->tot.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release();
     if (F->evFork) (void)hipEventDestroy(F->evFork);
     if (F->evJoin) (void)hipEventDestroy(F->evJoin);
     if (F->side) (void)hipStreamDestroy(F->side);
@@ -1380,7 +1505,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     const long long capBig = std::max<long long>(1 << 20, 64ll * 1024 * std::max(1, c->tree_max_ent));
     {   // shrink the pools proportionally if they would not fit
         const double fixed = (double)scratchLanes * capE * 64 + (double)capBig * 48;
-        const double need = (double)capC * sizeof(FItem) + (double)capU * sizeof(FItem) + (double)capW * 8 + (double)capA * 8
+        const double need = (double)capC * (sizeof(FItem) + sizeof(FVisit)) + (double)capU * (sizeof(FItem) + sizeof(FVisit)) + (double)capW * 8 + (double)capA * 8
                             + (double)capL * 24 + fixed;
         if (need > room) {
             const double f = std::max(0.05, (room - fixed) / (need - fixed));
@@ -1417,6 +1542,15 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, F.perm.reserve_exact(std::max(F.perm.cap, (size_t)fp.capU)));
     HIPCK(c, F.perm2.reserve_exact(std::max(F.perm2.cap, (size_t)fp.capU)));
     fp.perm = F.perm.p; fp.perm2 = F.perm2.p;
+    // the visiting-order layout of the items (k_fr_layout_*): one 32-byte record per item, the levels' ranges, per-search bases
+    fp.maxLevels = 4096;
+    fp.capVisit = fp.capU + fp.capC;
+    const bool layoutOK = m > 64 && fp.capVisit < (1ll << 31) - 64;       // (ranks are 32-bit; a handful of searches is not worth 90 launches)
+    if (layoutOK) HIPCK(c, F.visit.reserve_exact(std::max(F.visit.cap, (size_t)fp.capVisit * sizeof(FVisit))));
+    HIPCK(c, F.lvl.reserve((size_t)fp.maxLevels * 4));
+    HIPCK(c, F.tot.reserve((size_t)m));
+    HIPCK(c, F.vbase.reserve((size_t)m + 1));
+    fp.visit = layoutOK ? (FVisit *)F.visit.p : nullptr; fp.lvl = F.lvl.p; fp.tot = F.tot.p; fp.vbase = F.vbase.p;
     fp.sw = F.sw.p; fp.sa = F.sa.p; fp.sais = F.sais.p; fp.capE = capE;
     fp.bw = F.bw.p; fp.ba = F.ba.p; fp.capBig = (long long)F.bw.cap;
     fp.ctr = (FCtr *)F.ctr.p; fp.S = (FSearch *)F.srch.p; fp.recs = (FRec *)F.recs.p;
@@ -1514,10 +1648,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     };
     for (;;) {
         for (int g = 0; g < 8; g++) {
-            k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC);
+            k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC, fp.lvl, fp.maxLevels);
             TRY(level());
         }
-        k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC);
+        k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC, fp.lvl, fp.maxLevels);
         HIPCK(c, hipGetLastError());
         HIPCK(c, hipMemcpyAsync(&hc, fp.ctr, sizeof(FCtr), hipMemcpyDeviceToHost, s));
         HIPCK(c, hipStreamSynchronize(s));
@@ -1547,6 +1681,16 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     }
     TRY(maple_internal_ev_pair(c, &er0, &er1, MAPLE_K_FR_REPLAY, (double)m, 0.0));
     HIPCK(c, hipEventRecord(er0, s));
+    if (levels <= fp.maxLevels && fp.visit) {
+        // the items of every search in the order its walk visits them: sizes bottom-up, ranks top-down, one record each
+        for (int l = levels - 1; l >= 0; l--) k_fr_layout_sizes<<<1024, FR_BLOCK, 0, s>>>(fp, l);
+        k_fr_layout_totals<<<gridN, FR_BLOCK, 0, s>>>(m, fp);
+        k_fr_layout_scan<<<1, 1024, 0, s>>>(m, fp.tot, fp.vbase);
+        k_fr_layout_seeds<<<gridN, FR_BLOCK, 0, s>>>(m, fp);
+        for (int l = 0; l < levels; l++) k_fr_layout_place<<<1024, FR_BLOCK, 0, s>>>(fp, l);
+        HIPCK(c, hipGetLastError());
+        TRY(stage("k_fr_layout"));
+    } else fp.visit = nullptr;
     k_fr_replay<<<gridN, FR_BLOCK, 0, s>>>(P, m, fp, dout);
     TRY(stage("k_fr_replay"));
     if (anyWide) HIPCK(c, hipStreamWaitEvent(s, F.evJoin, 0));
