@@ -12,7 +12,7 @@ import sys
 
 name, out = sys.argv[1], sys.argv[2]
 extra = sys.argv[3] if len(sys.argv) > 3 else ""
-KERNELS = ("k_fr_cached", "k_fr_replay_wide", "k_fr_sort_level", "k_wit_score", "k_wit_pairs", "k_wit_hist", "k_fr_updating_wave", "k_fr_updating", "k_fr_replay", "k_fr_refine", "k_fr_begin", "k_append_queries_lds",
+KERNELS = ("k_fr_cached", "k_fr_replay_wide", "k_fr_layout_sizes", "k_fr_layout_place", "k_fr_sort_level", "k_wit_score", "k_wit_pairs", "k_wit_hist", "k_fr_updating_wave", "k_fr_updating", "k_fr_replay", "k_fr_refine", "k_fr_begin", "k_append_queries_lds",
            "k_append_queries", "k_spr_search_assisted", "k_spr_search", "k_finite_prefix")
 
 
