@@ -76,7 +76,7 @@ struct alignas(32) FItem {
     // out (written by the item's own lane)
     int32_t hA, hB, hMid;              // short-list record of an item that was still updating (M:7073 / 7295)
     double recDist;
-    int32_t size, pos;                 // items in the subtree the item heads, and its place in its search's visiting order (layout)
+    int32_t pad2[2];
 };
 static_assert(sizeof(FItem) == 96, "FItem");
 
@@ -138,6 +138,8 @@ struct FPools {
     int32_t *tn, *tna;
     long long capW, capA, capL;
     FVisit *visit; long long capVisit;   // the layout of k_fr_layout_* (null: k_fr_replay chases the items)
+    int32_t *lsize, *lpos, *lpar;      // per item (updating pool first, then the cached pool): items in the subtree it heads, its
+                                       // rank in its search's visiting order (-1: not laid out), the rank of the item that pushed it
     unsigned long long *lvl;           // [maxLevels][4]: loU, hiU, loC, hiC of every level
     int32_t maxLevels;
     int32_t *tot; long long *vbase;    // per search: items in its two seed subtrees, and where its visiting order starts
@@ -270,7 +272,7 @@ __device__ inline int fpush(const FPools &fp, const int budget, const int q, con
     it->q = q; it->t1 = t1; it->dir = (int8_t)dir; it->flags = upd ? FI_UPD_IN : 0; it->failsP = (int16_t)fails;
     it->hPassed = hPassed; it->hRpr = hRpr; it->distance = distance; it->lastLK = lastLK; it->pathBest = pathBest;
     it->child0 = it->child1 = FR_NONE; it->hA = it->hB = it->hMid = -1; it->next = FR_NONE; it->failsA = 0;
-    it->midProb = lastLK; it->recDist = 0.0; it->size = 1; it->pos = -1;
+    it->midProb = lastLK; it->recDist = 0.0;
     return ref;
 }
 
@@ -976,17 +978,21 @@ void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Sear
 
 // ---- the reference's own walk over the expanded items: "while nodesToVisit", M:6964-7434, with the real running best ------
 // ---- the visiting-order layout ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int fsize(const FPools &fp, int ref) { return ref == FR_NONE ? 0 : item_of(fp, ref).size; }
+__device__ __forceinline__ long long fidx(const FPools &fp, int ref) { return ref >= 0 ? fp.capU + ref : -(long long)(ref + 2); }
+__device__ __forceinline__ int fsize(const FPools &fp, int ref) { return ref == FR_NONE ? 0 : fp.lsize[fidx(fp, ref)]; }
 
 // subtree sizes, one level at a time from the last to the first (a child is one level below its parent)
+// (sizes, ranks and parents live in arrays of their own: the passes read one 32-byte sector of an item and 4-byte neighbours)
 __global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_sizes(FPools fp, int level)
 {
     const long long loU = (long long)fp.lvl[4 * level], hiU = (long long)fp.lvl[4 * level + 1];
     const long long loC = (long long)fp.lvl[4 * level + 2], hiC = (long long)fp.lvl[4 * level + 3];
     const long long n = (hiU - loU) + (hiC - loC);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        FItem &it = i < hiU - loU ? fp.U[loU + i] : fp.C[loC + (i - (hiU - loU))];
-        it.size = 1 + fsize(fp, it.child0) + fsize(fp, it.child1);
+        const bool isU = i < hiU - loU;
+        const long long at = isU ? loU + i : loC + (i - (hiU - loU));
+        const FItem &it = isU ? fp.U[at] : fp.C[at];
+        fp.lsize[isU ? at : fp.capU + at] = 1 + fsize(fp, it.child0) + fsize(fp, it.child1);
     }
 }
 __global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_totals(int n, FPools fp)
@@ -1022,8 +1028,8 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_seeds(int n, FPools fp)
         const FSearch &S = fp.S[q];
         if (S.state != FS_ACTIVE || fp.vbase[q + 1] > fp.capVisit) continue;
         long long p = fp.vbase[q];
-        if (S.seed1 != FR_NONE) { FItem &x = item_of(fp, S.seed1); x.pos = (int32_t)p; x.next = -1; p += x.size; }
-        if (S.seed0 != FR_NONE) { FItem &x = item_of(fp, S.seed0); x.pos = (int32_t)p; x.next = -1; }
+        if (S.seed1 != FR_NONE) { const long long x = fidx(fp, S.seed1); fp.lpos[x] = (int32_t)p; fp.lpar[x] = -1; p += fp.lsize[x]; }
+        if (S.seed0 != FR_NONE) { const long long x = fidx(fp, S.seed0); fp.lpos[x] = (int32_t)p; fp.lpar[x] = -1; }
     }
 }
 // ranks of the children and the item's own record, one level at a time from the first to the last
@@ -1035,16 +1041,17 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_place(FPools fp, int lev
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const bool isU = i < hiU - loU;
         const long long at = isU ? loU + i : loC + (i - (hiU - loU));
-        FItem &it = isU ? fp.U[at] : fp.C[at];
-        const int p = it.pos;
+        const long long own = isU ? at : fp.capU + at;
+        const int p = fp.lpos[own];
         if (p < 0) continue;                                                // (its search is not laid out)
+        const FItem &it = isU ? fp.U[at] : fp.C[at];
         FVisit v;
-        v.midProb = it.midProb; v.lastLK = it.lastLK; v.ref = isU ? -((int)at + 2) : (int)at; v.size = it.size;
-        v.parent = it.next; v.flags = it.flags; v.dir = it.dir; v.failsOut = 0;
+        v.midProb = it.midProb; v.lastLK = it.lastLK; v.ref = isU ? -((int)at + 2) : (int)at; v.size = fp.lsize[own];
+        v.parent = fp.lpar[own]; v.flags = it.flags; v.dir = it.dir; v.failsOut = 0;
         fp.visit[p] = v;
         int q = p + 1;
-        if (it.child1 != FR_NONE) { FItem &x = item_of(fp, it.child1); x.pos = q; x.next = p; q += x.size; }
-        if (it.child0 != FR_NONE) { FItem &x = item_of(fp, it.child0); x.pos = q; x.next = p; }
+        if (it.child1 != FR_NONE) { const long long x = fidx(fp, it.child1); fp.lpos[x] = q; fp.lpar[x] = p; q += fp.lsize[x]; }
+        if (it.child0 != FR_NONE) { const long long x = fidx(fp, it.child0); fp.lpos[x] = q; fp.lpar[x] = p; }
     }
 }
 
@@ -1426,7 +1433,7 @@ struct FrontierScratch {
     DevBuf<long long> toffW, toffA;
     DevBuf<int32_t> tn, tna, nodes, expQ, expNode;
     DevBuf<uint8_t> out, wideBr;
-    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, tot;
+    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, tot, lsize, lpos, lpar;
     DevBuf<uint8_t> visit;
     DevBuf<unsigned long long> lvl;
     DevBuf<long long> vbase;
@@ -1449,7 +1456,7 @@ void frontier_scratch_free(maple_ctx *c)
     F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
     F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
     F->expQ.release(); F->expNode.release();
-    F->perm.release(); F->perm2.release(); F->tot.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release();
+    F->perm.release(); F->perm2.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release();
     if (F->evFork) (void)hipEventDestroy(F->evFork);
     if (F->evJoin) (void)hipEventDestroy(F->evJoin);
     if (F->side) (void)hipStreamDestroy(F->side);
@@ -1505,7 +1512,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     const long long capBig = std::max<long long>(1 << 20, 64ll * 1024 * std::max(1, c->tree_max_ent));
     {   // shrink the pools proportionally if they would not fit
         const double fixed = (double)scratchLanes * capE * 64 + (double)capBig * 48;
-        const double need = (double)capC * (sizeof(FItem) + sizeof(FVisit)) + (double)capU * (sizeof(FItem) + sizeof(FVisit)) + (double)capW * 8 + (double)capA * 8
+        const double need = (double)capC * (sizeof(FItem) + sizeof(FVisit) + 12) + (double)capU * (sizeof(FItem) + sizeof(FVisit) + 12) + (double)capW * 8 + (double)capA * 8
                             + (double)capL * 24 + fixed;
         if (need > room) {
             const double f = std::max(0.05, (room - fixed) / (need - fixed));
@@ -1546,7 +1553,13 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     fp.maxLevels = 4096;
     fp.capVisit = fp.capU + fp.capC;
     const bool layoutOK = m > 64 && fp.capVisit < (1ll << 31) - 64;       // (ranks are 32-bit; a handful of searches is not worth 90 launches)
-    if (layoutOK) HIPCK(c, F.visit.reserve_exact(std::max(F.visit.cap, (size_t)fp.capVisit * sizeof(FVisit))));
+    if (layoutOK) {
+        HIPCK(c, F.visit.reserve_exact(std::max(F.visit.cap, (size_t)fp.capVisit * sizeof(FVisit))));
+        HIPCK(c, F.lsize.reserve_exact(std::max(F.lsize.cap, (size_t)fp.capVisit)));
+        HIPCK(c, F.lpos.reserve_exact(std::max(F.lpos.cap, (size_t)fp.capVisit)));
+        HIPCK(c, F.lpar.reserve_exact(std::max(F.lpar.cap, (size_t)fp.capVisit)));
+    }
+    fp.lsize = F.lsize.p; fp.lpos = F.lpos.p; fp.lpar = F.lpar.p;
     HIPCK(c, F.lvl.reserve((size_t)fp.maxLevels * 4));
     HIPCK(c, F.tot.reserve((size_t)m));
     HIPCK(c, F.vbase.reserve((size_t)m + 1));
@@ -1683,6 +1696,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, hipEventRecord(er0, s));
     if (levels <= fp.maxLevels && fp.visit) {
         // the items of every search in the order its walk visits them: sizes bottom-up, ranks top-down, one record each
+        HIPCK(c, hipMemsetAsync(fp.lpos, 0xFF, (size_t)fp.capVisit * sizeof(int32_t), s));   // (-1: not laid out)
         for (int l = levels - 1; l >= 0; l--) k_fr_layout_sizes<<<1024, FR_BLOCK, 0, s>>>(fp, l);
         k_fr_layout_totals<<<gridN, FR_BLOCK, 0, s>>>(m, fp);
         k_fr_layout_scan<<<1, 1024, 0, s>>>(m, fp.tot, fp.vbase);
