@@ -3310,7 +3310,10 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     if (patchedOnly) wideBudget = -1;                                   // (no tree-sized table is current)
     // (a long search costs the wave-assisted lane tier a tenth of what it cost one lane: twice the budget pays -- 100 000 tips:
     // 2 132 / 3 072 / 4 096 / 6 144 -> 693 / 688 / 668 / 692 ms per round; 10 000 tips: 256 / 384 / 512 -> 75 / 72 / 72)
-    if (sp->wideSearchBudget == 0 && !c->dm.usingErrorRate) wideBudget *= 2;
+    // (with an error model too, since the frontier tier: 100 000 tips, budget 2 132 / 3 000 / 4 264 / 8 528 -> 532 / 447 / 420 / 441 ms
+    // per round -- the searches between 2 000 and 4 000 items are the ones with the longest removed lists, which the dense kernel
+    // walks slowest: 28 116 rows take it 260 ms, 25 785 rows 114)
+    if (sp->wideSearchBudget == 0) wideBudget *= 2;
     const bool hybrid = wideBudget > 0;
     if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !c->tuning.noCladeScan) TRY(build_scan_tables(c, P));
     // rows of the score table come with the bitmap of their finite scores (FiniteRows) when the tables that go with it exist
