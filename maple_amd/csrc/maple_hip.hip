@@ -3313,7 +3313,9 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // (with an error model too, since the frontier tier: 100 000 tips, budget 2 132 / 3 000 / 4 264 / 8 528 -> 532 / 447 / 420 / 441 ms
     // per round -- the searches between 2 000 and 4 000 items are the ones with the longest removed lists, which the dense kernel
     // walks slowest: 28 116 rows take it 260 ms, 25 785 rows 114)
-    if (sp->wideSearchBudget == 0) wideBudget *= 2;
+    // (1 000 000 tips, 8 192 / 16 384: 2.32 / 2.73 s per 131 072 searches -- the pools of the longer searches are reallocated on
+    // the way: with an error model the doubling stops at 8 192)
+    if (sp->wideSearchBudget == 0) wideBudget = c->dm.usingErrorRate ? std::min(2 * wideBudget, std::max(wideBudget, 8192)) : 2 * wideBudget;
     const bool hybrid = wideBudget > 0;
     if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !c->tuning.noCladeScan) TRY(build_scan_tables(c, P));
     // rows of the score table come with the bitmap of their finite scores (FiniteRows) when the tables that go with it exist
