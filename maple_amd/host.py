@@ -116,3 +116,80 @@ def tip_genome_list(diffs, ref_idx, *, only_n_ambiguities=False, error_rate=None
     if pos <= l_ref:
         out.append((4, l_ref))
     return out
+
+
+_CODE_STATES = np.zeros((256, 4), dtype=np.float64)
+for _ch, _v in AMBIGUITY.items():
+    _CODE_STATES[ord(_ch)] = _v
+
+
+def tip_lists_packed(off, code, pos, length, ref_idx, *, error_rates=None, error_rate=None):
+    """tip_genome_list for MANY samples at once, straight into the packed form (genome_list.PackedLists): the samples'
+    MAPLE entries as flat arrays (``off[n + 1]``, ``code`` = the entry's character, ``pos`` 1-based, ``length`` = 1 or the
+    length of an n / - run) -- what synth.DiffCSR holds.  The same lists as ``pack_lists([tip_genome_list(d, ref_idx, ...)])``
+    (tests/test_abi_and_host.py), without a Python object per entry."""
+    from .genome_list import PackedLists
+    off = np.asarray(off, dtype=np.int64)
+    code = np.asarray(code, dtype=np.uint8)
+    pos = np.asarray(pos, dtype=np.int64)
+    length = np.asarray(length, dtype=np.int64)
+    l_ref = len(ref_idx)
+    n, nd = len(off) - 1, len(code)
+    cnt = np.diff(off)
+    has = cnt > 0
+    first = off[:-1][has]                                            # the first entry of every sample that has one
+    sample = np.repeat(np.arange(n, dtype=np.int64), cnt)
+    is_n = (code == ord("n")) | (code == ord("-"))
+    nuc = np.full(nd, 255, dtype=np.uint32)
+    for ch, k in NUC_INDEX.items():
+        nuc[code == ord(ch)] = k
+    is_nuc = nuc < 4
+    is_o = ~is_n & ~is_nuc
+    if is_o.any() and (_CODE_STATES[code[is_o]].sum(axis=1) == 0).any():
+        raise ValueError("unknown character in a MAPLE entry")
+    end = np.where(is_n, pos + length - 1, pos)                     # last position the entry covers
+    prev_end = np.zeros(nd, dtype=np.int64)
+    prev_end[1:] = end[:-1]
+    prev_end[first] = 0
+    pre_r = pos > prev_end + 1                                       # a reference run before the entry (M:3894-3896)
+    last_end = np.zeros(n, dtype=np.int64)
+    last_end[has] = end[off[1:][has] - 1]
+    tail_r = last_end < l_ref                                        # ... and after the sample's last entry (M:3940-3941)
+    per_diff = pre_r.astype(np.int64) + 1
+    ent_cnt = np.bincount(sample, weights=per_diff, minlength=n).astype(np.int64) + tail_r
+    ent_off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(ent_cnt, out=ent_off[1:])
+
+    def within(x):
+        """exclusive running sum of x inside every sample"""
+        c = np.cumsum(x) - x
+        return c - np.repeat(c[first], cnt[has])
+    at = ent_off[sample] + within(per_diff) + pre_r                  # where the entry itself goes
+    # aux stream: four doubles per O entry; every entry's word carries the running offset (as pack_lists stores it)
+    o_idx = np.nonzero(is_o)[0]
+    n_o = np.bincount(sample[o_idx], minlength=n).astype(np.int64)
+    aux_off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(4 * n_o, out=aux_off[1:])
+    auxoff = (4 * within(is_o.astype(np.int64))).astype(np.uint32) << 8
+    r = ref_idx[np.clip(pos - 1, 0, l_ref - 1)].astype(np.uint32)
+    same = is_nuc & (nuc == r)                                       # an explicit nucleotide equal to the reference: an R entry
+    meta = np.where(is_n, 5, np.where(is_o, 6 | (r << 3), np.where(same, 4, (nuc & 3) | (r << 3)))).astype(np.uint32)
+    out_pos = np.zeros(int(ent_off[-1]), dtype=np.int32)
+    out_meta = np.zeros(int(ent_off[-1]), dtype=np.uint32)
+    out_pos[at] = end
+    out_meta[at] = meta | auxoff
+    pr = np.nonzero(pre_r)[0]
+    out_pos[at[pr] - 1] = pos[pr] - 1
+    out_meta[at[pr] - 1] = 4 | auxoff[pr]
+    tl = np.nonzero(tail_r)[0]
+    out_pos[ent_off[1:][tl] - 1] = l_ref
+    out_meta[ent_off[1:][tl] - 1] = 4 | ((4 * n_o[tl]).astype(np.uint32) << 8)
+    vec = _CODE_STATES[code[o_idx]].copy()
+    if error_rates is not None or error_rate is not None:            # the error model smears the ambiguity vectors, M:3921-3937
+        e = (np.asarray(error_rates, dtype=np.float64)[pos[o_idx] - 1] if error_rates is not None
+             else np.full(len(o_idx), float(error_rate)))
+        ns = (vec != 0).sum(axis=1)[:, None]
+        e3 = (e * 0.33333)[:, None]
+        vec = np.where(ns == 2, np.where(vec == 0, e3, vec - e3),
+                       np.where(ns == 3, np.where(vec == 0, e3, vec - (e / 9)[:, None]), vec))
+    return PackedLists(ent_off, out_pos, out_meta, aux_off, vec.reshape(-1))

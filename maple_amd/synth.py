@@ -221,3 +221,97 @@ def write_maple(data: SynthData, path: str) -> None:
                     fh.write(f"{e[0]}\t{e[1]}\t{e[2]}\n")
                 else:
                     fh.write(f"{e[0]}\t{e[1]}\n")
+
+
+# ---- "synth v2": the same model generated by csrc/synth_gen.c (seconds instead of minutes at 1 000 000 samples) --------------
+class DiffCSR:
+    """The samples' MAPLE entries as three flat arrays + offsets; indexing gives the tuple form make_dataset returns."""
+
+    def __init__(self, off, code, pos, length):
+        self.off, self.code, self.pos, self.length = off, code, pos, length
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        lo, hi = int(self.off[i]), int(self.off[i + 1])
+        out = []
+        for c, p, ln in zip(self.code[lo:hi].tolist(), self.pos[lo:hi].tolist(), self.length[lo:hi].tolist()):
+            ch = chr(c)
+            out.append((ch, p, ln) if ch == "n" else (ch, p))
+        return out
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+_synth_lib = None
+
+
+def _load_synth_lib():
+    global _synth_lib
+    if _synth_lib is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmaple_synth.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(path)
+
+        class S(C.Structure):
+            _fields_ = [("n_samples", C.c_int64), ("n_nodes", C.c_int64), ("l_ref", C.c_int64), ("n_diffs", C.c_int64),
+                        ("ref", C.POINTER(C.c_int8)), ("parent", C.POINTER(C.c_int64)), ("blen", C.POINTER(C.c_double)),
+                        ("tip_node", C.POINTER(C.c_int64)), ("diff_off", C.POINTER(C.c_int64)),
+                        ("diff_code", C.POINTER(C.c_uint8)), ("diff_pos", C.POINTER(C.c_int32)),
+                        ("diff_len", C.POINTER(C.c_int32)), ("mean_depth", C.c_double), ("per_branch", C.c_double)]
+        lib.maple_synth_generate.restype = C.POINTER(S)
+        lib.maple_synth_generate.argtypes = [C.c_int64, C.c_int64, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_double]
+        lib.maple_synth_free.argtypes = [C.POINTER(S)]
+        lib.maple_synth_free.restype = None
+        _synth_lib = lib
+    return _synth_lib
+
+
+def make_dataset_native(n_samples: int, l_ref: int = 29903, seed: int = 1, mean_diffs: float = 30.0,
+                        rate_variation: bool = False, frac_with_n: float = 0.01, n_run_len=(50, 500),
+                        frac_ambig: float = 0.01, zero_branch_frac: float = 0.15) -> SynthData:
+    """make_dataset's model (same tree process, substitution process, ambiguities and missing-data runs) from the C generator:
+    ``diffs`` is a DiffCSR (``.off/.code/.pos/.length``), everything else as in make_dataset.  Its own seeded stream: the
+    data differ from make_dataset's for the same seed."""
+    lib = _load_synth_lib()
+    site_rates = None
+    site_cdf = None
+    if rate_variation:
+        site_rates = np.clip(np.random.default_rng(seed).gamma(0.5, 2.0, size=l_ref), 0.001, 0.005 * l_ref)
+        site_cdf = np.ascontiguousarray(np.cumsum(site_rates / site_rates.sum()))
+        site_cdf[-1] = 2.0
+    freqs_cdf = np.ascontiguousarray(np.cumsum(SARS2_FREQS / SARS2_FREQS.sum()))
+    exitp = SARS2_Q.copy()
+    np.fill_diagonal(exitp, 0.0)
+    exit_cdf = np.ascontiguousarray(np.cumsum(exitp / exitp.sum(axis=1, keepdims=True), axis=1))
+    exit_cdf[:, 3] = 2.0
+    ptr = lambda a: None if a is None else a.ctypes.data  # noqa: E731
+    h = lib.maple_synth_generate(n_samples, l_ref, seed, mean_diffs, ptr(site_cdf), ptr(freqs_cdf), ptr(exit_cdf),
+                                 frac_with_n, int(n_run_len[0]), int(n_run_len[1]), frac_ambig, zero_branch_frac)
+    if not h:
+        raise MemoryError("maple_synth_generate failed")
+    try:
+        s = h.contents
+        n, nn, nd = int(s.n_samples), int(s.n_nodes), int(s.n_diffs)
+        arr = lambda p, k: np.ctypeslib.as_array(p, shape=(max(1, k),))[:k].copy()  # noqa: E731
+        ref = arr(s.ref, l_ref)
+        parent, blen, tip_node = arr(s.parent, nn), arr(s.blen, nn), arr(s.tip_node, n)
+        diffs = DiffCSR(arr(s.diff_off, n + 1), arr(s.diff_code, nd), arr(s.diff_pos, nd), arr(s.diff_len, nd))
+        meta = dict(n_samples=n_samples, l_ref=l_ref, seed=seed, mean_diffs=mean_diffs, per_branch=float(s.per_branch),
+                    rate_variation=rate_variation, generator="synth v2 (csrc/synth_gen.c)")
+    finally:
+        lib.maple_synth_free(h)
+    ref_s = np.frombuffer(b"acgt", dtype=np.uint8)[ref].tobytes().decode()
+    names = [f"S{i:07d}" for i in range(n)]
+    return SynthData(ref=ref_s, names=names, diffs=diffs, parent=parent, blen=blen, tip_node=tip_node,
+                     site_rates=site_rates, meta=meta)

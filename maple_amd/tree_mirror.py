@@ -17,33 +17,47 @@ from .runtime import Device
 
 
 class TreeMirror:
-    def __init__(self, dev: Device, parent, blen, tip_lists):
-        """parent[n] (-1 root, parents precede children), blen[n], tip_lists: {node: tuple-form list}."""
+    def __init__(self, dev: Device, parent, blen, tip_lists=None, *, tip_packed=None):
+        """parent[n] (-1 root, parents precede children), blen[n]; the tips' lists either as ``tip_lists`` = {node: tuple-form
+        list} or as ``tip_packed`` = (nodes, PackedLists) (host.tip_lists_packed: no Python object per entry)."""
         self.dev = dev
         self.parent = np.asarray(parent, dtype=np.int64)
         self.dist = np.asarray(blen, dtype=np.float64)
         n = len(self.parent)
         self.n_nodes = n
+        # children in index order (child 0 = the smaller index); depths level by level (parents precede children)
         self.children = -np.ones((n, 2), dtype=np.int64)
-        for v in range(n):
-            p = self.parent[v]
-            if p >= 0:
-                k = 0 if self.children[p, 0] < 0 else 1
-                self.children[p, k] = v
+        kids = np.nonzero(self.parent >= 0)[0]
+        kids = kids[np.argsort(self.parent[kids], kind="stable")]
+        par = self.parent[kids]
+        firstk = np.ones(len(kids), dtype=bool)
+        firstk[1:] = par[1:] != par[:-1]
+        self.children[par[firstk], 0] = kids[firstk]
+        self.children[par[~firstk], 1] = kids[~firstk]
+        if (np.bincount(par, minlength=n) > 2).any():
+            raise ValueError("TreeMirror needs a binary tree")
         self.is_tip = self.children[:, 0] < 0
         self.root = int(np.nonzero(self.parent < 0)[0][0])
         depth = np.zeros(n, dtype=np.int64)
-        for v in range(n):
-            if self.parent[v] >= 0:
-                depth[v] = depth[self.parent[v]] + 1
+        level = np.asarray([self.root], dtype=np.int64)
+        d = 0
+        while len(level):
+            depth[level] = d
+            ch = self.children[level].reshape(-1)
+            level = ch[ch >= 0]
+            d += 1
         self.depth = depth
         self.lower = -np.ones(n, dtype=np.int32)
         self.up_right = -np.ones(n, dtype=np.int32)
         self.up_left = -np.ones(n, dtype=np.int32)
         self.tot_up = -np.ones(n, dtype=np.int32)
-        tips = sorted(tip_lists)
-        ids = dev.upload([tip_lists[t] for t in tips])
-        self.lower[np.asarray(tips, dtype=np.int64)] = ids
+        if tip_packed is not None:
+            nodes, pl = tip_packed
+            self.lower[np.asarray(nodes, dtype=np.int64)] = dev.upload_packed(pl)
+        else:
+            tips = sorted(tip_lists)
+            ids = dev.upload([tip_lists[t] for t in tips])
+            self.lower[np.asarray(tips, dtype=np.int64)] = ids
         self.launches = 0
 
     def build(self, max_restarts=64):

@@ -1070,3 +1070,34 @@ int omo_appendProbNode_batch(const OModel *m, const OEntry *all, const long long
     }
     return 0;
 }
+
+/* Lists in the HIP library's packed form (include/maple_hip.h: word = {pos, meta}, a per-list stream of doubles) as OEntry
+ * tuples -- what oracle_py.packed_to_entries does with numpy, for whole trees of 10^8 entries (a conversion, no arithmetic):
+ * meta = type | ref << 3 | hasD0 << 5 | hasD1 << 6 | flag << 7 | auxoff << 8; `len` = the Python tuple length (M:378-390). */
+int omo_entries_from_packed(long long nLists, const long long *entOff, const int *pos, const unsigned *meta,
+                            const long long *auxOff, const double *aux, int usingErrorRate, OEntry *out, int threads)
+{
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static, 4096)
+    for (long long l = 0; l < nLists; l++) {
+        const double *a = aux + auxOff[l];
+        for (long long k = entOff[l]; k < entOff[l + 1]; k++) {
+            const unsigned mt = meta[k];
+            const int type = (int)(mt & 7u), ref = (int)((mt >> 3) & 3u);
+            const int h0 = (int)((mt >> 5) & 1u), h1 = (int)((mt >> 6) & 1u), fl = (int)((mt >> 7) & 1u);
+            const double *q = a + (mt >> 8);
+            OEntry e;
+            e.type = type;
+            e.x = (type == 4 || type == 5) ? pos[k] : ref;
+            e.flag = usingErrorRate ? fl : 0;
+            e.d0 = h0 ? q[0] : 0.0;
+            e.d1 = h1 ? q[h0] : 0.0;
+            for (int j = 0; j < 4; j++) e.vec[j] = type == 6 ? q[h0 + h1 + j] : 0.0;
+            if (type == 6) e.len = 3 + h0;
+            else if (type == 5) e.len = 2;
+            else e.len = 2 + h0 + h1 + ((h0 + h1) > 0 && usingErrorRate ? 1 : 0);
+            out[k] = e;
+        }
+    }
+    return 0;
+}

@@ -135,6 +135,10 @@ int   omo_appendProbNode_batch(const OModel *m, const OEntry *all, const long lo
 int omo_appendProbNode_batch_mt(const OModel *m, const OEntry *all, const long long *off, int n, const int *pl,
                                 const int *cl, const unsigned char *tip, const double *bl, double *out, int threads);
 
+/* packed lists of the HIP library (include/maple_hip.h) -> OEntry tuples, for whole trees (a conversion, no arithmetic) */
+int omo_entries_from_packed(long long nLists, const long long *entOff, const int *pos, const unsigned *meta,
+                            const long long *auxOff, const double *aux, int usingErrorRate, OEntry *out, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,10 +112,9 @@ class OSearchResultC(C.Structure):
                 ("blen", C.c_double * 3), ("rpr", C.c_void_p), ("rprCap", C.c_int), ("rprN", C.c_int)]
 
 
-def packed_to_entries(pk, u):
+def packed_to_entries_numpy(pk, u):
     """Packed CSR lists (maple_amd.genome_list.PackedLists, e.g. Device.download_packed) -> one OENTRY array + CSR
-    offsets, vectorised (the per-entry Python loop of to_entries is too slow for whole trees)."""
-    n = len(pk.pos) if len(pk.ent_off) > 1 else 0
+    offsets, vectorised with numpy (kept as the check of the C conversion below)."""
     n = int(pk.ent_off[-1])
     pos = pk.pos[:n].astype(np.int64)
     meta = pk.meta[:n].astype(np.int64)
@@ -147,6 +146,20 @@ def packed_to_entries(pk, u):
     return arr, pk.ent_off.copy()
 
 
+def packed_to_entries(pk, u, threads=None):
+    """Packed CSR lists -> one OENTRY array + CSR offsets, by the oracle library's own converter (omo_entries_from_packed:
+    a whole 1 000 000-tip tree is 4 x 10^8 entries)."""
+    lib = C.CDLL(build())
+    n = int(pk.ent_off[-1])
+    arr = np.empty(max(1, n), dtype=OENTRY)[:n]
+    if threads is None:
+        threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 1))
+    lib.omo_entries_from_packed(C.c_longlong(len(pk.ent_off) - 1), _p(pk.ent_off), _p(pk.pos), _p(pk.meta), _p(pk.aux_off),
+                                _p(np.concatenate([pk.aux, np.zeros(8)]) if len(pk.aux) < 8 else pk.aux), int(bool(u)), _p(arr),
+                                int(threads))
+    return arr, pk.ent_off.copy()
+
+
 class OracleTree:
     """A frozen tree in the oracle's layout: topology + the four genome lists of every node (tuple form or None)."""
 
@@ -154,9 +167,14 @@ class OracleTree:
         u = oracle.u
         n = len(up)
         self.n = n
-        self.up = np.asarray([-1 if x is None else x for x in up], dtype=np.int32)
-        self.c0 = np.asarray([c[0] if c else -1 for c in children], dtype=np.int32)
-        self.c1 = np.asarray([c[1] if c else -1 for c in children], dtype=np.int32)
+        if isinstance(up, np.ndarray):                            # (numpy columns: up[n] with -1 at the root, children[n, 2] with -1)
+            self.up = np.ascontiguousarray(up, dtype=np.int32)
+            self.c0 = np.ascontiguousarray(children[:, 0], dtype=np.int32)
+            self.c1 = np.ascontiguousarray(children[:, 1], dtype=np.int32)
+        else:
+            self.up = np.asarray([-1 if x is None else x for x in up], dtype=np.int32)
+            self.c0 = np.asarray([c[0] if c else -1 for c in children], dtype=np.int32)
+            self.c1 = np.asarray([c[1] if c else -1 for c in children], dtype=np.int32)
         self.dist = np.asarray(dist, dtype=np.float64)
         self.nMinor = np.asarray(n_minor, dtype=np.int32)
         chunks, self.start, self.len = [], [], []
@@ -184,9 +202,10 @@ class OracleTree:
         self.ent = np.concatenate(chunks) if chunks else np.zeros(1, dtype=OENTRY)
         off = np.zeros(n + 1, dtype=np.int64)
         flat = []
-        for v in range(n):
-            flat.extend(mutations[v])
-            off[v + 1] = len(flat)
+        if mutations is not None:                                 # (None: a tree without MAT local references)
+            for v in range(n):
+                flat.extend(mutations[v])
+                off[v + 1] = len(flat)
         self.mut3 = np.ascontiguousarray(np.asarray(flat if flat else [[0, 0, 0]], dtype=np.int32).reshape(-1, 3))
         self.mutOff = off
         t = OTreeC()

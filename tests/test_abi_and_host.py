@@ -195,3 +195,42 @@ def test_committed_bench_line_follows_the_contract():
         assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * max(1.0, r["achieved"])
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_native_generator_and_packed_tip_lists_match_the_python_forms():
+    """The C generator of the big synthetic inputs (csrc/synth_gen.c, "synth v2") writes valid MAPLE entries (increasing,
+    non-overlapping, never equal to the reference), a binary tree whose parents precede their children, and is seeded; and
+    host.tip_lists_packed gives, for all samples at once, exactly pack_lists(tip_genome_list(...)) -- with and without the
+    error model's smearing of ambiguity vectors (M:3921-3937)."""
+    from maple_amd.genome_list import pack_lists
+    from maple_amd.host import reference_tables, tip_genome_list, tip_lists_packed
+    from maple_amd.synth import make_dataset_native
+    d = make_dataset_native(n_samples=3000, l_ref=29903, seed=7, mean_diffs=30.0, rate_variation=True, frac_with_n=0.3,
+                            frac_ambig=0.3)
+    d2 = make_dataset_native(n_samples=3000, l_ref=29903, seed=7, mean_diffs=30.0, rate_variation=True, frac_with_n=0.3,
+                             frac_ambig=0.3)
+    c = d.diffs
+    assert np.array_equal(c.pos, d2.diffs.pos) and np.array_equal(d.parent, d2.parent) and d.ref == d2.ref
+    n = len(d.parent)
+    assert n == 2 * 3000 - 1 and d.parent[0] == -1 and (d.parent[1:] < np.arange(1, n)).all()
+    assert (np.bincount(d.parent[1:], minlength=n) == np.where(np.isin(np.arange(n), d.tip_node), 0, 2)).all()
+    assert 20 < len(c.code) / 3000 < 45
+    seen_n = seen_o = 0
+    for i in range(len(c)):
+        last = 0
+        for m in c[i]:
+            assert m[1] > last, (i, m)
+            last = m[1] + (m[2] - 1 if len(m) > 2 else 0)
+            if m[0] in "acgt":
+                assert d.ref[m[1] - 1] != m[0]
+            seen_n += m[0] == "n"
+            seen_o += m[0] not in "acgtn"
+        assert last <= 29903
+    assert seen_n > 300 and seen_o > 300
+    ref_idx, _ = reference_tables(d.ref)
+    er = np.exp(np.random.default_rng(4).uniform(np.log(1e-10), np.log(1e-3), size=len(ref_idx)))
+    for kw in ({}, {"error_rates": er}, {"error_rate": 1e-4}):
+        got = tip_lists_packed(c.off, c.code, c.pos, c.length, ref_idx, **kw)
+        want = pack_lists([tip_genome_list(c[i], ref_idx, **kw) for i in range(len(c))], bool(kw))
+        for a in ("ent_off", "pos", "meta", "aux_off", "aux"):
+            assert np.array_equal(getattr(got, a), getattr(want, a)), (kw.keys(), a)

@@ -43,3 +43,22 @@ def test_oracle_spr_search_matches_reference(name):
             assert lists_match(out["removedPartials"][k], tup(want["bestRemovedPartials"]), 1e-9)
         got = sorted((nodes[k], int(out["placement"][k])) for k in range(len(nodes)) if out["placement"][k] >= 0)
         assert got == sorted((m[0], m[1]) for m in rnd["proposedMoves"])
+
+
+@pytest.mark.parametrize("name", NAMES[:3])
+def test_packed_lists_to_oracle_entries_c_equals_numpy(name):
+    """The oracle library's converter of packed lists (omo_entries_from_packed, used for whole trees of 10^8 entries) against
+    the numpy conversion and against to_entries() of the tuple form, on every list of a reference tree."""
+    import numpy as np
+    from maple_amd.genome_list import pack_lists
+    from oracle.oracle_py import packed_to_entries, packed_to_entries_numpy, to_entries
+    with gzip.open(os.path.join(GOLDEN, f"search_{name}.json.gz"), "rt") as fh:
+        f = json.load(fh)
+    t, u = f["tree"], bool(f["model"]["usingErrorRate"])
+    lists = [tup(gl) for kind in ("probVect", "probVectUpRight", "probVectUpLeft", "probVectTotUp") for gl in t[kind] if gl]
+    pk = pack_lists(lists, u)
+    a, off = packed_to_entries(pk, u, threads=3)
+    b, off2 = packed_to_entries_numpy(pk, u)
+    assert np.array_equal(off, off2) and a.tobytes() == b.tobytes()
+    want = np.concatenate([to_entries(gl, u) for gl in lists[:400]])
+    assert a[: len(want)].tobytes() == want.tobytes()
