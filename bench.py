@@ -347,7 +347,9 @@ def run_leg(args, env):
     # candidate placements this rank really WALKED (a candidate list against the removed list, entry by entry): those of the
     # searches the frontier / lane tiers finished, plus the (search, branch) pairs the witness filter or the dense kernel scored
     # for the whole-tree searches -- the rest of `value` are placements of whole-tree searches that are proved -inf and counted
-    walked_local = float(K["SPR_SEARCH"][2] + K["SPR_SCORE"][2])
+    # (the dense kernel scores EVERY branch for a search that went over its budget, the search then visits some of them: of
+    # those pairs, the ones that count are the placements the searches replayed)
+    walked_local = float(K["SPR_SEARCH"][2] + min(K["SPR_SCORE"][2], K["SPR_REPLAY"][2] + K["FR_WIDE"][2]))
     if distd is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cu)
         t = t if backend == "nccl" else t.cpu()

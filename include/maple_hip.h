@@ -257,6 +257,12 @@ int maple_spr_search_batch(maple_ctx *ctx, int32_t n, const int32_t *nodes, cons
  * references); *n pairs, MAPLE_ERR_ARG if they do not fit in cap. */
 int maple_spr_search_visited(maple_ctx *ctx, int64_t cap, int32_t *query, int32_t *node, int64_t *n);
 
+/* Profile of the last frontier-tier pass of maple_spr_search_batch (until the next maple_timing_reset): per level of the
+ * expansion, the items that still updated genome lists, the items in the cached regime, and the HIP-event time (ms) of the
+ * level's two kernels.  *n levels (the first min(*n, cap) are written).  A measurement aid; nothing is computed with it. */
+int maple_debug_frontier_levels(maple_ctx *ctx, int32_t cap, int64_t *itemsUpdating, int64_t *itemsCached, float *msUpdating,
+                                float *msCached, int32_t *n);
+
 typedef struct {
     double oneMutBLen;                          /* M:3606 */
     double effectivelyNon0BLen;                 /* M:3607 */

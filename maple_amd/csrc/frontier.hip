@@ -29,252 +29,11 @@
 // (rootVector, M:6916-6960 / 7406-7432), run out of scratch, or exceed the pools.  Searches that expand more than `budget`
 // items are whole-tree searches and go to the dense tier (status -5), as before.
 #include "ctx_host.h"
-#include "frontier.h"
-// (this translation unit's wavefront-wide walks serve the FEW items with the longest lists, one wavefront per compute unit:
-// staging areas for lists of 512 entries, 110 KB of LDS)
-#define MAPLE_WAVE_CAPW 512
-#define MAPLE_WU_IN 512
-#include "wave_dev.h"
-#include "wave_update.h"
+#include "frontier_dev.h"
 
-#include <algorithm>
-#include <cstring>
+using namespace frt;
 
 namespace {
-
-#define FR_BLOCK 256
-#ifndef FR_HEAVY_MULT
-#define FR_HEAVY_MULT 24               // (quarters of the mean list length: lists of this many entries together go one wavefront per item)
-#endif
-#ifndef FR_BIG_MIN
-#define FR_BIG_MIN 176
-#endif
-
-enum { FI_UPD_IN = 1, FI_UPD_OUT = 2, FI_SCORED = 4, FI_DEAD = 8, FI_REC_UPD = 16, FI_SEED = 32, FI_SEED_EMPTY = 64 };
-// FS_WIDE: a whole-tree search whose row of the dense score table is being made next to this tier.  Its items that still
-// update genome lists are expanded here like any other's (they are what made such a search slow for one lane: up to 200
-// updating steps in a row); an item that arrives in the cached regime on the way DOWN is left as a seed (FI_SEED) -- the clade
-// below it is scanned over the score row by k_fr_replay_wide (wave_scan_clade, search_dev.h) when the exact walk gets there.
-enum { FS_ACTIVE = 0, FS_FINAL = 1, FS_OVER = 2, FS_FALLBACK = 3, FS_WIDE = 4 };
-__device__ __forceinline__ bool fs_live(int st) { return st == FS_ACTIVE || st == FS_WIDE; }
-#define FR_NONE (-1)
-
-struct alignas(32) FItem {
-    // what the exact replay reads and writes per pop, in one 32-byte sector (the walk of the longest search is a chain of
-    // dependent misses on these)
-    int8_t dir;                        // 0 = moving from a parent to its child, 1 / 2 = crawling up from child 0 / 1
-    uint8_t flags;
-    int16_t failsA;                    // failedPasses the replay arrives with
-    int32_t next;                      // stack link, then short-list link
-    int32_t child0, child1;            // item refs in push order: >= 0 cached pool, <= -2 updating pool -(i + 2), -1 none
-    double midProb, lastLK;
-    // in (written by the parent item's lane)
-    int32_t q, t1;
-    int32_t hPassed, hRpr;             // list handles: >= 0 temporary list, <= -10 tree list -(id + 10), -1 None
-    double distance, pathBest;
-    int16_t failsP, pad;               // failedPasses under the permissive rules
-    // out (written by the item's own lane)
-    int32_t hA, hB, hMid;              // short-list record of an item that was still updating (M:7073 / 7295)
-    double recDist;
-    int32_t pad2[2];
-};
-static_assert(sizeof(FItem) == 96, "FItem");
-
-// The items of a search once more, in the order the exact walk visits them (the child pushed last first): rank p + 1 is the first
-// item visited after rank p, p + size skips the subtree -- the walk of k_fr_replay is a forward scan over these 32-byte records
-// instead of a chase through 96-byte items scattered over gigabytes (one miss to HBM per pop).
-struct alignas(32) FVisit {
-    double midProb, lastLK;
-    int32_t ref, size;
-    int32_t parent;                    // rank of the item that pushed it (its failedPasses are handed on), -1 for a seed
-    uint8_t flags; int8_t dir; int16_t failsOut;
-};
-static_assert(sizeof(FVisit) == 32, "FVisit");
-
-struct FSearch {
-    int32_t node, parent, sibling;     // pruned node, its parent (`node` of findBestParentTopology), its sibling
-    int32_t hRpr0;
-    int32_t seed0, seed1;
-    int32_t nItems;                    // expanded so far (atomic)
-    int32_t state;
-    int32_t slHead, nApp, recBase, recCount;
-    int32_t isRemovedTip, pad;
-    double removedBLen, curLK;
-};
-
-struct FRec { int32_t q, ref; double optimized, top, bottom, app; int32_t ok, pad; };
-
-struct FCtr {                          // device-side bookkeeping of the level loop
-    // (what every lane READS at the start of a kernel, and each counter the lanes bump, on cache lines of their own)
-    alignas(128) unsigned long long loU;
-    unsigned long long hiU, loC, hiC;  // the current level
-    alignas(128) unsigned long long usedU;   // items allocated in the two pools
-    alignas(128) unsigned long long usedC;
-    alignas(128) unsigned long long permDown;     // the level's one-lane updating items by direction (k_fr_sort_level)
-    alignas(128) unsigned long long permUp;
-    alignas(128) unsigned long long permDownB;    // ... those with long lists (16 to a wavefront)
-    alignas(128) unsigned long long permUpB;
-    alignas(128) unsigned long long nLists;       // temporary lists
-    alignas(128) unsigned long long usedW;
-    alignas(128) unsigned long long usedA;
-    alignas(128) unsigned long long nRecs;
-    unsigned long long bigUsed;        // entries taken from the shared scratch of over-long lists (reset every level)
-    alignas(128) unsigned long long itemsU;
-    unsigned long long bytesU;         // items k_fr_updating walked and the bytes of the lists their mergeVectors read and wrote
-    alignas(128) unsigned long long scoredC;
-    unsigned long long bytesC;         // cached-regime items scored by k_fr_cached and their SURVEY 8d bytes (8 E + 8 A + 8)
-    int32_t overflow, nLevels;
-#ifdef MAPLE_SPR_PROFILE
-    unsigned long long dbgCnt[8], dbgT[8], dbgMax[8];   // k_fr_updating's one-lane items by size (entries of the two lists): count, ticks, slowest
-#endif
-};
-
-struct FPools {
-    FItem *U, *C;
-    long long capU, capC;
-    // temporary lists
-    uint2 *tw; double *ta;
-    long long *toffW, *toffA;
-    int32_t *tn, *tna;
-    long long capW, capA, capL;
-    FVisit *visit; long long capVisit;   // the layout of k_fr_layout_* (null: k_fr_replay chases the items)
-    int32_t *lsize, *lpos, *lpar;      // per item (updating pool first, then the cached pool): items in the subtree it heads, its
-                                       // rank in its search's visiting order (-1: not laid out), the rank of the item that pushed it
-    unsigned long long *lvl;           // [maxLevels][4]: loU, hiU, loC, hiC of every level
-    int32_t maxLevels;
-    int32_t *tot; long long *vbase;    // per search: items in its two seed subtrees, and where its visiting order starts
-    int32_t *perm, *perm2;             // the level's one-lane updating items: moving down from the front, crawling up from the back
-                                       // (perm2: those with long lists)
-    // per-lane scratch
-    uint2 *sw; double *sa; double *sais;
-    int32_t capE;                      // entries one lane's scratch list takes (aux: 5 per entry; ais: 2 per entry)
-    uint2 *bw; double *ba;             // shared scratch for the few lists longer than that (bump-allocated, reset every level)
-    long long capBig;
-    FCtr *ctr;
-    FSearch *S;
-    FRec *recs;
-    long long capRecs;
-};
-
-__device__ __forceinline__ FItem &item_of(const FPools &fp, int ref) { return ref >= 0 ? fp.C[ref] : fp.U[-(ref + 2)]; }
-
-struct FList { const uint2 *w; const double *aux; int32_t n, na; };
-
-__device__ __forceinline__ bool fvalid(int h) { return h >= 0 || h <= -10; }
-__device__ __forceinline__ int ftree(int listId) { return listId < 0 ? -1 : -(listId + 10); }
-__device__ __forceinline__ FList flist(const ArenaViewS &av, const FPools &fp, int h)
-{
-    if (h >= 0) return FList{fp.tw + fp.toffW[h], fp.ta + fp.toffA[h], fp.tn[h], fp.tna[h]};
-    const int id = -h - 10;
-    return FList{av.words + av.ent_off[id], av.aux + av.aux_off[id], av.n_ent[id], av.n_aux[id]};
-}
-__device__ __forceinline__ ListRef fref(const FList &l) { return ListRef{l.w, l.aux}; }
-
-// room for one list of up to `need` entries: the lane's own slab, or -- for the few lists near the root that are longer --
-// a piece of the shared scratch (false: none left)
-struct FScr { uint2 *w; double *a; };
-__device__ inline bool fscratch(const FPools &fp, long long laneId, int need, FScr &o)
-{
-    if (need <= fp.capE) { o.w = fp.sw + laneId * fp.capE; o.a = fp.sa + laneId * 5ll * fp.capE; return true; }
-    const unsigned long long off = atomicAdd(&fp.ctr->bigUsed, (unsigned long long)need);
-    if ((long long)(off + need) > fp.capBig) return false;
-    o.w = fp.bw + off; o.a = fp.ba + 5ull * off;
-    return true;
-}
-
-// a scratch list becomes a temporary list of the batch: exact room, one copy; -2 when the pools are full
-__device__ inline int fstore(const FPools &fp, const Writer &wr)
-{
-    // The lanes of a wavefront that are here together take their room with ONE atomic per counter: the three counters share a
-    // cache line with everything else the level loop counts, and a million single-lane atomics per level on it were what a
-    // level of k_fr_updating waited for.
-    const unsigned long long act = __ballot(1);
-    const int lane = threadIdx.x & 63, leader = (int)__ffsll((long long)act) - 1;
-    int preN = 0, preA = 0, totN = 0, totA = 0, rank = 0, cnt = 0;
-    for (unsigned long long mm = act; mm; mm &= mm - 1) {
-        const int j = (int)__ffsll((long long)mm) - 1;
-        const int nj = __builtin_amdgcn_readlane(wr.n, j), aj = __builtin_amdgcn_readlane(wr.na, j);
-        if (j < lane) { preN += nj; preA += aj; rank++; }
-        totN += nj; totA += aj; cnt++;
-    }
-    unsigned long long id0 = 0, ow0 = 0, oa0 = 0;
-    if (lane == leader) {
-        id0 = atomicAdd(&fp.ctr->nLists, (unsigned long long)cnt);
-        ow0 = atomicAdd(&fp.ctr->usedW, (unsigned long long)totN);
-        oa0 = atomicAdd(&fp.ctr->usedA, (unsigned long long)totA);
-    }
-    auto bc = [&](unsigned long long x) {
-        return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(x >> 32), leader) << 32)
-               | (uint32_t)__builtin_amdgcn_readlane((int)x, leader);
-    };
-    const unsigned long long id = bc(id0) + (unsigned long long)rank, ow = bc(ow0) + (unsigned long long)preN,
-                             oa = bc(oa0) + (unsigned long long)preA;
-    if ((long long)id >= fp.capL || (long long)(ow + wr.n) > fp.capW || (long long)(oa + wr.na) > fp.capA) {
-        fp.ctr->overflow = 1;
-        return -2;
-    }
-    uint2 *dw = fp.tw + ow;
-    double *da = fp.ta + oa;
-    for (int k = 0; k < wr.n; k++) dw[k] = wr.w[k];
-    for (int k = 0; k < wr.na; k++) da[k] = wr.aux[k];
-    fp.toffW[id] = (long long)ow; fp.toffA[id] = (long long)oa; fp.tn[id] = wr.n; fp.tna[id] = wr.na;
-    return (int)id;
-}
-
-// would shorten() (M:3721-3745) change this list?  (the absorb test of shorten_walk, genome_dev.h)
-template <class C> __device__ inline bool shorten_would_merge(const C &c, ListRef L, int nEnt)
-{
-    const double thr = c.m.thresholdProb;
-    Cursor a;
-    a.init(L);
-    Ent head = a.e;
-    for (int k = 1; k < nEnt; k++) {
-        a.next();
-        const Ent &nw = a.e;
-        if (nw.type == 4 && head.type == 4 && nw.hasD0 == head.hasD0 && nw.hasD1 == head.hasD1) {
-            if (!nw.hasD0) return true;
-            if (!(fabs(nw.d0 - head.d0) > thr) && !(nw.hasD1 && fabs(nw.d1 - head.d1) > thr) && nw.flag == head.flag) return true;
-        }
-        head = nw;
-    }
-    return false;
-}
-
-// one more expanded item of search q; false when the search is over its budget (it becomes a dense-tier search) or the pool
-// is full (the search is handed back)
-__device__ inline int fpush(const FPools &fp, const int budget, const int q, const bool upd, const int t1, const int dir,
-                            const int hPassed, const double distance, const double lastLK, const int fails, const int hRpr,
-                            const double pathBest)
-{
-    FSearch &S = fp.S[q];
-    if (S.state != FS_WIDE && atomicAdd(&S.nItems, 1) >= budget) { S.state = FS_OVER; return FR_NONE; }
-    FItem *it;
-    int ref;
-    // one atomic per wavefront and pool: the lanes that are here together take consecutive items
-    unsigned long long *ctrp = upd ? &fp.ctr->usedU : &fp.ctr->usedC;
-    const unsigned long long act = __ballot(1);
-    const int lane = threadIdx.x & 63, leader = (int)__ffsll((long long)act) - 1;
-    const unsigned long long same = __ballot(upd);                           // (lanes pushing into the updating pool)
-    const unsigned long long mine = upd ? (act & same) : (act & ~same);
-    const int lead2 = (int)__ffsll((long long)mine) - 1;
-    unsigned long long base = 0;
-    if (lane == lead2) base = atomicAdd(ctrp, (unsigned long long)__popcll(mine));
-    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), lead2, 64) << 32) | (uint32_t)__shfl((int)base, lead2, 64);
-    (void)leader;
-    const unsigned long long i = base + (unsigned long long)__popcll(mine & ((1ull << lane) - 1ull));
-    if (upd) {
-        if ((long long)i >= fp.capU) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; return FR_NONE; }
-        it = &fp.U[i]; ref = -((int)i + 2);
-    } else {
-        if ((long long)i >= fp.capC) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; return FR_NONE; }
-        it = &fp.C[i]; ref = (int)i;
-    }
-    it->q = q; it->t1 = t1; it->dir = (int8_t)dir; it->flags = upd ? FI_UPD_IN : 0; it->failsP = (int16_t)fails;
-    it->hPassed = hPassed; it->hRpr = hRpr; it->distance = distance; it->lastLK = lastLK; it->pathBest = pathBest;
-    it->child0 = it->child1 = FR_NONE; it->hA = it->hB = it->hMid = -1; it->next = FR_NONE; it->failsA = 0;
-    it->midProb = lastLK; it->recDist = 0.0;
-    return ref;
-}
 
 // ---- the worker's prologue (M:9626-9674) and the seeding of nodesToVisit (M:6855-6914) ----------------------------------
 template <bool RV, bool U, bool SS>
@@ -305,14 +64,35 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
         const int vectUp = ftree(childIdx == 0 ? rp.upRight : rp.upLeft);
         if (!fvalid(vectUp) || rn.lower < 0) { o.status = -1; continue; }
         const FList lu = flist(av, fp, vectUp), ll = flist(av, fp, ftree(rn.lower));
-        const double curLK = append_walk(c, fref(lu), fref(ll), rn.isTip != 0, rn.dist);   // M:9646
+        const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        double curLK;
+        if (fp.mat && rn.mutId >= 0 && fp.mv.cnt[rn.mutId] > 0) {           // the parent's upper list in the node's own frame, M:9637-9638
+            const int cnt = fp.mv.cnt[rn.mutId];
+            FScr scr{nullptr, nullptr};
+            if (!fscratch(fp, laneId, lu.n + 2 * cnt, scr)) { S.state = FS_FALLBACK; continue; }
+            Writer wr;
+            wr.init(scr.w, scr.a);
+            pass_walk(c.m.lRef, fref(lu), fp.mv.mut3 + 3 * fp.mv.off[rn.mutId], cnt, false, wr);
+            curLK = append_walk(c, ListRef{scr.w, scr.a}, fref(ll), rn.isTip != 0, rn.dist);
+        } else
+        curLK = append_walk(c, fref(lu), fref(ll), rn.isTip != 0, rn.dist);   // M:9646
         o.currentLK = curLK;
         if (!(curLK < P.thrPlacement || rn.dist != 0.0)) { o.status = 2; continue; }        // M:9674
         S.parent = parent; S.sibling = childIdx == 0 ? rp.c1 : rp.c0;
         S.isRemovedTip = rn.isTip; S.removedBLen = rn.dist; S.curLK = curLK;
-        S.hRpr0 = ftree(rn.lower);
+        const NodeRec rs = T.nd[S.sibling];
+        // the removed list as the search starts with it (M:6838-6846): in the frame of the pruned node's parent, and once more in
+        // the sibling's (bestRemovedPartials).  A re-expressed list that shorten() (M:7087) would change: the one-lane kernel.
+        int rpr = ftree(rn.lower);
+        bool wouldMerge = shorten_would_merge(c, fref(ll), ll.n);           // M:7087 would edit the removed list
+        int hBest = rpr;
+        if (fp.mat && !wouldMerge) {
+            rpr = fpass_removed(c, fp, av, laneId, rpr, rn.mutId, true);
+            hBest = fvalid(rpr) ? fpass_removed(c, fp, av, laneId, rpr, rs.mutId, false) : rpr;
+            if (!fvalid(rpr) || !fvalid(hBest)) wouldMerge = true;          // (-2 / -3: handed back either way)
+        }
+        S.hRpr0 = hBest;
         // a search from a zero-length branch without an error model is a whole-tree search (see k_spr_search): dense tier
-        const bool wouldMerge = shorten_would_merge(c, fref(ll), ll.n);     // M:7087 would edit the removed list
         bool wide = false;
         if (forceWide && rowOf && rowOf[q] >= 0) {
             if (wouldMerge) { S.state = FS_OVER; o.status = -5; continue; }   // (the one-wavefront-per-search kernel edits the list in place)
@@ -330,19 +110,33 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
         const int pp = rp.up;
         const NodeRec rpp = T.nd[pp];
         const bool first = rpp.c0 == parent;
-        const NodeRec rs = T.nd[S.sibling];
         const double d = rs.dist + rp.dist;
-        S.seed0 = fpush(fp, budget, q, true, pp, first ? 1 : 2, ftree(rs.lower), d, curLK, 0, S.hRpr0, curLK);
-        S.seed1 = fpush(fp, budget, q, true, S.sibling, 0, ftree(first ? rpp.upRight : rpp.upLeft), d, curLK, 0, S.hRpr0, curLK);
+        int pv1 = ftree(rs.lower), rprUp = rpr, vUpUp = ftree(first ? rpp.upRight : rpp.upLeft), rprDown = rpr;
+        if (fp.mat) {                                                       // M:6876-6901
+            pv1 = fpass_store(fp, av, c.m.lRef, laneId, pv1, rs.mutId, true);
+            if (rp.mutId >= 0) {
+                pv1 = fvalid(pv1) ? fpass_store(fp, av, c.m.lRef, laneId, pv1, rp.mutId, true) : pv1;
+                rprUp = fpass_removed(c, fp, av, laneId, rpr, rp.mutId, true);
+            }
+            vUpUp = fpass_store(fp, av, c.m.lRef, laneId, vUpUp, rp.mutId, false);
+            if (rs.mutId >= 0) {
+                vUpUp = fvalid(vUpUp) ? fpass_store(fp, av, c.m.lRef, laneId, vUpUp, rs.mutId, false) : vUpUp;
+                rprDown = hBest;                                            // (the same pass: the removed list in the sibling's frame)
+            }
+            if (pv1 == -2 || vUpUp == -2 || !fvalid(rprUp) || !fvalid(rprDown)) { S.state = FS_FALLBACK; continue; }
+        }
+        S.seed0 = fpush(fp, budget, q, true, pp, first ? 1 : 2, pv1, d, curLK, 0, rprUp, curLK);
+        S.seed1 = fpush(fp, budget, q, true, S.sibling, 0, vUpUp, d, curLK, 0, rprDown, curLK);
     }
 }
 
-__global__ void k_fr_snap(FCtr *ctr, long long capU, long long capC, unsigned long long *lvl, int maxLevels)
+__global__ void k_fr_snap(FCtr *ctr, long long capU, long long capC, unsigned long long *lvl, int maxLevels, long long capPass)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         // (a pool that overflowed keeps counting what was asked of it: the items themselves end at its capacity)
         ctr->loU = ctr->hiU; ctr->hiU = min(ctr->usedU, (unsigned long long)capU);
         ctr->loC = ctr->hiC; ctr->hiC = min(ctr->usedC, (unsigned long long)capC);
+        ctr->loP = ctr->hiP; ctr->hiP = min(ctr->nPass, (unsigned long long)capPass);
         ctr->bigUsed = 0;
         ctr->permDown = ctr->permUp = ctr->permDownB = ctr->permUpB = 0;
         if (lvl) {
@@ -352,217 +146,31 @@ __global__ void k_fr_snap(FCtr *ctr, long long capU, long long capC, unsigned lo
     }
 }
 
-// The permissive form of the reference's rules after an item was scored (M:7083-7103 / 7306-7323): failedPasses under
-// pathBest, the new pathBest, and whether the item's relatives are pushed.
-struct PRule { int fails; double pathBest; bool go; };
-__device__ __forceinline__ PRule p_rule(const SearchParams &P, bool scored, double midProb, double lastLK, int fails, double pathBest)
-{
-    PRule r;
-    r.fails = fails; r.pathBest = pathBest;
-    if (scored) {
-        if (midProb > pathBest) { r.pathBest = midProb; r.fails = 0; }
-        else if (midProb < (lastLK - P.thrConsec)) r.fails = fails + 1;
-    }
-    // (the reference tests against the running best AFTER it took this score into account: pathBest is updated first, too)
-    const bool within = midProb > (r.pathBest - P.thrLKtopology);
-    r.go = P.strict ? (r.fails <= P.allowedFails && within) : (r.fails <= P.allowedFails || within);
-    return r;
-}
-
-// ---- items that arrived with needsUpdating == True (M:6982-7091, 7182-7304): lists merged along the path ----------------
-// (dir 3: the seeding of a search whose pruned node hangs off the root, M:6916-6960 -- two rootVector calls)
-// one such item by one lane (the one-lane list walks of genome_dev.h)
+// ---- trees with MAT local references: the removed list of the level's items that were pushed across a reference branch --------
+// The item's hRpr is still the list of the item that pushed it; here it goes through the branch (passGenomeListThroughBranch,
+// M:7111-7118 / 7148-7155 on the way down, 7359-7366 / 7388-7395 on the way up).  One lane per such item (about one push in a
+// hundred crosses a reference branch); a list that shorten() (M:7087) would change hands its search to the one-lane kernel.
 template <bool RV, bool U, bool SS>
-__device__ __forceinline__ void fr_upd_item_lane(const Ctx<RV, U, SS> &c, const ArenaViewS &av, const DevTree &T, const SearchParams &P, const FPools &fp,
-                                 const int budget, const long long laneId, const long long i, unsigned long long *algBytes = nullptr)
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_pass(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, FPools fp)
 {
-        FItem &it = fp.U[i];
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long lo = (long long)fp.ctr->loP, hi = (long long)fp.ctr->hiP;
+    for (long long i = lo + laneId; i < hi; i += (long long)gridDim.x * blockDim.x) {
+        FItem &it = item_of(fp, fp.passList[i]);
         FSearch &S = fp.S[it.q];
-        if (!fs_live(S.state)) { it.flags |= FI_DEAD; return; }
-        const int q = it.q, t1 = it.t1;
-        const NodeRec r1 = T.nd[t1];
-        const int hPassed = it.hPassed, hRpr = it.hRpr;
-        const double distance = it.distance, lastLK = it.lastLK;
-        const bool rt = S.isRemovedTip != 0;
-        const double rbl = S.removedBLen;
-        bool upd = true;
-        double midProb = lastLK;
-        Writer wr;
-        FScr scr{nullptr, nullptr};
-        // merge two lists into scratch (wr / scr); 0 ok, -1 None, -2 fatal / no room (then the search is handed back)
-        auto merge = [&](int h1, double b1, bool tp1, int h2, double b2, bool tp2, bool upDown) -> int {
-            if (!fvalid(h1) || !fvalid(h2)) return -2;
-            const FList l1 = flist(av, fp, h1), l2 = flist(av, fp, h2);
-            if (!fscratch(fp, laneId, l1.n + l2.n, scr)) { S.state = FS_FALLBACK; return -2; }
-            wr.init(scr.w, scr.a);
-            const int r = merge_walk(c, fref(l1), b1, tp1, fref(l2), b2, tp2, upDown, false, 0, 0, wr, nullptr);
-            // (the item's algorithmic bytes: the two lists a mergeVectors reads and the one it writes; the lists of the item's
-            // areVectorsDifferent and appendProbNode are among them or of the same size)
-            if (algBytes) *algBytes += 8ull * (unsigned long long)(l1.n + l1.na + l2.n + l2.na + (r > 0 ? wr.n + wr.na : 0));
-            return r == -1 ? -1 : (r < 0 ? -2 : 0);
-        };
-        // rootVector(list, bLen, isFromTip) without local references (M:4916-4996): the walk, then shorten; a stored handle,
-        // -2 when out of room
-        auto rootVector = [&](int h, double bLen, bool fromTip) -> int {
-            if (!fvalid(h)) return -2;
-            const FList l = flist(av, fp, h);
-            if (!fscratch(fp, laneId, l.n, scr)) return -2;
-            wr.init(scr.w, scr.a);
-            root_walk(c, fref(l), bLen, fromTip, wr);
-            const int hr = fstore(fp, wr);
-            if (hr < 0) return -2;
-            const FList lr = flist(av, fp, hr);
-            wr.init(scr.w, scr.a);
-            shorten_walk(c, fref(lr), lr.n, wr);
-            if (wr.n == lr.n) return hr;                                   // nothing merged: the list as it is
-            return fstore(fp, wr);
-        };
-        if (it.dir == 3) {                                                  // the pruned node's parent is the root; t1 = its sibling
-            it.midProb = lastLK;
-            it.flags |= FI_UPD_OUT;
-            if (r1.c0 >= 0) {
-                const int ch1 = r1.c0, ch2 = r1.c1;
-                const NodeRec rc1 = T.nd[ch1], rc2 = T.nd[ch2];
-                const int v1 = rootVector(ftree(rc2.lower), rc2.dist, rc2.isTip != 0);
-                const int v2 = v1 < 0 ? -2 : rootVector(ftree(rc1.lower), rc1.dist, rc1.isTip != 0);
-                if (v1 < 0 || v2 < 0) { S.state = FS_FALLBACK; return; }
-                it.child0 = fpush(fp, budget, q, true, ch1, 0, v1, rc1.dist, lastLK, 0, hRpr, it.pathBest);
-                it.child1 = fpush(fp, budget, q, true, ch2, 0, v2, rc2.dist, lastLK, 0, hRpr, it.pathBest);
-            }
-            return;
-        }
-        if (it.dir == 0) {                                                  // moving from a parent to its child, M:6982-7160
-            const int upT = r1.up;
-            const bool scored = !(upT == S.parent || upT < 0) && (r1.dist > P.effNon0 || r1.upIsRoot);
-            if (scored) {
-                if (merge(hPassed, distance / 2, false, ftree(r1.lower), distance / 2, r1.isTip != 0, true) != 0) { it.flags |= FI_DEAD; return; }
-                const ListRef mid{scr.w, scr.a};
-                if (r1.totUp >= 0) { const FList tu = flist(av, fp, ftree(r1.totUp)); if (!differ_walk(c, mid, fref(tu))) upd = false; }
-                const FList lr = flist(av, fp, hRpr);
-                midProb = append_walk(c, mid, fref(lr), rt, rbl);
-                it.flags |= FI_SCORED;
-                if (upd && midProb >= it.pathBest - P.thrOptTopo) {          // may be short-listed (M:7071): keep the record's lists
-                    const int hm = fstore(fp, wr);
-                    if (hm < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; return; }
-                    it.hA = hPassed; it.hB = ftree(r1.lower); it.hMid = hm; it.recDist = distance; it.flags |= FI_REC_UPD;
-                }
-            }
-            it.midProb = midProb;
-            if (upd) it.flags |= FI_UPD_OUT;
-            const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
-            if (pr.go && r1.c0 >= 0) {
-                for (int k = 0; k < 2; k++) {                               // child 0 uses vectUpRight, child 1 vectUpLeft
-                    const int ch = k == 0 ? r1.c0 : r1.c1, other = k == 0 ? r1.c1 : r1.c0;
-                    int ref = FR_NONE;
-                    if (upd) {
-                        const NodeRec ro = T.nd[other];
-                        const int r = merge(hPassed, distance, false, ftree(ro.lower), ro.dist, ro.isTip != 0, true);
-                        if (r == -2) { S.state = FS_FALLBACK; break; }
-                        if (r == 0) {
-                            const int hv = fstore(fp, wr);
-                            if (hv < 0) { S.state = FS_FALLBACK; break; }
-                            ref = fpush(fp, budget, q, true, ch, 0, hv, T.nd[ch].dist, midProb, pr.fails, hRpr, pr.pathBest);
-                        }
-                    } else if ((k == 0 ? r1.upRight : r1.upLeft) >= 0)
-                        ref = fpush(fp, budget, q, false, ch, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
-                    if (k == 0) it.child0 = ref; else it.child1 = ref;
-                }
-            }
-        } else {                                                             // crawling up from a child to its parent t1, M:7162-7434
-            const int other = (it.dir == 1) ? r1.c1 : r1.c0;
-            const int upT = r1.up;
-            const NodeRec ro = T.nd[other];
-            int hBottom = -1;
-            const int vectUp = upT >= 0 ? ftree(r1.whichChild ? T.nd[upT].upLeft : T.nd[upT].upRight) : -1;
-            const bool scored = upT >= 0 && (r1.dist > P.effNon0 || r1.upIsRoot);
-            if (scored) {
-                int r = merge(hPassed, distance, false, ftree(ro.lower), ro.dist, ro.isTip != 0, false);
-                if (r != 0) { it.flags |= FI_DEAD; return; }
-                hBottom = fstore(fp, wr);
-                if (hBottom < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; return; }
-                r = merge(vectUp, r1.dist / 2, false, hBottom, r1.dist / 2, false, true);
-                if (r != 0) { it.flags |= FI_DEAD; return; }
-                int hm = -1;
-                if (r1.totUp >= 0) {
-                    const ListRef mid{scr.w, scr.a};
-                    const FList tu = flist(av, fp, ftree(r1.totUp));
-                    if (!differ_walk(c, mid, fref(tu))) upd = false;
-                } else {
-                    // "Node has no probVectTotUp ... calculating new one", M:7198-7200: midTot is compared with a list merged on
-                    // the spot (midTot moves to the arena first: the scratch is needed for that merge)
-                    hm = fstore(fp, wr);
-                    if (hm < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; return; }
-                    const int rc = merge(vectUp, r1.dist / 2, false, ftree(r1.lower), r1.dist / 2, false, true);
-                    if (rc == 0) { const FList lm = flist(av, fp, hm); if (!differ_walk(c, fref(lm), ListRef{scr.w, scr.a})) upd = false; }
-                    else if (S.state == FS_FALLBACK) { it.flags |= FI_DEAD; return; }
-                }
-                const FList lr = flist(av, fp, hRpr);
-                if (hm >= 0) { const FList lm = flist(av, fp, hm); midProb = append_walk(c, fref(lm), fref(lr), rt, rbl); }
-                else midProb = append_walk(c, ListRef{scr.w, scr.a}, fref(lr), rt, rbl);
-                it.flags |= FI_SCORED;
-                if (upd && midProb >= it.pathBest - P.thrOptTopo) {          // M:7293
-                    if (hm < 0) hm = fstore(fp, wr);
-                    if (hm < 0) { S.state = FS_FALLBACK; it.flags |= FI_DEAD; return; }
-                    it.hA = vectUp; it.hB = hBottom; it.hMid = hm; it.recDist = r1.dist; it.flags |= FI_REC_UPD;
-                }
-            }
-            it.midProb = midProb;
-            if (upd) it.flags |= FI_UPD_OUT;
-            const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
-            if (!pr.go) return;
-            if (upT >= 0) {
-                int hUp = -1;
-                if (upd) {
-                    const int r = merge(vectUp, r1.dist, false, hPassed, distance, false, true);
-                    if (r == -2) { S.state = FS_FALLBACK; return; }
-                    if (r == 0) { hUp = fstore(fp, wr); if (hUp < 0) { S.state = FS_FALLBACK; return; } }
-                } else hUp = ftree(it.dir == 1 ? r1.upLeft : r1.upRight);
-                if (!fvalid(hUp)) return;
-                it.child0 = upd ? fpush(fp, budget, q, true, other, 0, hUp, ro.dist, midProb, pr.fails, hRpr, pr.pathBest)
-                                : fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
-                if (upd && hBottom < 0) {                                    // M:7376-7384
-                    const int r = merge(hPassed, distance, false, ftree(ro.lower), ro.dist, ro.isTip != 0, false);
-                    if (r != 0) return;
-                    hBottom = fstore(fp, wr);
-                    if (hBottom < 0) { S.state = FS_FALLBACK; return; }
-                }
-                it.child1 = upd ? fpush(fp, budget, q, true, upT, (int)r1.whichChild + 1, hBottom, r1.dist, midProb, pr.fails, hRpr, pr.pathBest)
-                                : fpush(fp, budget, q, false, upT, (int)r1.whichChild + 1, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
-            } else {                                                         // t1 is the root, M:7406-7432
-                if (upd) {
-                    const int hv = rootVector(hPassed, distance, false);
-                    if (hv < 0) { S.state = FS_FALLBACK; return; }
-                    it.child0 = fpush(fp, budget, q, true, other, 0, hv, ro.dist, midProb, pr.fails, hRpr, pr.pathBest);
-                } else
-                    it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
-            }
-        }
-}
-
-// (a real call: k_fr_updating_wave falls back to it from three places and is bound by its LDS, not its registers)
-template <bool RV, bool U, bool SS>
-__device__ __noinline__ void fr_upd_item_lane_call(const Ctx<RV, U, SS> &c, const ArenaViewS &av, const DevTree &T, const SearchParams &P,
-                                                   const FPools &fp, const int budget, const long long laneId, const long long i)
-{
-    fr_upd_item_lane(c, av, T, P, fp, budget, laneId, i);
-}
-
-// Is this item one of the few with long lists (near the root)?  One lane walking two lists of several hundred entries takes
-// milliseconds, and a level of the expansion lasts as long as its slowest item: those go to k_fr_updating_wave, a wavefront
-// per item.
-__device__ __forceinline__ int fr_upd_size(const ArenaViewS &av, const DevTree &T, const FPools &fp, const FItem &it)
-{
-    if (it.dir == 3) return 0;
-    const NodeRec &r1 = T.nd[it.t1];
-    const int other = it.dir == 0 ? it.t1 : (it.dir == 1 ? r1.c1 : r1.c0);
-    const int lw = T.nd[other].lower;
-    const int nTree = lw >= 0 ? av.n_ent[lw] : 0;
-    const int nPass = it.hPassed >= 0 ? fp.tn[it.hPassed] : (it.hPassed <= -10 ? av.n_ent[-it.hPassed - 10] : 0);
-    return nPass + nTree;
-}
-__device__ __forceinline__ bool fr_upd_heavy(const ArenaViewS &av, const DevTree &T, const FPools &fp, const FItem &it, int heavyMin)
-{
-    return heavyMin > 0 && it.dir != 3 && fr_upd_size(av, T, fp, it) >= heavyMin;
+        if (!fs_live(S.state)) continue;
+        const NodeRec r1 = T.nd[it.t1];
+        // dir 0: came down the branch above t1; dir 1 / 2: came up the branch above t1's child 0 / 1
+        const int mutId = it.dir == 0 ? r1.mutId : T.nd[it.dir == 1 ? r1.c0 : r1.c1].mutId;
+        const int h = fpass_removed(c, fp, av, laneId, it.hRpr, mutId, it.dir != 0);
+        if (!fvalid(h)) { S.state = FS_FALLBACK; continue; }
+        it.hRpr = h;
+        it.flags &= (uint8_t)~FI_NEEDPASS;
+    }
 }
 
 // The one-lane updating items of the level, by direction: an item that moves down (M:6982-7160) and one that crawls up
@@ -600,299 +208,6 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_sort_level(ArenaViewS av, DevTr
                 const long long at = (long long)(b0 + __popcll(mk & below));
                 pm[(k & 1) ? n - 1 - at : at] = (int32_t)i;
             }
-        }
-    }
-}
-
-template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, FPools fp, int budget, int heavyMin)
-{
-    __shared__ Lds lds;
-    const DevModel &m = *mp;
-    stage_model(m, lds);
-    Ctx<RV, U, SS> c(m, lds);
-    const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
-    // wavefronts of items moving down first, then wavefronts of items crawling up (k_fr_sort_level; heavy items are not listed)
-    const long long nDown = (long long)fp.ctr->permDown, nUp = (long long)fp.ctr->permUp, padDown = (nDown + 63) & ~63ll;
-    // the items with long lists first, 16 to a wavefront (lanes 0-15), then wavefronts of 64 moving down, then of 64 crawling up
-    const long long nDownB = (long long)fp.ctr->permDownB, nUpB = (long long)fp.ctr->permUpB;
-    const long long vDownB = ((nDownB + 15) >> 4) << 6, vUpB = ((nUpB + 15) >> 4) << 6, vBig = vDownB + vUpB;
-    unsigned long long nU = 0, bU = 0;
-    (void)heavyMin;
-    for (long long v0 = laneId; v0 < vBig + padDown + nUp; v0 += (long long)gridDim.x * blockDim.x) {
-        long long i;
-        if (v0 < vBig) {
-            const bool up = v0 >= vDownB;
-            const long long w = up ? v0 - vDownB : v0;
-            const int l = (int)(w & 63);
-            const long long j = (w >> 6) * 16 + l;
-            if (l >= 16 || j >= (up ? nUpB : nDownB)) continue;
-            i = lo + (up ? fp.perm2[(hi - lo) - 1 - j] : fp.perm2[j]);
-        } else {
-            const long long v = v0 - vBig;
-            if (v >= nDown && v < padDown) continue;
-            i = lo + (v < nDown ? fp.perm[v] : fp.perm[(hi - lo) - 1 - (v - padDown)]);
-        }
-#ifdef MAPLE_SPR_PROFILE
-        const long long t0 = wall_clock64();
-        int sz = 0;
-        {
-            const FItem &it = fp.U[i];
-            if (it.dir != 3) {
-                const NodeRec &r1 = T.nd[it.t1];
-                const int other = it.dir == 0 ? it.t1 : (it.dir == 1 ? r1.c1 : r1.c0);
-                const int lw = T.nd[other].lower;
-                sz = (lw >= 0 ? av.n_ent[lw] : 0) + (it.hPassed >= 0 ? fp.tn[it.hPassed] : (it.hPassed <= -10 ? av.n_ent[-it.hPassed - 10] : 0));
-            }
-        }
-#endif
-        fr_upd_item_lane(c, av, T, P, fp, budget, laneId, i, &bU);
-        nU++;
-#ifdef MAPLE_SPR_PROFILE
-        {
-            const unsigned long long dt = (unsigned long long)(wall_clock64() - t0);
-            const int b = sz < 64 ? 0 : sz < 96 ? 1 : sz < 128 ? 2 : sz < 192 ? 3 : sz < 256 ? 4 : sz < 384 ? 5 : sz < 512 ? 6 : 7;
-            atomicAdd(&fp.ctr->dbgCnt[b], 1ull); atomicAdd(&fp.ctr->dbgT[b], dt); atomicMax(&fp.ctr->dbgMax[b], dt);
-        }
-#endif
-    }
-    // (what the launch did, for the roofline of the bench line: one atomic per wavefront)
-    for (int off = 32; off > 0; off >>= 1) {
-        nU += ((unsigned long long)(uint32_t)__shfl_down((int)(nU >> 32), off, 64) << 32) | (uint32_t)__shfl_down((int)nU, off, 64);
-        bU += ((unsigned long long)(uint32_t)__shfl_down((int)(bU >> 32), off, 64) << 32) | (uint32_t)__shfl_down((int)bU, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0 && nU) { atomicAdd(&fp.ctr->itemsU, nU); atomicAdd(&fp.ctr->bytesU, bU); }
-}
-
-// ---- the same items by a whole wavefront: the few whose lists are long -------------------------------------------------------
-// mergeVectors, areVectorsDifferent and appendProbNode cut along the merge path of the two lists (wave_update.h, wave_dev.h:
-// lane d does step d of the walk; bit for bit the one-lane walks), every list of the item in LDS.  An item with a list beyond
-// the staging limit is walked by lane 0 alone.
-__device__ inline int fstore_wave(const FPools &fp, const unsigned long long *w, const double *a, int n, int na)
-{
-    const int lane = threadIdx.x & 63;
-    unsigned long long id = 0, ow = 0, oa = 0;
-    if (lane == 0) {
-        id = atomicAdd(&fp.ctr->nLists, 1ull);
-        ow = atomicAdd(&fp.ctr->usedW, (unsigned long long)n);
-        oa = atomicAdd(&fp.ctr->usedA, (unsigned long long)na);
-    }
-    auto bc = [](unsigned long long x) {
-        return ((unsigned long long)(uint32_t)__shfl((int)(x >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)x, 0, 64);
-    };
-    id = bc(id); ow = bc(ow); oa = bc(oa);
-    if ((long long)id >= fp.capL || (long long)(ow + n) > fp.capW || (long long)(oa + na) > fp.capA) {
-        if (lane == 0) fp.ctr->overflow = 1;
-        return -2;
-    }
-    unsigned long long *dw = (unsigned long long *)(fp.tw + ow);
-    double *da = fp.ta + oa;
-    for (int k = lane; k < n; k += 64) dw[k] = w[k];
-    for (int k = lane; k < na; k += 64) da[k] = a[k];
-    if (lane == 0) { fp.toffW[id] = (long long)ow; fp.toffA[id] = (long long)oa; fp.tn[id] = n; fp.tna[id] = na; }
-    __threadfence();
-    wave_sync();
-    return (int)id;
-}
-
-template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(64) void k_fr_updating_wave(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, FPools fp,
-                                                         int budget, int heavyMin, long long laneBase)
-{
-    __shared__ Lds lds;
-    __shared__ WaveUpdLds L;
-    const DevModel &m = *mp;
-    stage_model(m, lds);
-    Ctx<RV, U, SS> c(m, lds);
-    const int lane = threadIdx.x;
-    WaveLds &W = *reinterpret_cast<WaveLds *>(L.baux);                     // (appendProbNode's staging: baux is free by then)
-    static_assert(sizeof(WaveLds) <= sizeof(L.baux), "LDS alias");
-    const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
-    for (long long base = lo + (long long)blockIdx.x * 64; base < hi; base += (long long)gridDim.x * 64) {
-        const long long mine = base + lane;
-        const bool heavy = mine < hi && fr_upd_heavy(av, T, fp, fp.U[mine], heavyMin);
-        unsigned long long todo = __ballot(heavy);
-        while (todo) {
-            const int j = (int)__ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const long long i = base + j;
-            FItem &it = fp.U[i];
-            FSearch &S = fp.S[it.q];
-            if (!fs_live(S.state)) { if (lane == 0) it.flags |= FI_DEAD; continue; }
-            const int q = it.q, t1 = it.t1, dir = it.dir;
-            const NodeRec r1 = T.nd[t1];
-            const int hPassed = it.hPassed, hRpr = it.hRpr;
-            const double distance = it.distance, lastLK = it.lastLK;
-            const bool rt = S.isRemovedTip != 0;
-            const double rbl = S.removedBLen;
-            const int other = dir == 0 ? -1 : (dir == 1 ? r1.c1 : r1.c0);
-            const int upT = r1.up;
-            // every list the item touches must fit the staging areas; else lane 0 walks the item alone
-            const FList lp = fvalid(hPassed) ? flist(av, fp, hPassed) : FList{nullptr, nullptr, 0, 0};
-            const FList lr = flist(av, fp, hRpr);
-            bool fits = fvalid(hPassed) && lp.n <= MAPLE_WU_IN && lr.n <= MAPLE_WAVE_CAPW;
-            {
-                const int ids[6] = {r1.lower, r1.totUp, dir == 0 && r1.c0 >= 0 ? T.nd[r1.c0].lower : -1, dir == 0 && r1.c1 >= 0 ? T.nd[r1.c1].lower : -1,
-                                    other >= 0 ? T.nd[other].lower : -1,
-                                    (dir != 0 && upT >= 0) ? (r1.whichChild ? T.nd[upT].upLeft : T.nd[upT].upRight) : -1};
-                for (int k = 0; k < 6; k++) if (ids[k] >= 0 && av.n_ent[ids[k]] > MAPLE_WU_IN) fits = false;
-                // (crawling up, the merged lower list is an input of the next merge)
-                if (dir != 0 && other >= 0 && T.nd[other].lower >= 0 && lp.n + av.n_ent[T.nd[other].lower] > MAPLE_WU_IN) fits = false;
-            }
-            if (!fits) {
-                if (lane == 0) fr_upd_item_lane_call(c, av, T, P, fp, budget, laneBase + blockIdx.x, i);
-                wave_sync();
-                continue;
-            }
-            bool upd = true;
-            double midProb = lastLK;
-            int flagsAdd = 0;
-            int nM = 0, naM = 0;
-            // mergeVectors into L.m / L.maux: 0 ok, -1 None, -2 fatal
-            auto merge = [&](const FList &l1, double b1, bool tp1, const FList &l2, double b2, bool tp2, bool upDown) -> int {
-                wave_sync();
-                const int r = wave_merge(c, fref(l1), l1.n, b1, tp1, fref(l2), l2.n, b2, tp2, upDown, L, naM);
-                if (r < 0) return r == -1 ? -1 : -2;
-                nM = r;
-                return 0;
-            };
-            auto differs = [&](int listId) -> bool {                        // areVectorsDifferent(L.m, tree list)
-                const FList tu = flist(av, fp, ftree(listId));
-                const unsigned long long *tw = (const unsigned long long *)tu.w;
-                for (int k = lane; k < tu.n; k += 64) L.old[k] = tw[k];
-                wave_sync();
-                return wave_differ(c, L.m, L.maux, nM, L.old, tu.aux, tu.n);
-            };
-            auto score = [&]() -> double {                                  // appendProbNode(L.m, removed list)
-                wave_sync();
-                return wave_append(c, ListRef{(const uint2 *)L.m, L.maux}, nM, fref(lr), lr.n, rt, rbl, W);
-            };
-            auto push1 = [&](bool u, int node, int d, int h, double dst, double mp, int fails, double pb) -> int {
-                int ref = FR_NONE;
-                if (lane == 0) ref = fpush(fp, budget, q, u, node, d, h, dst, mp, fails, hRpr, pb);
-                return __shfl(ref, 0, 64);
-            };
-            bool dead = false, fallback = false;
-            int child0 = FR_NONE, child1 = FR_NONE, hA = -1, hB = -1, hMid = -1;
-            double recDist = 0.0;
-            if (dir == 0) {
-                const bool scored = !(upT == S.parent || upT < 0) && (r1.dist > P.effNon0 || r1.upIsRoot);
-                if (scored) {
-                    const FList ll = flist(av, fp, ftree(r1.lower));
-                    if (merge(lp, distance / 2, false, ll, distance / 2, r1.isTip != 0, true) != 0) dead = true;
-                    else {
-                        if (r1.totUp >= 0 && !differs(r1.totUp)) upd = false;
-                        midProb = score();
-                        flagsAdd |= FI_SCORED;
-                        if (upd && midProb >= it.pathBest - P.thrOptTopo) {
-                            wave_sync();
-                            hMid = fstore_wave(fp, L.m, L.maux, nM, naM);
-                            if (hMid < 0) { fallback = true; dead = true; }
-                            else { hA = hPassed; hB = ftree(r1.lower); recDist = distance; flagsAdd |= FI_REC_UPD; }
-                        }
-                    }
-                }
-                if (!dead) {
-                    const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
-                    if (pr.go && r1.c0 >= 0) {
-                        for (int k = 0; k < 2 && !fallback; k++) {
-                            const int ch = k == 0 ? r1.c0 : r1.c1, oth = k == 0 ? r1.c1 : r1.c0;
-                            int ref = FR_NONE;
-                            if (upd) {
-                                const NodeRec ro = T.nd[oth];
-                                const FList lo2 = flist(av, fp, ftree(ro.lower));
-                                const int r = ro.lower >= 0 ? merge(lp, distance, false, lo2, ro.dist, ro.isTip != 0, true) : -2;
-                                if (r == -2) { fallback = true; break; }
-                                if (r == 0) {
-                                    wave_sync();
-                                    const int hv = fstore_wave(fp, L.m, L.maux, nM, naM);
-                                    if (hv < 0) { fallback = true; break; }
-                                    ref = push1(true, ch, 0, hv, T.nd[ch].dist, midProb, pr.fails, pr.pathBest);
-                                }
-                            } else if ((k == 0 ? r1.upRight : r1.upLeft) >= 0)
-                                ref = push1(false, ch, 0, -1, 0.0, midProb, pr.fails, pr.pathBest);
-                            if (k == 0) child0 = ref; else child1 = ref;
-                        }
-                    }
-                }
-            } else {
-                const NodeRec ro = T.nd[other];
-                const int vectUp = upT >= 0 ? ftree(r1.whichChild ? T.nd[upT].upLeft : T.nd[upT].upRight) : -1;
-                const bool scored = upT >= 0 && (r1.dist > P.effNon0 || r1.upIsRoot);
-                int hBottom = -1;
-                const FList lo2 = flist(av, fp, ftree(ro.lower));
-                const FList lvu = fvalid(vectUp) ? flist(av, fp, vectUp) : FList{nullptr, nullptr, 0, 0};
-                if (scored) {
-                    if (!fvalid(vectUp) || r1.totUp < 0) {                  // (the on-the-spot probVectTotUp of M:7198-7200: one lane)
-                        if (lane == 0) fr_upd_item_lane_call(c, av, T, P, fp, budget, laneBase + blockIdx.x, i);
-                        wave_sync();
-                        continue;
-                    }
-                    int r = merge(lp, distance, false, lo2, ro.dist, ro.isTip != 0, false);
-                    if (r != 0) dead = true;
-                    else {
-                        wave_sync();
-                        hBottom = fstore_wave(fp, L.m, L.maux, nM, naM);
-                        if (hBottom < 0) { fallback = true; dead = true; }
-                        else {
-                            const FList lb = flist(av, fp, hBottom);            // (written by this wavefront, fenced in fstore_wave)
-                            r = merge(lvu, r1.dist / 2, false, lb, r1.dist / 2, false, true);
-                            if (r != 0) dead = true;
-                            else {
-                                if (!differs(r1.totUp)) upd = false;
-                                midProb = score();
-                                flagsAdd |= FI_SCORED;
-                                if (upd && midProb >= it.pathBest - P.thrOptTopo) {
-                                    wave_sync();
-                                    hMid = fstore_wave(fp, L.m, L.maux, nM, naM);
-                                    if (hMid < 0) { fallback = true; dead = true; }
-                                    else { hA = vectUp; hB = hBottom; recDist = r1.dist; flagsAdd |= FI_REC_UPD; }
-                                }
-                            }
-                        }
-                    }
-                }
-                if (!dead) {
-                    const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
-                    if (pr.go) {
-                        if (upT >= 0) {
-                            int hUp = -1;
-                            bool stop = false;
-                            if (upd) {
-                                const int r = fvalid(vectUp) ? merge(lvu, r1.dist, false, lp, distance, false, true) : -2;
-                                if (r == -2) { fallback = true; stop = true; }
-                                else if (r == 0) { wave_sync(); hUp = fstore_wave(fp, L.m, L.maux, nM, naM); if (hUp < 0) { fallback = true; stop = true; } }
-                            } else hUp = ftree(dir == 1 ? r1.upLeft : r1.upRight);
-                            if (!stop && fvalid(hUp)) {
-                                child0 = upd ? push1(true, other, 0, hUp, ro.dist, midProb, pr.fails, pr.pathBest)
-                                             : push1(false, other, 0, -1, 0.0, midProb, pr.fails, pr.pathBest);
-                                if (upd && hBottom < 0) {
-                                    const int r = merge(lp, distance, false, lo2, ro.dist, ro.isTip != 0, false);
-                                    if (r == 0) { wave_sync(); hBottom = fstore_wave(fp, L.m, L.maux, nM, naM); if (hBottom < 0) fallback = true; }
-                                    else stop = true;
-                                }
-                                if (!stop && !fallback)
-                                    child1 = upd ? push1(true, upT, (int)r1.whichChild + 1, hBottom, r1.dist, midProb, pr.fails, pr.pathBest)
-                                                 : push1(false, upT, (int)r1.whichChild + 1, -1, 0.0, midProb, pr.fails, pr.pathBest);
-                            }
-                        } else if (upd) {                                   // t1 is the root and the item still updates: rootVector, one lane
-                            // (nothing was pushed or stored yet that the one-lane walk would not redo)
-                            if (lane == 0) fr_upd_item_lane_call(c, av, T, P, fp, budget, laneBase + blockIdx.x, i);
-                            wave_sync();
-                            continue;
-                        } else
-                            child0 = push1(false, other, 0, -1, 0.0, midProb, pr.fails, pr.pathBest);
-                    }
-                }
-            }
-            if (lane == 0) {
-                if (fallback) S.state = FS_FALLBACK;
-                it.midProb = midProb; it.recDist = recDist; it.child0 = child0; it.child1 = child1; it.hA = hA; it.hB = hB; it.hMid = hMid;
-                it.flags |= (uint8_t)(flagsAdd | (upd ? FI_UPD_OUT : 0) | (dead ? FI_DEAD : 0));
-            }
-            wave_sync();
         }
     }
 }
@@ -954,18 +269,21 @@ void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Sear
         it.midProb = midProb;
         const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
         if (!pr.go) continue;
+        // (a relative in another MAT reference frame gets the removed list through the branch at the start of its level: k_fr_pass)
+        const bool x0 = fp.mat && r1.c0Frame != r1.frameOf, x1 = fp.mat && r1.c1Frame != r1.frameOf, xu = fp.mat && r1.upFrame != r1.frameOf;
         if (it.dir == 0) {
             if (r1.c0 < 0) continue;
-            if (r1.upRight >= 0) it.child0 = fpush(fp, budget, q, false, r1.c0, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
-            if (r1.upLeft >= 0) it.child1 = fpush(fp, budget, q, false, r1.c1, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
+            if (r1.upRight >= 0) it.child0 = fpush(fp, budget, q, false, r1.c0, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, x0);
+            if (r1.upLeft >= 0) it.child1 = fpush(fp, budget, q, false, r1.c1, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, x1);
         } else {
             const int other = (it.dir == 1) ? r1.c1 : r1.c0;
+            const bool xo = (it.dir == 1) ? x1 : x0;
             if (upT >= 0) {
                 if (((it.dir == 1) ? r1.upLeft : r1.upRight) < 0) continue;
-                it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
-                it.child1 = fpush(fp, budget, q, false, upT, (int)r1.whichChild + 1, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
+                it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, xo);
+                it.child1 = fpush(fp, budget, q, false, upT, (int)r1.whichChild + 1, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, xu);
             } else
-                it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest);
+                it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, xo);
         }
     }
     // (what the launch scored, for the roofline of the bench line: one atomic per wavefront)
@@ -1323,6 +641,10 @@ void k_fr_refine(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, FPoo
         if (it.flags & FI_REC_UPD) { hUp = it.hA; hDown = it.hB; hMid = it.hMid; distance = it.recDist; }
         else {
             hUp = r1.up >= 0 ? ftree(r1.whichChild ? T.nd[r1.up].upLeft : T.nd[r1.up].upRight) : -1;
+            if (fp.mat && fvalid(hUp)) {                                    // the parent's upper list in t1's own frame (M:7469-7470)
+                hUp = fpass_store(fp, av, c.m.lRef, laneId, hUp, r1.mutId, false);
+                if (hUp == -2) { S.state = FS_FALLBACK; continue; }
+            }
             hDown = ftree(r1.lower); hMid = ftree(r1.totUp); distance = r1.dist;
         }
         if (!fvalid(hUp) || !fvalid(hDown) || !fvalid(hMid)) { R.ok = -1; continue; }
@@ -1433,10 +755,12 @@ struct FrontierScratch {
     DevBuf<long long> toffW, toffA;
     DevBuf<int32_t> tn, tna, nodes, expQ, expNode;
     DevBuf<uint8_t> out, wideBr;
-    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, tot, lsize, lpos, lpar;
+    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, tot, lsize, lpos, lpar, passList;
     DevBuf<uint8_t> visit;
     DevBuf<unsigned long long> lvl;
     DevBuf<long long> vbase;
+    std::vector<unsigned long long> lastLvl;        // [levels][4]: the level ranges of the last call (frontier_level_profile)
+    std::vector<size_t> lastSlotsU, lastSlotsC;    // ... and the timing slots of its level kernels
     long long lastU = -1, lastC = -1;     // items of the last call (for frontier_export), -1: none
     long long needU = 0, needC = 0, needL = 0, needW = 0, needA = 0, needM = 0;   // what the last call asked of the pools, and its searches
     FPools lastPools{};
@@ -1456,7 +780,7 @@ void frontier_scratch_free(maple_ctx *c)
     F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
     F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
     F->expQ.release(); F->expNode.release();
-    F->perm.release(); F->perm2.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release();
+    F->perm.release(); F->perm2.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release(); F->passList.release();
     if (F->evFork) (void)hipEventDestroy(F->evFork);
     if (F->evJoin) (void)hipEventDestroy(F->evJoin);
     if (F->side) (void)hipStreamDestroy(F->side);
@@ -1464,16 +788,6 @@ void frontier_scratch_free(maple_ctx *c)
     c->frontier = nullptr;
 }
 
-#define FR_DISPATCH3(c, KERNEL, ...)                                                                       \
-    do {                                                                                                  \
-        const bool rv_ = (c)->dm.useRateVariation, u_ = (c)->dm.usingErrorRate, ss_ = (c)->dm.errorRateSiteSpecific; \
-        if (!rv_ && !u_) KERNEL<false, false, false> __VA_ARGS__;                                          \
-        else if (rv_ && !u_) KERNEL<true, false, false> __VA_ARGS__;                                       \
-        else if (!rv_ && u_ && !ss_) KERNEL<false, true, false> __VA_ARGS__;                               \
-        else if (!rv_ && u_ && ss_) KERNEL<false, true, true> __VA_ARGS__;                                 \
-        else if (rv_ && u_ && !ss_) KERNEL<true, true, false> __VA_ARGS__;                                 \
-        else KERNEL<true, true, true> __VA_ARGS__;                                                         \
-    } while (0)
 
 // Runs the searches nodes[0..m) through the frontier tier; out[k] as k_spr_search leaves it: status 0 / 1 / 2 / -1 final,
 // -5 = over `budget` expanded items (dense tier), FR_STATUS_FALLBACK = hand to the one-lane-per-search kernel.
@@ -1568,6 +882,14 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     fp.bw = F.bw.p; fp.ba = F.ba.p; fp.capBig = (long long)F.bw.cap;
     fp.ctr = (FCtr *)F.ctr.p; fp.S = (FSearch *)F.srch.p; fp.recs = (FRec *)F.recs.p;
     fp.capRecs = (long long)(F.recs.cap / sizeof(FRec));
+    // trees with MAT local references: the lists a search carries go through the reference branches it crosses
+    fp.mat = c->tree_has_mut ? 1 : 0;
+    fp.mv = mview(c);
+    fp.passList = nullptr; fp.capPass = 0;
+    if (fp.mat) {
+        HIPCK(c, F.passList.reserve_exact(std::max(F.passList.cap, (size_t)std::max<long long>(1 << 16, fp.capC / 8))));
+        fp.passList = F.passList.p; fp.capPass = (long long)F.passList.cap;
+    }
     hipStream_t s = c->stream;
     const bool dbgSync = c->tuning.verbose > 2;                            // (MAPLE_DEBUG=3: every launch awaited and named)
     auto stage = [&](const char *what) -> int {
@@ -1610,7 +932,8 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, hipStreamSynchronize(s));                                  // (wideIdx is a local)
     }
     const bool anyWide = useWide && !wideIdx.empty();
-    FR_DISPATCH3(c, k_fr_begin, <<<gridN, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, m, F.nodes.p, fp, dout, budget, zeroBudget,
+    // (the seeding of a tree with local references writes lists through the lanes' scratch slabs: no more lanes than slabs)
+    FR_DISPATCH3(c, k_fr_begin, <<<std::min(gridN, gridUpd), FR_BLOCK, 0, s>>>(c->d_model, av, T, P, m, F.nodes.p, fp, dout, budget, zeroBudget,
                                                             anyWide ? F.wideRow.p : nullptr, anyWide ? wide->forceWide : 0));
     HIPCK(c, hipGetLastError());
     if (anyWide && wide->rowsReady) HIPCK(c, hipStreamWaitEvent(s, wide->rowsReady, 0));   // (k_fr_cached reads the rows' bitmaps)
@@ -1633,6 +956,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     const hipStream_t s2 = F.side;
     auto level = [&]() -> int {                                            // the kernels of one level, each between its own events
         hipEvent_t a0, a1, b0, b1;
+        if (fp.mat) {                                                      // the removed lists of the items that crossed a reference branch
+            FR_DISPATCH3(c, k_fr_pass, <<<std::min(gridUpd, 256), FR_BLOCK, 0, s>>>(c->d_model, av, T, fp));
+            TRY(stage("k_fr_pass"));
+        }
         HIPCK(c, hipEventRecord(F.evFork, s));                             // (after the level's snap)
         HIPCK(c, hipStreamWaitEvent(s2, F.evFork, 0));
         TRY(maple_internal_ev_pair(c, &b0, &b1, MAPLE_K_FR_CACHED, 0.0, 0.0));
@@ -1649,10 +976,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, hipEventRecord(a0, s));
         k_fr_sort_level<<<512, FR_BLOCK, 0, s>>>(av, T, fp, heavyMin, bigMin);
         TRY(stage("k_fr_sort_level"));
-        FR_DISPATCH3(c, k_fr_updating, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, P, fp, budget, heavyMin));
+        TRY(fr_launch_updating(c, s, gridUpd, av, T, P, fp, budget, heavyMin));
         TRY(stage("k_fr_updating"));
         if (heavyMin > 0)
-            FR_DISPATCH3(c, k_fr_updating_wave, <<<gridWave, 64, 0, s>>>(c->d_model, av, T, P, fp, budget, heavyMin, scratchLanes));
+            TRY(fr_launch_updating_wave(c, s, gridWave, av, T, P, fp, budget, heavyMin, scratchLanes));
         TRY(stage("k_fr_updating_wave"));
         HIPCK(c, hipEventRecord(a1, s));
         HIPCK(c, hipStreamWaitEvent(s, F.evJoin, 0));
@@ -1661,10 +988,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     };
     for (;;) {
         for (int g = 0; g < 8; g++) {
-            k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC, fp.lvl, fp.maxLevels);
+            k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC, fp.lvl, fp.maxLevels, fp.capPass);
             TRY(level());
         }
-        k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC, fp.lvl, fp.maxLevels);
+        k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC, fp.lvl, fp.maxLevels, fp.capPass);
         HIPCK(c, hipGetLastError());
         HIPCK(c, hipMemcpyAsync(&hc, fp.ctr, sizeof(FCtr), hipMemcpyDeviceToHost, s));
         HIPCK(c, hipStreamSynchronize(s));
@@ -1761,6 +1088,12 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         F.needA = (long long)hc.usedA; F.needM = m;
     }
     F.lastU = std::min((long long)hc.usedU, fp.capU); F.lastC = std::min((long long)hc.usedC, fp.capC); F.lastPools = fp;
+    {
+        const int nl = std::min(levels, fp.maxLevels);
+        F.lastLvl.assign((size_t)nl * 4, 0ull);
+        if (nl) HIPCK(c, hipMemcpy(F.lastLvl.data(), fp.lvl, (size_t)nl * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        F.lastSlotsU = slotsU; F.lastSlotsC = slotsC;
+    }
     if (hc.overflow) F.lastU = F.lastC = -1;                              // (a pool overflowed: the item lists are not complete)
     if (stats) {
         stats->levels = levels; stats->itemsUpdating = (long long)hc.usedU; stats->itemsCached = (long long)hc.usedC;
@@ -1788,5 +1121,23 @@ int frontier_export(maple_ctx *c, long long cap, int32_t *q, int32_t *node, long
     HIPCK(c, hipMemcpyAsync(q, F->expQ.p, (size_t)tot * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(node, F->expNode.p, (size_t)tot * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    return MAPLE_OK;
+}
+
+// per level of the last frontier_search: updating / cached items and the HIP-event time of the level's two kernels (ms)
+int frontier_level_profile(maple_ctx *c, int cap, long long *itemsU, long long *itemsC, float *msU, float *msC, int *n)
+{
+    FrontierScratch *F = (FrontierScratch *)c->frontier;
+    if (!F) return fail(c, MAPLE_ERR_STATE, "no frontier search to report on");
+    const int nl = (int)std::min<size_t>(F->lastLvl.size() / 4, std::min(F->lastSlotsU.size(), F->lastSlotsC.size()));
+    *n = nl;
+    for (int l = 0; l < nl && l < cap; l++) {
+        itemsU[l] = (long long)(F->lastLvl[4 * l + 1] - F->lastLvl[4 * l]);
+        itemsC[l] = (long long)(F->lastLvl[4 * l + 3] - F->lastLvl[4 * l + 2]);
+        msU[l] = msC[l] = 0.f;
+        const size_t su = F->lastSlotsU[l], sc = F->lastSlotsC[l];
+        if (2 * su + 1 < c->ev_used) { HIPCK(c, hipEventSynchronize(c->evs[2 * su + 1])); HIPCK(c, hipEventElapsedTime(&msU[l], c->evs[2 * su], c->evs[2 * su + 1])); }
+        if (2 * sc + 1 < c->ev_used) { HIPCK(c, hipEventSynchronize(c->evs[2 * sc + 1])); HIPCK(c, hipEventElapsedTime(&msC[l], c->evs[2 * sc], c->evs[2 * sc + 1])); }
+    }
     return MAPLE_OK;
 }

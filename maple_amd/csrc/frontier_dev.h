@@ -1,0 +1,345 @@
+// maple_amd/csrc/frontier_dev.h -- what the translation units of the frontier tier share: the item / search / pool records,
+// the bump allocators of items and temporary lists, the permissive form of the reference's rules.  frontier.hip holds the
+// host side and the small kernels (seeding, cached-regime scoring, layout, replay, refinement, final selection);
+// frontier_upd.hip the kernels of the items that still update genome lists (the long compile).
+#pragma once
+#include "ctx_host.h"
+#include "frontier.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace frt {
+
+#define FR_BLOCK 256
+#ifndef FR_HEAVY_MULT
+#define FR_HEAVY_MULT 24               // (quarters of the mean list length: lists of this many entries together go one wavefront per item)
+#endif
+#ifndef FR_BIG_MIN
+#define FR_BIG_MIN 176
+#endif
+
+enum { FI_UPD_IN = 1, FI_UPD_OUT = 2, FI_SCORED = 4, FI_DEAD = 8, FI_REC_UPD = 16, FI_SEED = 32, FI_SEED_EMPTY = 64,
+       FI_NEEDPASS = 128 };             // (trees with MAT local references) hRpr is still in the frame of the item that pushed it: k_fr_pass
+// FS_WIDE: a whole-tree search whose row of the dense score table is being made next to this tier.  Its items that still
+// update genome lists are expanded here like any other's (they are what made such a search slow for one lane: up to 200
+// updating steps in a row); an item that arrives in the cached regime on the way DOWN is left as a seed (FI_SEED) -- the clade
+// below it is scanned over the score row by k_fr_replay_wide (wave_scan_clade, search_dev.h) when the exact walk gets there.
+enum { FS_ACTIVE = 0, FS_FINAL = 1, FS_OVER = 2, FS_FALLBACK = 3, FS_WIDE = 4 };
+__device__ __forceinline__ bool fs_live(int st) { return st == FS_ACTIVE || st == FS_WIDE; }
+#define FR_NONE (-1)
+
+struct alignas(32) FItem {
+    // what the exact replay reads and writes per pop, in one 32-byte sector (the walk of the longest search is a chain of
+    // dependent misses on these)
+    int8_t dir;                        // 0 = moving from a parent to its child, 1 / 2 = crawling up from child 0 / 1
+    uint8_t flags;
+    int16_t failsA;                    // failedPasses the replay arrives with
+    int32_t next;                      // stack link, then short-list link
+    int32_t child0, child1;            // item refs in push order: >= 0 cached pool, <= -2 updating pool -(i + 2), -1 none
+    double midProb, lastLK;
+    // in (written by the parent item's lane)
+    int32_t q, t1;
+    int32_t hPassed, hRpr;             // list handles: >= 0 temporary list, <= -10 tree list -(id + 10), -1 None
+    double distance, pathBest;
+    int16_t failsP, pad;               // failedPasses under the permissive rules
+    // out (written by the item's own lane)
+    int32_t hA, hB, hMid;              // short-list record of an item that was still updating (M:7073 / 7295)
+    double recDist;
+    int32_t pad2[2];
+};
+static_assert(sizeof(FItem) == 96, "FItem");
+
+// The items of a search once more, in the order the exact walk visits them (the child pushed last first): rank p + 1 is the first
+// item visited after rank p, p + size skips the subtree -- the walk of k_fr_replay is a forward scan over these 32-byte records
+// instead of a chase through 96-byte items scattered over gigabytes (one miss to HBM per pop).
+struct alignas(32) FVisit {
+    double midProb, lastLK;
+    int32_t ref, size;
+    int32_t parent;                    // rank of the item that pushed it (its failedPasses are handed on), -1 for a seed
+    uint8_t flags; int8_t dir; int16_t failsOut;
+};
+static_assert(sizeof(FVisit) == 32, "FVisit");
+
+struct FSearch {
+    int32_t node, parent, sibling;     // pruned node, its parent (`node` of findBestParentTopology), its sibling
+    int32_t hRpr0;
+    int32_t seed0, seed1;
+    int32_t nItems;                    // expanded so far (atomic)
+    int32_t state;
+    int32_t slHead, nApp, recBase, recCount;
+    int32_t isRemovedTip, pad;
+    double removedBLen, curLK;
+};
+
+struct FRec { int32_t q, ref; double optimized, top, bottom, app; int32_t ok, pad; };
+
+struct FCtr {                          // device-side bookkeeping of the level loop
+    // (what every lane READS at the start of a kernel, and each counter the lanes bump, on cache lines of their own)
+    alignas(128) unsigned long long loU;
+    unsigned long long hiU, loC, hiC;  // the current level
+    alignas(128) unsigned long long usedU;   // items allocated in the two pools
+    alignas(128) unsigned long long usedC;
+    alignas(128) unsigned long long permDown;     // the level's one-lane updating items by direction (k_fr_sort_level)
+    alignas(128) unsigned long long permUp;
+    alignas(128) unsigned long long permDownB;    // ... those with long lists (16 to a wavefront)
+    alignas(128) unsigned long long permUpB;
+    alignas(128) unsigned long long nLists;       // temporary lists
+    alignas(128) unsigned long long usedW;
+    alignas(128) unsigned long long usedA;
+    alignas(128) unsigned long long nRecs;
+    alignas(128) unsigned long long nPass;        // cached-regime items pushed across a MAT reference branch (passList)
+    unsigned long long loP, hiP;       // ... those of the current level
+    unsigned long long bigUsed;        // entries taken from the shared scratch of over-long lists (reset every level)
+    alignas(128) unsigned long long itemsU;
+    unsigned long long bytesU;         // items k_fr_updating walked and the bytes of the lists their mergeVectors read and wrote
+    alignas(128) unsigned long long scoredC;
+    unsigned long long bytesC;         // cached-regime items scored by k_fr_cached and their SURVEY 8d bytes (8 E + 8 A + 8)
+    int32_t overflow, nLevels;
+#ifdef MAPLE_SPR_PROFILE
+    unsigned long long dbgCnt[8], dbgT[8], dbgMax[8];   // k_fr_updating's one-lane items by size (entries of the two lists): count, ticks, slowest
+#endif
+};
+
+struct FPools {
+    FItem *U, *C;
+    long long capU, capC;
+    // temporary lists
+    uint2 *tw; double *ta;
+    long long *toffW, *toffA;
+    int32_t *tn, *tna;
+    long long capW, capA, capL;
+    FVisit *visit; long long capVisit;   // the layout of k_fr_layout_* (null: k_fr_replay chases the items)
+    int32_t *lsize, *lpos, *lpar;      // per item (updating pool first, then the cached pool): items in the subtree it heads, its
+                                       // rank in its search's visiting order (-1: not laid out), the rank of the item that pushed it
+    unsigned long long *lvl;           // [maxLevels][4]: loU, hiU, loC, hiC of every level
+    int32_t maxLevels;
+    int32_t *tot; long long *vbase;    // per search: items in its two seed subtrees, and where its visiting order starts
+    int32_t *perm, *perm2;             // the level's one-lane updating items: moving down from the front, crawling up from the back
+                                       // (perm2: those with long lists)
+    // per-lane scratch
+    uint2 *sw; double *sa; double *sais;
+    int32_t capE;                      // entries one lane's scratch list takes (aux: 5 per entry; ais: 2 per entry)
+    uint2 *bw; double *ba;             // shared scratch for the few lists longer than that (bump-allocated, reset every level)
+    long long capBig;
+    FCtr *ctr;
+    FSearch *S;
+    FRec *recs;
+    long long capRecs;
+    // trees with MAT local references (M:8296-8354): the lists of a node are written relative to the reference of its frame, and a
+    // search that crosses the branch above a reference node re-expresses what it carries (passGenomeListThroughBranch,
+    // M:6844-6847, 7111-7118, 7148-7155, 7359-7366, 7388-7395)
+    int32_t mat;                       // 1: the tree has reference nodes
+    MutViewS mv;
+    int32_t *passList; long long capPass;   // refs of the cached-pool items whose removed list is re-expressed at the start of their level
+};
+
+__device__ __forceinline__ FItem &item_of(const FPools &fp, int ref) { return ref >= 0 ? fp.C[ref] : fp.U[-(ref + 2)]; }
+
+struct FList { const uint2 *w; const double *aux; int32_t n, na; };
+
+__device__ __forceinline__ bool fvalid(int h) { return h >= 0 || h <= -10; }
+__device__ __forceinline__ int ftree(int listId) { return listId < 0 ? -1 : -(listId + 10); }
+__device__ __forceinline__ FList flist(const ArenaViewS &av, const FPools &fp, int h)
+{
+    if (h >= 0) return FList{fp.tw + fp.toffW[h], fp.ta + fp.toffA[h], fp.tn[h], fp.tna[h]};
+    const int id = -h - 10;
+    return FList{av.words + av.ent_off[id], av.aux + av.aux_off[id], av.n_ent[id], av.n_aux[id]};
+}
+__device__ __forceinline__ ListRef fref(const FList &l) { return ListRef{l.w, l.aux}; }
+
+// room for one list of up to `need` entries: the lane's own slab, or -- for the few lists near the root that are longer --
+// a piece of the shared scratch (false: none left)
+struct FScr { uint2 *w; double *a; };
+__device__ inline bool fscratch(const FPools &fp, long long laneId, int need, FScr &o)
+{
+    if (need <= fp.capE) { o.w = fp.sw + laneId * fp.capE; o.a = fp.sa + laneId * 5ll * fp.capE; return true; }
+    const unsigned long long off = atomicAdd(&fp.ctr->bigUsed, (unsigned long long)need);
+    if ((long long)(off + need) > fp.capBig) return false;
+    o.w = fp.bw + off; o.a = fp.ba + 5ull * off;
+    return true;
+}
+
+// a scratch list becomes a temporary list of the batch: exact room, one copy; -2 when the pools are full
+__device__ inline int fstore(const FPools &fp, const Writer &wr)
+{
+    // The lanes of a wavefront that are here together take their room with ONE atomic per counter: the three counters share a
+    // cache line with everything else the level loop counts, and a million single-lane atomics per level on it were what a
+    // level of k_fr_updating waited for.
+    const unsigned long long act = __ballot(1);
+    const int lane = threadIdx.x & 63, leader = (int)__ffsll((long long)act) - 1;
+    int preN = 0, preA = 0, totN = 0, totA = 0, rank = 0, cnt = 0;
+    for (unsigned long long mm = act; mm; mm &= mm - 1) {
+        const int j = (int)__ffsll((long long)mm) - 1;
+        const int nj = __builtin_amdgcn_readlane(wr.n, j), aj = __builtin_amdgcn_readlane(wr.na, j);
+        if (j < lane) { preN += nj; preA += aj; rank++; }
+        totN += nj; totA += aj; cnt++;
+    }
+    unsigned long long id0 = 0, ow0 = 0, oa0 = 0;
+    if (lane == leader) {
+        id0 = atomicAdd(&fp.ctr->nLists, (unsigned long long)cnt);
+        ow0 = atomicAdd(&fp.ctr->usedW, (unsigned long long)totN);
+        oa0 = atomicAdd(&fp.ctr->usedA, (unsigned long long)totA);
+    }
+    auto bc = [&](unsigned long long x) {
+        return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(x >> 32), leader) << 32)
+               | (uint32_t)__builtin_amdgcn_readlane((int)x, leader);
+    };
+    const unsigned long long id = bc(id0) + (unsigned long long)rank, ow = bc(ow0) + (unsigned long long)preN,
+                             oa = bc(oa0) + (unsigned long long)preA;
+    if ((long long)id >= fp.capL || (long long)(ow + wr.n) > fp.capW || (long long)(oa + wr.na) > fp.capA) {
+        fp.ctr->overflow = 1;
+        return -2;
+    }
+    uint2 *dw = fp.tw + ow;
+    double *da = fp.ta + oa;
+    for (int k = 0; k < wr.n; k++) dw[k] = wr.w[k];
+    for (int k = 0; k < wr.na; k++) da[k] = wr.aux[k];
+    fp.toffW[id] = (long long)ow; fp.toffA[id] = (long long)oa; fp.tn[id] = wr.n; fp.tna[id] = wr.na;
+    return (int)id;
+}
+
+// would shorten() (M:3721-3745) change this list?  (the absorb test of shorten_walk, genome_dev.h)
+template <class C> __device__ inline bool shorten_would_merge(const C &c, ListRef L, int nEnt)
+{
+    const double thr = c.m.thresholdProb;
+    Cursor a;
+    a.init(L);
+    Ent head = a.e;
+    for (int k = 1; k < nEnt; k++) {
+        a.next();
+        const Ent &nw = a.e;
+        if (nw.type == 4 && head.type == 4 && nw.hasD0 == head.hasD0 && nw.hasD1 == head.hasD1) {
+            if (!nw.hasD0) return true;
+            if (!(fabs(nw.d0 - head.d0) > thr) && !(nw.hasD1 && fabs(nw.d1 - head.d1) > thr) && nw.flag == head.flag) return true;
+        }
+        head = nw;
+    }
+    return false;
+}
+
+// passGenomeListThroughBranch (M:3749-3877) of list h through mutation list mutId: the handle of a new temporary list, h itself
+// when the branch carries no mutations, -2 when there is no room.  (h must be a stored list: the lane's scratch is written.)
+__device__ inline int fpass_store(const FPools &fp, const ArenaViewS &av, const int lRef, const long long laneId, const int h, const int mutId,
+                                  const bool dirUp)
+{
+    if (!fvalid(h) || mutId < 0) return h;
+    const int cnt = fp.mv.cnt[mutId];
+    if (cnt == 0) return h;
+    const FList l = flist(av, fp, h);
+    FScr scr{nullptr, nullptr};
+    if (!fscratch(fp, laneId, l.n + 2 * cnt, scr)) return -2;
+    Writer wr;
+    wr.init(scr.w, scr.a);
+    pass_walk(lRef, fref(l), fp.mv.mut3 + 3 * fp.mv.off[mutId], cnt, dirUp, wr);
+    return fstore(fp, wr);
+}
+// ... of the REMOVED list: the reference shortens that one in place at every improvement (M:7087); a search whose re-expressed
+// removed list shorten() would change is handed to the one-lane kernel, which does just that (-3)
+template <class C>
+__device__ inline int fpass_removed(const C &c, const FPools &fp, const ArenaViewS &av, const long long laneId, const int h, const int mutId,
+                                    const bool dirUp)
+{
+    const int r = fpass_store(fp, av, c.m.lRef, laneId, h, mutId, dirUp);
+    if (r == h || !fvalid(r)) return r;
+    const FList l = flist(av, fp, r);
+    return shorten_would_merge(c, fref(l), l.n) ? -3 : r;
+}
+
+// one more expanded item of search q; false when the search is over its budget (it becomes a dense-tier search) or the pool
+// is full (the search is handed back)
+__device__ inline int fpush(const FPools &fp, const int budget, const int q, const bool upd, const int t1, const int dir,
+                            const int hPassed, const double distance, const double lastLK, const int fails, const int hRpr,
+                            const double pathBest, const bool needPass = false)
+{
+    FSearch &S = fp.S[q];
+    if (S.state != FS_WIDE && atomicAdd(&S.nItems, 1) >= budget) { S.state = FS_OVER; return FR_NONE; }
+    FItem *it;
+    int ref;
+    // one atomic per wavefront and pool: the lanes that are here together take consecutive items
+    unsigned long long *ctrp = upd ? &fp.ctr->usedU : &fp.ctr->usedC;
+    const unsigned long long act = __ballot(1);
+    const int lane = threadIdx.x & 63, leader = (int)__ffsll((long long)act) - 1;
+    const unsigned long long same = __ballot(upd);                           // (lanes pushing into the updating pool)
+    const unsigned long long mine = upd ? (act & same) : (act & ~same);
+    const int lead2 = (int)__ffsll((long long)mine) - 1;
+    unsigned long long base = 0;
+    if (lane == lead2) base = atomicAdd(ctrp, (unsigned long long)__popcll(mine));
+    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), lead2, 64) << 32) | (uint32_t)__shfl((int)base, lead2, 64);
+    (void)leader;
+    const unsigned long long i = base + (unsigned long long)__popcll(mine & ((1ull << lane) - 1ull));
+    if (upd) {
+        if ((long long)i >= fp.capU) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; return FR_NONE; }
+        it = &fp.U[i]; ref = -((int)i + 2);
+    } else {
+        if ((long long)i >= fp.capC) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; return FR_NONE; }
+        it = &fp.C[i]; ref = (int)i;
+    }
+    it->q = q; it->t1 = t1; it->dir = (int8_t)dir; it->flags = upd ? FI_UPD_IN : 0; it->failsP = (int16_t)fails;
+    it->hPassed = hPassed; it->hRpr = hRpr; it->distance = distance; it->lastLK = lastLK; it->pathBest = pathBest;
+    it->child0 = it->child1 = FR_NONE; it->hA = it->hB = it->hMid = -1; it->next = FR_NONE; it->failsA = 0;
+    it->midProb = lastLK; it->recDist = 0.0;
+    if (needPass) {                                                         // (rare: ~1 push in 100 crosses a reference branch)
+        it->flags |= FI_NEEDPASS;
+        const unsigned long long k = atomicAdd(&fp.ctr->nPass, 1ull);
+        if ((long long)k >= fp.capPass) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; }
+        else fp.passList[k] = ref;
+    }
+    return ref;
+}
+
+// The permissive form of the reference's rules after an item was scored (M:7083-7103 / 7306-7323): failedPasses under
+// pathBest, the new pathBest, and whether the item's relatives are pushed.
+struct PRule { int fails; double pathBest; bool go; };
+__device__ __forceinline__ PRule p_rule(const SearchParams &P, bool scored, double midProb, double lastLK, int fails, double pathBest)
+{
+    PRule r;
+    r.fails = fails; r.pathBest = pathBest;
+    if (scored) {
+        if (midProb > pathBest) { r.pathBest = midProb; r.fails = 0; }
+        else if (midProb < (lastLK - P.thrConsec)) r.fails = fails + 1;
+    }
+    // (the reference tests against the running best AFTER it took this score into account: pathBest is updated first, too)
+    const bool within = midProb > (r.pathBest - P.thrLKtopology);
+    r.go = P.strict ? (r.fails <= P.allowedFails && within) : (r.fails <= P.allowedFails || within);
+    return r;
+}
+
+// Is this item one of the few with long lists (near the root)?  One lane walking two lists of several hundred entries takes
+// milliseconds, and a level of the expansion lasts as long as its slowest item: those go to k_fr_updating_wave, a wavefront
+// per item.
+__device__ __forceinline__ int fr_upd_size(const ArenaViewS &av, const DevTree &T, const FPools &fp, const FItem &it)
+{
+    if (it.dir == 3) return 0;
+    const NodeRec &r1 = T.nd[it.t1];
+    const int other = it.dir == 0 ? it.t1 : (it.dir == 1 ? r1.c1 : r1.c0);
+    const int lw = T.nd[other].lower;
+    const int nTree = lw >= 0 ? av.n_ent[lw] : 0;
+    const int nPass = it.hPassed >= 0 ? fp.tn[it.hPassed] : (it.hPassed <= -10 ? av.n_ent[-it.hPassed - 10] : 0);
+    return nPass + nTree;
+}
+__device__ __forceinline__ bool fr_upd_heavy(const ArenaViewS &av, const DevTree &T, const FPools &fp, const FItem &it, int heavyMin)
+{
+    return heavyMin > 0 && it.dir != 3 && fr_upd_size(av, T, fp, it) >= heavyMin;
+}
+
+}  // namespace frt
+
+#define FR_DISPATCH3(c, KERNEL, ...)                                                                       \
+    do {                                                                                                  \
+        const bool rv_ = (c)->dm.useRateVariation, u_ = (c)->dm.usingErrorRate, ss_ = (c)->dm.errorRateSiteSpecific; \
+        if (!rv_ && !u_) KERNEL<false, false, false> __VA_ARGS__;                                          \
+        else if (rv_ && !u_) KERNEL<true, false, false> __VA_ARGS__;                                       \
+        else if (!rv_ && u_ && !ss_) KERNEL<false, true, false> __VA_ARGS__;                               \
+        else if (!rv_ && u_ && ss_) KERNEL<false, true, true> __VA_ARGS__;                                 \
+        else if (rv_ && u_ && !ss_) KERNEL<true, true, false> __VA_ARGS__;                                 \
+        else KERNEL<true, true, true> __VA_ARGS__;                                                         \
+    } while (0)
+
+// the level kernels of frontier_upd.hip, queued on stream s (kernels of another translation unit cannot be launched directly)
+__attribute__((visibility("hidden")))
+int fr_launch_updating(maple_ctx *c, hipStream_t s, int grid, const ArenaViewS &av, const DevTree &T, const SearchParams &P, const frt::FPools &fp,
+                       int budget, int heavyMin);
+__attribute__((visibility("hidden")))
+int fr_launch_updating_wave(maple_ctx *c, hipStream_t s, int grid, const ArenaViewS &av, const DevTree &T, const SearchParams &P,
+                            const frt::FPools &fp, int budget, int heavyMin, long long laneBase);

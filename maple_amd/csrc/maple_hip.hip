@@ -3104,8 +3104,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // tips, full model: 460 ms against 541).
     bool assistOK = !c->dm.usingErrorRate;
     const bool assistFew = !c->dm.usingErrorRate;      // few searching lanes per wavefront, every request served by all 64 lanes
-    // (the frontier tier, frontier.hip, takes the searches of trees without MAT local references)
-    const bool useFrontier = sp->searchTier == 0 && !c->tree_has_mut && c->trace_query < 0;
+    // (the frontier tier, frontier.hip / frontier_upd.hip; searchTier 1 keeps every search in the one-lane kernels)
+    const bool useFrontier = sp->searchTier == 0 && c->trace_query < 0;
     const std::vector<int32_t> *rowOverride = nullptr;                 // rows of the score table the next cached launch reads
     FiniteRows finRows{nullptr, nullptr, 0};                           // ... and, where the rows come with one, the bitmap of their finite scores
     const int finWords = (c->n_scored + 63) / 64;                      // (words per row: one per tile of 64 candidates of the dense kernel)
@@ -3726,6 +3726,17 @@ extern "C" int maple_spr_search_visited(maple_ctx *c, int64_t cap, int32_t *quer
         return fail(c, MAPLE_ERR_STATE, "the last maple_spr_search_batch did not run wholly in the frontier tier (use wideSearchBudget < 0)");
     long long nn = 0;
     const int rc = frontier_export(c, cap, query, node, &nn);
+    *n = nn;
+    return rc;
+}
+
+extern "C" int maple_debug_frontier_levels(maple_ctx *c, int32_t cap, int64_t *itemsUpdating, int64_t *itemsCached, float *msUpdating,
+                                           float *msCached, int32_t *n)
+{
+    if (!c || cap < 0 || !itemsUpdating || !itemsCached || !msUpdating || !msCached || !n) return MAPLE_ERR_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    int nn = 0;
+    const int rc = frontier_level_profile(c, cap, (long long *)itemsUpdating, (long long *)itemsCached, msUpdating, msCached, &nn);
     *n = nn;
     return rc;
 }

@@ -25,7 +25,7 @@ EXPORTS = [
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
     "maple_timing_read_kind", "maple_placement_supports_batch", "maple_debug_gpv_batch", "maple_debug_simplify_batch",
-    "maple_candset_destroy", "maple_debug_calib_write", "maple_spr_search_visited", "maple_arena_compact", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev",
+    "maple_candset_destroy", "maple_debug_calib_write", "maple_spr_search_visited", "maple_arena_compact", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev", "maple_debug_frontier_levels",
 ]
 
 
@@ -565,6 +565,15 @@ class Device:
         n = C.c_int32()
         self._ck(self.lib.maple_timing_read_each(self.h, int(cap), _ptr(ms), C.byref(n)))
         return ms[: n.value].tolist()
+
+    def frontier_levels(self, cap=4096):
+        """Per level of the last frontier-tier pass: (updating items, cached items, ms of k_fr_updating, ms of k_fr_cached)."""
+        iu, ic = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
+        mu, mc = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        n = C.c_int32()
+        self._ck(self.lib.maple_debug_frontier_levels(self.h, int(cap), _ptr(iu), _ptr(ic), _ptr(mu), _ptr(mc), C.byref(n)))
+        k = min(cap, n.value)
+        return iu[:k], ic[:k], mu[:k], mc[:k]
 
     def timing_read(self):
         """(number of timed *_dev launches since the last reset, their summed HIP-event time in ms)."""

@@ -647,3 +647,33 @@ def test_deep_round_with_error_model_at_20k_tips_frontier_tier_equals_lane_tier(
             assert np.array_equal(g[k], lane[k]), (budget, k)
     assert (g["status"] == 0).sum() > 30000 and g["nAppend"].sum() > 1e7
     dev.close()
+
+
+@pytest.mark.parametrize("mode", ["unrest", "ratevar", "siteerr"])
+def test_frontier_tier_on_a_tree_with_local_references_equals_the_lane_tier(mode):
+    """Trees as MAPLE makes them carry MAT local references (makeNodeReference, M:8296-8354; here setUpMAT's rule, 50 descendants per
+    reference node): a search re-expresses the lists it carries at every reference branch it crosses (M:6844-6847, 7111-7118,
+    7148-7155, 7359-7366, 7388-7395).  The frontier tier (items carry the removed list of their frame; a list that leaves a frame goes
+    through passGenomeListThroughBranch) against the one-lane-per-search kernels on a 10 000-tip tree, every search of a deep
+    round: status, node ids, moves, candidate counts, scores and branch lengths bit for bit -- with and without the hand-over of
+    long searches to the dense tier."""
+    import bench
+    from maple_amd.mat import add_local_references
+    from maple_amd.tree_host import HostTree
+    data, dev, orc, m = build(10000, mode, seed=4)
+    ht = HostTree.from_mirror(m)
+    n_ref = add_local_references(dev, ht, 50)
+    assert n_ref > 100
+    dist = np.asarray([float(x or 0.0) for x in ht.dist])
+    dev.upload_tree(ht.root, m.parent, m.children[:, 0], m.children[:, 1], dist, m.is_tip, ht.id_lower, ht.id_upRight, ht.id_upLeft,
+                    ht.id_totUp, ht.id_mut)
+    kw = bench.search_kwargs(dev.lRef)
+    nodes = bench.preorder_nodes(m)
+    for budget in (-1, 0):
+        lane = dev.spr_search_batch(nodes, search_tier=1, wide_search_budget=budget, **kw)
+        for _ in range(2):                                              # (the second call: pools sized by the first)
+            g = dev.spr_search_batch(nodes, wide_search_budget=budget, **kw)
+            for k in ("status", "bestNode", "placement", "nAppend", "bestScore", "currentLK", "improvement", "blen"):
+                assert np.array_equal(g[k], lane[k]), (budget, k, int((g[k] != lane[k]).sum()))
+    assert (g["status"] == 0).sum() > 15000 and g["nAppend"].sum() > 1e7
+    dev.close()
