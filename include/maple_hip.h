@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MAPLE_ABI_VERSION 2
+#define MAPLE_ABI_VERSION 3
 
 enum {
     MAPLE_OK = 0,
@@ -85,6 +85,8 @@ typedef struct {
                                    from their first step (k_spr_search), instead of sharing its batched updating steps */
     int32_t denseWideScoring;   /* 1: the whole-tree SPR searches known beforehand are scored against EVERY branch by the dense kernel
                                    instead of only against the branches their witness filter cannot rule out (witness.hip) */
+    int32_t waveAllBelow;       /* frontier tier of the SPR search: a level of the expansion with at most this many items that still
+                                   update genome lists is walked one WAVEFRONT per item (0 = the library's choice, -1 = never) */
 } maple_tuning;
 int maple_set_tuning(maple_ctx *ctx, const maple_tuning *t);
 const char *maple_last_error(maple_ctx *ctx);

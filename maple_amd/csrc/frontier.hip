@@ -84,12 +84,13 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
         // the removed list as the search starts with it (M:6838-6846): in the frame of the pruned node's parent, and once more in
         // the sibling's (bestRemovedPartials).  A re-expressed list that shorten() (M:7087) would change: the one-lane kernel.
         int rpr = ftree(rn.lower);
-        bool wouldMerge = shorten_would_merge(c, fref(ll), ll.n);           // M:7087 would edit the removed list
+        const bool wouldMerge = shorten_would_merge(c, fref(ll), ll.n);     // M:7087 would edit the removed list (see fpass_removed)
+        S.rprMerge0 = wouldMerge ? 1 : 0;
         int hBest = rpr;
-        if (fp.mat && !wouldMerge) {
+        if (fp.mat) {
             rpr = fpass_removed(c, fp, av, laneId, rpr, rn.mutId, true);
             hBest = fvalid(rpr) ? fpass_removed(c, fp, av, laneId, rpr, rs.mutId, false) : rpr;
-            if (!fvalid(rpr) || !fvalid(hBest)) wouldMerge = true;          // (-2 / -3: handed back either way)
+            if (!fvalid(rpr) || !fvalid(hBest)) { S.state = FS_FALLBACK; continue; }
         }
         S.hRpr0 = hBest;
         // a search from a zero-length branch without an error model is a whole-tree search (see k_spr_search): dense tier
@@ -101,7 +102,6 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
             wide = rowOf && rowOf[q] >= 0 && !wouldMerge;
             if (!wide) { S.state = FS_OVER; o.status = -5; continue; }
         }
-        if (wouldMerge) { S.state = FS_FALLBACK; continue; }
         S.state = wide ? FS_WIDE : FS_ACTIVE;
         if (rp.up < 0) {                                                    // the parent is the root (M:6916-6960): seeded by an item
             S.seed0 = fpush(fp, budget, q, true, S.sibling, 3, -1, 0.0, curLK, 0, S.hRpr0, curLK);   // of its own (k_fr_updating)
@@ -138,7 +138,7 @@ __global__ void k_fr_snap(FCtr *ctr, long long capU, long long capC, unsigned lo
         ctr->loC = ctr->hiC; ctr->hiC = min(ctr->usedC, (unsigned long long)capC);
         ctr->loP = ctr->hiP; ctr->hiP = min(ctr->nPass, (unsigned long long)capPass);
         ctr->bigUsed = 0;
-        ctr->permDown = ctr->permUp = ctr->permDownB = ctr->permUpB = 0;
+        ctr->permDown = ctr->permUp = ctr->permDownB = ctr->permUpB = ctr->permHeavy = 0;
         if (lvl) {
             const int l = ctr->nLevels++;
             if (l < maxLevels) { lvl[4 * l] = ctr->loU; lvl[4 * l + 1] = ctr->hiU; lvl[4 * l + 2] = ctr->loC; lvl[4 * l + 3] = ctr->hiC; }
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_sort_level(ArenaViewS av, DevTr
     const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
     const long long n = hi - lo;
     const int lane = threadIdx.x & 63;
+    heavyMin = fr_level_heavy_min(fp, heavyMin);
     auto bc = [](unsigned long long x) {
         return ((unsigned long long)(uint32_t)__shfl((int)(x >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)x, 0, 64);
     };
@@ -196,6 +197,15 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_sort_level(ArenaViewS av, DevTr
             if (!(heavyMin > 0 && it.dir != 3 && sz >= heavyMin)) kind = (it.dir == 0 ? 0 : 1) + (sz >= bigMin ? 2 : 0);
         }
         const unsigned long long below = (1ull << lane) - 1ull;
+        {   // the items that go a wavefront each (kind -1)
+            const unsigned long long mh = __ballot(i < n && kind == -1);
+            if (mh) {
+                unsigned long long b0 = 0;
+                if (lane == 0) b0 = atomicAdd(&fp.ctr->permHeavy, (unsigned long long)__popcll(mh));
+                b0 = bc(b0);
+                if (i < n && kind == -1) fp.perm3[(long long)(b0 + __popcll(mh & below))] = (int32_t)i;
+            }
+        }
         for (int k = 0; k < 4; k++) {
             const unsigned long long mk = __ballot(kind == k);
             if (!mk) continue;
@@ -382,6 +392,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
         if (S.state != FS_ACTIVE) continue;
         double best = S.curLK;
         int nApp = 0, slHead = FR_NONE, slTail = FR_NONE;
+        bool marked = false;
         if (fp.visit && fp.vbase[q + 1] <= fp.capVisit) {
             // the same walk as a forward scan over the search's items in visiting order
             const long long end = fp.vbase[q + 1];
@@ -401,7 +412,12 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
                         if (slTail == FR_NONE) slHead = ref; else item_of(fp, slTail).next = ref;
                         slTail = ref;
                     }
-                    if (mp > best) { best = mp; fails = 0; }
+                    if (mp > best) {
+                        best = mp; fails = 0;
+                        // (M:7087: the reference shortens the branch's removed list in place here; if that changes the list, the
+                        // one-lane kernel takes the search)
+                        if (rec.dir == 0 && frpr_marked(fp, S, item_of(fp, rec.ref).hRpr)) { marked = true; break; }
+                    }
                     else if (mp < (rec.lastLK - P.thrConsec)) fails++;
                 }
                 const bool within = mp > (best - P.thrLKtopology);
@@ -433,7 +449,10 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
                     if (slTail == FR_NONE) slHead = ref; else item_of(fp, slTail).next = ref;
                     slTail = ref;
                 }
-                if (mp > best) { best = mp; fails = 0; }
+                if (mp > best) {
+                    best = mp; fails = 0;
+                    if (it.dir == 0 && frpr_marked(fp, S, it.hRpr)) { marked = true; break; }   // (M:7087, see above)
+                }
                 else if (mp < (it.lastLK - P.thrConsec)) fails++;
             }
             const bool within = mp > (best - P.thrLKtopology);
@@ -443,6 +462,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
             push(it.child1, fails);
         }
         }
+        if (marked) { S.state = FS_FALLBACK; out[q].status = FR_STATUS_FALLBACK; continue; }
         S.slHead = slHead; S.nApp = nApp;
         // the short-listed branches that are refined (M:7465: within thresholdLogLKoptimizationTopology of the ORIGINAL cost)
         int cnt = 0;
@@ -754,8 +774,8 @@ struct FrontierScratch {
     DevBuf<double> ta, sa, sais, ba;
     DevBuf<long long> toffW, toffA;
     DevBuf<int32_t> tn, tna, nodes, expQ, expNode;
-    DevBuf<uint8_t> out, wideBr;
-    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, tot, lsize, lpos, lpar, passList;
+    DevBuf<uint8_t> out, wideBr, tflag;
+    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, perm3, tot, lsize, lpos, lpar, passList;
     DevBuf<uint8_t> visit;
     DevBuf<unsigned long long> lvl;
     DevBuf<long long> vbase;
@@ -780,7 +800,7 @@ void frontier_scratch_free(maple_ctx *c)
     F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
     F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
     F->expQ.release(); F->expNode.release();
-    F->perm.release(); F->perm2.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release(); F->passList.release();
+    F->perm.release(); F->perm2.release(); F->perm3.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release(); F->passList.release(); F->tflag.release();
     if (F->evFork) (void)hipEventDestroy(F->evFork);
     if (F->evJoin) (void)hipEventDestroy(F->evJoin);
     if (F->side) (void)hipStreamDestroy(F->side);
@@ -847,6 +867,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, F.toffA.reserve_exact(grow((size_t)capL, F.toffA.cap)));
     HIPCK(c, F.tn.reserve_exact(grow((size_t)capL, F.tn.cap)));
     HIPCK(c, F.tna.reserve_exact(grow((size_t)capL, F.tna.cap)));
+    HIPCK(c, F.tflag.reserve_exact(grow((size_t)capL, F.tflag.cap)));
     HIPCK(c, F.sw.reserve_exact((size_t)(scratchLanes + 512) * capE));     // (+ one slab per wavefront of k_fr_updating_wave)
     HIPCK(c, F.sa.reserve_exact((size_t)(scratchLanes + 512) * capE * 5));
     HIPCK(c, F.sais.reserve_exact((size_t)(scratchLanes + 512) * capE * 2));
@@ -859,10 +880,13 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     fp.capU = (long long)(F.itemsU.cap / sizeof(FItem)); fp.capC = (long long)(F.itemsC.cap / sizeof(FItem));
     fp.tw = F.tw.p; fp.ta = F.ta.p; fp.toffW = F.toffW.p; fp.toffA = F.toffA.p; fp.tn = F.tn.p; fp.tna = F.tna.p;
     fp.capW = (long long)F.tw.cap; fp.capA = (long long)F.ta.cap;
-    fp.capL = (long long)std::min(std::min(F.toffW.cap, F.toffA.cap), std::min(F.tn.cap, F.tna.cap));
+    fp.tflag = F.tflag.p;
+    fp.capL = (long long)std::min(std::min(std::min(F.toffW.cap, F.toffA.cap), std::min(F.tn.cap, F.tna.cap)), F.tflag.cap);
     HIPCK(c, F.perm.reserve_exact(std::max(F.perm.cap, (size_t)fp.capU)));
     HIPCK(c, F.perm2.reserve_exact(std::max(F.perm2.cap, (size_t)fp.capU)));
-    fp.perm = F.perm.p; fp.perm2 = F.perm2.p;
+    HIPCK(c, F.perm3.reserve_exact(std::max(F.perm3.cap, (size_t)fp.capU)));
+    fp.perm = F.perm.p; fp.perm2 = F.perm2.p; fp.perm3 = F.perm3.p;
+    fp.waveAllBelow = c->tuning.waveAllBelow > 0 ? c->tuning.waveAllBelow : (c->tuning.waveAllBelow < 0 ? 0 : 6144);
     // the visiting-order layout of the items (k_fr_layout_*): one 32-byte record per item, the levels' ranges, per-search bases
     fp.maxLevels = 4096;
     fp.capVisit = fp.capU + fp.capC;

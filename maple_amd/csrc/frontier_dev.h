@@ -68,7 +68,8 @@ struct FSearch {
     int32_t nItems;                    // expanded so far (atomic)
     int32_t state;
     int32_t slHead, nApp, recBase, recCount;
-    int32_t isRemovedTip, pad;
+    int32_t isRemovedTip;
+    int32_t rprMerge0;                 // shorten() (M:7087) would change the pruned node's own lower list (never so for a stored list)
     double removedBLen, curLK;
 };
 
@@ -84,6 +85,7 @@ struct FCtr {                          // device-side bookkeeping of the level l
     alignas(128) unsigned long long permUp;
     alignas(128) unsigned long long permDownB;    // ... those with long lists (16 to a wavefront)
     alignas(128) unsigned long long permUpB;
+    alignas(128) unsigned long long permHeavy;    // ... those that go a wavefront each (k_fr_updating_wave)
     alignas(128) unsigned long long nLists;       // temporary lists
     alignas(128) unsigned long long usedW;
     alignas(128) unsigned long long usedA;
@@ -108,6 +110,7 @@ struct FPools {
     uint2 *tw; double *ta;
     long long *toffW, *toffA;
     int32_t *tn, *tna;
+    uint8_t *tflag;                    // per temporary list: 1 = a removed list that shorten() (M:7087) would change
     long long capW, capA, capL;
     FVisit *visit; long long capVisit;   // the layout of k_fr_layout_* (null: k_fr_replay chases the items)
     int32_t *lsize, *lpos, *lpar;      // per item (updating pool first, then the cached pool): items in the subtree it heads, its
@@ -117,6 +120,8 @@ struct FPools {
     int32_t *tot; long long *vbase;    // per search: items in its two seed subtrees, and where its visiting order starts
     int32_t *perm, *perm2;             // the level's one-lane updating items: moving down from the front, crawling up from the back
                                        // (perm2: those with long lists)
+    int32_t *perm3;                    // the level's items walked by a wavefront each
+    int32_t waveAllBelow;              // a level with at most this many updating items: all of them by wavefronts
     // per-lane scratch
     uint2 *sw; double *sa; double *sais;
     int32_t capE;                      // entries one lane's scratch list takes (aux: 5 per entry; ais: 2 per entry)
@@ -195,7 +200,7 @@ __device__ inline int fstore(const FPools &fp, const Writer &wr)
     double *da = fp.ta + oa;
     for (int k = 0; k < wr.n; k++) dw[k] = wr.w[k];
     for (int k = 0; k < wr.na; k++) da[k] = wr.aux[k];
-    fp.toffW[id] = (long long)ow; fp.toffA[id] = (long long)oa; fp.tn[id] = wr.n; fp.tna[id] = wr.na;
+    fp.toffW[id] = (long long)ow; fp.toffA[id] = (long long)oa; fp.tn[id] = wr.n; fp.tna[id] = wr.na; fp.tflag[id] = 0;
     return (int)id;
 }
 
@@ -234,16 +239,25 @@ __device__ inline int fpass_store(const FPools &fp, const ArenaViewS &av, const 
     pass_walk(lRef, fref(l), fp.mv.mut3 + 3 * fp.mv.off[mutId], cnt, dirUp, wr);
     return fstore(fp, wr);
 }
-// ... of the REMOVED list: the reference shortens that one in place at every improvement (M:7087); a search whose re-expressed
-// removed list shorten() would change is handed to the one-lane kernel, which does just that (-3)
+// ... of the REMOVED list.  The reference shortens that list IN PLACE whenever a branch on the way down beats the running best
+// (M:7087), and everything made from it afterwards sees the shortened form.  The expansion never shortens; a list that
+// shorten() would change is only MARKED here, and the exact walk (k_fr_replay) hands a search to the one-lane kernel -- which
+// does what the reference does -- if such a list is ever held by a branch that beats the running best.  (Beating the cost of
+// the current placement is rare; a marked list is not: a list re-expressed in a frame that shares a mutation with it gains an
+// R entry next to two others.)
 template <class C>
 __device__ inline int fpass_removed(const C &c, const FPools &fp, const ArenaViewS &av, const long long laneId, const int h, const int mutId,
                                     const bool dirUp)
 {
     const int r = fpass_store(fp, av, c.m.lRef, laneId, h, mutId, dirUp);
-    if (r == h || !fvalid(r)) return r;
+    if (r == h || r < 0) return r;                                          // (unchanged, or -2: no room)
     const FList l = flist(av, fp, r);
-    return shorten_would_merge(c, fref(l), l.n) ? -3 : r;
+    if (shorten_would_merge(c, fref(l), l.n)) fp.tflag[r] = 1;
+    return r;
+}
+__device__ __forceinline__ bool frpr_marked(const FPools &fp, const FSearch &S, const int h)
+{
+    return h >= 0 ? fp.tflag[h] != 0 : (h <= -10 && S.rprMerge0 != 0);
 }
 
 // one more expanded item of search q; false when the search is over its budget (it becomes a dense-tier search) or the pool
@@ -321,6 +335,14 @@ __device__ __forceinline__ int fr_upd_size(const ArenaViewS &av, const DevTree &
 __device__ __forceinline__ bool fr_upd_heavy(const ArenaViewS &av, const DevTree &T, const FPools &fp, const FItem &it, int heavyMin)
 {
     return heavyMin > 0 && it.dir != 3 && fr_upd_size(av, T, fp, it) >= heavyMin;
+}
+// One lane takes milliseconds for an item whatever the GPU is doing, and a level waits for its slowest item: a level with few
+// items -- every level past the first ten, where a few thousand searches near the root are still updating lists -- is walked by
+// wavefronts altogether (~0.1 ms per item, a few hundred at a time).
+__device__ __forceinline__ int fr_level_heavy_min(const FPools &fp, int heavyMin)
+{
+    const long long n = (long long)(fp.ctr->hiU - fp.ctr->loU);
+    return (heavyMin > 0 && n <= fp.waveAllBelow) ? 1 : heavyMin;
 }
 
 }  // namespace frt

@@ -63,7 +63,7 @@ __device__ __forceinline__ void fr_upd_item_lane(const Ctx<RV, U, SS> &c, const 
             if (wr.n == lr.n) return hr;                                   // nothing merged: the list as it is
             return fstore(fp, wr);
         };
-        // a stored list through the branch above a node (-2: no room); the removed list likewise (-2 / -3: the search is handed back)
+        // a stored list through the branch above a node (-2: no room); the removed list likewise
         auto passL = [&](int h, int mutId, bool up) -> int { return MAT ? fpass_store(fp, av, c.m.lRef, laneId, h, mutId, up) : h; };
         auto passR = [&](int h, int mutId, bool up) -> int { return MAT ? fpass_removed(c, fp, av, laneId, h, mutId, up) : h; };
         if (it.dir == 3) {                                                  // the pruned node's parent is the root; t1 = its sibling
@@ -315,7 +315,7 @@ __device__ inline int fstore_wave(const FPools &fp, const unsigned long long *w,
     double *da = fp.ta + oa;
     for (int k = lane; k < n; k += 64) dw[k] = w[k];
     for (int k = lane; k < na; k += 64) da[k] = a[k];
-    if (lane == 0) { fp.toffW[id] = (long long)ow; fp.toffA[id] = (long long)oa; fp.tn[id] = n; fp.tna[id] = na; }
+    if (lane == 0) { fp.toffW[id] = (long long)ow; fp.toffA[id] = (long long)oa; fp.tn[id] = n; fp.tna[id] = na; fp.tflag[id] = 0; }
     __threadfence();
     wave_sync();
     return (int)id;
@@ -333,15 +333,13 @@ __global__ __launch_bounds__(64) void k_fr_updating_wave(const DevModel *__restr
     const int lane = threadIdx.x;
     WaveLds &W = *reinterpret_cast<WaveLds *>(L.baux);                     // (appendProbNode's staging: baux is free by then)
     static_assert(sizeof(WaveLds) <= sizeof(L.baux), "LDS alias");
-    const long long lo = (long long)fp.ctr->loU, hi = (long long)fp.ctr->hiU;
-    for (long long base = lo + (long long)blockIdx.x * 64; base < hi; base += (long long)gridDim.x * 64) {
-        const long long mine = base + lane;
-        const bool heavy = mine < hi && fr_upd_heavy(av, T, fp, fp.U[mine], heavyMin);
-        unsigned long long todo = __ballot(heavy);
-        while (todo) {
-            const int j = (int)__ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const long long i = base + j;
+    const long long lo = (long long)fp.ctr->loU;
+    // the level's items that go a wavefront each, listed by k_fr_sort_level (perm3): dealt to the wavefronts one at a time
+    const long long nHeavy = (long long)fp.ctr->permHeavy;
+    (void)heavyMin;
+    for (long long kk = blockIdx.x; kk < nHeavy; kk += gridDim.x) {
+        {
+            const long long i = lo + fp.perm3[kk];
             FItem &it = fp.U[i];
             FSearch &S = fp.S[it.q];
             if (!fs_live(S.state)) { if (lane == 0) it.flags |= FI_DEAD; continue; }

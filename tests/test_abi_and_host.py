@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/maple_hip.h but not exported"
     assert set(runtime.EXPORTS) <= set(names)
-    assert lib.maple_abi_version() == 2
+    assert lib.maple_abi_version() == 3
 
 
 def test_no_gpu_means_loud_failure():

@@ -141,3 +141,143 @@ def test_config4_1M_full_model_searches_against_the_oracle(million):
     n_ok, n_pl = check_sample_against_oracle(orc, otree, nodes, g, sel, kw)
     assert n_ok > 250 and n_pl > 1e6
     print(f"config 4: {len(sel)} of {len(nodes)} searches ({n_pl} candidate placements) equal the oracle's; {time.time() - t0:.0f} s")
+
+
+def test_config5_online_update_of_the_1M_tree(million):
+    """BASELINE configs[4]: new samples added to the 1 000 000-tip tree one after the other (M:11692-11752: placement search,
+    tree edit, updatePartials), then an SPR round (--largeUpdate: the rounds run with every node dirty, M:12143-12159, 12274).
+    Here 2 048 samples through maple_placement_search_batch + maple_update_partials + maple_tree_patch (the tree edit is the
+    bench's stand-in for placeSampleOnTree, host code of the reference that is out of scope), checked as follows:
+
+    * every 50th sample: the search's score and the three branch lengths against the oracle's evaluation of the SAME placement
+      (the reference's refinement, M:8109-8147: three estimateBranchLengthWithDerivative around three mergeVectors, one
+      appendProbNode, the branch-length compensation), and the lists updatePartials wrote around the new nodes against the
+      oracle's mergeVectors + shorten of their current inputs, entry for entry;
+    * every list of the final tree that was never touched still IS the list of the tree before (same ids), and every touched node
+      has all the lists it should have;
+    * a deep SPR round over every node the additions touched plus 8 192 evenly spread others on the final tree: a sample of the
+      searches against the oracle on the whole downloaded tree, the second call identical."""
+    import bench
+    from maple_amd.host import tip_genome_list
+    from maple_amd.synth import perturb_diffs
+    data, dev, m, ref_idx, root_freqs, mkw, tip_kw = million
+    t0 = time.time()
+    l_ref = dev.lRef
+    ll = math.log(l_ref)
+    pkw = dict(oneMutBLen=1.0 / l_ref, effectivelyNon0BLen=1.0 / (10 * l_ref), thresholdLogLK=18.0 * ll,
+               thresholdLogLKoptimization=1.0 * ll, thresholdLogLKconsecutivePlacement=1.0)
+    n_add = 2048
+    prng = np.random.default_rng(21)
+    src = prng.choice(len(data.diffs), size=n_add, replace=False)
+    new_lists = [tip_genome_list(perturb_diffs(data.diffs[int(i)], data.ref, prng), ref_idx, **tip_kw) for i in src]
+    n0, cap = m.n_nodes, m.n_nodes + 2 * n_add
+
+    def grown(a, fill, dtype):
+        out = np.full(cap, fill, dtype=dtype)
+        out[:n0] = a
+        return out
+    up = grown(m.parent, -1, np.int32)
+    c0, c1 = grown(m.children[:, 0], -1, np.int32), grown(m.children[:, 1], -1, np.int32)
+    tip = grown(m.is_tip, 0, np.uint8)
+    dist = grown(m.dist, 0.0, np.float64)
+    mut = np.full(cap, -1, dtype=np.int32)
+    lower, up_right = grown(m.lower, -1, np.int32), grown(m.up_right, -1, np.int32)
+    up_left, tot_up = grown(m.up_left, -1, np.int32), grown(m.tot_up, -1, np.int32)
+    before = dict(lower=lower.copy(), up_right=up_right.copy(), up_left=up_left.copy(), tot_up=tot_up.copy())
+    depth = np.zeros(cap, dtype=np.int32)
+    depth[:n0] = m.depth * bench.DEPTH_STEP
+    n = n0
+    dev.upload_tree(m.root, up[:n], c0[:n], c1[:n], dist[:n], tip[:n], lower[:n], up_right[:n], up_left[:n], tot_up[:n], mut[:n])
+    from oracle.oracle_py import Oracle
+    orc = Oracle(ref_idx, root_freqs)
+    orc.set_model(**mkw)
+    touched_all = []
+    placed = checked = 0
+    t_loop = time.time()
+    for k, lst in enumerate(new_lists):
+        dev.placement_prepare(**pkw)
+        qid = int(dev.upload([lst])[0])
+        mark = dev.mark()
+        out = dev.placement_search_batch(np.asarray([qid], dtype=np.int32), **pkw)
+        dev.release(mark)
+        b = int(out["bestNode"][0])
+        if out["status"][0] != 0 or up[b] < 0:
+            continue
+        top, bottom, app = (float(x) for x in out["blen"][0])
+        g, p, s = int(up[b]), n, n + 1
+        check = (k % 50 == 0)
+        if check:
+            # the oracle's evaluation of this very placement on the lists of the tree as it is now (M:8109-8147)
+            vu = int(up_right[g] if c0[g] == b else up_left[g])
+            l_tot, l_low, l_up = dev.download([tot_up[b], lower[b], vu])
+            is_tip_b = bool(tip[b])
+            cost, o_bottom, o_top, o_app = orc.evaluatePlacement(l_tot, l_low, l_up, float(dist[b]), lst, True, is_tip_b)
+            initial = orc.appendProbNode(l_up, l_low, is_tip_b, float(dist[b]))
+            newpart = orc.appendProbNode(l_up, l_low, is_tip_b, o_bottom + o_top)
+            want = cost + newpart - initial
+            first = orc.appendProbNode(l_tot, lst, True, 1.0 / l_ref)       # the unrefined score the search arrived with (M:8049)
+            got = float(out["bestScore"][0])
+            if want >= first:                                               # M:8179: the refined placement replaces it
+                assert abs(got - want) <= 1e-9 * max(1.0, abs(want)), (k, got, want, first)
+                assert np.allclose([top, bottom, app], [o_top, o_bottom, o_app], rtol=1e-8, atol=1e-15), (k, out["blen"][0], (o_top, o_bottom, o_app))
+            else:                                                           # ... or it stays, with the lengths of M:8072
+                assert abs(got - first) <= 1e-9 * max(1.0, abs(first)), (k, got, want, first)
+        # ---- the stand-in tree edit (bench.serial_phase): p on the branch above b, the sample s as p's other child
+        if c0[g] == b:
+            c0[g] = p
+        else:
+            c1[g] = p
+        up[p], c0[p], c1[p], dist[p], tip[p] = g, b, s, top, 0
+        up[b], dist[b] = p, bottom
+        up[s], dist[s], tip[s], lower[s] = p, app, 1, qid
+        depth[p] = (depth[g] + depth[b]) // 2
+        depth[s] = depth[p] + 1
+        assert depth[g] < depth[p] < depth[b]
+        n += 2
+        dev.update_partials(m.root, up[:n], c0[:n], c1[:n], tip[:n], mut[:n], depth[:n], dist[:n], lower[:n], up_right[:n],
+                            up_left[:n], tot_up[:n], [b, s, p])
+        touched = np.unique(np.concatenate([dev.update_partials_touched(), [g, b, p, s]])).astype(np.int32)
+        dev.tree_patch(n, touched, up[touched], c0[touched], c1[touched], dist[touched], tip[touched], lower[touched],
+                       up_right[touched], up_left[touched], tot_up[touched])
+        touched_all.append(touched)
+        placed += 1
+        if check:
+            # what updatePartials wrote around the new nodes, from the lists that are there now (M:5479-5815)
+            lb, ls, lp, lur, lul = dev.download([lower[b], lower[s], lower[p], up_right[p], up_left[p]])
+            want_p = orc.mergeVectors(lb, float(dist[b]), bool(tip[b]), ls, float(dist[s]), True)
+            assert want_p is not None
+            want_p = orc.shorten(want_p)
+            assert len(lp) == len(want_p) and all(x[0] == y[0] and x[1] == y[1] for x, y in zip(lp, want_p)), k
+            # the new tip's mid-branch list: p's upper list for its child 1 (= s) merged with the sample (M:5700-5720)
+            if dist[s] > 0 and tot_up[s] >= 0:
+                (lt,) = dev.download([tot_up[s]])
+                want_t = orc.mergeVectors(lul, float(dist[s]) / 2, False, ls, float(dist[s]) / 2, True, isUpDown=True)
+                want_t = orc.shorten(want_t)
+                assert len(lt) == len(want_t) and all(x[0] == y[0] and x[1] == y[1] for x, y in zip(lt, want_t)), k
+            checked += 1
+    loop_s = time.time() - t_loop
+    assert placed > 0.95 * n_add and checked >= 35
+    touched_all = np.unique(np.concatenate(touched_all))
+    # lists that were never touched are the lists of the tree before; every node of the final tree has what it needs
+    untouched = np.setdiff1d(np.arange(n0), touched_all)
+    for name, col in (("lower", lower), ("up_right", up_right), ("up_left", up_left), ("tot_up", tot_up)):
+        assert np.array_equal(col[untouched], before[name][untouched]), name
+    inner = np.nonzero(c0[:n] >= 0)[0]
+    assert (lower[:n] >= 0).all() and (up_right[inner] >= 0).all() and (up_left[inner] >= 0).all()
+    assert (tot_up[:n][(dist[:n] > 0) & (up[:n] >= 0)] >= 0).all()
+    # ---- the round that follows the update, on the final tree (the library's copy is current through the patches)
+    kw = bench.search_kwargs(l_ref)
+    rest = np.setdiff1d(np.arange(n), touched_all)
+    nodes = np.concatenate([touched_all, rest[:: max(1, len(rest) // 8192)][:8192]]).astype(np.int64)
+    gres = dev.spr_search_batch(nodes, **kw)
+    assert not (gres["status"] < -1).any()
+    same_results(dev.spr_search_batch(nodes, **kw), gres)
+    children = np.stack([c0[:n], c1[:n]], axis=1)
+    orc2, otree = oracle_tree(dev, ref_idx, root_freqs, mkw, m.root, up[:n], children, dist[:n], lower[:n], up_right[:n], up_left[:n], tot_up[:n])
+    sel = np.concatenate([np.arange(0, len(touched_all), max(1, len(touched_all) // 160)), len(touched_all) + np.arange(0, 8192, 64)])
+    sel = sel[sel < len(nodes)]
+    n_ok, n_pl = check_sample_against_oracle(orc2, otree, nodes, gres, sel, kw)
+    assert n_ok > 200
+    print(f"config 5: {placed} samples added in {loop_s:.1f} s ({1e3 * loop_s / max(1, placed):.2f} ms per sample, {checked} checked against the "
+          f"oracle), {len(touched_all)} nodes touched; the round after it: {len(sel)} of {len(nodes)} searches equal the oracle's; "
+          f"{time.time() - t0:.0f} s")

@@ -677,3 +677,36 @@ def test_frontier_tier_on_a_tree_with_local_references_equals_the_lane_tier(mode
                 assert np.array_equal(g[k], lane[k]), (budget, k, int((g[k] != lane[k]).sum()))
     assert (g["status"] == 0).sum() > 15000 and g["nAppend"].sum() > 1e7
     dev.close()
+
+
+@pytest.mark.parametrize("mode", ["ratevar", "siteerr"])
+def test_frontier_levels_by_wavefronts_or_by_lanes_give_the_same_searches(mode):
+    """maple_tuning.waveAllBelow only chooses HOW a level of the frontier tier is walked -- a wavefront per item that still updates
+    genome lists (wave_update.h: the walks cut along their merge paths) or a lane per item: never, for the small levels only (the
+    default), for every level.  Same searches bit for bit, on a plain tree and on the same tree with MAT local references."""
+    import bench
+    from maple_amd.mat import add_local_references
+    from maple_amd.tree_host import HostTree
+    data, dev, orc, m = build(3000, mode, seed=8)
+    kw = bench.search_kwargs(dev.lRef)
+    nodes = bench.preorder_nodes(m)
+    no_mut = -np.ones(m.n_nodes, dtype=np.int32)
+    ht = HostTree.from_mirror(m)
+    for form in ("plain", "local references"):
+        if form == "plain":
+            dev.upload_tree(m.root, m.parent, m.children[:, 0], m.children[:, 1], m.dist, m.is_tip, m.lower, m.up_right, m.up_left, m.tot_up, no_mut)
+        else:
+            assert add_local_references(dev, ht, 40) > 20
+            dist = np.asarray([float(x or 0.0) for x in ht.dist])
+            dev.upload_tree(ht.root, m.parent, m.children[:, 0], m.children[:, 1], dist, m.is_tip, ht.id_lower, ht.id_upRight, ht.id_upLeft,
+                            ht.id_totUp, ht.id_mut)
+        res = []
+        for wab in (-1, 0, 1 << 30):
+            dev.set_tuning(wave_all_below=wab)
+            res.append(dev.spr_search_batch(nodes, wide_search_budget=-1, **kw))
+        dev.set_tuning()
+        for r in res[1:]:
+            for k in ("status", "bestNode", "placement", "nAppend", "bestScore", "currentLK", "improvement", "blen"):
+                assert np.array_equal(r[k], res[0][k]), (form, k)
+        assert (res[0]["status"] == 0).sum() > 4000
+    dev.close()
