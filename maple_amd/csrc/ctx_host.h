@@ -145,6 +145,10 @@ struct maple_ctx {
     int32_t tree_max_ent = 0;          // longest genome list of the uploaded tree (entries)
     int32_t n_scored = 0;              // nodes with a probVectTotUp, sorted by list length: t_i32[8] = list ids, t_scored_col = node ids
     DevBuf<int32_t> t_scored_col, t_scored_frame;
+    // the same candidates in the searches' own depth-first order whatever the tree (host): list id, preRank, reference frame
+    std::vector<int32_t> h_cand_ids, h_cand_rank, h_cand_frame;
+    DevBuf<int32_t> s_frame_parent, s_frame_node;   // the frames' nesting on the device (per call of the SPR search)
+    DevBuf<int32_t> t_cand_rank, s_cand_root;   // device: the ranks; the candidates' lists re-expressed in the root's frame (per call)
     DevBuf<int4> t_frame_chunks;       // trees with local references: the scored candidates in chunks of <= 64 within one frame
     int32_t n_frame_chunks = 0;
     DevBuf<uint8_t> s_tilebest;        // (query, 64-candidate tile) records of maple_append_queries_argmax_dev

@@ -18,6 +18,10 @@ struct FrontierWide {
     hipEvent_t rowsReady;              // recorded behind the launches that write the rows (or null: same stream)
     int forceWide;                     // 1: every search with a row is a whole-tree search (they were found by running over their
                                        // budget, with any model); 0: those the kernel's own routing hint names (zero-length branch, no error model)
+    // trees with MAT local references: the frames' nesting (device arrays by frame index; frame 0 = the root's), for the removed
+    // lists of the short-listed branches a clade scan finds in frames below its seed's
+    const int32_t *frameParent = nullptr, *frameNode = nullptr;
+    int nFrames = 0;
 };
 
 __attribute__((visibility("hidden")))

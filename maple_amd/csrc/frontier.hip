@@ -554,7 +554,10 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
                             if (nB >= capB) { bad = 1; break; }
                             br[nB++] = BestRec{it.t1, ref, WR_ITEM, -1, it.hRpr, mp, 0.0};
                         }
-                        if (mp > best) { best = mp; fails = 0; }
+                        if (mp > best) {
+                            best = mp; fails = 0;
+                            if (it.dir == 0 && frpr_marked(fp, S, it.hRpr)) { bad = 1; break; }   // (M:7087: see k_fr_replay)
+                        }
                         else if (mp < (it.lastLK - P.thrConsec)) fails++;
                     }
                     const bool within = mp > (best - P.thrLKtopology);
@@ -576,6 +579,7 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
             const bool firstScored = !(r1.up == S.parent || r1.up < 0) && (r1.dist > P.effNon0 || r1.upIsRoot);
             ScanState st;
             st.best = readfirst_f64(best);
+            const double bestBefore = st.best;
             st.nB = __builtin_amdgcn_readfirstlane(nB);
             st.nApp = __builtin_amdgcn_readfirstlane(nApp);
             st.overflow = 0;
@@ -585,6 +589,10 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
             wave_scan_clade(T.scan, T.scanParent, cs, nullptr, r1.preRank, firstScored, r1.frameOf, it.hRpr, it.lastLK, seedFails, P, br, capB,
                             slotLK, slotFails, slotOwner, T.scanDepthCap, st, fm, fpx, T.candBefore, T.cladeVisits);
             if (st.overflow) { bad = 1; break; }
+            // (a tree with local references: a branch of the clade that beats the running best would have its removed list -- the
+            // seed's, re-expressed in the branch's frame, which only exists after the scan -- shortened in place, M:7087: rare, and
+            // left to the one-lane kernel)
+            if (fp.mat && st.best > bestBefore) { bad = 1; break; }         // (wave-uniform: both are what lane 0 handed in)
             best = st.best; nB = st.nB; nApp = st.nApp;
             __threadfence();
 #ifdef MAPLE_SPR_PROFILE
@@ -626,6 +634,9 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
                         x.q = q; x.t1 = b.t1; x.dir = 0; x.flags = FI_SCORED; x.failsP = 0; x.hPassed = -1; x.hRpr = b.hRpr;
                         x.distance = 0.0; x.lastLK = b.score; x.pathBest = b.score; x.midProb = b.score; x.recDist = 0.0;
                         x.child0 = x.child1 = FR_NONE; x.hA = x.hB = x.hMid = -1; x.next = FR_NONE; x.failsA = 0;
+                        // (the scan's removed list is its seed's: a branch in a frame nested below the seed's gets it through the
+                        // reference branches in between before it is refined -- k_fr_wide_frames)
+                        if (fp.mat && b.hMid != b.hDown) { x.flags |= FI_NEEDPASS; x.hA = b.hDown; x.hB = b.hMid; }
                     }
                     FRec &x = fp.recs[base + kk++];
                     x.q = q; x.ref = ref; x.ok = 0;
@@ -633,6 +644,39 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- trees with MAT local references: the removed list of a short-listed branch the clade scan found in a frame nested below its
+// seed's: down the reference branches from the seed's frame (x.hA) to the branch's (x.hB), outermost first (M:7111-7118)
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_wide_frames(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, FPools fp,
+                                                             const int32_t *frameParent, const int32_t *frameNode)
+{
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nRecs = min((long long)fp.ctr->nRecs, fp.capRecs);
+    for (long long i = laneId; i < nRecs; i += (long long)gridDim.x * blockDim.x) {
+        const FRec &R = fp.recs[i];
+        if (R.ref < 0) continue;                                            // (only the scan's entries: cached-pool items)
+        FItem &x = fp.C[R.ref];
+        if (!(x.flags & FI_NEEDPASS)) continue;
+        FSearch &S = fp.S[R.q];
+        if (!fs_live(S.state)) continue;
+        int chain[24], n = 0;
+        for (int g = x.hB; g != x.hA && g > 0 && n < 24; g = frameParent[g]) chain[n++] = g;
+        int h = x.hRpr;
+        bool ok = n < 24;
+        for (int k = n - 1; k >= 0 && ok; k--) {
+            h = fpass_removed(c, fp, av, laneId, h, T.nd[frameNode[chain[k]]].mutId, false);
+            ok = fvalid(h);
+        }
+        if (!ok) { S.state = FS_FALLBACK; continue; }
+        x.hRpr = h; x.hA = x.hB = -1;
+        x.flags &= (uint8_t)~FI_NEEDPASS;
     }
 }
 
@@ -1059,6 +1103,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     k_fr_replay<<<gridN, FR_BLOCK, 0, s>>>(P, m, fp, dout);
     TRY(stage("k_fr_replay"));
     if (anyWide) HIPCK(c, hipStreamWaitEvent(s, F.evJoin, 0));
+    if (anyWide && fp.mat && wide->nFrames > 0) {
+        FR_DISPATCH3(c, k_fr_wide_frames, <<<std::min(gridUpd, 512), FR_BLOCK, 0, s>>>(c->d_model, av, T, fp, wide->frameParent, wide->frameNode));
+        TRY(stage("k_fr_wide_frames"));
+    }
     FR_DISPATCH3(c, k_fr_refine, <<<gridUpd, FR_BLOCK, 0, s>>>(c->d_model, av, T, fp));
     TRY(stage("k_fr_refine"));
     k_fr_finish<<<gridN, FR_BLOCK, 0, s>>>(av, T, P, m, fp, dout, poolW, poolA, poolUsed, poolCapW, poolCapA);

@@ -1291,7 +1291,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     for (auto &b : c->s_i64) b.release();
     c->s_words.release(); c->s_aux.release(); c->s_ais.release(); c->s_pool_w.release(); c->s_pool_a.release();
     for (auto &b : c->t_i32) b.release();
-    c->t_dist.release(); c->t_tip.release(); c->t_nodes.release(); c->t_scored_col.release(); c->t_scored_frame.release(); c->t_scan.release(); c->t_scan_parent.release(); c->t_cand_before.release(); c->t_clade_visits.release(); c->s_fin_mask.release(); c->s_fin_prefix.release(); c->s_tilebest.release(); c->s_comm_u64.release();
+    c->t_dist.release(); c->t_tip.release(); c->t_nodes.release(); c->t_scored_col.release(); c->t_scored_frame.release(); c->t_cand_rank.release(); c->s_cand_root.release(); c->s_frame_parent.release(); c->s_frame_node.release(); c->t_scan.release(); c->t_scan_parent.release(); c->t_cand_before.release(); c->t_clade_visits.release(); c->s_fin_mask.release(); c->s_fin_prefix.release(); c->s_tilebest.release(); c->s_comm_u64.release();
     if (c->d_tile_counters) (void)hipFree(c->d_tile_counters);
     c->s_search_ws.release(); c->s_search_ws_big.release(); c->s_search_out.release(); c->s_counter.release(); c->s_cache.release();
     for (auto &b : c->p_i32) b.release();
@@ -2614,6 +2614,15 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
                 return recs[a].frameOf != recs[b].frameOf ? recs[a].frameOf < recs[b].frameOf : recs[a].preRank < recs[b].preRank; });
         else
             std::stable_sort(col.begin(), col.end(), [&](int a, int b) { return recs[a].preRank < recs[b].preRank; });
+        {   // (in rank order whatever the tree: what the rows that come with bitmaps are indexed by, FiniteRows)
+            std::vector<int32_t> byRank(col);
+            if (c->tree_has_mut) std::stable_sort(byRank.begin(), byRank.end(), [&](int a, int b) { return recs[a].preRank < recs[b].preRank; });
+            c->h_cand_ids.resize(byRank.size()); c->h_cand_rank.resize(byRank.size()); c->h_cand_frame.resize(byRank.size());
+            for (size_t i = 0; i < byRank.size(); i++) {
+                c->h_cand_ids[i] = totUp[byRank[i]]; c->h_cand_rank[i] = recs[byRank[i]].preRank; c->h_cand_frame[i] = recs[byRank[i]].frameOf;
+            }
+            TRY(h2d(c, c->t_cand_rank, c->h_cand_rank.data(), c->h_cand_rank.size()));
+        }
         std::vector<int32_t> ids(col.size()), rank(col.size()), fr(col.size());
         for (size_t i = 0; i < col.size(); i++) { ids[i] = totUp[col[i]]; rank[i] = recs[col[i]].preRank; fr[i] = recs[col[i]].frameOf; }
         c->n_frame_chunks = 0;
@@ -3319,7 +3328,8 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     const bool hybrid = wideBudget > 0;
     if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !c->tuning.noCladeScan) TRY(build_scan_tables(c, P));
     // rows of the score table come with the bitmap of their finite scores (FiniteRows) when the tables that go with it exist
-    const bool useFin = hybrid && c->scan_valid && !c->tree_has_mut;
+    bool useFin = hybrid && c->scan_valid && !c->tree_has_mut;         // (trees with local references: only for the rows of the searches
+                                                                       // known beforehand, below)
     // Without an error model the whole-tree searches are known before anything runs: they are the ones that start from a
     // zero-length branch (the routing hint in the kernel gives those 16 placements and sends them on).  Their dense scoring
     // needs nothing from the lane searches, so it is launched first, on a side stream, and shares the GPU with them -- the
@@ -3328,7 +3338,14 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     std::vector<int32_t> preIdx, preRowOf;
     int preSpare = 0;
     const int nTpre = c->dtree.n;
-    if (hybrid && !c->tree_has_mut && !c->dm.usingErrorRate && wideBudget > 16) {
+    // Trees with MAT local references: appendProbNode does not depend on the frame its two lists are written in (the same sites
+    // need work, with the same nucleotides, lengths and rates, in the same order), so the rows of these searches are made in the
+    // ROOT's frame: every candidate list and every removed list re-expressed there once per call (passGenomeListThroughBranch up
+    // the chain of frames), the witness filter and the pair walks as on a plain tree.
+    const bool matPre = c->tree_has_mut;
+    int64_t preMark = -1;                                              // (the re-expressed lists live until the results are in)
+    std::vector<int32_t> preFrameParent, preFrameNode;
+    if (hybrid && !c->dm.usingErrorRate && wideBudget > 16 && (!matPre || (c->scan_valid && c->place && !c->tuning.noCladeScan && !c->tuning.denseWideScoring && !c->tuning.wideOutsideFrontier))) {
         {   // a node on a zero-length branch is searched at all only if its current placement is bad enough (M:9674): the
             // kernel's own test, on the same appendProbNode, for all of them at once
             std::vector<int32_t> zi, pl, cl;
@@ -3336,6 +3353,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             for (int i = 0; i < n; i++) {
                 const int v = nodes[i], u = c->h_tree_up[v];
                 if (c->h_tree_dist[v] != 0.0 || u < 0) continue;
+                if (matPre && c->h_tree_mut[v] >= 0) continue;          // (a reference node itself: the frame-by-frame path, below)
                 const int32_t vu = c->h_tree_c0[u] == v ? c->h_tree_upRight[u] : c->h_tree_upLeft[u];
                 if (vu < 0 || c->h_tree_lower[v] < 0) continue;
                 zi.push_back(i); pl.push_back(vu); cl.push_back(c->h_tree_lower[v]); tp.push_back(c->h_tree_tip[v]);
@@ -3374,6 +3392,35 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 preRowOf[preIdx[k]] = k;
                 qBytes += 8.0 * c->h_n_ent[ql[k]] + 8.0 * c->h_n_aux[ql[k]];
             }
+            if (matPre) {
+                const PlaceMeta &Fm = *c->place;
+                TRY(maple_arena_mark(c, &preMark));
+                // lists up the chain of their frames, one enclosing frame per round, until every one is in the root's
+                auto to_root = [&](std::vector<int32_t> &ids, std::vector<int32_t> fr) -> int {
+                    std::vector<int32_t> who, src, ml, out;
+                    std::vector<uint8_t> dir;
+                    for (;;) {
+                        who.clear(); src.clear(); ml.clear();
+                        for (size_t k = 0; k < ids.size(); k++)
+                            if (fr[k] != 0 && ids[k] >= 0) { who.push_back((int32_t)k); src.push_back(ids[k]); ml.push_back(c->h_tree_mut[Fm.frameNode[fr[k]]]); }
+                        if (who.empty()) return MAPLE_OK;
+                        dir.assign(who.size(), 1);
+                        out.resize(who.size());
+                        TRY(maple_pass_branch_batch(c, (int32_t)who.size(), src.data(), ml.data(), dir.data(), out.data()));
+                        for (size_t i = 0; i < who.size(); i++) { ids[who[i]] = out[i]; fr[who[i]] = Fm.frameParent[fr[who[i]]]; }
+                    }
+                };
+                std::vector<int32_t> qf(mZ);
+                for (int k = 0; k < mZ; k++) qf[k] = Fm.frameOf[nodes[preIdx[k]]];
+                TRY(to_root(ql, qf));
+                std::vector<int32_t> candRoot(c->h_cand_ids);
+                TRY(to_root(candRoot, c->h_cand_frame));
+                TRY(h2d(c, c->s_cand_root, candRoot.data(), candRoot.size()));
+                HIPCK(c, hipStreamSynchronize(c->stream));
+                preFrameParent = Fm.frameParent;
+                preFrameNode = Fm.frameNode;
+                useFin = true;
+            }
             HIPCK(c, c->z_ql.reserve(mZ)); HIPCK(c, c->z_qt.reserve(mZ)); HIPCK(c, c->z_qb.reserve(mZ));
             HIPCK(c, hipEventRecord(c->ev_fork, c->stream));               // (everything the tree tables wait for)
             HIPCK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -3383,12 +3430,13 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             HIPCK(c, hipStreamSynchronize(c->stream2));                     // (the three vectors are locals)
             // queued BEHIND the lane launch: a workgroup of the dense kernel wants most of a compute unit's LDS, so it starts
             // where the lane searches have thinned out -- launched first it would hold them off instead (measured: no overlap)
-            afterLaunch = [c, mZ, nTpre, qBytes, fin_prefix, useFin, finWords, dbgT]() -> int {
+            afterLaunch = [c, mZ, nTpre, qBytes, fin_prefix, useFin, finWords, dbgT, matPre]() -> int {
                 // (every one of these searches has removedBLen = 0 and there is no error model: only the pairs the witness
                 // filter cannot rule out are walked -- witness.hip)
                 if (useFin && !c->tuning.denseWideScoring) {
                     long long pairs = 0;
-                    TRY(witness_score(c, c->stream2, mZ, c->z_ql.p, c->z_qt.p, c->z_qb.p, c->n_scored, c->t_i32[8].p, c->t_scored_col.p,
+                    TRY(witness_score(c, c->stream2, mZ, c->z_ql.p, c->z_qt.p, c->z_qb.p, c->n_scored, matPre ? c->s_cand_root.p : c->t_i32[8].p,
+                                      matPre ? c->t_cand_rank.p : c->t_scored_col.p,
                                       c->s_cache.p, nTpre, c->s_fin_mask.p, finWords,
                                       c->n_scored ? c->scored_bytes_total / c->n_scored : 0.0, qBytes, &pairs));
                     if (dbgT) fprintf(stderr, "[maple] witness filter: %lld of %lld (search, branch) pairs walked\n", pairs, (long long)mZ * c->n_scored);
@@ -3426,6 +3474,11 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         if (!preIdx.empty() && !c->tuning.wideOutsideFrontier) {
             fw.rowOf = preRowOf.data(); fw.cacheS = c->s_cache.p; fw.rowsReady = c->ev_join;
             if (useFin) fw.fin = FiniteRows{c->s_fin_mask.p, c->s_fin_prefix.p, finWords};
+            if (matPre) {                                               // the frames' nesting, for the clade scans' short lists
+                TRY(h2d(c, c->s_frame_parent, preFrameParent.data(), preFrameParent.size()));
+                TRY(h2d(c, c->s_frame_node, preFrameNode.data(), preFrameNode.size()));
+                fw.frameParent = c->s_frame_parent.p; fw.frameNode = c->s_frame_node.p; fw.nFrames = (int)preFrameParent.size();
+            }
         }
         TRY(frontier_search(c, P, n, todo.data(), frontierBudget, (hybrid && wideBudget > MAPLE_ZERO_DIST_BUDGET) ? MAPLE_ZERO_DIST_BUDGET : (1 << 30),
                             ho.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs, 0, fw.rowOf ? &fw : nullptr));
@@ -3454,6 +3507,9 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             std::vector<double> qb2;
             for (int32_t i : wide) {
                 const int node = nodes[i];
+                // (a tree with local references: what the tier did not finish over these rows goes frame by frame, below -- the
+                // one-wavefront-per-search replay wants the removed list in every frame)
+                if (matPre) { rest.push_back(i); continue; }
                 if (preRowOf[i] >= 0) { qn.push_back(node); sl.push_back(i); rowsNow.push_back(preRowOf[i]); }
                 else if ((int)ql2.size() < preSpare) {
                     qn.push_back(node); sl.push_back(i); rowsNow.push_back(mZ + (int)ql2.size());
@@ -3694,6 +3750,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         }
     }
 #endif
+    if (preMark >= 0) TRY(maple_arena_release(c, preMark));             // (the root-frame copies of this call)
     for (int i = 0; i < n; i++) {
         bestNode[i] = ho[i].bestNode; bestScore[i] = ho[i].bestScore;
         blen3[3 * i] = ho[i].blen[0]; blen3[3 * i + 1] = ho[i].blen[1]; blen3[3 * i + 2] = ho[i].blen[2];

@@ -882,7 +882,7 @@ __device__ inline void wave_scan_clade(const SScan *__restrict__ SC, const int32
             if (rec1) {
                 const int hr = (rT && f != seedFrame) ? -(rT[f] + 10) : hSeed;
                 const int at = nB + __popcll(recM & ((1ull << lane) - 1ull));
-                br[at] = BestRec{rec.node, -1, -1, -1, hr, myMp, 0.0};
+                br[at] = BestRec{rec.node, -1, seedFrame, f, hr, myMp, 0.0};   // (hUp -1: a branch of the tree; the frames: frontier.hip)
             }
             nB += nRec;
         }
@@ -904,7 +904,7 @@ __device__ inline void wave_scan_clade(const SScan *__restrict__ SC, const int32
             const int hr = (rT && fi != seedFrame) ? -(rT[fi] + 10) : hSeed;
             nApp++;
             if (nB >= capB) { S.overflow = 5; break; }
-            if (lane == 0) br[nB] = BestRec{__builtin_amdgcn_readlane(rec.node, i), -1, -1, -1, hr, mp, 0.0};
+            if (lane == 0) br[nB] = BestRec{__builtin_amdgcn_readlane(rec.node, i), -1, seedFrame, fi, hr, mp, 0.0};
             nB++;
             best = mp;
             if (hr >= 0) S.shortenSeed = true;
