@@ -143,7 +143,8 @@ struct maple_ctx {
     std::vector<uint8_t> h_tree_tip;
     bool tree_has_mut = false;
     int32_t tree_max_ent = 0;          // longest genome list of the uploaded tree (entries)
-    int32_t n_scored = 0;              // nodes with a probVectTotUp, sorted by list length: t_i32[8] = list ids, t_scored_col = node ids
+    int32_t n_scored = 0;              // nodes with a probVectTotUp in the searches' depth-first order (trees with local references: by frame,
+                                       // then depth-first): t_i32[8] = list ids, t_scored_col = preRank, t_scored_frame = frame
     DevBuf<int32_t> t_scored_col, t_scored_frame;
     // the same candidates in the searches' own depth-first order whatever the tree (host): list id, preRank, reference frame
     std::vector<int32_t> h_cand_ids, h_cand_rank, h_cand_frame;

@@ -884,7 +884,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     // per-lane scratch for lists of up to capE entries (two average lists merged, with room); the few longer ones -- near the
     // root -- take pieces of a shared region.  As many lanes as the GPU holds at once at this kernel's occupancy.
     const int capE = std::max(256, std::min(1024, 6 * (int)meanEnt));
-    long long scratchLanes = 256ll * 4 * 4 * 64;                           // 256 CUs x 4 SIMDs x 4 wavefronts
+    long long scratchLanes = m <= 64 ? 16384 : 256ll * 4 * 4 * 64;         // 256 CUs x 4 SIMDs x 4 wavefronts (a handful of searches: what they can use)
     while (scratchLanes > 16384 && (double)scratchLanes * capE * 64 > 0.25 * room) scratchLanes /= 2;
     const int gridUpd = (int)(scratchLanes / FR_BLOCK);
     const long long capBig = std::max<long long>(1 << 20, 64ll * 1024 * std::max(1, c->tree_max_ent));
@@ -1054,19 +1054,24 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         levels++;
         return MAPLE_OK;
     };
+    // (an error inside the loop leaves nothing in flight on either stream behind it)
+    auto bail = [&](int rc) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(s2); return rc; };
+    // the host looks at the counters every few levels: a handful of searches (the re-search of a proposed move) is over after a few
+    // levels and each look costs them less than the levels it saves; a whole round runs ~40
+    const int groupLevels = m <= 64 ? 2 : 8;
     for (;;) {
-        for (int g = 0; g < 8; g++) {
+        for (int g = 0; g < groupLevels; g++) {
             k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC, fp.lvl, fp.maxLevels, fp.capPass);
-            TRY(level());
+            { const int rc_ = level(); if (rc_) return bail(rc_); }
         }
         k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC, fp.lvl, fp.maxLevels, fp.capPass);
-        HIPCK(c, hipGetLastError());
-        HIPCK(c, hipMemcpyAsync(&hc, fp.ctr, sizeof(FCtr), hipMemcpyDeviceToHost, s));
-        HIPCK(c, hipStreamSynchronize(s));
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&hc, fp.ctr, sizeof(FCtr), hipMemcpyDeviceToHost, s) != hipSuccess
+            || hipStreamSynchronize(s) != hipSuccess)
+            return bail(fail(c, MAPLE_ERR_HIP, "frontier level loop: HIP error"));
         if (hc.hiU == hc.loU && hc.hiC == hc.loC) break;
         // (the snap above opened the next level: the loop's first snap would skip it -- undo by running its kernels first)
-        TRY(level());
-        if (levels > 100000) return fail(c, MAPLE_ERR_FATAL, "frontier search did not terminate");
+        { const int rc_ = level(); if (rc_) return bail(rc_); }
+        if (levels > 100000) return bail(fail(c, MAPLE_ERR_FATAL, "frontier search did not terminate"));
     }
     size_t slotWide = (size_t)-1;
     if (anyWide) {

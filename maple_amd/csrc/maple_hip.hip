@@ -1276,12 +1276,15 @@ extern "C" int maple_set_tuning(maple_ctx *c, const maple_tuning *t)
 extern "C" int maple_destroy(maple_ctx *c)
 {
     if (!c) return MAPLE_OK;
+    // this context's device first, and nothing in flight on any of its streams, before anything is freed
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    (void)hipDeviceSynchronize();                                       // (the frontier tier's side stream lives in its scratch)
     update_scratch_free(c);
     frontier_scratch_free(c);
     witness_scratch_free(c);
     for (int k = 0; k < 2; k++) { if (c->stg_h[k]) (void)hipHostFree(c->stg_h[k]); if (c->stg_d[k]) (void)hipFree(c->stg_d[k]); }
-    (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_cumBases, c->d_rflec, c->d_model, c->d_words, c->d_aux, c->d_ent_off, c->d_aux_off, c->d_n_ent, c->d_n_aux, c->d_mut3, c->d_mut_off,
                     c->d_mut_cnt, c->d_cumRate, c->d_cumErr, c->d_siteRates, c->d_errorRates};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1806,7 +1809,12 @@ extern "C" int maple_lists_update(maple_ctx *c, int32_t n, const int32_t *ids, c
         else { eo[i] = ue; ao[i] = ua; ue += cnt[i]; ua += cna[i]; }
     }
     if (ue > c->cap_ent || ua > c->cap_aux) return fail(c, MAPLE_ERR_NOMEM, "arena full while updating %d lists", n);
-    for (int i = 0; i < n; i++) if (eo[i] >= c->used_ent) c->relocated.push_back(ids[i]);   // (maple_arena_release must not free their room)
+    // (maple_arena_release must not free their room; a list relocated again and again is listed once: the list is kept sorted)
+    for (int i = 0; i < n; i++)
+        if (eo[i] >= c->used_ent) {
+            auto at = std::lower_bound(c->relocated.begin(), c->relocated.end(), ids[i]);
+            if (at == c->relocated.end() || *at != ids[i]) c->relocated.insert(at, ids[i]);
+        }
     TRY(settle(c));
     std::vector<uint2> w;
     for (int i = 0; i < n; i++) {
@@ -3391,6 +3399,9 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 ql[k] = c->h_tree_lower[node]; qt[k] = c->h_tree_tip[node]; qb[k] = c->h_tree_dist[node];
                 preRowOf[preIdx[k]] = k;
                 qBytes += 8.0 * c->h_n_ent[ql[k]] + 8.0 * c->h_n_aux[ql[k]];
+                // (the witness filter writes -inf by omission ON THE PROOF that the pair is searched with removedBLen = 0 and no
+                // error model -- witness.hip: a row with another length must never get here)
+                if (qb[k] != 0.0) return fail(c, MAPLE_ERR_FATAL, "a search with removedBLen %g among the searches of the witness filter", qb[k]);
             }
             if (matPre) {
                 const PlaceMeta &Fm = *c->place;

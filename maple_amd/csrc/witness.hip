@@ -189,8 +189,8 @@ void witness_scratch_free(maple_ctx *c)
     c->witness = nullptr;
 }
 
-// Rows of the score table for nQ whole-tree searches (removed lists qList, all searched with removedBLen = 0, no error
-// model, no local references) against the nC candidate lists `cand`: out[q * ldOut + outCol[k]] for the finite scores,
+// Rows of the score table for nQ whole-tree searches (removed lists qList, ALL searched with removedBLen = 0 -- the caller checks
+// its host copy of the lengths -- no error model; on a tree with local references both sides re-expressed in the root's frame) against the nC candidate lists `cand`: out[q * ldOut + outCol[k]] for the finite scores,
 // finMask[q * nWords + k / 64] bit k % 64 set exactly for those.  Blocks on `st` once (the number of pairs).
 int witness_score(maple_ctx *c, hipStream_t st, int nQ, const int32_t *qList, const uint8_t *qTip, const double *qBLen, int nC,
                   const int32_t *cand, const int32_t *outCol, double *out, long long ldOut, unsigned long long *finMask, int nWords,

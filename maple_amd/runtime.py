@@ -54,7 +54,12 @@ class MaplePlacementParams(C.Structure):
 
 
 class MapleError(RuntimeError):
-    pass
+    """An error status of libmaple_hip.so; ``code`` is the MAPLE_ERR_* value (include/maple_hip.h)."""
+    ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_FATAL = -1, -2, -3, -4, -5
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 _lib = None
@@ -125,7 +130,7 @@ class Device:
     def _ck(self, rc):
         if rc != 0:
             msg = self.lib.maple_last_error(self.h)
-            raise MapleError(f"libmaple_hip error {rc}: {msg.decode() if msg else ''}")
+            raise MapleError(f"libmaple_hip error {rc}: {msg.decode() if msg else ''}", rc)
 
     def close(self):
         if getattr(self, "h", None):
@@ -436,12 +441,19 @@ class Device:
         return out
 
     def spr_search_visited(self, cap=1 << 22):
-        """(query index, node) pairs of every branch the searches of the last spr_search_batch may have read (see the header)."""
-        q = np.zeros(cap, np.int32)
-        v = np.zeros(cap, np.int32)
-        n = C.c_int64()
-        self._ck(self.lib.maple_spr_search_visited(self.h, C.c_int64(cap), _ptr(q), _ptr(v), C.byref(n)))
-        return q[: n.value], v[: n.value]
+        """(query index, node) pairs of every branch the searches of the last spr_search_batch may have read (see the header).
+        If they do not fit in ``cap`` the call is repeated with the room it asked for."""
+        for _ in range(2):
+            q = np.zeros(cap, np.int32)
+            v = np.zeros(cap, np.int32)
+            n = C.c_int64()
+            rc = self.lib.maple_spr_search_visited(self.h, C.c_int64(cap), _ptr(q), _ptr(v), C.byref(n))
+            if rc == MapleError.ERR_ARG and n.value > cap:
+                cap = int(n.value)
+                continue
+            self._ck(rc)
+            return q[: n.value], v[: n.value]
+        self._ck(rc)
 
     def placement_prepare(self, *, oneMutBLen, effectivelyNon0BLen, thresholdLogLK, thresholdLogLKoptimization,
                           thresholdLogLKconsecutivePlacement, allowedFails=5, strictStopRules=True, onlyFindIdentical=False):

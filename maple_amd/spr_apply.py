@@ -58,6 +58,7 @@ class SprApplier:
         self.skipped = 0
         self.patched = []
         self.batches = []              # (searched, kept) per batch of apply_batched
+        self.degraded = 0              # batches of which only the first result could be used (a search left the frontier tier)
 
     @classmethod
     def from_mirror(cls, dev, m):
@@ -147,9 +148,12 @@ class SprApplier:
             r = self.dev.spr_search_batch(np.asarray(chunk, dtype=np.int32), wide_search_budget=-1, **kw)
             try:
                 q, v = self.dev.spr_search_visited()
-            except MapleError:
+            except MapleError as e:
+                if e.code != MapleError.ERR_STATE:
+                    raise
                 # one of the searches was handed to the one-lane kernel (it keeps no record of what it read): only the first
                 # result of the batch -- searched on a clean tree -- can be used
+                self.degraded += 1
                 chunk = chunk[:1]
                 q, v = np.zeros(0, np.int32), np.zeros(0, np.int32)
             self.times["search"].append(time.perf_counter() - t0)
