@@ -144,6 +144,11 @@ def parse_args(argv=None):
                     help="optimised (default): the simulated tree after the branch-length passes MAPLE runs before its SPR rounds "
                          "(traverseTreeToOptimizeBranchLengths, M:11899-11906), until no length moves; truth: the simulated tree "
                          "with branch lengths = mutations / lRef (rounds 1-2)")
+    ap.add_argument("--refs", choices=["auto", "local", "none"], default="auto",
+                    help="local: the tree carries MAT local references (setUpMAT's rule, a reference node per 50 descendants, M:166 / "
+                         "6152-6164 -- the form MAPLE's own trees have, M:8296-8354), the searches re-express their lists at every "
+                         "reference branch they cross; none: every list in the root's frame (rounds 1-3); auto = local up to 200 000 "
+                         "samples, none above")
     ap.add_argument("--synth", choices=["auto", "v1", "v2"], default="auto",
                     help="generator of the synthetic input: v1 = maple_amd.synth.make_dataset (numpy stream; the 10 000 / 100 000-sample "
                          "trees of rounds 1-3), v2 = the same model from csrc/synth_gen.c (seconds at 1 000 000 samples); auto = v1 up to "
@@ -278,9 +283,28 @@ def run_leg(args, env):
     def upload_plain_tree():
         dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist, mirror.is_tip,
                         mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up, no_mut)
-    upload_plain_tree()
+    refs = args.refs if args.refs != "auto" else ("local" if args.samples <= 200000 else "none")
+    ht, n_ref, refs_s = None, 0, 0.0
+    if refs == "local":
+        # the tree as MAPLE itself keeps it: MAT local references (maple_amd/mat.py: the reference nodes chosen by setUpMAT's rule, every
+        # list of a clade written against its reference node's genome, all four lists of every node rebuilt on the GPU)
+        from maple_amd.mat import add_local_references
+        from maple_amd.tree_host import HostTree
+        t_r = time.perf_counter()
+        ht = HostTree.from_mirror(mirror)
+        n_ref = add_local_references(dev, ht, 50)
+        ht_dist = np.asarray([float(x or 0.0) for x in ht.dist])
+        refs_s = time.perf_counter() - t_r
+
+    def upload_headline_tree():
+        if ht is None:
+            upload_plain_tree()
+        else:
+            dev.upload_tree(ht.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], ht_dist, mirror.is_tip, ht.id_lower,
+                            ht.id_upRight, ht.id_upLeft, ht.id_totUp, ht.id_mut)
+    upload_headline_tree()
     t_up = time.perf_counter()
-    upload_plain_tree()                                  # (timed once more, warm: what a caller pays per change of the tree)
+    upload_headline_tree()                               # (timed once more, warm: what a caller pays per change of the tree)
     tree_upload_ms = 1e3 * (time.perf_counter() - t_up)
     st_res = dev.stats()
     n_lists_res, n_ent_res, n_aux_res = st_res["n_lists"], st_res["n_entries"], st_res["n_aux"]
@@ -374,7 +398,7 @@ def run_leg(args, env):
     extras = {}
     if not args.no_extras and rank == 0:
         extras = sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_plain_tree, torch, cu,
-                            first_step=kept[0] if kept else None, first_nodes=batch_of(0))
+                            first_step=kept[0] if kept else None, first_nodes=batch_of(0), headline_refs=(ht is not None))
 
     # HBM-side bytes per launch come from separate rocprofv3 PMC passes over this same command (a running process cannot
     # read its own PMCs); they are recorded under profiles/ and only reported for the workload they were measured on, with the
@@ -384,7 +408,8 @@ def run_leg(args, env):
         try:
             pmc = json.load(open(path))
             w = pmc["workload"]
-            if (w["samples"], w["model"], w["batch"], w["n_gpus"], w.get("tree", "truth")) == (args.samples, args.model, B, world, args.tree) \
+            if (w["samples"], w["model"], w["batch"], w["n_gpus"], w.get("tree", "truth"), w.get("refs", "none")) == \
+                    (args.samples, args.model, B, world, args.tree, refs) \
                     and "traffic_bytes_per_step" in pmc:
                 traffic = {k: v / max(1.0, pmc["launches_per_step"][k]) for k, v in pmc["traffic_bytes_per_step"].items()}
                 pmc_issue = pmc.get("issue", {})
@@ -482,7 +507,12 @@ def run_leg(args, env):
             "config": {"workload": f"{args.samples} synthetic SARS-CoV-2 diff-lists (lRef 29903, ~30 diffs/sample), "
                                    f"{MODEL_TEXT[args.model]}; SPR search (findBestParentTopology + worker, "
                                    f"{'fast initial' if args.spr_fast else 'deep'}-round parameters) for {B} pruned nodes per step; "
-                                   f"tree: {'branch lengths optimised as MAPLE does before its SPR rounds' if args.tree == 'optimised' else 'simulated tree, lengths = mutations / lRef'}",
+                                   f"tree: {'branch lengths optimised as MAPLE does before its SPR rounds' if args.tree == 'optimised' else 'simulated tree, lengths = mutations / lRef'}"
+                                   f"{', with MAT local references (' + str(n_ref) + ' reference nodes)' if refs == 'local' else ', no local references'}",
+                       "local_references": {"form": refs, "reference_nodes": int(n_ref), "setup_s": round(refs_s, 2),
+                                            "note": "local: MAT local references as MAPLE's own trees carry them (a reference node per 50 "
+                                                    "descendants; every list of a clade written against its reference node's genome); the plain "
+                                                    "form of the same tree is the sub-block spr_search_plain_tree"},
                        "samples": args.samples, "model": args.model, "tree": args.tree, "tree_nodes": int(mirror.n_nodes),
                        "searches_per_step": int(B), "searches_timed": int(total_searches),
                        "candidate_placements_timed": int(total_placements),
@@ -512,7 +542,7 @@ def run_leg(args, env):
         }
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, batch_of, kept, kw, args.cpu_seconds, mkw,
+            out["cpu_baseline"] = spr_cpu_baseline(dev, mirror, ht, ref_idx, root_freqs, batch_of, kept, kw, args.cpu_seconds, mkw,
                                                    args.steps)
     if distd is not None:
         distd.barrier()
@@ -602,13 +632,30 @@ def serial_phase(dev, m, new_lists, pkw):
     return dict(times=t, placed=placed, skipped=skipped, patched=patched, cols=cols)
 
 
-def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_plain_tree, torch, cu, first_step=None, first_nodes=None):
-    """Secondary measurements next to the headline, never mixed into it (rank 0 only)."""
+def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_plain_tree, torch, cu, first_step=None, first_nodes=None,
+               headline_refs=False):
+    """Secondary measurements next to the headline, never mixed into it (rank 0 only).  They run on the PLAIN form of the tree
+    (every list in the root's frame), which is what they were measured on in rounds 1-3."""
     from maple_amd.host import tip_genome_list
     from maple_amd.runtime import Device
     from maple_amd.synth import perturb_diffs
     l_ref = dev.lRef
     out = {}
+    upload_plain_tree()
+    if headline_refs:
+        # ---- the headline's steps once more on the plain form of the same tree (what rounds 1-3 timed) ----
+        nsteps = max(1, min(args.steps, 3))
+        dev.spr_search_batch(order[np.arange(nsteps * B, (nsteps + 1) * B) % len(order)], **kw)
+        t0 = time.perf_counter()
+        pl = fails = 0
+        for i in range(nsteps):
+            r = dev.spr_search_batch(order[np.arange(i * B, (i + 1) * B) % len(order)], **kw)
+            pl += int(r["nAppend"][r["status"] >= -1].sum())
+            fails += int((r["status"] < -1).sum())
+        wall = time.perf_counter() - t0
+        out["spr_search_plain_tree"] = {"what": "the same steps on the same tree WITHOUT local references (every list in the root's frame: the "
+                                                "tree of rounds 1-3)", "steps": nsteps, "candidate_placements": pl, "failed_or_overflow": fails,
+                                        "ms_per_step": 1e3 * wall / nsteps, "placements_per_s": pl / wall}
     # ---- the all-pairs scoring kernel on its own: Q query lists x every candidate branch (appendProbNode, M:8050) ----
     cand_nodes = mirror.candidates_by_length(1.0 / (10 * l_ref))
     cand_lists = mirror.tot_up[cand_nodes]
@@ -738,7 +785,7 @@ def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_pl
             "tree edit (maple_amd/spr_apply.py); sequential = one re-search per move (frontier tier on the patched node records); "
             "batched = 32 moves re-searched per call, a speculative result kept while nothing its search may have read was "
             "touched by the moves applied before it")
-    if args.local_refs or args.samples <= 200000:
+    if (args.local_refs or args.samples <= 200000) and not headline_refs:
         # ---- the same steps on the same tree after giving it MAT local references (setUpMAT's rule, 50 descendants per
         # reference node, M:166 / 6152-6164): the form real MAPLE trees have; lists are shorter, searches cross frames ----
         from maple_amd.mat import add_local_references
@@ -766,7 +813,7 @@ def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_pl
     return out
 
 
-def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, batch_of, gpu_results, kw, cpu_seconds, mkw, steps):
+def spr_cpu_baseline(dev, mirror, ht, ref_idx, root_freqs, batch_of, gpu_results, kw, cpu_seconds, mkw, steps):
     """The C oracle's SPR search (a port of findBestParentTopology + the worker body, oracle/maple_oracle_search.c,
     pinned to the reference's recorded searches) on one host core and on all of them (OpenMP over searches) over bounded,
     evenly spread samples of the timed searches; also cross-checks the GPU's node ids, moves and candidate counts."""
@@ -775,11 +822,16 @@ def spr_cpu_baseline(dev, mirror, ref_idx, root_freqs, batch_of, gpu_results, kw
     orc.set_model(**mkw)
     n = mirror.n_nodes
     lists4 = []
-    for ids in (mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up):
+    # (ht: the timed tree carried MAT local references -- its lists, branch lengths and mutation lists)
+    cols = (mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up) if ht is None else (ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp)
+    for ids in cols:
+        ids = np.asarray(ids)
         have = np.nonzero(ids >= 0)[0]
         have = have[np.argsort(ids[have], kind="stable")]              # arena order: the download moves whole runs
         lists4.append((have, dev.download_packed(ids[have])))
-    otree = OracleTree(orc, mirror.root, mirror.parent.astype(np.int32), mirror.children, mirror.dist, None, np.zeros(n, dtype=np.int32), lists4)
+    dist = mirror.dist if ht is None else np.asarray([float(x or 0.0) for x in ht.dist])
+    otree = OracleTree(orc, mirror.root, mirror.parent.astype(np.int32), mirror.children, dist, None if ht is None else ht.mutations,
+                       np.zeros(n, dtype=np.int32), lists4)
     nodes = np.concatenate([batch_of(i) for i in range(steps)])
     gpu = {k: np.concatenate([r[k] for r in gpu_results]) for k in ("status", "bestNode", "placement", "nAppend", "bestScore")}
     ties = [0]

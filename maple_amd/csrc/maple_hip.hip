@@ -1524,6 +1524,7 @@ extern "C" int maple_arena_release(maple_ctx *c, int64_t markBoth)
         c->h_mut_off.resize(mmark); c->h_mut_cnt.resize(mmark);
     }
     if (mark == (int64_t)c->h_n_ent.size()) return MAPLE_OK;
+    if (mark < c->cand_root_end) c->cand_root_end = -1;                 // (the candidates' root-frame copies go with the release)
     int64_t ue = c->h_ent_off[mark], ua = c->h_aux_off[mark];
     {   // a list below the mark that maple_lists_update moved to the end of the arena keeps its (new) room
         size_t k = 0;
@@ -1605,7 +1606,7 @@ extern "C" int maple_arena_compact(maple_ctx *c, int64_t nLive, const int32_t *l
     c->h_n_ent.assign(ne.begin(), ne.end()); c->h_n_aux.assign(na.begin(), na.end());
     c->used_ent = totE; c->used_aux = totA;
     c->relocated.clear();
-    c->tree_set = false; c->tree_stale = false; c->nodes_current = false; c->scan_valid = false;
+    c->tree_set = false; c->tree_stale = false; c->nodes_current = false; c->scan_valid = false; c->cand_root_end = -1;
     if (c->place) { c->place->valid = false; c->place->rootVect = -1; }
     for (auto &cs : c->candsets) {
         if (cs.lists) (void)hipFree(cs.lists);
@@ -2603,6 +2604,7 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     T.nd = (const NodeRec *)aligned;
     T.totUp = c->t_i32[6].p;
     c->scan_valid = false;
+    c->cand_root_end = -1;
     T.scan = nullptr; T.scanParent = nullptr; T.scanDepthCap = 0;
     c->tree_has_mut = false;
     c->tree_max_ent = 0;
@@ -2733,6 +2735,7 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
     c->dtree.n = nTotal;
     c->tree_stale = true;
     c->scan_valid = false;
+    c->cand_root_end = -1;
     c->h_clade.clear();
     // ---- the node records of the SPR search (search_dev.h): the touched nodes and their relatives are rewritten in place, so
     // that a small batch of searches -- the re-search of a proposed move before it is applied, M:9470-9484 -- can run on the
@@ -3405,7 +3408,6 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             }
             if (matPre) {
                 const PlaceMeta &Fm = *c->place;
-                TRY(maple_arena_mark(c, &preMark));
                 // lists up the chain of their frames, one enclosing frame per round, until every one is in the root's
                 auto to_root = [&](std::vector<int32_t> &ids, std::vector<int32_t> fr) -> int {
                     std::vector<int32_t> who, src, ml, out;
@@ -3421,13 +3423,19 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                         for (size_t i = 0; i < who.size(); i++) { ids[who[i]] = out[i]; fr[who[i]] = Fm.frameParent[fr[who[i]]]; }
                     }
                 };
+                // (the candidates' copies are made once per tree and stay in the arena -- until the tree changes or a release of the
+                // caller's takes them; the removed lists' copies live for this call)
+                if (c->cand_root_end < 0) {
+                    std::vector<int32_t> candRoot(c->h_cand_ids);
+                    TRY(to_root(candRoot, c->h_cand_frame));
+                    TRY(h2d(c, c->s_cand_root, candRoot.data(), candRoot.size()));
+                    HIPCK(c, hipStreamSynchronize(c->stream));
+                    c->cand_root_end = (int64_t)c->h_n_ent.size();
+                }
+                TRY(maple_arena_mark(c, &preMark));
                 std::vector<int32_t> qf(mZ);
                 for (int k = 0; k < mZ; k++) qf[k] = Fm.frameOf[nodes[preIdx[k]]];
                 TRY(to_root(ql, qf));
-                std::vector<int32_t> candRoot(c->h_cand_ids);
-                TRY(to_root(candRoot, c->h_cand_frame));
-                TRY(h2d(c, c->s_cand_root, candRoot.data(), candRoot.size()));
-                HIPCK(c, hipStreamSynchronize(c->stream));
                 preFrameParent = Fm.frameParent;
                 preFrameNode = Fm.frameNode;
                 useFin = true;
