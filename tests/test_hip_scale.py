@@ -710,3 +710,27 @@ def test_frontier_levels_by_wavefronts_or_by_lanes_give_the_same_searches(mode):
                 assert np.array_equal(r[k], res[0][k]), (form, k)
         assert (res[0]["status"] == 0).sum() > 4000
     dev.close()
+
+
+def test_local_references_batched_equals_one_by_one():
+    """maple_amd.mat.add_local_references (every step batched: what the 1 000 000-tip bench tree needs) against its first
+    form, one reference node at a time: the same reference nodes, the same mutation lists, the same four genome lists of
+    every node, entry for entry."""
+    from maple_amd.mat import add_local_references, add_local_references_one_by_one
+    from maple_amd.tree_host import HostTree
+    data, dev, orc, m = build(3000, "ratevar", seed=11)
+    trees = []
+    for fn in (add_local_references_one_by_one, add_local_references):
+        ht = HostTree.from_mirror(m)
+        n_ref = fn(dev, ht, 40)
+        trees.append((n_ref, ht))
+    (n1, a), (n2, b) = trees
+    assert n1 == n2 and n1 > 20
+    assert a.mutations == b.mutations
+    assert np.array_equal(np.asarray(a.id_mut) >= 0, np.asarray(b.id_mut) >= 0)
+    for col in ("id_lower", "id_upRight", "id_upLeft", "id_totUp"):
+        ia, ib = np.asarray(getattr(a, col)), np.asarray(getattr(b, col))
+        assert np.array_equal(ia >= 0, ib >= 0), col
+        have = np.nonzero(ia >= 0)[0]
+        assert dev.download(ia[have]) == dev.download(ib[have]), col
+    dev.close()

@@ -18,4 +18,7 @@ rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/calib -- python $R/tools/calib_fetch.p
 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/calibw -- python $R/tools/calib_fetch.py > $OUT/calibw.log 2>&1
 python $R/tools/summarize_round4.py $NAME $OUT "$EXTRA" "$COMMIT" > $OUT/summary.md 2> $OUT/summary.err
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+# (the raw per-dispatch CSVs are hundreds of MB: only the summaries travel back)
+du -sh $OUT/* 2>/dev/null | sort -h | tail -12 > $OUT/sizes.txt
+rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/sq1 $OUT/sq2 $OUT/lds $OUT/calib $OUT/calibw
 tail -40 $OUT/summary.md; tail -3 $OUT/summary.err
