@@ -138,7 +138,7 @@ __global__ void k_fr_snap(FCtr *ctr, long long capU, long long capC, unsigned lo
         ctr->loC = ctr->hiC; ctr->hiC = min(ctr->usedC, (unsigned long long)capC);
         ctr->loP = ctr->hiP; ctr->hiP = min(ctr->nPass, (unsigned long long)capPass);
         ctr->bigUsed = 0;
-        ctr->permDown = ctr->permUp = ctr->permDownB = ctr->permUpB = ctr->permHeavy = 0;
+        ctr->permDown = ctr->permUp = ctr->permDownB = ctr->permUpB = ctr->permHeavy = ctr->permHeavy2 = 0;
         if (lvl) {
             const int l = ctr->nLevels++;
             if (l < maxLevels) { lvl[4 * l] = ctr->loU; lvl[4 * l + 1] = ctr->hiU; lvl[4 * l + 2] = ctr->loC; lvl[4 * l + 3] = ctr->hiC; }
@@ -197,13 +197,17 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_sort_level(ArenaViewS av, DevTr
             if (!(heavyMin > 0 && it.dir != 3 && sz >= heavyMin)) kind = (it.dir == 0 ? 0 : 1) + (sz >= bigMin ? 2 : 0);
         }
         const unsigned long long below = (1ull << lane) - 1ull;
-        {   // the items that go a wavefront each (kind -1)
-            const unsigned long long mh = __ballot(i < n && kind == -1);
-            if (mh) {
+        {   // the items that go a wavefront each (kind -1), by size class
+            const bool hv = i < n && kind == -1;
+            const bool small = hv && fr_wave_fits(av, T, fp, fp.U[lo + i], FR_WAVE_SMALL_IN, FR_WAVE_SMALL_CAPW);
+            for (int cls = 0; cls < 2; cls++) {
+                const bool mine = hv && (small == (cls == 0));
+                const unsigned long long mh = __ballot(mine);
+                if (!mh) continue;
                 unsigned long long b0 = 0;
-                if (lane == 0) b0 = atomicAdd(&fp.ctr->permHeavy, (unsigned long long)__popcll(mh));
+                if (lane == 0) b0 = atomicAdd(cls == 0 ? &fp.ctr->permHeavy : &fp.ctr->permHeavy2, (unsigned long long)__popcll(mh));
                 b0 = bc(b0);
-                if (i < n && kind == -1) fp.perm3[(long long)(b0 + __popcll(mh & below))] = (int32_t)i;
+                if (mine) (cls == 0 ? fp.perm3 : fp.perm4)[(long long)(b0 + __popcll(mh & below))] = (int32_t)i;
             }
         }
         for (int k = 0; k < 4; k++) {
@@ -272,7 +276,11 @@ void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Sear
         if (scored) {
             if (r1.totUp < 0) { it.flags |= FI_DEAD; continue; }
             const FList lp = flist(av, fp, ftree(r1.totUp)), lr = flist(av, fp, hRpr);
+#ifdef MAPLE_FR_CACHED_PLAIN_WALK
             midProb = append_walk(c, fref(lp), fref(lr), S.isRemovedTip != 0, S.removedBLen);
+#else
+            midProb = append_walk_gathered(c, fref(lp), fref(lr), S.isRemovedTip != 0, S.removedBLen);
+#endif
             it.flags |= FI_SCORED;
             nSc++; bSc += 8ull * (unsigned long long)(lp.n + lp.na) + 8ull;
         }
@@ -819,7 +827,7 @@ struct FrontierScratch {
     DevBuf<long long> toffW, toffA;
     DevBuf<int32_t> tn, tna, nodes, expQ, expNode;
     DevBuf<uint8_t> out, wideBr, tflag;
-    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, perm3, tot, lsize, lpos, lpar, passList;
+    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, perm3, perm4, tot, lsize, lpos, lpar, passList;
     DevBuf<uint8_t> visit;
     DevBuf<unsigned long long> lvl;
     DevBuf<long long> vbase;
@@ -844,7 +852,7 @@ void frontier_scratch_free(maple_ctx *c)
     F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
     F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
     F->expQ.release(); F->expNode.release();
-    F->perm.release(); F->perm2.release(); F->perm3.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release(); F->passList.release(); F->tflag.release();
+    F->perm.release(); F->perm2.release(); F->perm3.release(); F->perm4.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release(); F->passList.release(); F->tflag.release();
     if (F->evFork) (void)hipEventDestroy(F->evFork);
     if (F->evJoin) (void)hipEventDestroy(F->evJoin);
     if (F->side) (void)hipStreamDestroy(F->side);
@@ -912,9 +920,9 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, F.tn.reserve_exact(grow((size_t)capL, F.tn.cap)));
     HIPCK(c, F.tna.reserve_exact(grow((size_t)capL, F.tna.cap)));
     HIPCK(c, F.tflag.reserve_exact(grow((size_t)capL, F.tflag.cap)));
-    HIPCK(c, F.sw.reserve_exact((size_t)(scratchLanes + 512) * capE));     // (+ one slab per wavefront of k_fr_updating_wave)
-    HIPCK(c, F.sa.reserve_exact((size_t)(scratchLanes + 512) * capE * 5));
-    HIPCK(c, F.sais.reserve_exact((size_t)(scratchLanes + 512) * capE * 2));
+    HIPCK(c, F.sw.reserve_exact((size_t)(scratchLanes + 2048) * capE));     // (+ one slab per wavefront of k_fr_updating_wave)
+    HIPCK(c, F.sa.reserve_exact((size_t)(scratchLanes + 2048) * capE * 5));
+    HIPCK(c, F.sais.reserve_exact((size_t)(scratchLanes + 2048) * capE * 2));
     HIPCK(c, F.bw.reserve_exact((size_t)capBig));
     HIPCK(c, F.ba.reserve_exact((size_t)capBig * 5));
     HIPCK(c, F.nodes.reserve((size_t)m));
@@ -929,8 +937,9 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, F.perm.reserve_exact(std::max(F.perm.cap, (size_t)fp.capU)));
     HIPCK(c, F.perm2.reserve_exact(std::max(F.perm2.cap, (size_t)fp.capU)));
     HIPCK(c, F.perm3.reserve_exact(std::max(F.perm3.cap, (size_t)fp.capU)));
-    fp.perm = F.perm.p; fp.perm2 = F.perm2.p; fp.perm3 = F.perm3.p;
-    fp.waveAllBelow = c->tuning.waveAllBelow > 0 ? c->tuning.waveAllBelow : (c->tuning.waveAllBelow < 0 ? 0 : 6144);
+    HIPCK(c, F.perm4.reserve_exact(std::max(F.perm4.cap, (size_t)fp.capU)));
+    fp.perm = F.perm.p; fp.perm2 = F.perm2.p; fp.perm3 = F.perm3.p; fp.perm4 = F.perm4.p;
+    fp.waveAllBelow = c->tuning.waveAllBelow > 0 ? c->tuning.waveAllBelow : (c->tuning.waveAllBelow < 0 ? 0 : 24576);
     // the visiting-order layout of the items (k_fr_layout_*): one 32-byte record per item, the levels' ranges, per-search bases
     fp.maxLevels = 4096;
     fp.capVisit = fp.capU + fp.capC;
@@ -1013,7 +1022,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     // items whose two lists add up to this many entries are walked by a wavefront each (k_fr_updating_wave: 54 KB of LDS per
     // wavefront, two per compute unit)
     // (a handful of searches -- the re-search of a proposed move -- wait for every single item: all of them by wavefronts)
-    const int heavyMin = m <= 64 ? 1 : std::max(256, FR_HEAVY_MULT * (int)meanEnt / 4), gridWave = 256;
+    const int heavyMin = m <= 64 ? 1 : std::max(256, FR_HEAVY_MULT * (int)meanEnt / 4), gridWave = 256, gridWaveSmall = 1280;
     const int bigMin = m <= 64 ? (1 << 30) : FR_BIG_MIN;                  // (lists of this many entries together: 16 items to a wavefront)
     std::vector<size_t> slotsC, slotsU;
     if (!F.side) {
@@ -1046,8 +1055,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         TRY(stage("k_fr_sort_level"));
         TRY(fr_launch_updating(c, s, gridUpd, av, T, P, fp, budget, heavyMin));
         TRY(stage("k_fr_updating"));
-        if (heavyMin > 0)
+        if (heavyMin > 0) {
+            TRY(fr_launch_updating_wave_small(c, s, gridWaveSmall, av, T, P, fp, budget, heavyMin, scratchLanes + 256));
             TRY(fr_launch_updating_wave(c, s, gridWave, av, T, P, fp, budget, heavyMin, scratchLanes));
+        }
         TRY(stage("k_fr_updating_wave"));
         HIPCK(c, hipEventRecord(a1, s));
         HIPCK(c, hipStreamWaitEvent(s, F.evJoin, 0));

@@ -85,7 +85,8 @@ struct FCtr {                          // device-side bookkeeping of the level l
     alignas(128) unsigned long long permUp;
     alignas(128) unsigned long long permDownB;    // ... those with long lists (16 to a wavefront)
     alignas(128) unsigned long long permUpB;
-    alignas(128) unsigned long long permHeavy;    // ... those that go a wavefront each (k_fr_updating_wave)
+    alignas(128) unsigned long long permHeavy;    // ... those that go a wavefront each, lists of <= 128 entries (k_fr_updating_wave_s)
+    alignas(128) unsigned long long permHeavy2;   // ... with longer lists (k_fr_updating_wave: one wavefront per compute unit)
     alignas(128) unsigned long long nLists;       // temporary lists
     alignas(128) unsigned long long usedW;
     alignas(128) unsigned long long usedA;
@@ -120,7 +121,7 @@ struct FPools {
     int32_t *tot; long long *vbase;    // per search: items in its two seed subtrees, and where its visiting order starts
     int32_t *perm, *perm2;             // the level's one-lane updating items: moving down from the front, crawling up from the back
                                        // (perm2: those with long lists)
-    int32_t *perm3;                    // the level's items walked by a wavefront each
+    int32_t *perm3, *perm4;            // the level's items walked by a wavefront each: the two size classes
     int32_t waveAllBelow;              // a level with at most this many updating items: all of them by wavefronts
     // per-lane scratch
     uint2 *sw; double *sa; double *sais;
@@ -336,6 +337,31 @@ __device__ __forceinline__ bool fr_upd_heavy(const ArenaViewS &av, const DevTree
 {
     return heavyMin > 0 && it.dir != 3 && fr_upd_size(av, T, fp, it) >= heavyMin;
 }
+// Does a wavefront-wide walk with staging areas for input lists of wuIn entries (and capW entries for appendProbNode's two
+// lists) take this item?  Every list the item touches must fit; an item next to a MAT reference branch re-expresses lists on
+// the way and is walked by one lane.
+__device__ inline bool fr_wave_fits(const ArenaViewS &av, const DevTree &T, const FPools &fp, const FItem &it, const int wuIn, const int capW)
+{
+    const int dir = it.dir;
+    if (dir == 3 || !fvalid(it.hPassed)) return false;
+    const NodeRec r1 = T.nd[it.t1];
+    if (fp.mat && (r1.c0Frame != r1.frameOf || r1.c1Frame != r1.frameOf || r1.upFrame != r1.frameOf)) return false;
+    const int nP = it.hPassed >= 0 ? fp.tn[it.hPassed] : av.n_ent[-it.hPassed - 10];
+    const int nR = it.hRpr >= 0 ? fp.tn[it.hRpr] : av.n_ent[-it.hRpr - 10];
+    if (nP > wuIn || nR > capW) return false;
+    const int other = dir == 0 ? -1 : (dir == 1 ? r1.c1 : r1.c0);
+    const int upT = r1.up;
+    const int ids[6] = {r1.lower, r1.totUp, dir == 0 && r1.c0 >= 0 ? T.nd[r1.c0].lower : -1, dir == 0 && r1.c1 >= 0 ? T.nd[r1.c1].lower : -1,
+                        other >= 0 ? T.nd[other].lower : -1,
+                        (dir != 0 && upT >= 0) ? (r1.whichChild ? T.nd[upT].upLeft : T.nd[upT].upRight) : -1};
+    for (int k = 0; k < 6; k++) if (ids[k] >= 0 && av.n_ent[ids[k]] > wuIn) return false;
+    // (crawling up, the merged lower list is an input of the next merge)
+    if (dir != 0 && ids[4] >= 0 && nP + av.n_ent[ids[4]] > wuIn) return false;
+    return true;
+}
+#define FR_WAVE_SMALL_IN 128           // the small class of the wavefront-wide items: staging for 128-entry lists (27 KB of LDS per
+#define FR_WAVE_SMALL_CAPW 256         // wavefront, five wavefronts per compute unit); the rest: 512 entries, one per compute unit
+
 // One lane takes milliseconds for an item whatever the GPU is doing, and a level waits for its slowest item: a level with few
 // items -- every level past the first ten, where a few thousand searches near the root are still updating lists -- is walked by
 // wavefronts altogether (~0.1 ms per item, a few hundred at a time).
@@ -365,3 +391,6 @@ int fr_launch_updating(maple_ctx *c, hipStream_t s, int grid, const ArenaViewS &
 __attribute__((visibility("hidden")))
 int fr_launch_updating_wave(maple_ctx *c, hipStream_t s, int grid, const ArenaViewS &av, const DevTree &T, const SearchParams &P,
                             const frt::FPools &fp, int budget, int heavyMin, long long laneBase);
+__attribute__((visibility("hidden")))        // (frontier_updw128.hip: the small size class)
+int fr_launch_updating_wave_small(maple_ctx *c, hipStream_t s, int grid, const ArenaViewS &av, const DevTree &T, const SearchParams &P,
+                                  const frt::FPools &fp, int budget, int heavyMin, long long laneBase);

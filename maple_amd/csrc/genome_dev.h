@@ -388,6 +388,30 @@ template <bool RV, bool U, bool SS> struct PairWalk {
         return false;
     }
 
+    // The whole walk with the lanes of a wavefront brought together at the sites that need work.  Most steps of a walk need
+    // none (both sides reference runs, or missing data); a wavefront that calls step() in a loop executes the ~100
+    // instructions of the per-site arithmetic at EVERY step, because at every step some lane of the 64 has a site to work on.
+    // Here a lane first runs ahead over its work-free steps (a dozen instructions each) and stops at its next site; the
+    // arithmetic is then executed once for all lanes that have one.  Same steps in the same order per lane: same result.
+    __device__ inline void run()
+    {
+        constexpr unsigned long long WORK = work_table();
+        for (;;) {
+            bool end = false;
+            for (;;) {
+                const int pa = (int)(uint32_t)wa, pb = (int)(uint32_t)wb;
+                const int t1 = (int)((wa >> 32) & 7ull), t2 = (int)((wb >> 32) & 7ull);
+                if ((WORK >> (t1 * 8 + t2)) & 1ull) break;
+                const int pos = min(pa, pb);
+                if (pos == lRef) { end = true; break; }
+                if (pa == pos) { ++ia; wa = pw[ia]; }
+                if (pb == pos) { ++ib; wb = cw[ib]; }
+            }
+            if (end) return;
+            if (step()) return;
+        }
+    }
+
     __device__ inline double finish() const
     {
         if (dead) return -INFINITY;
@@ -404,6 +428,15 @@ __device__ inline double append_walk(const Ctx<RV, U, SS> &c, ListRef P, ListRef
     PairWalk<RV, U, SS> w(c, Cl, isTipC, bLen);
     w.start(P);
     while (!w.step()) {}
+    return w.finish();
+}
+// ... for kernels whose lanes walk unrelated pairs side by side (PairWalk::run)
+template <bool RV, bool U, bool SS>
+__device__ inline double append_walk_gathered(const Ctx<RV, U, SS> &c, ListRef P, ListRef Cl, bool isTipC, double bLen)
+{
+    PairWalk<RV, U, SS> w(c, Cl, isTipC, bLen);
+    w.start(P);
+    w.run();
     return w.finish();
 }
 
