@@ -145,6 +145,21 @@ __device__ __forceinline__ double append_walk_m(const Ctx<RV, U, SS> &c, const P
     int nCarry = 0;
     constexpr unsigned long long WORK = work_table();
     for (;;) {
+#ifndef MAPLE_WALK_NO_GATHER
+        // (a lane first runs ahead over the steps that need no work and stops at its next site: the per-site arithmetic below is
+        // then executed once for all lanes of the wavefront that have a site, not at every step for the few that do -- see
+        // PairWalk::run, genome_dev.h.  Same steps in the same order per lane.)
+        bool atEnd = false;
+        for (;;) {
+            const int pa0 = (int)(uint32_t)wa, pb0 = (int)(uint32_t)wb;
+            if ((WORK >> ((int)((wa >> 32) & 7ull) * 8 + (int)((wb >> 32) & 7ull))) & 1ull) break;
+            const int pos0 = min(pa0, pb0);
+            if (pos0 == lRef) { atEnd = true; break; }
+            if (pa0 == pos0) { ++ia; wa = P.word(ia); }
+            if (pb0 == pos0) { ++ib; wb = C.word(ib); }
+        }
+        if (atEnd) break;
+#endif
         const int pa = (int)(uint32_t)wa, pb = (int)(uint32_t)wb;
         const uint32_t m1 = (uint32_t)(wa >> 32), m2 = (uint32_t)(wb >> 32);
         const int t1 = m1 & 7u, t2 = m2 & 7u;

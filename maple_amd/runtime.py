@@ -108,8 +108,10 @@ class Device:
 
     def __init__(self, ref_idx, root_freqs, *, device=0, thresholdProb=1e-8, minBLenSensitivity=None,
                  thresholdDiffForUpdate=1e-5, thresholdFoldChangeUpdate=1.01, defaultBLen=0.000033,
-                 arena_bytes=0):
-        self.lib = load_library()
+                 arena_bytes=0, lib=None):
+        # (lib: another library with the same C ABI, handed in explicitly -- the tests diff libmaple_hip.so against its CPU twin
+        # this way; nothing in the package ever passes one)
+        self.lib = lib if lib is not None else load_library()
         self.ref_idx = _u8(ref_idx)
         self.lRef = int(len(self.ref_idx))
         if minBLenSensitivity is None:
