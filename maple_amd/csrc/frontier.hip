@@ -151,13 +151,14 @@ __global__ void k_fr_snap(FCtr *ctr, long long capU, long long capC, unsigned lo
 // M:7111-7118 / 7148-7155 on the way down, 7359-7366 / 7388-7395 on the way up).  One lane per such item (about one push in a
 // hundred crosses a reference branch); a list that shorten() (M:7087) would change hands its search to the one-lane kernel.
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(FR_BLOCK) void k_fr_pass(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, FPools fp)
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_pass(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, FPools fp, long long slabBase)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
     const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long slab = slabBase + laneId;                                // (scratch slabs of its own: it runs next to k_fr_updating)
     const long long lo = (long long)fp.ctr->loP, hi = (long long)fp.ctr->hiP;
     for (long long i = lo + laneId; i < hi; i += (long long)gridDim.x * blockDim.x) {
         FItem &it = item_of(fp, fp.passList[i]);
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_pass(const DevModel *__restrict
         const NodeRec r1 = T.nd[it.t1];
         // dir 0: came down the branch above t1; dir 1 / 2: came up the branch above t1's child 0 / 1
         const int mutId = it.dir == 0 ? r1.mutId : T.nd[it.dir == 1 ? r1.c0 : r1.c1].mutId;
-        const int h = fpass_removed(c, fp, av, laneId, it.hRpr, mutId, it.dir != 0);
+        const int h = fpass_removed(c, fp, av, slab, it.hRpr, mutId, it.dir != 0);
         if (!fvalid(h)) { S.state = FS_FALLBACK; continue; }
         it.hRpr = h;
         it.flags &= (uint8_t)~FI_NEEDPASS;
@@ -920,9 +921,9 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, F.tn.reserve_exact(grow((size_t)capL, F.tn.cap)));
     HIPCK(c, F.tna.reserve_exact(grow((size_t)capL, F.tna.cap)));
     HIPCK(c, F.tflag.reserve_exact(grow((size_t)capL, F.tflag.cap)));
-    HIPCK(c, F.sw.reserve_exact((size_t)(scratchLanes + 2048) * capE));     // (+ one slab per wavefront of k_fr_updating_wave)
-    HIPCK(c, F.sa.reserve_exact((size_t)(scratchLanes + 2048) * capE * 5));
-    HIPCK(c, F.sais.reserve_exact((size_t)(scratchLanes + 2048) * capE * 2));
+    HIPCK(c, F.sw.reserve_exact((size_t)(scratchLanes + 2048 + 16384) * capE));     // (+ one slab per wavefront of k_fr_updating_wave)
+    HIPCK(c, F.sa.reserve_exact((size_t)(scratchLanes + 2048 + 16384) * capE * 5));
+    HIPCK(c, F.sais.reserve_exact((size_t)(scratchLanes + 2048 + 16384) * capE * 2));
     HIPCK(c, F.bw.reserve_exact((size_t)capBig));
     HIPCK(c, F.ba.reserve_exact((size_t)capBig * 5));
     HIPCK(c, F.nodes.reserve((size_t)m));
@@ -1033,15 +1034,17 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     const hipStream_t s2 = F.side;
     auto level = [&]() -> int {                                            // the kernels of one level, each between its own events
         hipEvent_t a0, a1, b0, b1;
-        if (fp.mat) {                                                      // the removed lists of the items that crossed a reference branch
-            FR_DISPATCH3(c, k_fr_pass, <<<std::min(gridUpd, 256), FR_BLOCK, 0, s>>>(c->d_model, av, T, fp));
-            TRY(stage("k_fr_pass"));
-        }
         HIPCK(c, hipEventRecord(F.evFork, s));                             // (after the level's snap)
         HIPCK(c, hipStreamWaitEvent(s2, F.evFork, 0));
         TRY(maple_internal_ev_pair(c, &b0, &b1, MAPLE_K_FR_CACHED, 0.0, 0.0));
         slotsC.push_back(c->ev_used / 2 - 1);
         HIPCK(c, hipEventRecord(b0, s2));
+        if (fp.mat) {
+            // the removed lists of the cached-regime items that crossed a reference branch: on the cached kernel's stream, ahead of
+            // it (only that kernel reads them), next to the level's updating items
+            FR_DISPATCH3(c, k_fr_pass, <<<64, FR_BLOCK, 0, s2>>>(c->d_model, av, T, fp, scratchLanes + 2048));
+            TRY(stage("k_fr_pass"));
+        }
         FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s2>>>(c->d_model, av, anyWide ? Tw : T, P, fp, budget,
                                                                         anyWide ? F.wideRow.p : nullptr,
                                                                         anyWide ? wide->fin : FiniteRows{nullptr, nullptr, 0}));

@@ -3052,6 +3052,36 @@ __global__ __launch_bounds__(64) void k_finite_prefix(int nRows, int nWords, con
     }
 }
 
+// Trees with MAT local references: lists up the chain of their frames (passGenomeListThroughBranch, one enclosing frame per
+// round, batched) until every one is written in the ROOT's frame.  ids / fr: list ids and their frames, both updated in place.
+static int lists_to_root_frame(maple_ctx *c, std::vector<int32_t> &ids, std::vector<int32_t> fr)
+{
+    const PlaceMeta &Fm = *c->place;
+    std::vector<int32_t> who, src, ml, out;
+    std::vector<uint8_t> dir;
+    for (;;) {
+        who.clear(); src.clear(); ml.clear();
+        for (size_t k = 0; k < ids.size(); k++)
+            if (fr[k] != 0 && ids[k] >= 0) { who.push_back((int32_t)k); src.push_back(ids[k]); ml.push_back(c->h_tree_mut[Fm.frameNode[fr[k]]]); }
+        if (who.empty()) return MAPLE_OK;
+        dir.assign(who.size(), 1);
+        out.resize(who.size());
+        TRY(maple_pass_branch_batch(c, (int32_t)who.size(), src.data(), ml.data(), dir.data(), out.data()));
+        for (size_t i = 0; i < who.size(); i++) { ids[who[i]] = out[i]; fr[who[i]] = Fm.frameParent[fr[who[i]]]; }
+    }
+}
+// ... the candidates' copies: made once per tree, kept in the arena until the tree changes or a release of the caller's takes them
+static int ensure_cand_root(maple_ctx *c)
+{
+    if (c->cand_root_end >= 0) return MAPLE_OK;
+    std::vector<int32_t> candRoot(c->h_cand_ids);
+    TRY(lists_to_root_frame(c, candRoot, c->h_cand_frame));
+    TRY(h2d(c, c->s_cand_root, candRoot.data(), candRoot.size()));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->cand_root_end = (int64_t)c->h_n_ent.size();
+    return MAPLE_OK;
+}
+
 extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *nodes, const maple_search_params *sp,
                                       int32_t ws_entries_per_lane, int32_t *bestNode, double *bestScore, double *blen3,
                                       int32_t *placement, double *improvement, double *currentLK, int32_t *nAppend,
@@ -3408,34 +3438,12 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             }
             if (matPre) {
                 const PlaceMeta &Fm = *c->place;
-                // lists up the chain of their frames, one enclosing frame per round, until every one is in the root's
-                auto to_root = [&](std::vector<int32_t> &ids, std::vector<int32_t> fr) -> int {
-                    std::vector<int32_t> who, src, ml, out;
-                    std::vector<uint8_t> dir;
-                    for (;;) {
-                        who.clear(); src.clear(); ml.clear();
-                        for (size_t k = 0; k < ids.size(); k++)
-                            if (fr[k] != 0 && ids[k] >= 0) { who.push_back((int32_t)k); src.push_back(ids[k]); ml.push_back(c->h_tree_mut[Fm.frameNode[fr[k]]]); }
-                        if (who.empty()) return MAPLE_OK;
-                        dir.assign(who.size(), 1);
-                        out.resize(who.size());
-                        TRY(maple_pass_branch_batch(c, (int32_t)who.size(), src.data(), ml.data(), dir.data(), out.data()));
-                        for (size_t i = 0; i < who.size(); i++) { ids[who[i]] = out[i]; fr[who[i]] = Fm.frameParent[fr[who[i]]]; }
-                    }
-                };
-                // (the candidates' copies are made once per tree and stay in the arena -- until the tree changes or a release of the
-                // caller's takes them; the removed lists' copies live for this call)
-                if (c->cand_root_end < 0) {
-                    std::vector<int32_t> candRoot(c->h_cand_ids);
-                    TRY(to_root(candRoot, c->h_cand_frame));
-                    TRY(h2d(c, c->s_cand_root, candRoot.data(), candRoot.size()));
-                    HIPCK(c, hipStreamSynchronize(c->stream));
-                    c->cand_root_end = (int64_t)c->h_n_ent.size();
-                }
+                // (the candidates' copies are made once per tree; the removed lists' copies live for this call)
+                TRY(ensure_cand_root(c));
                 TRY(maple_arena_mark(c, &preMark));
                 std::vector<int32_t> qf(mZ);
                 for (int k = 0; k < mZ; k++) qf[k] = Fm.frameOf[nodes[preIdx[k]]];
-                TRY(to_root(ql, qf));
+                TRY(lists_to_root_frame(c, ql, qf));
                 preFrameParent = Fm.frameParent;
                 preFrameNode = Fm.frameNode;
                 useFin = true;
@@ -3575,10 +3583,19 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         }
         size_t chunk = cacheBudget / rowBytes;
         if (chunk < 1) chunk = 1;
+        // Trees with local references: the rows of the searches that ran over their budget are made in the ROOT's frame as well
+        // (appendProbNode does not depend on the frame, see above) and replayed inside the frontier tier; only what the tier hands
+        // back goes the frame-by-frame way.
+        const bool rootRowsOK = nF > 1 && useFrontier && c->scan_valid && c->place && !c->tuning.noCladeScan && !c->tuning.wideOutsideFrontier
+                                && wide.size() >= 64;
+        std::vector<int32_t> frameWay;                                  // (searches of a tree with references left to the old path)
+        for (int wpass = 0; wpass < 2; wpass++) {
+        if (wpass == 1) { if (frameWay.empty()) break; wide.swap(frameWay); frameWay.clear(); }
+        const bool rootRows = rootRowsOK && wpass == 0;
         size_t w0 = 0;
         while (w0 < wide.size()) {
             int m = (int)std::min(chunk, wide.size() - w0);
-            if (nF > 1) {
+            if (nF > 1 && !rootRows) {
                 // the removed list goes into EVERY reference frame: bound the batch by what the arena can take
                 const int64_t freeEnt = (c->cap_ent - c->used_ent) / 3, freeAux = (c->cap_aux - c->used_aux) / 3;
                 int64_t needEnt = 0, needAux = 0;
@@ -3618,13 +3635,22 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             if (dbgT) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] t=%.1f ms: score table reserved\n", tms(tStart, tnow())); }
             TRY(h2d(c, c->s_u8[3], qt.data(), (size_t)m));
             TRY(h2d(c, c->s_f64[3], qb.data(), (size_t)m));
-            if (nF == 1) {
+            if (nF == 1 || rootRows) {
+                int64_t chunkMark = -1;
+                if (rootRows) {                                        // candidates (once per tree) and this chunk's removed lists in the root's frame
+                    TRY(ensure_cand_root(c));
+                    TRY(maple_arena_mark(c, &chunkMark));
+                    std::vector<int32_t> qf(m);
+                    for (int k = 0; k < m; k++) qf[k] = F.frameOf[qn[k]];
+                    TRY(lists_to_root_frame(c, ql, qf));
+                    useFin = true;
+                }
                 TRY(h2d(c, c->s_i32[6], ql.data(), (size_t)m));
                 double qBytes = 0.0;                                   // each query list once per launch
                 for (int k = 0; k < m; k++) qBytes += 8.0 * c->h_n_ent[ql[k]] + 8.0 * c->h_n_aux[ql[k]];
                 TRY(fin_reserve((size_t)m));
-                TRY(launch_append_queries(c, c->stream, m, c->s_i32[6].p, c->n_scored, c->t_i32[8].p, 0, 0.0, c->s_cache.p, nT,
-                                          c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p, MAPLE_K_SPR_SCORE,
+                TRY(launch_append_queries(c, c->stream, m, c->s_i32[6].p, c->n_scored, rootRows ? c->s_cand_root.p : c->t_i32[8].p, 0, 0.0, c->s_cache.p, nT,
+                                          rootRows ? c->t_cand_rank.p : c->t_scored_col.p, c->s_u8[3].p, c->s_f64[3].p, MAPLE_K_SPR_SCORE,
                                           (double)m * c->scored_bytes_total + qBytes, nullptr, nullptr, nullptr, 0, 1, useFin ? c->s_fin_mask.p : nullptr));
                 if (useFin) TRY(fin_prefix(c->stream, 0, (size_t)m));
                 if (dbgT) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] t=%.1f ms: scored\n", tms(tStart, tnow())); }
@@ -3636,6 +3662,11 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                     std::vector<int32_t> rowId(m);
                     for (int k = 0; k < m; k++) rowId[k] = k;
                     FrontierWide fw2{rowId.data(), c->s_cache.p, finRows, nullptr, 1};
+                    if (rootRows) {
+                        TRY(h2d(c, c->s_frame_parent, F.frameParent.data(), F.frameParent.size()));
+                        TRY(h2d(c, c->s_frame_node, F.frameNode.data(), F.frameNode.size()));
+                        fw2.frameParent = c->s_frame_parent.p; fw2.frameNode = c->s_frame_node.p; fw2.nFrames = (int)F.frameParent.size();
+                    }
                     std::vector<SearchOut> part(m);
                     FrontierStats fs2;
                     const int rcF = frontier_search(c, P, m, qn.data(), 1 << 30, 0, part.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs2, 0, &fw2);
@@ -3648,16 +3679,24 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                     if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: %d searches over budget replayed inside the frontier tier (%d levels), %zu handed back\n",
                                       tms(tStart, tnow()), m, fs2.levels, qn2.size());
                     qn.swap(qn2); sl.swap(sl2);
+                    if (rootRows) {                                     // (the one-wavefront-per-search replay wants the list in every frame)
+                        for (int32_t i : sl) frameWay.push_back(i);
+                        qn.clear();
+                    }
                     if (!qn.empty()) rowOverride = &rows2;
                     const int rcW = qn.empty() ? MAPLE_OK : run_queries(qn, sl, c->s_cache.p, 0, nullptr, 0);
                     rowOverride = nullptr;
                     finRows = FiniteRows{nullptr, nullptr, 0};
                     TRY(rcW);
+                } else if (rootRows) {                                  // (a tail chunk too small for the tier: the frame-by-frame way)
+                    for (int32_t i : sl) frameWay.push_back(i);
+                    finRows = FiniteRows{nullptr, nullptr, 0};
                 } else {
                 const int rcW = run_queries(qn, sl, c->s_cache.p, 0, nullptr, 0);
                 finRows = FiniteRows{nullptr, nullptr, 0};
                 TRY(rcW);
                 }
+                if (chunkMark >= 0) TRY(maple_arena_release(c, chunkMark));
                 if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: replayed\n", tms(tStart, tnow()));
             } else {
                 // the removed list in every MAT reference frame, along the paths the traversal itself takes
@@ -3717,6 +3756,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             }
             w0 += (size_t)m;
         }
+        }   // (wpass)
     }
 #ifdef MAPLE_SPR_PROFILE
     {
