@@ -147,8 +147,7 @@ def parse_args(argv=None):
     ap.add_argument("--refs", choices=["auto", "local", "none"], default="auto",
                     help="local: the tree carries MAT local references (setUpMAT's rule, a reference node per 50 descendants, M:166 / "
                          "6152-6164 -- the form MAPLE's own trees have, M:8296-8354), the searches re-express their lists at every "
-                         "reference branch they cross; none: every list in the root's frame (rounds 1-3); auto = local up to 200 000 "
-                         "samples, none above")
+                         "reference branch they cross; none: every list in the root's frame (rounds 1-3); auto = local")
     ap.add_argument("--synth", choices=["auto", "v1", "v2"], default="auto",
                     help="generator of the synthetic input: v1 = maple_amd.synth.make_dataset (numpy stream; the 10 000 / 100 000-sample "
                          "trees of rounds 1-3), v2 = the same model from csrc/synth_gen.c (seconds at 1 000 000 samples); auto = v1 up to "
@@ -283,7 +282,7 @@ def run_leg(args, env):
     def upload_plain_tree():
         dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist, mirror.is_tip,
                         mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up, no_mut)
-    refs = args.refs if args.refs != "auto" else ("local" if args.samples <= 200000 else "none")
+    refs = args.refs if args.refs != "auto" else "local"
     ht, n_ref, refs_s = None, 0, 0.0
     if refs == "local":
         # the tree as MAPLE itself keeps it: MAT local references (maple_amd/mat.py: the reference nodes chosen by setUpMAT's rule, every

@@ -261,9 +261,10 @@ int maple_spr_search_visited(maple_ctx *ctx, int64_t cap, int32_t *query, int32_
 
 /* Profile of the last frontier-tier pass of maple_spr_search_batch (until the next maple_timing_reset): per level of the
  * expansion, the items that still updated genome lists, the items in the cached regime, and the HIP-event time (ms) of the
- * level's two kernels.  *n levels (the first min(*n, cap) are written).  A measurement aid; nothing is computed with it. */
+ * level's two kernels; waveItems*: how many of the list-updating items were walked a wavefront each, by size class.  *n levels
+ * (the first min(*n, cap) are written).  A measurement aid; nothing is computed with it. */
 int maple_debug_frontier_levels(maple_ctx *ctx, int32_t cap, int64_t *itemsUpdating, int64_t *itemsCached, float *msUpdating,
-                                float *msCached, int32_t *n);
+                                float *msCached, int32_t *n, int64_t *waveItemsSmall /* or NULL */, int64_t *waveItemsBig /* or NULL */);
 
 typedef struct {
     double oneMutBLen;                          /* M:3606 */

@@ -145,7 +145,7 @@ __device__ __forceinline__ double append_walk_m(const Ctx<RV, U, SS> &c, const P
     int nCarry = 0;
     constexpr unsigned long long WORK = work_table();
     for (;;) {
-#ifndef MAPLE_WALK_NO_GATHER
+#ifdef MAPLE_WALK_GATHER                                                     // (measured on the 1 000 000-tip leg: 8 % slower)
         // (a lane first runs ahead over the steps that need no work and stops at its next site: the per-site arithmetic below is
         // then executed once for all lanes of the wavefront that have a site, not at every step for the few that do -- see
         // PairWalk::run, genome_dev.h.  Same steps in the same order per lane.)

@@ -31,4 +31,5 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
 __attribute__((visibility("hidden"))) void frontier_scratch_free(maple_ctx *c);
 __attribute__((visibility("hidden"))) int frontier_export(maple_ctx *c, long long cap, int32_t *q, int32_t *node, long long *n);
 __attribute__((visibility("hidden")))
-int frontier_level_profile(maple_ctx *c, int cap, long long *itemsU, long long *itemsC, float *msU, float *msC, int *n);
+int frontier_level_profile(maple_ctx *c, int cap, long long *itemsU, long long *itemsC, float *msU, float *msC, int *n,
+                           long long *waveSmall = nullptr, long long *waveBig = nullptr);

@@ -138,10 +138,12 @@ __global__ void k_fr_snap(FCtr *ctr, long long capU, long long capC, unsigned lo
         ctr->loC = ctr->hiC; ctr->hiC = min(ctr->usedC, (unsigned long long)capC);
         ctr->loP = ctr->hiP; ctr->hiP = min(ctr->nPass, (unsigned long long)capPass);
         ctr->bigUsed = 0;
+        const unsigned long long heavySmall = ctr->permHeavy, heavyBig = ctr->permHeavy2;
         ctr->permDown = ctr->permUp = ctr->permDownB = ctr->permUpB = ctr->permHeavy = ctr->permHeavy2 = 0;
         if (lvl) {
             const int l = ctr->nLevels++;
-            if (l < maxLevels) { lvl[4 * l] = ctr->loU; lvl[4 * l + 1] = ctr->hiU; lvl[4 * l + 2] = ctr->loC; lvl[4 * l + 3] = ctr->hiC; }
+            if (l < maxLevels) { lvl[6 * l] = ctr->loU; lvl[6 * l + 1] = ctr->hiU; lvl[6 * l + 2] = ctr->loC; lvl[6 * l + 3] = ctr->hiC; lvl[6 * l + 4] = lvl[6 * l + 5] = 0; }
+            if (l > 0 && l - 1 < maxLevels) { lvl[6 * (l - 1) + 4] = heavySmall; lvl[6 * (l - 1) + 5] = heavyBig; }   // (the level before: its wavefront-wide items)
         }
     }
 }
@@ -277,10 +279,10 @@ void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Sear
         if (scored) {
             if (r1.totUp < 0) { it.flags |= FI_DEAD; continue; }
             const FList lp = flist(av, fp, ftree(r1.totUp)), lr = flist(av, fp, hRpr);
-#ifdef MAPLE_FR_CACHED_PLAIN_WALK
-            midProb = append_walk(c, fref(lp), fref(lr), S.isRemovedTip != 0, S.removedBLen);
+#ifdef MAPLE_FR_CACHED_GATHERED_WALK                                            // (measured: 40 % slower -- the walk is bound by the chain of
+            midProb = append_walk_gathered(c, fref(lp), fref(lr), S.isRemovedTip != 0, S.removedBLen);   // dependent loads, and gathering lengthens it)
 #else
-            midProb = append_walk_gathered(c, fref(lp), fref(lr), S.isRemovedTip != 0, S.removedBLen);
+            midProb = append_walk(c, fref(lp), fref(lr), S.isRemovedTip != 0, S.removedBLen);
 #endif
             it.flags |= FI_SCORED;
             nSc++; bSc += 8ull * (unsigned long long)(lp.n + lp.na) + 8ull;
@@ -322,8 +324,8 @@ __device__ __forceinline__ int fsize(const FPools &fp, int ref) { return ref == 
 // (sizes, ranks and parents live in arrays of their own: the passes read one 32-byte sector of an item and 4-byte neighbours)
 __global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_sizes(FPools fp, int level)
 {
-    const long long loU = (long long)fp.lvl[4 * level], hiU = (long long)fp.lvl[4 * level + 1];
-    const long long loC = (long long)fp.lvl[4 * level + 2], hiC = (long long)fp.lvl[4 * level + 3];
+    const long long loU = (long long)fp.lvl[6 * level], hiU = (long long)fp.lvl[6 * level + 1];
+    const long long loC = (long long)fp.lvl[6 * level + 2], hiC = (long long)fp.lvl[6 * level + 3];
     const long long n = (hiU - loU) + (hiC - loC);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const bool isU = i < hiU - loU;
@@ -372,8 +374,8 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_seeds(int n, FPools fp)
 // ranks of the children and the item's own record, one level at a time from the first to the last
 __global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_place(FPools fp, int level)
 {
-    const long long loU = (long long)fp.lvl[4 * level], hiU = (long long)fp.lvl[4 * level + 1];
-    const long long loC = (long long)fp.lvl[4 * level + 2], hiC = (long long)fp.lvl[4 * level + 3];
+    const long long loU = (long long)fp.lvl[6 * level], hiU = (long long)fp.lvl[6 * level + 1];
+    const long long loC = (long long)fp.lvl[6 * level + 2], hiC = (long long)fp.lvl[6 * level + 3];
     const long long n = (hiU - loU) + (hiC - loC);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const bool isU = i < hiU - loU;
@@ -839,8 +841,8 @@ struct FrontierScratch {
     FPools lastPools{};
     // the two kernels of a level read disjoint items (they only meet in the pools' atomic counters): the cached-regime one runs
     // on a stream of its own next to the updating one -- a level of the latter lasts as long as its slowest item, on a few lanes
-    hipStream_t side = nullptr;
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr;     // (side2: the 512-entry class of the wavefront-wide items, next to the small class)
+    hipEvent_t evFork = nullptr, evJoin = nullptr, evFork2 = nullptr, evJoin2 = nullptr;
 };
 
 }  // namespace
@@ -856,7 +858,10 @@ void frontier_scratch_free(maple_ctx *c)
     F->perm.release(); F->perm2.release(); F->perm3.release(); F->perm4.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release(); F->passList.release(); F->tflag.release();
     if (F->evFork) (void)hipEventDestroy(F->evFork);
     if (F->evJoin) (void)hipEventDestroy(F->evJoin);
+    if (F->evFork2) (void)hipEventDestroy(F->evFork2);
+    if (F->evJoin2) (void)hipEventDestroy(F->evJoin2);
     if (F->side) (void)hipStreamDestroy(F->side);
+    if (F->side2) (void)hipStreamDestroy(F->side2);
     delete F;
     c->frontier = nullptr;
 }
@@ -952,7 +957,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, F.lpar.reserve_exact(std::max(F.lpar.cap, (size_t)fp.capVisit)));
     }
     fp.lsize = F.lsize.p; fp.lpos = F.lpos.p; fp.lpar = F.lpar.p;
-    HIPCK(c, F.lvl.reserve((size_t)fp.maxLevels * 4));
+    HIPCK(c, F.lvl.reserve((size_t)fp.maxLevels * 6));
     HIPCK(c, F.tot.reserve((size_t)m));
     HIPCK(c, F.vbase.reserve((size_t)m + 1));
     fp.visit = layoutOK ? (FVisit *)F.visit.p : nullptr; fp.lvl = F.lvl.p; fp.tot = F.tot.p; fp.vbase = F.vbase.p;
@@ -1030,8 +1035,11 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, hipStreamCreateWithFlags(&F.side, hipStreamNonBlocking));
         HIPCK(c, hipEventCreateWithFlags(&F.evFork, hipEventDisableTiming));
         HIPCK(c, hipEventCreateWithFlags(&F.evJoin, hipEventDisableTiming));
+        HIPCK(c, hipStreamCreateWithFlags(&F.side2, hipStreamNonBlocking));
+        HIPCK(c, hipEventCreateWithFlags(&F.evFork2, hipEventDisableTiming));
+        HIPCK(c, hipEventCreateWithFlags(&F.evJoin2, hipEventDisableTiming));
     }
-    const hipStream_t s2 = F.side;
+    const hipStream_t s2 = F.side, s3 = F.side2;
     auto level = [&]() -> int {                                            // the kernels of one level, each between its own events
         hipEvent_t a0, a1, b0, b1;
         HIPCK(c, hipEventRecord(F.evFork, s));                             // (after the level's snap)
@@ -1056,11 +1064,19 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, hipEventRecord(a0, s));
         k_fr_sort_level<<<512, FR_BLOCK, 0, s>>>(av, T, fp, heavyMin, bigMin);
         TRY(stage("k_fr_sort_level"));
+        if (heavyMin > 0) {
+            // the level's three kinds of list-updating items side by side: the 512-entry class of the wavefront-wide ones (few, the
+            // slowest: next to the root) on a stream of its own, the one-lane items and the small class behind each other
+            HIPCK(c, hipEventRecord(F.evFork2, s));
+            HIPCK(c, hipStreamWaitEvent(s3, F.evFork2, 0));
+            TRY(fr_launch_updating_wave(c, s3, gridWave, av, T, P, fp, budget, heavyMin, scratchLanes));
+            HIPCK(c, hipEventRecord(F.evJoin2, s3));
+        }
         TRY(fr_launch_updating(c, s, gridUpd, av, T, P, fp, budget, heavyMin));
         TRY(stage("k_fr_updating"));
         if (heavyMin > 0) {
             TRY(fr_launch_updating_wave_small(c, s, gridWaveSmall, av, T, P, fp, budget, heavyMin, scratchLanes + 256));
-            TRY(fr_launch_updating_wave(c, s, gridWave, av, T, P, fp, budget, heavyMin, scratchLanes));
+            HIPCK(c, hipStreamWaitEvent(s, F.evJoin2, 0));
         }
         TRY(stage("k_fr_updating_wave"));
         HIPCK(c, hipEventRecord(a1, s));
@@ -1069,7 +1085,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         return MAPLE_OK;
     };
     // (an error inside the loop leaves nothing in flight on either stream behind it)
-    auto bail = [&](int rc) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(s2); return rc; };
+    auto bail = [&](int rc) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(s2); (void)hipStreamSynchronize(s3); return rc; };
     // the host looks at the counters every few levels: a handful of searches (the re-search of a proposed move) is over after a few
     // levels and each look costs them less than the levels it saves; a whole round runs ~40
     const int groupLevels = m <= 64 ? 2 : 8;
@@ -1181,8 +1197,8 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     F.lastU = std::min((long long)hc.usedU, fp.capU); F.lastC = std::min((long long)hc.usedC, fp.capC); F.lastPools = fp;
     {
         const int nl = std::min(levels, fp.maxLevels);
-        F.lastLvl.assign((size_t)nl * 4, 0ull);
-        if (nl) HIPCK(c, hipMemcpy(F.lastLvl.data(), fp.lvl, (size_t)nl * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        F.lastLvl.assign((size_t)nl * 6, 0ull);
+        if (nl) HIPCK(c, hipMemcpy(F.lastLvl.data(), fp.lvl, (size_t)nl * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         F.lastSlotsU = slotsU; F.lastSlotsC = slotsC;
     }
     if (hc.overflow) F.lastU = F.lastC = -1;                              // (a pool overflowed: the item lists are not complete)
@@ -1216,15 +1232,18 @@ int frontier_export(maple_ctx *c, long long cap, int32_t *q, int32_t *node, long
 }
 
 // per level of the last frontier_search: updating / cached items and the HIP-event time of the level's two kernels (ms)
-int frontier_level_profile(maple_ctx *c, int cap, long long *itemsU, long long *itemsC, float *msU, float *msC, int *n)
+int frontier_level_profile(maple_ctx *c, int cap, long long *itemsU, long long *itemsC, float *msU, float *msC, int *n, long long *waveSmall,
+                           long long *waveBig)
 {
     FrontierScratch *F = (FrontierScratch *)c->frontier;
     if (!F) return fail(c, MAPLE_ERR_STATE, "no frontier search to report on");
-    const int nl = (int)std::min<size_t>(F->lastLvl.size() / 4, std::min(F->lastSlotsU.size(), F->lastSlotsC.size()));
+    const int nl = (int)std::min<size_t>(F->lastLvl.size() / 6, std::min(F->lastSlotsU.size(), F->lastSlotsC.size()));
     *n = nl;
     for (int l = 0; l < nl && l < cap; l++) {
-        itemsU[l] = (long long)(F->lastLvl[4 * l + 1] - F->lastLvl[4 * l]);
-        itemsC[l] = (long long)(F->lastLvl[4 * l + 3] - F->lastLvl[4 * l + 2]);
+        itemsU[l] = (long long)(F->lastLvl[6 * l + 1] - F->lastLvl[6 * l]);
+        itemsC[l] = (long long)(F->lastLvl[6 * l + 3] - F->lastLvl[6 * l + 2]);
+        if (waveSmall) waveSmall[l] = (long long)F->lastLvl[6 * l + 4];
+        if (waveBig) waveBig[l] = (long long)F->lastLvl[6 * l + 5];
         msU[l] = msC[l] = 0.f;
         const size_t su = F->lastSlotsU[l], sc = F->lastSlotsC[l];
         if (2 * su + 1 < c->ev_used) { HIPCK(c, hipEventSynchronize(c->evs[2 * su + 1])); HIPCK(c, hipEventElapsedTime(&msU[l], c->evs[2 * su], c->evs[2 * su + 1])); }

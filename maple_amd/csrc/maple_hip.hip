@@ -3847,12 +3847,13 @@ extern "C" int maple_spr_search_visited(maple_ctx *c, int64_t cap, int32_t *quer
 }
 
 extern "C" int maple_debug_frontier_levels(maple_ctx *c, int32_t cap, int64_t *itemsUpdating, int64_t *itemsCached, float *msUpdating,
-                                           float *msCached, int32_t *n)
+                                           float *msCached, int32_t *n, int64_t *waveItemsSmall, int64_t *waveItemsBig)
 {
     if (!c || cap < 0 || !itemsUpdating || !itemsCached || !msUpdating || !msCached || !n) return MAPLE_ERR_ARG;
     HIPCK(c, hipSetDevice(c->device));
     int nn = 0;
-    const int rc = frontier_level_profile(c, cap, (long long *)itemsUpdating, (long long *)itemsCached, msUpdating, msCached, &nn);
+    const int rc = frontier_level_profile(c, cap, (long long *)itemsUpdating, (long long *)itemsCached, msUpdating, msCached, &nn,
+                                          (long long *)waveItemsSmall, (long long *)waveItemsBig);
     *n = nn;
     return rc;
 }

@@ -583,10 +583,12 @@ class Device:
     def frontier_levels(self, cap=4096):
         """Per level of the last frontier-tier pass: (updating items, cached items, ms of k_fr_updating, ms of k_fr_cached)."""
         iu, ic = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
+        ws, wb = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
         mu, mc = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
         n = C.c_int32()
-        self._ck(self.lib.maple_debug_frontier_levels(self.h, int(cap), _ptr(iu), _ptr(ic), _ptr(mu), _ptr(mc), C.byref(n)))
+        self._ck(self.lib.maple_debug_frontier_levels(self.h, int(cap), _ptr(iu), _ptr(ic), _ptr(mu), _ptr(mc), C.byref(n), _ptr(ws), _ptr(wb)))
         k = min(cap, n.value)
+        self.last_wave_items = (ws[:k], wb[:k])      # (of the updating items: walked a wavefront each, small / 512-entry class)
         return iu[:k], ic[:k], mu[:k], mc[:k]
 
     def timing_read(self):

@@ -35,7 +35,8 @@ for i in range(3):
     r = dev.spr_search_batch(order, **kw)
     print(f"round {i}: {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
 iu, ic, mu, mc = dev.frontier_levels()
-print("level  updating_items  cached_items  ms_updating  ms_cached")
+ws, wb = dev.last_wave_items
+print("level  updating_items  (by wavefronts: small class, 512 class)  cached_items  ms_updating  ms_cached")
 for l in range(len(iu)):
-    print(f"{l:5d} {iu[l]:12d} {ic[l]:12d} {mu[l]:10.3f} {mc[l]:10.3f}")
+    print(f"{l:5d} {iu[l]:12d} {ws[l]:10d} {wb[l]:8d} {ic[l]:12d} {mu[l]:10.3f} {mc[l]:10.3f}")
 print("total", iu.sum(), ic.sum(), round(float(mu.sum()), 1), round(float(mc.sum()), 1))
