@@ -945,7 +945,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, F.perm3.reserve_exact(std::max(F.perm3.cap, (size_t)fp.capU)));
     HIPCK(c, F.perm4.reserve_exact(std::max(F.perm4.cap, (size_t)fp.capU)));
     fp.perm = F.perm.p; fp.perm2 = F.perm2.p; fp.perm3 = F.perm3.p; fp.perm4 = F.perm4.p;
-    fp.waveAllBelow = c->tuning.waveAllBelow > 0 ? c->tuning.waveAllBelow : (c->tuning.waveAllBelow < 0 ? 0 : 24576);
+    fp.waveAllBelow = c->tuning.waveAllBelow > 0 ? c->tuning.waveAllBelow : (c->tuning.waveAllBelow < 0 ? 0 : 8192);
     // the visiting-order layout of the items (k_fr_layout_*): one 32-byte record per item, the levels' ranges, per-search bases
     fp.maxLevels = 4096;
     fp.capVisit = fp.capU + fp.capC;
@@ -1064,19 +1064,14 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, hipEventRecord(a0, s));
         k_fr_sort_level<<<512, FR_BLOCK, 0, s>>>(av, T, fp, heavyMin, bigMin);
         TRY(stage("k_fr_sort_level"));
-        if (heavyMin > 0) {
-            // the level's three kinds of list-updating items side by side: the 512-entry class of the wavefront-wide ones (few, the
-            // slowest: next to the root) on a stream of its own, the one-lane items and the small class behind each other
-            HIPCK(c, hipEventRecord(F.evFork2, s));
-            HIPCK(c, hipStreamWaitEvent(s3, F.evFork2, 0));
-            TRY(fr_launch_updating_wave(c, s3, gridWave, av, T, P, fp, budget, heavyMin, scratchLanes));
-            HIPCK(c, hipEventRecord(F.evJoin2, s3));
-        }
+        // (the level's three kinds of list-updating items behind each other on this stream.  The 512-entry class on a stream of its
+        // own was measured: 175 ms per round instead of 152 -- a third side stream shares a hardware queue with the cached-regime
+        // kernel's and runs behind it.)
         TRY(fr_launch_updating(c, s, gridUpd, av, T, P, fp, budget, heavyMin));
         TRY(stage("k_fr_updating"));
         if (heavyMin > 0) {
             TRY(fr_launch_updating_wave_small(c, s, gridWaveSmall, av, T, P, fp, budget, heavyMin, scratchLanes + 256));
-            HIPCK(c, hipStreamWaitEvent(s, F.evJoin2, 0));
+            TRY(fr_launch_updating_wave(c, s, gridWave, av, T, P, fp, budget, heavyMin, scratchLanes));
         }
         TRY(stage("k_fr_updating_wave"));
         HIPCK(c, hipEventRecord(a1, s));
