@@ -926,9 +926,9 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, F.tn.reserve_exact(grow((size_t)capL, F.tn.cap)));
     HIPCK(c, F.tna.reserve_exact(grow((size_t)capL, F.tna.cap)));
     HIPCK(c, F.tflag.reserve_exact(grow((size_t)capL, F.tflag.cap)));
-    HIPCK(c, F.sw.reserve_exact((size_t)(scratchLanes + 2048 + 16384) * capE));     // (+ one slab per wavefront of k_fr_updating_wave)
-    HIPCK(c, F.sa.reserve_exact((size_t)(scratchLanes + 2048 + 16384) * capE * 5));
-    HIPCK(c, F.sais.reserve_exact((size_t)(scratchLanes + 2048 + 16384) * capE * 2));
+    HIPCK(c, F.sw.reserve_exact((size_t)(scratchLanes + 2048 + 65536) * capE));     // (+ one slab per wavefront of k_fr_updating_wave)
+    HIPCK(c, F.sa.reserve_exact((size_t)(scratchLanes + 2048 + 65536) * capE * 5));
+    HIPCK(c, F.sais.reserve_exact((size_t)(scratchLanes + 2048 + 65536) * capE * 2));
     HIPCK(c, F.bw.reserve_exact((size_t)capBig));
     HIPCK(c, F.ba.reserve_exact((size_t)capBig * 5));
     HIPCK(c, F.nodes.reserve((size_t)m));
@@ -1024,7 +1024,9 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     FCtr hc;
     std::memset(&hc, 0, sizeof hc);
     int levels = 0;
-    const int gridCached = 2048;
+    // (many short-lived workgroups rather than a grid-stride loop over few long-lived ones: wavefront slots come free all the
+    // time, and the dispatcher hands them to the higher-priority stream first)
+    const int gridCached = 16384;
     // items whose two lists add up to this many entries are walked by a wavefront each (k_fr_updating_wave: 54 KB of LDS per
     // wavefront, two per compute unit)
     // (a handful of searches -- the re-search of a proposed move -- wait for every single item: all of them by wavefronts)
@@ -1032,14 +1034,18 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     const int bigMin = m <= 64 ? (1 << 30) : FR_BIG_MIN;                  // (lists of this many entries together: 16 items to a wavefront)
     std::vector<size_t> slotsC, slotsU;
     if (!F.side) {
-        HIPCK(c, hipStreamCreateWithFlags(&F.side, hipStreamNonBlocking));
+        // (the cached-regime kernel's stream at the LOWEST priority: its kernel fills the GPU -- 128 registers x 4 wavefronts is a
+        // SIMD's whole register file -- and the level's list-updating kernels on the context's stream, a chain of four short
+        // launches that the level waits for, must not queue behind it for wavefront slots)
+        {
+            int prLow = 0, prHigh = 0;
+            if (hipDeviceGetStreamPriorityRange(&prLow, &prHigh) != hipSuccess) prLow = 0;
+            HIPCK(c, hipStreamCreateWithPriority(&F.side, hipStreamNonBlocking, prLow));
+        }
         HIPCK(c, hipEventCreateWithFlags(&F.evFork, hipEventDisableTiming));
         HIPCK(c, hipEventCreateWithFlags(&F.evJoin, hipEventDisableTiming));
-        HIPCK(c, hipStreamCreateWithFlags(&F.side2, hipStreamNonBlocking));
-        HIPCK(c, hipEventCreateWithFlags(&F.evFork2, hipEventDisableTiming));
-        HIPCK(c, hipEventCreateWithFlags(&F.evJoin2, hipEventDisableTiming));
     }
-    const hipStream_t s2 = F.side, s3 = F.side2;
+    const hipStream_t s2 = F.side;
     auto level = [&]() -> int {                                            // the kernels of one level, each between its own events
         hipEvent_t a0, a1, b0, b1;
         HIPCK(c, hipEventRecord(F.evFork, s));                             // (after the level's snap)
@@ -1050,7 +1056,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         if (fp.mat) {
             // the removed lists of the cached-regime items that crossed a reference branch: on the cached kernel's stream, ahead of
             // it (only that kernel reads them), next to the level's updating items
-            FR_DISPATCH3(c, k_fr_pass, <<<64, FR_BLOCK, 0, s2>>>(c->d_model, av, T, fp, scratchLanes + 2048));
+            FR_DISPATCH3(c, k_fr_pass, <<<256, FR_BLOCK, 0, s2>>>(c->d_model, av, T, fp, scratchLanes + 2048));
             TRY(stage("k_fr_pass"));
         }
         FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s2>>>(c->d_model, av, anyWide ? Tw : T, P, fp, budget,
@@ -1080,7 +1086,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         return MAPLE_OK;
     };
     // (an error inside the loop leaves nothing in flight on either stream behind it)
-    auto bail = [&](int rc) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(s2); (void)hipStreamSynchronize(s3); return rc; };
+    auto bail = [&](int rc) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(s2); return rc; };
     // the host looks at the counters every few levels: a handful of searches (the re-search of a proposed move) is over after a few
     // levels and each look costs them less than the levels it saves; a whole round runs ~40
     const int groupLevels = m <= 64 ? 2 : 8;
