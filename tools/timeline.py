@@ -35,3 +35,14 @@ cur_e = None
 for s, e, n in rnd:
     if cur_e is not None and s - cur_e > 1e6: print(f"  gap {(s-cur_e)/1e6:.2f} ms before {n} at {(s-t0)/1e6:.2f}")
     cur_e = e if cur_e is None else max(cur_e, e)
+# optional: the kernels of ONE level of the expansion (between the level's k_fr_snap and the next), with their start / end in ms
+if len(sys.argv) > 2:
+    snaps = [i for i, e in enumerate(rnd) if e[2] == "k_fr_snap"]
+    for lvl in (int(x) for x in sys.argv[2:]):
+        if lvl + 1 >= len(snaps):
+            continue
+        a, b = snaps[lvl], snaps[lvl + 1]
+        tl = rnd[a][0]
+        print(f"level {lvl}:")
+        for s, e, n in rnd[a:b + 1]:
+            print(f"    {n:28s} start {(s - tl)/1e6:8.3f}  end {(e - tl)/1e6:8.3f}  ({(e - s)/1e6:.3f} ms)")
