@@ -230,8 +230,11 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_sort_level(ArenaViewS av, DevTr
 }
 
 // ---- items in the cached regime (needsUpdating == False): appendProbNode(probVectTotUp[t1], removed list) ---------------
+#ifndef FR_CACHED_WAVES
+#define FR_CACHED_WAVES 4             // wavefronts per SIMD the cached-regime kernel is compiled for (128 registers)
+#endif
 template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(FR_CACHED_WAVES, FR_CACHED_WAVES)))
 void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, FPools fp, int budget,
                  const int32_t *rowOf, FiniteRows fin)
 {
@@ -394,13 +397,6 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_place(FPools fp, int lev
     }
 }
 
-#define FR_REPLAY_STACK 1024
-__device__ __forceinline__ void wave_sync_lds()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 // what the exact walk of one search leaves behind: the short list, the candidate count, the records to refine
 __device__ inline void fr_replay_done(const SearchParams &P, const FPools &fp, SearchOut *out, int q, FSearch &S, int slHead, int nApp, bool handBack)
 {
@@ -422,14 +418,13 @@ __device__ inline void fr_replay_done(const SearchParams &P, const FPools &fp, S
         if (item_of(fp, r).midProb >= S.curLK - P.thrOptTopo) { FRec &x = fp.recs[base + k++]; x.q = q; x.ref = r; x.ok = 0; }
 }
 
-__global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, FPools fp, SearchOut *out, int minLong)
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, FPools fp, SearchOut *out)
 {
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
         FSearch &S = fp.S[q];
         if (S.state == FS_OVER) { out[q].status = -5; continue; }
         if (S.state == FS_FALLBACK) { out[q].status = FR_STATUS_FALLBACK; continue; }
         if (S.state != FS_ACTIVE) continue;
-        if (minLong > 0 && fp.visit && fp.vbase[q + 1] <= fp.capVisit && fp.tot[q] >= minLong) continue;   // (k_fr_replay_long)
         double best = S.curLK;
         int nApp = 0, slHead = FR_NONE, slTail = FR_NONE;
         bool marked = false;
@@ -503,74 +498,6 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
         }
         }
         fr_replay_done(P, fp, out, q, S, slHead, nApp, marked);
-    }
-}
-
-// The same walk for the LONG ordinary searches of a batch (8 000-16 000 items: the ones k_fr_replay's launch used to last as long
-// as), one wavefront per search: the 64 records that follow are loaded together into LDS (one coalesced read instead of one
-// miss per pop), lane 0 applies the rules from there, and what an item hands to its children -- failedPasses -- waits on a small
-// stack of the ancestors whose clades are not finished (the record's own `parent` link is never followed).
-__global__ __launch_bounds__(64) void k_fr_replay_long(SearchParams P, int n, FPools fp, SearchOut *out, int minItems, int *counter)
-{
-    __shared__ FVisit sh[64];
-    __shared__ long long stEnd[FR_REPLAY_STACK];
-    __shared__ int stFails[FR_REPLAY_STACK];
-    const int lane = threadIdx.x;
-    for (;;) {
-        int q = 0;
-        if (lane == 0) q = atomicAdd(counter, 1);
-        q = __builtin_amdgcn_readfirstlane(q);
-        if (q >= n) break;
-        FSearch &S = fp.S[q];
-        if (S.state != FS_ACTIVE || !fp.visit || fp.vbase[q + 1] > fp.capVisit || fp.tot[q] < minItems) continue;
-        const long long end = fp.vbase[q + 1];
-        long long i = fp.vbase[q];
-        double best = S.curLK;
-        int nApp = 0, slHead = FR_NONE, slTail = FR_NONE, sp = 0;
-        bool marked = false, bad = false;
-        for (;;) {
-            const int iLo = __builtin_amdgcn_readfirstlane((int)(uint32_t)i), iHi = __builtin_amdgcn_readfirstlane((int)(i >> 32));
-            const long long base = ((long long)iHi << 32) | (uint32_t)iLo;
-            const int stop = __builtin_amdgcn_readfirstlane((marked || bad) ? 1 : 0);
-            if (base >= end || stop) break;
-            sh[lane] = fp.visit[min(base + lane, end - 1)];
-            wave_sync_lds();
-            if (lane == 0) {
-                i = base;
-                while (i < end && i < base + 64) {
-                    const FVisit &rec = sh[i - base];
-                    const int size = rec.size;
-                    if (rec.flags & FI_DEAD) { i += size; continue; }
-                    while (sp > 0 && stEnd[sp - 1] <= i) sp--;             // (clades that are finished)
-                    int fails = sp > 0 ? stFails[sp - 1] : 0;
-                    const double mp = rec.midProb;
-                    if (rec.flags & FI_SCORED) {
-                        nApp++;
-                        const bool list = (rec.dir == 0) ? (mp > best - P.thrOptTopo) : (mp >= best - P.thrOptTopo);   // M:7071 / 7293
-                        if (list) {
-                            const int ref = rec.ref;
-                            item_of(fp, ref).next = FR_NONE;
-                            if (slTail == FR_NONE) slHead = ref; else item_of(fp, slTail).next = ref;
-                            slTail = ref;
-                        }
-                        if (mp > best) {
-                            best = mp; fails = 0;
-                            if (rec.dir == 0 && frpr_marked(fp, S, item_of(fp, rec.ref).hRpr)) { marked = true; break; }   // (M:7087, see k_fr_replay)
-                        }
-                        else if (mp < (rec.lastLK - P.thrConsec)) fails++;
-                    }
-                    const bool within = mp > (best - P.thrLKtopology);
-                    const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);
-                    if (go && size > 1) {
-                        if (sp >= FR_REPLAY_STACK) { bad = true; break; }
-                        stEnd[sp] = i + size; stFails[sp] = fails; sp++;
-                    }
-                    i += go ? 1 : size;
-                }
-            }
-            wave_sync_lds();
-        }
-        if (lane == 0) fr_replay_done(P, fp, out, q, S, slHead, nApp, marked || bad);
     }
 }
 
@@ -1218,15 +1145,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, hipGetLastError());
         TRY(stage("k_fr_layout"));
     } else fp.visit = nullptr;
-    // (the searches with many items: a wavefront each, first -- the others' launch is as long as ITS longest search)
-    const int minLong = fp.visit ? 512 : 0;
-    if (minLong) {
-        HIPCK(c, F.wideCtr.reserve(4));
-        HIPCK(c, hipMemsetAsync(F.wideCtr.p + 2, 0, sizeof(int32_t), s));
-        k_fr_replay_long<<<std::min(m, 4096), 64, 0, s>>>(P, m, fp, dout, minLong, F.wideCtr.p + 2);
-        TRY(stage("k_fr_replay_long"));
-    }
-    k_fr_replay<<<gridN, FR_BLOCK, 0, s>>>(P, m, fp, dout, minLong);
+    k_fr_replay<<<gridN, FR_BLOCK, 0, s>>>(P, m, fp, dout);
     TRY(stage("k_fr_replay"));
     if (anyWide) HIPCK(c, hipStreamWaitEvent(s, F.evJoin, 0));
     if (anyWide && fp.mat && wide->nFrames > 0) {

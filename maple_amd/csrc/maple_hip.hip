@@ -2440,6 +2440,7 @@ extern "C" int maple_argmax_allreduce_dev(maple_ctx *c, int32_t n, double *score
 static int tree_rebuild_from_host(maple_ctx *c);
 #include "placement_host.h"
 #include "update_host.h"
+#include "rebuild_host.h"
 
 // MAT reference frames of the uploaded tree: frame 0 is the root's reference, every node whose branch carries mutations
 // opens a new one for its clade.  Frames are numbered by nesting depth (a parent frame always has a smaller index).

@@ -248,12 +248,22 @@ def tree_log_likelihood(dev: Device, tree: HostTree):
         dev.release(mark)
 
 
-def rebuild_genome_lists(dev: Device, tree: HostTree):
+def rebuild_genome_lists(dev: Device, tree: HostTree, native=True):
     """reCalculateAllGenomeLists (M:6013-6347) on the device for a tree WITH MAT local references: given only the
     tips' lower lists (already uploaded by HostTree.upload) recompute probVect of every internal node (pass 1) and
     probVectUpRight / probVectUpLeft / probVectTotUp of every node (pass 2), level by level, as batches of
-    passGenomeListThroughBranch / mergeVectors / rootVector / shorten launches.  Returns the four id arrays."""
+    passGenomeListThroughBranch / mergeVectors / rootVector / shorten launches.  Returns the four id arrays.
+    ``native``: the level loop inside the library (maple_tree_rebuild_lists: one fused launch per level); the Python loop
+    below is kept for the tests, which compare the two list for list."""
     n = tree.n
+    if native:
+        up_ = np.asarray([-1 if u is None else u for u in tree.up], dtype=np.int32)
+        c0_ = np.asarray([c[0] if c else -1 for c in tree.children], dtype=np.int32)
+        c1_ = np.asarray([c[1] if c else -1 for c in tree.children], dtype=np.int32)
+        tip_ = np.asarray([(not c) and (m == 0) for c, m in zip(tree.children, tree.n_minor)], dtype=np.uint8)
+        dist_ = np.ascontiguousarray(np.asarray(tree.dist, dtype=np.float64))
+        lo, ur, ul, tu, _ = dev.tree_rebuild_lists(tree.root, up_, c0_, c1_, tip_, tree.id_mut, dist_, tree.id_lower)
+        return lo, ur, ul, tu
     up = np.asarray([-1 if u is None else u for u in tree.up])
     c0 = np.asarray([c[0] if c else -1 for c in tree.children])
     c1 = np.asarray([c[1] if c else -1 for c in tree.children])

@@ -60,14 +60,15 @@ class TreeMirror:
             self.lower[np.asarray(tips, dtype=np.int64)] = ids
         self.launches = 0
 
-    def build(self, max_restarts=64):
+    def build(self, max_restarts=64, native=True):
         """Build all lists; zero-length branches that turn out to be inconsistent with the data (mergeVectors returns
         None, M:4757-4762; the reference then re-estimates the branch with updateBLen, M:5377-5414) are given the
-        length of one tenth of a mutation and the build is restarted."""
+        length of one tenth of a mutation and the build is restarted.  ``native``: the level loop inside the library
+        (maple_tree_rebuild_lists) instead of the Python one below (kept: the tests compare the two)."""
         mark = self.dev.mark()
         tip_ids = self.lower.copy()
         for _ in range(max_restarts):
-            bad = self._build_once()
+            bad = self._build_native() if native else self._build_once()
             if bad is None:
                 return self
             self.dist[bad] = np.maximum(self.dist[bad], 0.1 / self.dev.lRef)
@@ -77,6 +78,16 @@ class TreeMirror:
             self.up_left[:] = -1
             self.tot_up[:] = -1
         raise RuntimeError("inconsistent zero-length branches remain after restarts")
+
+    def _build_native(self):
+        dev = self.dev
+        self.dist = np.ascontiguousarray(self.dist, dtype=np.float64)
+        lo, ur, ul, tu, bad = dev.tree_rebuild_lists(self.root, self.parent, self.children[:, 0], self.children[:, 1], self.is_tip, None,
+                                                     self.dist, self.lower, bump_len=0.1 / dev.lRef)
+        if len(bad):
+            return bad
+        self.lower, self.up_right, self.up_left, self.tot_up = lo, ur, ul, tu
+        return None
 
     def _build_once(self):
         dev, ch, dist = self.dev, self.children, self.dist

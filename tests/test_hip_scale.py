@@ -225,6 +225,41 @@ def test_update_partials_on_a_tree_with_local_references(world):
     dev.release(mark)
 
 
+def test_rebuild_inside_the_library_equals_the_python_level_loop(world):
+    """maple_tree_rebuild_lists (reCalculateAllGenomeLists, M:6013-6347: the level loop inside the library, one fused
+    mergeVectors -> shorten launch per level) against the Python level loop of separate merge / shorten launches: every list of
+    the tree entry for entry -- on the tree with MAT local references (lists passed through reference branches) and as
+    TreeMirror.build()."""
+    from maple_amd.mat import add_local_references
+    from maple_amd.tree_host import HostTree, rebuild_genome_lists
+    from maple_amd.tree_mirror import TreeMirror
+    _, data, dev, orc, mirror = world
+    mark = dev.mark()
+    tree = HostTree.from_mirror(mirror)
+    assert add_local_references(dev, tree, 30) > 10
+    a = rebuild_genome_lists(dev, tree, native=True)
+    b = rebuild_genome_lists(dev, tree, native=False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x >= 0, y >= 0)
+        ok = np.nonzero(x >= 0)[0][::3]
+        for lx, ly in zip(dev.download(x[ok]), dev.download(y[ok])):
+            assert lx == ly
+    dev.release(mark)
+    mark = dev.mark()
+    tips = np.nonzero(mirror.is_tip)[0]
+    m1 = TreeMirror(dev, mirror.parent, mirror.dist.copy(), {int(v): l for v, l in zip(tips, dev.download(mirror.lower[tips]))})
+    m2 = TreeMirror(dev, mirror.parent, mirror.dist.copy(), {int(v): l for v, l in zip(tips, dev.download(mirror.lower[tips]))})
+    m1.build(native=True)
+    m2.build(native=False)
+    assert np.array_equal(m1.dist, m2.dist)
+    for x, y in ((m1.lower, m2.lower), (m1.up_right, m2.up_right), (m1.up_left, m2.up_left), (m1.tot_up, m2.tot_up)):
+        assert np.array_equal(x >= 0, y >= 0)
+        ok = np.nonzero(x >= 0)[0][::3]
+        for lx, ly in zip(dev.download(x[ok]), dev.download(y[ok])):
+            assert lx == ly
+    dev.release(mark)
+
+
 def test_wavefront_wide_evaluate_placement_is_the_one_lane_chain_bit_for_bit(world, monkeypatch):
     """k_evalplace_wave (one wavefront per item: the three branch-length solves, three merges and the append of
     evaluatePlacement, M:6790-6806, each cut along its merge path) against k_evalplace (one lane per item), in every model
