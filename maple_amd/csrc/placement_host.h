@@ -40,10 +40,9 @@ __global__ MAPLE_APPEND_ATTR void k_place_score(const DevModel *__restrict__ mp,
 }
 
 // one launch of k_place_score on the context's stream (timed): out[q * ldOut + (outCol ? outCol[k] : k)]
-static int launch_place_score(maple_ctx *c, int nQ, int nF, const int32_t *qFrameLists, int nC, const int32_t *cand,
-                              const int32_t *candFrame, int isTip, double bLen, double *out, long long ldOut,
-                              const int32_t *outCol, const uint8_t *qTip, const double *qBLen, int kind = MAPLE_K_PLACE_SCORE,
-                              double algBytes = 0.0)
+int launch_place_score(maple_ctx *c, int nQ, int nF, const int32_t *qFrameLists, int nC, const int32_t *cand,
+                       const int32_t *candFrame, int isTip, double bLen, double *out, long long ldOut,
+                       const int32_t *outCol, const uint8_t *qTip, const double *qBLen, int kind, double algBytes)
 {
     const long long tiles = (long long)nQ * ((nC + 63) / 64);
     if (tiles > 0x7fffffffLL - (1 << 20)) return fail(c, MAPLE_ERR_ARG, "nQ x nC too large for one launch");
