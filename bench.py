@@ -775,13 +775,18 @@ def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_pl
                       "nodes_patched_per_move_median": float(np.median(ap.patched)) if ap.patched else 0.0}
             if mode == "batched":
                 out_ap["batches_searched_kept"] = [list(x) for x in ap.batches]
+            else:
+                out_ap["whole_tree_re_searches"] = int(ap.whole_tree_searches)
+                out_ap["search_call_ms_mean"] = 1e3 * float(np.mean(ap.times["search"])) if ap.times["search"] else float("nan")
+                out_ap["search_call_ms_max"] = 1e3 * float(np.max(ap.times["search"])) if ap.times["search"] else float("nan")
             out["serial_path"].setdefault("apply_phase", {})[mode] = out_ap
             upload_plain_tree()
             dev.release(mark)
         out["serial_path"]["apply_phase"]["same_applied_sequence"] = rep["sequential"].applied == rep["batched"].applied
         out["serial_path"]["apply_phase"]["note"] = (
             "applySPRMovesParallel (M:9470-9484) over the proposed moves of the first timed step, best first, with a stand-in "
-            "tree edit (maple_amd/spr_apply.py); sequential = one re-search per move (frontier tier on the patched node records); "
+            "tree edit (maple_amd/spr_apply.py); sequential = one re-search per move (frontier tier on the patched node records; a "
+            "re-search from a zero-length branch -- a whole-tree search -- after the tree's tables were brought up to date); "
             "batched = 32 moves re-searched per call, a speculative result kept while nothing its search may have read was "
             "touched by the moves applied before it")
     if (args.local_refs or args.samples <= 200000) and not headline_refs:

@@ -59,6 +59,7 @@ class SprApplier:
         self.patched = []
         self.batches = []              # (searched, kept) per batch of apply_batched
         self.degraded = 0              # batches of which only the first result could be used (a search left the frontier tier)
+        self.whole_tree_searches = 0   # re-searches from a zero-length branch (apply_sequential: on freshly rebuilt tables)
 
     @classmethod
     def from_mirror(cls, dev, m):
@@ -134,7 +135,13 @@ class SprApplier:
     def apply_sequential(self, moves, kw):
         for node in moves:
             t0 = time.perf_counter()
-            r = self.dev.spr_search_batch(np.asarray([node], dtype=np.int32), wide_search_budget=-1, **kw)
+            # A pruned node on a zero-length branch is searched against the whole tree when there is no error model (M:9644, 6663):
+            # on the patched node records alone that is 10^5 items through the frontier tier and a walk of all of them by one
+            # lane (hundreds of ms).  With the library's own budget the call brings the tree's tables up to date first (one
+            # re-upload) and the search takes the witness filter + clade scan path of a round instead.
+            whole_tree = (not self.dev.u) and self.dist[node] == 0.0
+            r = self.dev.spr_search_batch(np.asarray([node], dtype=np.int32), wide_search_budget=0 if whole_tree else -1, **kw)
+            self.whole_tree_searches += int(whole_tree)
             self.times["search"].append(time.perf_counter() - t0)
             self._take(node, r, 0)
         return self

@@ -1,4 +1,5 @@
-"""Per level of the frontier tier's expansion on the bench tree: items and kernel times.  level_profile.py [samples] [model] [v1|v2]"""
+"""Per level of the frontier tier's expansion on the bench tree: items and kernel times.
+level_profile.py [samples] [model] [v1|v2] [searches per round: evenly spread over the pre-order; default all]"""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,6 +29,8 @@ m.build()
 bench.optimise_branch_lengths(dev, m, tip_ids, mark, 1.0 / (10 * dev.lRef))
 kw = bench.search_kwargs(dev.lRef)
 order = bench.preorder_nodes(m)
+if len(sys.argv) > 4:
+    order = order[:: max(1, len(order) // int(sys.argv[4]))][: int(sys.argv[4])]
 dev.upload_tree(m.root, m.parent, m.children[:, 0], m.children[:, 1], m.dist, m.is_tip, m.lower, m.up_right, m.up_left, m.tot_up, -np.ones(m.n_nodes, dtype=np.int32))
 for i in range(3):
     dev.timing_reset()
@@ -38,5 +41,7 @@ iu, ic, mu, mc = dev.frontier_levels()
 ws, wb = dev.last_wave_items
 print("level  updating_items  (by wavefronts: small class, 512 class)  cached_items  ms_updating  ms_cached")
 for l in range(len(iu)):
+    if l > 60 and l % 10 and l < len(iu) - 3:
+        continue
     print(f"{l:5d} {iu[l]:12d} {ws[l]:10d} {wb[l]:8d} {ic[l]:12d} {mu[l]:10.3f} {mc[l]:10.3f}")
 print("total", iu.sum(), ic.sum(), round(float(mu.sum()), 1), round(float(mc.sum()), 1))
