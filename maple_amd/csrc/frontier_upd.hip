@@ -15,8 +15,12 @@ namespace {
 
 #include "frontier_upd_lane.inc"
 
+#ifndef FR_UPD_WAVES
+#define FR_UPD_WAVES 4                // wavefronts per SIMD k_fr_updating is compiled for (128 registers, the rest of its state in scratch)
+#endif
+
 template <bool RV, bool U, bool SS, bool MAT>
-__global__ __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ __launch_bounds__(FR_BLOCK) __attribute__((amdgpu_waves_per_eu(FR_UPD_WAVES, FR_UPD_WAVES)))
 void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, FPools fp, int budget, int heavyMin)
 {
     __shared__ Lds lds;
