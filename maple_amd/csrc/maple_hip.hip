@@ -1141,31 +1141,46 @@ extern "C" int maple_lists_download(maple_ctx *c, int32_t n, const int32_t *ids,
     int rc = check_ids(c, n, ids, false, "ids");
     if (rc) return rc;
     // lists that sit back to back in the arena AND in the caller's buffers (the usual case: a tree's lists, downloaded in id
-    // order) move with one copy per run instead of one per list
+    // order) move with one copy per run instead of one per list; the copies of up to 32 M entries are queued together and
+    // awaited once (a tree whose four kinds of list are interleaved in the arena is millions of one-list runs)
     std::vector<uint2> w;
+    struct Run { int first; int64_t ne, wOff; };
+    std::vector<Run> runs;
     int i = 0;
     while (i < n) {
-        int j = i;
-        int64_t ne = 0, na = 0;
-        while (j < n) {
-            const int id = ids[j];
-            if (j > i) {
-                const int pid = ids[j - 1];
-                if (c->h_ent_off[id] != c->h_ent_off[pid] + c->h_n_ent[pid] || c->h_aux_off[id] != c->h_aux_off[pid] + c->h_n_aux[pid]
-                    || ent_off[j] != ent_off[j - 1] + c->h_n_ent[pid] || aux_off[j] != aux_off[j - 1] + c->h_n_aux[pid])
-                    break;
+        runs.clear();
+        int64_t tot = 0;
+        const int chunkStart = i;
+        while (i < n && tot < ((int64_t)32 << 20) && runs.size() < (size_t)1 << 16) {
+            int j = i;
+            int64_t ne = 0, na = 0;
+            while (j < n) {
+                const int id = ids[j];
+                if (j > i) {
+                    const int pid = ids[j - 1];
+                    if (c->h_ent_off[id] != c->h_ent_off[pid] + c->h_n_ent[pid] || c->h_aux_off[id] != c->h_aux_off[pid] + c->h_n_aux[pid]
+                        || ent_off[j] != ent_off[j - 1] + c->h_n_ent[pid] || aux_off[j] != aux_off[j - 1] + c->h_n_aux[pid])
+                        break;
+                }
+                ne += c->h_n_ent[id]; na += c->h_n_aux[id];
+                j++;
+                if (ne > (int64_t)32 << 20) break;
             }
-            ne += c->h_n_ent[id]; na += c->h_n_aux[id];
-            j++;
-            if (ne > (int64_t)32 << 20) break;
+            runs.push_back(Run{i, ne, tot});
+            tot += ne;
+            const int id0 = ids[i];
+            if (na) HIPCK(c, hipMemcpyAsync(aux + aux_off[i], c->d_aux + c->h_aux_off[id0], na * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            i = j;
         }
-        const int id0 = ids[i];
-        w.resize((size_t)ne);
-        HIPCK(c, hipMemcpyAsync(w.data(), c->d_words + c->h_ent_off[id0], ne * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
-        if (na) HIPCK(c, hipMemcpyAsync(aux + aux_off[i], c->d_aux + c->h_aux_off[id0], na * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        (void)chunkStart;
+        w.resize((size_t)tot);
+        for (const Run &r : runs)
+            if (r.ne) HIPCK(c, hipMemcpyAsync(w.data() + r.wOff, c->d_words + c->h_ent_off[ids[r.first]], r.ne * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
-        for (int64_t k = 0; k < ne; k++) { pos[ent_off[i] + k] = (int32_t)w[k].x; meta[ent_off[i] + k] = w[k].y; }
-        i = j;
+        for (const Run &r : runs) {
+            const int64_t o = ent_off[r.first];
+            for (int64_t k = 0; k < r.ne; k++) { pos[o + k] = (int32_t)w[r.wOff + k].x; meta[o + k] = w[r.wOff + k].y; }
+        }
     }
     return MAPLE_OK;
 }

@@ -107,19 +107,23 @@ extern "C" int maple_tree_rebuild_lists(maple_ctx *c, int32_t n, int32_t root, c
         for (size_t k = 0; k < lv.size(); k++) { const int p = up[lv[k]]; vu[k] = c0[p] == lv[k] ? upRight[p] : upLeft[p]; }
         TRY(upd_passed(c, mut, vu, lv, false));
         iL1.clear(); iL2.clear(); iNode.clear(); iKid.clear(); iB1.clear(); iB2.clear(); iT2.clear(); iKind.clear();
+        // (kind by kind: the new lists take their room in item order, so the level's probVectTotUp lists -- the candidate lists of
+        // every search -- end up next to each other in the arena, and a download of one kind moves in long runs)
         for (size_t k = 0; k < lv.size(); k++) {
             const int v = lv[k];
             if (dist[v] != 0.0) {                                           // probVectTotUp, M:6262-6275
                 iL1.push_back(vu[k]); iB1.push_back(dist[v] / 2); iL2.push_back(lower[v]); iB2.push_back(dist[v] / 2); iT2.push_back(tip[v]);
                 iNode.push_back(v); iKid.push_back(-1); iKind.push_back(0);
             }
-            if (c0[v] < 0) continue;
-            for (int which = 1; which >= 0; which--) {                      // probVectUpRight (child 1), probVectUpLeft (child 0)
+        }
+        for (int which = 1; which >= 0; which--)                            // probVectUpRight (child 1), then probVectUpLeft (child 0)
+            for (size_t k = 0; k < lv.size(); k++) {
+                const int v = lv[k];
+                if (c0[v] < 0) continue;
                 const int kd = which == 1 ? c1[v] : c0[v];
                 iL1.push_back(vu[k]); iB1.push_back(dist[v]); iL2.push_back(lower[kd]); iB2.push_back(dist[kd]); iT2.push_back(tip[kd]);
                 iNode.push_back(v); iKid.push_back(kd); iKind.push_back(which == 1 ? 1 : 2);
             }
-        }
         const size_t m = iL1.size();
         if (!m) continue;
         {   // the children's lower lists go through their own branches first where those carry mutations

@@ -130,17 +130,23 @@ def test_config4_1M_full_model_searches_against_the_oracle(million):
     assert len(order) == 1999999
     nodes = order[np.arange(3, len(order), len(order) // 16384)[:16384]]
     g = dev.spr_search_batch(nodes, **kw)
+    t1 = time.time()
     assert not (g["status"] < -1).any()
     searched = g["status"] == 0
     assert searched.sum() > 12000 and g["nAppend"][searched].sum() > 1e8
     same_results(dev.spr_search_batch(nodes, **kw), g)
+    t2 = time.time()
     sub = np.arange(0, len(nodes), 16)
     same_results(dev.spr_search_batch(nodes[sub], search_tier=1, **kw), g, None, sub)
+    t3 = time.time()
     orc, otree = oracle_tree(dev, ref_idx, root_freqs, mkw, m.root, m.parent, m.children, m.dist, m.lower, m.up_right, m.up_left, m.tot_up)
+    t4 = time.time()
     sel = np.arange(5, len(nodes), 48)
     n_ok, n_pl = check_sample_against_oracle(orc, otree, nodes, g, sel, kw)
     assert n_ok > 250 and n_pl > 1e6
-    print(f"config 4: {len(sel)} of {len(nodes)} searches ({n_pl} candidate placements) equal the oracle's; {time.time() - t0:.0f} s")
+    print(f"config 4: {len(sel)} of {len(nodes)} searches ({n_pl} candidate placements) equal the oracle's; {time.time() - t0:.0f} s "
+          f"(first call {t1 - t0:.1f}, second {t2 - t1:.1f}, lane tier on {len(sub)} nodes {t3 - t2:.1f}, tree to the oracle {t4 - t3:.1f}, "
+          f"oracle searches {time.time() - t4:.1f})")
 
 
 def test_config5_online_update_of_the_1M_tree(million):
