@@ -847,6 +847,7 @@ struct FrontierScratch {
     std::vector<size_t> lastSlotsU, lastSlotsC;    // ... and the timing slots of its level kernels
     long long lastU = -1, lastC = -1;     // items of the last call (for frontier_export), -1: none
     long long needU = 0, needC = 0, needL = 0, needW = 0, needA = 0, needM = 0;   // what the last call asked of the pools, and its searches
+    bool lastOverflow = false;         // ... and whether one of them ran over
     FPools lastPools{};
     // the two kernels of a level read disjoint items (they only meet in the pools' atomic counters): the cached-regime one runs
     // on a stream of its own next to the updating one -- a level of the latter lasts as long as its slowest item, on a few lanes
@@ -900,7 +901,8 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     if (F.needM > 0 && !(wide && wide->forceWide)) {
         // what the last batch asked for, scaled to this one: with an error model the searches are several times as long as the
         // first guess, and a pool that runs over hands its searches back
-        const double f = 1.25 * (double)m / (double)F.needM;
+        // (after an overflow the asks themselves are too low -- the searches that were handed back stopped asking: twice, not 1.25 x)
+        const double f = (F.lastOverflow ? 2.0 : 1.25) * (double)m / (double)F.needM;
         capU = std::max(capU, (long long)(f * F.needU)); capC = std::max(capC, (long long)(f * F.needC));
         capL = std::max(capL, (long long)(f * F.needL)); capW = std::max(capW, (long long)(f * F.needW)); capA = std::max(capA, (long long)(f * F.needA));
     }
@@ -1202,7 +1204,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
 #endif
     if (!(anyWide && wide->forceWide)) {                                  // (a batch of whole-tree searches only says nothing about the next full one)
         F.needU = (long long)hc.usedU; F.needC = (long long)hc.usedC; F.needL = (long long)hc.nLists; F.needW = (long long)hc.usedW;
-        F.needA = (long long)hc.usedA; F.needM = m;
+        F.needA = (long long)hc.usedA; F.needM = m; F.lastOverflow = hc.overflow != 0;
     }
     F.lastU = std::min((long long)hc.usedU, fp.capU); F.lastC = std::min((long long)hc.usedC, fp.capC); F.lastPools = fp;
     {
