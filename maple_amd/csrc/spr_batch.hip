@@ -559,6 +559,20 @@ int tree_rebuild_from_host(maple_ctx *c)
                              lower.data(), upRight.data(), upLeft.data(), totUp.data(), mut.data());
 }
 
+// maple_tree_patch's device writes in two launches instead of one small copy (and one synchronisation) per word: node records
+// by index, then single words by address
+struct PatchPoke { int32_t *p; int32_t v; int32_t pad; };
+__global__ __launch_bounds__(256) void k_patch_nodes(int nR, const int32_t *idx, const NodeRec *recs, NodeRec *dn)
+{
+    constexpr int W = (int)(sizeof(NodeRec) / 4);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nR * W; k += gridDim.x * blockDim.x)
+        ((int32_t *)(dn + idx[k / W]))[k % W] = ((const int32_t *)(recs + k / W))[k % W];
+}
+__global__ __launch_bounds__(256) void k_patch_pokes(int nP, const PatchPoke *pk)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nP; k += gridDim.x * blockDim.x) *pk[k].p = pk[k].v;
+}
+
 // A local change of the uploaded tree -- what placeSampleOnTree (M:8300-8722) and the updatePartials after it leave behind:
 // a few nodes with new relatives, branch lengths or list ids, one or two new nodes.  nodes[i] gets the record
 // (up, child0, child1, dist, isTip, lower, upRight, upLeft, totUp)[i]; ids >= the old node count are new nodes (all of them
@@ -594,11 +608,18 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
         if (!seenNew[k]) return fail(c, MAPLE_ERR_ARG, "new node %d is not in the patch", nOld + (int)k);
     {   // relatives must point back at each other in the tree AS PATCHED -- checked before anything changes, so that a
         // malformed patch leaves the library's copy as it was (the traversals trust these columns)
-        std::vector<int32_t> at((size_t)nTotal, -1);
-        for (int i = 0; i < nTouched; i++) at[nodes[i]] = i;
-        auto upOf = [&](int v) { return at[v] >= 0 ? up[at[v]] : c->h_tree_up[v]; };
-        auto c0Of = [&](int v) { return at[v] >= 0 ? child0[at[v]] : c->h_tree_c0[v]; };
-        auto c1Of = [&](int v) { return at[v] >= 0 ? child1[at[v]] : c->h_tree_c1[v]; };
+        // (position of a node in the patch, -1 if it is not in it: a sorted copy of the handful of touched nodes, not a tree-sized
+        // table -- at 1 000 000 tips that table was 8 MB written per patch)
+        std::vector<std::pair<int32_t, int32_t>> where((size_t)nTouched);
+        for (int i = 0; i < nTouched; i++) where[i] = {nodes[i], i};
+        std::sort(where.begin(), where.end());
+        auto at = [&](int v) -> int {
+            auto it = std::lower_bound(where.begin(), where.end(), std::make_pair((int32_t)v, (int32_t)-1));
+            return (it != where.end() && it->first == v) ? it->second : -1;
+        };
+        auto upOf = [&](int v) { const int a = at(v); return a >= 0 ? up[a] : c->h_tree_up[v]; };
+        auto c0Of = [&](int v) { const int a = at(v); return a >= 0 ? child0[a] : c->h_tree_c0[v]; };
+        auto c1Of = [&](int v) { const int a = at(v); return a >= 0 ? child1[a] : c->h_tree_c1[v]; };
         for (int i = 0; i < nTouched; i++) {
             const int v = nodes[i];
             for (int32_t ch : {child0[i], child1[i]})
@@ -629,6 +650,11 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
     // that a small batch of searches -- the re-search of a proposed move before it is applied, M:9470-9484 -- can run on the
     // patched tree at once (frontier tier, no tree-sized table); everything tree-sized (depth-first orders, score columns)
     // waits for the rebuild
+    bool inFlight = false;                                                // (a staged launch is queued: awaited once, before returning)
+    auto settle_patch = [&](int rc) -> int {
+        if (inFlight && hipStreamSynchronize(c->stream) != hipSuccess && rc == MAPLE_OK) return fail(c, MAPLE_ERR_HIP, "maple_tree_patch: hipStreamSynchronize failed");
+        return rc;
+    };
     if (c->nodes_current && !c->tree_has_mut && c->dtree.nd) {
         const size_t capNodes = (c->t_nodes.cap - 64) / sizeof(NodeRec);
         if ((size_t)nTotal > capNodes) c->nodes_current = false;
@@ -643,6 +669,8 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
             std::sort(redo.begin(), redo.end());
             redo.erase(std::unique(redo.begin(), redo.end()), redo.end());
             NodeRec *dn = const_cast<NodeRec *>(c->dtree.nd);
+            std::vector<NodeRec> recs;
+            recs.reserve(redo.size());
             for (int32_t v : redo) {
                 NodeRec &r = c->h_nodes[v];
                 const int32_t keepRank = v < nOld ? r.preRank : 0;
@@ -653,13 +681,21 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
                 r.upIsRoot = (r.up >= 0 && c->h_tree_up[r.up] < 0) ? 1 : 0;
                 r.whichChild = (r.up >= 0 && c->h_tree_c1[r.up] == v) ? 1 : 0;
                 r.preRank = keepRank;                                          // (stale: only the tree-sized tables use it)
-                HIPCK(c, hipMemcpyAsync(dn + v, &r, sizeof(NodeRec), hipMemcpyHostToDevice, c->stream));
+                recs.push_back(r);
             }
-            HIPCK(c, hipStreamSynchronize(c->stream));
+            if (!redo.empty()) {
+                TRY(stage_begin(c, redo.size() * (sizeof(NodeRec) + 8) + 256));
+                STAGE(dIdx, c, redo.data(), redo.size());
+                STAGE(dRec, c, recs.data(), recs.size());
+                TRY(stage_flush(c));
+                k_patch_nodes<<<1, 256, 0, c->stream>>>((int)redo.size(), dIdx, dRec, dn);
+                HIPCK(c, hipGetLastError());
+                inFlight = true;
+            }
         }
     } else c->nodes_current = false;
     PlaceMeta &M = *c->place;
-    if (!M.valid) return MAPLE_OK;                                        // nothing of the placement search to keep up to date
+    if (!M.valid) return settle_patch(MAPLE_OK);                          // nothing of the placement search to keep up to date
     // ---- the placement search's columns
     M.scanStale = true;
     M.frameOf.resize((size_t)nTotal, -1);
@@ -675,11 +711,22 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
         }
     }
     for (int i = 0; i < nTouched; i++)
-        if (M.frameOf[nodes[i]] < 0) return fail(c, MAPLE_ERR_ARG, "new node %d is not attached to the tree", nodes[i]);
+        if (M.frameOf[nodes[i]] < 0) return settle_patch(fail(c, MAPLE_ERR_ARG, "new node %d is not attached to the tree", nodes[i]));
+    std::vector<PatchPoke> pokes;                                         // (single words of the columns: written together at the end)
     auto poke = [&](DevBuf<int32_t> &b, size_t at, int32_t value) -> int {
         if (at >= b.cap) { M.valid = false; return MAPLE_OK; }            // out of room: the next search rebuilds everything
-        HIPCK(c, hipMemcpyAsync(b.p + at, &value, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIPCK(c, hipStreamSynchronize(c->stream));                       // (`value` is a local)
+        pokes.push_back(PatchPoke{b.p + at, value, 0});
+        return MAPLE_OK;
+    };
+    auto flush_pokes = [&]() -> int {
+        if (pokes.empty()) return MAPLE_OK;
+        if (inFlight) HIPCK(c, hipStreamSynchronize(c->stream));         // (the staging arenas alternate: the first one's copy is done)
+        TRY(stage_begin(c, pokes.size() * sizeof(PatchPoke) + 256));
+        STAGE(dPk, c, pokes.data(), pokes.size());
+        TRY(stage_flush(c));
+        k_patch_pokes<<<1, 256, 0, c->stream>>>((int)pokes.size(), dPk);
+        HIPCK(c, hipGetLastError());
+        inFlight = true;
         return MAPLE_OK;
     };
     for (int i = 0; i < nTouched && M.valid; i++) {
@@ -705,7 +752,7 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
         int lc = M.h_leafIdx[v];
         if (lc >= 0 && !leaf) M.h_leafIdx[v] = -1;
         else if (leaf) {
-            if (lower[i] < 0) return fail(c, MAPLE_ERR_STATE, "leaf %d has no lower genome list", v);
+            if (lower[i] < 0) { (void)flush_pokes(); return settle_patch(fail(c, MAPLE_ERR_STATE, "leaf %d has no lower genome list", v)); }
             if (lc >= 0) { if (M.h_leafList[lc] != lower[i]) { M.h_leafList[lc] = lower[i]; TRY(poke(M.d_leafList, lc, lower[i])); } }
             else {
                 lc = (int)M.leaves.size();
@@ -717,7 +764,8 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
             }
         }
     }
-    return MAPLE_OK;
+    { const int rc_ = flush_pokes(); if (rc_) return settle_patch(rc_); }
+    return settle_patch(MAPLE_OK);
 }
 
 #ifndef MAPLE_WIDE_BUDGET_DEFAULT
