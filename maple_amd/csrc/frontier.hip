@@ -432,11 +432,14 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
             // the same walk as a forward scan over the search's items in visiting order
             const long long end = fp.vbase[q + 1];
             long long i = fp.vbase[q];
+            // (failedPasses by rank in an array of its own -- lpos, which the layout is done with: a store into the records would
+            // throw their cache line out of L1 under the scan, and every record would come from L2 again)
+            int32_t *const failsAt = fp.lpos;
             while (i < end) {
-                FVisit &rec = fp.visit[i];
+                const FVisit rec = fp.visit[i];
                 const int size = rec.size;
                 if (rec.flags & FI_DEAD) { i += size; continue; }
-                int fails = rec.parent < 0 ? 0 : fp.visit[rec.parent].failsOut;
+                int fails = rec.parent < 0 ? 0 : failsAt[rec.parent];
                 const double mp = rec.midProb;
                 if (rec.flags & FI_SCORED) {
                     nApp++;
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
                 }
                 const bool within = mp > (best - P.thrLKtopology);
                 const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);
-                rec.failsOut = (int16_t)fails;
+                if (go && size > 1) failsAt[i] = fails;                    // (read by the item's children only)
                 i += go ? 1 : size;
             }
         } else {
