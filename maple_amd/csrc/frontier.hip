@@ -435,33 +435,40 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
             // (failedPasses by rank in an array of its own -- lpos, which the layout is done with: a store into the records would
             // throw their cache line out of L1 under the scan, and every record would come from L2 again)
             int32_t *const failsAt = fp.lpos;
+            // (the record that follows is asked for while this one is worked on: most steps go to it)
+            FVisit nxt = fp.visit[i < end ? i : 0];
             while (i < end) {
-                const FVisit rec = fp.visit[i];
+                const FVisit rec = nxt;
+                const FVisit ahead = fp.visit[i + 1 < end ? i + 1 : i];
                 const int size = rec.size;
-                if (rec.flags & FI_DEAD) { i += size; continue; }
-                int fails = rec.parent < 0 ? 0 : failsAt[rec.parent];
-                const double mp = rec.midProb;
-                if (rec.flags & FI_SCORED) {
-                    nApp++;
-                    const bool list = (rec.dir == 0) ? (mp > best - P.thrOptTopo) : (mp >= best - P.thrOptTopo);   // M:7071 / 7293
-                    if (list) {
-                        const int ref = rec.ref;
-                        item_of(fp, ref).next = FR_NONE;
-                        if (slTail == FR_NONE) slHead = ref; else item_of(fp, slTail).next = ref;
-                        slTail = ref;
+                long long step = size;
+                if (!(rec.flags & FI_DEAD)) {
+                    int fails = rec.parent < 0 ? 0 : failsAt[rec.parent];
+                    const double mp = rec.midProb;
+                    if (rec.flags & FI_SCORED) {
+                        nApp++;
+                        const bool list = (rec.dir == 0) ? (mp > best - P.thrOptTopo) : (mp >= best - P.thrOptTopo);   // M:7071 / 7293
+                        if (list) {
+                            const int ref = rec.ref;
+                            item_of(fp, ref).next = FR_NONE;
+                            if (slTail == FR_NONE) slHead = ref; else item_of(fp, slTail).next = ref;
+                            slTail = ref;
+                        }
+                        if (mp > best) {
+                            best = mp; fails = 0;
+                            // (M:7087: the reference shortens the branch's removed list in place here; if that changes the list, the
+                            // one-lane kernel takes the search)
+                            if (rec.dir == 0 && frpr_marked(fp, S, item_of(fp, rec.ref).hRpr)) { marked = true; break; }
+                        }
+                        else if (mp < (rec.lastLK - P.thrConsec)) fails++;
                     }
-                    if (mp > best) {
-                        best = mp; fails = 0;
-                        // (M:7087: the reference shortens the branch's removed list in place here; if that changes the list, the
-                        // one-lane kernel takes the search)
-                        if (rec.dir == 0 && frpr_marked(fp, S, item_of(fp, rec.ref).hRpr)) { marked = true; break; }
-                    }
-                    else if (mp < (rec.lastLK - P.thrConsec)) fails++;
+                    const bool within = mp > (best - P.thrLKtopology);
+                    const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);
+                    if (go && size > 1) failsAt[i] = fails;                    // (read by the item's children only)
+                    if (go) step = 1;
                 }
-                const bool within = mp > (best - P.thrLKtopology);
-                const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);
-                if (go && size > 1) failsAt[i] = fails;                    // (read by the item's children only)
-                i += go ? 1 : size;
+                i += step;
+                nxt = step == 1 ? ahead : fp.visit[i < end ? i : end - 1];
             }
         } else {
         int top = FR_NONE;
