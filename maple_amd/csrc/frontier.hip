@@ -436,10 +436,11 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
             // throw their cache line out of L1 under the scan, and every record would come from L2 again)
             int32_t *const failsAt = fp.lpos;
             // (the record that follows is asked for while this one is worked on: most steps go to it)
-            FVisit nxt = fp.visit[i < end ? i : 0];
+            FVisit nxt = fp.visit[i < end ? i : 0], nxt2 = fp.visit[i + 1 < end ? i + 1 : 0];
             while (i < end) {
                 const FVisit rec = nxt;
-                const FVisit ahead = fp.visit[i + 1 < end ? i + 1 : i];
+                const FVisit ahead = nxt2;
+                const FVisit ahead2 = fp.visit[i + 2 < end ? i + 2 : i];
                 const int size = rec.size;
                 long long step = size;
                 if (!(rec.flags & FI_DEAD)) {
@@ -468,7 +469,8 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
                     if (go) step = 1;
                 }
                 i += step;
-                nxt = step == 1 ? ahead : fp.visit[i < end ? i : end - 1];
+                if (step == 1) { nxt = ahead; nxt2 = ahead2; }
+                else { nxt = fp.visit[i < end ? i : end - 1]; nxt2 = fp.visit[i + 1 < end ? i + 1 : end - 1]; }
             }
         } else {
         int top = FR_NONE;
