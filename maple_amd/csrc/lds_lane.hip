@@ -1,8 +1,8 @@
-// maple_amd/csrc/lds_lane.hip -- measurement kernels: ONE lane per mergeVectors, the two input lists staged in LDS first.
-// A lane's walk over lists in global memory is a chain of dependent loads (the next word is asked for only when the step
-// before it decided which cursor moves: 0.5 us per step alone, 1.5-2 us in a wavefront of 64 different pairs); staged in LDS
-// by the whole wavefront with coalesced, independent loads, the chain runs at LDS latency.  maple_debug_merge_lds times the
-// two forms on the same pairs (tools/merge_latency_lds.py).
+// maple_amd/csrc/lds_lane.hip -- measurement kernels: ONE lane per mergeVectors, with the input lists in global memory or
+// staged in LDS by the whole wavefront (coalesced, independent loads) and the merged list written to global memory or to LDS.
+// The question they answer: is a step of the walk bound by where the lists live?  It is not -- 1.1-1.4 us per step
+// of 64 different pairs in every form: the divergent fp64 step body is the bound.  maple_debug_merge_lds times the forms on the
+// same pairs (tools/merge_latency_lds.py, profiles/r04_merge_step_lds.txt).
 #include "ctx_host.h"
 
 namespace {
@@ -98,11 +98,17 @@ extern "C" int maple_debug_merge_lds(maple_ctx *c, int32_t n, const int32_t *l1,
     HIPCK(c, hipSetDevice(c->device));
     int capOut = 0;
     for (int i = 0; i < n; i++) capOut = std::max(capOut, c->h_n_ent[l1[i]] + c->h_n_ent[l2[i]]);
-    int32_t *dl1, *dl2, *dn; double *db1, *db2, *oa; uint8_t *dt1, *dt2, *dud; uint2 *ow;
-    HIPCK(c, hipMalloc(&dl1, n * 4)); HIPCK(c, hipMalloc(&dl2, n * 4)); HIPCK(c, hipMalloc(&dn, n * 4));
-    HIPCK(c, hipMalloc(&db1, n * 8)); HIPCK(c, hipMalloc(&db2, n * 8));
-    HIPCK(c, hipMalloc(&dt1, n)); HIPCK(c, hipMalloc(&dt2, n)); HIPCK(c, hipMalloc(&dud, n));
-    HIPCK(c, hipMalloc(&ow, (size_t)n * capOut * 8)); HIPCK(c, hipMalloc(&oa, (size_t)n * capOut * 40));
+    // (grow-only scratch that frees itself on every way out)
+    struct Scratch {
+        DevBuf<int32_t> l1, l2, n; DevBuf<double> b1, b2, oa; DevBuf<uint8_t> t1, t2, ud; DevBuf<uint2> ow;
+        ~Scratch() { l1.release(); l2.release(); n.release(); b1.release(); b2.release(); oa.release(); t1.release(); t2.release(); ud.release(); ow.release(); }
+    } S;
+    HIPCK(c, S.l1.reserve_exact(n)); HIPCK(c, S.l2.reserve_exact(n)); HIPCK(c, S.n.reserve_exact(n));
+    HIPCK(c, S.b1.reserve_exact(n)); HIPCK(c, S.b2.reserve_exact(n));
+    HIPCK(c, S.t1.reserve_exact(n)); HIPCK(c, S.t2.reserve_exact(n)); HIPCK(c, S.ud.reserve_exact(n));
+    HIPCK(c, S.ow.reserve_exact((size_t)n * capOut)); HIPCK(c, S.oa.reserve_exact((size_t)n * capOut * 5));
+    int32_t *dl1 = S.l1.p, *dl2 = S.l2.p, *dn = S.n.p; double *db1 = S.b1.p, *db2 = S.b2.p, *oa = S.oa.p;
+    uint8_t *dt1 = S.t1.p, *dt2 = S.t2.p, *dud = S.ud.p; uint2 *ow = S.ow.p;
     HIPCK(c, hipMemcpy(dl1, l1, n * 4, hipMemcpyHostToDevice)); HIPCK(c, hipMemcpy(dl2, l2, n * 4, hipMemcpyHostToDevice));
     HIPCK(c, hipMemcpy(db1, b1, n * 8, hipMemcpyHostToDevice)); HIPCK(c, hipMemcpy(db2, b2, n * 8, hipMemcpyHostToDevice));
     HIPCK(c, hipMemcpy(dt1, t1, n, hipMemcpyHostToDevice)); HIPCK(c, hipMemcpy(dt2, t2, n, hipMemcpyHostToDevice));
@@ -138,7 +144,5 @@ extern "C" int maple_debug_merge_lds(maple_ctx *c, int32_t n, const int32_t *l1,
     *ms /= (float)reps;
     HIPCK(c, hipMemcpy(nOut, dn, n * 4, hipMemcpyDeviceToHost));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(dl1); (void)hipFree(dl2); (void)hipFree(dn); (void)hipFree(db1); (void)hipFree(db2);
-    (void)hipFree(dt1); (void)hipFree(dt2); (void)hipFree(dud); (void)hipFree(ow); (void)hipFree(oa);
     return MAPLE_OK;
 }
