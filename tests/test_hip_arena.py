@@ -79,3 +79,47 @@ def test_compaction_after_many_repairs_keeps_every_list_of_the_tree():
                                effectivelyNon0BLen=ctx["effectivelyNon0BLen"])
     assert (out["status"] >= -1).all()
     dev.close()
+
+
+def test_rebuild_lists_inside_the_library_edge_cases():
+    """maple_tree_rebuild_lists (reCalculateAllGenomeLists, M:6013-6347): two tips that differ at a site and hang on zero-length
+    branches cannot be merged (mergeVectors returns None, M:4753-4758): with bumpLen = 0 the call fails like the reference would
+    (it calls updateBLen there), with bumpLen > 0 the two branches are lengthened and the build goes through; malformed
+    trees are refused; downloads of lists that are interleaved in the arena come back intact whatever the order."""
+    from maple_amd.runtime import MapleError
+    f, dev, tree = _env()
+    l_ref = dev.lRef
+    ref = ref_indices(f["context"])
+    a = [(4, l_ref)]                                                          # the reference itself
+    other = (int(ref[9]) + 1) % 4
+    b = [(4, 9), (other, int(ref[9])), (4, l_ref)]                            # one difference at site 10
+    ids = dev.upload([a, b])
+    up = np.asarray([-1, 0, 0], np.int32)
+    c0 = np.asarray([1, -1, -1], np.int32)
+    c1 = np.asarray([2, -1, -1], np.int32)
+    tip = np.asarray([0, 1, 1], np.uint8)
+    lower = np.asarray([-1, ids[0], ids[1]], np.int32)
+    dist = np.zeros(3)
+    with pytest.raises(MapleError) as e:
+        dev.tree_rebuild_lists(0, up, c0, c1, tip, None, dist, lower)
+    assert e.value.code == MapleError.ERR_FATAL
+    dist = np.zeros(3)
+    lo, ur, ul, tu, bad = dev.tree_rebuild_lists(0, up, c0, c1, tip, None, dist, lower, bump_len=0.1 / l_ref)
+    assert len(bad) == 0 and dist[1] > 0 and dist[2] > 0 and dist[0] == 0
+    assert lo[0] >= 0 and ur[0] >= 0 and ul[0] >= 0 and tu[1] >= 0 and tu[2] >= 0 and tu[0] == -1
+    root_list = dev.download(lo[:1])[0]
+    assert root_list[0][0] == 4 and root_list[-1][1] == l_ref and any(e[0] == 6 for e in root_list)   # an O entry at the site that differs
+    # a node with one child, a child index out of range
+    with pytest.raises(MapleError) as e:
+        dev.tree_rebuild_lists(0, up, np.asarray([1, -1, -1], np.int32), np.asarray([-1, -1, -1], np.int32), tip, None, np.zeros(3), lower)
+    assert e.value.code == MapleError.ERR_ARG
+    with pytest.raises(MapleError) as e:
+        dev.tree_rebuild_lists(0, up, np.asarray([7, -1, -1], np.int32), c1, tip, None, np.zeros(3), lower)
+    assert e.value.code == MapleError.ERR_ARG
+    # lists of different kinds interleaved in the arena, downloaded in an order of their own
+    mix = np.asarray([tu[2], lo[0], ids[1], ur[0], ids[0], tu[1], ul[0]], np.int32)
+    got = dev.download(mix)
+    for i, l in zip(mix, got):
+        assert l == dev.download([i])[0]
+    assert got[2] == b and got[4] == a
+    dev.close()
