@@ -150,8 +150,8 @@ def parse_args(argv=None):
                          "reference branch they cross; none: every list in the root's frame (rounds 1-3); auto = local")
     ap.add_argument("--synth", choices=["auto", "v1", "v2"], default="auto",
                     help="generator of the synthetic input: v1 = maple_amd.synth.make_dataset (numpy stream; the 10 000 / 100 000-sample "
-                         "trees of rounds 1-3), v2 = the same model from csrc/synth_gen.c (seconds at 1 000 000 samples); auto = v1 up to "
-                         "200 000 samples, v2 above")
+                         "trees of rounds 1-4: 21 s at 100 000 samples), v2 = the same model from csrc/synth_gen.c (1 s at 1 000 000 "
+                         "samples); auto = v2")
     ap.add_argument("--queries", type=int, default=256, help="query lists of the all-pairs scoring sub-block")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate host time spent on cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -210,6 +210,92 @@ def init_env(args):
     return env
 
 
+LINE_LIMIT = 4096          # bytes: the final line must stay small enough for the driver to parse (round 4's 25 KB line was not)
+
+
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[: n - 1].rstrip() + "~"
+
+
+def _num(x, digits=6):
+    """Floats of the line to `digits` significant digits (the detail file keeps full precision)."""
+    if isinstance(x, float) and math.isfinite(x):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def compact_line(full):
+    """The ONE line rank 0 prints: the contract's fields, `roofline` and `cpu_baseline` as flat objects, the tree log-LK
+    check and a summary of the 1 000 000-tip leg -- numbers only, no prose beyond the workload sentence.  Everything else
+    run_leg measured (notes, per-kernel blocks, PMC counters, sub-blocks) goes to bench_detail.json (write_detail)."""
+    cfg = full.get("config", {})
+
+    def roof(r):
+        if not r:
+            return None
+        src = r.get("traffic_source")
+        return {"bound": r["bound"], "kernel": str(r["kernel"]).split()[0], "achieved": _num(r["achieved"]), "peak": r["peak"],
+                "unit": r["unit"], "frac": _num(r["frac"]), "traffic": _num(r.get("traffic")),
+                "traffic_over_algorithmic": _num(r["traffic"] / r["algorithmic_bytes_per_launch"], 4)
+                if r.get("traffic") and r.get("algorithmic_bytes_per_launch") else None,
+                "traffic_source": src.get("file") if isinstance(src, dict) else src,
+                "algorithmic_bytes_per_launch": _num(r.get("algorithmic_bytes_per_launch")), "kernel_ms": _num(r.get("kernel_ms")),
+                "launches_timed": r.get("launches_timed"), "kernel_ms_per_step": _num(r.get("kernel_ms_per_step"))}
+    line = {k: _num(full.get(k)) for k in ("metric", "value", "value_walked", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                           "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": _short(cfg.get("workload", ""), 260), "samples": cfg.get("samples"), "model": cfg.get("model"),
+                      "tree": cfg.get("tree"), "local_references": (cfg.get("local_references") or {}).get("form"),
+                      "tree_nodes": cfg.get("tree_nodes"), "searches_per_step": cfg.get("searches_per_step"),
+                      "candidate_placements_timed": cfg.get("candidate_placements_timed"),
+                      "parallelism": _short(cfg.get("parallelism", ""), 120), "setup_s": cfg.get("setup_s")}
+    line["roofline"] = roof(full.get("roofline"))
+    line["roofline_other_kernels"] = [
+        {"kernel": str(r["kernel"]).split()[0], "bound": r["bound"], "frac": _num(r["frac"], 4), "kernel_ms_per_step": _num(r["kernel_ms_per_step"], 4)}
+        for r in full.get("roofline_by_kernel", []) if r is not full.get("roofline") and r["kernel"] != (full.get("roofline") or {}).get("kernel")]
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _num(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": _short(cb.get("sample_short") or cb["sample"], 120),
+                                "one_core": _num((cb.get("one_core") or {}).get("value"))}
+    if full.get("tree_log_lk"):
+        line["tree_log_lk"] = {k: full["tree_log_lk"].get(k) for k in ("gpu", "oracle", "rel_delta", "tolerance")}
+    line["first_call_ms"] = _num(full.get("first_call_ms"), 5)
+    leg = full.get("config_1M_full_model")
+    if leg:
+        lc = leg.get("config", {})
+        line["config_1M"] = {"samples": lc.get("samples"), "model": lc.get("model"), "searches_per_step": lc.get("searches_per_step"),
+                             "value": _num(leg.get("value")), "value_walked": _num(leg.get("value_walked")),
+                             "ms_per_step": _num(leg.get("ms_per_step")), "steps": leg.get("steps"),
+                             "first_call_ms": _num(leg.get("first_call_ms"), 5),
+                             "roofline": {k: v for k, v in (roof(leg.get("roofline")) or {}).items()
+                                          if k in ("bound", "kernel", "achieved", "peak", "frac", "kernel_ms", "kernel_ms_per_step")}}
+    line["detail"] = full.get("detail_file")
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:                            # (cannot happen with the bounded fields above; never print a long line)
+        for k in ("roofline_other_kernels", "config_1M", "detail"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= LINE_LIMIT:
+                break
+    return line, text
+
+
+def write_detail(full):
+    """Everything a run measured, with its notes: bench_detail.json next to bench.py (and under gpurun_out/ when that exists, so
+    that a gpurun call brings it back).  Returns the path written (relative to the repository)."""
+    name = "bench_detail.json"
+    full["detail_file"] = name
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, name), "w") as f:
+                    json.dump(full, f, indent=1)
+            except OSError:
+                pass
+    return name
+
+
 def main():
     args = parse_args()
     env = init_env(args)
@@ -227,37 +313,41 @@ def main():
                     "config", "roofline", "roofline_by_kernel", "per_rank", "spr_search", "first_call_ms")
             out["config_1M_full_model"] = {k: leg2[k] for k in keep if k in leg2}
     if env.rank == 0:
-        print(json.dumps(out), flush=True)
+        write_detail(out)
+        _, text = compact_line(out)
+        print(text, flush=True)
     if env.distd is not None:
         env.distd.barrier()
         env.distd.destroy_process_group()
 
 
-def run_leg(args, env):
-    """One workload: build the tree on this rank's GPU, warm up, time the steps; returns the JSON object on rank 0 (None elsewhere)."""
-    torch, rank, world, local_rank, backend, distd, cu, coll_dev = (env.torch, env.rank, env.world, env.local_rank, env.backend,
-                                                                     env.distd, env.cu, env.coll_dev)
+class BenchTree:
+    """What build_bench_tree leaves behind: the device, the tree and what it took to make it."""
+
+
+def build_bench_tree(samples, model, *, device=0, tree="optimised", refs="auto", synth="auto", big_arena=False):
+    """The tree the bench steps search (tests/test_hip_configs.py builds the same one): synthetic samples, genome
+    lists built on the GPU, branch lengths optimised as MAPLE does before its SPR rounds (tree="optimised"), MAT local
+    references added (refs="local" / "auto"), uploaded for the searches."""
     from maple_amd.host import reference_tables, tip_genome_list, tip_lists_packed
-    from maple_amd.parallel import gather_proposals, pack_proposals
     from maple_amd.runtime import Device
     from maple_amd.synth import make_dataset, make_dataset_native
     from maple_amd.tree_mirror import TreeMirror
-
-    t_setup = time.time()
-    synth = args.synth if args.synth != "auto" else ("v1" if args.samples <= 200000 else "v2")
+    bt = BenchTree()
+    bt.t_setup = time.time()
+    synth = synth if synth != "auto" else "v2"
     gen = make_dataset if synth == "v1" else make_dataset_native
-    data = gen(n_samples=args.samples, l_ref=29903, seed=1, mean_diffs=30.0, rate_variation=(args.model != "unrest"))
-    gen_s = time.time() - t_setup
+    data = gen(n_samples=samples, l_ref=29903, seed=1, mean_diffs=30.0, rate_variation=(model != "unrest"))
+    bt.gen_s = time.time() - bt.t_setup
     ref_idx, root_freqs = reference_tables(data.ref)
     # genome-list arena: bigger trees get more of the 288 GB (the per-frame removed lists of the wide searches on trees
     # with local references are the big temporary)
     # (the tree's own lists take ~10 KB per sample; the sub-block with local references needs the large arena)
-    run_local_refs = (args.local_refs or args.samples <= 200000) and not args.no_extras
-    per_sample = (320 << 10) if run_local_refs else (64 << 10)
-    dev = Device(ref_idx, root_freqs, device=local_rank, arena_bytes=min(128 << 30, max(4 << 30, args.samples * per_sample)))
-    mkw = model_kwargs(args.model, len(ref_idx))
+    per_sample = (320 << 10) if big_arena else (64 << 10)
+    dev = Device(ref_idx, root_freqs, device=device, arena_bytes=min(128 << 30, max(4 << 30, samples * per_sample)))
+    mkw = model_kwargs(model, len(ref_idx))
     dev.set_model(**mkw)
-    tip_kw = dict(error_rates=mkw["errorRates"]) if args.model == "siteerr" else {}
+    tip_kw = dict(error_rates=mkw["errorRates"]) if model == "siteerr" else {}
     t_tips = time.time()
     if synth == "v1":
         tip_lists = {int(v): tip_genome_list(dl, ref_idx, **tip_kw) for v, dl in zip(data.tip_node, data.diffs)}
@@ -266,7 +356,7 @@ def run_leg(args, env):
         dc = data.diffs
         mirror = TreeMirror(dev, data.parent, data.blen, tip_packed=(data.tip_node, tip_lists_packed(dc.off, dc.code, dc.pos, dc.length,
                                                                                                       ref_idx, **tip_kw)))
-    tips_s = time.time() - t_tips
+    bt.tips_s = time.time() - t_tips
     tip_ids = mirror.lower.copy()
     mark_tree = dev.mark()
     t_b = time.perf_counter()
@@ -274,7 +364,7 @@ def run_leg(args, env):
     build_ms = 1e3 * (time.perf_counter() - t_b)
     l_ref = dev.lRef
     blen_opt = None
-    if args.tree == "optimised":
+    if tree == "optimised":
         blen_opt = optimise_branch_lengths(dev, mirror, tip_ids, mark_tree, 1.0 / (10 * l_ref))
         blen_opt["tree_build_ms"] = round(build_ms, 1)
     no_mut = -np.ones(mirror.n_nodes, dtype=np.int32)
@@ -282,8 +372,8 @@ def run_leg(args, env):
     def upload_plain_tree():
         dev.upload_tree(mirror.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], mirror.dist, mirror.is_tip,
                         mirror.lower, mirror.up_right, mirror.up_left, mirror.tot_up, no_mut)
-    refs = args.refs if args.refs != "auto" else "local"
-    ht, n_ref, refs_s = None, 0, 0.0
+    refs = refs if refs != "auto" else "local"
+    ht, n_ref, refs_s, ht_dist = None, 0, 0.0, None
     if refs == "local":
         # the tree as MAPLE itself keeps it: MAT local references (maple_amd/mat.py: the reference nodes chosen by setUpMAT's rule, every
         # list of a clade written against its reference node's genome, all four lists of every node rebuilt on the GPU)
@@ -302,6 +392,27 @@ def run_leg(args, env):
             dev.upload_tree(ht.root, mirror.parent, mirror.children[:, 0], mirror.children[:, 1], ht_dist, mirror.is_tip, ht.id_lower,
                             ht.id_upRight, ht.id_upLeft, ht.id_totUp, ht.id_mut)
     upload_headline_tree()
+    bt.dev, bt.mirror, bt.ht, bt.ht_dist, bt.data, bt.ref_idx, bt.root_freqs, bt.mkw, bt.tip_kw = (dev, mirror, ht, ht_dist, data, ref_idx,
+                                                                                                   root_freqs, mkw, tip_kw)
+    bt.tip_ids, bt.mark_tree, bt.blen_opt, bt.n_ref, bt.refs, bt.refs_s, bt.synth = tip_ids, mark_tree, blen_opt, n_ref, refs, refs_s, synth
+    bt.upload_plain_tree, bt.upload_headline_tree = upload_plain_tree, upload_headline_tree
+    return bt
+
+
+def run_leg(args, env):
+    """One workload: build the tree on this rank's GPU, warm up, time the steps; returns the JSON object on rank 0 (None elsewhere)."""
+    torch, rank, world, local_rank, backend, distd, cu, coll_dev = (env.torch, env.rank, env.world, env.local_rank, env.backend,
+                                                                     env.distd, env.cu, env.coll_dev)
+    from maple_amd.parallel import gather_proposals, pack_proposals
+    from maple_amd.runtime import Device
+
+    bt = build_bench_tree(args.samples, args.model, device=local_rank, tree=args.tree, refs=args.refs, synth=args.synth,
+                          big_arena=(args.local_refs or args.samples <= 200000) and not args.no_extras)
+    dev, mirror, ht, data, ref_idx, root_freqs, mkw, tip_kw, tip_ids = (bt.dev, bt.mirror, bt.ht, bt.data, bt.ref_idx, bt.root_freqs,
+                                                                        bt.mkw, bt.tip_kw, bt.tip_ids)
+    t_setup, gen_s, tips_s, refs_s, n_ref, refs, blen_opt = bt.t_setup, bt.gen_s, bt.tips_s, bt.refs_s, bt.n_ref, bt.refs, bt.blen_opt
+    upload_plain_tree, upload_headline_tree = bt.upload_plain_tree, bt.upload_headline_tree
+    l_ref = dev.lRef
     t_up = time.perf_counter()
     upload_headline_tree()                               # (timed once more, warm: what a caller pays per change of the tree)
     tree_upload_ms = 1e3 * (time.perf_counter() - t_up)
@@ -504,8 +615,7 @@ def run_leg(args, env):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.samples} synthetic SARS-CoV-2 diff-lists (lRef 29903, ~30 diffs/sample), "
-                                   f"{MODEL_TEXT[args.model]}; SPR search (findBestParentTopology + worker, "
-                                   f"{'fast initial' if args.spr_fast else 'deep'}-round parameters) for {B} pruned nodes per step; "
+                                   f"{MODEL_TEXT[args.model]}; SPR search ({'fast' if args.spr_fast else 'deep'}-round) of {B} pruned nodes per step; "
                                    f"tree: {'branch lengths optimised as MAPLE does before its SPR rounds' if args.tree == 'optimised' else 'simulated tree, lengths = mutations / lRef'}"
                                    f"{', with MAT local references (' + str(n_ref) + ' reference nodes)' if refs == 'local' else ', no local references'}",
                        "local_references": {"form": refs, "reference_nodes": int(n_ref), "setup_s": round(refs_s, 2),
@@ -541,6 +651,9 @@ def run_leg(args, env):
         }
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
+            out["tree_log_lk"] = tree_log_lk_check(dev, mirror, ht, tip_ids, mkw, ref_idx, root_freqs)
+            if not out["tree_log_lk"]["rel_delta"] <= 1e-6:
+                raise SystemExit(f"tree log-LK: GPU and oracle differ by more than 1e-6 relative: {out['tree_log_lk']}")
             out["cpu_baseline"] = spr_cpu_baseline(dev, mirror, ht, ref_idx, root_freqs, batch_of, kept, kw, args.cpu_seconds, mkw,
                                                    args.steps)
     if distd is not None:
@@ -887,6 +1000,7 @@ def spr_cpu_baseline(dev, mirror, ht, ref_idx, root_freqs, batch_of, gpu_results
     tn, pn, cn = timed_sample(cores, 2.0 * cpu_seconds / 3.0, 499, seen) if cores > 1 else (t1, p1, c1)
     full = float(gpu["nAppend"][gpu["status"] >= -1].sum())
     return {"value": pn / tn, "unit": "placements/s", "cores": cores, "kind": "port",
+            "sample_short": f"{cn} of {len(nodes)} timed searches, {pn} placements, C oracle (OpenMP) on {cores} threads, {tn:.1f} s; results = GPU's",
             "sample": f"{cn} of the {len(nodes)} timed searches (evenly spread), {pn} candidate placements, C oracle search "
                       f"(oracle/maple_oracle_search.c, OpenMP over searches like the reference's Pool.map over --numCores, M:12283-12293) "
                       f"on {cores} host threads, {tn:.1f} s; node ids, moves and candidate counts identical to the GPU's"
@@ -894,6 +1008,123 @@ def spr_cpu_baseline(dev, mirror, ht, ref_idx, root_freqs, batch_of, gpu_results
             "one_core": {"value": p1 / t1, "unit": "placements/s", "cores": 1,
                          "sample": f"{c1} searches, {p1} candidate placements, {t1:.1f} s"},
             "whole_workload_estimate_s": {"one_core": full / (p1 / t1), f"{cores}_cores": full / (pn / tn)}}
+
+
+def lk_post_order(root, children):
+    """Internal nodes in the order calculateTreeLikelihood adds their contributions (M:9721-9779: post-order, child 0 first)."""
+    order, stack = [], [(int(root), False)]
+    while stack:
+        v, done = stack.pop()
+        if children[v][0] < 0:
+            continue
+        if done:
+            order.append(v)
+        else:
+            stack.append((v, True))
+            stack.append((int(children[v][1]), False))
+            stack.append((int(children[v][0]), False))
+    return np.asarray(order, dtype=np.int64)
+
+
+def oracle_tree_log_lk(cpu, root, parent, children, dist, tip_nodes, tip_packed, mutations=None):
+    """calculateTreeLikelihood (M:9721-9779) by the C oracle alone, from the TIPS' lists and the branch lengths: the lower
+    lists bottom-up (mergeVectors + shorten per internal node, reCalculateAllGenomeLists pass 1, M:6031-6200), each merge
+    with returnLK (M:9756), the contributions summed in the reference's post-order, + findProbRoot (M:4865-4912) of the
+    root's list.  ``mutations`` (per node, the MAT mutation list of the branch above a reference node, M:8296-8354): the tips'
+    lists -- handed in against the root's reference -- are first taken down into their frames (passGenomeListThroughBranch
+    through every reference branch above them, outermost first, then shorten), and a reference node's lower list goes up
+    through its branch before it is merged (M:9749-9754); the value then is the reference's for THAT form of the tree (its
+    whole-genome term, M:4487, always uses the root's reference, so the two forms differ in the fifth digit).
+    ``cpu`` is a Device over oracle/libmaple_cpu.so (the CPU twin: oracle/maple_oracle.c behind the same C ABI); nothing of the
+    GPU's enters.  Returns (log-LK, root term)."""
+    n = len(parent)
+    children = np.asarray(children)
+    parent = np.asarray(parent)
+    is_tip = children[:, 0] < 0
+    depth = np.zeros(n, dtype=np.int64)
+    levels = []
+    level = np.asarray([root], dtype=np.int64)
+    while len(level):
+        depth[level] = len(levels)
+        levels.append(level)
+        ch = children[level].reshape(-1)
+        level = ch[ch >= 0]
+    tip_nodes = np.asarray(tip_nodes, dtype=np.int64)
+    cur = cpu.upload_packed(tip_packed)
+    mut_id = -np.ones(n, dtype=np.int32)
+    has = [v for v in range(n) if mutations[v]] if mutations is not None else []
+    if has:
+        mut_id[has] = cpu.upload_mutations([mutations[v] for v in has])
+        frame = -np.ones(n, dtype=np.int64)                  # the innermost reference node at or above each node
+        for lev in levels[1:]:
+            frame[lev] = np.where(mut_id[lev] >= 0, lev, frame[parent[lev]])
+        uniq, inv = np.unique(frame[tip_nodes], return_inverse=True)
+        chains = []
+        for f in uniq.tolist():                              # the reference nodes above a tip, outermost first
+            ch = []
+            while f >= 0:
+                ch.append(f)
+                f = int(frame[parent[f]])
+            chains.append(ch[::-1])
+        for k in range(max(len(c) for c in chains)):
+            fk = np.asarray([c[k] if len(c) > k else -1 for c in chains], dtype=np.int64)[inv]
+            need = np.nonzero(fk >= 0)[0]
+            cur[need] = cpu.pass_branch_batch(cur[need], mut_id[fk[need]], False)
+        cur = cpu.shorten_batch(cur)
+    lower = -np.ones(n, dtype=np.int32)
+    lower[tip_nodes] = cur
+    lk_node = np.zeros(n)
+    for lev in reversed(levels):
+        nodes = lev[~is_tip[lev]]
+        if len(nodes) == 0:
+            continue
+        c0, c1 = children[nodes, 0], children[nodes, 1]
+        l0, l1 = lower[c0].copy(), lower[c1].copy()
+        for arr, ch in ((l0, c0), (l1, c1)):
+            need = np.nonzero(mut_id[ch] >= 0)[0]
+            if len(need):
+                arr[need] = cpu.pass_branch_batch(arr[need], mut_id[ch[need]], True)
+        out, lk = cpu.merge_batch(l0, dist[c0], is_tip[c0], l1, dist[c1], is_tip[c1], False, returnLK=True)
+        if (out < 0).any():
+            raise SystemExit("oracle_tree_log_lk: mergeVectors returned None (inconsistent zero-length branch, M:9761)")
+        lower[nodes] = cpu.shorten_batch(out)
+        lk_node[nodes] = lk
+    total = 0.0
+    for x in lk_node[lk_post_order(root, children)].tolist():
+        total += x
+    root_lk = float(cpu.root_prob_batch([lower[root]])[0])
+    return total + root_lk, root_lk
+
+
+def tree_log_lk_check(dev, mirror, ht, tip_ids, mkw, ref_idx, root_freqs):
+    """The metric's second half ("tree log-LK delta vs ref"): calculateTreeLikelihood of the bench tree by the library
+    (maple_merge_batch(returnLK) over every internal node's two stored lower lists + maple_root_prob_batch,
+    tree_host.tree_log_likelihood -- on the tree as the timed steps searched it, local references included) against the C
+    oracle's own value from the tips' lists (oracle_tree_log_lk: no list of the GPU's enters).  North star: <= 1e-6 relative."""
+    import ctypes
+    from maple_amd.runtime import Device
+    from maple_amd.tree_host import HostTree, tree_log_likelihood
+    from oracle.oracle_py import build as build_oracle
+    t0 = time.perf_counter()
+    tree = ht if ht is not None else HostTree.from_mirror(mirror)
+    gpu_lk, gpu_root = tree_log_likelihood(dev, tree)
+    gpu_s = time.perf_counter() - t0
+    build_oracle()
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libmaple_cpu.so"))
+    lib.maple_last_error.restype = ctypes.c_char_p
+    cpu = Device(ref_idx, root_freqs, lib=lib)
+    cpu.set_model(**mkw)
+    tips = np.nonzero(mirror.is_tip)[0]
+    t0 = time.perf_counter()
+    dist = np.asarray([float(x or 0.0) for x in tree.dist]) if ht is not None else mirror.dist
+    orc_lk, orc_root = oracle_tree_log_lk(cpu, mirror.root, mirror.parent, mirror.children, dist, tips, dev.download_packed(tip_ids[tips]),
+                                          None if ht is None else ht.mutations)
+    orc_s = time.perf_counter() - t0
+    cpu.close()
+    return {"gpu": gpu_lk, "oracle": orc_lk, "rel_delta": abs(gpu_lk - orc_lk) / abs(orc_lk), "tolerance": 1e-6,
+            "gpu_root_term": gpu_root, "oracle_root_term": orc_root, "gpu_s": round(gpu_s, 2), "oracle_s": round(orc_s, 2),
+            "what": "calculateTreeLikelihood (M:9721-9779) of the bench tree in the form the timed steps searched (with its local "
+                    "references): the library over its stored lists vs oracle/libmaple_cpu.so from the tips' lists alone"}
 
 
 def usable_host_threads():

@@ -174,27 +174,95 @@ def test_usable_host_threads_is_positive_and_bounded():
     assert 1 <= n <= (os.cpu_count() or 1)
 
 
-def test_committed_bench_line_follows_the_contract():
-    """profiles/r02_bench_line.json is the last default `python bench.py` line measured on an MI355X: it must carry the
-    fields the driver and the judge read (metric / value / roofline / cpu_baseline ...), with consistent arithmetic, on
-    BASELINE.json's configs[2] (100 000 samples, UNREST + per-site rates)."""
-    import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_line.json")))
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+def _check_compact_line(line, text):
+    import bench
+    assert len(text) <= bench.LINE_LIMIT and "\n" not in text
+    assert json.loads(text) == json.loads(json.dumps(line))
+    for k in ("metric", "value", "value_walked", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, k
-    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None and d["dtype"] == "f64"
-    assert "workload" in d["config"] and d["config"]["samples"] == 100000 and d["config"]["model"] == "ratevar"
-    assert "100000" in d["config"]["workload"] and "per-site rates" in d["config"]["workload"]
+        assert k in line, k
+    assert line["higher_is_better"] is True and line["scaling"] == "strong" and line["vs_baseline"] is None and line["dtype"] == "f64"
+    cfg = line["config"]
+    assert "workload" in cfg and cfg["samples"] == 100000 and cfg["model"] == "ratevar"
+    assert "100000" in cfg["workload"] and "per-site rates" in cfg["workload"]
     # value = the search's own candidate placements over the wall time of the timed steps
-    assert abs(d["value"] - d["config"]["candidate_placements_timed"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
-    for r in (d["roofline"], d["roofline_second_kernel"]):
-        assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
-        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-        assert r["traffic"] is None or r["traffic"] > 0
-        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * max(1.0, r["achieved"])
-    cb = d["cpu_baseline"]
-    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert abs(line["value"] - cfg["candidate_placements_timed"] / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1e-4 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["kernel"].startswith("k_")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 * r["frac"]
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-4 * max(1.0, r["achieved"])
+    cb = line["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and len(cb["sample"]) <= 120
+
+
+def test_bench_line_is_small_and_follows_the_contract():
+    """bench.compact_line -- the function that makes the ONE line `python bench.py` prints -- on the full record of an MI355X run
+    (profiles/r04_bench_line.json: round 4's 25 KB line, which the driver could not parse; profiles/r05_bench_detail.json: this
+    round's bench_detail.json): the line stays under bench.LINE_LIMIT bytes and carries the fields the driver and the judge read
+    (metric / value / roofline / cpu_baseline / tree_log_lk ...), with consistent arithmetic, on BASELINE.json's configs[2]."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line.json")))
+    line, text = bench.compact_line(full)
+    _check_compact_line(line, text)
+    assert line["config_1M"]["samples"] == 1000000 and line["config_1M"]["roofline"]["frac"] > 0
+    # the worst case still fits: every prose field at its bound
+    full["config"]["workload"] = "x" * 5000
+    full["cpu_baseline"]["sample"] = "y" * 5000
+    assert len(bench.compact_line(full)[1]) <= bench.LINE_LIMIT
+    cur = os.path.join(ROOT, "profiles", "r05_bench_detail.json")
+    if os.path.exists(cur):
+        full = json.load(open(cur))
+        line, text = bench.compact_line(full)
+        _check_compact_line(line, text)
+        lk = line["tree_log_lk"]
+        assert lk["rel_delta"] <= 1e-6 and abs(lk["gpu"] - lk["oracle"]) <= 1e-6 * abs(lk["oracle"])
+        printed = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+        assert printed == json.loads(text)
+
+
+def test_oracle_tree_log_lk_from_the_tips_equals_calculateTreeLikelihood_over_stored_lists(monkeypatch):
+    """bench.oracle_tree_log_lk (the oracle's side of the metric's "tree log-LK delta": calculateTreeLikelihood from the tips'
+    lists alone, M:9721-9779 over M:6031-6200) against tree_host.tree_log_likelihood over the lists a full build stored -- both
+    through oracle/libmaple_cpu.so here (no GPU); the GPU test of the same name compares the library's value."""
+    import ctypes
+    import subprocess
+    import bench
+    from maple_amd.host import reference_tables, tip_genome_list
+    from maple_amd.runtime import Device
+    from maple_amd.synth import make_dataset
+    import maple_amd.mat as mat
+    from maple_amd.tree_host import HostTree, rebuild_genome_lists, tree_log_likelihood
+    from maple_amd.tree_mirror import TreeMirror
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libmaple_cpu.so"))
+    lib.maple_last_error.restype = ctypes.c_char_p
+    d = make_dataset(n_samples=200, l_ref=3000, seed=5, mean_diffs=12.0, frac_with_n=0.3, frac_ambig=0.3, n_run_len=(5, 80),
+                     rate_variation=True)
+    ref_idx, rf = reference_tables(d.ref)
+    for mode in ("unrest", "ratevar", "siteerr"):
+        mkw = bench.model_kwargs(mode, len(ref_idx))
+        tip_kw = dict(error_rates=mkw["errorRates"]) if mode == "siteerr" else {}
+        dev = Device(ref_idx, rf, lib=lib)
+        dev.set_model(**mkw)
+        m = TreeMirror(dev, d.parent, d.blen, {int(v): tip_genome_list(dl, ref_idx, **tip_kw) for v, dl in zip(d.tip_node, d.diffs)})
+        tip_ids = m.lower.copy()
+        m.build(native=False)
+        tree = HostTree.from_mirror(m)
+        want = tree_log_likelihood(dev, tree)
+        tips = np.nonzero(m.is_tip)[0]
+        cpu = Device(ref_idx, rf, lib=lib)
+        cpu.set_model(**mkw)
+        got = bench.oracle_tree_log_lk(cpu, m.root, m.parent, m.children, m.dist, tips, dev.download_packed(tip_ids[tips]))
+        assert got == want and want[0] < want[1] < 0
+        # ... and in the form with MAT local references (the twin has no maple_tree_rebuild_lists: the Python level loop)
+        monkeypatch.setattr(mat, "rebuild_genome_lists", lambda d_, t_: rebuild_genome_lists(d_, t_, native=False))
+        assert mat.add_local_references(dev, tree, 20) > 3
+        want_mat = tree_log_likelihood(dev, tree)
+        got_mat = bench.oracle_tree_log_lk(cpu, m.root, m.parent, m.children, m.dist, tips, dev.download_packed(tip_ids[tips]), tree.mutations)
+        assert got_mat == want_mat and 0 < abs(want_mat[0] - want[0]) < 1e-3 * abs(want[0])
+        cpu.close()
+        dev.close()
 
 
 def test_native_generator_and_packed_tip_lists_match_the_python_forms():

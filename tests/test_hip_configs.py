@@ -112,6 +112,35 @@ def test_config3_100k_ratevar_deep_round_against_the_oracle():
     print(f"config 3: {len(sel)} searches ({n_pl} candidate placements) equal the oracle's; {time.time() - t0:.0f} s")
 
 
+def test_config3_on_the_headline_tree_form_local_references_and_optimised_lengths():
+    """The tree `python bench.py` times (bench.build_bench_tree: synth v2, branch lengths optimised as MAPLE does before its SPR
+    rounds, MAT local references -- the form MAPLE's own trees have): one whole deep round; a sample of the searches against the
+    C oracle on the downloaded tree WITH its mutation lists (bench.spr_cpu_baseline: node ids, moves, candidate counts exact);
+    the lane tier identical on 2 048 nodes; and the metric's second half -- the tree log-likelihood by the library against the
+    oracle's value from the tips' lists alone (bench.tree_log_lk_check), 1e-6 relative by the north star, 1e-9 here."""
+    import bench
+    t0 = time.time()
+    bt = bench.build_bench_tree(100000, "ratevar")
+    dev, m = bt.dev, bt.mirror
+    assert bt.ht is not None and bt.n_ref > 1000 and bt.blen_opt["passes"] >= 1
+    kw = bench.search_kwargs(dev.lRef)
+    nodes = bench.preorder_nodes(m)
+    g = dev.spr_search_batch(nodes, **kw)
+    assert not (g["status"] < -1).any()
+    searched = g["status"] == 0
+    assert searched.sum() > 150000 and g["nAppend"][searched].sum() > 1e9
+    same_results(dev.spr_search_batch(nodes, **kw), g)
+    sub = np.arange(0, len(nodes), len(nodes) // 2048)[:2048]
+    same_results(dev.spr_search_batch(nodes[sub], search_tier=1, **kw), g, None, sub)
+    cb = bench.spr_cpu_baseline(dev, m, bt.ht, bt.ref_idx, bt.root_freqs, lambda i: nodes, [g], kw, 6.0, bt.mkw, 1)   # (SystemExit on a mismatch)
+    assert cb["value"] > 0 and "identical" in cb["sample"]
+    lk = bench.tree_log_lk_check(dev, m, bt.ht, bt.tip_ids, bt.mkw, bt.ref_idx, bt.root_freqs)
+    assert lk["rel_delta"] <= 1e-9 and lk["gpu"] < 0, lk
+    dev.close()
+    print(f"config 3, headline form: {bt.n_ref} reference nodes; {cb['sample']}; tree log-LK {lk['gpu']:.6f} vs oracle {lk['oracle']:.6f} "
+          f"(rel {lk['rel_delta']:.2e}); {time.time() - t0:.0f} s")
+
+
 @pytest.fixture(scope="module")
 def million():
     t0 = time.time()

@@ -769,3 +769,35 @@ def test_local_references_batched_equals_one_by_one():
         have = np.nonzero(ia >= 0)[0]
         assert dev.download(ia[have]) == dev.download(ib[have]), col
     dev.close()
+
+
+def test_oracle_tree_log_lk_from_the_tips_equals_the_library_on_plain_and_local_reference_trees(world):
+    """bench.tree_log_lk_check, the bench line's `tree_log_lk`: calculateTreeLikelihood (M:9721-9779) by the library over the
+    stored lower lists -- of the plain tree and of the same tree with MAT local references -- against the C oracle's value from
+    the tips' lists alone (no list of the GPU's enters it)."""
+    import bench
+    from maple_amd.mat import add_local_references
+    from maple_amd.tree_host import HostTree
+    mode, data, dev, orc, mirror = world
+    tips = np.nonzero(mirror.is_tip)[0]
+    tip_ids = mirror.lower.copy()
+    from maple_amd.host import reference_tables
+    ref_idx, rf = reference_tables(data.ref)
+    rng = np.random.default_rng(2 + 100)
+    kw = dict(Q=Q)
+    if mode != "unrest":
+        kw["siteRates"] = np.clip(rng.gamma(0.5, 2.0, size=len(ref_idx)), 0.001, 0.005 * len(ref_idx))
+    if mode == "siteerr":
+        er = np.exp(rng.uniform(math.log(1e-10), math.log(1e-3), size=len(ref_idx)))
+        kw.update(usingErrorRate=True, errorRates=er, errorRateGlobal=float(er.mean()))
+    plain = bench.tree_log_lk_check(dev, mirror, None, tip_ids, kw, ref_idx, rf)
+    assert plain["rel_delta"] <= 1e-12, plain
+    mark = dev.mark()
+    ht = HostTree.from_mirror(mirror)
+    assert add_local_references(dev, ht, 50) > 5
+    mat = bench.tree_log_lk_check(dev, mirror, ht, tip_ids, kw, ref_idx, rf)
+    # (the reference's whole-genome term, M:4487, uses the root's reference in every frame: the two forms of the tree differ in
+    # about the fifth digit, each equal to the oracle's value for its own form)
+    assert mat["rel_delta"] <= 1e-11 and 0 < abs(mat["oracle"] - plain["oracle"]) < 1e-3 * abs(plain["oracle"]), (mat, plain)
+    dev.release(mark)
+    assert len(tips) * 2 - 1 == mirror.n_nodes
