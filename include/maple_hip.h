@@ -202,7 +202,9 @@ int maple_update_partials_touched(maple_ctx *ctx, int32_t cap, int32_t *nodes, i
  * root.  The new lists are allocated after the caller's arena mark like any other.  bumpLen = 0: a None between zero-length
  * branches is MAPLE_ERR_FATAL (the reference calls updateBLen there, M:6087 / 6279).  bumpLen > 0 (a synthetic tree being built):
  * in the lower pass the two child branches are lengthened to bumpLen (dist is updated) and merged again; a None that remains, or
- * one in the upper pass, ends the call with *nBad > 0 and the nodes in badNodes (capBad >= 4) for the caller to lengthen. */
+ * one in the upper pass, ends the call with *nBad > 0 and the nodes in badNodes (capBad >= 4) for the caller to lengthen; *nBad counts
+ * every such node, badNodes holds the first capBad of them (capBad = n never cuts the list short).  `up` must agree with the
+ * children columns (checked). */
 int maple_tree_rebuild_lists(maple_ctx *ctx, int32_t n, int32_t root, const int32_t *up, const int32_t *child0, const int32_t *child1,
                              const uint8_t *isTip, const int32_t *mutList /* or NULL */, double *dist, int32_t *lower, int32_t *upRight,
                              int32_t *upLeft, int32_t *totUp, double bumpLen, int32_t capBad, int32_t *badNodes, int32_t *nBad);
@@ -277,14 +279,6 @@ int maple_spr_search_visited(maple_ctx *ctx, int64_t cap, int32_t *query, int32_
  * (the first min(*n, cap) are written).  A measurement aid; nothing is computed with it. */
 int maple_debug_frontier_levels(maple_ctx *ctx, int32_t cap, int64_t *itemsUpdating, int64_t *itemsCached, float *msUpdating,
                                 float *msCached, int32_t *n, int64_t *waveItemsSmall /* or NULL */, int64_t *waveItemsBig /* or NULL */);
-
-/* Times `reps` launches of a one-lane-per-pair mergeVectors kernel over n pairs of stored lists: mode 0 walks the input lists
- * where they are, mode 1 stages them in LDS first (slabW words + slabA aux doubles per lane; pairs that do not fit are walked
- * in place).  *ms = mean HIP-event time per launch, nOut[i] = entries of the merged list or its status.  A measurement aid
- * (tools/merge_latency_lds.py): nothing is committed to the arena.  lds_lane.hip. */
-int maple_debug_merge_lds(maple_ctx *ctx, int32_t n, const int32_t *l1, const double *b1, const uint8_t *tip1, const int32_t *l2,
-                          const double *b2, const uint8_t *tip2, const uint8_t *isUpDown, int32_t mode, int32_t slabW, int32_t slabA,
-                          int32_t reps, int32_t grid, float *ms, int32_t *nOut);
 
 typedef struct {
     double oneMutBLen;                          /* M:3606 */

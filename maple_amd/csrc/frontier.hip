@@ -922,11 +922,15 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     // root -- take pieces of a shared region.  As many lanes as the GPU holds at once at this kernel's occupancy.
     const int capE = std::max(256, std::min(1024, 6 * (int)meanEnt));
     long long scratchLanes = m <= 64 ? 16384 : 256ll * 4 * 4 * 64;         // 256 CUs x 4 SIMDs x 4 wavefronts (a handful of searches: what they can use)
-    while (scratchLanes > 16384 && (double)scratchLanes * capE * 64 > 0.25 * room) scratchLanes /= 2;
+    // slabs beyond the lanes' own: one per wavefront of the two wavefront-wide kernels (256 + 1 280 <= 2 048) and, on a tree with MAT
+    // local references, one per lane of k_fr_pass (256 workgroups), which runs next to k_fr_updating
+    const bool matTree = c->tree_has_mut;
+    const long long extraSlabs = 2048 + (matTree ? 256ll * FR_BLOCK : 0);
+    while (scratchLanes > 16384 && (double)(scratchLanes + extraSlabs) * capE * 64 > 0.25 * room) scratchLanes /= 2;
     const int gridUpd = (int)(scratchLanes / FR_BLOCK);
     const long long capBig = std::max<long long>(1 << 20, 64ll * 1024 * std::max(1, c->tree_max_ent));
     {   // shrink the pools proportionally if they would not fit
-        const double fixed = (double)scratchLanes * capE * 64 + (double)capBig * 48;
+        const double fixed = (double)(scratchLanes + extraSlabs) * capE * 64 + (double)capBig * 48;
         const double need = (double)capC * (sizeof(FItem) + sizeof(FVisit) + 12) + (double)capU * (sizeof(FItem) + sizeof(FVisit) + 12) + (double)capW * 8 + (double)capA * 8
                             + (double)capL * 24 + fixed;
         if (need > room) {
@@ -949,9 +953,9 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, F.tn.reserve_exact(grow((size_t)capL, F.tn.cap)));
     HIPCK(c, F.tna.reserve_exact(grow((size_t)capL, F.tna.cap)));
     HIPCK(c, F.tflag.reserve_exact(grow((size_t)capL, F.tflag.cap)));
-    HIPCK(c, F.sw.reserve_exact((size_t)(scratchLanes + 2048 + 65536) * capE));     // (+ one slab per wavefront of k_fr_updating_wave)
-    HIPCK(c, F.sa.reserve_exact((size_t)(scratchLanes + 2048 + 65536) * capE * 5));
-    HIPCK(c, F.sais.reserve_exact((size_t)(scratchLanes + 2048 + 65536) * capE * 2));
+    HIPCK(c, F.sw.reserve_exact((size_t)(scratchLanes + extraSlabs) * capE));
+    HIPCK(c, F.sa.reserve_exact((size_t)(scratchLanes + extraSlabs) * capE * 5));
+    HIPCK(c, F.sais.reserve_exact((size_t)(scratchLanes + extraSlabs) * capE * 2));
     HIPCK(c, F.bw.reserve_exact((size_t)capBig));
     HIPCK(c, F.ba.reserve_exact((size_t)capBig * 5));
     HIPCK(c, F.nodes.reserve((size_t)m));
@@ -1128,6 +1132,9 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         if (levels > 100000) return bail(fail(c, MAPLE_ERR_FATAL, "frontier search did not terminate"));
     }
     size_t slotWide = (size_t)-1;
+    // (replay, refinement, final selection: an error in here must not return with kernels still in flight on either stream --
+    // the caller may reuse or free the pools -- so the stage is a lambda and its status goes through bail() like the loop's)
+    auto finishStage = [&]() -> int {
     if (anyWide) {
         // the whole-tree searches: the same exact walk, a wavefront each, the clades in the cached regime scanned over the rows
         // of the dense score table -- next to the other searches' walk (k_fr_replay: one lane each, as long as its longest search)
@@ -1175,6 +1182,9 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, hipMemcpyAsync(hostOut, dout, (size_t)m * sizeof(SearchOut), hipMemcpyDeviceToHost, s));
     HIPCK(c, hipMemcpyAsync(&hc, fp.ctr, sizeof(FCtr), hipMemcpyDeviceToHost, s));
     HIPCK(c, hipStreamSynchronize(s));
+    return MAPLE_OK;
+    };
+    { const int rc_ = finishStage(); if (rc_) return bail(rc_); }
     {   // what this tier did, for maple_timing_read_kind: candidate placements of the searches it finished (SURVEY 8d bytes)
         const double meanCand = c->n_scored ? c->scored_bytes_total / c->n_scored : 0.0;
         double units = 0.0, bytes = 0.0;

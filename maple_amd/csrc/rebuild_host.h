@@ -33,6 +33,7 @@ extern "C" int maple_tree_rebuild_lists(maple_ctx *c, int32_t n, int32_t root, c
             const int ch = k == 0 ? c0[v] : c1[v];
             if (ch < 0) continue;
             if (ch >= n || depth[ch] >= 0) return fail(c, MAPLE_ERR_ARG, "node %d: child %d out of range or reached twice", v, ch);
+            if (up[ch] != v) return fail(c, MAPLE_ERR_ARG, "node %d is a child of %d but its `up` entry says %d", ch, v, up[ch]);   // (pass 2 reads `up`)
             if ((c0[v] < 0) != (c1[v] < 0)) return fail(c, MAPLE_ERR_ARG, "node %d has one child", v);
             depth[ch] = depth[v] + 1;
             maxd = std::max(maxd, depth[ch]);
@@ -47,7 +48,8 @@ extern "C" int maple_tree_rebuild_lists(maple_ctx *c, int32_t n, int32_t root, c
         else if (lower[v] < 0) return fail(c, MAPLE_ERR_ARG, "tip %d has no lower list", v);
         upRight[v] = upLeft[v] = totUp[v] = -1;
     }
-    auto bad = [&](int v) { if (nBad && *nBad < capBad) badNodes[(*nBad)++] = v; };
+    // (*nBad counts every bad node, also those beyond capBad: a caller that sees *nBad > capBad knows the list is cut short)
+    auto bad = [&](int v) { if (nBad) { if (*nBad < capBad) badNodes[*nBad] = v; (*nBad)++; } };
     std::vector<int32_t> nodes, a, b, pa, pb, out, old;
     std::vector<double> da, db;
     std::vector<uint8_t> ta, tb, ud, mode, none, diff;
@@ -148,6 +150,8 @@ extern "C" int maple_tree_rebuild_lists(maple_ctx *c, int32_t n, int32_t root, c
             }
             (iKind[i] == 1 ? upRight : upLeft)[v] = out[i];
         }
+        // (bad nodes of this level: the levels below a node without its upper lists cannot be made, but every other node of THIS
+        // level has been looked at -- the caller lengthens all of them before it starts over)
         if (nBad && *nBad) return MAPLE_OK;
     }
     return MAPLE_OK;

@@ -25,7 +25,7 @@ EXPORTS = [
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
     "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
     "maple_timing_read_kind", "maple_placement_supports_batch", "maple_debug_gpv_batch", "maple_debug_simplify_batch",
-    "maple_candset_destroy", "maple_debug_calib_write", "maple_spr_search_visited", "maple_arena_compact", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev", "maple_debug_frontier_levels", "maple_debug_merge_lds", "maple_tree_rebuild_lists",
+    "maple_candset_destroy", "maple_debug_calib_write", "maple_spr_search_visited", "maple_arena_compact", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev", "maple_debug_frontier_levels", "maple_tree_rebuild_lists",
 ]
 
 
@@ -602,27 +602,12 @@ class Device:
         assert dist.dtype == np.float64 and dist.flags.c_contiguous
         lower = _i32(lower).copy()
         ur, ul, tu = (np.full(n, -1, np.int32) for _ in range(3))
-        bad = np.zeros(64, np.int32)
+        bad = np.zeros(max(64, n), np.int32)                  # (every node can be named: nothing is dropped)
         nbad = C.c_int32()
         self._ck(self.lib.maple_tree_rebuild_lists(self.h, n, int(root), _ptr(up), _ptr(c0), _ptr(c1), _ptr(tip), _ptr(mutp), _ptr(dist),
                                                    _ptr(lower), _ptr(ur), _ptr(ul), _ptr(tu), C.c_double(bump_len), len(bad), _ptr(bad),
                                                    C.byref(nbad)))
-        return lower, ur, ul, tu, bad[: nbad.value].copy()
-
-    def debug_merge_lds(self, l1, b1, t1, l2, b2, t2, up_down, mode, slab_w=128, slab_a=64, reps=20, grid=0):
-        """(mean ms per launch, entries of every merged list) of the measurement kernel of lds_lane.hip."""
-        l1, l2 = _i32(l1), _i32(l2)
-        n = len(l1)
-        b1 = np.ascontiguousarray(np.broadcast_to(np.asarray(b1, np.float64), (n,)))
-        b2 = np.ascontiguousarray(np.broadcast_to(np.asarray(b2, np.float64), (n,)))
-        t1 = np.ascontiguousarray(np.broadcast_to(np.asarray(t1, np.uint8), (n,)))
-        t2 = np.ascontiguousarray(np.broadcast_to(np.asarray(t2, np.uint8), (n,)))
-        ud = np.ascontiguousarray(np.broadcast_to(np.asarray(up_down, np.uint8), (n,)))
-        ms = C.c_float()
-        out = np.zeros(n, np.int32)
-        self._ck(self.lib.maple_debug_merge_lds(self.h, n, _ptr(l1), _ptr(b1), _ptr(t1), _ptr(l2), _ptr(b2), _ptr(t2), _ptr(ud), int(mode),
-                                                int(slab_w), int(slab_a), int(reps), int(grid), C.byref(ms), _ptr(out)))
-        return ms.value, out
+        return lower, ur, ul, tu, np.unique(bad[: min(nbad.value, len(bad))])
 
     def timing_read(self):
         """(number of timed *_dev launches since the last reset, their summed HIP-event time in ms)."""
