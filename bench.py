@@ -246,7 +246,7 @@ def compact_line(full):
                                            "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     line["config"] = {"workload": _short(cfg.get("workload", ""), 260), "samples": cfg.get("samples"), "model": cfg.get("model"),
                       "tree": cfg.get("tree"), "local_references": (cfg.get("local_references") or {}).get("form"),
-                      "tree_nodes": cfg.get("tree_nodes"), "searches_per_step": cfg.get("searches_per_step"),
+                      "tree_nodes": cfg.get("tree_nodes"), "searches_per_step": cfg.get("searches_per_step"), "searches_timed": cfg.get("searches_timed"),
                       "candidate_placements_timed": cfg.get("candidate_placements_timed"),
                       "parallelism": _short(cfg.get("parallelism", ""), 120), "setup_s": cfg.get("setup_s")}
     line["roofline"] = roof(full.get("roofline"))

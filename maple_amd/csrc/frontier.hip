@@ -130,20 +130,46 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
     }
 }
 
-__global__ void k_fr_snap(FCtr *ctr, long long capU, long long capC, unsigned long long *lvl, int maxLevels, long long capPass)
+// The two streams of the expansion keep their own books.  k_fr_snap_u closes a level of the list-updating items and opens the
+// next (after k_fr_begin: the first), and PUBLISHES what the kernels before it on its stream pushed into the cached pool: only
+// kernels that have finished -- items that are written in full.  k_fr_snap_c opens a launch of the cached-regime items: what the
+// cached launches before it pushed (same stream: finished) and the roots published so far.
+#define FR_LVL 8                       // per level / launch in FPools::lvl: loU hiU | loC hiC loR hiR (roots: absolute refs) | wavefront-wide items: small, 512
+__global__ void k_fr_snap_u(FCtr *ctr, long long capU, long long capR, long long capPassR, unsigned long long *lvl, int maxLevels)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         // (a pool that overflowed keeps counting what was asked of it: the items themselves end at its capacity)
         ctr->loU = ctr->hiU; ctr->hiU = min(ctr->usedU, (unsigned long long)capU);
-        ctr->loC = ctr->hiC; ctr->hiC = min(ctr->usedC, (unsigned long long)capC);
-        ctr->loP = ctr->hiP; ctr->hiP = min(ctr->nPass, (unsigned long long)capPass);
+        // (the pass entries first: a cached launch that sees the new root count must see at least the pass entries that go with it --
+        // k_fr_snap_c on the other stream reads the two in the opposite order)
+        atomicExch(&ctr->safePassR, min(ctr->nPassR, (unsigned long long)capPassR));
+        __threadfence();
+        atomicExch(&ctr->safeR, min(ctr->usedR, (unsigned long long)capR));
         ctr->bigUsed = 0;
         const unsigned long long heavySmall = ctr->permHeavy, heavyBig = ctr->permHeavy2;
         ctr->permDown = ctr->permUp = ctr->permDownB = ctr->permUpB = ctr->permHeavy = ctr->permHeavy2 = 0;
         if (lvl) {
             const int l = ctr->nLevels++;
-            if (l < maxLevels) { lvl[6 * l] = ctr->loU; lvl[6 * l + 1] = ctr->hiU; lvl[6 * l + 2] = ctr->loC; lvl[6 * l + 3] = ctr->hiC; lvl[6 * l + 4] = lvl[6 * l + 5] = 0; }
-            if (l > 0 && l - 1 < maxLevels) { lvl[6 * (l - 1) + 4] = heavySmall; lvl[6 * (l - 1) + 5] = heavyBig; }   // (the level before: its wavefront-wide items)
+            if (l < maxLevels) { lvl[FR_LVL * l] = ctr->loU; lvl[FR_LVL * l + 1] = ctr->hiU; lvl[FR_LVL * l + 6] = lvl[FR_LVL * l + 7] = 0; }
+            if (l > 0 && l - 1 < maxLevels) { lvl[FR_LVL * (l - 1) + 6] = heavySmall; lvl[FR_LVL * (l - 1) + 7] = heavyBig; }   // (the level before: its wavefront-wide items)
+        }
+    }
+}
+__global__ void k_fr_snap_c(FCtr *ctr, long long capCC, long long capPass, unsigned long long *lvl, int maxLevels)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ctr->loC = ctr->hiC; ctr->hiC = min(ctr->usedC, (unsigned long long)capCC);
+        ctr->loR = ctr->hiR; ctr->hiR = atomicAdd(&ctr->safeR, 0ull);
+        __threadfence();
+        ctr->loP = ctr->hiP; ctr->hiP = min(ctr->nPass, (unsigned long long)capPass);
+        ctr->loPR = ctr->hiPR; ctr->hiPR = atomicAdd(&ctr->safePassR, 0ull);
+        ctr->bigUsedC = 0;
+        if (lvl) {
+            const int k = ctr->nLevelsC++;
+            if (k < maxLevels) {
+                lvl[FR_LVL * k + 2] = ctr->loC; lvl[FR_LVL * k + 3] = ctr->hiC;
+                lvl[FR_LVL * k + 4] = (unsigned long long)capCC + ctr->loR; lvl[FR_LVL * k + 5] = (unsigned long long)capCC + ctr->hiR;
+            }
         }
     }
 }
@@ -161,9 +187,10 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_pass(const DevModel *__restrict
     Ctx<RV, U, SS> c(m, lds);
     const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long slab = slabBase + laneId;                                // (scratch slabs of its own: it runs next to k_fr_updating)
-    const long long lo = (long long)fp.ctr->loP, hi = (long long)fp.ctr->hiP;
-    for (long long i = lo + laneId; i < hi; i += (long long)gridDim.x * blockDim.x) {
-        FItem &it = item_of(fp, fp.passList[i]);
+    // (the launch's two kinds of items: pushed by cached-regime items, and roots)
+    const long long loA = (long long)fp.ctr->loP, nA = (long long)fp.ctr->hiP - loA, loB = (long long)fp.ctr->loPR, nB = (long long)fp.ctr->hiPR - loB;
+    for (long long i = laneId; i < nA + nB; i += (long long)gridDim.x * blockDim.x) {
+        FItem &it = item_of(fp, i < nA ? fp.passList[loA + i] : fp.passListR[loB + (i - nA)]);
         FSearch &S = fp.S[it.q];
         if (!fs_live(S.state)) continue;
         const NodeRec r1 = T.nd[it.t1];
@@ -194,15 +221,23 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_sort_level(ArenaViewS av, DevTr
     for (long long base = (long long)blockIdx.x * blockDim.x; base < n; base += (long long)gridDim.x * blockDim.x) {
         const long long i = base + threadIdx.x;
         int kind = -1;                                                      // 0 down, 1 up, 2 / 3 the same with long lists, -1 a wavefront's item
+        bool small = false;
         if (i < n) {
             const FItem &it = fp.U[lo + i];
             const int sz = fr_upd_size(av, T, fp, it);
             if (!(heavyMin > 0 && it.dir != 3 && sz >= heavyMin)) kind = (it.dir == 0 ? 0 : 1) + (sz >= bigMin ? 2 : 0);
+            else {
+                // An item no wavefront-wide walk takes -- next to a MAT reference branch (it re-expresses lists on the way), or with
+                // a list beyond the 512-entry staging -- would be walked by lane 0 of a wavefront of the 512 class, of which there
+                // is one per compute unit: 0.3-1.7 ms each, one after the other (a level of 32 000 items by wavefronts: 10.5 ms,
+                // 8 of them for its 2 800 such items).  They stay one-lane items, 16 to a wavefront, next to each other.
+                small = fr_wave_fits(av, T, fp, it, FR_WAVE_SMALL_IN, FR_WAVE_SMALL_CAPW);
+                if (!small && !fr_wave_fits(av, T, fp, it, 512, 512)) kind = (it.dir == 0 ? 2 : 3);
+            }
         }
         const unsigned long long below = (1ull << lane) - 1ull;
         {   // the items that go a wavefront each (kind -1), by size class
             const bool hv = i < n && kind == -1;
-            const bool small = hv && fr_wave_fits(av, T, fp, fp.U[lo + i], FR_WAVE_SMALL_IN, FR_WAVE_SMALL_CAPW);
             for (int cls = 0; cls < 2; cls++) {
                 const bool mine = hv && (small == (cls == 0));
                 const unsigned long long mh = __ballot(mine);
@@ -230,6 +265,13 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_sort_level(ArenaViewS av, DevTr
 }
 
 // ---- items in the cached regime (needsUpdating == False): appendProbNode(probVectTotUp[t1], removed list) ---------------
+// One lane per item: the item, its search, the node record; the score (a one-lane walk of the branch's probVectTotUp against the
+// removed list); the rule and the pushes.
+// (Round 5, measured and not kept: the score by a GROUP of 16 lanes per item -- the two lists staged in LDS with loads that cover
+// whole lines, the steps found on the merge path, the factors multiplied in walk order as wave_append does: bit-identical, no
+// list word ever waited for, and SLOWER, 204-215 us per 64 items against 168: four wavefronts per SIMD then run out of issue
+// slots -- a binary search per step and 16 lanes' worth of control per item cost ~7 x the instructions of the one-lane walk,
+// which only ever waits.  DESIGN.md section 3T.)
 #ifndef FR_CACHED_WAVES
 #define FR_CACHED_WAVES 4             // wavefronts per SIMD the cached-regime kernel is compiled for (128 registers)
 #endif
@@ -242,73 +284,130 @@ void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Sear
     const DevModel &m = *mp;
     stage_model(m, lds);
     Ctx<RV, U, SS> c(m, lds);
-    const long long lo = (long long)fp.ctr->loC, hi = (long long)fp.ctr->hiC;
+    const int lane = threadIdx.x & 63;
+    // the launch's items: what the cached launches before it pushed, then the roots published since
+    const long long loC = (long long)fp.ctr->loC, nC = (long long)fp.ctr->hiC - loC, loR = fp.capCC + (long long)fp.ctr->loR,
+                    hi = nC + (long long)fp.ctr->hiR - (long long)fp.ctr->loR;
     unsigned long long nSc = 0, bSc = 0;
-    for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long long)gridDim.x * blockDim.x) {
-        FItem &it = fp.C[i];
-        FSearch &S = fp.S[it.q];
-        const int st = S.state;
-        if (!fs_live(st)) { it.flags |= FI_DEAD; continue; }
-        if (st == FS_WIDE && it.dir == 0) {                                 // (the clade below it: k_fr_replay_wide)
-            // Most such clades hold no finite score at all for this search.  What the scan does with one of those only
-            // depends on the state the walk arrives with: noted here, applied by the walk itself without a scan.
-            int fl = FI_SEED;
-            if (fin.mask && rowOf) {
-                const NodeRec r1s = T.nd[it.t1];
-                const SScan rec = T.scan[r1s.preRank];
-                const size_t row = (size_t)rowOf[it.q];
-                const unsigned long long *fm = fin.mask + row * fin.nWords;
-                const int32_t *fpx = fin.prefix + row * (fin.nWords + 1);
-                const int lo = T.candBefore[r1s.preRank], hi = T.candBefore[r1s.preRank + rec.size];
-                if (fin_count_before(fm, fpx, hi) == fin_count_before(fm, fpx, lo)) {
-                    const bool firstScored = !(r1s.up == S.parent || r1s.up < 0) && (r1s.dist > P.effNon0 || r1s.upIsRoot);
-                    const bool dropped = firstScored && !(rec.ff & SS_TOTUP);
-                    fl |= FI_SEED_EMPTY;
-                    it.hA = (firstScored && !dropped) ? 1 : 0;               // the clade's root counts as one placement
-                    it.hB = T.cladeVisits[r1s.preRank];                      // placements below it when it is descended into
-                    it.hMid = ((rec.ff & SS_INNER) && !dropped) ? 1 : 0;
+    for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < hi; i0 += (long long)gridDim.x * blockDim.x) {
+        const long long i = i0 + threadIdx.x;
+#ifdef MAPLE_SPR_PROFILE
+        const long long tp0 = wall_clock64();
+#endif
+        // ---- one lane per item: what to do with it (0 nothing more, 1 not scored: the rule and the pushes, 2 scored first)
+        int mode = 0;
+        FItem *itp = nullptr;
+        const FSearch *Sp = nullptr;
+        NodeRec r1{};
+        FList lp{nullptr, nullptr, 0, 0}, lr{nullptr, nullptr, 0, 0};
+        bool rt = false;
+        double rbl = 0.0;
+        if (i < hi) {
+            FItem &it = fp.C[i < nC ? loC + i : loR + (i - nC)];
+            FSearch &S = fp.S[it.q];
+            itp = &it; Sp = &S;
+            const int st = S.state;
+            if (!fs_live(st)) it.flags |= FI_DEAD;
+            else if (st == FS_WIDE && it.dir == 0) {                        // (the clade below it: k_fr_replay_wide)
+                // Most such clades hold no finite score at all for this search.  What the scan does with one of those only
+                // depends on the state the walk arrives with: noted here, applied by the walk itself without a scan.
+                int fl = FI_SEED;
+                if (fin.mask && rowOf) {
+                    const NodeRec r1s = T.nd[it.t1];
+                    const SScan rec = T.scan[r1s.preRank];
+                    const size_t row = (size_t)rowOf[it.q];
+                    const unsigned long long *fm = fin.mask + row * fin.nWords;
+                    const int32_t *fpx = fin.prefix + row * (fin.nWords + 1);
+                    const int clo = T.candBefore[r1s.preRank], chi = T.candBefore[r1s.preRank + rec.size];
+                    if (fin_count_before(fm, fpx, chi) == fin_count_before(fm, fpx, clo)) {
+                        const bool firstScored = !(r1s.up == S.parent || r1s.up < 0) && (r1s.dist > P.effNon0 || r1s.upIsRoot);
+                        const bool dropped = firstScored && !(rec.ff & SS_TOTUP);
+                        fl |= FI_SEED_EMPTY;
+                        it.hA = (firstScored && !dropped) ? 1 : 0;           // the clade's root counts as one placement
+                        it.hB = T.cladeVisits[r1s.preRank];                  // placements below it when it is descended into
+                        it.hMid = ((rec.ff & SS_INNER) && !dropped) ? 1 : 0;
+                    }
+                }
+                it.flags |= (uint8_t)fl;
+            } else {
+                r1 = T.nd[it.t1];
+                const int upT = r1.up;
+                const bool scored = (it.dir == 0) ? (!(upT == S.parent || upT < 0) && (r1.dist > P.effNon0 || r1.upIsRoot))
+                                                  : (upT >= 0 && (r1.dist > P.effNon0 || r1.upIsRoot));
+                mode = 1;
+                if (scored) {
+                    if (r1.totUp < 0) { it.flags |= FI_DEAD; mode = 0; }
+                    else {
+                        lp = flist(av, fp, ftree(r1.totUp)); lr = flist(av, fp, it.hRpr);
+                        rt = S.isRemovedTip != 0; rbl = S.removedBLen;
+                        mode = 2;
+                    }
                 }
             }
-            it.flags |= (uint8_t)fl;
-            continue;
         }
-        const int q = it.q, t1 = it.t1, hRpr = it.hRpr;
-        const NodeRec r1 = T.nd[t1];
-        const double lastLK = it.lastLK;
-        const int upT = r1.up;
-        double midProb = lastLK;
-        const bool scored = (it.dir == 0) ? (!(upT == S.parent || upT < 0) && (r1.dist > P.effNon0 || r1.upIsRoot))
-                                          : (upT >= 0 && (r1.dist > P.effNon0 || r1.upIsRoot));
-        if (scored) {
-            if (r1.totUp < 0) { it.flags |= FI_DEAD; continue; }
-            const FList lp = flist(av, fp, ftree(r1.totUp)), lr = flist(av, fp, hRpr);
-#ifdef MAPLE_FR_CACHED_GATHERED_WALK                                            // (measured: 40 % slower -- the walk is bound by the chain of
-            midProb = append_walk_gathered(c, fref(lp), fref(lr), S.isRemovedTip != 0, S.removedBLen);   // dependent loads, and gathering lengthens it)
-#else
-            midProb = append_walk(c, fref(lp), fref(lr), S.isRemovedTip != 0, S.removedBLen);
+#ifdef MAPLE_SPR_PROFILE
+        __builtin_amdgcn_s_waitcnt(0);
+        const long long tp1 = wall_clock64();
 #endif
-            it.flags |= FI_SCORED;
-            nSc++; bSc += 8ull * (unsigned long long)(lp.n + lp.na) + 8ull;
+        // ---- the score
+        double scoreV = 0.0;
+        if (mode == 2) scoreV = append_walk(c, fref(lp), fref(lr), rt, rbl);
+        const int nS = __popcll(__ballot(mode == 2));
+        (void)nS;
+#ifdef MAPLE_SPR_PROFILE
+        const long long tp2 = wall_clock64();
+#endif
+        // ---- one lane per item again: the rule (M:7090-7103 / 7311-7323 in its permissive form) and the pushes
+        if (mode != 0) {
+            FItem &it = *itp;
+            const FSearch &S = *Sp;
+            const int q = it.q, hRpr = it.hRpr, upT = r1.up;
+            const double lastLK = it.lastLK;
+            double midProb = lastLK;
+            const bool scored = mode == 2;
+            if (scored) {
+                midProb = scoreV;
+                it.flags |= FI_SCORED;
+                nSc++; bSc += 8ull * (unsigned long long)(lp.n + lp.na) + 8ull;
+            }
+            it.midProb = midProb;
+            const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
+            if (pr.go) {
+                // (a relative in another MAT reference frame gets the removed list through the branch at the start of its level: k_fr_pass)
+                const bool x0 = fp.mat && r1.c0Frame != r1.frameOf, x1 = fp.mat && r1.c1Frame != r1.frameOf, xu = fp.mat && r1.upFrame != r1.frameOf;
+                if (it.dir == 0) {
+                    if (r1.c0 >= 0) {
+                        if (r1.upRight >= 0) it.child0 = fpush(fp, budget, q, false, r1.c0, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, x0, true);
+                        if (r1.upLeft >= 0) it.child1 = fpush(fp, budget, q, false, r1.c1, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, x1, true);
+                    }
+                } else {
+                    const int other = (it.dir == 1) ? r1.c1 : r1.c0;
+                    const bool xo = (it.dir == 1) ? x1 : x0;
+                    if (upT >= 0) {
+                        if (((it.dir == 1) ? r1.upLeft : r1.upRight) >= 0) {
+                            it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, xo, true);
+                            it.child1 = fpush(fp, budget, q, false, upT, (int)r1.whichChild + 1, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, xu, true);
+                        }
+                    } else
+                        it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, xo, true);
+                }
+            }
+            (void)S;
         }
-        it.midProb = midProb;
-        const PRule pr = p_rule(P, scored, midProb, lastLK, it.failsP, it.pathBest);
-        if (!pr.go) continue;
-        // (a relative in another MAT reference frame gets the removed list through the branch at the start of its level: k_fr_pass)
-        const bool x0 = fp.mat && r1.c0Frame != r1.frameOf, x1 = fp.mat && r1.c1Frame != r1.frameOf, xu = fp.mat && r1.upFrame != r1.frameOf;
-        if (it.dir == 0) {
-            if (r1.c0 < 0) continue;
-            if (r1.upRight >= 0) it.child0 = fpush(fp, budget, q, false, r1.c0, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, x0);
-            if (r1.upLeft >= 0) it.child1 = fpush(fp, budget, q, false, r1.c1, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, x1);
-        } else {
-            const int other = (it.dir == 1) ? r1.c1 : r1.c0;
-            const bool xo = (it.dir == 1) ? x1 : x0;
-            if (upT >= 0) {
-                if (((it.dir == 1) ? r1.upLeft : r1.upRight) < 0) continue;
-                it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, xo);
-                it.child1 = fpush(fp, budget, q, false, upT, (int)r1.whichChild + 1, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, xu);
-            } else
-                it.child0 = fpush(fp, budget, q, false, other, 0, -1, 0.0, midProb, pr.fails, hRpr, pr.pathBest, xo);
+#ifdef MAPLE_SPR_PROFILE
+        {
+            __builtin_amdgcn_s_waitcnt(0);
+            const long long tp3 = wall_clock64();
+            int len = mode == 2 ? lp.n + lr.n : 0, tot = len;
+            for (int off = 32; off > 0; off >>= 1) { len = max(len, __shfl_down(len, off, 64)); tot += __shfl_down(tot, off, 64); }
+            if (lane == 0) {
+                atomicAdd(&fp.ctr->dbgC[0], 1ull); atomicAdd(&fp.ctr->dbgC[1], (unsigned long long)(tp1 - tp0));
+                atomicAdd(&fp.ctr->dbgC[2], (unsigned long long)(tp2 - tp1)); atomicAdd(&fp.ctr->dbgC[3], (unsigned long long)(tp3 - tp2));
+                atomicAdd(&fp.ctr->dbgC[4], (unsigned long long)len); atomicAdd(&fp.ctr->dbgC[5], (unsigned long long)nS);
+                atomicAdd(&fp.ctr->dbgC[6], (unsigned long long)tot);
+            }
         }
+#endif
     }
     // (what the launch scored, for the roofline of the bench line: one atomic per wavefront)
     for (int off = 32; off > 0; off >>= 1) {
@@ -325,14 +424,23 @@ __device__ __forceinline__ int fsize(const FPools &fp, int ref) { return ref == 
 
 // subtree sizes, one level at a time from the last to the first (a child is one level below its parent)
 // (sizes, ranks and parents live in arrays of their own: the passes read one 32-byte sector of an item and 4-byte neighbours)
-__global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_sizes(FPools fp, int level)
+// (which = 0: level `level` of the list-updating items; 1: launch `level` of the cached-regime items -- its two ranges.  A child of an
+// updating item is in the next updating level or in some cached launch; a child of a cached item is in a LATER cached launch:
+// bottom-up = the cached launches from the last to the first, then the updating levels from the last to the first)
+__device__ __forceinline__ void fr_layer(const FPools &fp, int level, int which, long long &lo1, long long &n1, long long &lo2, long long &n2)
 {
-    const long long loU = (long long)fp.lvl[6 * level], hiU = (long long)fp.lvl[6 * level + 1];
-    const long long loC = (long long)fp.lvl[6 * level + 2], hiC = (long long)fp.lvl[6 * level + 3];
-    const long long n = (hiU - loU) + (hiC - loC);
+    const unsigned long long *L = fp.lvl + (size_t)FR_LVL * level;
+    if (which == 0) { lo1 = (long long)L[0]; n1 = (long long)L[1] - lo1; lo2 = 0; n2 = 0; }
+    else { lo1 = (long long)L[2]; n1 = (long long)L[3] - lo1; lo2 = (long long)L[4]; n2 = (long long)L[5] - lo2; }
+}
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_sizes(FPools fp, int level, int which)
+{
+    long long lo1, n1, lo2, n2;
+    fr_layer(fp, level, which, lo1, n1, lo2, n2);
+    const long long n = n1 + n2;
+    const bool isU = which == 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const bool isU = i < hiU - loU;
-        const long long at = isU ? loU + i : loC + (i - (hiU - loU));
+        const long long at = i < n1 ? lo1 + i : lo2 + (i - n1);
         const FItem &it = isU ? fp.U[at] : fp.C[at];
         fp.lsize[isU ? at : fp.capU + at] = 1 + fsize(fp, it.child0) + fsize(fp, it.child1);
     }
@@ -375,14 +483,14 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_seeds(int n, FPools fp)
     }
 }
 // ranks of the children and the item's own record, one level at a time from the first to the last
-__global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_place(FPools fp, int level)
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_place(FPools fp, int level, int which)
 {
-    const long long loU = (long long)fp.lvl[6 * level], hiU = (long long)fp.lvl[6 * level + 1];
-    const long long loC = (long long)fp.lvl[6 * level + 2], hiC = (long long)fp.lvl[6 * level + 3];
-    const long long n = (hiU - loU) + (hiC - loC);
+    long long lo1, n1, lo2, n2;
+    fr_layer(fp, level, which, lo1, n1, lo2, n2);
+    const long long n = n1 + n2;
+    const bool isU = which == 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const bool isU = i < hiU - loU;
-        const long long at = isU ? loU + i : loC + (i - (hiU - loU));
+        const long long at = i < n1 ? lo1 + i : lo2 + (i - n1);
         const long long own = isU ? at : fp.capU + at;
         const int p = fp.lpos[own];
         if (p < 0) continue;                                                // (its search is not laid out)
@@ -647,7 +755,7 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
             if (!bad) {
                 base = atomicAdd(&fp.ctr->nRecs, (unsigned long long)cnt);
                 ibase = cntScan ? atomicAdd(&fp.ctr->usedC, (unsigned long long)cntScan) : 0ull;
-                if ((long long)(base + cnt) > fp.capRecs || (long long)(ibase + cntScan) > fp.capC) {
+                if ((long long)(base + cnt) > fp.capRecs || (long long)(ibase + cntScan) > fp.capCC) {
                     bad = 1; fp.ctr->overflow = 1;
                     for (long long k2 = (long long)base; k2 < min((long long)(base + cnt), fp.capRecs); k2++) { fp.recs[k2].q = q; fp.recs[k2].ref = FR_NONE; }
                 }
@@ -835,11 +943,11 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_finish(ArenaViewS av, DevTree T
 }
 
 // (query index, node) of every expanded item of the last call: a superset of what each search visited
-__global__ __launch_bounds__(FR_BLOCK) void k_fr_export(FPools fp, long long nU, long long nC, int32_t *outQ, int32_t *outNode)
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_export(FPools fp, long long nU, long long nC, long long nR, int32_t *outQ, int32_t *outNode)
 {
-    const long long n = nU + nC;
+    const long long n = nU + nC + nR;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const FItem &it = i < nU ? fp.U[i] : fp.C[i - nU];
+        const FItem &it = i < nU ? fp.U[i] : (i < nU + nC ? fp.C[i - nU] : fp.C[fp.capCC + (i - nU - nC)]);
         outQ[i] = it.q; outNode[i] = it.t1;
     }
 }
@@ -851,13 +959,15 @@ struct FrontierScratch {
     DevBuf<long long> toffW, toffA;
     DevBuf<int32_t> tn, tna, nodes, expQ, expNode;
     DevBuf<uint8_t> out, wideBr, tflag;
-    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, perm3, perm4, tot, lsize, lpos, lpar, passList;
+    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, perm3, perm4, tot, lsize, lpos, lpar, passList, passListR;
+    DevBuf<uint2> bw2; DevBuf<double> ba2;   // k_fr_pass's own shared scratch (it runs next to the updating levels)
     DevBuf<uint8_t> visit;
     DevBuf<unsigned long long> lvl;
     DevBuf<long long> vbase;
     std::vector<unsigned long long> lastLvl;        // [levels][4]: the level ranges of the last call (frontier_level_profile)
     std::vector<size_t> lastSlotsU, lastSlotsC;    // ... and the timing slots of its level kernels
-    long long lastU = -1, lastC = -1;     // items of the last call (for frontier_export), -1: none
+    long long lastU = -1, lastC = -1, lastR = 0;     // items of the last call (for frontier_export), -1: none
+    long long needR = 0;
     long long needU = 0, needC = 0, needL = 0, needW = 0, needA = 0, needM = 0;   // what the last call asked of the pools, and its searches
     bool lastOverflow = false;         // ... and whether one of them ran over
     FPools lastPools{};
@@ -877,7 +987,7 @@ void frontier_scratch_free(maple_ctx *c)
     F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
     F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
     F->expQ.release(); F->expNode.release();
-    F->perm.release(); F->perm2.release(); F->perm3.release(); F->perm4.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release(); F->passList.release(); F->tflag.release();
+    F->perm.release(); F->perm2.release(); F->perm3.release(); F->perm4.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release(); F->passList.release(); F->passListR.release(); F->bw2.release(); F->ba2.release(); F->tflag.release();
     if (F->evFork) (void)hipEventDestroy(F->evFork);
     if (F->evJoin) (void)hipEventDestroy(F->evJoin);
     if (F->evFork2) (void)hipEventDestroy(F->evFork2);
@@ -902,11 +1012,13 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t)8 << 30;
     const size_t held = F.itemsU.cap + F.itemsC.cap + F.tw.cap * sizeof(uint2) + F.ta.cap * sizeof(double)
-                        + F.sw.cap * sizeof(uint2) + F.sa.cap * sizeof(double) + F.sais.cap * sizeof(double) + F.bw.cap * 48;
+                        + F.sw.cap * sizeof(uint2) + F.sa.cap * sizeof(double) + F.sais.cap * sizeof(double) + F.bw.cap * 48 + F.bw2.cap * 48;
     const double room = 0.5 * (double)(freeB + held);
     const long long perSearchC = std::min<long long>(budget, 768);
     long long capC = std::max<long long>(1 << 16, std::max((long long)m * perSearchC, itemsHint));
     long long capU = std::max<long long>(1 << 14, (long long)m * std::min<long long>(budget, 16));
+    // (roots: the cached-regime items the list-updating items push -- the upper part of the cached pool)
+    long long capR = std::max<long long>(1 << 16, std::min(capC, (long long)m * std::min<long long>(budget, 32)));
     const long long meanEnt = std::max<long long>(16, c->h_n_ent.empty() ? 64 : c->used_ent / (long long)c->h_n_ent.size());   // entries per list in the arena
     long long capL = 2 * capU;
     long long capW = 2 * capL * meanEnt, capA = capW;
@@ -915,7 +1027,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         // first guess, and a pool that runs over hands its searches back
         // (after an overflow the asks themselves are too low -- the searches that were handed back stopped asking: twice, not 1.25 x)
         const double f = (F.lastOverflow ? 2.0 : 1.25) * (double)m / (double)F.needM;
-        capU = std::max(capU, (long long)(f * F.needU)); capC = std::max(capC, (long long)(f * F.needC));
+        capU = std::max(capU, (long long)(f * F.needU)); capC = std::max(capC, (long long)(f * F.needC)); capR = std::max(capR, (long long)(f * F.needR));
         capL = std::max(capL, (long long)(f * F.needL)); capW = std::max(capW, (long long)(f * F.needW)); capA = std::max(capA, (long long)(f * F.needA));
     }
     // per-lane scratch for lists of up to capE entries (two average lists merged, with room); the few longer ones -- near the
@@ -929,20 +1041,22 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     while (scratchLanes > 16384 && (double)(scratchLanes + extraSlabs) * capE * 64 > 0.25 * room) scratchLanes /= 2;
     const int gridUpd = (int)(scratchLanes / FR_BLOCK);
     const long long capBig = std::max<long long>(1 << 20, 64ll * 1024 * std::max(1, c->tree_max_ent));
+    const long long capBig2 = matTree ? std::max<long long>(1 << 20, capBig / 4) : 0;
     {   // shrink the pools proportionally if they would not fit
-        const double fixed = (double)(scratchLanes + extraSlabs) * capE * 64 + (double)capBig * 48;
-        const double need = (double)capC * (sizeof(FItem) + sizeof(FVisit) + 12) + (double)capU * (sizeof(FItem) + sizeof(FVisit) + 12) + (double)capW * 8 + (double)capA * 8
+        const double fixed = (double)(scratchLanes + extraSlabs) * capE * 64 + (double)(capBig + capBig2) * 48;
+        const double need = (double)(capC + capR) * (sizeof(FItem) + sizeof(FVisit) + 12) + (double)capU * (sizeof(FItem) + sizeof(FVisit) + 12) + (double)capW * 8 + (double)capA * 8
                             + (double)capL * 24 + fixed;
         if (need > room) {
             const double f = std::max(0.05, (room - fixed) / (need - fixed));
             capC = std::max<long long>(1 << 16, (long long)(capC * f)); capU = std::max<long long>(1 << 14, (long long)(capU * f));
+            capR = std::max<long long>(1 << 16, (long long)(capR * f));
             capL = 2 * capU; capW = 2 * capL * meanEnt; capA = capW;
         }
     }
     const long long capRecs = std::max<long long>(1 << 14, (long long)m * 16);
     auto grow = [](size_t want, size_t cap) { return want <= cap ? cap : std::max(want, cap + cap / 2); };
     HIPCK(c, F.itemsU.reserve_exact(grow((size_t)capU * sizeof(FItem), F.itemsU.cap)));
-    HIPCK(c, F.itemsC.reserve_exact(grow((size_t)capC * sizeof(FItem), F.itemsC.cap)));
+    HIPCK(c, F.itemsC.reserve_exact(grow((size_t)(capC + capR) * sizeof(FItem), F.itemsC.cap)));
     HIPCK(c, F.srch.reserve((size_t)m * sizeof(FSearch)));
     HIPCK(c, F.recs.reserve_exact(grow((size_t)capRecs * sizeof(FRec), F.recs.cap)));
     HIPCK(c, F.ctr.reserve(sizeof(FCtr)));
@@ -958,11 +1072,14 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, F.sais.reserve_exact((size_t)(scratchLanes + extraSlabs) * capE * 2));
     HIPCK(c, F.bw.reserve_exact((size_t)capBig));
     HIPCK(c, F.ba.reserve_exact((size_t)capBig * 5));
+    if (capBig2) { HIPCK(c, F.bw2.reserve_exact((size_t)capBig2)); HIPCK(c, F.ba2.reserve_exact((size_t)capBig2 * 5)); }
     HIPCK(c, F.nodes.reserve((size_t)m));
     HIPCK(c, F.out.reserve((size_t)m * sizeof(SearchOut)));
     FPools fp;
     fp.U = (FItem *)F.itemsU.p; fp.C = (FItem *)F.itemsC.p;
     fp.capU = (long long)(F.itemsU.cap / sizeof(FItem)); fp.capC = (long long)(F.itemsC.cap / sizeof(FItem));
+    // (a buffer kept from a larger call: both parts grow with it)
+    fp.capCC = fp.capC - std::max(capR, (long long)((double)fp.capC * capR / (double)(capC + capR)));
     fp.tw = F.tw.p; fp.ta = F.ta.p; fp.toffW = F.toffW.p; fp.toffA = F.toffA.p; fp.tn = F.tn.p; fp.tna = F.tna.p;
     fp.capW = (long long)F.tw.cap; fp.capA = (long long)F.ta.cap;
     fp.tflag = F.tflag.p;
@@ -984,21 +1101,23 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, F.lpar.reserve_exact(std::max(F.lpar.cap, (size_t)fp.capVisit)));
     }
     fp.lsize = F.lsize.p; fp.lpos = F.lpos.p; fp.lpar = F.lpar.p;
-    HIPCK(c, F.lvl.reserve((size_t)fp.maxLevels * 6));
+    HIPCK(c, F.lvl.reserve((size_t)fp.maxLevels * FR_LVL));
     HIPCK(c, F.tot.reserve((size_t)m));
     HIPCK(c, F.vbase.reserve((size_t)m + 1));
     fp.visit = layoutOK ? (FVisit *)F.visit.p : nullptr; fp.lvl = F.lvl.p; fp.tot = F.tot.p; fp.vbase = F.vbase.p;
     fp.sw = F.sw.p; fp.sa = F.sa.p; fp.sais = F.sais.p; fp.capE = capE;
-    fp.bw = F.bw.p; fp.ba = F.ba.p; fp.capBig = (long long)F.bw.cap;
+    fp.bw = F.bw.p; fp.ba = F.ba.p; fp.capBig = (long long)F.bw.cap; fp.bigSide = 0;
     fp.ctr = (FCtr *)F.ctr.p; fp.S = (FSearch *)F.srch.p; fp.recs = (FRec *)F.recs.p;
     fp.capRecs = (long long)(F.recs.cap / sizeof(FRec));
     // trees with MAT local references: the lists a search carries go through the reference branches it crosses
     fp.mat = c->tree_has_mut ? 1 : 0;
     fp.mv = mview(c);
-    fp.passList = nullptr; fp.capPass = 0;
+    fp.passList = nullptr; fp.capPass = 0; fp.passListR = nullptr; fp.capPassR = 0;
     if (fp.mat) {
         HIPCK(c, F.passList.reserve_exact(std::max(F.passList.cap, (size_t)std::max<long long>(1 << 16, fp.capC / 8))));
         fp.passList = F.passList.p; fp.capPass = (long long)F.passList.cap;
+        HIPCK(c, F.passListR.reserve_exact(std::max(F.passListR.cap, (size_t)std::max<long long>(1 << 16, (fp.capC - fp.capCC) / 4))));
+        fp.passListR = F.passListR.p; fp.capPassR = (long long)F.passListR.cap;
     }
     hipStream_t s = c->stream;
     const bool dbgSync = c->tuning.verbose > 2;                            // (MAPLE_DEBUG=3: every launch awaited and named)
@@ -1046,7 +1165,6 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     FR_DISPATCH3(c, k_fr_begin, <<<std::min(gridN, gridUpd), FR_BLOCK, 0, s>>>(c->d_model, av, T, P, m, F.nodes.p, fp, dout, budget, zeroBudget,
                                                             anyWide ? F.wideRow.p : nullptr, anyWide ? wide->forceWide : 0));
     HIPCK(c, hipGetLastError());
-    if (anyWide && wide->rowsReady) HIPCK(c, hipStreamWaitEvent(s, wide->rowsReady, 0));   // (k_fr_cached reads the rows' bitmaps)
     // level loop: the counters stay on the device; the host looks at them every few levels
     FCtr hc;
     std::memset(&hc, 0, sizeof hc);
@@ -1073,25 +1191,17 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, hipEventCreateWithFlags(&F.evJoin, hipEventDisableTiming));
     }
     const hipStream_t s2 = F.side;
-    auto level = [&]() -> int {                                            // the kernels of one level, each between its own events
-        hipEvent_t a0, a1, b0, b1;
-        HIPCK(c, hipEventRecord(F.evFork, s));                             // (after the level's snap)
-        HIPCK(c, hipStreamWaitEvent(s2, F.evFork, 0));
-        TRY(maple_internal_ev_pair(c, &b0, &b1, MAPLE_K_FR_CACHED, 0.0, 0.0));
-        slotsC.push_back(c->ev_used / 2 - 1);
-        HIPCK(c, hipEventRecord(b0, s2));
-        if (fp.mat) {
-            // the removed lists of the cached-regime items that crossed a reference branch: on the cached kernel's stream, ahead of
-            // it (only that kernel reads them), next to the level's updating items
-            FR_DISPATCH3(c, k_fr_pass, <<<256, FR_BLOCK, 0, s2>>>(c->d_model, av, T, fp, scratchLanes + 2048));
-            TRY(stage("k_fr_pass"));
-        }
-        FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s2>>>(c->d_model, av, anyWide ? Tw : T, P, fp, budget,
-                                                                        anyWide ? F.wideRow.p : nullptr,
-                                                                        anyWide ? wide->fin : FiniteRows{nullptr, nullptr, 0}));
-        HIPCK(c, hipEventRecord(b1, s2));
-        HIPCK(c, hipEventRecord(F.evJoin, s2));
-        TRY(stage("k_fr_cached"));
+    // The two kinds of items run on two streams that never wait for each other inside the expansion: the list-updating levels
+    // on the context's stream -- a chain of ~20 levels, each as long as its slowest item -- and the cached-regime launches on the
+    // side stream, each taking whatever was complete when it started (k_fr_snap_c).  A cached launch is queued behind every
+    // updating level's publication (two per level: the cached subtrees are deeper than the updating chain is long), the rest
+    // follow when the updating items are done.  (Round 4 joined the streams after every level: sum over levels of
+    // max(updating, cached) instead of the longer of the two sums.)
+    FPools fpC = fp;                                                       // (k_fr_pass: its own shared scratch and counter)
+    fpC.bw = F.bw2.p; fpC.ba = F.ba2.p; fpC.capBig = (long long)F.bw2.cap; fpC.bigSide = 1;
+    int launchesC = 0;
+    auto u_level = [&]() -> int {                                          // the kernels of the open level, between events of their own
+        hipEvent_t a0, a1;
         TRY(maple_internal_ev_pair(c, &a0, &a1, MAPLE_K_FR_UPDATING, 0.0, 0.0));
         slotsU.push_back(c->ev_used / 2 - 1);
         HIPCK(c, hipEventRecord(a0, s));
@@ -1108,29 +1218,66 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         }
         TRY(stage("k_fr_updating_wave"));
         HIPCK(c, hipEventRecord(a1, s));
-        HIPCK(c, hipStreamWaitEvent(s, F.evJoin, 0));
+        // the next level is opened, and what this one pushed into the cached pool is published
+        k_fr_snap_u<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC - fp.capCC, fp.capPassR, fp.lvl, fp.maxLevels);
+        HIPCK(c, hipEventRecord(F.evFork, s));
+        HIPCK(c, hipStreamWaitEvent(s2, F.evFork, 0));
         levels++;
+        return MAPLE_OK;
+    };
+    auto c_launch = [&]() -> int {
+        hipEvent_t b0, b1;
+        TRY(maple_internal_ev_pair(c, &b0, &b1, MAPLE_K_FR_CACHED, 0.0, 0.0));
+        slotsC.push_back(c->ev_used / 2 - 1);
+        k_fr_snap_c<<<1, 64, 0, s2>>>(fp.ctr, fp.capCC, fp.capPass, fp.lvl, fp.maxLevels);
+        HIPCK(c, hipEventRecord(b0, s2));
+        if (fp.mat) {
+            // the removed lists of the launch's items that crossed a reference branch, ahead of the kernel that reads them
+            FR_DISPATCH3(c, k_fr_pass, <<<256, FR_BLOCK, 0, s2>>>(c->d_model, av, T, fpC, scratchLanes + 2048));
+            TRY(stage("k_fr_pass"));
+        }
+        FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s2>>>(c->d_model, av, anyWide ? Tw : T, P, fp, budget,
+                                                                        anyWide ? F.wideRow.p : nullptr,
+                                                                        anyWide ? wide->fin : FiniteRows{nullptr, nullptr, 0}));
+        HIPCK(c, hipEventRecord(b1, s2));
+        TRY(stage("k_fr_cached"));
+        launchesC++;
         return MAPLE_OK;
     };
     // (an error inside the loop leaves nothing in flight on either stream behind it)
     auto bail = [&](int rc) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(s2); return rc; };
+    // the first level is opened (the seeds of k_fr_begin) and the cached stream let go
+    k_fr_snap_u<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC - fp.capCC, fp.capPassR, fp.lvl, fp.maxLevels);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(F.evFork, s) != hipSuccess || hipStreamWaitEvent(s2, F.evFork, 0) != hipSuccess
+        || (anyWide && wide->rowsReady && hipStreamWaitEvent(s2, wide->rowsReady, 0) != hipSuccess))   // (k_fr_cached reads the rows' bitmaps)
+        return bail(fail(c, MAPLE_ERR_HIP, "frontier level loop: HIP error"));
     // the host looks at the counters every few levels: a handful of searches (the re-search of a proposed move) is over after a few
-    // levels and each look costs them less than the levels it saves; a whole round runs ~40
+    // levels and each look costs them less than the levels it saves; a whole round runs ~20 updating levels
     const int groupLevels = m <= 64 ? 2 : 8;
     for (;;) {
         for (int g = 0; g < groupLevels; g++) {
-            k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC, fp.lvl, fp.maxLevels, fp.capPass);
-            { const int rc_ = level(); if (rc_) return bail(rc_); }
+            { const int rc_ = u_level(); if (rc_) return bail(rc_); }
+            for (int k2 = 0; k2 < 2; k2++) { const int rc_ = c_launch(); if (rc_) return bail(rc_); }
         }
-        k_fr_snap<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC, fp.lvl, fp.maxLevels, fp.capPass);
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&hc, fp.ctr, sizeof(FCtr), hipMemcpyDeviceToHost, s) != hipSuccess
             || hipStreamSynchronize(s) != hipSuccess)
             return bail(fail(c, MAPLE_ERR_HIP, "frontier level loop: HIP error"));
-        if (hc.hiU == hc.loU && hc.hiC == hc.loC) break;
-        // (the snap above opened the next level: the loop's first snap would skip it -- undo by running its kernels first)
-        { const int rc_ = level(); if (rc_) return bail(rc_); }
+        if (hc.hiU == hc.loU) break;                                       // (the level that was just opened is empty)
         if (levels > 100000) return bail(fail(c, MAPLE_ERR_FATAL, "frontier search did not terminate"));
     }
+    // the cached-regime items that are left: launches until one has found nothing new behind its snapshot
+    for (;;) {
+        for (int g = 0; g < groupLevels; g++) { const int rc_ = c_launch(); if (rc_) return bail(rc_); }
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&hc, fp.ctr, sizeof(FCtr), hipMemcpyDeviceToHost, s2) != hipSuccess
+            || hipStreamSynchronize(s2) != hipSuccess)
+            return bail(fail(c, MAPLE_ERR_HIP, "frontier level loop: HIP error"));
+        const unsigned long long haveC = std::min<unsigned long long>(hc.usedC, (unsigned long long)fp.capCC),
+                                 haveR = std::min<unsigned long long>(hc.usedR, (unsigned long long)(fp.capC - fp.capCC));
+        if (hc.hiC == haveC && hc.hiR == haveR) break;
+        if (launchesC > 200000) return bail(fail(c, MAPLE_ERR_FATAL, "frontier search did not terminate"));
+    }
+    if (hipEventRecord(F.evJoin, s2) != hipSuccess || hipStreamWaitEvent(s, F.evJoin, 0) != hipSuccess)
+        return bail(fail(c, MAPLE_ERR_HIP, "frontier level loop: HIP error"));
     size_t slotWide = (size_t)-1;
     // (replay, refinement, final selection: an error in here must not return with kernels still in flight on either stream --
     // the caller may reuse or free the pools -- so the stage is a lambda and its status goes through bail() like the loop's)
@@ -1155,14 +1302,16 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     }
     TRY(maple_internal_ev_pair(c, &er0, &er1, MAPLE_K_FR_REPLAY, (double)m, 0.0));
     HIPCK(c, hipEventRecord(er0, s));
-    if (levels <= fp.maxLevels && fp.visit) {
+    if (levels <= fp.maxLevels && launchesC <= fp.maxLevels && fp.visit) {
         // the items of every search in the order its walk visits them: sizes bottom-up, ranks top-down, one record each
         HIPCK(c, hipMemsetAsync(fp.lpos, 0xFF, (size_t)fp.capVisit * sizeof(int32_t), s));   // (-1: not laid out)
-        for (int l = levels - 1; l >= 0; l--) k_fr_layout_sizes<<<1024, FR_BLOCK, 0, s>>>(fp, l);
+        for (int l = launchesC - 1; l >= 0; l--) k_fr_layout_sizes<<<1024, FR_BLOCK, 0, s>>>(fp, l, 1);
+        for (int l = levels - 1; l >= 0; l--) k_fr_layout_sizes<<<1024, FR_BLOCK, 0, s>>>(fp, l, 0);
         k_fr_layout_totals<<<gridN, FR_BLOCK, 0, s>>>(m, fp);
         k_fr_layout_scan<<<1, 1024, 0, s>>>(m, fp.tot, fp.vbase);
         k_fr_layout_seeds<<<gridN, FR_BLOCK, 0, s>>>(m, fp);
-        for (int l = 0; l < levels; l++) k_fr_layout_place<<<1024, FR_BLOCK, 0, s>>>(fp, l);
+        for (int l = 0; l < levels; l++) k_fr_layout_place<<<1024, FR_BLOCK, 0, s>>>(fp, l, 0);
+        for (int l = 0; l < launchesC; l++) k_fr_layout_place<<<1024, FR_BLOCK, 0, s>>>(fp, l, 1);
         HIPCK(c, hipGetLastError());
         TRY(stage("k_fr_layout"));
     } else fp.visit = nullptr;
@@ -1214,6 +1363,18 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
             if (hc.dbgCnt[b]) fprintf(stderr, "[maple] one-lane updating items, lists of %s entries: %llu items, mean %.3f ms, slowest %.3f ms\n", nm[b],
                                       hc.dbgCnt[b], hc.dbgT[b] * 1e-5 / hc.dbgCnt[b], hc.dbgMax[b] * 1e-5);
     }
+    if (hc.dbgC[0])
+        fprintf(stderr, "[maple] k_fr_cached, per wavefront-iteration (%llu of them, %.1f scored items each): %.2f us before the scores (item, search, node, "
+                        "list table), %.2f us in the scores (%.1f entries per scored item in its two lists, the longest of an iteration %.1f), %.2f us "
+                        "after them (rule, pushes)\n",
+                hc.dbgC[0], (double)hc.dbgC[5] / hc.dbgC[0], hc.dbgC[1] * 1e-2 / hc.dbgC[0], hc.dbgC[2] * 1e-2 / hc.dbgC[0],
+                (double)hc.dbgC[6] / std::max(1.0, (double)hc.dbgC[5]), (double)hc.dbgC[4] / hc.dbgC[0], hc.dbgC[3] * 1e-2 / hc.dbgC[0]);
+    {
+        const char *nm[4] = {"small class", "512 class", "small class, one lane (a list does not fit)", "512 class, one lane (a list does not fit)"};
+        for (int b = 0; b < 4; b++)
+            if (hc.dbgWCnt[b]) fprintf(stderr, "[maple] wavefront-wide updating items, %s: %llu items, mean %.3f ms, slowest %.3f ms\n", nm[b],
+                                       hc.dbgWCnt[b], hc.dbgWT[b] * 1e-5 / hc.dbgWCnt[b], hc.dbgWMax[b] * 1e-5);
+    }
     if (anyWide) {
         double tw = 0, ts = 0, mw = 0, ms = 0; long long ns = 0, mxn = 0;
         for (int k : wideIdx) {
@@ -1225,19 +1386,26 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     }
 #endif
     if (!(anyWide && wide->forceWide)) {                                  // (a batch of whole-tree searches only says nothing about the next full one)
-        F.needU = (long long)hc.usedU; F.needC = (long long)hc.usedC; F.needL = (long long)hc.nLists; F.needW = (long long)hc.usedW;
+        F.needU = (long long)hc.usedU; F.needC = (long long)hc.usedC; F.needR = (long long)hc.usedR; F.needL = (long long)hc.nLists; F.needW = (long long)hc.usedW;
         F.needA = (long long)hc.usedA; F.needM = m; F.lastOverflow = hc.overflow != 0;
     }
-    F.lastU = std::min((long long)hc.usedU, fp.capU); F.lastC = std::min((long long)hc.usedC, fp.capC); F.lastPools = fp;
+    F.lastU = std::min((long long)hc.usedU, fp.capU); F.lastC = std::min((long long)hc.usedC, fp.capCC);
+    F.lastR = std::min((long long)hc.usedR, fp.capC - fp.capCC); F.lastPools = fp;
     {
-        const int nl = std::min(levels, fp.maxLevels);
-        F.lastLvl.assign((size_t)nl * 6, 0ull);
-        if (nl) HIPCK(c, hipMemcpy(F.lastLvl.data(), fp.lvl, (size_t)nl * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        const int nl = std::min(std::max(levels, launchesC), fp.maxLevels);
+        F.lastLvl.assign((size_t)nl * FR_LVL, 0ull);
+        if (nl) HIPCK(c, hipMemcpy(F.lastLvl.data(), fp.lvl, (size_t)nl * FR_LVL * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        // (rows beyond what a stream ran hold an earlier call's numbers: zeroed)
+        for (int l = 0; l < nl; l++) {
+            unsigned long long *L = F.lastLvl.data() + (size_t)FR_LVL * l;
+            if (l >= levels) L[0] = L[1] = L[6] = L[7] = 0;
+            if (l >= launchesC) L[2] = L[3] = L[4] = L[5] = 0;
+        }
         F.lastSlotsU = slotsU; F.lastSlotsC = slotsC;
     }
     if (hc.overflow) F.lastU = F.lastC = -1;                              // (a pool overflowed: the item lists are not complete)
     if (stats) {
-        stats->levels = levels; stats->itemsUpdating = (long long)hc.usedU; stats->itemsCached = (long long)hc.usedC;
+        stats->levels = levels; stats->itemsUpdating = (long long)hc.usedU; stats->itemsCached = (long long)(hc.usedC + hc.usedR);
         stats->tempLists = (long long)hc.nLists; stats->tempWords = (long long)hc.usedW; stats->tempAux = (long long)hc.usedA;
         stats->records = (long long)hc.nRecs; stats->overflow = hc.overflow;
     }
@@ -1250,13 +1418,13 @@ int frontier_export(maple_ctx *c, long long cap, int32_t *q, int32_t *node, long
 {
     FrontierScratch *F = (FrontierScratch *)c->frontier;
     if (!F || F->lastU < 0) return fail(c, MAPLE_ERR_STATE, "no complete frontier search to export");
-    const long long tot = F->lastU + F->lastC;
+    const long long tot = F->lastU + F->lastC + F->lastR;
     *n = tot;
     if (tot > cap) return fail(c, MAPLE_ERR_ARG, "%lld expanded items do not fit in %lld", tot, cap);
     if (tot == 0) return MAPLE_OK;
     HIPCK(c, F->expQ.reserve((size_t)tot));
     HIPCK(c, F->expNode.reserve((size_t)tot));
-    k_fr_export<<<(int)std::min<long long>(1024, (tot + FR_BLOCK - 1) / FR_BLOCK), FR_BLOCK, 0, c->stream>>>(F->lastPools, F->lastU, F->lastC,
+    k_fr_export<<<(int)std::min<long long>(1024, (tot + FR_BLOCK - 1) / FR_BLOCK), FR_BLOCK, 0, c->stream>>>(F->lastPools, F->lastU, F->lastC, F->lastR,
                                                                                                           F->expQ.p, F->expNode.p);
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(q, F->expQ.p, (size_t)tot * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1271,15 +1439,16 @@ int frontier_level_profile(maple_ctx *c, int cap, long long *itemsU, long long *
 {
     FrontierScratch *F = (FrontierScratch *)c->frontier;
     if (!F) return fail(c, MAPLE_ERR_STATE, "no frontier search to report on");
-    const int nl = (int)std::min<size_t>(F->lastLvl.size() / 6, std::min(F->lastSlotsU.size(), F->lastSlotsC.size()));
+    const int nl = (int)(F->lastLvl.size() / FR_LVL);
     *n = nl;
     for (int l = 0; l < nl && l < cap; l++) {
-        itemsU[l] = (long long)(F->lastLvl[6 * l + 1] - F->lastLvl[6 * l]);
-        itemsC[l] = (long long)(F->lastLvl[6 * l + 3] - F->lastLvl[6 * l + 2]);
-        if (waveSmall) waveSmall[l] = (long long)F->lastLvl[6 * l + 4];
-        if (waveBig) waveBig[l] = (long long)F->lastLvl[6 * l + 5];
+        const unsigned long long *L = F->lastLvl.data() + (size_t)FR_LVL * l;
+        itemsU[l] = (long long)(L[1] - L[0]);
+        itemsC[l] = (long long)(L[3] - L[2]) + (long long)(L[5] - L[4]);
+        if (waveSmall) waveSmall[l] = (long long)L[6];
+        if (waveBig) waveBig[l] = (long long)L[7];
         msU[l] = msC[l] = 0.f;
-        const size_t su = F->lastSlotsU[l], sc = F->lastSlotsC[l];
+        const size_t su = l < (int)F->lastSlotsU.size() ? F->lastSlotsU[l] : (size_t)-1 / 4, sc = l < (int)F->lastSlotsC.size() ? F->lastSlotsC[l] : (size_t)-1 / 4;
         if (2 * su + 1 < c->ev_used) { HIPCK(c, hipEventSynchronize(c->evs[2 * su + 1])); HIPCK(c, hipEventElapsedTime(&msU[l], c->evs[2 * su], c->evs[2 * su + 1])); }
         if (2 * sc + 1 < c->ev_used) { HIPCK(c, hipEventSynchronize(c->evs[2 * sc + 1])); HIPCK(c, hipEventElapsedTime(&msC[l], c->evs[2 * sc], c->evs[2 * sc + 1])); }
     }

@@ -78,9 +78,19 @@ struct FRec { int32_t q, ref; double optimized, top, bottom, app; int32_t ok, pa
 struct FCtr {                          // device-side bookkeeping of the level loop
     // (what every lane READS at the start of a kernel, and each counter the lanes bump, on cache lines of their own)
     alignas(128) unsigned long long loU;
-    unsigned long long hiU, loC, hiC;  // the current level
-    alignas(128) unsigned long long usedU;   // items allocated in the two pools
+    unsigned long long hiU;            // the current level of the items that still update lists (the stream of k_fr_updating*)
+    // The cached-regime items run on a stream of their own, one launch after the other, never waited for by the updating levels:
+    // a launch takes what was COMPLETE when it started -- the items earlier cached launches pushed (lower part of the pool:
+    // loC .. hiC) and the "roots" pushed by the updating levels that have finished (upper part: loR .. hiR <= safeR).
+    alignas(128) unsigned long long loC;
+    unsigned long long hiC, loR, hiR, loPR, hiPR;
+    alignas(128) unsigned long long safeR;    // roots / their pass entries pushed by kernels that have finished (published by k_fr_snap_u)
+    unsigned long long safePassR;
+    alignas(128) unsigned long long usedU;   // items allocated in the pools
     alignas(128) unsigned long long usedC;
+    alignas(128) unsigned long long usedR;
+    alignas(128) unsigned long long nPassR;       // roots pushed across a MAT reference branch (passListR)
+    alignas(128) unsigned long long bigUsedC;     // shared scratch of k_fr_pass (reset by every cached launch)
     alignas(128) unsigned long long permDown;     // the level's one-lane updating items by direction (k_fr_sort_level)
     alignas(128) unsigned long long permUp;
     alignas(128) unsigned long long permDownB;    // ... those with long lists (16 to a wavefront)
@@ -98,15 +108,19 @@ struct FCtr {                          // device-side bookkeeping of the level l
     unsigned long long bytesU;         // items k_fr_updating walked and the bytes of the lists their mergeVectors read and wrote
     alignas(128) unsigned long long scoredC;
     unsigned long long bytesC;         // cached-regime items scored by k_fr_cached and their SURVEY 8d bytes (8 E + 8 A + 8)
-    int32_t overflow, nLevels;
+    int32_t overflow, nLevels, nLevelsC;
 #ifdef MAPLE_SPR_PROFILE
     unsigned long long dbgCnt[8], dbgT[8], dbgMax[8];   // k_fr_updating's one-lane items by size (entries of the two lists): count, ticks, slowest
+    unsigned long long dbgC[8];        // k_fr_cached per wavefront-iteration: iterations, ticks before the walk (item, search, node, list table),
+                                       // ticks of the walk, ticks after it (rule, pushes), the longest lane's entries (two lists), scored lanes
+    unsigned long long dbgWCnt[4], dbgWT[4], dbgWMax[4]; // the wavefront-wide items: small class, 512 class, walked by lane 0 alone (small / 512)
 #endif
 };
 
 struct FPools {
     FItem *U, *C;
     long long capU, capC;
+    long long capCC;                   // the cached pool's lower part [0, capCC): items pushed by cached-regime items; [capCC, capC): roots
     // temporary lists
     uint2 *tw; double *ta;
     long long *toffW, *toffA;
@@ -128,6 +142,7 @@ struct FPools {
     int32_t capE;                      // entries one lane's scratch list takes (aux: 5 per entry; ais: 2 per entry)
     uint2 *bw; double *ba;             // shared scratch for the few lists longer than that (bump-allocated, reset every level)
     long long capBig;
+    int32_t bigSide;                   // 0: the updating levels' region and counter; 1: k_fr_pass's own (it runs next to them)
     FCtr *ctr;
     FSearch *S;
     FRec *recs;
@@ -138,6 +153,7 @@ struct FPools {
     int32_t mat;                       // 1: the tree has reference nodes
     MutViewS mv;
     int32_t *passList; long long capPass;   // refs of the cached-pool items whose removed list is re-expressed at the start of their level
+    int32_t *passListR; long long capPassR; // ... of the roots among them
 };
 
 __device__ __forceinline__ FItem &item_of(const FPools &fp, int ref) { return ref >= 0 ? fp.C[ref] : fp.U[-(ref + 2)]; }
@@ -160,7 +176,7 @@ struct FScr { uint2 *w; double *a; };
 __device__ inline bool fscratch(const FPools &fp, long long laneId, int need, FScr &o)
 {
     if (need <= fp.capE) { o.w = fp.sw + laneId * fp.capE; o.a = fp.sa + laneId * 5ll * fp.capE; return true; }
-    const unsigned long long off = atomicAdd(&fp.ctr->bigUsed, (unsigned long long)need);
+    const unsigned long long off = atomicAdd(fp.bigSide ? &fp.ctr->bigUsedC : &fp.ctr->bigUsed, (unsigned long long)need);
     if ((long long)(off + need) > fp.capBig) return false;
     o.w = fp.bw + off; o.a = fp.ba + 5ull * off;
     return true;
@@ -265,14 +281,16 @@ __device__ __forceinline__ bool frpr_marked(const FPools &fp, const FSearch &S, 
 // is full (the search is handed back)
 __device__ inline int fpush(const FPools &fp, const int budget, const int q, const bool upd, const int t1, const int dir,
                             const int hPassed, const double distance, const double lastLK, const int fails, const int hRpr,
-                            const double pathBest, const bool needPass = false)
+                            const double pathBest, const bool needPass = false, const bool fromC = false)
 {
     FSearch &S = fp.S[q];
     if (S.state != FS_WIDE && atomicAdd(&S.nItems, 1) >= budget) { S.state = FS_OVER; return FR_NONE; }
     FItem *it;
     int ref;
     // one atomic per wavefront and pool: the lanes that are here together take consecutive items
-    unsigned long long *ctrp = upd ? &fp.ctr->usedU : &fp.ctr->usedC;
+    // (fromC: the pusher is a cached-regime item -- the lower part of the cached pool; everybody else's cached-regime pushes are
+    // roots: the upper part.  Uniform over a kernel.)
+    unsigned long long *ctrp = upd ? &fp.ctr->usedU : (fromC ? &fp.ctr->usedC : &fp.ctr->usedR);
     const unsigned long long act = __ballot(1);
     const int lane = threadIdx.x & 63, leader = (int)__ffsll((long long)act) - 1;
     const unsigned long long same = __ballot(upd);                           // (lanes pushing into the updating pool)
@@ -286,9 +304,12 @@ __device__ inline int fpush(const FPools &fp, const int budget, const int q, con
     if (upd) {
         if ((long long)i >= fp.capU) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; return FR_NONE; }
         it = &fp.U[i]; ref = -((int)i + 2);
-    } else {
-        if ((long long)i >= fp.capC) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; return FR_NONE; }
+    } else if (fromC) {
+        if ((long long)i >= fp.capCC) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; return FR_NONE; }
         it = &fp.C[i]; ref = (int)i;
+    } else {
+        if ((long long)i >= fp.capC - fp.capCC) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; return FR_NONE; }
+        it = &fp.C[fp.capCC + i]; ref = (int)(fp.capCC + i);
     }
     it->q = q; it->t1 = t1; it->dir = (int8_t)dir; it->flags = upd ? FI_UPD_IN : 0; it->failsP = (int16_t)fails;
     it->hPassed = hPassed; it->hRpr = hRpr; it->distance = distance; it->lastLK = lastLK; it->pathBest = pathBest;
@@ -296,9 +317,9 @@ __device__ inline int fpush(const FPools &fp, const int budget, const int q, con
     it->midProb = lastLK; it->recDist = 0.0;
     if (needPass) {                                                         // (rare: ~1 push in 100 crosses a reference branch)
         it->flags |= FI_NEEDPASS;
-        const unsigned long long k = atomicAdd(&fp.ctr->nPass, 1ull);
-        if ((long long)k >= fp.capPass) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; }
-        else fp.passList[k] = ref;
+        const unsigned long long k = atomicAdd(fromC ? &fp.ctr->nPass : &fp.ctr->nPassR, 1ull);
+        if ((long long)k >= (fromC ? fp.capPass : fp.capPassR)) { S.state = FS_FALLBACK; fp.ctr->overflow = 1; }
+        else (fromC ? fp.passList : fp.passListR)[k] = ref;
     }
     return ref;
 }
@@ -338,25 +359,30 @@ __device__ __forceinline__ bool fr_upd_heavy(const ArenaViewS &av, const DevTree
     return heavyMin > 0 && it.dir != 3 && fr_upd_size(av, T, fp, it) >= heavyMin;
 }
 // Does a wavefront-wide walk with staging areas for input lists of wuIn entries (and capW entries for appendProbNode's two
-// lists) take this item?  Every list the item touches must fit; an item next to a MAT reference branch re-expresses lists on
-// the way and is walked by one lane.
+// lists) take this item?  Every list the item touches must fit, with room for what a pass through a MAT reference branch adds.
 __device__ inline bool fr_wave_fits(const ArenaViewS &av, const DevTree &T, const FPools &fp, const FItem &it, const int wuIn, const int capW)
 {
     const int dir = it.dir;
     if (dir == 3 || !fvalid(it.hPassed)) return false;
     const NodeRec r1 = T.nd[it.t1];
-    if (fp.mat && (r1.c0Frame != r1.frameOf || r1.c1Frame != r1.frameOf || r1.upFrame != r1.frameOf)) return false;
     const int nP = it.hPassed >= 0 ? fp.tn[it.hPassed] : av.n_ent[-it.hPassed - 10];
     const int nR = it.hRpr >= 0 ? fp.tn[it.hRpr] : av.n_ent[-it.hRpr - 10];
     if (nP > wuIn || nR > capW) return false;
     const int other = dir == 0 ? -1 : (dir == 1 ? r1.c1 : r1.c0);
     const int upT = r1.up;
+    // (next to a MAT reference branch a list is re-expressed before it is staged: passGenomeListThroughBranch adds at most two
+    // entries per mutation of the branch)
+    const bool mat = fp.mat && (r1.c0Frame != r1.frameOf || r1.c1Frame != r1.frameOf || r1.upFrame != r1.frameOf);
+    auto grow = [&](int mutId) { return (mat && mutId >= 0) ? 2 * fp.mv.cnt[mutId] : 0; };
+    const int g0 = (dir == 0 && r1.c0 >= 0) ? grow(T.nd[r1.c0].mutId) : 0, g1 = (dir == 0 && r1.c1 >= 0) ? grow(T.nd[r1.c1].mutId) : 0;
+    const int gO = other >= 0 ? grow(T.nd[other].mutId) : 0, gU = (dir != 0 && upT >= 0) ? grow(r1.mutId) : 0;
     const int ids[6] = {r1.lower, r1.totUp, dir == 0 && r1.c0 >= 0 ? T.nd[r1.c0].lower : -1, dir == 0 && r1.c1 >= 0 ? T.nd[r1.c1].lower : -1,
                         other >= 0 ? T.nd[other].lower : -1,
                         (dir != 0 && upT >= 0) ? (r1.whichChild ? T.nd[upT].upLeft : T.nd[upT].upRight) : -1};
-    for (int k = 0; k < 6; k++) if (ids[k] >= 0 && av.n_ent[ids[k]] > wuIn) return false;
+    const int add[6] = {0, 0, g0, g1, gO, gU};
+    for (int k = 0; k < 6; k++) if (ids[k] >= 0 && av.n_ent[ids[k]] + add[k] > wuIn) return false;
     // (crawling up, the merged lower list is an input of the next merge)
-    if (dir != 0 && ids[4] >= 0 && nP + av.n_ent[ids[4]] > wuIn) return false;
+    if (dir != 0 && ids[4] >= 0 && nP + av.n_ent[ids[4]] + gO > wuIn) return false;
     return true;
 }
 #define FR_WAVE_SMALL_IN 128           // the small class of the wavefront-wide items: staging for 128-entry lists (27 KB of LDS per
