@@ -325,7 +325,7 @@ class BenchTree:
     """What build_bench_tree leaves behind: the device, the tree and what it took to make it."""
 
 
-def build_bench_tree(samples, model, *, device=0, tree="optimised", refs="auto", synth="auto", big_arena=False):
+def build_bench_tree(samples, model, *, device=0, tree="optimised", refs="auto", synth="auto", big_arena=False, debug_library=False):
     """The tree the bench steps search (tests/test_hip_configs.py builds the same one): synthetic samples, genome
     lists built on the GPU, branch lengths optimised as MAPLE does before its SPR rounds (tree="optimised"), MAT local
     references added (refs="local" / "auto"), uploaded for the searches."""
@@ -344,7 +344,8 @@ def build_bench_tree(samples, model, *, device=0, tree="optimised", refs="auto",
     # with local references are the big temporary)
     # (the tree's own lists take ~10 KB per sample; the sub-block with local references needs the large arena)
     per_sample = (320 << 10) if big_arena else (64 << 10)
-    dev = Device(ref_idx, root_freqs, device=device, arena_bytes=min(128 << 30, max(4 << 30, samples * per_sample)))
+    # (debug_library: libmaple_hip_debug.so, for tools that read the level profile -- never the bench itself)
+    dev = Device(ref_idx, root_freqs, device=device, arena_bytes=min(128 << 30, max(4 << 30, samples * per_sample)), debug=debug_library)
     mkw = model_kwargs(model, len(ref_idx))
     dev.set_model(**mkw)
     tip_kw = dict(error_rates=mkw["errorRates"]) if model == "siteerr" else {}

@@ -3,6 +3,9 @@
 // frontier.hip (the frontier tier of the SPR search).
 #pragma once
 #include "../../include/maple_hip.h"
+#ifdef MAPLE_DEBUG_ABI
+#include "../../include/maple_hip_debug.h"
+#endif
 #include "genome_dev.h"
 #include "search_dev.h"
 #include "placement_dev.h"

@@ -31,6 +31,8 @@
 #include "ctx_host.h"
 #include "frontier_dev.h"
 
+#include <chrono>
+
 using namespace frt;
 
 namespace {
@@ -1008,6 +1010,9 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     if (!c->frontier) c->frontier = new FrontierScratch();
     FrontierScratch &F = *(FrontierScratch *)c->frontier;
     if (budget < 1) budget = 1 << 30;
+    const auto tEnter = std::chrono::steady_clock::now();
+    auto sinceEnter = [&] { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tEnter).count() * 1e-3; };
+    const bool dbgTime = c->tuning.verbose != 0;
     // pools, sized for the batch and bounded by what the device has free
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t)8 << 30;
@@ -1119,6 +1124,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, F.passListR.reserve_exact(std::max(F.passListR.cap, (size_t)std::max<long long>(1 << 16, (fp.capC - fp.capCC) / 4))));
         fp.passListR = F.passListR.p; fp.capPassR = (long long)F.passListR.cap;
     }
+    if (dbgTime) fprintf(stderr, "[maple]   frontier +%.1f ms: pools reserved\n", sinceEnter());
     hipStream_t s = c->stream;
     const bool dbgSync = c->tuning.verbose > 2;                            // (MAPLE_DEBUG=3: every launch awaited and named)
     auto stage = [&](const char *what) -> int {
@@ -1278,6 +1284,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     }
     if (hipEventRecord(F.evJoin, s2) != hipSuccess || hipStreamWaitEvent(s, F.evJoin, 0) != hipSuccess)
         return bail(fail(c, MAPLE_ERR_HIP, "frontier level loop: HIP error"));
+    if (dbgTime) fprintf(stderr, "[maple]   frontier +%.1f ms: expansion done (%d updating levels, %d cached launches)\n", sinceEnter(), levels, launchesC);
     size_t slotWide = (size_t)-1;
     // (replay, refinement, final selection: an error in here must not return with kernels still in flight on either stream --
     // the caller may reuse or free the pools -- so the stage is a lambda and its status goes through bail() like the loop's)
@@ -1334,6 +1341,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     return MAPLE_OK;
     };
     { const int rc_ = finishStage(); if (rc_) return bail(rc_); }
+    if (dbgTime) fprintf(stderr, "[maple]   frontier +%.1f ms: replay, refinement, final selection done; results on the host\n", sinceEnter());
     {   // what this tier did, for maple_timing_read_kind: candidate placements of the searches it finished (SURVEY 8d bytes)
         const double meanCand = c->n_scored ? c->scored_bytes_total / c->n_scored : 0.0;
         double units = 0.0, bytes = 0.0;

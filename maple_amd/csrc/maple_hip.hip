@@ -2067,6 +2067,24 @@ extern "C" int maple_argmax_allreduce_dev(maple_ctx *c, int32_t n, double *score
 #include "update_host.h"
 #include "rebuild_host.h"
 
+// appendProbNode by a whole wavefront per pair (wave_dev.h), small batches of maple_append_batch; the hook of the parity tests is below
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(64) void k_wave_append(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *pl,
+                                                    const int32_t *cl, const uint8_t *tip, const double *bl, double *out)
+{
+    __shared__ Lds lds;
+    __shared__ WaveLds wl;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const double v = wave_append(c, list_ref(av, pl[i]), av.n_ent[pl[i]], list_ref(av, cl[i]), av.n_ent[cl[i]], tip[i] != 0, bl[i], wl);
+        if (threadIdx.x == 0) out[i] = v;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+#ifdef MAPLE_DEBUG_ABI                                                   // (libmaple_hip_debug.so: include/maple_hip_debug.h)
 // Calibration of the FETCH_SIZE counter for THIS library's access pattern (MI355X_MICROARCH.md, HBM section: the
 // counter is only calibrated for 16 B/lane coalesced streams).  Every lane walks its own contiguous 512-byte "list"
 // with dependent 8-byte loads, exactly like a genome-list walk, over a buffer far larger than the 256 MiB Infinity
@@ -2213,23 +2231,6 @@ extern "C" int maple_debug_simplify_batch(maple_ctx *c, int32_t n, const double 
 }
 
 // debugging aid: record the visit sequence (t1, direction, needsUpdating, failedPasses, lastLK, midProb) of one query
-// appendProbNode by a whole wavefront per pair (wave_dev.h), for parity tests against the one-lane walk and for timing
-template <bool RV, bool U, bool SS>
-__global__ __launch_bounds__(64) void k_wave_append(const DevModel *__restrict__ mp, ArenaView av, int n, const int32_t *pl,
-                                                    const int32_t *cl, const uint8_t *tip, const double *bl, double *out)
-{
-    __shared__ Lds lds;
-    __shared__ WaveLds wl;
-    const DevModel &m = *mp;
-    stage_model(m, lds);
-    Ctx<RV, U, SS> c(m, lds);
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const double v = wave_append(c, list_ref(av, pl[i]), av.n_ent[pl[i]], list_ref(av, cl[i]), av.n_ent[cl[i]], tip[i] != 0, bl[i], wl);
-        if (threadIdx.x == 0) out[i] = v;
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 extern "C" int maple_debug_wave_append_batch(maple_ctx *c, int32_t n, const int32_t *pl, const int32_t *cl, const uint8_t *tip,
                                              const double *bl, double *out, float *ms)
 {
@@ -2275,6 +2276,8 @@ extern "C" int maple_debug_trace_read(maple_ctx *c, int32_t *n, int32_t *items4,
     HIPCK(c, hipMemcpy(vals2, c->s_trace_d.p, 2 * 4096 * sizeof(double), hipMemcpyDeviceToHost));
     return MAPLE_OK;
 }
+
+#endif  // MAPLE_DEBUG_ABI
 
 extern "C" int maple_timing_reset(maple_ctx *c)
 {

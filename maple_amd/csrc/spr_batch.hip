@@ -1421,7 +1421,9 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // then replayed exactly -- for trees without MAT local references.  What it hands back (a search that would edit its
     // removed list in place, touches the root while still updating lists, or overflows a pool) runs one lane per search.
     if (useFrontier) {
+        if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: prologue done\n", tms(tStart, tnow()));
         if (afterLaunch) { std::function<int()> f; f.swap(afterLaunch); TRY(f()); }   // (the side-stream scoring starts alongside)
+        if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: side-stream scoring queued\n", tms(tStart, tnow()));
         FrontierStats fs;
         // An item of the frontier tier costs about what half a (search, branch) pair costs the dense tier on full walks (1.1e9
         // items/s against 2.3e9 pairs/s), so a search only pays for a row of the whole tree once it has expanded half a tree's
@@ -1746,6 +1748,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     }
 #endif
     if (preMark >= 0) TRY(maple_arena_release(c, preMark));             // (the root-frame copies of this call)
+    if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: results in host memory\n", tms(tStart, tnow()));
     for (int i = 0; i < n; i++) {
         bestNode[i] = ho[i].bestNode; bestScore[i] = ho[i].bestScore;
         blen3[3 * i] = ho[i].blen[0]; blen3[3 * i + 1] = ho[i].blen[1]; blen3[3 * i + 2] = ho[i].blen[2];
@@ -1767,6 +1770,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         TRY(stage_flush(c));
         TRY(commit_lists(c, n, dwo, dao, c->s_i32[2].p, c->s_i32[3].p, outRprList, poolW, poolA));
     }
+    if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: outputs written\n", tms(tStart, tnow()));
     return MAPLE_OK;
 }
 
@@ -1782,6 +1786,7 @@ extern "C" int maple_spr_search_visited(maple_ctx *c, int64_t cap, int32_t *quer
     return rc;
 }
 
+#ifdef MAPLE_DEBUG_ABI
 extern "C" int maple_debug_frontier_levels(maple_ctx *c, int32_t cap, int64_t *itemsUpdating, int64_t *itemsCached, float *msUpdating,
                                            float *msCached, int32_t *n, int64_t *waveItemsSmall, int64_t *waveItemsBig)
 {
@@ -1793,4 +1798,5 @@ extern "C" int maple_debug_frontier_levels(maple_ctx *c, int32_t cap, int64_t *i
     *n = nn;
     return rc;
 }
+#endif
 

@@ -21,12 +21,18 @@ EXPORTS = [
     "maple_lists_upload", "maple_lists_update", "maple_lists_sizes", "maple_lists_download", "maple_arena_mark", "maple_arena_release",
     "maple_arena_stats", "maple_mutations_upload", "maple_append_batch", "maple_merge_batch", "maple_blen_batch",
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
-    "maple_evaluate_placement_batch", "maple_update_partials", "maple_update_partials_touched", "maple_tree_patch", "maple_debug_wave_append_batch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
+    "maple_evaluate_placement_batch", "maple_update_partials", "maple_update_partials_touched", "maple_tree_patch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
-    "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy", "maple_debug_trace_query", "maple_debug_calib_walk", "maple_debug_trace_read",
-    "maple_timing_read_kind", "maple_placement_supports_batch", "maple_debug_gpv_batch", "maple_debug_simplify_batch",
-    "maple_candset_destroy", "maple_debug_calib_write", "maple_spr_search_visited", "maple_arena_compact", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev", "maple_debug_frontier_levels", "maple_tree_rebuild_lists",
+    "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy",
+    "maple_timing_read_kind", "maple_placement_supports_batch",
+    "maple_candset_destroy", "maple_spr_search_visited", "maple_arena_compact", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev", "maple_tree_rebuild_lists",
 ]
+
+
+# include/maple_hip_debug.h: measurement aids and test hooks, exported by libmaple_hip_debug.so only (Device(..., debug=True))
+DEBUG_EXPORTS = ["maple_debug_wave_append_batch", "maple_debug_trace_query", "maple_debug_trace_read", "maple_debug_calib_walk",
+                 "maple_debug_calib_write", "maple_debug_gpv_batch", "maple_debug_simplify_batch", "maple_debug_frontier_levels"]
+LIB_PATH_DEBUG = os.path.join(HERE, "libmaple_hip_debug.so")
 
 
 class MapleParams(C.Structure):
@@ -63,13 +69,16 @@ class MapleError(RuntimeError):
 
 
 _lib = None
+_lib_debug = None
 
 
-def load_library():
-    """Load libmaple_hip.so; raises if it has not been built (see __graft_entry__.build)."""
-    global _lib
-    if _lib is None:
-        lib_path = os.environ.get("MAPLE_HIP_LIB", LIB_PATH)         # (kernel-variant experiments: another build of the library)
+def load_library(debug=False):
+    """Load libmaple_hip.so (``debug``: libmaple_hip_debug.so, the same library with the entry points of
+    include/maple_hip_debug.h); raises if it has not been built (see __graft_entry__.build)."""
+    global _lib, _lib_debug
+    if (_lib_debug if debug else _lib) is None:
+        default = LIB_PATH_DEBUG if debug else LIB_PATH
+        lib_path = os.environ.get("MAPLE_HIP_LIB", default)          # (kernel-variant experiments: another build of the library)
         if not os.path.exists(lib_path):
             raise MapleError(f"{lib_path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`; "
                              "there is no CPU fallback for the placement path")
@@ -81,10 +90,13 @@ def load_library():
             pass
         lib = C.CDLL(lib_path)
         lib.maple_last_error.restype = C.c_char_p
-        for name in EXPORTS:
+        for name in EXPORTS + (DEBUG_EXPORTS if debug else []):
             getattr(lib, name)       # fail early if a declared symbol is not exported
-        _lib = lib
-    return _lib
+        if debug:
+            _lib_debug = lib
+        else:
+            _lib = lib
+    return _lib_debug if debug else _lib
 
 
 def _ptr(a):
@@ -108,10 +120,11 @@ class Device:
 
     def __init__(self, ref_idx, root_freqs, *, device=0, thresholdProb=1e-8, minBLenSensitivity=None,
                  thresholdDiffForUpdate=1e-5, thresholdFoldChangeUpdate=1.01, defaultBLen=0.000033,
-                 arena_bytes=0, lib=None):
+                 arena_bytes=0, lib=None, debug=False):
         # (lib: another library with the same C ABI, handed in explicitly -- the tests diff libmaple_hip.so against its CPU twin
         # this way; nothing in the package ever passes one)
-        self.lib = lib if lib is not None else load_library()
+        # (debug: libmaple_hip_debug.so -- the same library plus the measurement aids and test hooks of include/maple_hip_debug.h)
+        self.lib = lib if lib is not None else load_library(debug)
         self.ref_idx = _u8(ref_idx)
         self.lRef = int(len(self.ref_idx))
         if minBLenSensitivity is None:

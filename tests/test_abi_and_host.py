@@ -14,8 +14,8 @@ from golden_util import GOLDEN, fixture_names, load, tup
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "maple_hip.h")).read()
+def declared_symbols(header="maple_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(maple_[a-z0-9_]+)\s*\(", text)))
 
@@ -31,6 +31,17 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/maple_hip.h but not exported"
     assert set(runtime.EXPORTS) <= set(names)
     assert lib.maple_abi_version() == 3
+    # the product library is the operator boundary and nothing else: the measurement aids and test hooks of
+    # include/maple_hip_debug.h are exported by libmaple_hip_debug.so only, which also has everything above
+    dbg_names = declared_symbols("maple_hip_debug.h")
+    assert sorted(dbg_names) == sorted(runtime.DEBUG_EXPORTS) and all(n.startswith("maple_debug_") for n in dbg_names)
+    assert not [n for n in names if n.startswith("maple_debug_")]
+    dbg = runtime.load_library(debug=True)
+    for n in dbg_names:
+        assert not hasattr(lib, n), f"{n} is exported by the product library"
+        assert hasattr(dbg, n), n
+    for n in names:
+        assert hasattr(dbg, n), n
 
 
 def test_no_gpu_means_loud_failure():

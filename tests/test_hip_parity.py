@@ -17,13 +17,14 @@ REL = 1e-9
 FIXTURES = fixture_names()
 
 
-def make_device(f):
+def make_device(f, debug=False):
+    """debug: libmaple_hip_debug.so (the product library plus the test hooks of include/maple_hip_debug.h)"""
     from maple_amd.runtime import Device
     ctx = f["context"]
     return Device(ref_indices(ctx), ctx["rootFreqs"], thresholdProb=ctx["thresholdProb"],
                   minBLenSensitivity=ctx["minBLenSensitivity"], thresholdDiffForUpdate=ctx["thresholdDiffForUpdate"],
                   thresholdFoldChangeUpdate=ctx["thresholdFoldChangeUpdate"], defaultBLen=ctx["defaultBLen"],
-                  arena_bytes=256 << 20)
+                  arena_bytes=256 << 20, debug=debug)
 
 
 def make_oracle(f):
@@ -89,22 +90,27 @@ def test_wavefront_wide_appendProbNode_is_the_one_lane_walk_bit_for_bit(env):
     product in walk order) against the one-lane walk of maple_append_batch on every recorded appendProbNode call of the
     fixture, in every model mode: identical doubles (including -inf), not just close ones."""
     f, dev, o = env
+    dbg = make_device(f, debug=True)              # (the hook lives in libmaple_hip_debug.so; the one-lane walk is the product library's)
     total = 0
     for mid, recs in by_model(f, "appendProbNode").items():
         dev.set_model(**model_args(f["models"][mid]))
-        mark = dev.mark()
+        dbg.set_model(**model_args(f["models"][mid]))
+        mark, mark_d = dev.mark(), dbg.mark()
         n = len(recs)
-        ids = dev.upload([tup(r["P"]) for r in recs] + [tup(r["C"]) for r in recs])
+        lists = [tup(r["P"]) for r in recs] + [tup(r["C"]) for r in recs]
+        ids, ids_d = dev.upload(lists), dbg.upload(lists)
         tips, bls = [r["isTipC"] for r in recs], [r["bLen"] for r in recs]
         one = dev.append_batch(ids[:n], ids[n:], tips, bls)
-        wave, _ = dev.debug_wave_append_batch(ids[:n], ids[n:], tips, bls)
+        wave, _ = dbg.debug_wave_append_batch(ids_d[:n], ids_d[n:], tips, bls)
         assert np.array_equal(one, wave), [(a, b) for a, b in zip(one, wave) if a != b][:3]
         # ... and with the roles of the two lists exchanged (other merge paths, other ties)
         one = dev.append_batch(ids[n:], ids[:n], tips, bls)
-        wave, _ = dev.debug_wave_append_batch(ids[n:], ids[:n], tips, bls)
+        wave, _ = dbg.debug_wave_append_batch(ids_d[n:], ids_d[:n], tips, bls)
         assert np.array_equal(one, wave)
         dev.release(mark)
+        dbg.release(mark_d)
         total += n
+    dbg.close()
     assert total > 100
 
 
@@ -249,7 +255,8 @@ def test_getPartialVec_and_simplify_on_the_gpu(env):
     """a3 / a4 directly on the HIP path: every recorded getPartialVec (M:4073-4141) and simplify (M:3697-3717) call of
     the reference through the one-lane-per-call hooks, plus the negative-clamp exits (M:4096, 4106, 4122, 4139: any
     component that goes negative turns the whole vector into [0.25] * 4) on inputs built to reach each of them."""
-    f, dev, o = env
+    f, _, o = env
+    dev = make_device(f, debug=True)              # (the hooks of include/maple_hip_debug.h: the same device functions the product library is built from)
     Q = f["models"][0]["Q"]
     n_calls = 0
     for u, recs in _u_groups(f, "getPartialVec").items():
@@ -285,6 +292,7 @@ def test_getPartialVec_and_simplify_on_the_gpu(env):
             assert [float(x) for x in g] == want, (c, g, want)
             n_clamped += want == [0.25] * 4
         assert n_clamped >= 4
+    dev.close()
 
 
 def test_appendProbNode_log_of_zero_is_minus_infinity(env):

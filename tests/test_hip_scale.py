@@ -18,6 +18,17 @@ Q = [[-0.5524, 0.0602, 0.3655, 0.1267], [0.1666, -2.6077, 0.0405, 2.4006],
      [0.8421, 0.1305, -2.4012, 1.4286], [0.0688, 0.4849, 0.0502, -0.6039]]
 
 
+def world_model_kwargs(mode, l_ref, seed=2):
+    rng = np.random.default_rng(seed + 100)
+    kw = dict(Q=Q)
+    if mode != "unrest":
+        kw["siteRates"] = np.clip(rng.gamma(0.5, 2.0, size=l_ref), 0.001, 0.005 * l_ref)
+    if mode == "siteerr":
+        er = np.exp(rng.uniform(math.log(1e-10), math.log(1e-3), size=l_ref))
+        kw.update(usingErrorRate=True, errorRates=er, errorRateGlobal=float(er.mean()))
+    return kw
+
+
 def build(n_tips, mode, seed=2):
     from maple_amd.host import reference_tables, tip_genome_list
     from maple_amd.runtime import Device
@@ -27,13 +38,7 @@ def build(n_tips, mode, seed=2):
     data = make_dataset(n_samples=n_tips, l_ref=29903, seed=seed, mean_diffs=30.0, rate_variation=(mode != "unrest"),
                         frac_with_n=0.05, frac_ambig=0.05)
     ref_idx, rf = reference_tables(data.ref)
-    rng = np.random.default_rng(seed + 100)
-    kw = dict(Q=Q)
-    if mode != "unrest":
-        kw["siteRates"] = np.clip(rng.gamma(0.5, 2.0, size=len(ref_idx)), 0.001, 0.005 * len(ref_idx))
-    if mode == "siteerr":
-        er = np.exp(rng.uniform(math.log(1e-10), math.log(1e-3), size=len(ref_idx)))
-        kw.update(usingErrorRate=True, errorRates=er, errorRateGlobal=float(er.mean()))
+    kw = world_model_kwargs(mode, len(ref_idx), seed)
     dev = Device(ref_idx, rf, arena_bytes=3 << 30)
     dev.set_model(**kw)
     orc = Oracle(ref_idx, rf)
@@ -533,7 +538,16 @@ def test_wavefront_wide_append_on_tree_lists(world):
     cl = mirror.lower[rng.choice(tips, size=4000)]
     bl = np.where(rng.random(4000) < 0.2, 0.0, 1.0 / dev.lRef)          # some zero-length attachments: -inf results
     one = dev.append_batch(pl, cl, True, bl)
-    wave, ms = dev.debug_wave_append_batch(pl, cl, True, bl)
+    # (the wavefront-wide kernel's entry point is a hook of libmaple_hip_debug.so: the same lists on a device of that library)
+    from maple_amd.host import reference_tables
+    from maple_amd.runtime import Device
+    ref_idx, rf = reference_tables(data.ref)
+    dbg = Device(ref_idx, rf, arena_bytes=1 << 30, debug=True)
+    dbg.set_model(**world_model_kwargs(mode, len(ref_idx)))
+    pl_d, cl_d = dbg.upload_packed(dev.download_packed(pl)), dbg.upload_packed(dev.download_packed(cl))
+    assert np.array_equal(dbg.append_batch(pl_d, cl_d, True, bl), one)
+    wave, ms = dbg.debug_wave_append_batch(pl_d, cl_d, True, bl)
+    dbg.close()
     assert np.array_equal(one, wave), int((one != wave).sum())
     assert np.isfinite(one).any() and (mode == "siteerr" or np.isinf(one).any())   # (with an error model a zero-length mismatch is finite)
     print(f"{mode}: 4000 wavefront-wide appendProbNode in {ms:.3f} ms")
@@ -783,13 +797,7 @@ def test_oracle_tree_log_lk_from_the_tips_equals_the_library_on_plain_and_local_
     tip_ids = mirror.lower.copy()
     from maple_amd.host import reference_tables
     ref_idx, rf = reference_tables(data.ref)
-    rng = np.random.default_rng(2 + 100)
-    kw = dict(Q=Q)
-    if mode != "unrest":
-        kw["siteRates"] = np.clip(rng.gamma(0.5, 2.0, size=len(ref_idx)), 0.001, 0.005 * len(ref_idx))
-    if mode == "siteerr":
-        er = np.exp(rng.uniform(math.log(1e-10), math.log(1e-3), size=len(ref_idx)))
-        kw.update(usingErrorRate=True, errorRates=er, errorRateGlobal=float(er.mean()))
+    kw = world_model_kwargs(mode, len(ref_idx))
     plain = bench.tree_log_lk_check(dev, mirror, None, tip_ids, kw, ref_idx, rf)
     assert plain["rel_delta"] <= 1e-12, plain
     mark = dev.mark()

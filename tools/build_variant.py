@@ -1,10 +1,11 @@
-"""Build a variant of libmaple_hip.so next to the product library: tools/build_variant.py NAME [extra hipcc flags ...]
+"""Build a variant of libmaple_hip_debug.so (the product library plus include/maple_hip_debug.h: -DMAPLE_DEBUG_ABI is always on)
+next to the product library: tools/build_variant.py NAME [extra hipcc flags ...]
 -> maple_amd/libmaple_hip_NAME.so (objects under build/NAME/).  Run anything with MAPLE_HIP_LIB=<that path> to use it."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
-name, extra = sys.argv[1], sys.argv[2:]
+name, extra = sys.argv[1], ["-DMAPLE_DEBUG_ABI"] + sys.argv[2:]
 out = os.path.join(ROOT, "build", name)
 os.makedirs(out, exist_ok=True)
 objs, jobs = [], []

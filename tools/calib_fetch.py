@@ -4,7 +4,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maple_amd.runtime import Device
-dev = Device(np.zeros(100, dtype=np.uint8), [0.25] * 4, arena_bytes=16 << 20)
+dev = Device(np.zeros(100, dtype=np.uint8), [0.25] * 4, arena_bytes=16 << 20, debug=True)
 nbytes = 2 << 30
 ms = dev.debug_calib_walk(nbytes, 3)
 print(f"calib: {nbytes} bytes x 3 launches in {ms:.3f} ms -> {3 * nbytes / ms / 1e6:.1f} GB/s")

@@ -11,7 +11,7 @@ f = json.load(gzip.open(os.path.join(GOLDEN, f"search_{name}.json.gz"), "rt"))
 ctx, t = f["context"], f["tree"]
 dev = Device(ref_indices(ctx), ctx["rootFreqs"], thresholdProb=ctx["thresholdProb"], minBLenSensitivity=ctx["minBLenSensitivity"],
              thresholdDiffForUpdate=ctx["thresholdDiffForUpdate"], thresholdFoldChangeUpdate=ctx["thresholdFoldChangeUpdate"],
-             defaultBLen=ctx["defaultBLen"], arena_bytes=256 << 20)
+             defaultBLen=ctx["defaultBLen"], arena_bytes=256 << 20, debug=True)
 dev.set_model(**model_args(f["model"]))
 tree = HostTree(t["root"], t["up"], t["children"], t["dist"], t["mutations"], t["nMinor"], t["probVect"],
                 t["probVectUpRight"], t["probVectUpLeft"], t["probVectTotUp"]).upload(dev)

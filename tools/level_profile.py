@@ -7,7 +7,7 @@ import bench
 
 samples = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 model = sys.argv[2] if len(sys.argv) > 2 else "ratevar"
-bt = bench.build_bench_tree(samples, model, refs=sys.argv[4] if len(sys.argv) > 4 else "local")
+bt = bench.build_bench_tree(samples, model, refs=sys.argv[4] if len(sys.argv) > 4 else "local", debug_library=True)
 dev, m = bt.dev, bt.mirror
 kw = bench.search_kwargs(dev.lRef)
 if os.environ.get("MAPLE_VERBOSE"):

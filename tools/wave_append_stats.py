@@ -25,7 +25,7 @@ def main():
     model = sys.argv[2] if len(sys.argv) > 2 else "ratevar"
     data = make_dataset(n_samples=n_tips, l_ref=29903, seed=1, mean_diffs=30.0, rate_variation=(model != "unrest"))
     ref_idx, rf = reference_tables(data.ref)
-    dev = Device(ref_idx, rf, arena_bytes=4 << 30)
+    dev = Device(ref_idx, rf, arena_bytes=4 << 30, debug=True)
     dev.set_model(**bench.model_kwargs(model, len(ref_idx)))
     tips = {int(v): tip_genome_list(dl, ref_idx) for v, dl in zip(data.tip_node, data.diffs)}
     m = TreeMirror(dev, data.parent, data.blen, tips).build()
