@@ -86,8 +86,9 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
         // the removed list as the search starts with it (M:6838-6846): in the frame of the pruned node's parent, and once more in
         // the sibling's (bestRemovedPartials).  A re-expressed list that shorten() (M:7087) would change: the one-lane kernel.
         int rpr = ftree(rn.lower);
-        const bool wouldMerge = shorten_would_merge(c, fref(ll), ll.n);     // M:7087 would edit the removed list (see fpass_removed)
-        S.rprMerge0 = wouldMerge ? 1 : 0;
+        const int mergeLevel = shorten_would_merge(c, fref(ll), ll.n);      // M:7087 would edit the removed list (see fpass_removed)
+        const bool wouldMerge = mergeLevel != 0;
+        S.rprMerge0 = mergeLevel;
         int hBest = rpr;
         if (fp.mat) {
             rpr = fpass_removed(c, fp, av, laneId, rpr, rn.mutId, true);
@@ -508,8 +509,12 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_place(FPools fp, int lev
 }
 
 // what the exact walk of one search leaves behind: the short list, the candidate count, the records to refine
-__device__ inline void fr_replay_done(const SearchParams &P, const FPools &fp, SearchOut *out, int q, FSearch &S, int slHead, int nApp, bool handBack)
+// (hShort: the removed lists the reference shortened in place on the way, M:7087 -- see k_fr_replay)
+__device__ inline void fr_replay_done(const SearchParams &P, const FPools &fp, SearchOut *out, int q, FSearch &S, int slHead, int nApp, bool handBack,
+                                      const int *hShort = nullptr, int nShort = 0)
 {
+    // (the list the search starts from, bestRemovedPartials when nothing better is found, shortened: the one-lane kernel)
+    for (int k = 0; k < nShort; k++) if (hShort[k] == S.hRpr0) handBack = true;
     if (handBack) { S.state = FS_FALLBACK; out[q].status = FR_STATUS_FALLBACK; return; }
     S.slHead = slHead; S.nApp = nApp;
     // the short-listed branches that are refined (M:7465: within thresholdLogLKoptimizationTopology of the ORIGINAL cost)
@@ -525,7 +530,14 @@ __device__ inline void fr_replay_done(const SearchParams &P, const FPools &fp, S
     S.recBase = (int32_t)base; S.recCount = cnt;
     int k = 0;
     for (int r = slHead; r != FR_NONE; r = item_of(fp, r).next)
-        if (item_of(fp, r).midProb >= S.curLK - P.thrOptTopo) { FRec &x = fp.recs[base + k++]; x.q = q; x.ref = r; x.ok = 0; }
+        if (item_of(fp, r).midProb >= S.curLK - P.thrOptTopo) {
+            FRec &x = fp.recs[base + k++];
+            x.q = q; x.ref = r; x.ok = 0; x.hRprS = -1;
+            // (the short list holds the list OBJECT: shortened in place at any time of the walk, it is the shortened list by the
+            // time the refinement reads it)
+            const int hr = item_of(fp, r).hRpr;
+            for (int j = 0; j < nShort; j++) if (hShort[j] == hr) x.hRprS = FR_SHORTEN;
+        }
 }
 
 __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, FPools fp, SearchOut *out)
@@ -538,6 +550,15 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
         double best = S.curLK;
         int nApp = 0, slHead = FR_NONE, slTail = FR_NONE;
         bool marked = false;
+        // The reference shortens a branch's removed list IN PLACE when the branch beats the running best on the way down (M:7087).
+        // A list that shorten() would change is marked by the expansion (shorten_would_merge): level 2 -- tails merged within a
+        // tolerance: another list to every reader -- hands the search to the one-lane kernel.  Level 1 -- the entries that go
+        // away have exactly the tail of the one that stays -- changes no score; what it does change is emulated: the list is
+        // noted here (with the rank of the event), the records that hold it are refined with its shortened form (fr_replay_done,
+        // k_fr_refine), and a search in which a list is re-expressed FROM it after the event (an item that crosses a reference
+        // branch, pushed by an item visited later than the event) goes to the one-lane kernel after all.
+        int hShort[4], nShort = 0;
+        long long rankShort[4];
         if (fp.visit && fp.vbase[q + 1] <= fp.capVisit) {
             // the same walk as a forward scan over the search's items in visiting order
             const long long end = fp.vbase[q + 1];
@@ -556,6 +577,12 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
                 if (!(rec.flags & FI_DEAD)) {
                     int fails = rec.parent < 0 ? 0 : failsAt[rec.parent];
                     const double mp = rec.midProb;
+                    if (nShort && rec.parent >= 0) {                            // (after an event only: two item records per visit)
+                        const int hr = item_of(fp, rec.ref).hRpr, hp = item_of(fp, fp.visit[rec.parent].ref).hRpr;
+                        if (hr != hp)
+                            for (int j = 0; j < nShort; j++) if (hShort[j] == hp && (long long)rec.parent > rankShort[j]) marked = true;
+                        if (marked) break;
+                    }
                     if (rec.flags & FI_SCORED) {
                         nApp++;
                         const bool list = (rec.dir == 0) ? (mp > best - P.thrOptTopo) : (mp >= best - P.thrOptTopo);   // M:7071 / 7293
@@ -569,7 +596,18 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
                             best = mp; fails = 0;
                             // (M:7087: the reference shortens the branch's removed list in place here; if that changes the list, the
                             // one-lane kernel takes the search)
-                            if (rec.dir == 0 && frpr_marked(fp, S, item_of(fp, rec.ref).hRpr)) { marked = true; break; }
+                            if (rec.dir == 0) {
+                                const int hr = item_of(fp, rec.ref).hRpr, lvl = frpr_marked(fp, S, hr);
+                                if (lvl == 2) { marked = true; break; }
+                                if (lvl == 1) {
+                                    bool known = false;
+                                    for (int j = 0; j < nShort; j++) known |= hShort[j] == hr;
+                                    if (!known) {
+                                        if (nShort == 4) { marked = true; break; }
+                                        hShort[nShort] = hr; rankShort[nShort] = i; nShort++;
+                                    }
+                                }
+                            }
                         }
                         else if (mp < (rec.lastLK - P.thrConsec)) fails++;
                     }
@@ -619,7 +657,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
             push(it.child1, fails);
         }
         }
-        fr_replay_done(P, fp, out, q, S, slHead, nApp, marked);
+        fr_replay_done(P, fp, out, q, S, slHead, nApp, marked, hShort, nShort);
     }
 }
 
@@ -781,7 +819,7 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
                         if (fp.mat && b.hMid != b.hDown) { x.flags |= FI_NEEDPASS; x.hA = b.hDown; x.hB = b.hMid; }
                     }
                     FRec &x = fp.recs[base + kk++];
-                    x.q = q; x.ref = ref; x.ok = 0;
+                    x.q = q; x.ref = ref; x.ok = 0; x.hRprS = -1;
                 }
             }
         }
@@ -854,7 +892,19 @@ void k_fr_refine(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, FPoo
             hDown = ftree(r1.lower); hMid = ftree(r1.totUp); distance = r1.dist;
         }
         if (!fvalid(hUp) || !fvalid(hDown) || !fvalid(hMid)) { R.ok = -1; continue; }
-        const FList lUp = flist(av, fp, hUp), lDown = flist(av, fp, hDown), lMid = flist(av, fp, hMid), lRem = flist(av, fp, it.hRpr);
+        int hRem = it.hRpr;
+        if (R.hRprS == FR_SHORTEN) {                                        // the reference shortened this list in place on its way (M:7087)
+            const FList l0 = flist(av, fp, hRem);
+            FScr scrS;
+            if (!fscratch(fp, laneId, l0.n, scrS)) { S.state = FS_FALLBACK; continue; }
+            Writer ws;
+            ws.init(scrS.w, scrS.a);
+            shorten_walk(c, fref(l0), l0.n, ws);
+            hRem = fstore(fp, ws);
+            if (hRem < 0) { S.state = FS_FALLBACK; continue; }
+            R.hRprS = hRem;
+        }
+        const FList lUp = flist(av, fp, hUp), lDown = flist(av, fp, hDown), lMid = flist(av, fp, hMid), lRem = flist(av, fp, hRem);
         const bool ft = r1.isTip != 0, rt = S.isRemovedTip != 0;
         const int need = max(lDown.n + lRem.n, max(lUp.n + lRem.n, lUp.n + lDown.n));
         FScr scr0;
@@ -912,7 +962,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_finish(ArenaViewS av, DevTree T
             nApp += 3;
             if (R.optimized >= bestScore) {
                 const FItem &it = item_of(fp, R.ref);
-                bestNode = it.t1; bestScore = R.optimized; bl0 = R.top; bl1 = R.bottom; bl2 = R.app; hBestRpr = it.hRpr;
+                bestNode = it.t1; bestScore = R.optimized; bl0 = R.top; bl1 = R.bottom; bl2 = R.app; hBestRpr = R.hRprS >= 0 ? R.hRprS : it.hRpr;
             }
         }
         o.nAppend = nApp;

@@ -69,11 +69,13 @@ struct FSearch {
     int32_t state;
     int32_t slHead, nApp, recBase, recCount;
     int32_t isRemovedTip;
-    int32_t rprMerge0;                 // shorten() (M:7087) would change the pruned node's own lower list (never so for a stored list)
+    int32_t rprMerge0;                 // shorten() (M:7087) would change the pruned node's own lower list (never so for a stored list): shorten_would_merge's level
     double removedBLen, curLK;
 };
 
-struct FRec { int32_t q, ref; double optimized, top, bottom, app; int32_t ok, pad; };
+struct FRec { int32_t q, ref; double optimized, top, bottom, app; int32_t ok;
+              int32_t hRprS; };        // in: FR_SHORTEN = the reference shortened this record's removed list in place (M:7087); out: the shortened list
+#define FR_SHORTEN (-3)
 
 struct FCtr {                          // device-side bookkeeping of the level loop
     // (what every lane READS at the start of a kernel, and each counter the lanes bump, on cache lines of their own)
@@ -125,7 +127,7 @@ struct FPools {
     uint2 *tw; double *ta;
     long long *toffW, *toffA;
     int32_t *tn, *tna;
-    uint8_t *tflag;                    // per temporary list: 1 = a removed list that shorten() (M:7087) would change
+    uint8_t *tflag;                    // per temporary list: a removed list that shorten() (M:7087) would change (shorten_would_merge's level)
     long long capW, capA, capL;
     FVisit *visit; long long capVisit;   // the layout of k_fr_layout_* (null: k_fr_replay chases the items)
     int32_t *lsize, *lpos, *lpar;      // per item (updating pool first, then the cached pool): items in the subtree it heads, its
@@ -221,23 +223,37 @@ __device__ inline int fstore(const FPools &fp, const Writer &wr)
     return (int)id;
 }
 
-// would shorten() (M:3721-3745) change this list?  (the absorb test of shorten_walk, genome_dev.h)
-template <class C> __device__ inline bool shorten_would_merge(const C &c, ListRef L, int nEnt)
+// would shorten() (M:3721-3745) change this list?  (the absorb test of shorten_walk, genome_dev.h: a run of R entries of one
+// kind collapses into its LAST entry, each candidate compared with the run's FIRST entry)
+//   0  no;
+//   1  yes, and every entry that goes away has exactly the tail of the entry that stays (none at all, or the same doubles and
+//      flag): no appendProbNode can tell the two forms apart -- an R entry only enters a site factor through its tail;
+//   2  yes, with tails that are equal only within the tolerance: the merged list is another list to every reader.
+template <class C> __device__ inline int shorten_would_merge(const C &c, ListRef L, int nEnt)
 {
     const double thr = c.m.thresholdProb;
     Cursor a;
     a.init(L);
     Ent head = a.e;
+    int level = 0;
+    bool exact = true;                                                      // (of the current run: every absorbed tail == the head's so far)
     for (int k = 1; k < nEnt; k++) {
         a.next();
         const Ent &nw = a.e;
+        bool absorb = false;
         if (nw.type == 4 && head.type == 4 && nw.hasD0 == head.hasD0 && nw.hasD1 == head.hasD1) {
-            if (!nw.hasD0) return true;
-            if (!(fabs(nw.d0 - head.d0) > thr) && !(nw.hasD1 && fabs(nw.d1 - head.d1) > thr) && nw.flag == head.flag) return true;
+            if (!nw.hasD0) absorb = true;
+            else if (fabs(nw.d0 - head.d0) > thr) absorb = false;
+            else if (nw.hasD1 && fabs(nw.d1 - head.d1) > thr) absorb = false;
+            else absorb = (nw.flag == head.flag);
         }
-        head = nw;
+        if (absorb) {
+            // (the run ends up with the LAST entry's tail: all its tails must be the same doubles for the merge to be invisible)
+            if (nw.hasD0 && (nw.d0 != head.d0 || (nw.hasD1 && nw.d1 != head.d1))) exact = false;
+            level = max(level, exact ? 1 : 2);
+        } else { head = nw; exact = true; }
     }
-    return false;
+    return level;
 }
 
 // passGenomeListThroughBranch (M:3749-3877) of list h through mutation list mutId: the handle of a new temporary list, h itself
@@ -269,12 +285,12 @@ __device__ inline int fpass_removed(const C &c, const FPools &fp, const ArenaVie
     const int r = fpass_store(fp, av, c.m.lRef, laneId, h, mutId, dirUp);
     if (r == h || r < 0) return r;                                          // (unchanged, or -2: no room)
     const FList l = flist(av, fp, r);
-    if (shorten_would_merge(c, fref(l), l.n)) fp.tflag[r] = 1;
+    fp.tflag[r] = (uint8_t)shorten_would_merge(c, fref(l), l.n);
     return r;
 }
-__device__ __forceinline__ bool frpr_marked(const FPools &fp, const FSearch &S, const int h)
+__device__ __forceinline__ int frpr_marked(const FPools &fp, const FSearch &S, const int h)
 {
-    return h >= 0 ? fp.tflag[h] != 0 : (h <= -10 && S.rprMerge0 != 0);
+    return h >= 0 ? (int)fp.tflag[h] : (h <= -10 ? S.rprMerge0 : 0);
 }
 
 // one more expanded item of search q; false when the search is over its budget (it becomes a dense-tier search) or the pool
