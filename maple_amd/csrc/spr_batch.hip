@@ -1078,6 +1078,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     }
     HIPCK(c, hipMemsetAsync(c->s_counter.p, 0, 8 * sizeof(int32_t), c->stream));
     unsigned long long *poolUsed = (unsigned long long *)(c->s_counter.p + 2);
+    if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: result records cleared\n", tms(tStart, tnow()));
     // per-lane list workspace: a search near the root of a tree with long lists (rate variation: many O vectors) merges
     // lists of several hundred entries a few hundred times before it is handed over or done
     const int capW0 = ws_entries_per_lane > 0 ? ws_entries_per_lane : std::max(16384, 64 * c->tree_max_ent);
@@ -1341,6 +1342,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 if (rc != MAPLE_OK) return rc;
                 for (size_t k = 0; k < zi.size(); k++) if (cur[k] < P.thrPlacement) preIdx.push_back(zi[k]);
             }
+            if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: current placements of %zu nodes on zero-length branches scored\n", tms(tStart, tnow()), zi.size());
         }
         size_t freeB = 0, totalB = 0;
         size_t budgetB = (size_t)4ull << 30;
@@ -1380,6 +1382,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 std::vector<int32_t> qf(mZ);
                 for (int k = 0; k < mZ; k++) qf[k] = Fm.frameOf[nodes[preIdx[k]]];
                 TRY(lists_to_root_frame(c, ql, qf));
+                if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: their removed lists in the root's frame\n", tms(tStart, tnow()));
                 preFrameParent = Fm.frameParent;
                 preFrameNode = Fm.frameNode;
                 useFin = true;

@@ -150,7 +150,24 @@ class SprApplier:
         moves = [int(v) for v in moves]
         pos = 0
         while pos < len(moves):
+            # A re-search from a zero-length branch without an error model is a whole-tree search (see apply_sequential): it goes
+            # alone, with the library's own budget (tables brought up to date, witness filter + clade scan) -- on the patched node
+            # records alone it is 10^5 items for ONE lane's walk, and in a speculative batch it made every batch that slow
+            # (round 4: 78 ms per move against the sequential driver's 9.6).  A batch ends in front of the next such move.
+            if (not self.dev.u) and self.dist[moves[pos]] == 0.0:
+                t0 = time.perf_counter()
+                r = self.dev.spr_search_batch(np.asarray([moves[pos]], dtype=np.int32), wide_search_budget=0, **kw)
+                self.whole_tree_searches += 1
+                self.times["search"].append(time.perf_counter() - t0)
+                self._take(moves[pos], r, 0)
+                self.batches.append((1, 1))
+                pos += 1
+                continue
             chunk = moves[pos:pos + batch]
+            for k in range(1, len(chunk)):
+                if (not self.dev.u) and self.dist[chunk[k]] == 0.0:
+                    chunk = chunk[:k]
+                    break
             t0 = time.perf_counter()
             r = self.dev.spr_search_batch(np.asarray(chunk, dtype=np.int32), wide_search_budget=-1, **kw)
             try:
