@@ -307,7 +307,9 @@ def main():
     default_line = (args.samples, args.model, args.batch, args.spr_fast, args.tree) == (100000, "ratevar", 0, False, "optimised")
     if default_line and not args.no_1m:
         a2 = argparse.Namespace(**vars(args))
-        a2.samples, a2.model, a2.batch, a2.steps, a2.warmup = 1000000, "siteerr", 131072, args.steps_1m, 2
+        # (three warm-up calls: the frontier tier's pools are sized by what the calls before asked for, and a call whose pools ran over
+        # under-reports -- at this size they stop growing after the third call)
+        a2.samples, a2.model, a2.batch, a2.steps, a2.warmup = 1000000, "siteerr", 131072, args.steps_1m, 3
         a2.no_extras, a2.no_cpu_baseline, a2.synth = True, True, "v2"
         leg2 = run_leg(a2, env)
         if env.rank == 0:

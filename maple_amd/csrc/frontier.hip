@@ -1097,16 +1097,29 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     const int gridUpd = (int)(scratchLanes / FR_BLOCK);
     const long long capBig = std::max<long long>(1 << 20, 64ll * 1024 * std::max(1, c->tree_max_ent));
     const long long capBig2 = matTree ? std::max<long long>(1 << 20, capBig / 4) : 0;
-    {   // shrink the pools proportionally if they would not fit
+    {   // What a pool already holds it keeps (a request below its capacity costs nothing, and a pool that shrinks and grows from
+        // call to call is freed and allocated again -- tens of GB: 1.3 s of a 1 000 000-tip step); what a pool would GROW by is cut
+        // down proportionally if the total would not fit.  (The temporary lists' pools used to be set back to their first guess
+        // whenever the total met the room -- always, at 1 000 000 tips: the list words overflowed on EVERY step and sent 15 000
+        // of 131 072 searches to the one-lane kernel, 550 ms.)
+        const long long curU = (long long)(F.itemsU.cap / sizeof(FItem)), curCR = (long long)(F.itemsC.cap / sizeof(FItem));
+        const long long curL = (long long)std::min(std::min(std::min(F.toffW.cap, F.toffA.cap), std::min(F.tn.cap, F.tna.cap)), F.tflag.cap);
+        const long long curW = (long long)F.tw.cap, curA = (long long)F.ta.cap;
+        const double perItem = (double)(sizeof(FItem) + sizeof(FVisit) + 12);
         const double fixed = (double)(scratchLanes + extraSlabs) * capE * 64 + (double)(capBig + capBig2) * 48;
-        const double need = (double)(capC + capR) * (sizeof(FItem) + sizeof(FVisit) + 12) + (double)capU * (sizeof(FItem) + sizeof(FVisit) + 12) + (double)capW * 8 + (double)capA * 8
-                            + (double)capL * 24 + fixed;
-        if (need > room) {
-            const double f = std::max(0.05, (room - fixed) / (need - fixed));
-            capC = std::max<long long>(1 << 16, (long long)(capC * f)); capU = std::max<long long>(1 << 14, (long long)(capU * f));
-            capR = std::max<long long>(1 << 16, (long long)(capR * f));
-            capL = 2 * capU; capW = 2 * capL * meanEnt; capA = capW;
-        }
+        const double base = (double)(curCR + curU) * perItem + (double)(curW + curA) * 8 + (double)curL * 24 + fixed;
+        const double gCR = std::max<double>(0.0, (double)(capC + capR - curCR)), gU = std::max<double>(0.0, (double)(capU - curU));
+        const double gL = std::max<double>(0.0, (double)(capL - curL)), gW = std::max<double>(0.0, (double)(capW - curW)), gA = std::max<double>(0.0, (double)(capA - curA));
+        const double growth = (gCR + gU) * perItem + (gW + gA) * 8 + gL * 24;
+        double f = 1.0;
+        if (base + growth > room && growth > 0) f = std::max(0.0, (room - base) / growth);
+        const double wantCR = std::max<double>((double)curCR, (double)curCR + f * gCR);
+        const double shareR = (double)capR / (double)(capC + capR);
+        capR = std::max<long long>(1 << 16, (long long)(wantCR * shareR)); capC = std::max<long long>(1 << 16, (long long)wantCR - capR);
+        capU = std::max<long long>(1 << 14, std::max(curU, (long long)(curU + f * gU)));
+        capL = std::max<long long>(2 * (1 << 14), std::max(curL, (long long)(curL + f * gL)));
+        capW = std::max<long long>(1 << 20, std::max(curW, (long long)(curW + f * gW)));
+        capA = std::max<long long>(1 << 20, std::max(curA, (long long)(curA + f * gA)));
     }
     const long long capRecs = std::max<long long>(1 << 14, (long long)m * 16);
     auto grow = [](size_t want, size_t cap) { return want <= cap ? cap : std::max(want, cap + cap / 2); };
@@ -1392,6 +1405,11 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     };
     { const int rc_ = finishStage(); if (rc_) return bail(rc_); }
     if (dbgTime) fprintf(stderr, "[maple]   frontier +%.1f ms: replay, refinement, final selection done; results on the host\n", sinceEnter());
+    if (dbgTime && hc.overflow)
+        fprintf(stderr, "[maple]   frontier pools, asked / capacity: updating items %llu / %lld, cached items %llu / %lld, roots %llu / %lld, temporary lists %llu / %lld "
+                        "(words %llu / %lld, aux %llu / %lld), pass entries %llu / %lld, of roots %llu / %lld, records %llu / %lld\n",
+                hc.usedU, fp.capU, hc.usedC, fp.capCC, hc.usedR, fp.capC - fp.capCC, hc.nLists, fp.capL, hc.usedW, fp.capW, hc.usedA, fp.capA,
+                hc.nPass, fp.capPass, hc.nPassR, fp.capPassR, hc.nRecs, fp.capRecs);
     {   // what this tier did, for maple_timing_read_kind: candidate placements of the searches it finished (SURVEY 8d bytes)
         const double meanCand = c->n_scored ? c->scored_bytes_total / c->n_scored : 0.0;
         double units = 0.0, bytes = 0.0;
