@@ -531,8 +531,8 @@ def run_leg(args, env):
         try:
             pmc = json.load(open(path))
             w = pmc["workload"]
-            if (w["samples"], w["model"], w["batch"], w["n_gpus"], w.get("tree", "truth"), w.get("refs", "none")) == \
-                    (args.samples, args.model, B, world, args.tree, refs) \
+            if (w["samples"], w["model"], w["batch"], w["n_gpus"], w.get("tree", "truth"), w.get("refs", "none"), w.get("synth", "v1")) == \
+                    (args.samples, args.model, B, world, args.tree, refs, bt.synth) \
                     and "traffic_bytes_per_step" in pmc:
                 traffic = {k: v / max(1.0, pmc["launches_per_step"][k]) for k, v in pmc["traffic_bytes_per_step"].items()}
                 pmc_issue = pmc.get("issue", {})
@@ -646,7 +646,7 @@ def run_leg(args, env):
                                       "tree mirror replicated, one all-gather of proposed moves per step",
                        "setup_s": round(setup_s, 1),
                        "setup_breakdown_s": {"synthetic_input": round(gen_s, 1), "tip_lists_and_upload": round(tips_s, 1),
-                                             "generator": data.meta.get("generator", "synth v1 (maple_amd.synth.make_dataset)")},
+                                             "generator": data.meta.get("generator", "synth v1 (maple_amd.synth.make_dataset)"), "synth": bt.synth},
                        "resident_inputs": {"genome_lists": int(n_lists_res), "list_bytes": int(8 * n_ent_res + 8 * n_aux_res),
                                            "tree_upload_ms": round(tree_upload_ms, 1),
                                            "note": "lists and tree tables are in HBM when the timed region starts; a step's own "

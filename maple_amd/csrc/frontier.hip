@@ -566,59 +566,67 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
             // (failedPasses by rank in an array of its own -- lpos, which the layout is done with: a store into the records would
             // throw their cache line out of L1 under the scan, and every record would come from L2 again)
             int32_t *const failsAt = fp.lpos;
-            // (the record that follows is asked for while this one is worked on: most steps go to it)
-            FVisit nxt = fp.visit[i < end ? i : 0], nxt2 = fp.visit[i + 1 < end ? i + 1 : 0];
-            while (i < end) {
-                const FVisit rec = nxt;
-                const FVisit ahead = nxt2;
-                const FVisit ahead2 = fp.visit[i + 2 < end ? i + 2 : i];
-                const int size = rec.size;
-                long long step = size;
-                if (!(rec.flags & FI_DEAD)) {
-                    int fails = rec.parent < 0 ? 0 : failsAt[rec.parent];
-                    const double mp = rec.midProb;
-                    if (nShort && rec.parent >= 0) {                            // (after an event only: two item records per visit)
-                        const int hr = item_of(fp, rec.ref).hRpr, hp = item_of(fp, fp.visit[rec.parent].ref).hRpr;
-                        if (hr != hp)
-                            for (int j = 0; j < nShort; j++) if (hShort[j] == hp && (long long)rec.parent > rankShort[j]) marked = true;
-                        if (marked) break;
-                    }
-                    if (rec.flags & FI_SCORED) {
-                        nApp++;
-                        const bool list = (rec.dir == 0) ? (mp > best - P.thrOptTopo) : (mp >= best - P.thrOptTopo);   // M:7071 / 7293
-                        if (list) {
-                            const int ref = rec.ref;
-                            item_of(fp, ref).next = FR_NONE;
-                            if (slTail == FR_NONE) slHead = ref; else item_of(fp, slTail).next = ref;
-                            slTail = ref;
+            // The records are read EIGHT at a time (independent loads, one wait) and worked through in order while the walk goes to
+            // the record that follows; a skip over a subtree starts the next block at the place it lands.  (One record per
+            // iteration, asked for two iterations ahead: ~0.5 us per record for the longest search of a round -- a 128-byte line
+            // holds four records and the next line was a miss every time: 7.8 ms.)
+            bool stop = false;
+            while (i < end && !stop) {
+                constexpr int BLK = 8;
+                FVisit w[BLK];
+#pragma unroll
+                for (int k = 0; k < BLK; k++) w[k] = fp.visit[i + k < end ? i + k : end - 1];
+                const long long i0 = i;
+#pragma unroll
+                for (int k = 0; k < BLK; k++) {
+                    if (stop || i != i0 + k || i >= end) continue;
+                    const FVisit rec = w[k];
+                    const int size = rec.size;
+                    long long step = size;
+                    if (!(rec.flags & FI_DEAD)) {
+                        int fails = rec.parent < 0 ? 0 : failsAt[rec.parent];
+                        const double mp = rec.midProb;
+                        if (nShort && rec.parent >= 0) {                            // (after an event only: two item records per visit)
+                            const int hr = item_of(fp, rec.ref).hRpr, hp = item_of(fp, fp.visit[rec.parent].ref).hRpr;
+                            if (hr != hp)
+                                for (int j = 0; j < nShort; j++) if (hShort[j] == hp && (long long)rec.parent > rankShort[j]) marked = true;
+                            if (marked) stop = true;
                         }
-                        if (mp > best) {
-                            best = mp; fails = 0;
-                            // (M:7087: the reference shortens the branch's removed list in place here; if that changes the list, the
-                            // one-lane kernel takes the search)
-                            if (rec.dir == 0) {
-                                const int hr = item_of(fp, rec.ref).hRpr, lvl = frpr_marked(fp, S, hr);
-                                if (lvl == 2) { marked = true; break; }
-                                if (lvl == 1) {
-                                    bool known = false;
-                                    for (int j = 0; j < nShort; j++) known |= hShort[j] == hr;
-                                    if (!known) {
-                                        if (nShort == 4) { marked = true; break; }
-                                        hShort[nShort] = hr; rankShort[nShort] = i; nShort++;
+                        if (rec.flags & FI_SCORED) {
+                            nApp++;
+                            const bool list = (rec.dir == 0) ? (mp > best - P.thrOptTopo) : (mp >= best - P.thrOptTopo);   // M:7071 / 7293
+                            if (list) {
+                                const int ref = rec.ref;
+                                item_of(fp, ref).next = FR_NONE;
+                                if (slTail == FR_NONE) slHead = ref; else item_of(fp, slTail).next = ref;
+                                slTail = ref;
+                            }
+                            if (mp > best) {
+                                best = mp; fails = 0;
+                                // (M:7087: the reference shortens the branch's removed list in place here; if that changes the list, the
+                                // one-lane kernel takes the search)
+                                if (rec.dir == 0) {
+                                    const int hr = item_of(fp, rec.ref).hRpr, lvl = frpr_marked(fp, S, hr);
+                                    if (lvl == 2) { marked = true; stop = true; }
+                                    if (lvl == 1) {
+                                        bool known = false;
+                                        for (int j = 0; j < nShort; j++) known |= hShort[j] == hr;
+                                        if (!known) {
+                                            if (nShort == 4) { marked = true; stop = true; }
+                                            else { hShort[nShort] = hr; rankShort[nShort] = i; nShort++; }
+                                        }
                                     }
                                 }
                             }
+                            else if (mp < (rec.lastLK - P.thrConsec)) fails++;
                         }
-                        else if (mp < (rec.lastLK - P.thrConsec)) fails++;
+                        const bool within = mp > (best - P.thrLKtopology);
+                        const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);
+                        if (go && size > 1) failsAt[i] = fails;                    // (read by the item's children only)
+                        if (go) step = 1;
                     }
-                    const bool within = mp > (best - P.thrLKtopology);
-                    const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);
-                    if (go && size > 1) failsAt[i] = fails;                    // (read by the item's children only)
-                    if (go) step = 1;
+                    i += step;
                 }
-                i += step;
-                if (step == 1) { nxt = ahead; nxt2 = ahead2; }
-                else { nxt = fp.visit[i < end ? i : end - 1]; nxt2 = fp.visit[i + 1 < end ? i + 1 : end - 1]; }
             }
         } else {
         int top = FR_NONE;

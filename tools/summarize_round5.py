@@ -13,7 +13,7 @@ import sys
 name, out = sys.argv[1], sys.argv[2]
 extra = sys.argv[3] if len(sys.argv) > 3 else ""
 commit = sys.argv[4] if len(sys.argv) > 4 else None
-KERNELS = ("k_fr_pass", "k_fr_wide_frames", "k_fr_cached", "k_fr_replay_wide", "k_fr_layout_sizes", "k_fr_layout_place", "k_fr_sort_level", "k_wit_score", "k_wit_pairs", "k_wit_hist", "k_fr_updating_wave", "k_fr_updating", "k_fr_replay", "k_fr_refine", "k_fr_begin", "k_append_queries_lds",
+KERNELS = ("k_fr_pass", "k_fr_wide_frames", "k_fr_cached", "k_fr_replay_wide", "k_fr_layout_sizes", "k_fr_layout_place", "k_fr_sort_level", "k_wit_score", "k_wit_pairs", "k_wit_hist", "k_fr_updating_wave_s", "k_fr_updating_wave", "k_fr_updating", "k_fr_replay", "k_fr_refine", "k_fr_begin", "k_append_queries_lds",
            "k_append_queries", "k_spr_search_assisted", "k_spr_search", "k_finite_prefix")
 
 
@@ -45,7 +45,7 @@ except Exception as e:                                                     # noq
     lines.append(f"(no bench line: {e})\n")
 st = one(out + "/stats/*/*_kernel_stats.csv")
 if st:
-    lines.append("## kernel_stats.csv of the traced run (1 warm-up + 2 timed steps, plus tree build and branch-length passes)\n\n"
+    lines.append("## kernel_stats.csv of the traced run (1 warm-up + 2 timed steps + 1 step after a re-upload of the tree, plus tree build and branch-length passes)\n\n"
                  "| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|\n")
     for i, r in enumerate(csv.DictReader(open(st))):
         if i < 16:
@@ -73,7 +73,7 @@ if f:
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_calib_write" in r["Kernel_Name"]]
     if len(v) >= 2:
         wcal = {"stream": v[0] * 1024 / (2 << 30), "per_line_store": v[1] * 1024 / ((2 << 30) / 8)}
-STEPS = 3.0
+STEPS = 4.0   # (1 warm-up + 2 timed steps + the step after the re-upload)
 
 
 def tot(d, c):
@@ -83,7 +83,7 @@ def tot(d, c):
 
 lines.append("\n## PMC, summed over a kernel's launches, per STEP of the bench (a step is one deep SPR round)\n\n")
 lines.append("| kernel | launches / step | FETCH_SIZE GB (calibrated) | WRITE_SIZE GB | VALU / SALU / VMEM_RD / LDS / BRANCH wave-insts (M) | "
-             "WAVE_CYCLES / WAIT_ANY / ACTIVE_VALU / ACTIVE_LDS (M quad-cycles) | LDS_IDX_ACTIVE / BANK_CONFLICT (M) | VGPR SGPR LDS scratch |\n"
+             "WAVE_CYCLES / WAIT_ANY / WAIT_INST_ANY / ACTIVE_VALU / ACTIVE_LDS (M quad-cycles) | LDS_IDX_ACTIVE / BANK_CONFLICT (M) | VGPR SGPR LDS scratch |\n"
              "|---|---|---|---|---|---|---|---|\n")
 traffic = {}
 issue = {}
@@ -98,13 +98,13 @@ for k in KERNELS:
     insts = sum(tot(d, c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM")
                 if tot(d, c) == tot(d, c))
     issue[k] = {"wave_insts_per_step": insts, "wave_quad_cycles_per_step": tot(d, "SQ_WAVE_CYCLES"), "wait_any": tot(d, "SQ_WAIT_ANY"),
-                "active_valu": tot(d, "SQ_ACTIVE_INST_VALU"), "active_lds": tot(d, "SQ_ACTIVE_INST_LDS"),
+                "wait_inst_any": tot(d, "SQ_WAIT_INST_ANY"), "active_valu": tot(d, "SQ_ACTIVE_INST_VALU"), "active_lds": tot(d, "SQ_ACTIVE_INST_LDS"),
                 "lds_idx_active": tot(d, "SQ_LDS_IDX_ACTIVE"), "lds_bank_conflict": tot(d, "SQ_LDS_BANK_CONFLICT"),
                 "busy_cycles": tot(d, "SQ_BUSY_CYCLES")}
     lines.append(f"| `{k}` | {n:.1f} | {fetch_b/1e9:.2f} | {write_b/1e9:.2f} | "
                  f"{tot(d,'SQ_INSTS_VALU')/1e6:.0f} / {tot(d,'SQ_INSTS_SALU')/1e6:.0f} / {tot(d,'SQ_INSTS_VMEM_RD')/1e6:.0f} / "
                  f"{tot(d,'SQ_INSTS_LDS')/1e6:.0f} / {tot(d,'SQ_INSTS_BRANCH')/1e6:.0f} | "
-                 f"{tot(d,'SQ_WAVE_CYCLES')/1e6:.0f} / {tot(d,'SQ_WAIT_ANY')/1e6:.0f} / {tot(d,'SQ_ACTIVE_INST_VALU')/1e6:.0f} / {tot(d,'SQ_ACTIVE_INST_LDS')/1e6:.0f} | "
+                 f"{tot(d,'SQ_WAVE_CYCLES')/1e6:.0f} / {tot(d,'SQ_WAIT_ANY')/1e6:.0f} / {tot(d,'SQ_WAIT_INST_ANY')/1e6:.0f} / {tot(d,'SQ_ACTIVE_INST_VALU')/1e6:.0f} / {tot(d,'SQ_ACTIVE_INST_LDS')/1e6:.0f} | "
                  f"{tot(d,'SQ_LDS_IDX_ACTIVE')/1e6:.0f} / {tot(d,'SQ_LDS_BANK_CONFLICT')/1e6:.0f} | {' '.join(str(x) for x in meta[k])} |\n")
 if wcal:
     lines.append(f"\nWRITE_SIZE calibration (k_calib_write over a 2 GiB buffer): a coalesced 8-byte stream is reported as "
@@ -135,7 +135,8 @@ if bench:
           "issue": issue,
           "calibration": {"fetch_counted_over_read": calib, "write": wcal},
           "workload": {"samples": w["samples"], "model": w["model"], "batch": w["searches_per_step"], "n_gpus": bench["n_gpus"],
-                       "tree": w.get("tree"), "refs": (w.get("local_references") or {}).get("form", "none")},
+                       "tree": w.get("tree"), "refs": (w.get("local_references") or {}).get("form", "none"),
+                       "synth": (w.get("setup_breakdown_s") or {}).get("synth", "v1")},
           "library_commit": commit,
           "source": f"profiles/{name}.md"}
     json.dump(pj, open(os.path.join(out, "pmc_spr.json"), "w"), indent=1)
