@@ -511,11 +511,11 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_layout_place(FPools fp, int lev
 // what the exact walk of one search leaves behind: the short list, the candidate count, the records to refine
 // (hShort: the removed lists the reference shortened in place on the way, M:7087 -- see k_fr_replay)
 __device__ inline void fr_replay_done(const SearchParams &P, const FPools &fp, SearchOut *out, int q, FSearch &S, int slHead, int nApp, bool handBack,
-                                      const int *hShort = nullptr, int nShort = 0)
+                                      const int *hShort = nullptr, int nShort = 0, int reason = 0)
 {
     // (the list the search starts from, bestRemovedPartials when nothing better is found, shortened: the one-lane kernel)
-    for (int k = 0; k < nShort; k++) if (hShort[k] == S.hRpr0) handBack = true;
-    if (handBack) { S.state = FS_FALLBACK; out[q].status = FR_STATUS_FALLBACK; return; }
+    for (int k = 0; k < nShort; k++) if (hShort[k] == S.hRpr0 && !handBack) { handBack = true; reason = 4; }
+    if (handBack) { S.state = FS_FALLBACK; out[q].status = FR_STATUS_FALLBACK; atomicAdd(&fp.ctr->fbReason[reason & 7], 1); return; }
     S.slHead = slHead; S.nApp = nApp;
     // the short-listed branches that are refined (M:7465: within thresholdLogLKoptimizationTopology of the ORIGINAL cost)
     int cnt = 0;
@@ -550,6 +550,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
         double best = S.curLK;
         int nApp = 0, slHead = FR_NONE, slTail = FR_NONE;
         bool marked = false;
+        int why = 0;                                                        // 1 a merge within tolerance, 2 a list re-expressed from a shortened one, 3 a fifth list, 4 the search's own first list, 5 no layout
         // The reference shortens a branch's removed list IN PLACE when the branch beats the running best on the way down (M:7087).
         // A list that shorten() would change is marked by the expansion (shorten_would_merge): level 2 -- tails merged within a
         // tolerance: another list to every reader -- hands the search to the one-lane kernel.  Level 1 -- the entries that go
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
                             const int hr = item_of(fp, rec.ref).hRpr, hp = item_of(fp, fp.visit[rec.parent].ref).hRpr;
                             if (hr != hp)
                                 for (int j = 0; j < nShort; j++) if (hShort[j] == hp && (long long)rec.parent > rankShort[j]) marked = true;
-                            if (marked) stop = true;
+                            if (marked) { stop = true; why = 2; }
                         }
                         if (rec.flags & FI_SCORED) {
                             nApp++;
@@ -607,12 +608,12 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
                                 // one-lane kernel takes the search)
                                 if (rec.dir == 0) {
                                     const int hr = item_of(fp, rec.ref).hRpr, lvl = frpr_marked(fp, S, hr);
-                                    if (lvl == 2) { marked = true; stop = true; }
+                                    if (lvl == 2) { marked = true; stop = true; why = 1; }
                                     if (lvl == 1) {
                                         bool known = false;
                                         for (int j = 0; j < nShort; j++) known |= hShort[j] == hr;
                                         if (!known) {
-                                            if (nShort == 4) { marked = true; stop = true; }
+                                            if (nShort == 4) { marked = true; stop = true; why = 3; }
                                             else { hShort[nShort] = hr; rankShort[nShort] = i; nShort++; }
                                         }
                                     }
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
                 }
                 if (mp > best) {
                     best = mp; fails = 0;
-                    if (it.dir == 0 && frpr_marked(fp, S, it.hRpr)) { marked = true; break; }   // (M:7087, see above)
+                    if (it.dir == 0 && frpr_marked(fp, S, it.hRpr)) { marked = true; why = 5; break; }   // (M:7087, see above)
                 }
                 else if (mp < (it.lastLK - P.thrConsec)) fails++;
             }
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
             push(it.child1, fails);
         }
         }
-        fr_replay_done(P, fp, out, q, S, slHead, nApp, marked, hShort, nShort);
+        fr_replay_done(P, fp, out, q, S, slHead, nApp, marked, hShort, nShort, why);
     }
 }
 
@@ -1165,7 +1166,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, F.perm3.reserve_exact(std::max(F.perm3.cap, (size_t)fp.capU)));
     HIPCK(c, F.perm4.reserve_exact(std::max(F.perm4.cap, (size_t)fp.capU)));
     fp.perm = F.perm.p; fp.perm2 = F.perm2.p; fp.perm3 = F.perm3.p; fp.perm4 = F.perm4.p;
-    fp.waveAllBelow = c->tuning.waveAllBelow > 0 ? c->tuning.waveAllBelow : (c->tuning.waveAllBelow < 0 ? 0 : 8192);
+    fp.waveAllBelow = c->tuning.waveAllBelow > 0 ? c->tuning.waveAllBelow : (c->tuning.waveAllBelow < 0 ? 0 : 49152);
     // the visiting-order layout of the items (k_fr_layout_*): one 32-byte record per item, the levels' ranges, per-search bases
     fp.maxLevels = 4096;
     fp.capVisit = fp.capU + fp.capC;
@@ -1248,7 +1249,9 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     int levels = 0;
     // (many short-lived workgroups rather than a grid-stride loop over few long-lived ones: wavefront slots come free all the
     // time, and the dispatcher hands them to the higher-priority stream first)
-    const int gridCached = 16384;
+    // (a launch of 16 384 workgroups costs 0.4-0.5 ms even when it finds ten thousand items: the grid goes with the batch -- a
+    // round's largest launch holds ~21 items per search)
+    const int gridCached = (int)std::min<long long>(16384, std::max<long long>(512, (long long)m / 12));
     // items whose two lists add up to this many entries are walked by a wavefront each (k_fr_updating_wave: 54 KB of LDS per
     // wavefront, two per compute unit)
     // (a handful of searches -- the re-search of a proposed move -- wait for every single item: all of them by wavefronts)
@@ -1380,16 +1383,17 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     }
     TRY(maple_internal_ev_pair(c, &er0, &er1, MAPLE_K_FR_REPLAY, (double)m, 0.0));
     HIPCK(c, hipEventRecord(er0, s));
+    const int gridLayout = (int)std::min<long long>(1024, std::max<long long>(64, (long long)m / 64));   // (~100 small launches: the grid goes with the batch)
     if (levels <= fp.maxLevels && launchesC <= fp.maxLevels && fp.visit) {
         // the items of every search in the order its walk visits them: sizes bottom-up, ranks top-down, one record each
         HIPCK(c, hipMemsetAsync(fp.lpos, 0xFF, (size_t)fp.capVisit * sizeof(int32_t), s));   // (-1: not laid out)
-        for (int l = launchesC - 1; l >= 0; l--) k_fr_layout_sizes<<<1024, FR_BLOCK, 0, s>>>(fp, l, 1);
-        for (int l = levels - 1; l >= 0; l--) k_fr_layout_sizes<<<1024, FR_BLOCK, 0, s>>>(fp, l, 0);
+        for (int l = launchesC - 1; l >= 0; l--) k_fr_layout_sizes<<<gridLayout, FR_BLOCK, 0, s>>>(fp, l, 1);
+        for (int l = levels - 1; l >= 0; l--) k_fr_layout_sizes<<<gridLayout, FR_BLOCK, 0, s>>>(fp, l, 0);
         k_fr_layout_totals<<<gridN, FR_BLOCK, 0, s>>>(m, fp);
         k_fr_layout_scan<<<1, 1024, 0, s>>>(m, fp.tot, fp.vbase);
         k_fr_layout_seeds<<<gridN, FR_BLOCK, 0, s>>>(m, fp);
-        for (int l = 0; l < levels; l++) k_fr_layout_place<<<1024, FR_BLOCK, 0, s>>>(fp, l, 0);
-        for (int l = 0; l < launchesC; l++) k_fr_layout_place<<<1024, FR_BLOCK, 0, s>>>(fp, l, 1);
+        for (int l = 0; l < levels; l++) k_fr_layout_place<<<gridLayout, FR_BLOCK, 0, s>>>(fp, l, 0);
+        for (int l = 0; l < launchesC; l++) k_fr_layout_place<<<gridLayout, FR_BLOCK, 0, s>>>(fp, l, 1);
         HIPCK(c, hipGetLastError());
         TRY(stage("k_fr_layout"));
     } else fp.visit = nullptr;
@@ -1413,6 +1417,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     };
     { const int rc_ = finishStage(); if (rc_) return bail(rc_); }
     if (dbgTime) fprintf(stderr, "[maple]   frontier +%.1f ms: replay, refinement, final selection done; results on the host\n", sinceEnter());
+    if (dbgTime && (hc.fbReason[0] | hc.fbReason[1] | hc.fbReason[2] | hc.fbReason[3] | hc.fbReason[4] | hc.fbReason[5]))
+        fprintf(stderr, "[maple]   exact walk handed searches to the one-lane kernel: %d a merge within tolerance, %d a list re-expressed from a shortened one, "
+                        "%d a fifth shortened list, %d the search's own first list shortened, %d marked list without a layout, %d other\n",
+                hc.fbReason[1], hc.fbReason[2], hc.fbReason[3], hc.fbReason[4], hc.fbReason[5], hc.fbReason[0]);
     if (dbgTime && hc.overflow)
         fprintf(stderr, "[maple]   frontier pools, asked / capacity: updating items %llu / %lld, cached items %llu / %lld, roots %llu / %lld, temporary lists %llu / %lld "
                         "(words %llu / %lld, aux %llu / %lld), pass entries %llu / %lld, of roots %llu / %lld, records %llu / %lld\n",

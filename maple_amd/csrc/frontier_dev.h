@@ -111,6 +111,7 @@ struct FCtr {                          // device-side bookkeeping of the level l
     alignas(128) unsigned long long scoredC;
     unsigned long long bytesC;         // cached-regime items scored by k_fr_cached and their SURVEY 8d bytes (8 E + 8 A + 8)
     int32_t overflow, nLevels, nLevelsC;
+    int32_t fbReason[8];               // searches handed to the one-lane kernel by the exact walk, by reason (k_fr_replay; printed with verbose)
 #ifdef MAPLE_SPR_PROFILE
     unsigned long long dbgCnt[8], dbgT[8], dbgMax[8];   // k_fr_updating's one-lane items by size (entries of the two lists): count, ticks, slowest
     unsigned long long dbgC[8];        // k_fr_cached per wavefront-iteration: iterations, ticks before the walk (item, search, node, list table),
