@@ -181,6 +181,38 @@ __global__ void k_fr_snap_c(FCtr *ctr, long long capCC, long long capPass, unsig
 // The item's hRpr is still the list of the item that pushed it; here it goes through the branch (passGenomeListThroughBranch,
 // M:7111-7118 / 7148-7155 on the way down, 7359-7366 / 7388-7395 on the way up).  One lane per such item (about one push in a
 // hundred crosses a reference branch); a list that shorten() (M:7087) would change hands its search to the one-lane kernel.
+// A launch with FEW such items lasts as long as its slowest list, and one lane takes 0.1-0.4 ms for one (0.35 ms per launch,
+// 56 launches per round): those launches take a WAVEFRONT per item (wave_pass, frontier_dev.h: one lane per entry of the list).
+// With many items the lanes win: 65 536 of them at 0.3 ms against 4 096 wavefronts at ~50 us (a round's large launches hold
+// ~170 000 such items: 10-15 ms per launch by wavefronts, measured, against 4-5).
+#define FR_PASS_WAVE_BELOW 8192
+template <bool RV, bool U, bool SS>
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_pass_wave(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, FPools fp)
+{
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    // (the launch's two kinds of items: pushed by cached-regime items, and roots)
+    const long long loA = (long long)fp.ctr->loP, nA = (long long)fp.ctr->hiP - loA, loB = (long long)fp.ctr->loPR, nB = (long long)fp.ctr->hiPR - loB;
+    if (nA + nB > FR_PASS_WAVE_BELOW) return;                                // (k_fr_pass: one lane per item)
+    for (long long i = wave; i < nA + nB; i += nWaves) {
+        FItem &it = item_of(fp, i < nA ? fp.passList[loA + i] : fp.passListR[loB + (i - nA)]);
+        FSearch &S = fp.S[it.q];
+        if (!fs_live(S.state)) continue;
+        const NodeRec r1 = T.nd[it.t1];
+        // dir 0: came down the branch above t1; dir 1 / 2: came up the branch above t1's child 0 / 1
+        const int mutId = it.dir == 0 ? r1.mutId : T.nd[it.dir == 1 ? r1.c0 : r1.c1].mutId;
+        const int h = wave_pass(c, fp, av, it.hRpr, mutId, it.dir != 0, true);
+        if (lane == 0) {
+            if (!fvalid(h)) S.state = FS_FALLBACK;
+            else { it.hRpr = h; it.flags &= (uint8_t)~FI_NEEDPASS; }
+        }
+    }
+}
+
 template <bool RV, bool U, bool SS>
 __global__ __launch_bounds__(FR_BLOCK) void k_fr_pass(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, FPools fp, long long slabBase)
 {
@@ -192,6 +224,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_pass(const DevModel *__restrict
     const long long slab = slabBase + laneId;                                // (scratch slabs of its own: it runs next to k_fr_updating)
     // (the launch's two kinds of items: pushed by cached-regime items, and roots)
     const long long loA = (long long)fp.ctr->loP, nA = (long long)fp.ctr->hiP - loA, loB = (long long)fp.ctr->loPR, nB = (long long)fp.ctr->hiPR - loB;
+    if (nA + nB <= FR_PASS_WAVE_BELOW) return;                               // (k_fr_pass_wave: a wavefront per item)
     for (long long i = laneId; i < nA + nB; i += (long long)gridDim.x * blockDim.x) {
         FItem &it = item_of(fp, i < nA ? fp.passList[loA + i] : fp.passListR[loB + (i - nA)]);
         FSearch &S = fp.S[it.q];
@@ -1313,6 +1346,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, hipEventRecord(b0, s2));
         if (fp.mat) {
             // the removed lists of the launch's items that crossed a reference branch, ahead of the kernel that reads them
+            FR_DISPATCH3(c, k_fr_pass_wave, <<<1024, FR_BLOCK, 0, s2>>>(c->d_model, av, T, fp));
             FR_DISPATCH3(c, k_fr_pass, <<<256, FR_BLOCK, 0, s2>>>(c->d_model, av, T, fpC, scratchLanes + 2048));
             TRY(stage("k_fr_pass"));
         }

@@ -224,6 +224,17 @@ __device__ inline int fstore(const FPools &fp, const Writer &wr)
     return (int)id;
 }
 
+__device__ inline int wave_excl_sum_f(int v, int lane, int &total)
+{
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        incl += (lane >= off) ? t : 0;
+    }
+    total = __shfl(incl, 63);
+    return incl - v;
+}
+
 // would shorten() (M:3721-3745) change this list?  (the absorb test of shorten_walk, genome_dev.h: a run of R entries of one
 // kind collapses into its LAST entry, each candidate compared with the run's FIRST entry)
 //   0  no;
@@ -289,6 +300,130 @@ __device__ inline int fpass_removed(const C &c, const FPools &fp, const ArenaVie
     fp.tflag[r] = (uint8_t)shorten_would_merge(c, fref(l), l.n);
     return r;
 }
+// ---- passGenomeListThroughBranch (M:3749-3877) by a whole WAVEFRONT: the handle of a new temporary list, h itself when the
+// branch carries no mutations, -2 when there is no room.  Every lane calls with the same arguments and gets the result.
+// The walk of pass_walk (genome_dev.h) needs nothing from the entries before but the position reached, and every packed entry
+// carries its last position: lane i takes entry i, finds the branch's mutations inside it (two binary searches over the sorted
+// mutation list), counts what it writes -- an N entry or a single-site entry one entry; a reference run one entry per mutated
+// site plus the stretches between them -- and, after a prefix sum over the wavefront, writes them where they belong in the new
+// list.  The list is written straight into the temporary lists' pool (room for the most a pass can add: two entries per
+// mutation; what is not used stays empty).  One lane takes ~1.2 us per entry (0.1-0.4 ms per list, up to four lists per item
+// next to a reference branch: the slowest wavefront-wide items, 1.4 ms, and the 0.35 ms floor of every k_fr_pass launch).
+// `removed`: the list is a removed list -- graded for the in-place shorten() of M:7087 (tflag, see shorten_would_merge).
+template <class C>
+__device__ inline int wave_pass(const C &c, const FPools &fp, const ArenaViewS &av, const int h, const int mutId, const bool dirUp, const bool removed)
+{
+    if (!fvalid(h) || mutId < 0) return h;
+    const int cnt = fp.mv.cnt[mutId];
+    if (cnt == 0) return h;
+    const int lane = threadIdx.x & 63;
+    const FList l = flist(av, fp, h);
+    const int32_t *mut = fp.mv.mut3 + 3 * fp.mv.off[mutId];
+    const unsigned long long *lw = (const unsigned long long *)l.w;
+    auto bc = [](unsigned long long x) {
+        return ((unsigned long long)(uint32_t)__shfl((int)(x >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)x, 0, 64);
+    };
+    auto sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // room for the most the pass can write: an entry per mutated site and one stretch before it (+ one after the last), each
+    // piece of a run with the run's tail (<= 2 doubles)
+    const int capN = l.n + 2 * cnt, capA = l.na + 4 * cnt;
+    unsigned long long id = 0, ow = 0, oa = 0;
+    if (lane == 0) {
+        id = atomicAdd(&fp.ctr->nLists, 1ull);
+        ow = atomicAdd(&fp.ctr->usedW, (unsigned long long)capN);
+        oa = atomicAdd(&fp.ctr->usedA, (unsigned long long)capA);
+    }
+    id = bc(id); ow = bc(ow); oa = bc(oa);
+    if ((long long)id >= fp.capL || (long long)(ow + capN) > fp.capW || (long long)(oa + capA) > fp.capA) {
+        if (lane == 0) fp.ctr->overflow = 1;
+        return -2;
+    }
+    uint2 *dw = fp.tw + ow;
+    double *da = fp.ta + oa;
+    auto lower = [&](int pos) {                                             // mutations before position `pos`
+        int lo = 0, hi = cnt;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (mut[3 * mid] < pos) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    int nOut = 0, nAux = 0;
+    for (int base = 0; base < l.n; base += 64) {
+        const int i = base + lane;
+        int cntOut = 0, auxOut = 0, a = 0, b = 0, prevEnd = 0, tail = 0;
+        Ent e;
+        e.type = 5; e.pos = 0; e.ref = 0; e.hasD0 = e.hasD1 = e.flag = false; e.d0 = e.d1 = 0.0; e.vec = nullptr;
+        if (i < l.n) {
+            decode_word(lw[i], l.aux, e);
+            prevEnd = i > 0 ? (int)(uint32_t)lw[i - 1] : 0;
+            a = lower(prevEnd + 1); b = lower(e.pos + 1);                    // the mutations at prevEnd < position <= e.pos
+            tail = (e.hasD0 ? 1 : 0) + (e.hasD1 ? 1 : 0);
+            if (e.type == 5) cntOut = 1;                                     // (mutations inside a run of N are passed over)
+            else if (e.type == 4) {
+                int last = prevEnd;
+                for (int k = a; k < b; k++) { const int mp = mut[3 * k]; cntOut += (mp > last + 1) ? 2 : 1; last = mp; }
+                if (last < e.pos) cntOut++;
+                auxOut = cntOut * tail;
+            } else { cntOut = 1; auxOut = tail + (e.type == 6 ? 4 : 0); }
+        }
+        int totN, totA;
+        int idx = nOut + wave_excl_sum_f(cntOut, lane, totN);
+        int ao = nAux + wave_excl_sum_f(auxOut, lane, totA);
+        if (i < l.n) {
+            auto put = [&](int type, int pos, int ref, bool tails, bool vec) {
+                const uint32_t meta = (uint32_t)type | ((uint32_t)ref << 3) | ((tails && e.hasD0) ? 1u << 5 : 0u) | ((tails && e.hasD1) ? 1u << 6 : 0u)
+                                      | ((tails && e.flag) ? 1u << 7 : 0u) | ((uint32_t)ao << 8);
+                dw[idx++] = make_uint2((uint32_t)pos, meta);
+                if (tails && e.hasD0) da[ao++] = e.d0;
+                if (tails && e.hasD1) da[ao++] = e.d1;
+                if (vec) { da[ao] = e.vec[0]; da[ao + 1] = e.vec[1]; da[ao + 2] = e.vec[2]; da[ao + 3] = e.vec[3]; ao += 4; }
+            };
+            if (e.type == 5) put(5, e.pos, 0, false, false);
+            else if (e.type == 4) {
+                // split the reference run around mutated sites; each mutated site becomes an explicit nucleotide
+                int last = prevEnd;
+                for (int k = a; k < b; k++) {
+                    const int mp = mut[3 * k], from = mut[3 * k + 1], to = mut[3 * k + 2];
+                    if (mp > last + 1) put(4, mp - 1, 0, true, false);
+                    put(dirUp ? to : from, mp, dirUp ? from : to, true, false);
+                    last = mp;
+                }
+                if (last < e.pos) put(4, e.pos, 0, true, false);
+            } else if (a < b) {                                              // a single-site entry on a mutated site
+                const int newRef = dirUp ? mut[3 * a + 1] : mut[3 * a + 2];
+                if (e.type == 6) put(6, e.pos, newRef, true, true);
+                else if (e.type == newRef) put(4, e.pos, 0, true, false);    // equals the new reference -> R
+                else put(e.type, e.pos, newRef, true, false);
+            } else put(e.type, e.pos, e.ref, true, e.type == 6);
+        }
+        nOut += totN; nAux += totA;
+    }
+    __threadfence();
+    sync();
+    int level = 0;
+    if (removed) {
+        // would shorten() (M:7087) change the new list?  Neighbouring R entries of one kind without tails: yes, exactly (level 1);
+        // with tails the answer depends on the run's first entry: lane 0 walks the list as shorten_would_merge does
+        bool plain = false, tails = false;
+        for (int j = 1 + lane; j < nOut; j += 64) {
+            const uint32_t m1 = dw[j].y, m0 = dw[j - 1].y;
+            if ((m1 & 7u) == 4u && (m0 & 7u) == 4u && ((m1 ^ m0) & 0x60u) == 0u) { if (m1 & 0x20u) tails = true; else plain = true; }
+        }
+        if (__ballot(tails)) {
+            if (lane == 0) level = shorten_would_merge(c, ListRef{dw, da}, nOut);
+            level = __shfl(level, 0, 64);
+        } else level = __ballot(plain) ? 1 : 0;
+    }
+    if (lane == 0) {
+        fp.toffW[id] = (long long)ow; fp.toffA[id] = (long long)oa; fp.tn[id] = nOut; fp.tna[id] = nAux; fp.tflag[id] = (uint8_t)level;
+    }
+    __threadfence();
+    sync();
+    return (int)id;
+}
+
 __device__ __forceinline__ int frpr_marked(const FPools &fp, const FSearch &S, const int h)
 {
     return h >= 0 ? (int)fp.tflag[h] : (h <= -10 ? S.rprMerge0 : 0);
