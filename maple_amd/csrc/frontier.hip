@@ -158,7 +158,7 @@ __global__ void k_fr_snap_u(FCtr *ctr, long long capU, long long capR, long long
         }
     }
 }
-__global__ void k_fr_snap_c(FCtr *ctr, long long capCC, long long capPass, unsigned long long *lvl, int maxLevels)
+__global__ void k_fr_snap_c(FCtr *ctr, long long capCC, long long capPass, long long capDeferred, unsigned long long *lvl, int maxLevels)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         ctr->loC = ctr->hiC; ctr->hiC = min(ctr->usedC, (unsigned long long)capCC);
@@ -167,6 +167,7 @@ __global__ void k_fr_snap_c(FCtr *ctr, long long capCC, long long capPass, unsig
         ctr->loP = ctr->hiP; ctr->hiP = min(ctr->nPass, (unsigned long long)capPass);
         ctr->loPR = ctr->hiPR; ctr->hiPR = atomicAdd(&ctr->safePassR, 0ull);
         ctr->bigUsedC = 0;
+        ctr->loD = ctr->hiD; ctr->hiD = min(ctr->nDeferred, (unsigned long long)capDeferred);
         if (lvl) {
             const int k = ctr->nLevelsC++;
             if (k < maxLevels) {
@@ -208,7 +209,12 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_pass_wave(const DevModel *__res
         const int h = wave_pass(c, fp, av, it.hRpr, mutId, it.dir != 0, true);
         if (lane == 0) {
             if (!fvalid(h)) S.state = FS_FALLBACK;
-            else { it.hRpr = h; it.flags &= (uint8_t)~FI_NEEDPASS; }
+            else {
+                it.hRpr = h;
+                const unsigned long long k = atomicAdd(&fp.ctr->nDeferred, 1ull);
+                if ((long long)k < fp.capDeferred) fp.deferred[k] = (int32_t)(&it - fp.C);
+                else { S.state = FS_FALLBACK; fp.ctr->overflow = 1; }
+            }
         }
     }
 }
@@ -235,7 +241,9 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_pass(const DevModel *__restrict
         const int h = fpass_removed(c, fp, av, slab, it.hRpr, mutId, it.dir != 0);
         if (!fvalid(h)) { S.state = FS_FALLBACK; continue; }
         it.hRpr = h;
-        it.flags &= (uint8_t)~FI_NEEDPASS;
+        const unsigned long long k = atomicAdd(&fp.ctr->nDeferred, 1ull);
+        if ((long long)k < fp.capDeferred) fp.deferred[k] = (int32_t)(&it - fp.C);
+        else { S.state = FS_FALLBACK; fp.ctr->overflow = 1; }
     }
 }
 
@@ -322,8 +330,10 @@ void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Sear
     Ctx<RV, U, SS> c(m, lds);
     const int lane = threadIdx.x & 63;
     // the launch's items: what the cached launches before it pushed, then the roots published since
+    // ... then the items of earlier launches whose removed list has been re-expressed since (deferred)
     const long long loC = (long long)fp.ctr->loC, nC = (long long)fp.ctr->hiC - loC, loR = fp.capCC + (long long)fp.ctr->loR,
-                    hi = nC + (long long)fp.ctr->hiR - (long long)fp.ctr->loR;
+                    nCR = nC + (long long)fp.ctr->hiR - (long long)fp.ctr->loR, loD = (long long)fp.ctr->loD,
+                    hi = nCR + (long long)fp.ctr->hiD - loD;
     unsigned long long nSc = 0, bSc = 0;
     for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < hi; i0 += (long long)gridDim.x * blockDim.x) {
         const long long i = i0 + threadIdx.x;
@@ -339,11 +349,12 @@ void k_fr_cached(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Sear
         bool rt = false;
         double rbl = 0.0;
         if (i < hi) {
-            FItem &it = fp.C[i < nC ? loC + i : loR + (i - nC)];
+            FItem &it = fp.C[i < nC ? loC + i : (i < nCR ? loR + (i - nC) : (long long)fp.deferred[loD + (i - nCR)])];
             FSearch &S = fp.S[it.q];
             itp = &it; Sp = &S;
             const int st = S.state;
-            if (!fs_live(st)) it.flags |= FI_DEAD;
+            if (i < nCR && (it.flags & FI_NEEDPASS)) { }                    // (pushed across a reference branch: the next launch, see FCtr::nDeferred)
+            else if (!fs_live(st)) it.flags |= FI_DEAD;
             else if (st == FS_WIDE && it.dir == 0) {                        // (the clade below it: k_fr_replay_wide)
                 // Most such clades hold no finite score at all for this search.  What the scan does with one of those only
                 // depends on the state the walk arrives with: noted here, applied by the walk itself without a scan.
@@ -850,6 +861,7 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
                     const BestRec b = br[i];
                     if (!(b.score >= S.curLK - P.thrOptTopo)) continue;
                     int ref = b.hUp;
+                    bool frames = false;
                     if (b.hDown != WR_ITEM) {
                         ref = (int)(ibase + ks++);
                         FItem &x = fp.C[ref];
@@ -858,10 +870,10 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
                         x.child0 = x.child1 = FR_NONE; x.hA = x.hB = x.hMid = -1; x.next = FR_NONE; x.failsA = 0;
                         // (the scan's removed list is its seed's: a branch in a frame nested below the seed's gets it through the
                         // reference branches in between before it is refined -- k_fr_wide_frames)
-                        if (fp.mat && b.hMid != b.hDown) { x.flags |= FI_NEEDPASS; x.hA = b.hDown; x.hB = b.hMid; }
+                        if (fp.mat && b.hMid != b.hDown) { frames = true; x.hA = b.hDown; x.hB = b.hMid; }
                     }
                     FRec &x = fp.recs[base + kk++];
-                    x.q = q; x.ref = ref; x.ok = 0; x.hRprS = -1;
+                    x.q = q; x.ref = ref; x.ok = 0; x.hRprS = frames ? FR_FRAMES : -1;
                 }
             }
         }
@@ -882,10 +894,9 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_wide_frames(const DevModel *__r
     const long long laneId = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nRecs = min((long long)fp.ctr->nRecs, fp.capRecs);
     for (long long i = laneId; i < nRecs; i += (long long)gridDim.x * blockDim.x) {
-        const FRec &R = fp.recs[i];
-        if (R.ref < 0) continue;                                            // (only the scan's entries: cached-pool items)
+        FRec &R = fp.recs[i];
+        if (R.ref < 0 || R.hRprS != FR_FRAMES) continue;                    // (only the scan's entries: cached-pool items)
         FItem &x = fp.C[R.ref];
-        if (!(x.flags & FI_NEEDPASS)) continue;
         FSearch &S = fp.S[R.q];
         if (!fs_live(S.state)) continue;
         int chain[24], n = 0;
@@ -898,7 +909,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_wide_frames(const DevModel *__r
         }
         if (!ok) { S.state = FS_FALLBACK; continue; }
         x.hRpr = h; x.hA = x.hB = -1;
-        x.flags &= (uint8_t)~FI_NEEDPASS;
+        R.hRprS = -1;
     }
 }
 
@@ -1053,7 +1064,7 @@ struct FrontierScratch {
     DevBuf<long long> toffW, toffA;
     DevBuf<int32_t> tn, tna, nodes, expQ, expNode;
     DevBuf<uint8_t> out, wideBr, tflag;
-    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, perm3, perm4, tot, lsize, lpos, lpar, passList, passListR;
+    DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, perm3, perm4, tot, lsize, lpos, lpar, passList, passListR, deferred;
     DevBuf<uint2> bw2; DevBuf<double> ba2;   // k_fr_pass's own shared scratch (it runs next to the updating levels)
     DevBuf<uint8_t> visit;
     DevBuf<unsigned long long> lvl;
@@ -1067,7 +1078,7 @@ struct FrontierScratch {
     FPools lastPools{};
     // the two kernels of a level read disjoint items (they only meet in the pools' atomic counters): the cached-regime one runs
     // on a stream of its own next to the updating one -- a level of the latter lasts as long as its slowest item, on a few lanes
-    hipStream_t side = nullptr, side2 = nullptr;     // (side2: the 512-entry class of the wavefront-wide items, next to the small class)
+    hipStream_t side = nullptr, side2 = nullptr;     // (side: the cached-regime launches; side2: the k_fr_pass kernels next to them)
     hipEvent_t evFork = nullptr, evJoin = nullptr, evFork2 = nullptr, evJoin2 = nullptr;
 };
 
@@ -1081,7 +1092,7 @@ void frontier_scratch_free(maple_ctx *c)
     F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
     F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
     F->expQ.release(); F->expNode.release();
-    F->perm.release(); F->perm2.release(); F->perm3.release(); F->perm4.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release(); F->passList.release(); F->passListR.release(); F->bw2.release(); F->ba2.release(); F->tflag.release();
+    F->perm.release(); F->perm2.release(); F->perm3.release(); F->perm4.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release(); F->passList.release(); F->passListR.release(); F->deferred.release(); F->bw2.release(); F->ba2.release(); F->tflag.release();
     if (F->evFork) (void)hipEventDestroy(F->evFork);
     if (F->evJoin) (void)hipEventDestroy(F->evJoin);
     if (F->evFork2) (void)hipEventDestroy(F->evFork2);
@@ -1222,12 +1233,14 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     // trees with MAT local references: the lists a search carries go through the reference branches it crosses
     fp.mat = c->tree_has_mut ? 1 : 0;
     fp.mv = mview(c);
-    fp.passList = nullptr; fp.capPass = 0; fp.passListR = nullptr; fp.capPassR = 0;
+    fp.passList = nullptr; fp.capPass = 0; fp.passListR = nullptr; fp.capPassR = 0; fp.deferred = nullptr; fp.capDeferred = 0;
     if (fp.mat) {
         HIPCK(c, F.passList.reserve_exact(std::max(F.passList.cap, (size_t)std::max<long long>(1 << 16, fp.capC / 8))));
         fp.passList = F.passList.p; fp.capPass = (long long)F.passList.cap;
         HIPCK(c, F.passListR.reserve_exact(std::max(F.passListR.cap, (size_t)std::max<long long>(1 << 16, (fp.capC - fp.capCC) / 4))));
         fp.passListR = F.passListR.p; fp.capPassR = (long long)F.passListR.cap;
+        HIPCK(c, F.deferred.reserve_exact(F.passList.cap + F.passListR.cap));
+        fp.deferred = F.deferred.p; fp.capDeferred = (long long)F.deferred.cap;
     }
     if (dbgTime) fprintf(stderr, "[maple]   frontier +%.1f ms: pools reserved\n", sinceEnter());
     hipStream_t s = c->stream;
@@ -1299,11 +1312,14 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
             int prLow = 0, prHigh = 0;
             if (hipDeviceGetStreamPriorityRange(&prLow, &prHigh) != hipSuccess) prLow = 0;
             HIPCK(c, hipStreamCreateWithPriority(&F.side, hipStreamNonBlocking, prLow));
+            HIPCK(c, hipStreamCreateWithPriority(&F.side2, hipStreamNonBlocking, prLow));
         }
+        HIPCK(c, hipEventCreateWithFlags(&F.evFork2, hipEventDisableTiming));
+        HIPCK(c, hipEventCreateWithFlags(&F.evJoin2, hipEventDisableTiming));
         HIPCK(c, hipEventCreateWithFlags(&F.evFork, hipEventDisableTiming));
         HIPCK(c, hipEventCreateWithFlags(&F.evJoin, hipEventDisableTiming));
     }
-    const hipStream_t s2 = F.side;
+    const hipStream_t s2 = F.side, s3 = F.side2;
     // The two kinds of items run on two streams that never wait for each other inside the expansion: the list-updating levels
     // on the context's stream -- a chain of ~20 levels, each as long as its slowest item -- and the cached-regime launches on the
     // side stream, each taking whatever was complete when it started (k_fr_snap_c).  A cached launch is queued behind every
@@ -1338,16 +1354,23 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         levels++;
         return MAPLE_OK;
     };
+    bool passQueued = false;
     auto c_launch = [&]() -> int {
         hipEvent_t b0, b1;
         TRY(maple_internal_ev_pair(c, &b0, &b1, MAPLE_K_FR_CACHED, 0.0, 0.0));
         slotsC.push_back(c->ev_used / 2 - 1);
-        k_fr_snap_c<<<1, 64, 0, s2>>>(fp.ctr, fp.capCC, fp.capPass, fp.lvl, fp.maxLevels);
+        if (fp.mat && passQueued) HIPCK(c, hipStreamWaitEvent(s2, F.evJoin2, 0));      // (the deferred items of the launch before)
+        k_fr_snap_c<<<1, 64, 0, s2>>>(fp.ctr, fp.capCC, fp.capPass, fp.capDeferred, fp.lvl, fp.maxLevels);
         HIPCK(c, hipEventRecord(b0, s2));
         if (fp.mat) {
-            // the removed lists of the launch's items that crossed a reference branch, ahead of the kernel that reads them
-            FR_DISPATCH3(c, k_fr_pass_wave, <<<1024, FR_BLOCK, 0, s2>>>(c->d_model, av, T, fp));
-            FR_DISPATCH3(c, k_fr_pass, <<<256, FR_BLOCK, 0, s2>>>(c->d_model, av, T, fpC, scratchLanes + 2048));
+            // the removed lists of the launch's items that crossed a reference branch are re-expressed NEXT to the launch's
+            // k_fr_cached, on a stream of their own: the launch scores every other item, these are the next launch's
+            HIPCK(c, hipEventRecord(F.evFork2, s2));
+            HIPCK(c, hipStreamWaitEvent(s3, F.evFork2, 0));
+            FR_DISPATCH3(c, k_fr_pass_wave, <<<1024, FR_BLOCK, 0, s3>>>(c->d_model, av, T, fp));
+            FR_DISPATCH3(c, k_fr_pass, <<<256, FR_BLOCK, 0, s3>>>(c->d_model, av, T, fpC, scratchLanes + 2048));
+            HIPCK(c, hipEventRecord(F.evJoin2, s3));
+            passQueued = true;
             TRY(stage("k_fr_pass"));
         }
         FR_DISPATCH3(c, k_fr_cached, <<<gridCached, FR_BLOCK, 0, s2>>>(c->d_model, av, anyWide ? Tw : T, P, fp, budget,
@@ -1359,7 +1382,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         return MAPLE_OK;
     };
     // (an error inside the loop leaves nothing in flight on either stream behind it)
-    auto bail = [&](int rc) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(s2); return rc; };
+    auto bail = [&](int rc) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(s2); (void)hipStreamSynchronize(s3); return rc; };
     // the first level is opened (the seeds of k_fr_begin) and the cached stream let go
     k_fr_snap_u<<<1, 64, 0, s>>>(fp.ctr, fp.capU, fp.capC - fp.capCC, fp.capPassR, fp.lvl, fp.maxLevels);
     if (hipGetLastError() != hipSuccess || hipEventRecord(F.evFork, s) != hipSuccess || hipStreamWaitEvent(s2, F.evFork, 0) != hipSuccess
@@ -1382,12 +1405,13 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     // the cached-regime items that are left: launches until one has found nothing new behind its snapshot
     for (;;) {
         for (int g = 0; g < groupLevels; g++) { const int rc_ = c_launch(); if (rc_) return bail(rc_); }
+        if (passQueued && hipStreamWaitEvent(s2, F.evJoin2, 0) != hipSuccess) return bail(fail(c, MAPLE_ERR_HIP, "frontier level loop: HIP error"));
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&hc, fp.ctr, sizeof(FCtr), hipMemcpyDeviceToHost, s2) != hipSuccess
             || hipStreamSynchronize(s2) != hipSuccess)
             return bail(fail(c, MAPLE_ERR_HIP, "frontier level loop: HIP error"));
         const unsigned long long haveC = std::min<unsigned long long>(hc.usedC, (unsigned long long)fp.capCC),
                                  haveR = std::min<unsigned long long>(hc.usedR, (unsigned long long)(fp.capC - fp.capCC));
-        if (hc.hiC == haveC && hc.hiR == haveR) break;
+        if (hc.hiC == haveC && hc.hiR == haveR && hc.hiD == std::min<unsigned long long>(hc.nDeferred, (unsigned long long)fp.capDeferred)) break;
         if (launchesC > 200000) return bail(fail(c, MAPLE_ERR_FATAL, "frontier search did not terminate"));
     }
     if (hipEventRecord(F.evJoin, s2) != hipSuccess || hipStreamWaitEvent(s, F.evJoin, 0) != hipSuccess)

@@ -20,7 +20,7 @@ namespace frt {
 #endif
 
 enum { FI_UPD_IN = 1, FI_UPD_OUT = 2, FI_SCORED = 4, FI_DEAD = 8, FI_REC_UPD = 16, FI_SEED = 32, FI_SEED_EMPTY = 64,
-       FI_NEEDPASS = 128 };             // (trees with MAT local references) hRpr is still in the frame of the item that pushed it: k_fr_pass
+       FI_NEEDPASS = 128 };             // (trees with MAT local references; never cleared on an expanded item) pushed across a reference branch: hRpr is re-expressed by k_fr_pass
 // FS_WIDE: a whole-tree search whose row of the dense score table is being made next to this tier.  Its items that still
 // update genome lists are expanded here like any other's (they are what made such a search slow for one lane: up to 200
 // updating steps in a row); an item that arrives in the cached regime on the way DOWN is left as a seed (FI_SEED) -- the clade
@@ -76,6 +76,7 @@ struct FSearch {
 struct FRec { int32_t q, ref; double optimized, top, bottom, app; int32_t ok;
               int32_t hRprS; };        // in: FR_SHORTEN = the reference shortened this record's removed list in place (M:7087); out: the shortened list
 #define FR_SHORTEN (-3)
+#define FR_FRAMES (-2)                  // (a record of k_fr_replay_wide whose removed list is still in its seed's frame: k_fr_wide_frames)
 
 struct FCtr {                          // device-side bookkeeping of the level loop
     // (what every lane READS at the start of a kernel, and each counter the lanes bump, on cache lines of their own)
@@ -93,6 +94,11 @@ struct FCtr {                          // device-side bookkeeping of the level l
     alignas(128) unsigned long long usedR;
     alignas(128) unsigned long long nPassR;       // roots pushed across a MAT reference branch (passListR)
     alignas(128) unsigned long long bigUsedC;     // shared scratch of k_fr_pass (reset by every cached launch)
+    // An item that was pushed across a reference branch is scored one launch LATER than the launch that holds it: its removed
+    // list is re-expressed by k_fr_pass on a stream of its own, next to the launch's k_fr_cached, and the item is handed to the
+    // next launch through `deferred` (k_fr_cached passes over such an item where it finds it in its ranges).
+    alignas(128) unsigned long long nDeferred;
+    unsigned long long loD, hiD;
     alignas(128) unsigned long long permDown;     // the level's one-lane updating items by direction (k_fr_sort_level)
     alignas(128) unsigned long long permUp;
     alignas(128) unsigned long long permDownB;    // ... those with long lists (16 to a wavefront)
@@ -157,6 +163,7 @@ struct FPools {
     MutViewS mv;
     int32_t *passList; long long capPass;   // refs of the cached-pool items whose removed list is re-expressed at the start of their level
     int32_t *passListR; long long capPassR; // ... of the roots among them
+    int32_t *deferred; long long capDeferred;   // refs of the items whose removed list has been re-expressed: the next launch scores them
 };
 
 __device__ __forceinline__ FItem &item_of(const FPools &fp, int ref) { return ref >= 0 ? fp.C[ref] : fp.U[-(ref + 2)]; }
