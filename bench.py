@@ -434,6 +434,8 @@ def run_leg(args, env):
         return order[sel][rank::world]
 
     dbg = os.environ.get("MAPLE_DEBUG") is not None
+    if os.environ.get("MAPLE_VERBOSE"):                   # (the library's own account of a call on stderr: tools/timeline_step.py's companion)
+        dev.set_tuning(verbose=int(os.environ["MAPLE_VERBOSE"]))
 
     def step(i):
         ta = time.perf_counter()

@@ -23,6 +23,8 @@ using namespace maple;
 typedef maple::ArenaViewS ArenaView;   // {words, aux, ent_off[], aux_off[], n_ent[], n_aux[]} per list
 typedef maple::MutViewS MutView;       // {mut3, off[], cnt[]} per mutation list
 
+struct DevBufStats { size_t allocs = 0, bytes = 0; };   // (for the verbose account of a call: what it had to allocate)
+inline DevBufStats &devbuf_stats() { static DevBufStats s; return s; }
 template <class T> struct DevBuf {     // grow-only device scratch
     T *p = nullptr;
     size_t cap = 0;
@@ -34,6 +36,7 @@ template <class T> struct DevBuf {     // grow-only device scratch
         size_t want = n + n / 2 + 64;
         hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
         cap = (e == hipSuccess) ? want : 0;
+        devbuf_stats().allocs++; devbuf_stats().bytes += want * sizeof(T);
         return e;
     }
     hipError_t reserve_exact(size_t n)     // for the very large buffers: no growth margin
@@ -43,6 +46,7 @@ template <class T> struct DevBuf {     // grow-only device scratch
         p = nullptr;
         hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
         cap = (e == hipSuccess) ? n : 0;
+        devbuf_stats().allocs++; devbuf_stats().bytes += n * sizeof(T);
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }

@@ -1078,6 +1078,7 @@ struct FrontierScratch {
     FPools lastPools{};
     // the two kernels of a level read disjoint items (they only meet in the pools' atomic counters): the cached-regime one runs
     // on a stream of its own next to the updating one -- a level of the latter lasts as long as its slowest item, on a few lanes
+    int capE = 0;                                    // entries of a per-lane scratch slab
     hipStream_t side = nullptr, side2 = nullptr;     // (side: the cached-regime launches; side2: the k_fr_pass kernels next to them)
     hipEvent_t evFork = nullptr, evJoin = nullptr, evFork2 = nullptr, evJoin2 = nullptr;
 };
@@ -1119,6 +1120,13 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     // pools, sized for the batch and bounded by what the device has free
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t)8 << 30;
+    const DevBufStats allocs0 = devbuf_stats();
+    struct PoolCap { const char *name; const size_t *cap; size_t elem, before; };
+    PoolCap poolCaps[] = {{"itemsU", &F.itemsU.cap, 1, 0}, {"itemsC", &F.itemsC.cap, 1, 0}, {"tw", &F.tw.cap, 8, 0}, {"ta", &F.ta.cap, 8, 0},
+                          {"toffW", &F.toffW.cap, 8, 0}, {"sw", &F.sw.cap, 8, 0}, {"sa", &F.sa.cap, 8, 0}, {"sais", &F.sais.cap, 8, 0},
+                          {"bw", &F.bw.cap, 8, 0}, {"bw2", &F.bw2.cap, 8, 0}, {"visit", &F.visit.cap, 1, 0}, {"recs", &F.recs.cap, 1, 0},
+                          {"perm", &F.perm.cap, 4, 0}, {"passList", &F.passList.cap, 4, 0}};
+    for (PoolCap &pc : poolCaps) pc.before = *pc.cap;
     const size_t held = F.itemsU.cap + F.itemsC.cap + F.tw.cap * sizeof(uint2) + F.ta.cap * sizeof(double)
                         + F.sw.cap * sizeof(uint2) + F.sa.cap * sizeof(double) + F.sais.cap * sizeof(double) + F.bw.cap * 48 + F.bw2.cap * 48;
     const double room = 0.5 * (double)(freeB + held);
@@ -1136,11 +1144,17 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         // (after an overflow the asks themselves are too low -- the searches that were handed back stopped asking: twice, not 1.25 x)
         const double f = (F.lastOverflow ? 2.0 : 1.25) * (double)m / (double)F.needM;
         capU = std::max(capU, (long long)(f * F.needU)); capC = std::max(capC, (long long)(f * F.needC)); capR = std::max(capR, (long long)(f * F.needR));
-        capL = std::max(capL, (long long)(f * F.needL)); capW = std::max(capW, (long long)(f * F.needW)); capA = std::max(capA, (long long)(f * F.needA));
+        capL = std::max(capL, (long long)(f * F.needL));
+        // (the words' first guess goes with the arena's mean list length, which moves by an entry when the tree is uploaded again:
+        // 47 -> 48 made two 5 GB pools "grow" by half -- 0.73 s of the first round on a changed tree.  Once a batch has said what it
+        // used, that alone sizes them.)
+        capW = std::max<long long>(1 << 20, (long long)(f * F.needW)); capA = std::max<long long>(1 << 20, (long long)(f * F.needA));
     }
     // per-lane scratch for lists of up to capE entries (two average lists merged, with room); the few longer ones -- near the
     // root -- take pieces of a shared region.  As many lanes as the GPU holds at once at this kernel's occupancy.
-    const int capE = std::max(256, std::min(1024, 6 * (int)meanEnt));
+    // (in steps of 32 and never below what the slabs were cut for: they are 6 GB, and 282 -> 288 entries would allocate them again)
+    const int capE = std::max(F.capE, std::max(256, std::min(1024, (6 * (int)meanEnt + 31) / 32 * 32)));
+    F.capE = capE;
     long long scratchLanes = m <= 64 ? 16384 : 256ll * 4 * 4 * 64;         // 256 CUs x 4 SIMDs x 4 wavefronts (a handful of searches: what they can use)
     // slabs beyond the lanes' own: one per wavefront of the two wavefront-wide kernels (256 + 1 280 <= 2 048) and, on a tree with MAT
     // local references, one per lane of k_fr_pass (256 workgroups), which runs next to k_fr_updating
@@ -1242,7 +1256,12 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, F.deferred.reserve_exact(F.passList.cap + F.passListR.cap));
         fp.deferred = F.deferred.p; fp.capDeferred = (long long)F.deferred.cap;
     }
-    if (dbgTime) fprintf(stderr, "[maple]   frontier +%.1f ms: pools reserved\n", sinceEnter());
+    if (dbgTime) fprintf(stderr, "[maple]   frontier +%.1f ms: pools reserved (%zu allocations, %.2f GB; free %.1f GB, room %.1f GB; per-lane scratch %lld x %d entries, shared %lld + %lld)\n", sinceEnter(),
+                         devbuf_stats().allocs - allocs0.allocs, 1e-9 * (double)(devbuf_stats().bytes - allocs0.bytes), 1e-9 * (double)freeB, 1e-9 * room,
+                         scratchLanes + extraSlabs, capE, capBig, capBig2);
+    if (dbgTime)
+        for (const PoolCap &pc : poolCaps)
+            if (*pc.cap != pc.before) fprintf(stderr, "[maple]     %s: %.3f -> %.3f GB\n", pc.name, 1e-9 * (double)(pc.before * pc.elem), 1e-9 * (double)(*pc.cap * pc.elem));
     hipStream_t s = c->stream;
     const bool dbgSync = c->tuning.verbose > 2;                            // (MAPLE_DEBUG=3: every launch awaited and named)
     auto stage = [&](const char *what) -> int {

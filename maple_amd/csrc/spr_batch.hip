@@ -1304,7 +1304,10 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // the way: with an error model the doubling stops at 8 192)
     if (sp->wideSearchBudget == 0) wideBudget = c->dm.usingErrorRate ? std::min(2 * wideBudget, std::max(wideBudget, 8192)) : 2 * wideBudget;
     const bool hybrid = wideBudget > 0;
-    if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !c->tuning.noCladeScan) TRY(build_scan_tables(c, P));
+    if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !c->tuning.noCladeScan) {
+        TRY(build_scan_tables(c, P));
+        if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: scan tables of the tree built (first search since it changed)\n", tms(tStart, tnow()));
+    }
     // rows of the score table come with the bitmap of their finite scores (FiniteRows) when the tables that go with it exist
     bool useFin = hybrid && c->scan_valid && !c->tree_has_mut;         // (trees with local references: only for the rows of the searches
                                                                        // known beforehand, below)

@@ -22,6 +22,16 @@ for i in range(3):
     t0 = time.perf_counter()
     r = dev.spr_search_batch(order, **kw)
     print(f"round {i}: {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
+if os.environ.get("REUPLOAD"):                                   # (what bench.py reports as first_step_after_upload_ms)
+    for i in range(2):
+        t0 = time.perf_counter()
+        bt.upload_headline_tree()
+        t1 = time.perf_counter()
+        r = dev.spr_search_batch(order, **kw)
+        print(f"upload {1e3 * (t1 - t0):.1f} ms, round after it: {1e3 * (time.perf_counter() - t1):.1f} ms", flush=True)
+    t0 = time.perf_counter()
+    r = dev.spr_search_batch(order, **kw)
+    print(f"round after that: {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
 iu, ic, mu, mc = dev.frontier_levels()
 ws, wb = dev.last_wave_items
 print("level  updating_items  (by wavefronts: small class, 512 class)  cached_items  ms_updating  ms_cached")
