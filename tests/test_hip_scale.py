@@ -630,6 +630,39 @@ def test_bench_two_ranks_plumbing():
     assert line2["value"] > 0 and line2["roofline"]["frac"] >= 0
 
 
+def test_bench_two_ranks_rccl():
+    """The same two-rank run over RCCL (backend "nccl"), one GPU per rank -- only where two GPUs are visible (the boxes of this
+    project's rounds have one: skipped there; the gloo form above is what runs).  Proposal records then stay in device memory
+    through the all-gather (maple_amd.parallel.gather_proposals with a cuda device)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the RCCL form of the two-rank run needs two")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--samples", "1500", "--model", "unrest", "--batch", "600", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+              "--no-extras"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MAPLE_BENCH_BACKEND", None)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert two.returncode == 0, two.stderr[-2000:]
+    line2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True,
+                         timeout=900, env=env, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    line1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line2["n_gpus"] == 2 and line2["config"]["searches_timed"] == line1["config"]["searches_timed"]
+    assert line2["config"]["candidate_placements_timed"] == line1["config"]["candidate_placements_timed"]
+
+
 def test_apply_phase_batched_equals_sequential(world):
     """applySPRMovesParallel (M:9470-9484) in its two drivers (maple_amd/spr_apply.py): the proposed moves of a deep round on a
     tree with misplaced tips, re-searched one at a time on the current tree and applied -- against the same moves re-searched

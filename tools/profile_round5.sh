@@ -18,6 +18,8 @@ rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/calib -- python $R/tools/calib_fetch.p
 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/calibw -- python $R/tools/calib_fetch.py > $OUT/calibw.log 2>&1
 python $R/tools/summarize_round5.py $NAME $OUT "$EXTRA" "$COMMIT" > $OUT/summary.md 2> $OUT/summary.err
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+# (the traced command runs 1 warm-up + 2 timed steps + the step after the re-upload: the timeline of the second timed step)
+python $R/tools/timeline_step.py $OUT/stats/*/*_kernel_trace.csv 4 2 > $OUT/timeline_step.txt 2>&1
 # (the raw per-dispatch CSVs are hundreds of MB: only the summaries travel back)
 du -sh $OUT/* 2>/dev/null | sort -h | tail -12 > $OUT/sizes.txt
 rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/sq1 $OUT/sq2 $OUT/lds $OUT/calib $OUT/calibw
