@@ -823,9 +823,11 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
                             slotLK, slotFails, slotOwner, T.scanDepthCap, st, fm, fpx, T.candBefore, T.cladeVisits);
             if (st.overflow) { bad = 1; break; }
             // (a tree with local references: a branch of the clade that beats the running best would have its removed list -- the
-            // seed's, re-expressed in the branch's frame, which only exists after the scan -- shortened in place, M:7087: rare, and
-            // left to the one-lane kernel)
-            if (fp.mat && st.best > bestBefore) { bad = 1; break; }         // (wave-uniform: both are what lane 0 handed in)
+            // seed's, re-expressed in the branch's frame, which only exists after the scan -- shortened in place, M:7087.  That is a
+            // no-op unless shorten() would merge entries of THAT list: looked at when the list exists -- below for a branch in the
+            // seed's own frame, in k_fr_wide_frames for the others (FR_FRAMES_EVENT) -- instead of handing back every such search:
+            // one of them is 100 ms of one wavefront at 1 000 000 tips)
+            (void)bestBefore;
             best = st.best; nB = st.nB; nApp = st.nApp;
             __threadfence();
 #ifdef MAPLE_SPR_PROFILE
@@ -842,6 +844,17 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
         if (lane == 0) {
             // the short-listed branches that are refined (M:7465), in visiting order; the scan's become cached-pool items
             int cnt = 0, cntScan = 0;
+            int why = bad ? 6 : 0;
+            if (fp.mat && !bad) {
+                // the branches that beat the running best when they were visited (all of them are short-listed), in visiting order
+                double rb = S.curLK;
+                for (int i = 0; i < nB; i++) {
+                    const BestRec b = br[i];
+                    if (!(b.score > rb)) continue;
+                    rb = b.score;
+                    if (b.hDown != WR_ITEM && b.hMid == b.hDown && frpr_marked(fp, S, b.hRpr)) { bad = 1; why = 7; break; }
+                }
+            }
             for (int i = 0; i < nB && !bad; i++)
                 if (br[i].score >= S.curLK - P.thrOptTopo) { cnt++; if (br[i].hDown != WR_ITEM) cntScan++; }
             unsigned long long base = 0ull, ibase = 0ull;
@@ -853,12 +866,15 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
                     for (long long k2 = (long long)base; k2 < min((long long)(base + cnt), fp.capRecs); k2++) { fp.recs[k2].q = q; fp.recs[k2].ref = FR_NONE; }
                 }
             }
-            if (bad) S.state = FS_FALLBACK;                                  // (short list, depth slots or pools too small: the one-lane kernel)
+            if (bad) { S.state = FS_FALLBACK; atomicAdd(&fp.ctr->fbReason[why ? why : 6], 1); }   // (short list, depth slots or pools too small, a list shorten() would change: the one-lane kernel)
             else {
                 S.recBase = (int32_t)base; S.recCount = cnt; S.nApp = nApp;
                 int kk = 0, ks = 0;
+                double rb = S.curLK;
                 for (int i = 0; i < nB; i++) {
                     const BestRec b = br[i];
+                    const bool event = b.score > rb;
+                    if (event) rb = b.score;
                     if (!(b.score >= S.curLK - P.thrOptTopo)) continue;
                     int ref = b.hUp;
                     bool frames = false;
@@ -873,7 +889,7 @@ __global__ __launch_bounds__(64) void k_fr_replay_wide(DevTree T, SearchParams P
                         if (fp.mat && b.hMid != b.hDown) { frames = true; x.hA = b.hDown; x.hB = b.hMid; }
                     }
                     FRec &x = fp.recs[base + kk++];
-                    x.q = q; x.ref = ref; x.ok = 0; x.hRprS = frames ? FR_FRAMES : -1;
+                    x.q = q; x.ref = ref; x.ok = 0; x.hRprS = frames ? (event ? FR_FRAMES_EVENT : FR_FRAMES) : -1;
                 }
             }
         }
@@ -895,7 +911,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_wide_frames(const DevModel *__r
     const long long nRecs = min((long long)fp.ctr->nRecs, fp.capRecs);
     for (long long i = laneId; i < nRecs; i += (long long)gridDim.x * blockDim.x) {
         FRec &R = fp.recs[i];
-        if (R.ref < 0 || R.hRprS != FR_FRAMES) continue;                    // (only the scan's entries: cached-pool items)
+        if (R.ref < 0 || (R.hRprS != FR_FRAMES && R.hRprS != FR_FRAMES_EVENT)) continue;   // (only the scan's entries: cached-pool items)
         FItem &x = fp.C[R.ref];
         FSearch &S = fp.S[R.q];
         if (!fs_live(S.state)) continue;
@@ -908,6 +924,9 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_wide_frames(const DevModel *__r
             ok = fvalid(h);
         }
         if (!ok) { S.state = FS_FALLBACK; continue; }
+        // (the branch beat the running best when the scan visited it: the reference shortened THIS list in place there, M:7087 --
+        // nothing to emulate unless that would merge entries)
+        if (R.hRprS == FR_FRAMES_EVENT && frpr_marked(fp, S, h)) { S.state = FS_FALLBACK; atomicAdd(&fp.ctr->fbReason[7], 1); continue; }
         x.hRpr = h; x.hA = x.hB = -1;
         R.hRprS = -1;
     }
@@ -1494,10 +1513,11 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     };
     { const int rc_ = finishStage(); if (rc_) return bail(rc_); }
     if (dbgTime) fprintf(stderr, "[maple]   frontier +%.1f ms: replay, refinement, final selection done; results on the host\n", sinceEnter());
-    if (dbgTime && (hc.fbReason[0] | hc.fbReason[1] | hc.fbReason[2] | hc.fbReason[3] | hc.fbReason[4] | hc.fbReason[5]))
+    if (dbgTime && (hc.fbReason[0] | hc.fbReason[1] | hc.fbReason[2] | hc.fbReason[3] | hc.fbReason[4] | hc.fbReason[5] | hc.fbReason[6] | hc.fbReason[7]))
         fprintf(stderr, "[maple]   exact walk handed searches to the one-lane kernel: %d a merge within tolerance, %d a list re-expressed from a shortened one, "
-                        "%d a fifth shortened list, %d the search's own first list shortened, %d marked list without a layout, %d other\n",
-                hc.fbReason[1], hc.fbReason[2], hc.fbReason[3], hc.fbReason[4], hc.fbReason[5], hc.fbReason[0]);
+                        "%d a fifth shortened list, %d the search's own first list shortened, %d marked list without a layout, %d other; whole-tree searches: "
+                        "%d short list / scan slots / marked item list, %d a scanned branch whose list shorten() would change\n",
+                hc.fbReason[1], hc.fbReason[2], hc.fbReason[3], hc.fbReason[4], hc.fbReason[5], hc.fbReason[0], hc.fbReason[6], hc.fbReason[7]);
     if (dbgTime && hc.overflow)
         fprintf(stderr, "[maple]   frontier pools, asked / capacity: updating items %llu / %lld, cached items %llu / %lld, roots %llu / %lld, temporary lists %llu / %lld "
                         "(words %llu / %lld, aux %llu / %lld), pass entries %llu / %lld, of roots %llu / %lld, records %llu / %lld\n",

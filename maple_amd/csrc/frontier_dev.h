@@ -76,6 +76,7 @@ struct FSearch {
 struct FRec { int32_t q, ref; double optimized, top, bottom, app; int32_t ok;
               int32_t hRprS; };        // in: FR_SHORTEN = the reference shortened this record's removed list in place (M:7087); out: the shortened list
 #define FR_SHORTEN (-3)
+#define FR_FRAMES_EVENT (-4)            // ... and the branch beat the running best when it was visited (M:7087 applies to that list)
 #define FR_FRAMES (-2)                  // (a record of k_fr_replay_wide whose removed list is still in its seed's frame: k_fr_wide_frames)
 
 struct FCtr {                          // device-side bookkeeping of the level loop
