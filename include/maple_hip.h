@@ -87,6 +87,9 @@ typedef struct {
                                    instead of only against the branches their witness filter cannot rule out (witness.hip) */
     int32_t waveAllBelow;       /* frontier tier of the SPR search: a level of the expansion with at most this many items that still
                                    update genome lists is walked one WAVEFRONT per item (0 = the library's choice, -1 = never) */
+    int32_t noOverHint;         /* 1: with an error model, a node whose SPR search ran over the whole-tree budget the last time is
+                                   NOT sent to the dense tier at once the next time (the library remembers that per node between
+                                   calls on one tree: maple_spr_search_batch) */
 } maple_tuning;
 int maple_set_tuning(maple_ctx *ctx, const maple_tuning *t);
 const char *maple_last_error(maple_ctx *ctx);

@@ -27,7 +27,8 @@ struct FrontierWide {
 __attribute__((visibility("hidden")))
 int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *nodes, int budget, int zeroBudget, SearchOut *hostOut,
                     uint2 *poolW, double *poolA, unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
-                    FrontierStats *stats, long long itemsHint, const FrontierWide *wide = nullptr);   // itemsHint: expected expanded items (0 = by the budget)
+                    FrontierStats *stats, long long itemsHint, const FrontierWide *wide = nullptr,    // itemsHint: expected expanded items (0 = by the budget)
+                    const uint8_t *overHint = nullptr);   // host, per search (or null): leave at once as "over the budget" (status -5) -- the caller knows it would
 __attribute__((visibility("hidden"))) void frontier_scratch_free(maple_ctx *c);
 __attribute__((visibility("hidden"))) int frontier_export(maple_ctx *c, long long cap, int32_t *q, int32_t *node, long long *n);
 __attribute__((visibility("hidden")))

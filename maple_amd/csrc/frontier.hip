@@ -41,7 +41,7 @@ namespace {
 template <bool RV, bool U, bool SS>
 __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, int n,
                                                        const int32_t *nodes, FPools fp, SearchOut *out, int budget, int zeroBudget,
-                                                       const int32_t *rowOf, int forceWide)
+                                                       const int32_t *rowOf, int forceWide, const uint8_t *overHint)
 {
     __shared__ Lds lds;
     const DevModel &m = *mp;
@@ -80,6 +80,9 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
         curLK = append_walk(c, fref(lu), fref(ll), rn.isTip != 0, rn.dist);   // M:9646
         o.currentLK = curLK;
         if (!(curLK < P.thrPlacement || rn.dist != 0.0)) { o.status = 2; continue; }        // M:9674
+        // (the caller has seen this node's search run over the budget on this tree before: it goes to the dense tier without
+        // expanding a budget's worth of items first -- same result either way, the dense tier is exact for any search)
+        if (overHint && overHint[q]) { S.state = FS_OVER; o.status = -5; continue; }
         S.parent = parent; S.sibling = childIdx == 0 ? rp.c1 : rp.c0;
         S.isRemovedTip = rn.isTip; S.removedBLen = rn.dist; S.curLK = curLK;
         const NodeRec rs = T.nd[S.sibling];
@@ -1082,7 +1085,7 @@ struct FrontierScratch {
     DevBuf<double> ta, sa, sais, ba;
     DevBuf<long long> toffW, toffA;
     DevBuf<int32_t> tn, tna, nodes, expQ, expNode;
-    DevBuf<uint8_t> out, wideBr, tflag;
+    DevBuf<uint8_t> out, wideBr, tflag, overHint;
     DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, perm3, perm4, tot, lsize, lpos, lpar, passList, passListR, deferred;
     DevBuf<uint2> bw2; DevBuf<double> ba2;   // k_fr_pass's own shared scratch (it runs next to the updating levels)
     DevBuf<uint8_t> visit;
@@ -1112,7 +1115,7 @@ void frontier_scratch_free(maple_ctx *c)
     F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
     F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
     F->expQ.release(); F->expNode.release();
-    F->perm.release(); F->perm2.release(); F->perm3.release(); F->perm4.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release(); F->passList.release(); F->passListR.release(); F->deferred.release(); F->bw2.release(); F->ba2.release(); F->tflag.release();
+    F->perm.release(); F->perm2.release(); F->perm3.release(); F->perm4.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release(); F->passList.release(); F->passListR.release(); F->deferred.release(); F->overHint.release(); F->bw2.release(); F->ba2.release(); F->tflag.release();
     if (F->evFork) (void)hipEventDestroy(F->evFork);
     if (F->evJoin) (void)hipEventDestroy(F->evJoin);
     if (F->evFork2) (void)hipEventDestroy(F->evFork2);
@@ -1128,7 +1131,7 @@ void frontier_scratch_free(maple_ctx *c)
 // -5 = over `budget` expanded items (dense tier), FR_STATUS_FALLBACK = hand to the one-lane-per-search kernel.
 int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *nodes, int budget, int zeroBudget, SearchOut *hostOut,
                     uint2 *poolW, double *poolA, unsigned long long *poolUsed, long long poolCapW, long long poolCapA,
-                    FrontierStats *stats, long long itemsHint, const FrontierWide *wide)
+                    FrontierStats *stats, long long itemsHint, const FrontierWide *wide, const uint8_t *overHint)
 {
     if (!c->frontier) c->frontier = new FrontierScratch();
     FrontierScratch &F = *(FrontierScratch *)c->frontier;
@@ -1291,6 +1294,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     };
     HIPCK(c, hipMemsetAsync(fp.ctr, 0, sizeof(FCtr), s));
     HIPCK(c, hipMemcpyAsync(F.nodes.p, nodes, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (overHint) {
+        HIPCK(c, F.overHint.reserve((size_t)m));
+        HIPCK(c, hipMemcpyAsync(F.overHint.p, overHint, (size_t)m, hipMemcpyHostToDevice, s));
+    }
     SearchOut *dout = (SearchOut *)F.out.p;
     DevTree T = c->dtree;
     const ArenaViewS av = view(c);
@@ -1325,7 +1332,8 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     const bool anyWide = useWide && !wideIdx.empty();
     // (the seeding of a tree with local references writes lists through the lanes' scratch slabs: no more lanes than slabs)
     FR_DISPATCH3(c, k_fr_begin, <<<std::min(gridN, gridUpd), FR_BLOCK, 0, s>>>(c->d_model, av, T, P, m, F.nodes.p, fp, dout, budget, zeroBudget,
-                                                            anyWide ? F.wideRow.p : nullptr, anyWide ? wide->forceWide : 0));
+                                                            anyWide ? F.wideRow.p : nullptr, anyWide ? wide->forceWide : 0,
+                                                            overHint ? F.overHint.p : nullptr));
     HIPCK(c, hipGetLastError());
     // level loop: the counters stay on the device; the host looks at them every few levels
     FCtr hc;

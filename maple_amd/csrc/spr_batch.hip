@@ -493,6 +493,7 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     T.totUp = c->t_i32[6].p;
     c->scan_valid = false;
     c->cand_root_end = -1;
+    c->h_over_hint.clear();
     T.scan = nullptr; T.scanParent = nullptr; T.scanDepthCap = 0;
     c->tree_has_mut = false;
     c->tree_max_ent = 0;
@@ -555,8 +556,12 @@ int tree_rebuild_from_host(maple_ctx *c)
                                upRight = c->h_tree_upRight, upLeft = c->h_tree_upLeft, totUp = c->h_tree_totUp, mut = c->h_tree_mut;
     const std::vector<double> dist = c->h_tree_dist;
     const std::vector<uint8_t> tip = c->h_tree_tip;
-    return maple_tree_upload(c, (int32_t)up.size(), c->dtree.root, up.data(), c0.data(), c1.data(), dist.data(), tip.data(),
-                             lower.data(), upRight.data(), upLeft.data(), totUp.data(), mut.data());
+    std::vector<uint8_t> hint;                                         // (the same tree, patched: what its nodes' searches did last time still holds)
+    hint.swap(c->h_over_hint);
+    const int rc = maple_tree_upload(c, (int32_t)up.size(), c->dtree.root, up.data(), c0.data(), c1.data(), dist.data(), tip.data(),
+                                     lower.data(), upRight.data(), upLeft.data(), totUp.data(), mut.data());
+    c->h_over_hint.swap(hint);
+    return rc;
 }
 
 // maple_tree_patch's device writes in two launches instead of one small copy (and one synchronisation) per word: node records
@@ -1059,6 +1064,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     HIPCK(c, c->s_counter.reserve(8));
     std::vector<SearchOut> &ho = c->h_search_out;
     ho.assign((size_t)n, SearchOut{});
+    std::vector<uint8_t> hintedNow;                                    // (searches sent to the dense tier on the strength of h_over_hint)
     std::vector<int32_t> todo(nodes, nodes + n), slot(n);
     for (int i = 0; i < n; i++) slot[i] = i;
     // output pool for bestRemovedPartials: a list re-expressed in another frame stays close to its original size
@@ -1451,8 +1457,28 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 fw.frameParent = c->s_frame_parent.p; fw.frameNode = c->s_frame_node.p; fw.nFrames = (int)preFrameParent.size();
             }
         }
+        // With an error model nothing says beforehand which searches are long (no routing hint), and a long one expands a whole
+        // budget of items here before it leaves for the dense tier -- half of this pass's items at 100 000 tips.  What does say it:
+        // the node's search ran over the budget the last time it was searched on this tree (rounds repeat over the same nodes;
+        // maple_tree_patch keeps node ids).  Such a search leaves at once.  Only a hint: the dense tier is exact for any search.
+        std::vector<uint8_t> overHint;
+        if (hybrid && c->dm.usingErrorRate && !c->tuning.noOverHint && (int)c->h_over_hint.size() >= c->dtree.n) {
+            overHint.resize((size_t)n);
+            size_t nHint = 0;
+            for (int i = 0; i < n; i++) { overHint[i] = c->h_over_hint[todo[i]]; nHint += overHint[i]; }
+            if (!nHint) overHint.clear();
+            else if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: %zu searches that ran over the budget last time go to the dense tier at once\n", tms(tStart, tnow()), nHint);
+        }
         TRY(frontier_search(c, P, n, todo.data(), frontierBudget, (hybrid && wideBudget > MAPLE_ZERO_DIST_BUDGET) ? MAPLE_ZERO_DIST_BUDGET : (1 << 30),
-                            ho.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs, 0, fw.rowOf ? &fw : nullptr));
+                            ho.data(), poolW, poolA, poolUsed, poolCapW, poolCapA, &fs, 0, fw.rowOf ? &fw : nullptr,
+                            overHint.empty() ? nullptr : overHint.data()));
+        if (hybrid && c->dm.usingErrorRate) {
+            // what this pass saw: over the budget -> the hint is set; a hinted search's hint is looked at again when its result is in
+            if ((int)c->h_over_hint.size() < c->dtree.n) c->h_over_hint.resize((size_t)c->dtree.n, 0);
+            for (int i = 0; i < n; i++)
+                if (ho[i].status == -5 && (overHint.empty() || !overHint[i])) c->h_over_hint[todo[i]] = 1;
+            hintedNow.swap(overHint);
+        }
         std::vector<int32_t> todoFb, slotFb;
         for (int i = 0; i < n; i++)
             if (ho[i].status == FR_STATUS_FALLBACK) { todoFb.push_back(todo[i]); slotFb.push_back(i); }
@@ -1754,6 +1780,9 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     }
 #endif
     if (preMark >= 0) TRY(maple_arena_release(c, preMark));             // (the root-frame copies of this call)
+    // (a hinted search that turned out short -- the tree changed around it -- is tried within the budget again next time)
+    for (size_t i = 0; i < hintedNow.size(); i++)
+        if (hintedNow[i] && ho[i].status == 0 && ho[i].nAppend <= wideBudget / 4) c->h_over_hint[nodes[i]] = 0;
     if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: results in host memory\n", tms(tStart, tnow()));
     for (int i = 0; i < n; i++) {
         bestNode[i] = ho[i].bestNode; bestScore[i] = ho[i].bestScore;

@@ -728,6 +728,16 @@ def test_deep_round_with_error_model_at_20k_tips_frontier_tier_equals_lane_tier(
         for k in ("status", "bestNode", "placement", "nAppend", "bestScore", "currentLK", "improvement", "blen"):
             assert np.array_equal(g[k], lane[k]), (budget, k)
     assert (g["status"] == 0).sum() > 30000 and g["nAppend"].sum() > 1e7
+    # (from the second call on, the nodes whose search ran over the budget went to the dense tier at once -- the library remembers
+    # them per tree: maple_tuning.noOverHint switches that off; a hint left by ANOTHER budget is only a hint)
+    dev.set_tuning(no_over_hint=True)
+    g = dev.spr_search_batch(nodes, **kw)
+    dev.set_tuning()
+    for k in ("status", "bestNode", "placement", "nAppend", "bestScore", "currentLK", "improvement", "blen"):
+        assert np.array_equal(g[k], lane[k]), ("no hints", k)
+    g = dev.spr_search_batch(nodes[::3], wide_search_budget=300, **kw)
+    for k in ("status", "bestNode", "placement", "nAppend", "bestScore", "currentLK", "improvement", "blen"):
+        assert np.array_equal(g[k], lane[k][::3]), ("hints of another budget", k)
     dev.close()
 
 
