@@ -107,6 +107,10 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
         } else if (!U && budget > zeroBudget && rn.dist == 0.0) {
             wide = rowOf && rowOf[q] >= 0 && !wouldMerge;
             if (!wide) { S.state = FS_OVER; o.status = -5; continue; }
+        } else if (U && rowOf && rowOf[q] >= 0) {
+            // (error model: the caller gave this search a row because it ran over the budget the last time)
+            if (wouldMerge) { S.state = FS_OVER; o.status = -5; continue; }
+            wide = true;
         }
         S.state = wide ? FS_WIDE : FS_ACTIVE;
         if (rp.up < 0) {                                                    // the parent is the root (M:6916-6960): seeded by an item

@@ -1332,35 +1332,20 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     const bool matPre = c->tree_has_mut;
     int64_t preMark = -1;                                              // (the re-expressed lists live until the results are in)
     std::vector<int32_t> preFrameParent, preFrameNode;
-    if (hybrid && !c->dm.usingErrorRate && wideBudget > 16 && (!matPre || (c->scan_valid && c->place && !c->tuning.noCladeScan && !c->tuning.denseWideScoring && !c->tuning.wideOutsideFrontier))) {
-        {   // a node on a zero-length branch is searched at all only if its current placement is bad enough (M:9674): the
-            // kernel's own test, on the same appendProbNode, for all of them at once
-            std::vector<int32_t> zi, pl, cl;
-            std::vector<uint8_t> tp;
-            for (int i = 0; i < n; i++) {
-                const int v = nodes[i], u = c->h_tree_up[v];
-                if (c->h_tree_dist[v] != 0.0 || u < 0) continue;
-                if (matPre && c->h_tree_mut[v] >= 0) continue;          // (a reference node itself: the frame-by-frame path, below)
-                const int32_t vu = c->h_tree_c0[u] == v ? c->h_tree_upRight[u] : c->h_tree_upLeft[u];
-                if (vu < 0 || c->h_tree_lower[v] < 0) continue;
-                zi.push_back(i); pl.push_back(vu); cl.push_back(c->h_tree_lower[v]); tp.push_back(c->h_tree_tip[v]);
-            }
-            if (zi.size() >= 64) {
-                std::vector<double> bl(zi.size(), 0.0), cur(zi.size());
-                const int rc = maple_append_batch(c, (int32_t)zi.size(), pl.data(), cl.data(), tp.data(), bl.data(), cur.data());
-                if (rc != MAPLE_OK) return rc;
-                for (size_t k = 0; k < zi.size(); k++) if (cur[k] < P.thrPlacement) preIdx.push_back(zi[k]);
-            }
-            if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: current placements of %zu nodes on zero-length branches scored\n", tms(tStart, tnow()), zi.size());
-        }
+    auto pre_rows_max = [&]() -> size_t {                             // rows the score table may have: half of what is free, 96 GiB at most
         size_t freeB = 0, totalB = 0;
         size_t budgetB = (size_t)4ull << 30;
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess)
             budgetB = std::max(budgetB, std::min((freeB + c->s_cache.cap * sizeof(double)) / 2, (size_t)96ull << 30));
-        const size_t rowsMax = budgetB / ((size_t)nTpre * sizeof(double));
+        return budgetB / ((size_t)nTpre * sizeof(double));
+    };
+    // the searches `preIdx` get their rows of the score table on the side stream, next to the pass that follows, and are whole-tree
+    // searches inside the tier (witnessOK: removedBLen = 0 and no error model -- the witness filter instead of the dense kernel)
+    auto pre_rows = [&](const bool witnessOK) -> int {
+        const size_t rowsMax = pre_rows_max();
         if (preIdx.size() < 64 || preIdx.size() > rowsMax) preIdx.clear();
         else {
-            preSpare = (int)std::min<size_t>(4096, rowsMax - preIdx.size());
+            preSpare = witnessOK ? (int)std::min<size_t>(4096, rowsMax - preIdx.size()) : 0;
             const int mZ = (int)preIdx.size();
             HIPCK(c, c->s_cache.reserve_exact((size_t)(mZ + preSpare) * nTpre));
             TRY(fin_reserve((size_t)mZ + preSpare));
@@ -1381,7 +1366,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                 qBytes += 8.0 * c->h_n_ent[ql[k]] + 8.0 * c->h_n_aux[ql[k]];
                 // (the witness filter writes -inf by omission ON THE PROOF that the pair is searched with removedBLen = 0 and no
                 // error model -- witness.hip: a row with another length must never get here)
-                if (qb[k] != 0.0) return fail(c, MAPLE_ERR_FATAL, "a search with removedBLen %g among the searches of the witness filter", qb[k]);
+                if (witnessOK && qb[k] != 0.0) return fail(c, MAPLE_ERR_FATAL, "a search with removedBLen %g among the searches of the witness filter", qb[k]);
             }
             if (matPre) {
                 const PlaceMeta &Fm = *c->place;
@@ -1405,10 +1390,10 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             HIPCK(c, hipStreamSynchronize(c->stream2));                     // (the three vectors are locals)
             // queued BEHIND the lane launch: a workgroup of the dense kernel wants most of a compute unit's LDS, so it starts
             // where the lane searches have thinned out -- launched first it would hold them off instead (measured: no overlap)
-            afterLaunch = [c, mZ, nTpre, qBytes, fin_prefix, useFin, finWords, dbgT, matPre]() -> int {
+            afterLaunch = [c, mZ, nTpre, qBytes, fin_prefix, useFin, finWords, dbgT, matPre, witnessOK]() -> int {
                 // (every one of these searches has removedBLen = 0 and there is no error model: only the pairs the witness
                 // filter cannot rule out are walked -- witness.hip)
-                if (useFin && !c->tuning.denseWideScoring) {
+                if (witnessOK && useFin && !c->tuning.denseWideScoring) {
                     long long pairs = 0;
                     TRY(witness_score(c, c->stream2, mZ, c->z_ql.p, c->z_qt.p, c->z_qb.p, c->n_scored, matPre ? c->s_cand_root.p : c->t_i32[8].p,
                                       matPre ? c->t_cand_rank.p : c->t_scored_col.p,
@@ -1419,15 +1404,51 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
                     HIPCK(c, hipEventRecord(c->ev_join, c->stream2));
                     return MAPLE_OK;
                 }
-                TRY(launch_append_queries(c, c->stream2, mZ, c->z_ql.p, c->n_scored, c->t_i32[8].p, 0, 0.0, c->s_cache.p, nTpre,
-                                          c->t_scored_col.p, c->z_qt.p, c->z_qb.p, MAPLE_K_SPR_SCORE,
+                // (a tree with local references: candidates and removed lists both in the root's frame, as for the witness filter)
+                TRY(launch_append_queries(c, c->stream2, mZ, c->z_ql.p, c->n_scored, matPre ? c->s_cand_root.p : c->t_i32[8].p, 0, 0.0, c->s_cache.p, nTpre,
+                                          matPre ? c->t_cand_rank.p : c->t_scored_col.p, c->z_qt.p, c->z_qb.p, MAPLE_K_SPR_SCORE,
                                           (double)mZ * c->scored_bytes_total + qBytes, nullptr, nullptr, nullptr, 0, 1, useFin ? c->s_fin_mask.p : nullptr));
                 if (useFin) TRY(fin_prefix(c->stream2, 0, (size_t)mZ));
                 HIPCK(c, hipEventRecord(c->ev_join, c->stream2));
                 return MAPLE_OK;
             };
-            if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: %d searches from zero-length branches to be scored on the side stream\n", tms(tStart, tnow()), mZ);
+            if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: %d searches %s to be scored on the side stream\n", tms(tStart, tnow()), mZ,
+                              witnessOK ? "from zero-length branches" : "that ran over the budget the last time");
         }
+        return MAPLE_OK;
+    };
+    if (hybrid && !c->dm.usingErrorRate && wideBudget > 16 && (!matPre || (c->scan_valid && c->place && !c->tuning.noCladeScan && !c->tuning.denseWideScoring && !c->tuning.wideOutsideFrontier))) {
+        {   // a node on a zero-length branch is searched at all only if its current placement is bad enough (M:9674): the
+            // kernel's own test, on the same appendProbNode, for all of them at once
+            std::vector<int32_t> zi, pl, cl;
+            std::vector<uint8_t> tp;
+            for (int i = 0; i < n; i++) {
+                const int v = nodes[i], u = c->h_tree_up[v];
+                if (c->h_tree_dist[v] != 0.0 || u < 0) continue;
+                if (matPre && c->h_tree_mut[v] >= 0) continue;          // (a reference node itself: the frame-by-frame path, below)
+                const int32_t vu = c->h_tree_c0[u] == v ? c->h_tree_upRight[u] : c->h_tree_upLeft[u];
+                if (vu < 0 || c->h_tree_lower[v] < 0) continue;
+                zi.push_back(i); pl.push_back(vu); cl.push_back(c->h_tree_lower[v]); tp.push_back(c->h_tree_tip[v]);
+            }
+            if (zi.size() >= 64) {
+                std::vector<double> bl(zi.size(), 0.0), cur(zi.size());
+                const int rc = maple_append_batch(c, (int32_t)zi.size(), pl.data(), cl.data(), tp.data(), bl.data(), cur.data());
+                if (rc != MAPLE_OK) return rc;
+                for (size_t k = 0; k < zi.size(); k++) if (cur[k] < P.thrPlacement) preIdx.push_back(zi[k]);
+            }
+            if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: current placements of %zu nodes on zero-length branches scored\n", tms(tStart, tnow()), zi.size());
+        }
+        TRY(pre_rows(true));
+    } else if (hybrid && c->dm.usingErrorRate && useFrontier && !c->tuning.noOverHint && (int)c->h_over_hint.size() >= c->dtree.n && wideBudget > 16
+               && c->scan_valid && c->place && !c->tuning.noCladeScan && !c->tuning.wideOutsideFrontier) {
+        // With an error model nothing about a node says that its search will be long -- except that it was, the last time the node was
+        // searched on this tree (h_over_hint, below).  Those searches get their rows now, on the side stream next to the budgeted
+        // pass, and stay in the tier as whole-tree searches like the zero-length ones above: no budget's worth of items expanded for
+        // nothing, no second pass over the tier for them.  (As many as the table takes; the rest leave the pass at once.)
+        const size_t rowsMax = pre_rows_max();
+        for (int i = 0; i < n && preIdx.size() < rowsMax; i++)
+            if (c->h_over_hint[nodes[i]] && !(matPre && c->h_tree_mut[nodes[i]] >= 0)) preIdx.push_back(i);   // (a reference node itself: as above)
+        TRY(pre_rows(false));
     }
     // Frontier tier (frontier.hip): every search of the batch expanded level by level, one lane per (search, branch) item,
     // then replayed exactly -- for trees without MAT local references.  What it hands back (a search that would edit its
@@ -1465,7 +1486,12 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
         if (hybrid && c->dm.usingErrorRate && !c->tuning.noOverHint && (int)c->h_over_hint.size() >= c->dtree.n) {
             overHint.resize((size_t)n);
             size_t nHint = 0;
-            for (int i = 0; i < n; i++) { overHint[i] = c->h_over_hint[todo[i]]; nHint += overHint[i]; }
+            hintedNow.assign((size_t)n, 0);
+            for (int i = 0; i < n; i++) {
+                hintedNow[i] = c->h_over_hint[todo[i]];
+                overHint[i] = hintedNow[i] && !(!preRowOf.empty() && preRowOf[i] >= 0);   // (with a row: a whole-tree search inside this pass)
+                nHint += overHint[i];
+            }
             if (!nHint) overHint.clear();
             else if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: %zu searches that ran over the budget last time go to the dense tier at once\n", tms(tStart, tnow()), nHint);
         }
@@ -1477,7 +1503,6 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             if ((int)c->h_over_hint.size() < c->dtree.n) c->h_over_hint.resize((size_t)c->dtree.n, 0);
             for (int i = 0; i < n; i++)
                 if (ho[i].status == -5 && (overHint.empty() || !overHint[i])) c->h_over_hint[todo[i]] = 1;
-            hintedNow.swap(overHint);
         }
         std::vector<int32_t> todoFb, slotFb;
         for (int i = 0; i < n; i++)
