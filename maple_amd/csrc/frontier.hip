@@ -1157,7 +1157,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
                         + F.sw.cap * sizeof(uint2) + F.sa.cap * sizeof(double) + F.sais.cap * sizeof(double) + F.bw.cap * 48 + F.bw2.cap * 48;
     const double room = 0.5 * (double)(freeB + held);
     // (first guesses, for a context's first batch: afterwards the pools go by what the batch before used.  With an error model a fifth
-    // of the searches runs to the budget -- a quarter of it per search on average, and twice the temporary lists: measured 1 500
+    // of the searches runs to the budget -- a quarter of it per search on average, and three times the temporary lists: measured 1 500
     // cached items and 61 lists per search at 1 000 000 tips, where a first call that ran over took 2.9-5.3 s and the two calls
     // after it 2.3-3.1 s before the pools had grown)
     const bool longSearches = c->dm.usingErrorRate && !(wide && wide->forceWide);
@@ -1167,7 +1167,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     // (roots: the cached-regime items the list-updating items push -- the upper part of the cached pool)
     long long capR = std::max<long long>(1 << 16, std::min(capC, (long long)m * std::min<long long>(budget, 32)));
     const long long meanEnt = std::max<long long>(16, c->h_n_ent.empty() ? 64 : c->used_ent / (long long)c->h_n_ent.size());   // entries per list in the arena
-    long long capL = (longSearches ? 4 : 2) * capU;
+    long long capL = (longSearches ? 6 : 2) * capU;
     long long capW = 2 * capL * meanEnt, capA = capW;
     if (F.needM > 0 && !(wide && wide->forceWide)) {
         // what the last batch asked for, scaled to this one: with an error model the searches are several times as long as the
