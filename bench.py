@@ -574,8 +574,10 @@ def run_leg(args, env):
                  "events); algorithmic bytes, counted on the device = the two lists every mergeVectors of an item reads and the one it "
                  "writes (8E + 8A each).  A level lasts as long as its slowest wavefront (64 items, ~1000 dependent list steps): "
                  "latency-bound, see DESIGN.md"),
-            roof("k_wit_score (whole-tree searches: the witness filter rules out the branches that score -inf by appendProbNode's own "
-                 "rule, the pairs that are left are walked)", "SPR_SCORE",
+            roof(("k_append_queries_lds (whole-tree searches with an error model: every (search, branch) pair walked, a tile of 64 "
+                  "candidate lists staged in LDS per 512 queries)") if args.model == "siteerr" else
+                 ("k_wit_score (whole-tree searches: the witness filter rules out the branches that score -inf by appendProbNode's own "
+                  "rule, the pairs that are left are walked)"), "SPR_SCORE",
                  "rank 0; units = (search, branch) pairs walked, algorithmic bytes = SURVEY 8d for those pairs (8E + 8A + 8 per candidate "
                  "list, each removed list once); the time is the whole stage: witnesses, buckets, pair list, walks, bitmap prefix "
                  "(when the dense kernel k_append_queries_lds runs instead -- error model, local references, searches that were not "
