@@ -156,6 +156,8 @@ struct maple_ctx {
     // the same candidates in the searches' own depth-first order whatever the tree (host): list id, preRank, reference frame
     std::vector<int32_t> h_cand_ids, h_cand_rank, h_cand_frame;
     std::vector<uint8_t> h_over_hint;  // per node: its SPR search ran over the wide-search budget the last time (error model: routing hint, dropped with the tree)
+    int64_t cand_root_mark = -1, cand_root_top = -1;   // where the copies begin (an arena mark) and the list count right after them: stale copies
+                                        // that are still the arena's last lists are released before new ones are made
     int64_t cand_root_end = -1;        // >= 0: s_cand_root is current (the root-frame copies are arena lists below this id); dropped with the
                                        // tree, by a maple_arena_release below them, by maple_arena_compact
     DevBuf<int32_t> s_frame_parent, s_frame_node;   // the frames' nesting on the device (per call of the SPR search)

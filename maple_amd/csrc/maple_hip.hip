@@ -1212,6 +1212,7 @@ extern "C" int maple_arena_release(maple_ctx *c, int64_t markBoth)
     }
     if (mark == (int64_t)c->h_n_ent.size()) return MAPLE_OK;
     if (mark < c->cand_root_end) c->cand_root_end = -1;                 // (the candidates' root-frame copies go with the release)
+    if (mark < c->cand_root_top) c->cand_root_mark = c->cand_root_top = -1;
     int64_t ue = c->h_ent_off[mark], ua = c->h_aux_off[mark];
     {   // a list below the mark that maple_lists_update moved to the end of the arena keeps its (new) room
         size_t k = 0;
@@ -1294,6 +1295,7 @@ extern "C" int maple_arena_compact(maple_ctx *c, int64_t nLive, const int32_t *l
     c->used_ent = totE; c->used_aux = totA;
     c->relocated.clear();
     c->tree_set = false; c->tree_stale = false; c->nodes_current = false; c->scan_valid = false; c->cand_root_end = -1;
+    c->cand_root_mark = c->cand_root_top = -1;                          // (the lists were renumbered)
     if (c->place) { c->place->valid = false; c->place->rootVect = -1; }
     for (auto &cs : c->candsets) {
         if (cs.lists) (void)hipFree(cs.lists);

@@ -1015,11 +1015,19 @@ static int lists_to_root_frame(maple_ctx *c, std::vector<int32_t> &ids, std::vec
 static int ensure_cand_root(maple_ctx *c)
 {
     if (c->cand_root_end >= 0) return MAPLE_OK;
+    // (the copies of a tree that has been patched or uploaded again since: n_scored lists nobody reads any more.  They go when they are
+    // still the last lists of the arena -- the usual case in a loop of searches and patches; lists the caller appended behind them pin
+    // them until the caller's own release)
+    if (c->cand_root_mark >= 0 && c->cand_root_top == (int64_t)c->h_n_ent.size()) TRY(maple_arena_release(c, c->cand_root_mark));
+    c->cand_root_mark = c->cand_root_top = -1;
+    int64_t begin = -1;
+    TRY(maple_arena_mark(c, &begin));
     std::vector<int32_t> candRoot(c->h_cand_ids);
     TRY(lists_to_root_frame(c, candRoot, c->h_cand_frame));
     TRY(h2d(c, c->s_cand_root, candRoot.data(), candRoot.size()));
     HIPCK(c, hipStreamSynchronize(c->stream));
     c->cand_root_end = (int64_t)c->h_n_ent.size();
+    c->cand_root_mark = begin; c->cand_root_top = c->cand_root_end;
     return MAPLE_OK;
 }
 

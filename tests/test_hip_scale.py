@@ -597,6 +597,40 @@ def test_batch_kernel_with_queries_longer_than_the_lds_stage():
     dev.close()
 
 
+def test_root_frame_candidate_copies_do_not_pile_up_in_the_arena():
+    """A tree with local references: the whole-tree searches' rows are made in the ROOT's frame, from copies of every candidate list
+    re-expressed there once per tree (ensure_cand_root, spr_batch.hip).  maple_tree_patch / maple_tree_upload drop the copies'
+    validity; the next search makes new ones.  The stale ones must go when they are still the arena's last lists -- a loop of
+    rounds and patches used to gain n_scored lists per turn -- and the rounds' results must not change."""
+    import bench
+    from maple_amd.mat import add_local_references
+    from maple_amd.tree_host import HostTree
+    data, dev, orc, m = build(3000, "unrest", seed=6)
+    ht = HostTree.from_mirror(m)
+    assert add_local_references(dev, ht, 50) > 20
+    dist = np.asarray([float(x or 0.0) for x in ht.dist])
+    cols = (m.parent, m.children[:, 0], m.children[:, 1], dist, m.is_tip, ht.id_lower, ht.id_upRight, ht.id_upLeft, ht.id_totUp)
+    dev.upload_tree(ht.root, *cols, ht.id_mut)
+    kw = bench.search_kwargs(dev.lRef)
+    nodes = bench.preorder_nodes(m)
+    first, counts = None, []
+    before = dev.stats()["n_lists"]
+    touched = np.asarray(nodes[:8], dtype=np.int32)
+    for turn in range(4):
+        g = dev.spr_search_batch(nodes, **kw)
+        if first is None:
+            first = g
+        for k in ("status", "bestNode", "placement", "nAppend", "bestScore", "currentLK", "improvement", "blen"):
+            assert np.array_equal(g[k], first[k]), (turn, k)
+        counts.append(dev.stats()["n_lists"])
+        # the same records again: nothing changes but the library's tables are stale
+        dev.tree_patch(m.n_nodes, touched, *[np.asarray(c)[touched] for c in cols])
+    assert (first["status"] == 0).sum() > 1000
+    assert counts[0] - before > 1000, (before, counts)               # (the copies were made: one per scored branch)
+    assert counts[0] == counts[1] == counts[2] == counts[3], counts  # (... and replaced, not added to, after every patch)
+    dev.close()
+
+
 def test_bench_two_ranks_plumbing():
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank) on a box with ONE GPU:
     MAPLE_BENCH_BACKEND=gloo lets both ranks share it and sends the collectives through host memory.  Checks the N > 1
