@@ -261,7 +261,10 @@ int maple_tree_patch(maple_ctx *ctx, int32_t nTotal, int32_t nTouched, const int
  *   (the "candidate placements" of the metric); status: 0 searched, 1 root, 2 not searched (M:9674),
  *   -1 the reference would have raised inside the search (its worker swallows it, M:9703),
  *   -3 per-lane workspace exhausted (retry with a larger ws_entries_per_lane).
- * outRprList (may be NULL): new list ids of bestRemovedPartials.  ws_entries_per_lane: 0 = default. */
+ * outRprList (may be NULL): new list ids of bestRemovedPartials.  ws_entries_per_lane: 0 = default.
+ * State kept between calls (scheduling only, never results): with an error model the context remembers, per node of the uploaded
+ * tree, that the node's search ran over the whole-tree budget, and sends it to the dense tier at once the next time -- kept across
+ * maple_tree_patch, dropped by maple_tree_upload, switched off by maple_tuning.noOverHint. */
 int maple_spr_search_batch(maple_ctx *ctx, int32_t n, const int32_t *nodes, const maple_search_params *params,
                            int32_t ws_entries_per_lane, int32_t *bestNode, double *bestScore, double *blen3,
                            int32_t *placement, double *improvement, double *currentLK, int32_t *nAppend,
