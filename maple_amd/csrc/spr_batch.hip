@@ -393,6 +393,14 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         || !totUp || !mutList)
         return MAPLE_ERR_ARG;
     HIPCK(c, hipSetDevice(c->device));
+    const bool dbgU = c->tuning.verbose != 0;
+    auto tU0 = std::chrono::steady_clock::now();
+    auto lapU = [&](const char *what) {
+        if (!dbgU) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[maple] tree upload: %s %.1f ms\n", what, std::chrono::duration_cast<std::chrono::microseconds>(t - tU0).count() * 1e-3);
+        tU0 = t;
+    };
     TRY(check_ids(c, n, lower, true, "lower"));
     TRY(check_ids(c, n, upRight, true, "upRight"));
     TRY(check_ids(c, n, upLeft, true, "upLeft"));
@@ -423,6 +431,7 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
             }
         }
     }
+    lapU("columns checked, reachability");
     const int32_t *src[9] = {up, child0, child1, lower, upRight, upLeft, totUp, mutList, nullptr};
     for (int k = 0; k < 8; k++) TRY(h2d(c, c->t_i32[k], src[k], (size_t)n));
     TRY(h2d(c, c->t_dist, dist, (size_t)n));
@@ -442,7 +451,9 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
     c->place->valid = false;
     c->place->rootVect = -1;
     c->dtree.n = n; c->dtree.root = root;
+    lapU("columns on the device and in the host copy");
     TRY(compute_frames(c));
+    lapU("reference frames");
     const PlaceMeta &F = *c->place;
     std::vector<NodeRec> recs((size_t)n);
     for (int i = 0; i < n; i++) {
@@ -459,6 +470,7 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         r.c1Frame = child1[i] >= 0 ? F.frameOf[child1[i]] : r.frameOf;
         r.upFrame = up[i] >= 0 ? F.frameOf[up[i]] : r.frameOf;
     }
+    std::vector<int32_t> rankOrder;                                    // node of every depth-first rank
     {   // depth-first ranks in the order the searches descend (the child pushed last, child 1, is visited first)
         std::vector<int32_t> st;
         std::vector<uint8_t> seen((size_t)n, 0);
@@ -481,7 +493,9 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
             const int v = byRank[r], u = up[v];
             if (u >= 0 && seen[v] && recs[u].preRank < r) c->h_depth[v] = c->h_depth[u] + 1;
         }
+        rankOrder.swap(byRank);
     }
+    lapU("node records, depth-first ranks, depths");
     HIPCK(c, c->t_nodes.reserve(((size_t)n + (size_t)n / 8 + 1024) * sizeof(NodeRec) + 64));   // (room for the nodes patches add)
     uint8_t *aligned = (uint8_t *)(((uintptr_t)c->t_nodes.p + 63) & ~(uintptr_t)63);
     HIPCK(c, hipMemcpy(aligned, recs.data(), (size_t)n * sizeof(NodeRec), hipMemcpyHostToDevice));
@@ -502,20 +516,26 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         for (const int32_t *col : {lower, upRight, upLeft, totUp})
             if (col[i] >= 0) c->tree_max_ent = std::max(c->tree_max_ent, c->h_n_ent[col[i]]);
     }
+    lapU("node records on the device, longest list");
     {   // The dense scoring of the whole-tree searches takes its candidates in the searches' own depth-first order: the 64
         // scores of a tile then land next to each other in the search's row of the score table (a contiguous 512-byte
         // store instead of 64 partial-line stores, which WRITE_SIZE counts 4x), and neighbours in the tree have lists of
         // similar length anyway.  Measured at 100 000 tips: 1 017 -> 940 ms per round against candidates sorted by length.
+        // (ranks are a permutation: the candidates in rank order are read off the rank table, and "by frame, then by rank" is one
+        // stable counting pass over that -- two comparison sorts of 2 M nodes through their 100-byte records were 1.4 s of a
+        // 1.7 s upload at 1 000 000 tips)
+        std::vector<int32_t> byRank;
+        byRank.reserve((size_t)n);
+        for (int r = 0; r < n; r++) { const int v = rankOrder[r]; if (totUp[v] >= 0) byRank.push_back(v); }
         std::vector<int32_t> col;
-        for (int i = 0; i < n; i++) if (totUp[i] >= 0) col.push_back(i);
-        if (c->tree_has_mut)                                          // by reference frame, then depth-first: a chunk of 64
-            std::stable_sort(col.begin(), col.end(), [&](int a, int b) {     // candidates shares ONE copy of the query
-                return recs[a].frameOf != recs[b].frameOf ? recs[a].frameOf < recs[b].frameOf : recs[a].preRank < recs[b].preRank; });
-        else
-            std::stable_sort(col.begin(), col.end(), [&](int a, int b) { return recs[a].preRank < recs[b].preRank; });
+        if (c->tree_has_mut) {                                        // by reference frame, then depth-first: a chunk of 64
+            std::vector<int64_t> start((size_t)F.nF + 1, 0);          // candidates shares ONE copy of the query
+            for (int v : byRank) start[(size_t)recs[v].frameOf + 1]++;
+            for (int f = 0; f < F.nF; f++) start[f + 1] += start[f];
+            col.resize(byRank.size());
+            for (int v : byRank) col[(size_t)start[recs[v].frameOf]++] = v;
+        } else col = byRank;
         {   // (in rank order whatever the tree: what the rows that come with bitmaps are indexed by, FiniteRows)
-            std::vector<int32_t> byRank(col);
-            if (c->tree_has_mut) std::stable_sort(byRank.begin(), byRank.end(), [&](int a, int b) { return recs[a].preRank < recs[b].preRank; });
             c->h_cand_ids.resize(byRank.size()); c->h_cand_rank.resize(byRank.size()); c->h_cand_frame.resize(byRank.size());
             for (size_t i = 0; i < byRank.size(); i++) {
                 c->h_cand_ids[i] = totUp[byRank[i]]; c->h_cand_rank[i] = recs[byRank[i]].preRank; c->h_cand_frame[i] = recs[byRank[i]].frameOf;
@@ -544,6 +564,7 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         TRY(h2d(c, c->t_scored_frame, fr.data(), fr.size()));
         HIPCK(c, hipStreamSynchronize(c->stream));
     }
+    lapU("candidate order");
     c->tree_set = true;
     c->tree_stale = false;
     return MAPLE_OK;
