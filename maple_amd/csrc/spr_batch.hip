@@ -381,6 +381,7 @@ static int compute_frames(maple_ctx *c)
     for (auto &f : M.frameOf) if (f >= 0) f = inv[f];
     M.nF = nF;
     for (auto &f : M.frameOf) if (f < 0) f = 0;                           // nodes not reachable from the root
+    c->h_depth.swap(depth);                                               // (levels below the root; 0 for what the root does not reach)
     return MAPLE_OK;
 }
 
@@ -471,29 +472,14 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         r.upFrame = up[i] >= 0 ? F.frameOf[up[i]] : r.frameOf;
     }
     std::vector<int32_t> rankOrder;                                    // node of every depth-first rank
-    {   // depth-first ranks in the order the searches descend (the child pushed last, child 1, is visited first)
-        std::vector<int32_t> st;
+    {   // depth-first ranks in the order the searches descend (the child pushed last, child 1, is visited first): the order
+        // compute_frames walked the tree in (PlaceMeta::order; it left the depths in h_depth) -- not walked a third time
         std::vector<uint8_t> seen((size_t)n, 0);
         int32_t next = 0;
-        if (root >= 0 && root < n) st.push_back(root);
-        while (!st.empty()) {
-            const int32_t v = st.back();
-            st.pop_back();
-            if (v < 0 || v >= n || seen[v]) continue;
-            seen[v] = 1;
-            recs[v].preRank = next++;
-            if (child0[v] >= 0) { st.push_back(child0[v]); st.push_back(child1[v]); }
-        }
-        for (int i = 0; i < n; i++) if (!seen[i]) recs[i].preRank = next++;   // nodes not reachable from the root
-        std::vector<int32_t> byRank((size_t)n, 0);
-        for (int i = 0; i < n; i++) byRank[recs[i].preRank] = i;
-        c->h_depth.assign((size_t)n, 0);
+        rankOrder.assign((size_t)n, 0);
+        for (const int32_t v : F.order) { seen[v] = 1; recs[v].preRank = next; rankOrder[(size_t)next++] = v; }
+        for (int i = 0; i < n; i++) if (!seen[i]) { recs[i].preRank = next; rankOrder[(size_t)next++] = i; }   // nodes not reachable from the root
         c->h_clade.clear();
-        for (int r = 0; r < n; r++) {                                          // parents precede their children in rank order
-            const int v = byRank[r], u = up[v];
-            if (u >= 0 && seen[v] && recs[u].preRank < r) c->h_depth[v] = c->h_depth[u] + 1;
-        }
-        rankOrder.swap(byRank);
     }
     lapU("node records, depth-first ranks, depths");
     HIPCK(c, c->t_nodes.reserve(((size_t)n + (size_t)n / 8 + 1024) * sizeof(NodeRec) + 64));   // (room for the nodes patches add)
