@@ -922,8 +922,12 @@ static int build_scan_tables(maple_ctx *c, const SearchParams &P)
     // Node slots the root does not reach (a tree read from a file keeps the slots of collapsed nodes, their `up` still
     // naming a live node) rank behind every reachable node and belong to no clade: counted into their stale parent's
     // clade they made the scan of that parent -- and of every ancestor -- run past the clade's end.
+    // (what the root reaches, and how deep: the upload's own walk of the tree has both -- PlaceMeta::order, h_depth)
     std::vector<uint8_t> reach(nT, 0);
-    {
+    int32_t maxDepth = 0;
+    if (!c->tree_stale && c->place && (int)c->h_depth.size() == nT && !c->place->order.empty() && c->place->order[0] == c->dtree.root) {
+        for (const int32_t v : c->place->order) { reach[v] = 1; depth[v] = c->h_depth[v]; maxDepth = std::max(maxDepth, depth[v]); }
+    } else {
         std::vector<int32_t> stk{c->dtree.root};
         while (!stk.empty()) {
             const int v = stk.back();
@@ -931,13 +935,12 @@ static int build_scan_tables(maple_ctx *c, const SearchParams &P)
             reach[v] = 1;
             if (c->h_tree_c0[v] >= 0) { stk.push_back(c->h_tree_c0[v]); stk.push_back(c->h_tree_c1[v]); }
         }
-    }
-    int32_t maxDepth = 0;
-    for (int r = 0; r < nT; r++) {                                      // parents precede their clades in rank order
-        const int v = byRank[r];
-        const int u = c->h_tree_up[v];
-        if (reach[v] && u >= 0 && v != c->dtree.root && c->h_nodes[u].preRank < r) depth[v] = depth[u] + 1;
-        maxDepth = std::max(maxDepth, depth[v]);
+        for (int r = 0; r < nT; r++) {                                  // parents precede their clades in rank order
+            const int v = byRank[r];
+            const int u = c->h_tree_up[v];
+            if (reach[v] && u >= 0 && v != c->dtree.root && c->h_nodes[u].preRank < r) depth[v] = depth[u] + 1;
+            maxDepth = std::max(maxDepth, depth[v]);
+        }
     }
     for (int r = nT - 1; r >= 0; r--) {
         const int v = byRank[r];
