@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0     # ... the measured copy rate, the denominator SURVEY 8d names: reported next to the spec peak (frac_of_copy)
 
 UNREST_Q = [[-0.5524, 0.0602, 0.3655, 0.1267],
             [0.1666, -2.6077, 0.0405, 2.4006],
@@ -161,6 +162,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-1m", action="store_true",
                     help="skip the second leg of the default run (BASELINE configs[3]: 1 000 000 samples, full model)")
     ap.add_argument("--steps-1m", type=int, default=3, help="timed steps of the 1 000 000-sample leg (131 072 searches each)")
+    ap.add_argument("--online-add", type=int, default=50000,
+                    help="BASELINE configs[4] on the 1 000 000-sample leg's tree (one GPU): this many new samples added one after the "
+                         "other (placement search, tree edit, maple_update_partials, maple_tree_patch: M:11692-11752), then one round "
+                         "of searches on the grown tree; 0 = skip")
     return ap.parse_args(argv)
 
 
@@ -236,7 +241,8 @@ def compact_line(full):
             return None
         src = r.get("traffic_source")
         return {"bound": r["bound"], "kernel": str(r["kernel"]).split()[0], "achieved": _num(r["achieved"]), "peak": r["peak"],
-                "unit": r["unit"], "frac": _num(r["frac"]), "traffic": _num(r.get("traffic")),
+                "unit": r["unit"], "frac": _num(r["frac"]), "peak_copy": r.get("peak_copy"), "frac_of_copy": _num(r.get("frac_of_copy")),
+                "traffic": _num(r.get("traffic")),
                 "traffic_over_algorithmic": _num(r["traffic"] / r["algorithmic_bytes_per_launch"], 4)
                 if r.get("traffic") and r.get("algorithmic_bytes_per_launch") else None,
                 "traffic_source": src.get("file") if isinstance(src, dict) else src,
@@ -272,6 +278,10 @@ def compact_line(full):
                              "first_step_after_upload_ms": _num(leg.get("first_step_after_upload_ms"), 5),
                              "roofline": {k: v for k, v in (roof(leg.get("roofline")) or {}).items()
                                           if k in ("bound", "kernel", "achieved", "peak", "frac", "kernel_ms", "kernel_ms_per_step")}}
+    c5 = full.get("config_5")
+    if c5:
+        line["config_5"] = {"samples_added": c5["samples_added"], "ms_per_sample": _num(c5["ms_per_sample"], 4), "total_s": _num(c5["total_s"], 4),
+                            "round_after_ms": _num(c5["round_after"]["round_after_ms"], 5), "round_after_searches": c5["round_after"]["searches"]}
     line["detail"] = full.get("detail_file")
     text = json.dumps(line, separators=(",", ":"))
     if len(text) > LINE_LIMIT:                            # (cannot happen with the bounded fields above; never print a long line)
@@ -311,11 +321,14 @@ def main():
         # under-reports -- at this size they stop growing after the third call)
         a2.samples, a2.model, a2.batch, a2.steps, a2.warmup = 1000000, "siteerr", 131072, args.steps_1m, 3
         a2.no_extras, a2.no_cpu_baseline, a2.synth = True, True, "v2"
+        a2.online_leg = args.online_add if env.world == 1 else 0   # (configs[4]: the serial loop of one process; see online_update_leg)
         leg2 = run_leg(a2, env)
         if env.rank == 0:
             keep = ("metric", "value", "value_walked", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "data",
                     "config", "roofline", "roofline_by_kernel", "per_rank", "spr_search", "first_call_ms", "first_step_after_upload_ms", "tree_reupload_ms")
             out["config_1M_full_model"] = {k: leg2[k] for k in keep if k in leg2}
+            if leg2.get("config_5"):
+                out["config_5"] = leg2["config_5"]
     if env.rank == 0:
         write_detail(out)
         _, text = compact_line(out)
@@ -558,7 +571,9 @@ def run_leg(args, env):
             ach = (bytes_ / (ms * 1e-3) / 1e9) if ms else 0.0
             peak = {"hbm": HBM_PEAK_GBS, "lds": LDS_PEAK_GBS, "counted": None}[bound]
             return {"bound": bound, "kernel": kernel, "achieved": ach if peak else None, "peak": peak, "unit": "GB/s",
-                    "frac": (ach / peak) if peak else None, "traffic": traffic.get(kernel.split()[0]), "traffic_source": traffic_source,
+                    "frac": (ach / peak) if peak else None,
+                    "peak_copy": HBM_COPY_GBS if bound == "hbm" else None, "frac_of_copy": (ach / HBM_COPY_GBS) if bound == "hbm" else None,
+                    "traffic": traffic.get(kernel.split()[0]), "traffic_source": traffic_source,
                     "pmc_per_step": pmc_issue.get(kernel.split()[0]),
                     "algorithmic_bytes_per_launch": bytes_ / max(1, n), "kernel_ms": ms / max(1, n), "launches_timed": n,
                     "kernel_ms_per_step": ms / steps, "units_per_step": units / steps, "note": what}
@@ -675,10 +690,67 @@ def run_leg(args, env):
                 raise SystemExit(f"tree log-LK: GPU and oracle differ by more than 1e-6 relative: {out['tree_log_lk']}")
             out["cpu_baseline"] = spr_cpu_baseline(dev, mirror, ht, ref_idx, root_freqs, batch_of, kept, kw, args.cpu_seconds, mkw,
                                                    args.steps)
+    if getattr(args, "online_leg", 0) and rank == 0 and world == 1:
+        out["config_5"] = online_update_leg(dev, mirror, data, ref_idx, tip_kw, kw, args.online_leg, B)
     if distd is not None:
         distd.barrier()
     dev.close()
     return out if rank == 0 else None
+
+
+def online_update_leg(dev, mirror, data, ref_idx, tip_kw, kw, n_add, round_nodes):
+    """BASELINE configs[4]: ``n_add`` new samples added to the leg's tree one after the other -- the reference's loop M:11692-11752:
+    findBestParentForNewSample, placeSampleOnTree, updatePartials; here serial_phase (single-query placement search, the
+    stand-in tree edit, maple_update_partials, maple_tree_patch) -- then one round of searches on the grown tree
+    (--largeUpdate: the rounds run with every node dirty, M:12143-12159; timed here: ``round_nodes`` of them, the nodes the
+    additions touched first).  On the plain form of the tree (every list in the root's frame), as the config-5 test
+    (tests/test_hip_configs.py) runs it; the new samples are tips of the tree with one to three changes each
+    (maple_amd.synth.perturb_diffs).  Wall times through the Python binding, the sample lists packed beforehand."""
+    from maple_amd.host import tip_genome_list
+    from maple_amd.synth import perturb_diffs
+    l_ref = dev.lRef
+    ll = math.log(l_ref)
+    pkw = dict(oneMutBLen=1.0 / l_ref, effectivelyNon0BLen=1.0 / (10 * l_ref), thresholdLogLK=18.0 * ll,
+               thresholdLogLKoptimization=1.0 * ll, thresholdLogLKconsecutivePlacement=1.0)
+    prng = np.random.default_rng(21)
+    t0 = time.perf_counter()
+    src = prng.choice(len(data.diffs), size=n_add, replace=False)
+    new_lists = [tip_genome_list(perturb_diffs(data.diffs[int(i)], data.ref, prng), ref_idx, **tip_kw) for i in src]
+    prep_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sp = serial_phase(dev, mirror, new_lists, pkw)
+    total_s = time.perf_counter() - t0
+    cols = sp["cols"]
+    n = cols["n"]
+    per = {k: (1e3 * float(np.mean(v)) if len(v) else float("nan")) for k, v in sp["times"].items()}
+    third = max(1, len(sp["times"]["search"]) // 3)
+    # ---- the round after the update, on the grown tree (the library's copy is current through the patches)
+    first = sp["touched_nodes"]
+    rest = np.setdiff1d(np.arange(n), first)
+    nodes = np.concatenate([first[:: max(1, -(-len(first) // (round_nodes // 2)))], rest[:: max(1, len(rest) // (round_nodes // 2))]])[:round_nodes]
+    t0 = time.perf_counter()
+    r = dev.spr_search_batch(nodes.astype(np.int64), **kw)
+    round_first_ms = 1e3 * (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    r = dev.spr_search_batch(nodes.astype(np.int64), **kw)
+    round_ms = 1e3 * (time.perf_counter() - t0)
+    bad = int((r["status"] < -1).sum())
+    if bad:
+        raise SystemExit(f"config 5: {bad} searches of the round after the update failed")
+    return {"samples_added": int(sp["placed"]), "samples_offered": int(n_add), "skipped": int(sp["skipped"]),
+            "ms_per_sample": 1e3 * total_s / max(1, n_add), "total_s": total_s,
+            "loop_ms_per_sample_mean": {"upload_of_the_sample": per["upload"], "placement_search": per["search"],
+                                        "update_partials": per["update"], "tree_patch": per["patch"]},
+            "placement_search_ms_first_third_last_third": [1e3 * float(np.mean(sp["times"]["search"][:third])),
+                                                           1e3 * float(np.mean(sp["times"]["search"][-third:]))],
+            "nodes_patched_per_sample_mean": float(np.mean(sp["patched"])) if sp["patched"] else 0.0, "nodes_touched": int(len(first)),
+            "tree_nodes_before_after": [int(mirror.n_nodes), int(n)],
+            "sample_lists_prepared_s": prep_s,
+            "round_after": {"searches": int(len(nodes)), "first_call_ms": round_first_ms, "round_after_ms": round_ms,
+                            "candidate_placements": int(r["nAppend"][r["status"] >= -1].sum()),
+                            "proposed_moves": int((r["placement"] >= 0).sum())},
+            "note": "one process, one GPU: the loop is serial by construction (every sample is placed on the tree the one before it "
+                    "left); tree edit = bench.serial_phase's stand-in for placeSampleOnTree (host code of the reference, out of scope)"}
 
 
 DEPTH_STEP = 1 << 12        # serial_phase keeps depths in units of 1/4096 of a level: a node put on a branch gets one in between
@@ -715,7 +787,7 @@ def serial_phase(dev, m, new_lists, pkw):
     n = n0
     dev.upload_tree(m.root, up[:n], c0[:n], c1[:n], dist[:n], tip[:n], lower[:n], up_right[:n], up_left[:n], tot_up[:n], mut[:n])
     t = dict(upload=[], search=[], update=[], patch=[])
-    placed, skipped, patched = 0, 0, []
+    placed, skipped, patched, touched_nodes = 0, 0, [], []
     for lst in new_lists:
         dev.placement_prepare(**pkw)
         t0 = time.perf_counter()
@@ -757,10 +829,12 @@ def serial_phase(dev, m, new_lists, pkw):
                        up_right[touched], up_left[touched], tot_up[touched])
         t["patch"].append(time.perf_counter() - t0)
         patched.append(len(touched))
+        touched_nodes.append(touched)
         placed += 1
     cols = dict(n=n, root=m.root, up=up, c0=c0, c1=c1, dist=dist, tip=tip, lower=lower, up_right=up_right, up_left=up_left,
                 tot_up=tot_up, mut=mut)
-    return dict(times=t, placed=placed, skipped=skipped, patched=patched, cols=cols)
+    return dict(times=t, placed=placed, skipped=skipped, patched=patched, cols=cols,
+                touched_nodes=np.unique(np.concatenate(touched_nodes)) if touched_nodes else np.zeros(0, dtype=np.int32))
 
 
 def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_plain_tree, torch, cu, first_step=None, first_nodes=None,

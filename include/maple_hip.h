@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define MAPLE_ABI_VERSION 3
+/* 4 (round 6): maple_tuning begins with its own size, so that a caller compiled against an older header (a shorter struct) is
+ * read for exactly what it passed; the measurement aids of versions <= 3 (maple_debug_*) live in maple_hip_debug.h /
+ * libmaple_hip_debug.so.  A binding checks maple_abi_version() == MAPLE_ABI_VERSION after loading the library. */
+#define MAPLE_ABI_VERSION 4
 
 enum {
     MAPLE_OK = 0,
@@ -74,6 +77,8 @@ int maple_destroy(maple_ctx *ctx);
 /* How the library schedules its work -- never WHAT it computes (every setting gives bit-identical results; the tests flip
  * them to compare kernels).  Zero-initialise, set what is wanted, the rest keeps the library's choice. */
 typedef struct {
+    uint32_t structSize;        /* = sizeof(maple_tuning) of the header the CALLER was compiled with: fields beyond it keep the
+                                   library's choice (0), fields the library does not know are ignored; 0 is an error */
     int32_t wavePerItemMax;     /* the explicit-pair operators (append / merge / blen / differ / shorten), maple_update_partials'
                                    levels and evaluatePlacement batches of at most this many items run one WAVEFRONT per item
                                    (lowest latency), larger ones one lane per item; 0 = the library's own thresholds, -1 = never */

@@ -155,6 +155,7 @@ struct maple_ctx {
     DevBuf<int32_t> t_scored_col, t_scored_frame;
     // the same candidates in the searches' own depth-first order whatever the tree (host): list id, preRank, reference frame
     std::vector<int32_t> h_cand_ids, h_cand_rank, h_cand_frame;
+    int over_hint_budget = -1; double over_hint_eff0 = -1.0;   // the budget and effectivelyNon0BLen the hints were taken under: another pair drops them
     std::vector<uint8_t> h_over_hint;  // per node: its SPR search ran over the wide-search budget the last time (error model: routing hint, dropped with the tree)
     int64_t cand_root_mark = -1, cand_root_top = -1;   // where the copies begin (an arena mark) and the list count right after them: stale copies
                                         // that are still the arena's last lists are released before new ones are made

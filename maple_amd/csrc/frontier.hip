@@ -102,14 +102,14 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restric
         // a search from a zero-length branch without an error model is a whole-tree search (see k_spr_search): dense tier
         bool wide = false;
         if (forceWide && rowOf && rowOf[q] >= 0) {
-            if (wouldMerge) { S.state = FS_OVER; o.status = -5; continue; }   // (the one-wavefront-per-search kernel edits the list in place)
+            if (wouldMerge) { S.state = FS_OVER; o.status = -5; o.nAppend = -1; continue; }   // (the one-wavefront-per-search kernel edits the list in place; nAppend -1: NOT a search over the budget -- no routing hint from it)
             wide = true;
         } else if (!U && budget > zeroBudget && rn.dist == 0.0) {
             wide = rowOf && rowOf[q] >= 0 && !wouldMerge;
-            if (!wide) { S.state = FS_OVER; o.status = -5; continue; }
+            if (!wide) { S.state = FS_OVER; o.status = -5; o.nAppend = -1; continue; }
         } else if (U && rowOf && rowOf[q] >= 0) {
             // (error model: the caller gave this search a row because it ran over the budget the last time)
-            if (wouldMerge) { S.state = FS_OVER; o.status = -5; continue; }
+            if (wouldMerge) { S.state = FS_OVER; o.status = -5; o.nAppend = -1; continue; }
             wide = true;
         }
         S.state = wide ? FS_WIDE : FS_ACTIVE;
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_replay(SearchParams P, int n, F
                         if (nShort && rec.parent >= 0) {                            // (after an event only: two item records per visit)
                             const int hr = item_of(fp, rec.ref).hRpr, hp = item_of(fp, fp.visit[rec.parent].ref).hRpr;
                             if (hr != hp)
-                                for (int j = 0; j < nShort; j++) if (hShort[j] == hp && (long long)rec.parent > rankShort[j]) marked = true;
+                                for (int j = 0; j < nShort; j++) if (hShort[j] == hp && (long long)rec.parent >= rankShort[j]) marked = true;   // (>=: the event item shortens at its own visit, BEFORE it pushes its children, M:7087 / 7116-7118)
                             if (marked) { stop = true; why = 2; }
                         }
                         if (rec.flags & FI_SCORED) {

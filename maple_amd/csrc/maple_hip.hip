@@ -948,8 +948,12 @@ static void update_scratch_free(maple_ctx *c);   // update_host.h
 extern "C" int maple_set_tuning(maple_ctx *c, const maple_tuning *t)
 {
     if (!c || !t) return MAPLE_ERR_ARG;
+    if (t->structSize < sizeof(uint32_t) + sizeof(int32_t)) return fail(c, MAPLE_ERR_ARG, "maple_set_tuning: structSize is not set (sizeof(maple_tuning) of the caller's header)");
     const int32_t verbose = c->tuning.verbose;
-    c->tuning = *t;
+    maple_tuning mine{};                                              // (what the caller's struct does not reach keeps the library's choice)
+    memcpy(&mine, t, std::min<size_t>(t->structSize, sizeof(maple_tuning)));
+    mine.structSize = (uint32_t)sizeof(maple_tuning);
+    c->tuning = mine;
     if (!t->verbose && getenv("MAPLE_DEBUG")) c->tuning.verbose = verbose;   // (the environment variable keeps it on)
     return MAPLE_OK;
 }
@@ -1007,6 +1011,7 @@ extern "C" int maple_set_model(maple_ctx *c, const double *Q16, const double *si
     HIPCK(c, hipSetDevice(c->device));
     DevModel &m = c->dm;
     const int lRef = c->lRef;
+    c->h_over_hint.clear();                                           // (which searches run over the budget is a property of the model too)
     for (int i = 0; i < 16; i++) m.Q[i] = Q16[i];
     m.useRateVariation = siteRates ? 1 : 0;
     m.usingErrorRate = usingErrorRate ? 1 : 0;

@@ -1028,10 +1028,12 @@ static int ensure_cand_root(maple_ctx *c)
     // (the copies of a tree that has been patched or uploaded again since: n_scored lists nobody reads any more.  They go when they are
     // still the last lists of the arena -- the usual case in a loop of searches and patches; lists the caller appended behind them pin
     // them until the caller's own release)
-    if (c->cand_root_mark >= 0 && c->cand_root_top == (int64_t)c->h_n_ent.size()) TRY(maple_arena_release(c, c->cand_root_mark));
+    // (only the genome lists go: the release mark carries the CURRENT count of mutation lists, so that MAT mutation lists the caller
+    // uploaded -- or released -- since the copies were made are left as they are)
+    if (c->cand_root_mark >= 0 && c->cand_root_top == (int64_t)c->h_n_ent.size())
+        TRY(maple_arena_release(c, c->cand_root_mark | ((int64_t)c->h_mut_cnt.size() << 40)));
     c->cand_root_mark = c->cand_root_top = -1;
-    int64_t begin = -1;
-    TRY(maple_arena_mark(c, &begin));
+    const int64_t begin = (int64_t)c->h_n_ent.size();                  // (the list count alone, not an arena mark of both kinds)
     std::vector<int32_t> candRoot(c->h_cand_ids);
     TRY(lists_to_root_frame(c, candRoot, c->h_cand_frame));
     TRY(h2d(c, c->s_cand_root, candRoot.data(), candRoot.size()));
@@ -1328,6 +1330,10 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
     // the way: with an error model the doubling stops at 8 192)
     if (sp->wideSearchBudget == 0) wideBudget = c->dm.usingErrorRate ? std::min(2 * wideBudget, std::max(wideBudget, 8192)) : 2 * wideBudget;
     const bool hybrid = wideBudget > 0;
+    if (c->over_hint_budget != wideBudget || c->over_hint_eff0 != sp->effectivelyNon0BLen) {   // (hints taken under another budget or
+        c->h_over_hint.clear();                                                                // threshold say nothing about this one)
+        c->over_hint_budget = wideBudget; c->over_hint_eff0 = sp->effectivelyNon0BLen;
+    }
     if (hybrid && !(c->scan_valid && c->scan_eff == P.effNon0) && !c->tuning.noCladeScan) {
         TRY(build_scan_tables(c, P));
         if (dbgT) fprintf(stderr, "[maple] t=%.1f ms: scan tables of the tree built (first search since it changed)\n", tms(tStart, tnow()));
@@ -1520,7 +1526,7 @@ extern "C" int maple_spr_search_batch(maple_ctx *c, int32_t n, const int32_t *no
             // what this pass saw: over the budget -> the hint is set; a hinted search's hint is looked at again when its result is in
             if ((int)c->h_over_hint.size() < c->dtree.n) c->h_over_hint.resize((size_t)c->dtree.n, 0);
             for (int i = 0; i < n; i++)
-                if (ho[i].status == -5 && (overHint.empty() || !overHint[i])) c->h_over_hint[todo[i]] = 1;
+                if (ho[i].status == -5 && ho[i].nAppend >= 0 && (overHint.empty() || !overHint[i])) c->h_over_hint[todo[i]] = 1;   // (nAppend -1: left for shorten(), k_fr_begin -- not over the budget)
         }
         std::vector<int32_t> todoFb, slotFb;
         for (int i = 0; i < n; i++)

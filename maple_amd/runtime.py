@@ -49,7 +49,7 @@ class MapleSearchParams(C.Structure):
 
 
 class MapleTuning(C.Structure):
-    _fields_ = [("wavePerItemMax", C.c_int32), ("placementChunkMax", C.c_int32), ("noCladeScan", C.c_int32), ("verbose", C.c_int32),
+    _fields_ = [("structSize", C.c_uint32), ("wavePerItemMax", C.c_int32), ("placementChunkMax", C.c_int32), ("noCladeScan", C.c_int32), ("verbose", C.c_int32),
                 ("wideOutsideFrontier", C.c_int32), ("denseWideScoring", C.c_int32), ("waveAllBelow", C.c_int32), ("noOverHint", C.c_int32)]
 
 
@@ -78,7 +78,10 @@ def load_library(debug=False):
     global _lib, _lib_debug
     if (_lib_debug if debug else _lib) is None:
         default = LIB_PATH_DEBUG if debug else LIB_PATH
-        lib_path = os.environ.get("MAPLE_HIP_LIB", default)          # (kernel-variant experiments: another build of the library)
+        # (kernel-variant experiments: another build of the library.  MAPLE_HIP_LIB names a product build and never the debug
+        # one -- a product variant has no maple_debug_* symbols, a debug build behind the product handle would carry the debug ABI;
+        # MAPLE_HIP_LIB_DEBUG names a debug variant)
+        lib_path = os.environ.get("MAPLE_HIP_LIB_DEBUG" if debug else "MAPLE_HIP_LIB", default)
         if not os.path.exists(lib_path):
             raise MapleError(f"{lib_path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`; "
                              "there is no CPU fallback for the placement path")
@@ -91,7 +94,9 @@ def load_library(debug=False):
         lib = C.CDLL(lib_path)
         lib.maple_last_error.restype = C.c_char_p
         for name in EXPORTS + (DEBUG_EXPORTS if debug else []):
-            getattr(lib, name)       # fail early if a declared symbol is not exported
+            if not hasattr(lib, name):       # fail early if a declared symbol is not exported
+                raise MapleError(f"{lib_path} does not export {name} (include/maple_hip{'_debug' if name in DEBUG_EXPORTS else ''}.h): "
+                                 "rebuild it with __graft_entry__.build()")
         if debug:
             _lib_debug = lib
         else:
@@ -162,7 +167,7 @@ class Device:
     def set_tuning(self, *, wave_per_item_max=0, placement_chunk_max=0, no_clade_scan=False, verbose=0, wide_outside_frontier=False,
                    dense_wide_scoring=False, wave_all_below=0, no_over_hint=False):
         """How the library schedules its work (never what it computes): see maple_tuning in include/maple_hip.h."""
-        t = MapleTuning(int(wave_per_item_max), int(placement_chunk_max), int(bool(no_clade_scan)), int(verbose),
+        t = MapleTuning(C.sizeof(MapleTuning), int(wave_per_item_max), int(placement_chunk_max), int(bool(no_clade_scan)), int(verbose),
                         int(bool(wide_outside_frontier)), int(bool(dense_wide_scoring)), int(wave_all_below), int(bool(no_over_hint)))
         self._ck(self.lib.maple_set_tuning(self.h, C.byref(t)))
 

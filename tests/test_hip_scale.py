@@ -613,7 +613,7 @@ def test_root_frame_candidate_copies_do_not_pile_up_in_the_arena():
     dev.upload_tree(ht.root, *cols, ht.id_mut)
     kw = bench.search_kwargs(dev.lRef)
     nodes = bench.preorder_nodes(m)
-    first, counts = None, []
+    first, counts, mut_ids = None, [], []
     before = dev.stats()["n_lists"]
     touched = np.asarray(nodes[:8], dtype=np.int32)
     for turn in range(4):
@@ -623,8 +623,18 @@ def test_root_frame_candidate_copies_do_not_pile_up_in_the_arena():
         for k in ("status", "bestNode", "placement", "nAppend", "bestScore", "currentLK", "improvement", "blen"):
             assert np.array_equal(g[k], first[k]), (turn, k)
         counts.append(dev.stats()["n_lists"])
+        # a MAT mutation list uploaded between the rounds (as a caller does for a new reference branch) must survive the release of
+        # the stale copies: an arena mark also carries the count of mutation lists, ensure_cand_root must not release through it
+        mut_ids.append(int(dev.upload_mutations([[(10 + turn, 0, 1), (500 + turn, 2, 3)]])[0]))
         # the same records again: nothing changes but the library's tables are stale
         dev.tree_patch(m.n_nodes, touched, *[np.asarray(c)[touched] for c in cols])
+    # every mutation list uploaded on the way is still there and still its own (pass a list through each: position 10+turn A->C)
+    lst = dev.upload([[(4, dev.lRef)]])
+    for turn, mid in enumerate(mut_ids):
+        assert mid == mut_ids[0] + turn, mut_ids
+        out = dev.download(dev.pass_branch_batch(lst, [mid], False))[0]
+        # R up to the first mutated site, the site as an explicit nucleotide, R up to the second, the site, R to the end
+        assert [e[0] for e in out] == [4, 0, 4, 2, 4] and [e[1] for e in out[::2]] == [9 + turn, 499 + turn, dev.lRef], (turn, out)
     assert (first["status"] == 0).sum() > 1000
     assert counts[0] - before > 1000, (before, counts)               # (the copies were made: one per scored branch)
     assert counts[0] == counts[1] == counts[2] == counts[3], counts  # (... and replaced, not added to, after every patch)

@@ -1,6 +1,7 @@
 """Build a variant of libmaple_hip_debug.so (the product library plus include/maple_hip_debug.h: -DMAPLE_DEBUG_ABI is always on)
 next to the product library: tools/build_variant.py NAME [extra hipcc flags ...]
--> maple_amd/libmaple_hip_NAME.so (objects under build/NAME/).  Run anything with MAPLE_HIP_LIB=<that path> to use it."""
+-> maple_amd/libmaple_hip_NAME.so (objects under build/NAME/).  Run anything with MAPLE_HIP_LIB=<that path> to use it
+(tools that open Device(debug=True): MAPLE_HIP_LIB_DEBUG=<that path> as well -- runtime.load_library keeps the two apart)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
