@@ -279,7 +279,9 @@ def compact_line(full):
                              "roofline": {k: v for k, v in (roof(leg.get("roofline")) or {}).items()
                                           if k in ("bound", "kernel", "achieved", "peak", "frac", "kernel_ms", "kernel_ms_per_step")}}
     c5 = full.get("config_5")
-    if c5:
+    if c5 and "error" in c5:
+        line["config_5"] = {"error": _short(c5["error"], 120)}
+    elif c5:
         line["config_5"] = {"samples_added": c5["samples_added"], "ms_per_sample": _num(c5["ms_per_sample"], 4), "total_s": _num(c5["total_s"], 4),
                             "round_after_ms": _num(c5["round_after"]["round_after_ms"], 5), "round_after_searches": c5["round_after"]["searches"]}
     line["detail"] = full.get("detail_file")
@@ -691,7 +693,11 @@ def run_leg(args, env):
             out["cpu_baseline"] = spr_cpu_baseline(dev, mirror, ht, ref_idx, root_freqs, batch_of, kept, kw, args.cpu_seconds, mkw,
                                                    args.steps)
     if getattr(args, "online_leg", 0) and rank == 0 and world == 1:
-        out["config_5"] = online_update_leg(dev, mirror, data, ref_idx, tip_kw, kw, args.online_leg, B)
+        try:                                             # (a secondary leg must never take the headline's line with it)
+            out["config_5"] = online_update_leg(dev, mirror, data, ref_idx, tip_kw, kw, args.online_leg, B)
+        except (Exception, SystemExit) as e:
+            out["config_5"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            print(f"[bench] config 5 leg failed: {out['config_5']['error']}", file=sys.stderr, flush=True)
     if distd is not None:
         distd.barrier()
     dev.close()
@@ -753,7 +759,37 @@ def online_update_leg(dev, mirror, data, ref_idx, tip_kw, kw, n_add, round_nodes
                     "left); tree edit = bench.serial_phase's stand-in for placeSampleOnTree (host code of the reference, out of scope)"}
 
 
-DEPTH_STEP = 1 << 12        # serial_phase keeps depths in units of 1/4096 of a level: a node put on a branch gets one in between
+DEPTH_STEP = 1 << 12        # (the least a level is worth in serial_phase's depths, see tree_depths)
+
+
+def tree_depths(root, c0, c1, n, cap):
+    """Depths for maple_update_partials (which only compares them) with room in between: a level is worth the largest power of two
+    that keeps the deepest tip below 2^30, so that a node put on a branch gets a depth of its own between its neighbours'
+    (place_depths) -- 20-odd times over on one branch before the tree has to be numbered again.  Level by level, vectorised."""
+    level = np.zeros(cap, dtype=np.int64)
+    front = np.asarray([root], dtype=np.int64)
+    d = 0
+    while len(front):
+        level[front] = d
+        kids = np.concatenate([c0[front], c1[front]])
+        front = kids[kids >= 0].astype(np.int64)
+        d += 1
+    step = max(DEPTH_STEP, 1 << int(math.floor(math.log2((1 << 30) / (d + 2)))))
+    depth = np.zeros(cap, dtype=np.int32)
+    depth[:n] = (level[:n] * step).astype(np.int32)
+    return depth, step
+
+
+def place_depths(depth, step, g, p, b, s, root, c0, c1, n):
+    """Node p goes on the branch g -> b and gets the new tip s: depths for p and s; the tree is numbered again (returns the new
+    array and step) when the branch has no depth left in between."""
+    if depth[b] - depth[g] < 2:
+        depth, step = tree_depths(root, c0, c1, n, len(depth))             # (p and s are not linked in yet: numbered below)
+    depth[p] = (int(depth[g]) + int(depth[b])) // 2
+    depth[s] = min(int(depth[p]) + step, (1 << 31) - 2)                    # (a tip: anything below p; room for a later node above it)
+    if not (depth[g] < depth[p] < depth[b]):
+        raise SystemExit("serial_phase: no depth left between two nodes right after numbering the tree")
+    return depth, step
 
 
 def serial_phase(dev, m, new_lists, pkw):
@@ -780,10 +816,7 @@ def serial_phase(dev, m, new_lists, pkw):
     mut = np.full(cap, -1, dtype=np.int32)
     lower, up_right = grown(m.lower, -1, np.int32), grown(m.up_right, -1, np.int32)
     up_left, tot_up = grown(m.up_left, -1, np.int32), grown(m.tot_up, -1, np.int32)
-    depth = np.zeros(cap, dtype=np.int32)                # (maple_update_partials only compares depths)
-    for v in preorder_nodes(m):
-        if up[v] >= 0:
-            depth[v] = depth[up[v]] + DEPTH_STEP
+    depth, dstep = tree_depths(m.root, c0, c1, n0, cap)   # (maple_update_partials only compares depths)
     n = n0
     dev.upload_tree(m.root, up[:n], c0[:n], c1[:n], dist[:n], tip[:n], lower[:n], up_right[:n], up_left[:n], tot_up[:n], mut[:n])
     t = dict(upload=[], search=[], update=[], patch=[])
@@ -805,6 +838,7 @@ def serial_phase(dev, m, new_lists, pkw):
         top, bottom, app = (float(x) for x in out["blen"][0])
         g, p, s = int(up[b]), n, n + 1
         # ---- the stand-in tree edit: p on the branch above b, the sample s as p's other child
+        depth, dstep = place_depths(depth, dstep, g, p, b, s, m.root, c0, c1, n)   # (before p is linked in: the tree as it was)
         if c0[g] == b:
             c0[g] = p
         else:
@@ -812,10 +846,6 @@ def serial_phase(dev, m, new_lists, pkw):
         up[p], c0[p], c1[p], dist[p], tip[p] = g, b, s, top, 0
         up[b], dist[b] = p, bottom
         up[s], dist[s], tip[s], lower[s] = p, app, 1, qid
-        depth[p] = (depth[g] + depth[b]) // 2
-        depth[s] = depth[p] + 1
-        if not (depth[g] < depth[p] < depth[b]):
-            raise SystemExit("serial_phase: ran out of depth resolution on one branch (raise DEPTH_STEP)")
         n += 2
         # ---- updatePartials around the new nodes, inside the library, on these very columns
         t0 = time.perf_counter()

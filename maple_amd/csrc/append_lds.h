@@ -164,15 +164,41 @@ __device__ __forceinline__ double append_walk_m(const Ctx<RV, U, SS> &c, const P
         const uint32_t m1 = (uint32_t)(wa >> 32), m2 = (uint32_t)(wb >> 32);
         const int t1 = m1 & 7u, t2 = m2 & 7u;
         const int pos = min(pa, pb);
+#ifndef MAPLE_WALK_OLD
+        if ((t1 != 5) & (t2 != 5) & ((t1 != t2) | (t1 == 6))) {         // (work_table() in 32-bit compares)
+#else
         if ((WORK >> (t1 * 8 + t2)) & 1ull) {
+#endif
             const int site = pos - 1;
             bool dead = false;
             const double r = RV ? ((pa == pos) ? P.rate(ia, site, c) : C.rate(ib, site, c)) : 1.0;
             if (t1 == 6 || t2 == 6 || (m1 & (1u << 6))) {               // O vector or observation beyond the root
+#ifndef MAPLE_WALK_OLD
+                // (one O vector against a nucleotide / R: the vector's entry for that nucleotide first -- above 0.02 it IS the factor,
+                // M:6615 / 6692 / 6746, five of six such sites on the bench trees: one read instead of two decoded entries)
+                double f = 0.0;
+                bool general = true;
+                if ((t1 == 6) != (t2 == 6)) {
+                    const bool o1 = t1 == 6;
+                    const uint32_t mo = o1 ? m1 : m2;
+                    const int tn = o1 ? t2 : t1;
+                    const uint32_t off = (mo >> 8) + ((mo >> 5) & 1u) + ((mo >> 6) & 1u) + (uint32_t)((tn == 4) ? (int)((mo >> 3) & 3u) : tn);
+                    f = o1 ? P.aux(off) : C.aux(off);
+                    general = !(f > 0.02);
+                }
+                if (general) {
+                    EntV e1, e2;
+                    decode_v(wa, P, e1);
+                    decode_v(wb, C, e2);
+                    f = site_factor_v(c, e1, e2, site, r, isTipC, bLen);
+                }
+                tf *= f;
+#else
                 EntV e1, e2;
                 decode_v(wa, P, e1);
                 decode_v(wb, C, e2);
                 tf *= site_factor_v(c, e1, e2, site, r, isTipC, bLen);
+#endif
             } else {                                                     // two different nucleotides (R = the reference one)
                 double cl = bLen;                                        // M:6640-6668, 6713-6742
                 if (m1 & (1u << 5)) cl += P.aux(m1 >> 8);

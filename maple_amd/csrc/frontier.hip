@@ -37,6 +37,14 @@ using namespace frt;
 
 namespace {
 
+// the arena's list table as one record per list (FPools::arec), from its four arrays: at the start of every call, for every list
+// the arena holds (1 000 000 tips: 10 M lists, 0.4 GB moved: ~0.1 ms)
+__global__ __launch_bounds__(FR_BLOCK) void k_fr_arena_recs(ArenaViewS av, int n, LRec *out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = lrec_make(av.ent_off[i], av.n_ent[i], av.aux_off[i], av.n_aux[i]);
+}
+
 // ---- the worker's prologue (M:9626-9674) and the seeding of nodesToVisit (M:6855-6914) ----------------------------------
 template <bool RV, bool U, bool SS>
 __global__ __launch_bounds__(FR_BLOCK) void k_fr_begin(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, SearchParams P, int n,
@@ -1087,8 +1095,8 @@ struct FrontierScratch {
     DevBuf<uint8_t> itemsU, itemsC, srch, recs, ctr;
     DevBuf<uint2> tw, sw, bw;
     DevBuf<double> ta, sa, sais, ba;
-    DevBuf<long long> toffW, toffA;
-    DevBuf<int32_t> tn, tna, nodes, expQ, expNode;
+    DevBuf<LRec> trec, arec;                       // one 16-byte record per temporary list / per list of the arena (FPools)
+    DevBuf<int32_t> nodes, expQ, expNode;
     DevBuf<uint8_t> out, wideBr, tflag, overHint;
     DevBuf<int32_t> wideRow, wideQ, wideCtr, perm, perm2, perm3, perm4, tot, lsize, lpos, lpar, passList, passListR, deferred;
     DevBuf<uint2> bw2; DevBuf<double> ba2;   // k_fr_pass's own shared scratch (it runs next to the updating levels)
@@ -1117,7 +1125,7 @@ void frontier_scratch_free(maple_ctx *c)
     if (!F) return;
     F->itemsU.release(); F->itemsC.release(); F->srch.release(); F->recs.release(); F->ctr.release();
     F->tw.release(); F->sw.release(); F->ta.release(); F->sa.release(); F->sais.release(); F->bw.release(); F->ba.release();
-    F->toffW.release(); F->toffA.release(); F->tn.release(); F->tna.release(); F->nodes.release(); F->out.release();
+    F->trec.release(); F->arec.release(); F->nodes.release(); F->out.release();
     F->expQ.release(); F->expNode.release();
     F->perm.release(); F->perm2.release(); F->perm3.release(); F->perm4.release(); F->tot.release(); F->lsize.release(); F->lpos.release(); F->lpar.release(); F->visit.release(); F->lvl.release(); F->vbase.release(); F->wideBr.release(); F->wideRow.release(); F->wideQ.release(); F->wideCtr.release(); F->passList.release(); F->passListR.release(); F->deferred.release(); F->overHint.release(); F->bw2.release(); F->ba2.release(); F->tflag.release();
     if (F->evFork) (void)hipEventDestroy(F->evFork);
@@ -1149,7 +1157,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     const DevBufStats allocs0 = devbuf_stats();
     struct PoolCap { const char *name; const size_t *cap; size_t elem, before; };
     PoolCap poolCaps[] = {{"itemsU", &F.itemsU.cap, 1, 0}, {"itemsC", &F.itemsC.cap, 1, 0}, {"tw", &F.tw.cap, 8, 0}, {"ta", &F.ta.cap, 8, 0},
-                          {"toffW", &F.toffW.cap, 8, 0}, {"sw", &F.sw.cap, 8, 0}, {"sa", &F.sa.cap, 8, 0}, {"sais", &F.sais.cap, 8, 0},
+                          {"trec", &F.trec.cap, 16, 0}, {"sw", &F.sw.cap, 8, 0}, {"sa", &F.sa.cap, 8, 0}, {"sais", &F.sais.cap, 8, 0},
                           {"bw", &F.bw.cap, 8, 0}, {"bw2", &F.bw2.cap, 8, 0}, {"visit", &F.visit.cap, 1, 0}, {"recs", &F.recs.cap, 1, 0},
                           {"perm", &F.perm.cap, 4, 0}, {"passList", &F.passList.cap, 4, 0}};
     for (PoolCap &pc : poolCaps) pc.before = *pc.cap;
@@ -1201,7 +1209,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         // whenever the total met the room -- always, at 1 000 000 tips: the list words overflowed on EVERY step and sent 15 000
         // of 131 072 searches to the one-lane kernel, 550 ms.)
         const long long curU = (long long)(F.itemsU.cap / sizeof(FItem)), curCR = (long long)(F.itemsC.cap / sizeof(FItem));
-        const long long curL = (long long)std::min(std::min(std::min(F.toffW.cap, F.toffA.cap), std::min(F.tn.cap, F.tna.cap)), F.tflag.cap);
+        const long long curL = (long long)std::min(F.trec.cap, F.tflag.cap);
         const long long curW = (long long)F.tw.cap, curA = (long long)F.ta.cap;
         const double perItem = (double)(sizeof(FItem) + sizeof(FVisit) + 12);
         const double fixed = (double)(scratchLanes + extraSlabs) * capE * 64 + (double)(capBig + capBig2) * 48;
@@ -1228,10 +1236,8 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     HIPCK(c, F.ctr.reserve(sizeof(FCtr)));
     HIPCK(c, F.tw.reserve_exact(grow((size_t)capW, F.tw.cap)));
     HIPCK(c, F.ta.reserve_exact(grow((size_t)capA, F.ta.cap)));
-    HIPCK(c, F.toffW.reserve_exact(grow((size_t)capL, F.toffW.cap)));
-    HIPCK(c, F.toffA.reserve_exact(grow((size_t)capL, F.toffA.cap)));
-    HIPCK(c, F.tn.reserve_exact(grow((size_t)capL, F.tn.cap)));
-    HIPCK(c, F.tna.reserve_exact(grow((size_t)capL, F.tna.cap)));
+    HIPCK(c, F.trec.reserve_exact(grow((size_t)capL, F.trec.cap)));
+    HIPCK(c, F.arec.reserve_exact(grow(c->h_n_ent.size(), F.arec.cap)));
     HIPCK(c, F.tflag.reserve_exact(grow((size_t)capL, F.tflag.cap)));
     HIPCK(c, F.sw.reserve_exact((size_t)(scratchLanes + extraSlabs) * capE));
     HIPCK(c, F.sa.reserve_exact((size_t)(scratchLanes + extraSlabs) * capE * 5));
@@ -1246,10 +1252,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
     fp.capU = (long long)(F.itemsU.cap / sizeof(FItem)); fp.capC = (long long)(F.itemsC.cap / sizeof(FItem));
     // (a buffer kept from a larger call: both parts grow with it)
     fp.capCC = fp.capC - std::max(capR, (long long)((double)fp.capC * capR / (double)(capC + capR)));
-    fp.tw = F.tw.p; fp.ta = F.ta.p; fp.toffW = F.toffW.p; fp.toffA = F.toffA.p; fp.tn = F.tn.p; fp.tna = F.tna.p;
+    fp.tw = F.tw.p; fp.ta = F.ta.p; fp.trec = F.trec.p; fp.arec = F.arec.p; fp.nArec = (int32_t)c->h_n_ent.size();
     fp.capW = (long long)F.tw.cap; fp.capA = (long long)F.ta.cap;
     fp.tflag = F.tflag.p;
-    fp.capL = (long long)std::min(std::min(std::min(F.toffW.cap, F.toffA.cap), std::min(F.tn.cap, F.tna.cap)), F.tflag.cap);
+    fp.capL = (long long)std::min(F.trec.cap, F.tflag.cap);
     HIPCK(c, F.perm.reserve_exact(std::max(F.perm.cap, (size_t)fp.capU)));
     HIPCK(c, F.perm2.reserve_exact(std::max(F.perm2.cap, (size_t)fp.capU)));
     HIPCK(c, F.perm3.reserve_exact(std::max(F.perm3.cap, (size_t)fp.capU)));
@@ -1339,6 +1345,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         HIPCK(c, hipStreamSynchronize(s));                                  // (wideIdx is a local)
     }
     const bool anyWide = useWide && !wideIdx.empty();
+    if (fp.nArec > 0) {
+        k_fr_arena_recs<<<std::min(4096, (fp.nArec + FR_BLOCK - 1) / FR_BLOCK), FR_BLOCK, 0, s>>>(av, fp.nArec, F.arec.p);
+        HIPCK(c, hipGetLastError());
+    }
     // (the seeding of a tree with local references writes lists through the lanes' scratch slabs: no more lanes than slabs)
     FR_DISPATCH3(c, k_fr_begin, <<<std::min(gridN, gridUpd), FR_BLOCK, 0, s>>>(c->d_model, av, T, P, m, F.nodes.p, fp, dout, budget, zeroBudget,
                                                             anyWide ? F.wideRow.p : nullptr, anyWide ? wide->forceWide : 0,

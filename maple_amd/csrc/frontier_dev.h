@@ -29,6 +29,15 @@ enum { FS_ACTIVE = 0, FS_FINAL = 1, FS_OVER = 2, FS_FALLBACK = 3, FS_WIDE = 4 };
 __device__ __forceinline__ bool fs_live(int st) { return st == FS_ACTIVE || st == FS_WIDE; }
 #define FR_NONE (-1)
 
+// where a list is: offset of its words (low 40 bits) and their number (high 24); the same for its aux doubles
+struct alignas(16) LRec { unsigned long long w, a; };
+#define LREC_OFF(x) ((long long)((x) & ((1ull << 40) - 1)))
+#define LREC_N(x) ((int32_t)((x) >> 40))
+__device__ __host__ __forceinline__ LRec lrec_make(long long offW, int n, long long offA, int na)
+{
+    return LRec{(unsigned long long)offW | ((unsigned long long)(uint32_t)n << 40), (unsigned long long)offA | ((unsigned long long)(uint32_t)na << 40)};
+}
+
 struct alignas(32) FItem {
     // what the exact replay reads and writes per pop, in one 32-byte sector (the walk of the longest search is a chain of
     // dependent misses on these)
@@ -133,8 +142,12 @@ struct FPools {
     long long capCC;                   // the cached pool's lower part [0, capCC): items pushed by cached-regime items; [capCC, capC): roots
     // temporary lists
     uint2 *tw; double *ta;
-    long long *toffW, *toffA;
-    int32_t *tn, *tna;
+    // ONE 16-byte record per list -- where its words and its aux doubles begin and how many there are -- instead of four arrays:
+    // an item reads the table for two or three lists, and four gathers from four arrays were four sectors of four different
+    // cache lines per list.  trec: the batch's temporary lists; arec: the same for the genome-list arena, made from its four
+    // arrays at the start of a call (k_fr_arena_recs) for the nArec lists the arena held then.
+    LRec *trec;
+    const LRec *arec; int32_t nArec;
     uint8_t *tflag;                    // per temporary list: a removed list that shorten() (M:7087) would change (shorten_would_merge's level)
     long long capW, capA, capL;
     FVisit *visit; long long capVisit;   // the layout of k_fr_layout_* (null: k_fr_replay chases the items)
@@ -173,11 +186,24 @@ struct FList { const uint2 *w; const double *aux; int32_t n, na; };
 
 __device__ __forceinline__ bool fvalid(int h) { return h >= 0 || h <= -10; }
 __device__ __forceinline__ int ftree(int listId) { return listId < 0 ? -1 : -(listId + 10); }
+__device__ __forceinline__ LRec lrec_load(const LRec *p)
+{
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);      // (one 16-byte load)
+    return LRec{v.x, v.y};
+}
 __device__ __forceinline__ FList flist(const ArenaViewS &av, const FPools &fp, int h)
 {
-    if (h >= 0) return FList{fp.tw + fp.toffW[h], fp.ta + fp.toffA[h], fp.tn[h], fp.tna[h]};
+    if (h >= 0) { const LRec r = lrec_load(fp.trec + h); return FList{fp.tw + LREC_OFF(r.w), fp.ta + LREC_OFF(r.a), LREC_N(r.w), LREC_N(r.a)}; }
     const int id = -h - 10;
-    return FList{av.words + av.ent_off[id], av.aux + av.aux_off[id], av.n_ent[id], av.n_aux[id]};
+    if (id < fp.nArec) { const LRec r = lrec_load(fp.arec + id); return FList{av.words + LREC_OFF(r.w), av.aux + LREC_OFF(r.a), LREC_N(r.w), LREC_N(r.a)}; }
+    return FList{av.words + av.ent_off[id], av.aux + av.aux_off[id], av.n_ent[id], av.n_aux[id]};   // (a list the arena got during the call)
+}
+// the number of entries of a list alone
+__device__ __forceinline__ int flen(const ArenaViewS &av, const FPools &fp, int h)
+{
+    if (h >= 0) return LREC_N(fp.trec[h].w);
+    const int id = -h - 10;
+    return id < fp.nArec ? LREC_N(fp.arec[id].w) : av.n_ent[id];
 }
 __device__ __forceinline__ ListRef fref(const FList &l) { return ListRef{l.w, l.aux}; }
 
@@ -228,7 +254,7 @@ __device__ inline int fstore(const FPools &fp, const Writer &wr)
     double *da = fp.ta + oa;
     for (int k = 0; k < wr.n; k++) dw[k] = wr.w[k];
     for (int k = 0; k < wr.na; k++) da[k] = wr.aux[k];
-    fp.toffW[id] = (long long)ow; fp.toffA[id] = (long long)oa; fp.tn[id] = wr.n; fp.tna[id] = wr.na; fp.tflag[id] = 0;
+    fp.trec[id] = lrec_make((long long)ow, wr.n, (long long)oa, wr.na); fp.tflag[id] = 0;
     return (int)id;
 }
 
@@ -425,7 +451,7 @@ __device__ inline int wave_pass(const C &c, const FPools &fp, const ArenaViewS &
         } else level = __ballot(plain) ? 1 : 0;
     }
     if (lane == 0) {
-        fp.toffW[id] = (long long)ow; fp.toffA[id] = (long long)oa; fp.tn[id] = nOut; fp.tna[id] = nAux; fp.tflag[id] = (uint8_t)level;
+        fp.trec[id] = lrec_make((long long)ow, nOut, (long long)oa, nAux); fp.tflag[id] = (uint8_t)level;
     }
     __threadfence();
     sync();
@@ -510,8 +536,8 @@ __device__ __forceinline__ int fr_upd_size(const ArenaViewS &av, const DevTree &
     const NodeRec &r1 = T.nd[it.t1];
     const int other = it.dir == 0 ? it.t1 : (it.dir == 1 ? r1.c1 : r1.c0);
     const int lw = T.nd[other].lower;
-    const int nTree = lw >= 0 ? av.n_ent[lw] : 0;
-    const int nPass = it.hPassed >= 0 ? fp.tn[it.hPassed] : (it.hPassed <= -10 ? av.n_ent[-it.hPassed - 10] : 0);
+    const int nTree = lw >= 0 ? flen(av, fp, ftree(lw)) : 0;
+    const int nPass = fvalid(it.hPassed) ? flen(av, fp, it.hPassed) : 0;
     return nPass + nTree;
 }
 __device__ __forceinline__ bool fr_upd_heavy(const ArenaViewS &av, const DevTree &T, const FPools &fp, const FItem &it, int heavyMin)
@@ -525,8 +551,7 @@ __device__ inline bool fr_wave_fits(const ArenaViewS &av, const DevTree &T, cons
     const int dir = it.dir;
     if (dir == 3 || !fvalid(it.hPassed)) return false;
     const NodeRec r1 = T.nd[it.t1];
-    const int nP = it.hPassed >= 0 ? fp.tn[it.hPassed] : av.n_ent[-it.hPassed - 10];
-    const int nR = it.hRpr >= 0 ? fp.tn[it.hRpr] : av.n_ent[-it.hRpr - 10];
+    const int nP = flen(av, fp, it.hPassed), nR = flen(av, fp, it.hRpr);
     if (nP > wuIn || nR > capW) return false;
     const int other = dir == 0 ? -1 : (dir == 1 ? r1.c1 : r1.c0);
     const int upT = r1.up;

@@ -59,7 +59,7 @@ void k_fr_updating(const DevModel *__restrict__ mp, ArenaViewS av, DevTree T, Se
                 const NodeRec &r1 = T.nd[it.t1];
                 const int other = it.dir == 0 ? it.t1 : (it.dir == 1 ? r1.c1 : r1.c0);
                 const int lw = T.nd[other].lower;
-                sz = (lw >= 0 ? av.n_ent[lw] : 0) + (it.hPassed >= 0 ? fp.tn[it.hPassed] : (it.hPassed <= -10 ? av.n_ent[-it.hPassed - 10] : 0));
+                sz = (lw >= 0 ? flen(av, fp, ftree(lw)) : 0) + (fvalid(it.hPassed) ? flen(av, fp, it.hPassed) : 0);
             }
         }
 #endif

@@ -337,6 +337,79 @@ template <bool RV, bool U, bool SS> struct PairWalk {
     }
 
     // one segment of the two-list walk; returns true when the end of the genome (or a dead end) is reached
+#ifndef MAPLE_WALK_OLD
+    // The lanes of a wavefront walk unrelated pairs, so a step costs the wavefront the UNION of the cases its lanes are in.
+    // Per pair of neighbouring lists on the bench trees (94 steps): 67 steps need no work, 13 are two different nucleotides,
+    // 11.5 an O vector against a nucleotide / R whose entry of the vector is > 0.02 (the reference's shortcut, M:6615 / 6692 /
+    // 6746: the factor IS that entry), 2 the same with a smaller entry, 0.3 anything else.  So: the test for work in 32-bit
+    // compares (no 64-bit shift), the two common cases without decoding the entries (one load for the shortcut; the branch
+    // lengths of the two-nucleotide case and the site's rate requested together, one wait), the rest through the general
+    // site_factor as before.  Same operations on the same operands in the same order: bit-identical.
+    __device__ inline bool step()
+    {
+        const int pa = (int)(uint32_t)wa, pb = (int)(uint32_t)wb;
+        const uint32_t m1 = (uint32_t)(wa >> 32), m2 = (uint32_t)(wb >> 32);
+        const int t1 = m1 & 7u, t2 = m2 & 7u;
+        const int pos = min(pa, pb);
+        // work unless N is involved, both sides are reference runs, or both show the same nucleotide (work_table())
+        if ((t1 != 5) & (t2 != 5) & ((t1 != t2) | (t1 == 6))) {
+            const int site = pos - 1;
+            const bool o1 = t1 == 6, o2 = t2 == 6;
+            double f = 0.0;
+            bool general = false;
+            if (!(o1 | o2)) {
+                if (m1 & (1u << 6)) general = true;                      // observation beyond the root on the parent side
+                else {                                                   // two different nucleotides (R = the reference one)
+                    double d1v = 0.0, d2v = 0.0;                         // M:6640-6668, 6713-6742
+                    if (m1 & (1u << 5)) d1v = P.aux[m1 >> 8];
+                    if ((m2 & (1u << 5)) && !(m2 & (1u << 6))) d2v = Cl.aux[m2 >> 8];
+                    const double r = c.rate(site);
+                    const double er = U ? c.err(site) : 0.0;
+                    const double cl = (bLen + d1v) + d2v;                // (x + 0.0 == x: the sums the reference makes)
+                    const int i1 = (t1 == 4) ? (int)((m2 >> 3) & 3u) : t1;
+                    const int i2 = (t2 == 4) ? (int)((m1 >> 3) & 3u) : t2;
+                    const double qv = c.q(r, i1, i2);
+                    f = fmin_py(0.25, qv * cl);
+                    if (U) {
+                        const bool flag1 = (t1 != 4) && (m1 & (1u << 5)) && (m1 & (1u << 7));
+                        const bool flag2 = isTipC || ((m2 & (1u << 5)) && (m2 & (1u << 7)));
+                        if (t1 == 4) { if (flag2) f += er * 0.33333; else if (cl == 0.0) dead = true; }
+                        else if (flag1 || flag2) f += (double)((int)flag1 + (int)flag2) * 0.33333 * er;
+                        else if (cl == 0.0) dead = true;
+                    } else if (cl == 0.0) dead = true;                   // zero-length mismatch: -inf (M:6663, 6742)
+                }
+            } else if (o1 & o2) general = true;
+            else {
+                // one O vector: its entry for the other side's nucleotide (R: the O entry's own reference nucleotide)
+                const uint32_t mo = o1 ? m1 : m2;
+                const double *ao = o1 ? P.aux : Cl.aux;
+                const int tn = o1 ? t2 : t1;
+                const int i = (tn == 4) ? (int)((mo >> 3) & 3u) : tn;
+                f = ao[(mo >> 8) + ((mo >> 5) & 1u) + ((mo >> 6) & 1u) + (uint32_t)i];
+                general = !(f > 0.02);                                   // M:6615, 6692, 6746
+            }
+            if (general) {
+                Ent e1, e2;
+                decode_word(wa, P.aux, e1);
+                decode_word(wb, Cl.aux, e2);
+                if (site_factor(c, e1, e2, site, isTipC, bLen, &f) == 1) dead = true;
+            }
+            if (dead) return true;
+            tf *= f;
+            if (tf <= carry) {                                           // M:6772-6783
+                if (tf < 2.2250738585072014e-308) { dead = true; return true; }
+                if (nCarry == 2) { Lk += log(carry1); carry1 = carry2; nCarry = 1; }     // a third one: settle the oldest
+                if (nCarry == 0) carry1 = tf; else carry2 = tf;
+                ++nCarry;
+                tf = 1.0;
+            }
+        }
+        if (pos == lRef) return true;
+        if (pa == pos) { ++ia; wa = pw[ia]; }
+        if (pb == pos) { ++ib; wb = cw[ib]; }
+        return false;
+    }
+#else
     __device__ inline bool step()
     {
         const int pa = (int)(uint32_t)wa, pb = (int)(uint32_t)wb;
@@ -387,6 +460,7 @@ template <bool RV, bool U, bool SS> struct PairWalk {
         if (pb == pos) { ++ib; wb = cw[ib]; }
         return false;
     }
+#endif
 
     // The whole walk with the lanes of a wavefront brought together at the sites that need work.  Most steps of a walk need
     // none (both sides reference runs, or missing data); a wavefront that calls step() in a loop executes the ~100

@@ -222,8 +222,7 @@ def test_config5_online_update_of_the_1M_tree(million):
     lower, up_right = grown(m.lower, -1, np.int32), grown(m.up_right, -1, np.int32)
     up_left, tot_up = grown(m.up_left, -1, np.int32), grown(m.tot_up, -1, np.int32)
     before = dict(lower=lower.copy(), up_right=up_right.copy(), up_left=up_left.copy(), tot_up=tot_up.copy())
-    depth = np.zeros(cap, dtype=np.int32)
-    depth[:n0] = m.depth * bench.DEPTH_STEP
+    depth, dstep = bench.tree_depths(m.root, c0, c1, n0, cap)
     n = n0
     dev.upload_tree(m.root, up[:n], c0[:n], c1[:n], dist[:n], tip[:n], lower[:n], up_right[:n], up_left[:n], tot_up[:n], mut[:n])
     from oracle.oracle_py import Oracle
@@ -261,6 +260,7 @@ def test_config5_online_update_of_the_1M_tree(million):
             else:                                                           # ... or it stays, with the lengths of M:8072
                 assert abs(got - first) <= 1e-9 * max(1.0, abs(first)), (k, got, want, first)
         # ---- the stand-in tree edit (bench.serial_phase): p on the branch above b, the sample s as p's other child
+        depth, dstep = bench.place_depths(depth, dstep, g, p, b, s, m.root, c0, c1, n)
         if c0[g] == b:
             c0[g] = p
         else:
@@ -268,9 +268,6 @@ def test_config5_online_update_of_the_1M_tree(million):
         up[p], c0[p], c1[p], dist[p], tip[p] = g, b, s, top, 0
         up[b], dist[b] = p, bottom
         up[s], dist[s], tip[s], lower[s] = p, app, 1, qid
-        depth[p] = (depth[g] + depth[b]) // 2
-        depth[s] = depth[p] + 1
-        assert depth[g] < depth[p] < depth[b]
         n += 2
         dev.update_partials(m.root, up[:n], c0[:n], c1[:n], tip[:n], mut[:n], depth[:n], dist[:n], lower[:n], up_right[:n],
                             up_left[:n], tot_up[:n], [b, s, p])

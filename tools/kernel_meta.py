@@ -1,5 +1,15 @@
 import subprocess,sys,re
-out=subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf","--notes",sys.argv[1]],text=True)
+"""Registers, spills, scratch and LDS of every kernel of a code object: tools/kernel_meta.py FILE [name filter].
+FILE: a gfx950 ELF, an offload bundle (hipcc --cuda-device-only -c) or a host object with a .hip_fatbin section."""
+import os,tempfile
+BIN="/opt/rocm/lib/llvm/bin/"
+src=sys.argv[1]
+tmp=tempfile.mkdtemp()
+if open(src,"rb").read(4)==b"\x7fELF" and b".hip_fatbin" in subprocess.check_output([BIN+"llvm-readelf","-S",src]):
+    subprocess.check_call([BIN+"llvm-objcopy","--dump-section",".hip_fatbin="+tmp+"/fat",src]); src=tmp+"/fat"
+if open(src,"rb").read(4)!=b"\x7fELF":
+    subprocess.check_call([BIN+"clang-offload-bundler","--unbundle","--type=o","--input="+src,"--targets=hipv4-amdgcn-amd-amdhsa--gfx950","--output="+tmp+"/co"]); src=tmp+"/co"
+out=subprocess.check_output([BIN+"llvm-readelf","--notes",src],text=True)
 ks=[];cur={}
 for line in out.splitlines():
     m=re.match(r"\s+(-\s+)?\.(\w+):\s+(.*)",line)
