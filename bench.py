@@ -464,7 +464,7 @@ def run_leg(args, env):
         if len(bad):
             raise SystemExit(f"SPR search failed: status {sorted(set(bad.tolist()))} (workspace / pool capacity)")
         rec = pack_proposals(mine, res["placement"], res["improvement"])
-        moves = gather_proposals(rec, device=coll_dev) if distd is not None else rec
+        moves = gather_proposals(rec, device=coll_dev, cap=-(-B // world)) if distd is not None else rec   # (cap: the largest shard)
         return res, moves
 
     first_call_ms = None

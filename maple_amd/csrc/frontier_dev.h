@@ -30,12 +30,18 @@ __device__ __forceinline__ bool fs_live(int st) { return st == FS_ACTIVE || st =
 #define FR_NONE (-1)
 
 // where a list is: offset of its words (low 40 bits) and their number (high 24); the same for its aux doubles
-struct alignas(16) LRec { unsigned long long w, a; };
+// (x: the words, y: the aux doubles.  The vector type itself, so that a record is stored and loaded as ONE 16-byte access of one
+// type: a record stored as a struct and loaded through a cast to ulonglong2 let the compiler move the load of a list's record
+// ahead of the store that had just made it -- fpass_removed reads the list fstore returned -- and a walk went off into the blue.)
+typedef ulonglong2 LRec;
 #define LREC_OFF(x) ((long long)((x) & ((1ull << 40) - 1)))
 #define LREC_N(x) ((int32_t)((x) >> 40))
 __device__ __host__ __forceinline__ LRec lrec_make(long long offW, int n, long long offA, int na)
 {
-    return LRec{(unsigned long long)offW | ((unsigned long long)(uint32_t)n << 40), (unsigned long long)offA | ((unsigned long long)(uint32_t)na << 40)};
+    LRec r;
+    r.x = (unsigned long long)offW | ((unsigned long long)(uint32_t)n << 40);
+    r.y = (unsigned long long)offA | ((unsigned long long)(uint32_t)na << 40);
+    return r;
 }
 
 struct alignas(32) FItem {
@@ -186,24 +192,19 @@ struct FList { const uint2 *w; const double *aux; int32_t n, na; };
 
 __device__ __forceinline__ bool fvalid(int h) { return h >= 0 || h <= -10; }
 __device__ __forceinline__ int ftree(int listId) { return listId < 0 ? -1 : -(listId + 10); }
-__device__ __forceinline__ LRec lrec_load(const LRec *p)
-{
-    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);      // (one 16-byte load)
-    return LRec{v.x, v.y};
-}
 __device__ __forceinline__ FList flist(const ArenaViewS &av, const FPools &fp, int h)
 {
-    if (h >= 0) { const LRec r = lrec_load(fp.trec + h); return FList{fp.tw + LREC_OFF(r.w), fp.ta + LREC_OFF(r.a), LREC_N(r.w), LREC_N(r.a)}; }
+    if (h >= 0) { const LRec r = fp.trec[h]; return FList{fp.tw + LREC_OFF(r.x), fp.ta + LREC_OFF(r.y), LREC_N(r.x), LREC_N(r.y)}; }
     const int id = -h - 10;
-    if (id < fp.nArec) { const LRec r = lrec_load(fp.arec + id); return FList{av.words + LREC_OFF(r.w), av.aux + LREC_OFF(r.a), LREC_N(r.w), LREC_N(r.a)}; }
+    if (id < fp.nArec) { const LRec r = fp.arec[id]; return FList{av.words + LREC_OFF(r.x), av.aux + LREC_OFF(r.y), LREC_N(r.x), LREC_N(r.y)}; }
     return FList{av.words + av.ent_off[id], av.aux + av.aux_off[id], av.n_ent[id], av.n_aux[id]};   // (a list the arena got during the call)
 }
 // the number of entries of a list alone
 __device__ __forceinline__ int flen(const ArenaViewS &av, const FPools &fp, int h)
 {
-    if (h >= 0) return LREC_N(fp.trec[h].w);
+    if (h >= 0) return LREC_N(fp.trec[h].x);
     const int id = -h - 10;
-    return id < fp.nArec ? LREC_N(fp.arec[id].w) : av.n_ent[id];
+    return id < fp.nArec ? LREC_N(fp.arec[id].x) : av.n_ent[id];
 }
 __device__ __forceinline__ ListRef fref(const FList &l) { return ListRef{l.w, l.aux}; }
 

@@ -39,31 +39,41 @@ def pack_proposals(nodes, placement, improvement):
     return rec
 
 
-def gather_proposals(local_records, device=None):
+def gather_proposals(local_records, device=None, cap=None):
     """All-gather the proposal records of every rank and return them sorted ascending by improvement
-    (ties keep rank order, then local order -- the order of the reference's list concatenation)."""
+    (ties keep rank order, then local order -- the order of the reference's list concatenation).
+
+    ONE collective per (sub)round: every rank sends a block of ``cap + 1`` fixed-size records -- a header row that
+    holds its count, then its records, zero-padded.  ``cap`` must be the same on every rank and at least every rank's count:
+    the callers pass the size of the largest shard of searched nodes (a search proposes at most one move), which every rank
+    knows without asking, since the node list is the same everywhere.  Without ``cap`` the counts are exchanged first (a second,
+    8-byte collective)."""
     import torch
     import torch.distributed as dist
-    rec = torch.as_tensor(np.ascontiguousarray(local_records, dtype=np.float64))
-    if device is not None:
-        rec = rec.to(device)
+    rec = np.ascontiguousarray(local_records, dtype=np.float64).reshape(-1, 3)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        allrec = rec
+        a = rec
     else:
         world = dist.get_world_size()
-        cnt = torch.tensor([rec.shape[0]], dtype=torch.int64, device=rec.device)
-        counts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(counts, cnt)
-        counts = [int(c.item()) for c in counts]
-        m = max(counts) if counts else 0
-        if m == 0:                                                  # nobody proposes a move: nothing to exchange
-            return []
-        pad = torch.zeros((m, 3), dtype=torch.float64, device=rec.device)
-        pad[: rec.shape[0]] = rec
-        bufs = [torch.zeros_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad)                                  # ONE collective of fixed-size records
-        allrec = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
-    a = allrec.cpu().numpy()
+        if cap is None:
+            cnt = torch.tensor([rec.shape[0]], dtype=torch.int64)
+            cnt = cnt.to(device) if device is not None else cnt
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+            cap = int(cnt.item())
+        if rec.shape[0] > cap:
+            raise ValueError(f"gather_proposals: {rec.shape[0]} records but cap {cap}")
+        block = np.zeros((cap + 1, 3), dtype=np.float64)
+        block[0, 0] = rec.shape[0]
+        block[1: 1 + rec.shape[0]] = rec
+        mine = torch.from_numpy(block)
+        if device is not None:
+            mine = mine.to(device)
+        out = torch.empty((world * (cap + 1), 3), dtype=torch.float64, device=mine.device)
+        dist.all_gather_into_tensor(out, mine)                      # the round's ONE collective: fixed-size records
+        out = out.cpu().numpy().reshape(world, cap + 1, 3)
+        a = np.concatenate([out[r, 1: 1 + int(out[r, 0, 0])] for r in range(world)], axis=0)
+    if len(a) == 0:
+        return []
     order = np.argsort(a[:, 0], kind="stable")
     a = a[order]
     return [(int(r[1]), int(r[2]), float(r[0])) for r in a]
@@ -150,4 +160,4 @@ def sharded_spr_round(dev, nodes, search_kwargs, rank: int = 0, world: int = 1, 
     if len(bad):
         raise RuntimeError(f"SPR search could not finish some queries (status {sorted(set(bad.tolist()))})")
     rec = pack_proposals(mine, res["placement"], res["improvement"])
-    return gather_proposals(rec, device=device), res
+    return gather_proposals(rec, device=device, cap=len(nodes[0::world])), res
