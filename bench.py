@@ -704,7 +704,7 @@ def run_leg(args, env):
     return out if rank == 0 else None
 
 
-def online_update_leg(dev, mirror, data, ref_idx, tip_kw, kw, n_add, round_nodes):
+def online_update_leg(dev, mirror, data, ref_idx, tip_kw, kw, n_add, round_nodes, ahead=512):
     """BASELINE configs[4]: ``n_add`` new samples added to the leg's tree one after the other -- the reference's loop M:11692-11752:
     findBestParentForNewSample, placeSampleOnTree, updatePartials; here serial_phase (single-query placement search, the
     stand-in tree edit, maple_update_partials, maple_tree_patch) -- then one round of searches on the grown tree
@@ -724,7 +724,7 @@ def online_update_leg(dev, mirror, data, ref_idx, tip_kw, kw, n_add, round_nodes
     new_lists = [tip_genome_list(perturb_diffs(data.diffs[int(i)], data.ref, prng), ref_idx, **tip_kw) for i in src]
     prep_s = time.perf_counter() - t0
     t0 = time.perf_counter()
-    sp = serial_phase(dev, mirror, new_lists, pkw)
+    sp = serial_phase(dev, mirror, new_lists, pkw, ahead=ahead)
     total_s = time.perf_counter() - t0
     cols = sp["cols"]
     n = cols["n"]
@@ -745,8 +745,13 @@ def online_update_leg(dev, mirror, data, ref_idx, tip_kw, kw, n_add, round_nodes
         raise SystemExit(f"config 5: {bad} searches of the round after the update failed")
     return {"samples_added": int(sp["placed"]), "samples_offered": int(n_add), "skipped": int(sp["skipped"]),
             "ms_per_sample": 1e3 * total_s / max(1, n_add), "total_s": total_s,
-            "loop_ms_per_sample_mean": {"upload_of_the_sample": per["upload"], "placement_search": per["search"],
-                                        "update_partials": per["update"], "tree_patch": per["patch"]},
+            "loop_ms_per_sample_mean": {"upload_of_the_sample": 1e3 * float(np.sum(sp["times"]["upload"])) / max(1, n_add),
+                                        "rows_made_ahead": 1e3 * float(np.sum(sp["times"]["ahead"])) / max(1, n_add),
+                                        "placement_search": per["search"], "update_partials": per["update"], "tree_patch": per["patch"]},
+            "samples_announced_at_a_time": int(ahead),
+            "ahead_note": "maple_placement_ahead: the score rows of the next samples made in one launch of the batch kernel and kept "
+                          "current under maple_tree_patch (the columns whose list changed are scored again for the samples still "
+                          "waiting); the searches' results are those of the plain loop (tests/test_hip_search.py)",
             "placement_search_ms_first_third_last_third": [1e3 * float(np.mean(sp["times"]["search"][:third])),
                                                            1e3 * float(np.mean(sp["times"]["search"][-third:]))],
             "nodes_patched_per_sample_mean": float(np.mean(sp["patched"])) if sp["patched"] else 0.0, "nodes_touched": int(len(first)),
@@ -792,7 +797,7 @@ def place_depths(depth, step, g, p, b, s, root, c0, c1, n):
     return depth, step
 
 
-def serial_phase(dev, m, new_lists, pkw):
+def serial_phase(dev, m, new_lists, pkw, ahead=0):
     """The serial placement phase on the tree of TreeMirror ``m``: the samples ``new_lists`` one after the other --
     single-query placement search, tree edit, maple_update_partials around the new nodes, maple_tree_patch of the touched
     records.  The tree edit is a STAND-IN for MAPLE's placeSampleOnTree (M:8300-8722), which stays host code of the
@@ -801,7 +806,9 @@ def serial_phase(dev, m, new_lists, pkw):
     the shape and the locality of the reference's), not for parity
     (tests/test_hip_search.py::test_online_sample_additions_through_tree_patch applies the reference's own recorded edits).
     The tree lives in plain numpy columns with room to grow; nothing in the loop touches all nodes.  Returns the per-step
-    times (s) and the columns of the final tree (which is also the tree uploaded to ``dev`` when it returns)."""
+    times (s) and the columns of the final tree (which is also the tree uploaded to ``dev`` when it returns).
+    ``ahead`` > 0: the samples are announced that many at a time (maple_placement_ahead: their score rows made in one launch of
+    the batch kernel and kept current under the patches; the searches' results are the same)."""
     n_add = len(new_lists)
     n0, cap = m.n_nodes, m.n_nodes + 2 * n_add
 
@@ -819,19 +826,34 @@ def serial_phase(dev, m, new_lists, pkw):
     depth, dstep = tree_depths(m.root, c0, c1, n0, cap)   # (maple_update_partials only compares depths)
     n = n0
     dev.upload_tree(m.root, up[:n], c0[:n], c1[:n], dist[:n], tip[:n], lower[:n], up_right[:n], up_left[:n], tot_up[:n], mut[:n])
-    t = dict(upload=[], search=[], update=[], patch=[])
-    placed, skipped, patched, touched_nodes = 0, 0, [], []
-    for lst in new_lists:
+    t = dict(upload=[], search=[], update=[], patch=[], ahead=[])
+    placed, skipped, patched, touched_nodes, results = 0, 0, [], [], []
+    waiting, rest = [], []                               # list ids of the samples announced and not yet searched / uploaded and not yet announced
+    for k, lst in enumerate(new_lists):
         dev.placement_prepare(**pkw)
         t0 = time.perf_counter()
-        qid = int(dev.upload([lst])[0])                  # the sample's list stays: it becomes the new tip's lower list
-        t["upload"].append(time.perf_counter() - t0)
+        if ahead > 0:
+            if not waiting:
+                if not rest:                             # the next samples' lists, uploaded together
+                    rest = [int(x) for x in dev.upload(new_lists[k: k + ahead])]
+                    t["upload"].append(time.perf_counter() - t0)
+                t0 = time.perf_counter()
+                got = dev.placement_ahead(np.asarray(rest, dtype=np.int32), **pkw)
+                t["ahead"].append(time.perf_counter() - t0)
+                # (fewer rows than samples: the others are announced when these are done; no rows at all: the plain search)
+                got = got if got > 0 else len(rest)
+                waiting, rest = rest[:got], rest[got:]
+            qid = waiting.pop(0)
+        else:
+            qid = int(dev.upload([lst])[0])              # the sample's list stays: it becomes the new tip's lower list
+            t["upload"].append(time.perf_counter() - t0)
         mark = dev.mark()
         t0 = time.perf_counter()
         out = dev.placement_search_batch(np.asarray([qid], dtype=np.int32), **pkw)
         t["search"].append(time.perf_counter() - t0)
         dev.release(mark)
         b = int(out["bestNode"][0])
+        results.append((int(out["status"][0]), b, float(out["bestScore"][0]), tuple(float(x) for x in out["blen"][0]), int(out["nAppend"][0])))
         if out["status"][0] != 0 or up[b] < 0:
             skipped += 1
             continue
@@ -863,7 +885,7 @@ def serial_phase(dev, m, new_lists, pkw):
         placed += 1
     cols = dict(n=n, root=m.root, up=up, c0=c0, c1=c1, dist=dist, tip=tip, lower=lower, up_right=up_right, up_left=up_left,
                 tot_up=tot_up, mut=mut)
-    return dict(times=t, placed=placed, skipped=skipped, patched=patched, cols=cols,
+    return dict(times=t, placed=placed, skipped=skipped, patched=patched, cols=cols, results=results,
                 touched_nodes=np.unique(np.concatenate(touched_nodes)) if touched_nodes else np.zeros(0, dtype=np.int32))
 
 

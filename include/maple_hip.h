@@ -308,6 +308,17 @@ typedef struct {
  * searches that follow do not recompute them; they are dropped when the tree is uploaded again or the arena is released
  * below them. */
 int maple_placement_prepare(maple_ctx *ctx, const maple_placement_params *params);
+/* The serial placement loop (M:11692-11752: one sample placed, the tree edited, the next sample placed) scores every sample
+ * against every branch of the tree as it is then.  A placement changes a handful of lists; every other branch scores what it
+ * scored before.  maple_placement_ahead scores the next nQ samples (qLists, in the order they will be searched) against the
+ * CURRENT tree in one launch; while those rows live, maple_tree_patch notes the columns whose list changes and the columns
+ * it adds, and a maple_placement_search_batch call for ONE sample that is the next of the announced ones only scores those
+ * columns again (for all samples still waiting) and then runs the traversal over its row: the same scores, the same
+ * result as without the announcement.  *nTaken = the leading samples the library made rows for (what fits its page-locked
+ * tables; 0 on a tree with MAT reference frames, where the call changes nothing); announce the rest when those are done.
+ * The rows are dropped by anything that renumbers the columns or changes what a score means (maple_tree_upload,
+ * maple_set_model, other parameters, a release of the samples' lists), and by a search of any other sample. */
+int maple_placement_ahead(maple_ctx *ctx, int32_t nQ, const int32_t *qLists, const maple_placement_params *params, int32_t *nTaken);
 int maple_placement_search_batch(maple_ctx *ctx, int32_t nQ, const int32_t *qLists, const maple_placement_params *params,
                                  int32_t *bestNode, double *bestScore, double *blen3, int32_t *bestDiffs,
                                  int32_t *nAppend, int32_t *status);

@@ -120,7 +120,7 @@ __attribute__((visibility("hidden")))
 int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int32_t *qList, int nC, const int32_t *cand, int isTip, double bLen,
                           double *out, long long ldOut, const int32_t *outCol, const uint8_t *qTip, const double *qBLen, int kind,
                           double algBytes, TileBest *tileBest = nullptr, const int32_t *visitRank = nullptr, const int4 *chunkTab = nullptr,
-                          int nChunkTab = 0, int nF = 1, unsigned long long *finMask = nullptr);
+                          int nChunkTab = 0, int nF = 1, unsigned long long *finMask = nullptr, bool lanesOnly = false);
 // one launch of the placement phase's scoring kernel (k_place_score, placement_host.h) on the context's stream
 __attribute__((visibility("hidden")))
 int launch_place_score(maple_ctx *c, int nQ, int nF, const int32_t *qFrameLists, int nC, const int32_t *cand, const int32_t *candFrame,

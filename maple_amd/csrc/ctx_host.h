@@ -85,6 +85,40 @@ struct PlaceMeta {                     // derived from the uploaded tree, rebuil
     DevBuf<int32_t> d_frameOf, d_candIdx, d_leafIdx, d_candList, d_candFrame, d_leafList, d_leafFrame;
 };
 
+// maple_placement_ahead: the score rows of the NEXT samples of a serial placement loop (M:11692-11752), made in one launch of
+// the batch kernel and kept current under maple_tree_patch -- see placement_host.h
+struct PlaceAhead {
+    bool active = false;
+    int32_t K = 0, next = 0;           // rows; the row the next single-query search takes
+    std::vector<int32_t> q;            // the samples' list ids in the order they will be searched
+    maple_placement_params pp{};
+    // the score rows live in HBM ([K][ld] f64: kernels writing them straight into host memory moved 9 GB/s over PCIe, a
+    // millisecond per 1 000 000-tip row); the row of the sample that is searched next is copied to the host by the copy engine
+    // while the sample before it is being placed (hRow: two page-locked rows, taking turns), and what the placement in between
+    // changed -- a handful of columns -- is patched into it from `hPatch`
+    DevBuf<double> dTable;
+    double *hRow[2] = {nullptr, nullptr}; size_t capRow = 0;    // doubles per row buffer
+    int32_t rowInBuf[2] = {-1, -1};    // which row each buffer holds (or is receiving)
+    double *hPatch = nullptr, *dPatch = nullptr; size_t capPatch = 0;   // page-locked, written by k_ahead_gather (zero copy: a few values)
+    void *hMinor = nullptr; uint8_t *dMinor = nullptr; size_t capMinor = 0;   // [K][ldL] u8 minor-sequence flags, page-locked, written by the kernel (1 MB per row)
+    hipStream_t copyStream = nullptr;
+    int64_t ld = 0, ldL = 0;           // row strides: the columns at scoring time + room for what the placements add; [ld - 1] = the root vector's score
+    DevBuf<int32_t> dQ, dCols, dLists;
+    std::vector<int32_t> dirtyCols, dirtyLeaves;     // columns whose list changed (or that are new) since the rows were last brought up to date
+    bool rootDirty = false;            // ... the root vector (its score sits at [ld - 1])
+    long long refreshes = 0, refreshedPairs = 0;
+    void release()
+    {
+        for (double *&r : hRow) { if (r) (void)hipHostFree(r); r = nullptr; }
+        if (hPatch) (void)hipHostFree(hPatch);
+        if (hMinor) (void)hipHostFree(hMinor);
+        if (copyStream) (void)hipStreamDestroy(copyStream);
+        hPatch = nullptr; dPatch = nullptr; hMinor = nullptr; dMinor = nullptr; copyStream = nullptr; capRow = capPatch = capMinor = 0;
+        dTable.release(); dQ.release(); dCols.release(); dLists.release();
+        active = false;
+    }
+};
+
 struct maple_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -190,6 +224,7 @@ struct maple_ctx {
     std::vector<CandSet> candsets;     // resident candidate sets (maple_candset_create)
     // batched placement (maple_placement_search_batch)
     PlaceMeta *place = nullptr;
+    PlaceAhead *ahead = nullptr;
     std::vector<int32_t> h_tree_c0, h_tree_c1, h_tree_mut, h_tree_totUp, h_tree_upRight, h_tree_upLeft;
     std::vector<NodeRec> h_nodes;      // host copy of the node records (host-side traversal of tiny placement batches)
     DevBuf<int32_t> p_i32[4];

@@ -992,6 +992,7 @@ extern "C" int maple_destroy(maple_ctx *c)
         M.d_leafList.release(); M.d_leafFrame.release();
         delete c->place;
     }
+    if (c->ahead) { c->ahead->release(); delete c->ahead; }
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     for (auto &cs : c->candsets) { if (cs.lists) (void)hipFree(cs.lists); if (cs.frame) (void)hipFree(cs.frame); }
     if (c->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->rccl_comm);
@@ -1012,6 +1013,7 @@ extern "C" int maple_set_model(maple_ctx *c, const double *Q16, const double *si
     DevModel &m = c->dm;
     const int lRef = c->lRef;
     c->h_over_hint.clear();                                           // (which searches run over the budget is a property of the model too)
+    if (c->ahead) c->ahead->active = false;                             // (rows scored under another model)
     for (int i = 0; i < 16; i++) m.Q[i] = Q16[i];
     m.useRateVariation = siteRates ? 1 : 0;
     m.usingErrorRate = usingErrorRate ? 1 : 0;
@@ -1216,6 +1218,8 @@ extern "C" int maple_arena_release(maple_ctx *c, int64_t markBoth)
         c->h_mut_off.resize(mmark); c->h_mut_cnt.resize(mmark);
     }
     if (mark == (int64_t)c->h_n_ent.size()) return MAPLE_OK;
+    if (c->ahead && c->ahead->active)                                   // (rows of samples whose lists go with the release)
+        for (int32_t id : c->ahead->q) if (id >= mark) { c->ahead->active = false; break; }
     if (mark < c->cand_root_end) c->cand_root_end = -1;                 // (the candidates' root-frame copies go with the release)
     if (mark < c->cand_root_top) c->cand_root_mark = c->cand_root_top = -1;
     int64_t ue = c->h_ent_off[mark], ua = c->h_aux_off[mark];
@@ -1876,7 +1880,7 @@ int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int32_t *qL
                           int isTip, double bLen, double *out, long long ldOut, const int32_t *outCol,
                           const uint8_t *qTip, const double *qBLen, int kind, double algBytes, TileBest *tileBest,
                           const int32_t *visitRank, const int4 *chunkTab, int nChunkTab, int nF,
-                          unsigned long long *finMask)
+                          unsigned long long *finMask, bool lanesOnly)
 {
     const long long tiles = (long long)nQ * (chunkTab ? nChunkTab : (nC + 63) / 64);
     if (tiles > 0x7fffffffLL - (1 << 20)) return fail(c, MAPLE_ERR_ARG, "nQ x nC too large for one launch");
@@ -1888,7 +1892,9 @@ int launch_append_queries(maple_ctx *c, hipStream_t s, int nQ, const int32_t *qL
     hipEvent_t e0, e1;
     TRY(ev_pair(c, &e0, &e1, kind, (double)nQ * (double)nC, algBytes));
     HIPCK(c, hipEventRecord(e0, s));
-    if (chunkTab || nQ >= 32) {
+    // (lanesOnly: many queries against a HANDFUL of candidates -- the columns a placement changed, for every sample still waiting,
+    // placement_host.h: the LDS kernel would be one workgroup with a few lanes of each wavefront at work)
+    if (!lanesOnly && (chunkTab || nQ >= 32)) {
         // enough queries to reuse a staged candidate chunk: the LDS kernel, one workgroup of 16 wavefronts per CU
         const long long units = (long long)(chunkTab ? nChunkTab : (nC + 63) / 64) * ((nQ + MAPLE_LDS_QB - 1) / MAPLE_LDS_QB);
         const int gridL = units < 256 ? (int)units : 256;

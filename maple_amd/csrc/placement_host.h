@@ -61,15 +61,17 @@ int launch_place_score(maple_ctx *c, int nQ, int nF, const int32_t *qFrameLists,
     return MAPLE_OK;
 }
 
+// out[q * ldOut + (outCol ? outCol[k] : k)]; leafFrame null: one reference frame
 __global__ __launch_bounds__(MAPLE_BLOCK) void k_place_minor(int lRef, ArenaView av, int nQ, int nF, const int32_t *qFrameLists,
                                                              int nL, const int32_t *leaf, const int32_t *leafFrame,
-                                                             int onlyIdentical, uint8_t *out)
+                                                             int onlyIdentical, uint8_t *out, long long ldOut, const int32_t *outCol)
 {
     const long long tot = (long long)nQ * nL;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(i / nL), k = (int)(i - (long long)q * nL);
-        out[i] = (uint8_t)minor_walk(lRef, list_ref(av, leaf[k]), list_ref(av, qFrameLists[(long long)q * nF + leafFrame[k]]),
-                                     onlyIdentical != 0);
+        out[(long long)q * ldOut + (outCol ? outCol[k] : k)] =
+            (uint8_t)minor_walk(lRef, list_ref(av, leaf[k]), list_ref(av, qFrameLists[(long long)q * nF + (leafFrame ? leafFrame[k] : 0)]),
+                                onlyIdentical != 0);
     }
 }
 
@@ -77,6 +79,7 @@ static int place_meta(maple_ctx *c, double effNon0)
 {
     PlaceMeta &M = *c->place;
     if (M.valid && M.effNon0 == effNon0) return MAPLE_OK;
+    if (c->ahead) c->ahead->active = false;                               // (the columns are numbered anew: rows made ahead are void)
     const int32_t n = c->dtree.n, root = c->dtree.root;
     const auto &up = c->h_tree_up;
     const auto &c0 = c->h_tree_c0, &totUp = c->h_tree_totUp, &lower = c->h_tree_lower;
@@ -253,6 +256,178 @@ extern "C" int maple_placement_prepare(maple_ctx *c, const maple_placement_param
     return MAPLE_OK;
 }
 
+// ---- score rows made AHEAD of a serial placement loop (M:11692-11752) --------------------------------------------------
+// The loop places one sample, edits the tree, places the next: every search scores its sample against every branch of the
+// tree as it is then -- one launch of the one-lane-per-branch kernel per sample, 1.6 ms at 1 000 000 tips, most of it the
+// latency of a kernel that holds one query.  But a placement changes a handful of lists (updatePartials stops where the lists
+// stop changing: 6.5 nodes per sample on the 1 000 000-tip tree), and a branch whose list did not change scores what it scored
+// before.  maple_placement_ahead scores the next K samples against the current tree in ONE launch of the batch kernel
+// (k_append_queries_lds: a tile of 64 candidate lists staged in LDS for 512 queries) and the minor-sequence tests likewise,
+// into page-locked host tables the kernels write directly; maple_tree_patch notes the columns whose list changed and the
+// columns it adds; the next single-query search of one of those samples first brings the rows of ALL samples still waiting up
+// to date (one small launch: waiting rows x changed columns), then runs the reference's traversal over its own row -- the same
+// scores the search would have computed, so the same result (tests/test_hip_search.py compares the two loops).
+// Only on trees without MAT reference frames (one frame: the query needs no re-expression per frame).
+__global__ void k_ahead_gather(const double *row, const int32_t *cols, int n, double *out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = row[cols[i]];
+}
+
+// Brings the rows of the samples still waiting up to date with the tree (the columns maple_tree_patch noted), and the host copy
+// of the row of the sample searched NOW (A.next): *rowOut = that row in page-locked host memory.
+static int ahead_refresh(maple_ctx *c, const double **rowOut)
+{
+    PlaceAhead &A = *c->ahead;
+    PlaceMeta &M = *c->place;
+    const int32_t pending = A.K - A.next;
+    auto uniq = [](std::vector<int32_t> &v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); };
+    uniq(A.dirtyCols); uniq(A.dirtyLeaves);
+    // the row of this sample: on its way since the search before (or copied now)
+    int buf = A.rowInBuf[0] == A.next ? 0 : (A.rowInBuf[1] == A.next ? 1 : -1);
+    const bool prefetched = buf >= 0;
+    if (!prefetched) buf = 0;
+    bool launched = false;
+    size_t nPatch = 0;
+    if (pending > 0 && (!A.dirtyCols.empty() || A.rootDirty)) {
+        std::vector<int32_t> lists(A.dirtyCols.size());
+        for (size_t i = 0; i < lists.size(); i++) lists[i] = M.h_candList[A.dirtyCols[i]];
+        if (A.rootDirty) { A.dirtyCols.push_back((int32_t)(A.ld - 1)); lists.push_back(M.rootVect); }   // (the root's list changed: its new root vector)
+        const size_t n = A.dirtyCols.size();
+        if (n > A.capPatch) {
+            if (A.hPatch) (void)hipHostFree(A.hPatch);
+            A.hPatch = nullptr; A.capPatch = 0;
+            HIPCK(c, hipHostMalloc((void **)&A.hPatch, (n + 1024) * sizeof(double), hipHostMallocDefault));
+            void *dp = nullptr;
+            HIPCK(c, hipHostGetDevicePointer(&dp, A.hPatch, 0));
+            A.dPatch = (double *)dp; A.capPatch = n + 1024;
+        }
+        TRY(h2d(c, A.dCols, A.dirtyCols.data(), n));
+        TRY(h2d(c, A.dLists, lists.data(), n));
+        TRY(launch_append_queries(c, c->stream, pending, A.dQ.p + A.next, (int)n, A.dLists.p, 1, A.pp.oneMutBLen,
+                                  A.dTable.p + (size_t)A.next * A.ld, A.ld, A.dCols.p, nullptr, nullptr, MAPLE_K_PLACE_SCORE, 0.0,
+                                  nullptr, nullptr, nullptr, 0, 1, nullptr, true));
+        if (prefetched) {                                                   // (the copy on its way does not have these columns: patched below)
+            k_ahead_gather<<<1, 256, 0, c->stream>>>(A.dTable.p + (size_t)A.next * A.ld, A.dCols.p, (int)n, A.dPatch);
+            HIPCK(c, hipGetLastError());
+            nPatch = n;
+        }
+        A.refreshes++; A.refreshedPairs += (long long)pending * (long long)n;
+        launched = true;
+    }
+    if (!prefetched) {                                                      // (the first row of a batch: copied now, behind the launch above)
+        HIPCK(c, hipMemcpyAsync(A.hRow[buf], A.dTable.p + (size_t)A.next * A.ld, (size_t)A.ld * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        A.rowInBuf[buf] = A.next;
+        launched = true;
+    }
+    if (launched) HIPCK(c, hipStreamSynchronize(c->stream));
+    if (pending > 0 && !A.dirtyLeaves.empty()) {
+        const size_t n = A.dirtyLeaves.size();
+        std::vector<int32_t> lists(n);
+        for (size_t i = 0; i < n; i++) lists[i] = M.h_leafList[A.dirtyLeaves[i]];
+        TRY(h2d(c, A.dCols, A.dirtyLeaves.data(), n));
+        TRY(h2d(c, A.dLists, lists.data(), n));
+        hipLaunchKernelGGL(k_place_minor, dim3(grid_for((int)std::min<long long>((long long)pending * (long long)n, 1 << 30))), dim3(MAPLE_BLOCK), 0,
+                           c->stream, c->lRef, view(c), pending, 1, A.dQ.p + A.next, (int)n, A.dLists.p, (const int32_t *)nullptr,
+                           A.pp.onlyFindIdentical, A.dMinor + (size_t)A.next * A.ldL, (long long)A.ldL, A.dCols.p);
+        HIPCK(c, hipGetLastError());
+        HIPCK(c, hipStreamSynchronize(c->stream));
+    }
+    if (prefetched) {
+        HIPCK(c, hipStreamSynchronize(A.copyStream));                       // (long done: it was queued a whole placement ago)
+        for (size_t i = 0; i < nPatch; i++) A.hRow[buf][A.dirtyCols[i]] = A.hPatch[i];
+    }
+    A.dirtyCols.clear(); A.dirtyLeaves.clear(); A.rootDirty = false;
+    // ... and the row of the sample after this one sets off: every column it holds now is current as of this search; what the
+    // placement of this sample changes is patched in when its turn comes
+    if (A.next + 1 < A.K) {
+        const int nb = buf ^ 1;
+        HIPCK(c, hipMemcpyAsync(A.hRow[nb], A.dTable.p + (size_t)(A.next + 1) * A.ld, (size_t)A.ld * sizeof(double), hipMemcpyDeviceToHost, A.copyStream));
+        A.rowInBuf[nb] = A.next + 1;
+    }
+    *rowOut = A.hRow[buf];
+    return MAPLE_OK;
+}
+
+extern "C" int maple_placement_ahead(maple_ctx *c, int32_t nQ, const int32_t *qLists, const maple_placement_params *pp, int32_t *nTaken)
+{
+    if (!c || nQ < 0 || (nQ && !qLists) || !pp || !nTaken) return MAPLE_ERR_ARG;
+    *nTaken = 0;
+    HIPCK(c, hipSetDevice(c->device));
+    TRY(need_model(c));
+    if (!c->tree_set) return fail(c, MAPLE_ERR_STATE, "maple_tree_upload has not been called");
+    if (c->ahead) {
+        if (c->ahead->copyStream) HIPCK(c, hipStreamSynchronize(c->ahead->copyStream));
+        c->ahead->active = false;
+    }
+    if (nQ == 0) return MAPLE_OK;
+    TRY(check_ids(c, nQ, qLists, false, "qLists"));
+    TRY(maple_placement_prepare(c, pp));                                 // (tables of the current tree, the root vector)
+    PlaceMeta &M = *c->place;
+    if (M.nF != 1) return MAPLE_OK;                                      // (reference frames: the single-query path as it is; nTaken = 0)
+    if (!c->ahead) c->ahead = new PlaceAhead();
+    PlaceAhead &A = *c->ahead;
+    const int32_t nC = (int32_t)M.cand.size(), nCols = nC + 1, nL = (int32_t)M.leaves.size();
+    // rows: what fits in a quarter of the free device memory (1 000 000 tips: 2 M columns, 16 MB per row -- 512 rows are 8.4 GB)
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t)8 << 30;
+    int32_t K = nQ;
+    const int64_t room = (int64_t)((freeB + A.dTable.cap * sizeof(double)) / 4);
+    for (;;) {
+        A.ld = ((int64_t)nCols + 2 * (int64_t)K + 64 + 15) / 16 * 16;
+        A.ldL = ((int64_t)nL + (int64_t)K + 64 + 63) / 64 * 64;
+        if (K <= 1 || (int64_t)K * A.ld * 8 <= room) break;
+        K = std::max(1, K / 2);
+    }
+    HIPCK(c, A.dTable.reserve_exact((size_t)K * (size_t)A.ld));
+    if ((size_t)A.ld > A.capRow) {
+        for (double *&r : A.hRow) { if (r) (void)hipHostFree(r); r = nullptr; }
+        A.capRow = 0;
+        const size_t want = (size_t)A.ld + (size_t)A.ld / 8 + 4096;
+        for (double *&r : A.hRow) HIPCK(c, hipHostMalloc((void **)&r, want * sizeof(double), hipHostMallocDefault));
+        A.capRow = want;
+    }
+    const size_t needM = (size_t)K * (size_t)A.ldL;
+    if (needM > A.capMinor) {
+        if (A.hMinor) (void)hipHostFree(A.hMinor);
+        A.hMinor = nullptr; A.capMinor = 0;
+        HIPCK(c, hipHostMalloc(&A.hMinor, needM + needM / 8, hipHostMallocDefault));
+        A.capMinor = needM + needM / 8;
+    }
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, A.hMinor, 0) != hipSuccess || !dp) { (void)hipGetLastError(); return MAPLE_OK; }   // (no zero copy: no rows ahead)
+    A.dMinor = (uint8_t *)dp;
+    if (!A.copyStream) HIPCK(c, hipStreamCreateWithFlags(&A.copyStream, hipStreamNonBlocking));
+    A.K = K; A.next = 0; A.pp = *pp;
+    A.rowInBuf[0] = A.rowInBuf[1] = -1;
+    A.q.assign(qLists, qLists + K);
+    A.dirtyCols.clear(); A.dirtyLeaves.clear(); A.rootDirty = false;
+    TRY(h2d(c, A.dQ, A.q.data(), (size_t)K));
+    HIPCK(c, A.dCols.reserve(4096)); HIPCK(c, A.dLists.reserve(4096));
+    const int32_t rootVect = M.rootVect;
+    HIPCK(c, hipMemcpyAsync(M.d_candList.p + nC, &rootVect, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    const bool dbgA = c->tuning.verbose > 1;
+    const auto tA0 = std::chrono::steady_clock::now();
+    auto msSince = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count() * 1e-3; };
+    TRY(launch_append_queries(c, c->stream, K, A.dQ.p, nCols, M.d_candList.p, 1, pp->oneMutBLen, A.dTable.p, A.ld, nullptr, nullptr, nullptr,
+                              MAPLE_K_PLACE_SCORE, 0.0));
+    // the root vector's score sits in the column behind the last branch -- a column the first new branch will take: to the end of the row
+    HIPCK(c, hipMemcpy2DAsync(A.dTable.p + (A.ld - 1), (size_t)A.ld * sizeof(double), A.dTable.p + nC, (size_t)A.ld * sizeof(double), sizeof(double),
+                              (size_t)K, hipMemcpyDeviceToDevice, c->stream));
+    if (dbgA) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] rows ahead: %d x %d scores in %.1f ms\n", K, nCols, msSince(tA0)); }
+    const auto tA1 = std::chrono::steady_clock::now();
+    if (nL > 0) {
+        hipLaunchKernelGGL(k_place_minor, dim3(grid_for((int)std::min<long long>((long long)K * nL, 1 << 30))), dim3(MAPLE_BLOCK), 0,
+                           c->stream, c->lRef, view(c), K, 1, A.dQ.p, nL, M.d_leafList.p, (const int32_t *)nullptr,
+                           pp->onlyFindIdentical, A.dMinor, (long long)A.ldL, (const int32_t *)nullptr);
+        HIPCK(c, hipGetLastError());
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (dbgA) fprintf(stderr, "[maple] rows ahead: %d x %d minor-sequence tests in %.1f ms\n", K, nL, msSince(tA1));
+    A.active = true;
+    *nTaken = K;
+    return MAPLE_OK;
+}
+
 // what the computePlacementSupportOnly=True exit of findBestParentForNewSample hands back (M:8101-8290), CSR over queries
 struct SupportsOut {
     double thrOptTopo, minBranchSupport;
@@ -378,8 +553,17 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
         }
         auto t2 = tnow();
         // ---- scores, minor tests, traversal
+        // (a sample whose rows were made ahead, maple_placement_ahead: no scoring launch -- the waiting rows are brought up to date
+        // with the tree's changes, then the traversal reads this sample's row)
+        PlaceAhead *const ah = (c->ahead && c->ahead->active && !sup && nQ == 1 && nF == 1 && c->ahead->next < c->ahead->K
+                                && c->ahead->q[c->ahead->next] == qLists[0]
+                                && memcmp(&c->ahead->pp, pp, sizeof(maple_placement_params)) == 0
+                                && (int64_t)nCols < c->ahead->ld - 1 && (int64_t)nL <= c->ahead->ldL) ? c->ahead : nullptr;
+        const double *aheadRow = nullptr;
+        if (ah) TRY(ahead_refresh(c, &aheadRow));
+        if (dbg) fprintf(stderr, "[maple]   %s\n", ah ? "rows made ahead: brought up to date" : "scoring launch");
         DevBuf<int32_t> &dU = c->p_i32[0];
-        TRY(h2d(c, dU, U.data(), U.size()));
+        if (!ah) TRY(h2d(c, dU, U.data(), U.size()));
         HIPCK(c, c->p_score.reserve((size_t)nq * nCols));
         HIPCK(c, c->p_minor.reserve((size_t)nq * std::max(nL, 1)));
         // a handful of queries: the traversal runs on the host (below), and the kernels write the scores it reads straight
@@ -389,7 +573,13 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
         double *hs = nullptr, *scoreOut = c->p_score.p;
         uint8_t *hm = nullptr, *minorOut = c->p_minor.p;
         bool zeroCopy = false;
-        if (hostReplay) {
+        int rootCol = nC;
+        if (ah) {
+            hs = const_cast<double *>(aheadRow);
+            hm = (uint8_t *)ah->hMinor + (size_t)ah->next * ah->ldL;
+            rootCol = (int)(ah->ld - 1);
+            zeroCopy = true;
+        } else if (hostReplay) {
             HIPCK(c, c->pin_place.reserve(nS * sizeof(double) + nM));
             hs = (double *)c->pin_place.p;
             hm = (uint8_t *)(hs + nS);
@@ -400,16 +590,17 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                 minorOut = (uint8_t *)((double *)dp + nS);
             } else (void)hipGetLastError();
         }
-        if (nF == 1)   // one reference frame: the plain batch kernel (query words staged in LDS) does the same job faster
+        if (ah) { }
+        else if (nF == 1)   // one reference frame: the plain batch kernel (query words staged in LDS) does the same job faster
             TRY(launch_append_queries(c, c->stream, nq, dU.p, nCols, M.d_candList.p, 1, pp->oneMutBLen, scoreOut, nCols,
                                       nullptr, nullptr, nullptr, MAPLE_K_PLACE_SCORE, 0.0));
         else
             TRY(launch_place_score(c, nq, nF, dU.p, nCols, M.d_candList.p, M.d_candFrame.p, 1, pp->oneMutBLen, scoreOut, nCols,
                                    nullptr, nullptr, nullptr));
-        if (nL > 0) {
+        if (nL > 0 && !ah) {
             hipLaunchKernelGGL(k_place_minor, dim3(grid_for((int)std::min<long long>((long long)nq * nL, 1 << 30))), dim3(MAPLE_BLOCK), 0,
                                c->stream, c->lRef, view(c), nq, nF, dU.p, nL, M.d_leafList.p, M.d_leafFrame.p,
-                               pp->onlyFindIdentical, minorOut);
+                               pp->onlyFindIdentical, minorOut, (long long)std::max(nL, 1), nullptr);
             HIPCK(c, hipGetLastError());
         }
         const size_t SL = MAPLE_PLACE_SHORTLIST;
@@ -450,8 +641,9 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                 oq.bestLK += q; oq.originalLK += q; oq.bestShort += q;
                 oq.slNode += (size_t)q * SL; oq.slLK += (size_t)q * SL; oq.slShort += (size_t)q * SL;
                 if (oq.fromBits) oq.fromBits += (size_t)q * words;
-                place_replay_ptr(c, M, P, hs + (size_t)q * nCols, nC, hm + (size_t)q * std::max(nL, 1), nF, oq);
+                place_replay_ptr(c, M, P, hs + (size_t)q * nCols, rootCol, hm + (size_t)q * std::max(nL, 1), nF, oq);
             }
+            if (ah) { ah->next++; if (ah->next >= ah->K) ah->active = false; }
         } else {
             HIPCK(c, c->p_f64[0].reserve((size_t)nq * stackCap));         // per-depth lastLK
             HIPCK(c, c->p_i16.reserve((size_t)nq * stackCap));            // per-depth fails

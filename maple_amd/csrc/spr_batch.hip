@@ -741,13 +741,18 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
         inFlight = true;
         return MAPLE_OK;
     };
+    // (score rows made ahead, maple_placement_ahead: the columns whose list changes here, and the new ones, are scored again for
+    // the samples still waiting before the next of them is searched)
+    PlaceAhead *const ah = (c->ahead && c->ahead->active) ? c->ahead : nullptr;
+    auto dirty_col = [&](int col) { if (ah) { if ((int64_t)col >= ah->ld - 1) ah->active = false; else ah->dirtyCols.push_back(col); } };
+    auto dirty_leaf = [&](int lc) { if (ah) { if ((int64_t)lc >= ah->ldL) ah->active = false; else ah->dirtyLeaves.push_back(lc); } };
     for (int i = 0; i < nTouched && M.valid; i++) {
         const int v = nodes[i];
-        if (v == root && lower[i] != -1) M.rootVect = -1;                 // (recomputed by the next search if the root's list changed)
+        if (v == root && lower[i] != -1) { M.rootVect = -1; if (ah) ah->rootDirty = true; }   // (recomputed by the next search if the root's list changed)
         const bool cand = v != root && up[i] >= 0 && dist[i] > M.effNon0 && totUp[i] >= 0;        // M:8049
         int col = M.h_candIdx[v];
         if (col >= 0 && !cand) M.h_candIdx[v] = -1;                       // (the column stays and is scored for nothing)
-        else if (col >= 0) { if (M.h_candList[col] != totUp[i]) { M.h_candList[col] = totUp[i]; TRY(poke(M.d_candList, col, totUp[i])); } }
+        else if (col >= 0) { if (M.h_candList[col] != totUp[i]) { M.h_candList[col] = totUp[i]; TRY(poke(M.d_candList, col, totUp[i])); dirty_col(col); } }
         else if (cand) {
             col = (int)M.cand.size();                                     // the column of the root vector moves up by one
             M.cand.push_back(v);
@@ -759,13 +764,14 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
             TRY(poke(M.d_candFrame, col, M.frameOf[v]));
             TRY(poke(M.d_candFrame, col + 1, rootFrame));
             if ((size_t)col + 1 >= M.d_candList.cap) M.valid = false;
+            dirty_col(col);
         }
         const bool leaf = child0[i] < 0;
         int lc = M.h_leafIdx[v];
         if (lc >= 0 && !leaf) M.h_leafIdx[v] = -1;
         else if (leaf) {
             if (lower[i] < 0) { (void)flush_pokes(); return settle_patch(fail(c, MAPLE_ERR_STATE, "leaf %d has no lower genome list", v)); }
-            if (lc >= 0) { if (M.h_leafList[lc] != lower[i]) { M.h_leafList[lc] = lower[i]; TRY(poke(M.d_leafList, lc, lower[i])); } }
+            if (lc >= 0) { if (M.h_leafList[lc] != lower[i]) { M.h_leafList[lc] = lower[i]; TRY(poke(M.d_leafList, lc, lower[i])); dirty_leaf(lc); } }
             else {
                 lc = (int)M.leaves.size();
                 M.leaves.push_back(v);
@@ -773,10 +779,12 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
                 M.h_leafList.push_back(lower[i]); M.h_leafFrame.push_back(M.frameOf[v]);
                 TRY(poke(M.d_leafList, lc, lower[i]));
                 TRY(poke(M.d_leafFrame, lc, M.frameOf[v]));
+                dirty_leaf(lc);
             }
         }
     }
     { const int rc_ = flush_pokes(); if (rc_) return settle_patch(rc_); }
+    if (ah && !M.valid) ah->active = false;                              // (the columns will be numbered anew)
     return settle_patch(MAPLE_OK);
 }
 

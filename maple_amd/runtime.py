@@ -23,7 +23,7 @@ EXPORTS = [
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
     "maple_evaluate_placement_batch", "maple_update_partials", "maple_update_partials_touched", "maple_tree_patch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
-    "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_set_fatal_policy",
+    "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_placement_ahead", "maple_set_fatal_policy",
     "maple_timing_read_kind", "maple_placement_supports_batch",
     "maple_candset_destroy", "maple_spr_search_visited", "maple_arena_compact", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev", "maple_tree_rebuild_lists",
 ]
@@ -482,6 +482,19 @@ class Device:
                                   thresholdLogLKconsecutivePlacement, int(allowedFails), int(bool(strictStopRules)),
                                   int(bool(onlyFindIdentical)))
         self._ck(self.lib.maple_placement_prepare(self.h, C.byref(pp)))
+
+    def placement_ahead(self, q_lists, *, oneMutBLen, effectivelyNon0BLen, thresholdLogLK, thresholdLogLKoptimization,
+                        thresholdLogLKconsecutivePlacement, allowedFails=5, strictStopRules=True, onlyFindIdentical=False):
+        """Announce the next samples of a serial placement loop (maple_placement_ahead): their score rows are made in one launch
+        and kept current under tree_patch; single-sample placement_search_batch calls for them, in this order and with these
+        parameters, then skip the scoring.  Returns how many of the leading samples got rows (0: nothing changes)."""
+        q = _i32(q_lists)
+        pp = MaplePlacementParams(oneMutBLen, effectivelyNon0BLen, thresholdLogLK, thresholdLogLKoptimization,
+                                  thresholdLogLKconsecutivePlacement, int(allowedFails), int(bool(strictStopRules)),
+                                  int(bool(onlyFindIdentical)))
+        taken = C.c_int32(0)
+        self._ck(self.lib.maple_placement_ahead(self.h, len(q), _ptr(q), C.byref(pp), C.byref(taken)))
+        return taken.value
 
     def placement_search_batch(self, q_lists, *, oneMutBLen, effectivelyNon0BLen, thresholdLogLK,
                                thresholdLogLKoptimization, thresholdLogLKconsecutivePlacement, allowedFails=5,

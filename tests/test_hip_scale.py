@@ -896,3 +896,50 @@ def test_oracle_tree_log_lk_from_the_tips_equals_the_library_on_plain_and_local_
     assert mat["rel_delta"] <= 1e-11 and 0 < abs(mat["oracle"] - plain["oracle"]) < 1e-3 * abs(plain["oracle"]), (mat, plain)
     dev.release(mark)
     assert len(tips) * 2 - 1 == mirror.n_nodes
+
+
+@pytest.mark.parametrize("mode", ["ratevar", "siteerr"])
+def test_serial_loop_with_rows_made_ahead_equals_the_plain_loop(mode):
+    """maple_placement_ahead (include/maple_hip.h): the score rows of the next samples of the serial placement loop (M:11692-11752)
+    made in ONE launch and kept current under maple_tree_patch.  The loop with the samples announced 64 at a time against the
+    plain loop (one scoring launch per sample) on a 6 000-tip tree, 400 new samples -- among them copies of tips (minor sequences:
+    skipped by the stand-in edit) and samples placed next to samples added before them: every search's status, node, score,
+    branch lengths and candidate count bit for bit, the final trees identical (relatives, lengths), the lists of a sample of the
+    final tree's nodes entry for entry; and the rows were really used (the library counts its refreshes)."""
+    import bench
+    from maple_amd.host import tip_genome_list
+    from maple_amd.synth import perturb_diffs
+    data, dev, orc, m = build(6000, mode, seed=9)
+    l_ref = dev.lRef
+    ll = math.log(l_ref)
+    pkw = dict(oneMutBLen=1.0 / l_ref, effectivelyNon0BLen=1.0 / (10 * l_ref), thresholdLogLK=18.0 * ll,
+               thresholdLogLKoptimization=1.0 * ll, thresholdLogLKconsecutivePlacement=1.0)
+    kw = world_model_kwargs(mode, l_ref, 9)
+    tip_kw = dict(error_rates=kw["errorRates"]) if mode == "siteerr" else {}
+    prng = np.random.default_rng(3)
+    src = prng.choice(len(data.diffs), size=400, replace=True)            # (with replacement: several samples next to one tip)
+    new_lists = []
+    for k, i in enumerate(src):
+        dl = data.diffs[int(i)] if k % 25 == 0 else perturb_diffs(data.diffs[int(i)], data.ref, prng)
+        new_lists.append(tip_genome_list(dl, dev.ref_idx, **tip_kw))
+    runs = []
+    for ahead in (0, 64):
+        mark = dev.mark()
+        sp = bench.serial_phase(dev, m, new_lists, pkw, ahead=ahead)
+        c = sp["cols"]
+        n = c["n"]
+        probe = np.arange(0, n, 97)
+        lists = {name: dev.download(c[name][probe][c[name][probe] >= 0]) for name in ("lower", "tot_up", "up_right")}
+        runs.append((sp, lists))
+        dev.release(mark)
+    (a, la), (b, lb) = runs
+    assert a["placed"] == b["placed"] and a["placed"] > 300
+    assert a["results"] == b["results"]
+    ca, cb = a["cols"], b["cols"]
+    assert ca["n"] == cb["n"]
+    for name in ("up", "c0", "c1", "dist", "tip"):
+        assert np.array_equal(ca[name][: ca["n"]], cb[name][: cb["n"]]), name
+    for name in la:
+        assert la[name] == lb[name], name
+    assert len(b["times"]["ahead"]) >= 6 and len(a["times"]["ahead"]) == 0
+    dev.close()
