@@ -278,6 +278,11 @@ def compact_line(full):
                              "first_step_after_upload_ms": _num(leg.get("first_step_after_upload_ms"), 5),
                              "roofline": {k: v for k, v in (roof(leg.get("roofline")) or {}).items()
                                           if k in ("bound", "kernel", "achieved", "peak", "frac", "kernel_ms", "kernel_ms_per_step")}}
+    rc = full.get("round_on_a_changing_tree")
+    if rc and "error" not in rc:
+        line["changing_tree"] = {"moves": rc["proposed_moves"], "applied": rc["moves_applied"], "apply_ms_per_move": _num(rc["apply_ms_per_proposed_move"], 4),
+                                 "round_s": _num(rc["round_s"], 4), "next_first_ms": _num(rc["next_round_first_search_ms"], 5),
+                                 "next_ms": _num(rc["next_round_search_ms"], 5)}
     c5 = full.get("config_5")
     if c5 and "error" in c5:
         line["config_5"] = {"error": _short(c5["error"], 120)}
@@ -1047,6 +1052,52 @@ def sub_blocks(args, dev, mirror, data, ref_idx, tip_kw, kw, order, B, upload_pl
             "re-search from a zero-length branch -- a whole-tree search -- after the tree's tables were brought up to date); "
             "batched = 32 moves re-searched per call, a speculative result kept while nothing its search may have read was "
             "touched by the moves applied before it")
+    if first_step is not None and len(first_nodes) == len(order):
+        # ---- a WHOLE round on a tree that changes (M:12283-12316 search, 12306-12312 gather + sort, applySPRMovesParallel
+        # M:9470-9484, then the next round's search): every node searched (the timed steps' round), EVERY proposed move
+        # re-searched and applied best first, the next round searched on the tree the moves left -- its first call (the
+        # per-tree tables follow the patches or are rebuilt) against the call after it
+        from maple_amd.spr_apply import SprApplier
+        try:
+            mark = dev.mark()
+            ap = SprApplier.from_mirror(dev, mirror)
+            all_nodes = np.asarray(order)
+            t0 = time.perf_counter()
+            r1 = dev.spr_search_batch(all_nodes, **kw)
+            search1_ms = 1e3 * (time.perf_counter() - t0)
+            prop = np.nonzero(r1["placement"] >= 0)[0]
+            prop = prop[np.argsort(-r1["improvement"][prop], kind="stable")]
+            t0 = time.perf_counter()
+            ap.apply_batched(all_nodes[prop], kw)
+            apply_s = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            r2 = dev.spr_search_batch(all_nodes, **kw)
+            search2_first_ms = 1e3 * (time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            r3 = dev.spr_search_batch(all_nodes, **kw)
+            search2_ms = 1e3 * (time.perf_counter() - t0)
+            out["round_on_a_changing_tree"] = {
+                "searches_per_round": int(len(all_nodes)), "search_ms": search1_ms, "proposed_moves": int(len(prop)),
+                "moves_applied": len(ap.applied), "no_longer_proposed": int(ap.no_longer_proposed),
+                "skipped_by_the_stand_in_edit": int(ap.skipped), "apply_phase_s": apply_s,
+                "apply_ms_per_proposed_move": 1e3 * apply_s / max(1, len(prop)), "search_calls_of_the_apply_phase": len(ap.times["search"]),
+                "whole_tree_re_searches": int(ap.whole_tree_searches),
+                "apply_ms_split": {"search_calls": 1e3 * float(np.sum(ap.times["search"])), "update_partials": 1e3 * float(np.sum(ap.times["update"])),
+                                   "tree_patch": 1e3 * float(np.sum(ap.times["patch"]))},
+                "round_s": (search1_ms * 1e-3) + apply_s,
+                "next_round_first_search_ms": search2_first_ms, "next_round_search_ms": search2_ms,
+                "first_over_steady": search2_first_ms / max(1e-9, search2_ms),
+                "next_round_proposed_moves": int((r3["placement"] >= 0).sum()),
+                "next_round_same_twice": bool(np.array_equal(r2["placement"], r3["placement"]) and np.array_equal(r2["bestScore"], r3["bestScore"])),
+                "note": "plain form of the headline tree; the tree edit is maple_amd/spr_apply.py's stand-in for cutAndPasteNode (host "
+                        "code of the reference, out of scope); apply_batched: 32 moves re-searched per call, a speculative result kept "
+                        "while nothing its search read was touched by the moves applied before it (the applied sequence is the "
+                        "sequential driver's, tests/test_hip_scale.py)"}
+            upload_plain_tree()
+            dev.release(mark)
+        except (Exception, SystemExit) as e:
+            out["round_on_a_changing_tree"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            upload_plain_tree()
     if (args.local_refs or args.samples <= 200000) and not headline_refs:
         # ---- the same steps on the same tree after giving it MAT local references (setUpMAT's rule, 50 descendants per
         # reference node, M:166 / 6152-6164): the form real MAPLE trees have; lists are shorter, searches cross frames ----

@@ -244,4 +244,111 @@ __device__ __forceinline__ double append_walk_m(const Ctx<RV, U, SS> &c, const P
     return (tf > 0.0) ? lk + log(tf) : -INFINITY;
 }
 
+// ---- the same walk over lists whose plain reference runs may be left out ------------------------------------------------------
+// Half the entries of a genome list are reference runs without a tail, and two of three steps of the walk above end on the
+// boundary of one and do nothing.  A list in the SKIPPING form leaves out every tail-less R entry that is followed by a
+// single-site entry (types 0-3, 6): what lies between the entry before and that single-site entry is then reference by
+// omission.  Kept are all single-site entries, N runs, R runs with a tail, the list's last entry (so that the walk still ends on
+// lRef), and a tail-less R that is followed by a run -- so a run's first position is always the position after the entry
+// before it.  (A list with nothing left out is a list in skipping form too.)  The walk goes from event to event: where both
+// lists are reference by omission nothing is looked at.  The sites that need work, their entries and the order of the factors
+// are those of append_walk_m: bit-identical.
+// keep(w, next): may entry w be left out?  No if it is the last entry (next == 0).
+__device__ __forceinline__ bool skip_form_drops(unsigned long long w, unsigned long long next, bool last)
+{
+    const uint32_t m = (uint32_t)(w >> 32), t = m & 7u, tn = (uint32_t)(next >> 32) & 7u;
+    return !last && t == 4u && !(m & 0x60u) && (tn < 4u || tn == 6u);
+}
+// (Tried on top of it and not kept: the lanes of a wavefront taking the general site_factor TOGETHER -- a lane that reaches such
+// a site waits, the path runs when a dozen lanes wait or nobody else can go on.  Bit-identical, and 1.7 x SLOWER on the
+// 100 000-tip tree, 512 queries x every branch: 56.7 ms against 32.8 -- the waiting lanes lengthen every wavefront's walk by
+// more than the shared path saves, and the state kept across the vote costs another 100 spilled registers.)
+template <bool RV, bool U, bool SS, class PM, class CM>
+__device__ __forceinline__ double append_walk_c(const Ctx<RV, U, SS> &c, const PM &P, const CM &C, bool isTipC, double bLen, bool valid = true)
+{
+    if (!valid) return -INFINITY;
+    const int lRef = c.m.lRef;
+    const double carry = c.m.minimumCarryOver;
+    unsigned long long wa = P.word(0), wb = C.word(0);
+    int ia = 0, ib = 0, cur = 0;
+    double tf = 1.0;
+    double Lk = bLen * c.m.globalTotRate;                               // M:6541
+    if (U && isTipC) Lk += c.m.totError;                                // M:6542-6543
+    double carry1 = 1.0, carry2 = 1.0;
+    int nCarry = 0;
+    for (;;) {
+        const int pa = (int)(uint32_t)wa, pb = (int)(uint32_t)wb;
+        const uint32_t ma = (uint32_t)(wa >> 32), mb = (uint32_t)(wb >> 32);
+        const int ta = ma & 7u, tb = mb & 7u;
+        const bool sa = ta < 4 || ta == 6, sb = tb < 4 || tb == 6;       // single-site entries
+        // a run reaches back to the position after the entry before it: it covers cur + 1; a single-site entry covers cur + 1 only
+        // if it IS there -- else reference by omission up to the site before it
+        bool realA = !sa || pa == cur + 1, realB = !sb || pb == cur + 1;
+        if (!realA && !realB) {                                          // both reference by omission: on to the next entry of either
+            cur = min(pa, pb) - 1;
+            realA = pa == cur + 1; realB = pb == cur + 1;
+        }
+        const int endA = realA ? pa : pa - 1, endB = realB ? pb : pb - 1;
+        const int pos = min(endA, endB);
+        const uint32_t m1 = realA ? ma : 4u, m2 = realB ? mb : 4u;
+        const int t1 = m1 & 7u, t2 = m2 & 7u;
+        if ((t1 != 5) & (t2 != 5) & ((t1 != t2) | (t1 == 6))) {
+            const int site = pos - 1;
+            bool dead = false;
+            const double r = RV ? ((realA && pa == pos) ? P.rate(ia, site, c) : C.rate(ib, site, c)) : 1.0;
+            if (t1 == 6 || t2 == 6 || (m1 & (1u << 6))) {               // O vector or observation beyond the root
+                double f = 0.0;
+                bool general = true;
+                if ((t1 == 6) != (t2 == 6)) {                            // (the reference's shortcut first, see append_walk_m)
+                    const bool o1 = t1 == 6;
+                    const uint32_t mo = o1 ? m1 : m2;
+                    const int tn = o1 ? t2 : t1;
+                    const uint32_t off = (mo >> 8) + ((mo >> 5) & 1u) + ((mo >> 6) & 1u) + (uint32_t)((tn == 4) ? (int)((mo >> 3) & 3u) : tn);
+                    f = o1 ? P.aux(off) : C.aux(off);
+                    general = !(f > 0.02);
+                }
+                if (general) {
+                    EntV e1, e2;
+                    decode_v(realA ? wa : (((unsigned long long)4u << 32) | (uint32_t)pos), P, e1);
+                    decode_v(realB ? wb : (((unsigned long long)4u << 32) | (uint32_t)pos), C, e2);
+                    f = site_factor_v(c, e1, e2, site, r, isTipC, bLen);
+                }
+                tf *= f;
+            } else {                                                     // two different nucleotides (R = the reference one)
+                double cl = bLen;                                        // M:6640-6668, 6713-6742
+                if (m1 & (1u << 5)) cl += P.aux(m1 >> 8);
+                if ((m2 & (1u << 5)) && !(m2 & (1u << 6))) cl += C.aux(m2 >> 8);
+                const int i1 = (t1 == 4) ? (int)((m2 >> 3) & 3u) : t1;
+                const int i2 = (t2 == 4) ? (int)((m1 >> 3) & 3u) : t2;
+                const double qv = c.q(r, i1, i2);
+                double f = fmin_py(0.25, qv * cl);
+                if (U) {
+                    const bool flag1 = (t1 != 4) && (m1 & (1u << 5)) && (m1 & (1u << 7));
+                    const bool flag2 = isTipC || ((m2 & (1u << 5)) && (m2 & (1u << 7)));
+                    if (t1 == 4) { if (flag2) f += c.err(site) * 0.33333; else if (cl == 0.0) dead = true; }
+                    else if (flag1 || flag2) f += (double)((int)flag1 + (int)flag2) * 0.33333 * c.err(site);
+                    else if (cl == 0.0) dead = true;
+                } else if (cl == 0.0) dead = true;                       // zero-length mismatch: -inf (M:6663, 6742)
+                tf *= f;
+            }
+            if (dead) return -INFINITY;
+            if (tf <= carry) {                                           // M:6772-6783
+                if (tf < 2.2250738585072014e-308) return -INFINITY;
+                if (nCarry == 2) { Lk += log(carry1); carry1 = carry2; nCarry = 1; }
+                if (nCarry == 0) carry1 = tf; else carry2 = tf;
+                ++nCarry;
+                tf = 1.0;
+            }
+        }
+        if (pos == lRef) break;
+        cur = pos;
+        if (realA && pa == pos) { ++ia; wa = P.word(ia); }
+        if (realB && pb == pos) { ++ib; wb = C.word(ib); }
+    }
+    double lk = Lk;
+    if (nCarry >= 1) lk += log(carry1);
+    if (nCarry >= 2) lk += log(carry2);
+    return (tf > 0.0) ? lk + log(tf) : -INFINITY;
+}
+
 }  // namespace maple

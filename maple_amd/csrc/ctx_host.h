@@ -78,6 +78,9 @@ struct PlaceMeta {                     // derived from the uploaded tree, rebuil
     std::vector<int32_t> order;                    // nodes reachable from the root, depth-first
     int32_t rootVect = -1;                         // rootVector(probVect[root]) of the uploaded tree (list id), kept while it lives
     std::vector<int32_t> h_candIdx, h_leafIdx;     // per node: column in the score / minor matrix or -1
+    struct PNode { int32_t candCol, leafCol, c0, c1; };
+    std::vector<PNode> h_pn;                       // per node, for the host traversal of a single query: what a visit reads, in ONE 16-byte
+                                                   // record (four arrays of 4-8 MB each were four cache misses per visit at 1 000 000 tips)
     std::vector<int32_t> h_candList, h_candFrame, h_leafList, h_leafFrame;   // host copies of the column arrays (maple_tree_patch)
     bool scanStale = false;                        // the tree changed through maple_tree_patch: h_scan / d_scan / order are old
     std::vector<ScanRec> h_scan;                   // the tree in traversal order (placement_dev.h)

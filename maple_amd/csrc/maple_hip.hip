@@ -222,11 +222,30 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
                 const unsigned long long *sw = (const unsigned long long *)(av.words + av.ent_off[li]);
                 const double *sa = av.aux + av.aux_off[li];
                 const int w0 = cwoff[i], nw = cwoff[i + 1] - w0, a0 = caoff[i], na2 = caoff[i + 1] - a0;
+#ifndef MAPLE_DENSE_PLAIN
+                // (staged in the SKIPPING form of append_lds.h: the tail-less reference runs in front of single-site entries are left
+                // out -- half the entries, and with them half the steps of every walk over the chunk)
+                int kept = 0;
+                for (int j0 = 0; j0 < nw; j0 += 64) {
+                    const int j = j0 + lane;
+                    unsigned long long w = 0;
+                    bool keep = false;
+                    if (j < nw) { w = sw[j]; keep = !skip_form_drops(w, j + 1 < nw ? sw[j + 1] : 0ull, j + 1 == nw); }
+                    const unsigned long long bal = __ballot(keep);
+                    if (keep) {
+                        const int d = w0 + kept + __popcll(bal & ((1ull << lane) - 1ull));
+                        cW[d] = w;
+                        if (RV) cR[d] = c.rate((int)(uint32_t)w - 1);
+                    }
+                    kept += __popcll(bal);
+                }
+#else
                 for (int j = lane; j < nw; j += 64) {
                     const unsigned long long w = sw[j];
                     cW[w0 + j] = w;
                     if (RV) cR[w0 + j] = c.rate((int)(uint32_t)w - 1);
                 }
+#endif
                 for (int j = lane; j < na2; j += 64) cA[a0 + j] = sa[j];
             }
         }
@@ -243,17 +262,58 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
             const ListRef qref = list_ref(av, ql);
             const bool stagedQ = nq <= MAPLE_QLDS;                          // wave-uniform
             if (stagedQ) {
+#ifndef MAPLE_DENSE_PLAIN
+                const unsigned long long *qsrc = (const unsigned long long *)qref.w;
+                int kept = 0;
+                for (int j0 = 0; j0 < nq; j0 += 64) {
+                    const int j = j0 + lane;
+                    unsigned long long w = 0;
+                    bool keep = false;
+                    if (j < nq) { w = qsrc[j]; keep = !skip_form_drops(w, j + 1 < nq ? qsrc[j + 1] : 0ull, j + 1 == nq); }
+                    const unsigned long long bal = __ballot(keep);
+                    if (keep) {
+                        const int d = kept + __popcll(bal & ((1ull << lane) - 1ull));
+                        myq[d] = w;
+                        if (RV) myqR[d] = c.rate((int)(uint32_t)w - 1);
+                    }
+                    kept += __popcll(bal);
+                }
+#else
                 for (int i = lane; i < nq; i += 64) {
                     const unsigned long long w = ((const unsigned long long *)qref.w)[i];
                     myq[i] = w;
                     if (RV) myqR[i] = c.rate((int)(uint32_t)w - 1);
                 }
+#endif
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
             bool finite = false;
+#ifndef MAPLE_DENSE_PLAIN
+            // (the walk in skipping form votes over the whole wavefront, append_lds.h: every lane calls, those without a candidate
+            // with valid = false)
+            const bool validL = cl >= 0;
+            double lkAll;
+            {
+                const bool tipq = qTip ? qTip[q] != 0 : isTip != 0;
+                const double blq = qBLen ? qBLen[q] : bLen;
+                const MemLG qL{(lds_u64p)myq, qref.aux, (lds_f64p)myqR};
+                const MemG qG{(const unsigned long long *)qref.w, qref.aux};
+                if (stagedC) {                                              // (block-uniform; stagedQ is wave-uniform)
+                    const MemL pL{(lds_u64p)(cW + myW), (lds_f64p)(cA + myA), (lds_f64p)(cR + myW)};
+                    lkAll = stagedQ ? append_walk_c(c, pL, qL, tipq, blq, validL) : append_walk_c(c, pL, qG, tipq, blq, validL);
+                } else {
+                    const ListRef pr = validL ? list_ref(av, cl) : qref;
+                    const MemG pG{(const unsigned long long *)pr.w, pr.aux};
+                    lkAll = stagedQ ? append_walk_c(c, pG, qL, tipq, blq, validL) : append_walk_c(c, pG, qG, tipq, blq, validL);
+                }
+            }
+#endif
             if (cl >= 0) {
+#ifndef MAPLE_DENSE_PLAIN
+                const double lk = lkAll;
+#else
                 const bool tipq = qTip ? qTip[q] != 0 : isTip != 0;
                 const double blq = qBLen ? qBLen[q] : bLen;
                 const MemLG qL{(lds_u64p)myq, qref.aux, (lds_f64p)myqR};
@@ -267,6 +327,7 @@ void k_append_queries_lds(const DevModel *__restrict__ mp, ArenaView av, int nQ,
                     const MemG pG{(const unsigned long long *)pr.w, pr.aux};
                     lk = stagedQ ? append_walk_m(c, pG, qL, tipq, blq) : append_walk_m(c, pG, qG, tipq, blq);
                 }
+#endif
                 // finMask: which of the tile's 64 scores are finite goes out as ONE word per (query, tile) and only the finite
                 // scores are stored -- the searches these rows are for are the ones whose scores are nearly all -inf (a mismatch
                 // over a zero-length branch), and an 8-byte store into every line of a row was most of the kernel's HBM traffic

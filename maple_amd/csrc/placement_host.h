@@ -148,6 +148,8 @@ static int place_meta(maple_ctx *c, double effNon0)
     TRY(h2d(c, M.d_leafList, leafList.data(), leafList.size()));
     TRY(h2d(c, M.d_leafFrame, leafFrame.data(), leafFrame.size()));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    M.h_pn.resize((size_t)n);
+    for (int32_t v = 0; v < n; v++) M.h_pn[v] = PlaceMeta::PNode{candIdx[v], leafIdx[v], c->h_tree_c0[v], c->h_tree_c1[v]};
     M.effNon0 = effNon0;
     M.valid = true;
     M.scanStale = false;
@@ -161,7 +163,7 @@ static void place_replay_ptr(const maple_ctx *c, const PlaceMeta &M, const Place
                              const uint8_t *mn, int nF, const PlaceOut &o)
 {
     const int32_t root = c->dtree.root;
-    const auto &c0 = c->h_tree_c0, &c1 = c->h_tree_c1;
+    const PlaceMeta::PNode *const pn = M.h_pn.data();
     std::vector<uint32_t> frameBits((size_t)(nF + 31) >> 5, 0u);
     if (o.fromBits) for (int i = 0; i < (nF + 31) >> 5; i++) o.fromBits[i] = 0u;
     int32_t *slN = o.slNode;
@@ -172,13 +174,21 @@ static void place_replay_ptr(const maple_ctx *c, const PlaceMeta &M, const Place
     int bestNode = root;
     struct It { int32_t node; int32_t fails; double parentLK; };
     std::vector<It> st;
-    if (!P.supportOnly && M.h_leafIdx[root] >= 0 && mn[M.h_leafIdx[root]] == 1) { status = 1; minorNode = root; nAppend = 0; }
-    if (c0[root] >= 0) { st.push_back(It{c0[root], 0, bestLK}); st.push_back(It{c1[root], 0, bestLK}); }
+    if (!P.supportOnly && pn[root].leafCol >= 0 && mn[pn[root].leafCol] == 1) { status = 1; minorNode = root; nAppend = 0; }
+    if (pn[root].c0 >= 0) { st.push_back(It{pn[root].c0, 0, bestLK}); st.push_back(It{pn[root].c1, 0, bestLK}); }
     while (!st.empty() && status == 0) {                                  // M:7972-8100
         const It it = st.back();
         st.pop_back();
         const int t1 = it.node;
-        const int candCol = M.h_candIdx[t1], leafCol = M.h_leafIdx[t1];
+        const PlaceMeta::PNode me = pn[t1];                                // (asked for when the node was pushed)
+        const int candCol = me.candCol, leafCol = me.leafCol;
+        // (the visit after this one -- unless this node pushes children -- is the node now on top: its record is here since it
+        // was pushed; its score and its minor flag are asked for now, a visit ahead)
+        if (!st.empty()) {
+            const PlaceMeta::PNode nx = pn[st.back().node];
+            if (nx.candCol >= 0) __builtin_prefetch(sc + nx.candCol);
+            if (nx.leafCol >= 0) __builtin_prefetch(mn + nx.leafCol);
+        }
         int fails = it.fails;
         if (leafCol >= 0) {
             const int cmp = mn[leafCol];
@@ -209,12 +219,15 @@ static void place_replay_ptr(const maple_ctx *c, const PlaceMeta &M, const Place
         }
         const bool within = lk > bestLK - P.thrLK;
         const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);   // M:8080-8093
-        if (go && c0[t1] >= 0) {
-            st.push_back(It{c0[t1], fails, lk}); st.push_back(It{c1[t1], fails, lk});
-            const int f = M.frameOf[t1];
-            if (o.fromBits && ((frameBits[f >> 5] >> (f & 31)) & 1u))       // (see place_replay_one)
-                for (int32_t ch : {c0[t1], c1[t1]})
-                    if (M.frameOf[ch] != f) o.fromBits[M.frameOf[ch] >> 5] |= 1u << (M.frameOf[ch] & 31);
+        if (go && me.c0 >= 0) {
+            st.push_back(It{me.c0, fails, lk}); st.push_back(It{me.c1, fails, lk});
+            __builtin_prefetch(pn + me.c0); __builtin_prefetch(pn + me.c1);
+            if (o.fromBits) {
+                const int f = M.frameOf[t1];
+                if ((frameBits[f >> 5] >> (f & 31)) & 1u)                  // (see place_replay_one)
+                    for (int32_t ch : {me.c0, me.c1})
+                        if (M.frameOf[ch] != f) o.fromBits[M.frameOf[ch] >> 5] |= 1u << (M.frameOf[ch] & 31);
+            }
         }
     }
     int k = 0;

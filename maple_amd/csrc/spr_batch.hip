@@ -783,6 +783,13 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
             }
         }
     }
+    if (M.valid) {                                                        // (the host traversal's per-node records follow)
+        M.h_pn.resize((size_t)nTotal, PlaceMeta::PNode{-1, -1, -1, -1});
+        for (int i = 0; i < nTouched; i++) {
+            const int v = nodes[i];
+            M.h_pn[v] = PlaceMeta::PNode{M.h_candIdx[v], M.h_leafIdx[v], c->h_tree_c0[v], c->h_tree_c1[v]};
+        }
+    }
     { const int rc_ = flush_pokes(); if (rc_) return settle_patch(rc_); }
     if (ah && !M.valid) ah->active = false;                              // (the columns will be numbered anew)
     return settle_patch(MAPLE_OK);
