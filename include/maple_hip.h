@@ -95,6 +95,8 @@ typedef struct {
     int32_t noOverHint;         /* 1: with an error model, a node whose SPR search ran over the whole-tree budget the last time is
                                    NOT sent to the dense tier at once the next time (the library remembers that per node between
                                    calls on one tree: maple_spr_search_batch) */
+    int32_t noAheadExpansion;   /* 1: maple_placement_ahead scores EVERY branch for the samples it is given, instead of only the
+                                   branches an expansion under permissive rules reaches (the tests compare the two) */
 } maple_tuning;
 int maple_set_tuning(maple_ctx *ctx, const maple_tuning *t);
 const char *maple_last_error(maple_ctx *ctx);
@@ -316,9 +318,15 @@ int maple_placement_prepare(maple_ctx *ctx, const maple_placement_params *params
  * columns again (for all samples still waiting) and then runs the traversal over its row: the same scores, the same
  * result as without the announcement.  *nTaken = the leading samples the library made rows for (what fits its page-locked
  * tables; 0 on a tree with MAT reference frames, where the call changes nothing); announce the rest when those are done.
+ * The rows hold the branches an expansion of all announced samples under permissive rules reaches (every branch the
+ * reference's traversal can visit on the tree as it is then; maple_tuning.noAheadExpansion: every branch of the tree).
  * The rows are dropped by anything that renumbers the columns or changes what a score means (maple_tree_upload,
  * maple_set_model, other parameters, a release of the samples' lists), and by a search of any other sample. */
 int maple_placement_ahead(maple_ctx *ctx, int32_t nQ, const int32_t *qLists, const maple_placement_params *params, int32_t *nTaken);
+/* What the rows made ahead were used for since the context was created: out5 = searches that took a row, those among them whose
+ * row had to be scored in full after all (the traversal asked for a branch the expansion had not reached), items the
+ * expansions scored, launches that brought waiting rows up to date, (row, column) pairs they scored. */
+int maple_placement_ahead_stats(maple_ctx *ctx, int64_t *out5);
 int maple_placement_search_batch(maple_ctx *ctx, int32_t nQ, const int32_t *qLists, const maple_placement_params *params,
                                  int32_t *bestNode, double *bestScore, double *blen3, int32_t *bestDiffs,
                                  int32_t *nAppend, int32_t *status);

@@ -86,6 +86,8 @@ struct PlaceMeta {                     // derived from the uploaded tree, rebuil
     std::vector<ScanRec> h_scan;                   // the tree in traversal order (placement_dev.h)
     DevBuf<ScanRec> d_scan;
     DevBuf<int32_t> d_frameOf, d_candIdx, d_leafIdx, d_candList, d_candFrame, d_leafList, d_leafFrame;
+    DevBuf<int32_t> d_pn;                          // h_pn on the device (4 words per node; kept current by maple_tree_patch): the expansion of
+                                                   // maple_placement_ahead walks the tree there
 };
 
 // maple_placement_ahead: the score rows of the NEXT samples of a serial placement loop (M:11692-11752), made in one launch of
@@ -110,6 +112,11 @@ struct PlaceAhead {
     std::vector<int32_t> dirtyCols, dirtyLeaves;     // columns whose list changed (or that are new) since the rows were last brought up to date
     bool rootDirty = false;            // ... the root vector (its score sits at [ld - 1])
     long long refreshes = 0, refreshedPairs = 0;
+    // the rows hold the scores of the branches an expansion under permissive rules reached (placement_host.h); every other column
+    // holds PLACE_NO_SCORE, and a traversal that asks for one has the whole row scored first (counted)
+    bool sparse = false;
+    long long fallbacks = 0, expanded = 0, searches = 0;
+    DevBuf<uint8_t> dItems; DevBuf<unsigned long long> dCtr;
     void release()
     {
         for (double *&r : hRow) { if (r) (void)hipHostFree(r); r = nullptr; }
@@ -117,7 +124,7 @@ struct PlaceAhead {
         if (hMinor) (void)hipHostFree(hMinor);
         if (copyStream) (void)hipStreamDestroy(copyStream);
         hPatch = nullptr; dPatch = nullptr; hMinor = nullptr; dMinor = nullptr; copyStream = nullptr; capRow = capPatch = capMinor = 0;
-        dTable.release(); dQ.release(); dCols.release(); dLists.release();
+        dTable.release(); dQ.release(); dCols.release(); dLists.release(); dItems.release(); dCtr.release();
         active = false;
     }
 };

@@ -1050,7 +1050,7 @@ extern "C" int maple_destroy(maple_ctx *c)
     if (c->place) {
         PlaceMeta &M = *c->place;
         M.d_scan.release(); M.d_frameOf.release(); M.d_candIdx.release(); M.d_leafIdx.release(); M.d_candList.release(); M.d_candFrame.release();
-        M.d_leafList.release(); M.d_leafFrame.release();
+        M.d_leafList.release(); M.d_leafFrame.release(); M.d_pn.release();
         delete c->place;
     }
     if (c->ahead) { c->ahead->release(); delete c->ahead; }

@@ -80,6 +80,7 @@ static int place_meta(maple_ctx *c, double effNon0)
     PlaceMeta &M = *c->place;
     if (M.valid && M.effNon0 == effNon0) return MAPLE_OK;
     if (c->ahead) c->ahead->active = false;                               // (the columns are numbered anew: rows made ahead are void)
+    M.d_pn.release();
     const int32_t n = c->dtree.n, root = c->dtree.root;
     const auto &up = c->h_tree_up;
     const auto &c0 = c->h_tree_c0, &totUp = c->h_tree_totUp, &lower = c->h_tree_lower;
@@ -159,8 +160,10 @@ static int place_meta(maple_ctx *c, double effNon0)
 // The same traversal as place_replay_one (placement_dev.h), over the host's own tree columns instead of the scan array: the
 // single-query calls of the sequential placement phase use it, so that a tree changed through maple_tree_patch needs no
 // re-linearisation.  Children in the order of compute_frames' depth-first order: child 1's clade first.
+// sparse: the row holds PLACE_NO_SCORE in the columns nobody scored (rows by expansion): a visit that needs one ends the
+// traversal with status -7 and the caller scores the whole row
 static void place_replay_ptr(const maple_ctx *c, const PlaceMeta &M, const PlaceParams &P, const double *sc, int rootCol,
-                             const uint8_t *mn, int nF, const PlaceOut &o)
+                             const uint8_t *mn, int nF, const PlaceOut &o, bool sparse = false)
 {
     const int32_t root = c->dtree.root;
     const PlaceMeta::PNode *const pn = M.h_pn.data();
@@ -198,6 +201,11 @@ static void place_replay_ptr(const maple_ctx *c, const PlaceMeta &M, const Place
         double lk = it.parentLK;
         if (candCol >= 0) {
             lk = sc[candCol];
+            if (sparse) {
+                unsigned long long bits;
+                memcpy(&bits, &lk, sizeof bits);
+                if (bits == 0x7ff8dead0badc0deull) { status = -7; break; }
+            }
             nAppend++;
             bool keep = false;
             if (lk >= bestLK) {                                           // M:8065-8073
@@ -281,6 +289,83 @@ extern "C" int maple_placement_prepare(maple_ctx *c, const maple_placement_param
 // to date (one small launch: waiting rows x changed columns), then runs the reference's traversal over its own row -- the same
 // scores the search would have computed, so the same result (tests/test_hip_search.py compares the two loops).
 // Only on trees without MAT reference frames (one frame: the query needs no re-expression per frame).
+// ---- the rows of maple_placement_ahead by EXPANSION instead of by scoring every branch --------------------------------------
+// The traversal of a placement search (M:7972-8100) visits ~10 000 of the 1 170 000 branches of the 1 000 000-tip tree; scoring
+// every branch for every sample is a hundred times the work that is read.  What a traversal visits depends on the running
+// best -- but only through rules that are MONOTONE in it: with `pathBest` = the best score among a node's ancestors (never
+// above the real running best when the node is visited) and failedPasses reset whenever a score reaches pathBest, every node
+// the reference's traversal visits is visited (the frontier tier of the SPR search, frontier.hip, rests on the same argument).
+// So: all samples of a batch are walked down the tree together, level by level, an item = (sample, node, score of the parent,
+// failedPasses, pathBest); an item scores its branch (one lane, append_walk -- the scoring kernels' arithmetic) into the
+// sample's row and pushes the node's children if the permissive rule lets it.  Columns nobody reached keep PLACE_NO_SCORE; the
+// host traversal that meets one -- the tree changed under the batch in a way that leads it elsewhere -- has the row scored in
+// full (PlaceAhead::fallbacks).
+#define PLACE_NO_SCORE_BITS 0x7ff8dead0badc0deull
+struct PEItem { int32_t r, node, fails, pad; double parentLK, pathBest; };
+struct PECtr { unsigned long long lo, hi, used, cap, overflow, pad[3]; };
+
+__global__ __launch_bounds__(256) void k_pe_fill(unsigned long long *p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = PLACE_NO_SCORE_BITS;
+}
+// the two children of the root for every sample (M:7958-7970); the root vector's score is in the row already ([ld - 1])
+__global__ __launch_bounds__(256) void k_pe_seed(int K, const int32_t *pn, int root, const double *table, long long ld, PEItem *items, PECtr *ctr)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= K) return;
+    const int c0 = pn[4 * root + 2], c1 = pn[4 * root + 3];
+    if (c0 < 0) return;
+    const double lk = table[(long long)r * ld + (ld - 1)];
+    const unsigned long long at = atomicAdd(&ctr->used, 2ull);
+    if (at + 2 > ctr->cap) { ctr->overflow = 1; return; }
+    items[at] = PEItem{r, c0, 0, 0, lk, lk};
+    items[at + 1] = PEItem{r, c1, 0, 0, lk, lk};
+}
+__global__ void k_pe_snap(PECtr *ctr)
+{
+    ctr->lo = ctr->hi;
+    ctr->hi = ctr->used < ctr->cap ? ctr->used : ctr->cap;
+}
+template <bool RV, bool U, bool SS>
+__global__ MAPLE_APPEND_ATTR void k_pe_level(const DevModel *__restrict__ mp, ArenaView av, const int32_t *qList, const int32_t *pn,
+                                             const int32_t *candList, PlaceParams P, double bLen, PEItem *items, PECtr *ctr, double *table,
+                                             long long ld)
+{
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const unsigned long long lo = ctr->lo, hi = ctr->hi;
+    for (unsigned long long i = lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const PEItem it = items[i];
+        const int4 me = *reinterpret_cast<const int4 *>(pn + 4 * (long long)it.node);     // candCol, leafCol, c0, c1
+        double lk = it.parentLK, pathBest = it.pathBest;
+        int fails = it.fails;
+        if (me.x >= 0) {
+            lk = append_walk(c, list_ref(av, candList[me.x]), list_ref(av, qList[it.r]), true, bLen);
+            table[(long long)it.r * ld + me.x] = lk;
+            if (lk >= pathBest) { pathBest = lk; fails = 0; }              // (the reference resets on the REAL best, which is no lower: M:8065)
+            else if (lk < it.parentLK - P.thrConsec) fails++;             // M:8076-8077
+        }
+        const bool within = lk > pathBest - P.thrLK;
+        const bool go = P.strict ? (fails <= P.allowedFails && within) : (fails <= P.allowedFails || within);   // M:8080-8093
+        const bool push = go && me.z >= 0;
+        const unsigned long long pm = __ballot(push);                      // (one atomic per wavefront, not per item)
+        if (push) {
+            const int lane = threadIdx.x & 63, leader = (int)__ffsll((long long)pm) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&ctr->used, 2ull * (unsigned long long)__popcll(pm));
+            base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), leader, 64) << 32) | (uint32_t)__shfl((int)base, leader, 64);
+            const unsigned long long at = base + 2ull * (unsigned long long)__popcll(pm & ((1ull << lane) - 1ull));
+            if (at + 2 > ctr->cap) ctr->overflow = 1;
+            else {
+                items[at] = PEItem{it.r, me.z, fails, 0, lk, pathBest};
+                items[at + 1] = PEItem{it.r, me.w, fails, 0, lk, pathBest};
+            }
+        }
+    }
+}
+
 __global__ void k_ahead_gather(const double *row, const int32_t *cols, int n, double *out)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = row[cols[i]];
@@ -361,6 +446,66 @@ static int ahead_refresh(maple_ctx *c, const double **rowOut)
     return MAPLE_OK;
 }
 
+// rows [0, K) of the table by expansion (see above); false in *done: not possible here (no room for the device copy of the node
+// records) -- the caller scores every branch instead
+static int ahead_expand(maple_ctx *c, const maple_placement_params *pp, bool *done)
+{
+    PlaceAhead &A = *c->ahead;
+    PlaceMeta &M = *c->place;
+    *done = false;
+    const int32_t n = c->dtree.n, K = A.K;
+    if (!M.d_pn.cap) {                                                    // (room for the nodes the batches to come add)
+        HIPCK(c, M.d_pn.reserve_exact((size_t)4 * ((size_t)n + 262144)));
+        HIPCK(c, hipMemcpyAsync(M.d_pn.p, M.h_pn.data(), (size_t)n * sizeof(PlaceMeta::PNode), hipMemcpyHostToDevice, c->stream));
+    }
+    if ((size_t)4 * ((size_t)n + 2 * (size_t)K) + 4 >= M.d_pn.cap) return MAPLE_OK;
+    static_assert(sizeof(PlaceMeta::PNode) == 16, "PNode");
+    const size_t capItems = std::max<size_t>((size_t)1 << 20, (size_t)K * 65536);
+    HIPCK(c, A.dItems.reserve_exact(capItems * sizeof(PEItem)));
+    HIPCK(c, A.dCtr.reserve(sizeof(PECtr) / 8));
+    PECtr h{};
+    h.cap = capItems;
+    HIPCK(c, hipMemcpyAsync(A.dCtr.p, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    k_pe_fill<<<4096, 256, 0, c->stream>>>((unsigned long long *)A.dTable.p, (size_t)K * (size_t)A.ld);
+    HIPCK(c, hipGetLastError());
+    // the root vector's score of every sample, at [ld - 1]
+    const int32_t rootCol = (int32_t)(A.ld - 1), rootVect = M.rootVect;
+    TRY(h2d(c, A.dCols, &rootCol, 1));
+    TRY(h2d(c, A.dLists, &rootVect, 1));
+    TRY(launch_append_queries(c, c->stream, K, A.dQ.p, 1, A.dLists.p, 1, pp->oneMutBLen, A.dTable.p, A.ld, A.dCols.p, nullptr, nullptr,
+                              MAPLE_K_PLACE_SCORE, 0.0, nullptr, nullptr, nullptr, 0, 1, nullptr, true));
+    PlaceParams P{};
+    P.thrLK = pp->thresholdLogLK; P.thrOpt = pp->thresholdLogLKoptimization; P.thrConsec = pp->thresholdLogLKconsecutivePlacement;
+    P.allowedFails = pp->allowedFails; P.strict = pp->strictStopRules;
+    PEItem *items = (PEItem *)A.dItems.p;
+    PECtr *ctr = (PECtr *)A.dCtr.p;
+    k_pe_seed<<<(K + 255) / 256, 256, 0, c->stream>>>(K, M.d_pn.p, c->dtree.root, A.dTable.p, A.ld, items, ctr);
+    HIPCK(c, hipGetLastError());
+    // as many levels as the tree is deep (the placements since the tables were made add at most one level each: counted in)
+    const int levels = M.maxDepth + 8 + (int)std::min<size_t>(4096, M.h_pn.size() - std::min(M.h_pn.size(), M.order.size()));
+    int launchedLevels = 0;
+    for (int l = 0; l < levels; l++) {
+        k_pe_snap<<<1, 1, 0, c->stream>>>(ctr);
+        DISPATCH3(c, k_pe_level, <<<2048, MAPLE_BLOCK, 0, c->stream>>>(c->d_model, view(c), A.dQ.p, M.d_pn.p, M.d_candList.p, P, pp->oneMutBLen, items, ctr,
+                                                                        A.dTable.p, A.ld));
+        launchedLevels++;
+        if ((l & 15) == 15) {                                             // (the host looks every 16 levels whether anything is left)
+            HIPCK(c, hipMemcpyAsync(&h, A.dCtr.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            if (h.used <= h.hi || h.overflow) break;                        // nothing was pushed by the last level that ran
+        }
+    }
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(&h, A.dCtr.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    A.expanded += (long long)std::min(h.used, h.cap);
+    if (c->tuning.verbose > 1)
+        fprintf(stderr, "[maple] rows ahead by expansion: %d samples, %llu items (%.0f per sample), %d levels launched%s, last level %llu items\n", K,
+                (unsigned long long)h.used, (double)h.used / K, launchedLevels, h.overflow ? ", item pool ran over" : "", (unsigned long long)(h.hi - h.lo));
+    *done = true;
+    return MAPLE_OK;
+}
+
 extern "C" int maple_placement_ahead(maple_ctx *c, int32_t nQ, const int32_t *qLists, const maple_placement_params *pp, int32_t *nTaken)
 {
     if (!c || nQ < 0 || (nQ && !qLists) || !pp || !nTaken) return MAPLE_ERR_ARG;
@@ -421,12 +566,17 @@ extern "C" int maple_placement_ahead(maple_ctx *c, int32_t nQ, const int32_t *qL
     const bool dbgA = c->tuning.verbose > 1;
     const auto tA0 = std::chrono::steady_clock::now();
     auto msSince = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count() * 1e-3; };
-    TRY(launch_append_queries(c, c->stream, K, A.dQ.p, nCols, M.d_candList.p, 1, pp->oneMutBLen, A.dTable.p, A.ld, nullptr, nullptr, nullptr,
-                              MAPLE_K_PLACE_SCORE, 0.0));
-    // the root vector's score sits in the column behind the last branch -- a column the first new branch will take: to the end of the row
-    HIPCK(c, hipMemcpy2DAsync(A.dTable.p + (A.ld - 1), (size_t)A.ld * sizeof(double), A.dTable.p + nC, (size_t)A.ld * sizeof(double), sizeof(double),
-                              (size_t)K, hipMemcpyDeviceToDevice, c->stream));
-    if (dbgA) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] rows ahead: %d x %d scores in %.1f ms\n", K, nCols, msSince(tA0)); }
+    bool expanded = false;
+    if (!c->tuning.noAheadExpansion) TRY(ahead_expand(c, pp, &expanded));
+    A.sparse = expanded;
+    if (!expanded) {
+        TRY(launch_append_queries(c, c->stream, K, A.dQ.p, nCols, M.d_candList.p, 1, pp->oneMutBLen, A.dTable.p, A.ld, nullptr, nullptr, nullptr,
+                                  MAPLE_K_PLACE_SCORE, 0.0));
+        // the root vector's score sits in the column behind the last branch -- a column the first new branch will take: to the end of the row
+        HIPCK(c, hipMemcpy2DAsync(A.dTable.p + (A.ld - 1), (size_t)A.ld * sizeof(double), A.dTable.p + nC, (size_t)A.ld * sizeof(double), sizeof(double),
+                                  (size_t)K, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (dbgA) { HIPCK(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "[maple] rows ahead: %d x %d scores %s in %.1f ms\n", K, nCols, expanded ? "(by expansion)" : "(every branch)", msSince(tA0)); }
     const auto tA1 = std::chrono::steady_clock::now();
     if (nL > 0) {
         hipLaunchKernelGGL(k_place_minor, dim3(grid_for((int)std::min<long long>((long long)K * nL, 1 << 30))), dim3(MAPLE_BLOCK), 0,
@@ -438,6 +588,16 @@ extern "C" int maple_placement_ahead(maple_ctx *c, int32_t nQ, const int32_t *qL
     if (dbgA) fprintf(stderr, "[maple] rows ahead: %d x %d minor-sequence tests in %.1f ms\n", K, nL, msSince(tA1));
     A.active = true;
     *nTaken = K;
+    return MAPLE_OK;
+}
+
+extern "C" int maple_placement_ahead_stats(maple_ctx *c, int64_t *out5)
+{
+    if (!c || !out5) return MAPLE_ERR_ARG;
+    for (int i = 0; i < 5; i++) out5[i] = 0;
+    if (!c->ahead) return MAPLE_OK;
+    const PlaceAhead &A = *c->ahead;
+    out5[0] = A.searches; out5[1] = A.fallbacks; out5[2] = A.expanded; out5[3] = A.refreshes; out5[4] = A.refreshedPairs;
     return MAPLE_OK;
 }
 
@@ -654,9 +814,19 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                 oq.bestLK += q; oq.originalLK += q; oq.bestShort += q;
                 oq.slNode += (size_t)q * SL; oq.slLK += (size_t)q * SL; oq.slShort += (size_t)q * SL;
                 if (oq.fromBits) oq.fromBits += (size_t)q * words;
-                place_replay_ptr(c, M, P, hs + (size_t)q * nCols, rootCol, hm + (size_t)q * std::max(nL, 1), nF, oq);
+                place_replay_ptr(c, M, P, hs + (size_t)q * nCols, rootCol, hm + (size_t)q * std::max(nL, 1), nF, oq, ah && ah->sparse);
+                if (ah && oq.status[0] == -7) {
+                    // the traversal asked for a branch the expansion did not reach (the tree changed under the batch and led it
+                    // elsewhere): every branch scored for this sample, as the plain search does, and once more
+                    TRY(launch_append_queries(c, c->stream, 1, ah->dQ.p + ah->next, nC, M.d_candList.p, 1, pp->oneMutBLen,
+                                              ah->dTable.p + (size_t)ah->next * ah->ld, ah->ld, nullptr, nullptr, nullptr, MAPLE_K_PLACE_SCORE, 0.0));
+                    HIPCK(c, hipMemcpyAsync(hs, ah->dTable.p + (size_t)ah->next * ah->ld, (size_t)ah->ld * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                    HIPCK(c, hipStreamSynchronize(c->stream));
+                    ah->fallbacks++;
+                    place_replay_ptr(c, M, P, hs, rootCol, hm, nF, oq, false);
+                }
             }
-            if (ah) { ah->next++; if (ah->next >= ah->K) ah->active = false; }
+            if (ah) { ah->searches++; ah->next++; if (ah->next >= ah->K) ah->active = false; }
         } else {
             HIPCK(c, c->p_f64[0].reserve((size_t)nq * stackCap));         // per-depth lastLK
             HIPCK(c, c->p_i16.reserve((size_t)nq * stackCap));            // per-depth fails

@@ -783,11 +783,16 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
             }
         }
     }
-    if (M.valid) {                                                        // (the host traversal's per-node records follow)
+    if (M.valid) {                                                        // (the host traversal's per-node records follow, and their device copy)
         M.h_pn.resize((size_t)nTotal, PlaceMeta::PNode{-1, -1, -1, -1});
-        for (int i = 0; i < nTouched; i++) {
+        for (int i = 0; i < nTouched && M.valid; i++) {
             const int v = nodes[i];
-            M.h_pn[v] = PlaceMeta::PNode{M.h_candIdx[v], M.h_leafIdx[v], c->h_tree_c0[v], c->h_tree_c1[v]};
+            const PlaceMeta::PNode r{M.h_candIdx[v], M.h_leafIdx[v], c->h_tree_c0[v], c->h_tree_c1[v]};
+            M.h_pn[v] = r;
+            if (M.d_pn.cap) {
+                if ((size_t)4 * v + 3 >= M.d_pn.cap) { M.d_pn.release(); if (ah) ah->active = false; }   // (no room: no expansion until the tables are made again)
+                else { TRY(poke(M.d_pn, (size_t)4 * v, r.candCol)); TRY(poke(M.d_pn, (size_t)4 * v + 1, r.leafCol)); TRY(poke(M.d_pn, (size_t)4 * v + 2, r.c0)); TRY(poke(M.d_pn, (size_t)4 * v + 3, r.c1)); }
+            }
         }
     }
     { const int rc_ = flush_pokes(); if (rc_) return settle_patch(rc_); }

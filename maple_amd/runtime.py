@@ -23,7 +23,7 @@ EXPORTS = [
     "maple_differ_batch", "maple_pass_branch_batch", "maple_shorten_batch", "maple_root_vector_batch",
     "maple_evaluate_placement_batch", "maple_update_partials", "maple_update_partials_touched", "maple_tree_patch", "maple_append_batch_dev", "maple_append_queries_dev", "maple_timing_reset", "maple_timing_read", "maple_timing_read_each",
     "maple_append_algorithmic_bytes", "maple_tree_upload", "maple_spr_search_batch", "maple_minor_batch", "maple_root_prob_batch", "maple_candset_create", "maple_append_candset",
-    "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_placement_ahead", "maple_set_fatal_policy",
+    "maple_minor_candset", "maple_placement_search_batch", "maple_placement_prepare", "maple_placement_ahead", "maple_placement_ahead_stats", "maple_set_fatal_policy",
     "maple_timing_read_kind", "maple_placement_supports_batch",
     "maple_candset_destroy", "maple_spr_search_visited", "maple_arena_compact", "maple_append_queries_argmax_dev", "maple_comm_unique_id", "maple_comm_init", "maple_argmax_allreduce_dev", "maple_tree_rebuild_lists",
 ]
@@ -50,7 +50,7 @@ class MapleSearchParams(C.Structure):
 
 class MapleTuning(C.Structure):
     _fields_ = [("structSize", C.c_uint32), ("wavePerItemMax", C.c_int32), ("placementChunkMax", C.c_int32), ("noCladeScan", C.c_int32), ("verbose", C.c_int32),
-                ("wideOutsideFrontier", C.c_int32), ("denseWideScoring", C.c_int32), ("waveAllBelow", C.c_int32), ("noOverHint", C.c_int32)]
+                ("wideOutsideFrontier", C.c_int32), ("denseWideScoring", C.c_int32), ("waveAllBelow", C.c_int32), ("noOverHint", C.c_int32), ("noAheadExpansion", C.c_int32)]
 
 
 class MaplePlacementParams(C.Structure):
@@ -165,10 +165,11 @@ class Device:
 
     # -- model -------------------------------------------------------------------------------
     def set_tuning(self, *, wave_per_item_max=0, placement_chunk_max=0, no_clade_scan=False, verbose=0, wide_outside_frontier=False,
-                   dense_wide_scoring=False, wave_all_below=0, no_over_hint=False):
+                   dense_wide_scoring=False, wave_all_below=0, no_over_hint=False, no_ahead_expansion=False):
         """How the library schedules its work (never what it computes): see maple_tuning in include/maple_hip.h."""
         t = MapleTuning(C.sizeof(MapleTuning), int(wave_per_item_max), int(placement_chunk_max), int(bool(no_clade_scan)), int(verbose),
-                        int(bool(wide_outside_frontier)), int(bool(dense_wide_scoring)), int(wave_all_below), int(bool(no_over_hint)))
+                        int(bool(wide_outside_frontier)), int(bool(dense_wide_scoring)), int(wave_all_below), int(bool(no_over_hint)),
+                        int(bool(no_ahead_expansion)))
         self._ck(self.lib.maple_set_tuning(self.h, C.byref(t)))
 
     def set_model(self, Q, siteRates=None, usingErrorRate=False, errorRateGlobal=0.0, errorRates=None):
@@ -495,6 +496,11 @@ class Device:
         taken = C.c_int32(0)
         self._ck(self.lib.maple_placement_ahead(self.h, len(q), _ptr(q), C.byref(pp), C.byref(taken)))
         return taken.value
+
+    def placement_ahead_stats(self):
+        out = np.zeros(5, dtype=np.int64)
+        self._ck(self.lib.maple_placement_ahead_stats(self.h, _ptr(out)))
+        return dict(zip(("searches", "fallbacks", "expanded_items", "refreshes", "refreshed_pairs"), (int(x) for x in out)))
 
     def placement_search_batch(self, q_lists, *, oneMutBLen, effectivelyNon0BLen, thresholdLogLK,
                                thresholdLogLKoptimization, thresholdLogLKconsecutivePlacement, allowedFails=5,

@@ -922,24 +922,37 @@ def test_serial_loop_with_rows_made_ahead_equals_the_plain_loop(mode):
     for k, i in enumerate(src):
         dl = data.diffs[int(i)] if k % 25 == 0 else perturb_diffs(data.diffs[int(i)], data.ref, prng)
         new_lists.append(tip_genome_list(dl, dev.ref_idx, **tip_kw))
-    runs = []
-    for ahead in (0, 64):
+    runs, stats = [], []
+    for ahead, expansion in ((0, True), (64, True), (64, False)):
         mark = dev.mark()
+        dev.set_tuning(no_ahead_expansion=not expansion)
+        before = dev.placement_ahead_stats()
         sp = bench.serial_phase(dev, m, new_lists, pkw, ahead=ahead)
+        after = dev.placement_ahead_stats()
+        stats.append({k: after[k] - before[k] for k in after})
         c = sp["cols"]
         n = c["n"]
         probe = np.arange(0, n, 97)
         lists = {name: dev.download(c[name][probe][c[name][probe] >= 0]) for name in ("lower", "tot_up", "up_right")}
         runs.append((sp, lists))
         dev.release(mark)
-    (a, la), (b, lb) = runs
-    assert a["placed"] == b["placed"] and a["placed"] > 300
-    assert a["results"] == b["results"]
-    ca, cb = a["cols"], b["cols"]
-    assert ca["n"] == cb["n"]
-    for name in ("up", "c0", "c1", "dist", "tip"):
-        assert np.array_equal(ca[name][: ca["n"]], cb[name][: cb["n"]]), name
-    for name in la:
-        assert la[name] == lb[name], name
-    assert len(b["times"]["ahead"]) >= 6 and len(a["times"]["ahead"]) == 0
+    dev.set_tuning()
+    (a, la) = runs[0]
+    assert a["placed"] > 300 and len(a["times"]["ahead"]) == 0 and stats[0]["searches"] == 0
+    for (b, lb), st in zip(runs[1:], stats[1:]):
+        assert a["placed"] == b["placed"]
+        assert a["results"] == b["results"]
+        ca, cb = a["cols"], b["cols"]
+        assert ca["n"] == cb["n"]
+        for name in ("up", "c0", "c1", "dist", "tip"):
+            assert np.array_equal(ca[name][: ca["n"]], cb[name][: cb["n"]]), name
+        for name in la:
+            assert la[name] == lb[name], name
+        assert len(b["times"]["ahead"]) >= 6 and st["searches"] == len(new_lists), st
+    # rows by expansion: items were expanded, far fewer than samples x branches, and few rows had to be scored in full after all
+    assert stats[1]["expanded_items"] > 0 and stats[2]["expanded_items"] == 0
+    assert stats[1]["expanded_items"] < 0.5 * len(new_lists) * m.n_nodes
+    assert stats[1]["fallbacks"] <= 0.2 * len(new_lists), stats[1]
+    assert stats[2]["fallbacks"] == 0
+    print("rows made ahead:", stats)
     dev.close()
