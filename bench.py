@@ -595,7 +595,7 @@ def run_leg(args, env):
                  "rank 0; units = items one lane each walked (the few with very long lists go to k_fr_updating_wave, inside the same "
                  "events); algorithmic bytes, counted on the device = the two lists every mergeVectors of an item reads and the one it "
                  "writes (8E + 8A each).  A level lasts as long as its slowest wavefront (64 items, ~1000 dependent list steps): "
-                 "latency-bound, see DESIGN.md"),
+                 "latency-bound, see DESIGN.md section 3"),
             roof(("k_append_queries_lds (whole-tree searches with an error model: every (search, branch) pair walked, a tile of 64 "
                   "candidate lists staged in LDS per 512 queries)") if args.model == "siteerr" else
                  ("k_wit_score (whole-tree searches: the witness filter rules out the branches that score -inf by appendProbNode's own "

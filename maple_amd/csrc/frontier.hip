@@ -330,7 +330,7 @@ __global__ __launch_bounds__(FR_BLOCK) void k_fr_sort_level(ArenaViewS av, DevTr
 // whole lines, the steps found on the merge path, the factors multiplied in walk order as wave_append does: bit-identical, no
 // list word ever waited for, and SLOWER, 204-215 us per 64 items against 168: four wavefronts per SIMD then run out of issue
 // slots -- a binary search per step and 16 lanes' worth of control per item cost ~7 x the instructions of the one-lane walk,
-// which only ever waits.  DESIGN.md section 3T.)
+// which only ever waits.  docs/NOTES.md section 3T.)
 #ifndef FR_CACHED_WAVES
 #define FR_CACHED_WAVES 4             // wavefronts per SIMD the cached-regime kernel is compiled for (128 registers)
 #endif
