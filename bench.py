@@ -754,9 +754,10 @@ def online_update_leg(dev, mirror, data, ref_idx, tip_kw, kw, n_add, round_nodes
                                         "rows_made_ahead": 1e3 * float(np.sum(sp["times"]["ahead"])) / max(1, n_add),
                                         "placement_search": per["search"], "update_partials": per["update"], "tree_patch": per["patch"]},
             "samples_announced_at_a_time": int(ahead),
-            "ahead_note": "maple_placement_ahead: the score rows of the next samples made in one launch of the batch kernel and kept "
-                          "current under maple_tree_patch (the columns whose list changed are scored again for the samples still "
-                          "waiting); the searches' results are those of the plain loop (tests/test_hip_search.py)",
+            "ahead_note": "maple_placement_ahead: the score rows of the next samples made ahead, by an expansion of all of them down the "
+                          "tree under permissive rules (every branch the reference's traversal can visit); maple_tree_patch notes the "
+                          "columns whose list changed, and a search scores those for its own sample before it reads its row; the searches' "
+                          "results are those of the plain loop (tests/test_hip_scale.py)",
             "placement_search_ms_first_third_last_third": [1e3 * float(np.mean(sp["times"]["search"][:third])),
                                                            1e3 * float(np.mean(sp["times"]["search"][-third:]))],
             "nodes_patched_per_sample_mean": float(np.mean(sp["patched"])) if sp["patched"] else 0.0, "nodes_touched": int(len(first)),

@@ -104,12 +104,12 @@ struct PlaceAhead {
     DevBuf<double> dTable;
     double *hRow[2] = {nullptr, nullptr}; size_t capRow = 0;    // doubles per row buffer
     int32_t rowInBuf[2] = {-1, -1};    // which row each buffer holds (or is receiving)
-    double *hPatch = nullptr, *dPatch = nullptr; size_t capPatch = 0;   // page-locked, written by k_ahead_gather (zero copy: a few values)
+    double *hPatch = nullptr, *dPatch = nullptr; size_t capPatch = 0;   // page-locked (bytes), written by the scoring launch of a search: the changed columns' scores, then the changed leaves' flags
     void *hMinor = nullptr; uint8_t *dMinor = nullptr; size_t capMinor = 0;   // [K][ldL] u8 minor-sequence flags, page-locked, written by the kernel (1 MB per row)
     hipStream_t copyStream = nullptr;
     int64_t ld = 0, ldL = 0;           // row strides: the columns at scoring time + room for what the placements add; [ld - 1] = the root vector's score
     DevBuf<int32_t> dQ, dCols, dLists;
-    std::vector<int32_t> dirtyCols, dirtyLeaves;     // columns whose list changed (or that are new) since the rows were last brought up to date
+    std::vector<int32_t> dirtyCols, dirtyLeaves;     // columns whose list changed (or that are new) since the rows were made: every search scores them for its sample
     bool rootDirty = false;            // ... the root vector (its score sits at [ld - 1])
     long long refreshes = 0, refreshedPairs = 0;
     // the rows hold the scores of the branches an expansion under permissive rules reached (placement_host.h); every other column

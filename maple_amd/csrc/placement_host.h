@@ -366,83 +366,65 @@ __global__ MAPLE_APPEND_ATTR void k_pe_level(const DevModel *__restrict__ mp, Ar
     }
 }
 
-__global__ void k_ahead_gather(const double *row, const int32_t *cols, int n, double *out)
-{
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = row[cols[i]];
-}
 
-// Brings the rows of the samples still waiting up to date with the tree (the columns maple_tree_patch noted), and the host copy
-// of the row of the sample searched NOW (A.next): *rowOut = that row in page-locked host memory.
+// The row of the sample searched NOW (A.next), current: *rowOut = that row in page-locked host memory.  The device table keeps
+// the rows as they were made (the tree of the batch's start); what changed since -- every column maple_tree_patch noted since the
+// batch began, a few per placement -- is scored for THIS sample in one launch (1 x changed columns, straight into a page-locked
+// patch buffer) and written over the host copy of its row, which the copy engine brought over during the placement before.
 static int ahead_refresh(maple_ctx *c, const double **rowOut)
 {
     PlaceAhead &A = *c->ahead;
     PlaceMeta &M = *c->place;
-    const int32_t pending = A.K - A.next;
     auto uniq = [](std::vector<int32_t> &v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); };
     uniq(A.dirtyCols); uniq(A.dirtyLeaves);
-    // the row of this sample: on its way since the search before (or copied now)
     int buf = A.rowInBuf[0] == A.next ? 0 : (A.rowInBuf[1] == A.next ? 1 : -1);
     const bool prefetched = buf >= 0;
     if (!prefetched) buf = 0;
-    bool launched = false;
-    size_t nPatch = 0;
-    if (pending > 0 && (!A.dirtyCols.empty() || A.rootDirty)) {
-        std::vector<int32_t> lists(A.dirtyCols.size());
-        for (size_t i = 0; i < lists.size(); i++) lists[i] = M.h_candList[A.dirtyCols[i]];
-        if (A.rootDirty) { A.dirtyCols.push_back((int32_t)(A.ld - 1)); lists.push_back(M.rootVect); }   // (the root's list changed: its new root vector)
-        const size_t n = A.dirtyCols.size();
-        if (n > A.capPatch) {
-            if (A.hPatch) (void)hipHostFree(A.hPatch);
-            A.hPatch = nullptr; A.capPatch = 0;
-            HIPCK(c, hipHostMalloc((void **)&A.hPatch, (n + 1024) * sizeof(double), hipHostMallocDefault));
-            void *dp = nullptr;
-            HIPCK(c, hipHostGetDevicePointer(&dp, A.hPatch, 0));
-            A.dPatch = (double *)dp; A.capPatch = n + 1024;
-        }
-        TRY(h2d(c, A.dCols, A.dirtyCols.data(), n));
-        TRY(h2d(c, A.dLists, lists.data(), n));
-        TRY(launch_append_queries(c, c->stream, pending, A.dQ.p + A.next, (int)n, A.dLists.p, 1, A.pp.oneMutBLen,
-                                  A.dTable.p + (size_t)A.next * A.ld, A.ld, A.dCols.p, nullptr, nullptr, MAPLE_K_PLACE_SCORE, 0.0,
-                                  nullptr, nullptr, nullptr, 0, 1, nullptr, true));
-        if (prefetched) {                                                   // (the copy on its way does not have these columns: patched below)
-            k_ahead_gather<<<1, 256, 0, c->stream>>>(A.dTable.p + (size_t)A.next * A.ld, A.dCols.p, (int)n, A.dPatch);
-            HIPCK(c, hipGetLastError());
-            nPatch = n;
-        }
-        A.refreshes++; A.refreshedPairs += (long long)pending * (long long)n;
-        launched = true;
+    std::vector<int32_t> cols(A.dirtyCols), lists(A.dirtyCols.size());
+    for (size_t i = 0; i < lists.size(); i++) lists[i] = M.h_candList[cols[i]];
+    if (A.rootDirty) { cols.push_back((int32_t)(A.ld - 1)); lists.push_back(M.rootVect); }   // (the root's list changed: its new root vector)
+    const size_t n = cols.size(), nl = A.dirtyLeaves.size();
+    if (n * sizeof(double) + nl + 64 > A.capPatch) {
+        if (A.hPatch) (void)hipHostFree(A.hPatch);
+        A.hPatch = nullptr; A.capPatch = 0;
+        const size_t want = 2 * (n * sizeof(double) + nl) + (1 << 16);
+        HIPCK(c, hipHostMalloc((void **)&A.hPatch, want, hipHostMallocDefault));
+        void *dp = nullptr;
+        HIPCK(c, hipHostGetDevicePointer(&dp, A.hPatch, 0));
+        A.dPatch = (double *)dp; A.capPatch = want;
     }
-    if (!prefetched) {                                                      // (the first row of a batch: copied now, behind the launch above)
+    uint8_t *const hPatchM = (uint8_t *)(A.hPatch + n), *const dPatchM = (uint8_t *)(A.dPatch + n);
+    if (n) {
+        TRY(h2d(c, A.dLists, lists.data(), n));
+        TRY(launch_append_queries(c, c->stream, 1, A.dQ.p + A.next, (int)n, A.dLists.p, 1, A.pp.oneMutBLen, A.dPatch, (long long)n, nullptr,
+                                  nullptr, nullptr, MAPLE_K_PLACE_SCORE, 0.0));
+        A.refreshes++; A.refreshedPairs += (long long)n;
+    }
+    if (nl) {
+        std::vector<int32_t> ll(nl);
+        for (size_t i = 0; i < nl; i++) ll[i] = M.h_leafList[A.dirtyLeaves[i]];
+        TRY(h2d(c, A.dCols, ll.data(), nl));
+        hipLaunchKernelGGL(k_place_minor, dim3(grid_for((int)nl)), dim3(MAPLE_BLOCK), 0, c->stream, c->lRef, view(c), 1, 1, A.dQ.p + A.next, (int)nl,
+                           A.dCols.p, (const int32_t *)nullptr, A.pp.onlyFindIdentical, dPatchM, (long long)nl, (const int32_t *)nullptr);
+        HIPCK(c, hipGetLastError());
+    }
+    if (!prefetched) {                                                      // (the first row of a batch: copied now)
         HIPCK(c, hipMemcpyAsync(A.hRow[buf], A.dTable.p + (size_t)A.next * A.ld, (size_t)A.ld * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         A.rowInBuf[buf] = A.next;
-        launched = true;
     }
-    if (launched) HIPCK(c, hipStreamSynchronize(c->stream));
-    if (pending > 0 && !A.dirtyLeaves.empty()) {
-        const size_t n = A.dirtyLeaves.size();
-        std::vector<int32_t> lists(n);
-        for (size_t i = 0; i < n; i++) lists[i] = M.h_leafList[A.dirtyLeaves[i]];
-        TRY(h2d(c, A.dCols, A.dirtyLeaves.data(), n));
-        TRY(h2d(c, A.dLists, lists.data(), n));
-        hipLaunchKernelGGL(k_place_minor, dim3(grid_for((int)std::min<long long>((long long)pending * (long long)n, 1 << 30))), dim3(MAPLE_BLOCK), 0,
-                           c->stream, c->lRef, view(c), pending, 1, A.dQ.p + A.next, (int)n, A.dLists.p, (const int32_t *)nullptr,
-                           A.pp.onlyFindIdentical, A.dMinor + (size_t)A.next * A.ldL, (long long)A.ldL, A.dCols.p);
-        HIPCK(c, hipGetLastError());
-        HIPCK(c, hipStreamSynchronize(c->stream));
-    }
-    if (prefetched) {
-        HIPCK(c, hipStreamSynchronize(A.copyStream));                       // (long done: it was queued a whole placement ago)
-        for (size_t i = 0; i < nPatch; i++) A.hRow[buf][A.dirtyCols[i]] = A.hPatch[i];
-    }
-    A.dirtyCols.clear(); A.dirtyLeaves.clear(); A.rootDirty = false;
-    // ... and the row of the sample after this one sets off: every column it holds now is current as of this search; what the
-    // placement of this sample changes is patched in when its turn comes
+    if (n || nl || !prefetched) HIPCK(c, hipStreamSynchronize(c->stream));
+    if (prefetched) HIPCK(c, hipStreamSynchronize(A.copyStream));           // (long done: it was queued a whole placement ago)
+    double *const row = A.hRow[buf];
+    for (size_t i = 0; i < n; i++) row[cols[i]] = A.hPatch[i];
+    uint8_t *const mrow = (uint8_t *)A.hMinor + (size_t)A.next * A.ldL;
+    for (size_t i = 0; i < nl; i++) mrow[A.dirtyLeaves[i]] = hPatchM[i];
+    // ... and the row of the sample after this one sets off (the device rows never change: no order to keep)
     if (A.next + 1 < A.K) {
         const int nb = buf ^ 1;
         HIPCK(c, hipMemcpyAsync(A.hRow[nb], A.dTable.p + (size_t)(A.next + 1) * A.ld, (size_t)A.ld * sizeof(double), hipMemcpyDeviceToHost, A.copyStream));
         A.rowInBuf[nb] = A.next + 1;
     }
-    *rowOut = A.hRow[buf];
+    *rowOut = row;
     return MAPLE_OK;
 }
 
@@ -536,7 +518,9 @@ extern "C" int maple_placement_ahead(maple_ctx *c, int32_t nQ, const int32_t *qL
         if (K <= 1 || (int64_t)K * A.ld * 8 <= room) break;
         K = std::max(1, K / 2);
     }
-    HIPCK(c, A.dTable.reserve_exact((size_t)K * (size_t)A.ld));
+    // (with room: the columns grow by ~2 per placement, and a table that grows by a sliver per batch would be 5 GB freed and
+    // allocated again every 512 samples)
+    if ((size_t)K * (size_t)A.ld > A.dTable.cap) HIPCK(c, A.dTable.reserve_exact((size_t)K * ((size_t)A.ld + (size_t)A.ld / 8 + 65536)));
     if ((size_t)A.ld > A.capRow) {
         for (double *&r : A.hRow) { if (r) (void)hipHostFree(r); r = nullptr; }
         A.capRow = 0;
