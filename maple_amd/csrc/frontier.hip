@@ -1181,7 +1181,7 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
         // what the last batch asked for, scaled to this one: with an error model the searches are several times as long as the
         // first guess, and a pool that runs over hands its searches back
         // (after an overflow the asks themselves are too low -- the searches that were handed back stopped asking: twice, not 1.25 x)
-        const double f = (F.lastOverflow ? 2.0 : 1.25) * (double)m / (double)F.needM;
+        const double f = (F.lastOverflow ? 2.0 : 1.25) * std::min(16.0, (double)m / (double)F.needM);   // (a far smaller batch is no measure: capped)
         capU = std::max(capU, (long long)(f * F.needU)); capC = std::max(capC, (long long)(f * F.needC)); capR = std::max(capR, (long long)(f * F.needR));
         capL = std::max(capL, (long long)(f * F.needL));
         // (the words' first guess goes with the arena's mean list length, which moves by an entry when the tree is uploaded again:
@@ -1601,7 +1601,10 @@ int frontier_search(maple_ctx *c, const SearchParams &P, int m, const int32_t *n
                 wideIdx.size(), tw, mw, ts, ms, ns, mxn);
     }
 #endif
-    if (!(anyWide && wide->forceWide)) {                                  // (a batch of whole-tree searches only says nothing about the next full one)
+    // (a batch of whole-tree searches only says nothing about the next full one -- and neither does a handful of searches: the
+    // re-searches of the apply phase, one to 32 at a time, used to leave their asks behind, the next ROUND scaled them up by
+    // 200 000 / 1 and grew the pools to whatever fitted: 1.8 s of hipMalloc in the first search after the moves, round 6)
+    if (!(anyWide && wide->forceWide) && (m >= 1024 || m >= F.needM)) {
         F.needU = (long long)hc.usedU; F.needC = (long long)hc.usedC; F.needR = (long long)hc.usedR; F.needL = (long long)hc.nLists; F.needW = (long long)hc.usedW;
         F.needA = (long long)hc.usedA; F.needM = m; F.lastOverflow = hc.overflow != 0;
     }
