@@ -96,7 +96,8 @@ typedef struct {
                                    NOT sent to the dense tier at once the next time (the library remembers that per node between
                                    calls on one tree: maple_spr_search_batch) */
     int32_t noAheadExpansion;   /* 1: maple_placement_ahead scores EVERY branch for the samples it is given, instead of only the
-                                   branches an expansion under permissive rules reaches (the tests compare the two) */
+                                   branches an expansion under permissive rules reaches (the tests compare the two); 2: the
+                                   expansion stops after six levels (tests: every search then takes the full-row path) */
 } maple_tuning;
 int maple_set_tuning(maple_ctx *ctx, const maple_tuning *t);
 const char *maple_last_error(maple_ctx *ctx);

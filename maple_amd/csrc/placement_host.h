@@ -464,7 +464,10 @@ static int ahead_expand(maple_ctx *c, const maple_placement_params *pp, bool *do
     k_pe_seed<<<(K + 255) / 256, 256, 0, c->stream>>>(K, M.d_pn.p, c->dtree.root, A.dTable.p, A.ld, items, ctr);
     HIPCK(c, hipGetLastError());
     // as many levels as the tree is deep (the placements since the tables were made add at most one level each: counted in)
-    const int levels = M.maxDepth + 8 + (int)std::min<size_t>(4096, M.h_pn.size() - std::min(M.h_pn.size(), M.order.size()));
+    // (noAheadExpansion = 2, for the tests: the expansion stops after six levels, so that nearly every traversal meets a column
+    // without a score and takes the full-row path)
+    const int levels = c->tuning.noAheadExpansion == 2 ? 6
+                       : M.maxDepth + 8 + (int)std::min<size_t>(4096, M.h_pn.size() - std::min(M.h_pn.size(), M.order.size()));
     int launchedLevels = 0;
     for (int l = 0; l < levels; l++) {
         k_pe_snap<<<1, 1, 0, c->stream>>>(ctr);
@@ -551,7 +554,7 @@ extern "C" int maple_placement_ahead(maple_ctx *c, int32_t nQ, const int32_t *qL
     const auto tA0 = std::chrono::steady_clock::now();
     auto msSince = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count() * 1e-3; };
     bool expanded = false;
-    if (!c->tuning.noAheadExpansion) TRY(ahead_expand(c, pp, &expanded));
+    if (c->tuning.noAheadExpansion != 1) TRY(ahead_expand(c, pp, &expanded));
     A.sparse = expanded;
     if (!expanded) {
         TRY(launch_append_queries(c, c->stream, K, A.dQ.p, nCols, M.d_candList.p, 1, pp->oneMutBLen, A.dTable.p, A.ld, nullptr, nullptr, nullptr,

@@ -169,7 +169,7 @@ class Device:
         """How the library schedules its work (never what it computes): see maple_tuning in include/maple_hip.h."""
         t = MapleTuning(C.sizeof(MapleTuning), int(wave_per_item_max), int(placement_chunk_max), int(bool(no_clade_scan)), int(verbose),
                         int(bool(wide_outside_frontier)), int(bool(dense_wide_scoring)), int(wave_all_below), int(bool(no_over_hint)),
-                        int(bool(no_ahead_expansion)))
+                        int(no_ahead_expansion))
         self._ck(self.lib.maple_set_tuning(self.h, C.byref(t)))
 
     def set_model(self, Q, siteRates=None, usingErrorRate=False, errorRateGlobal=0.0, errorRates=None):
