@@ -98,6 +98,8 @@ typedef struct {
     int32_t noAheadExpansion;   /* 1: maple_placement_ahead scores EVERY branch for the samples it is given, instead of only the
                                    branches an expansion under permissive rules reaches (the tests compare the two); 2: the
                                    expansion stops after six levels (tests: every search then takes the full-row path) */
+    int32_t noAheadSpeculation; /* 1: the traversal of the next announced sample (maple_placement_ahead) is not run ahead of its search by a
+                                   host thread of the library while the caller places the sample before it */
 } maple_tuning;
 int maple_set_tuning(maple_ctx *ctx, const maple_tuning *t);
 const char *maple_last_error(maple_ctx *ctx);
@@ -326,7 +328,8 @@ int maple_placement_prepare(maple_ctx *ctx, const maple_placement_params *params
 int maple_placement_ahead(maple_ctx *ctx, int32_t nQ, const int32_t *qLists, const maple_placement_params *params, int32_t *nTaken);
 /* What the rows made ahead were used for since the context was created: out5 = searches that took a row, those among them whose
  * row had to be scored in full after all (the traversal asked for a branch the expansion had not reached), items the
- * expansions scored, launches that brought waiting rows up to date, (row, column) pairs they scored. */
+ * expansions scored, traversals made ahead of their search that were used, and that were dropped (the placement in between
+ * touched a node they had visited). */
 int maple_placement_ahead_stats(maple_ctx *ctx, int64_t *out5);
 int maple_placement_search_batch(maple_ctx *ctx, int32_t nQ, const int32_t *qLists, const maple_placement_params *params,
                                  int32_t *bestNode, double *bestScore, double *blen3, int32_t *bestDiffs,

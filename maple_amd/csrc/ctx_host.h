@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace maple;
@@ -116,9 +117,33 @@ struct PlaceAhead {
     // holds PLACE_NO_SCORE, and a traversal that asks for one has the whole row scored first (counted)
     bool sparse = false;
     long long fallbacks = 0, expanded = 0, searches = 0;
+    // The traversal of the NEXT announced sample, run by a host thread while the library's caller is busy with the sample just
+    // searched (refinement, tree edit, updatePartials): speculative -- made on the tree as it is BEFORE that sample's placement --
+    // and used only if the placement's patch touches no node the traversal visited (placement_host.h).
+    struct Spec {
+        std::thread th;
+        int32_t row = -1, id = 0, status = -1, buf = 0;     // the row it is for (-1: none), its epoch in visitEpoch, 0 = outputs usable
+        std::vector<int32_t> cols, lists, leafCols, leafLists;   // the changed columns as of its start
+        std::vector<int32_t> hi; std::vector<double> hf; std::vector<uint8_t> hb;   // the traversal's outputs (PlaceOut over these)
+        std::vector<int32_t> touched;                        // nodes patched since it set off
+        bool rootTouched = false;
+    } spec;
+    std::vector<int32_t> visitEpoch;   // per node: the epoch of the last speculative traversal that visited it
+    int32_t specSeq = 0;
+    hipStream_t specStream = nullptr;
+    DevBuf<int32_t> dSpecLists, dSpecLeaf;
+    double *hSpecPatch = nullptr, *dSpecPatch = nullptr; size_t capSpecPatch = 0;   // bytes
+    long long specUsed = 0, specDropped = 0;
+    void join() { if (spec.th.joinable()) spec.th.join(); }
     DevBuf<uint8_t> dItems; DevBuf<unsigned long long> dCtr;
     void release()
     {
+        join();
+        if (hSpecPatch) (void)hipHostFree(hSpecPatch);
+        hSpecPatch = nullptr; dSpecPatch = nullptr; capSpecPatch = 0;
+        if (specStream) (void)hipStreamDestroy(specStream);
+        specStream = nullptr;
+        dSpecLists.release(); dSpecLeaf.release();
         for (double *&r : hRow) { if (r) (void)hipHostFree(r); r = nullptr; }
         if (hPatch) (void)hipHostFree(hPatch);
         if (hMinor) (void)hipHostFree(hMinor);

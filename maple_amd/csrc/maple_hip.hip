@@ -1074,7 +1074,7 @@ extern "C" int maple_set_model(maple_ctx *c, const double *Q16, const double *si
     DevModel &m = c->dm;
     const int lRef = c->lRef;
     c->h_over_hint.clear();                                           // (which searches run over the budget is a property of the model too)
-    if (c->ahead) c->ahead->active = false;                             // (rows scored under another model)
+    if (c->ahead) { c->ahead->join(); c->ahead->spec.row = -1; c->ahead->active = false; }   // (rows scored under another model)
     for (int i = 0; i < 16; i++) m.Q[i] = Q16[i];
     m.useRateVariation = siteRates ? 1 : 0;
     m.usingErrorRate = usingErrorRate ? 1 : 0;
@@ -1310,6 +1310,7 @@ static int grid_for(int n);
 // replaced list keeps its room until then.
 extern "C" int maple_arena_compact(maple_ctx *c, int64_t nLive, const int32_t *live, int32_t *newIds)
 {
+    if (c && c->ahead) { c->ahead->join(); c->ahead->spec.row = -1; c->ahead->active = false; }
     if (!c || nLive < 0 || (nLive && (!live || !newIds))) return MAPLE_ERR_ARG;
     HIPCK(c, hipSetDevice(c->device));
     TRY(settle(c));

@@ -163,7 +163,8 @@ static int place_meta(maple_ctx *c, double effNon0)
 // sparse: the row holds PLACE_NO_SCORE in the columns nobody scored (rows by expansion): a visit that needs one ends the
 // traversal with status -7 and the caller scores the whole row
 static void place_replay_ptr(const maple_ctx *c, const PlaceMeta &M, const PlaceParams &P, const double *sc, int rootCol,
-                             const uint8_t *mn, int nF, const PlaceOut &o, bool sparse = false)
+                             const uint8_t *mn, int nF, const PlaceOut &o, bool sparse = false, int32_t *visitEpoch = nullptr,
+                             int32_t epoch = 0)
 {
     const int32_t root = c->dtree.root;
     const PlaceMeta::PNode *const pn = M.h_pn.data();
@@ -177,6 +178,7 @@ static void place_replay_ptr(const maple_ctx *c, const PlaceMeta &M, const Place
     int bestNode = root;
     struct It { int32_t node; int32_t fails; double parentLK; };
     std::vector<It> st;
+    if (visitEpoch) visitEpoch[root] = epoch;                             // (a speculative traversal notes what it read: ahead_spec_*)
     if (!P.supportOnly && pn[root].leafCol >= 0 && mn[pn[root].leafCol] == 1) { status = 1; minorNode = root; nAppend = 0; }
     if (pn[root].c0 >= 0) { st.push_back(It{pn[root].c0, 0, bestLK}); st.push_back(It{pn[root].c1, 0, bestLK}); }
     while (!st.empty() && status == 0) {                                  // M:7972-8100
@@ -184,6 +186,7 @@ static void place_replay_ptr(const maple_ctx *c, const PlaceMeta &M, const Place
         st.pop_back();
         const int t1 = it.node;
         const PlaceMeta::PNode me = pn[t1];                                // (asked for when the node was pushed)
+        if (visitEpoch) visitEpoch[t1] = epoch;
         const int candCol = me.candCol, leafCol = me.leafCol;
         // (the visit after this one -- unless this node pushes children -- is the node now on top: its record is here since it
         // was pushed; its score and its minor flag are asked for now, a visit ahead)
@@ -367,14 +370,124 @@ __global__ MAPLE_APPEND_ATTR void k_pe_level(const DevModel *__restrict__ mp, Ar
 }
 
 
+// ---- the traversal of the next announced sample, ahead of its search (PlaceAhead::Spec) -------------------------------------
+// one lane per changed column: out[k] = appendProbNode(list[k], the sample's list) -- no tile counters, no timing slots: nothing
+// of the context is touched, the launch comes from the speculating thread
+template <bool RV, bool U, bool SS>
+__global__ MAPLE_APPEND_ATTR void k_ahead_cols(const DevModel *__restrict__ mp, ArenaView av, const int32_t *qList, int n, const int32_t *lists,
+                                               double bLen, double *out)
+{
+    __shared__ Lds lds;
+    const DevModel &m = *mp;
+    stage_model(m, lds);
+    Ctx<RV, U, SS> c(m, lds);
+    const ListRef q = list_ref(av, qList[0]);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) out[k] = append_walk(c, list_ref(av, lists[k]), q, true, bLen);
+}
+#define MAPLE_SPEC_CAP 32768             // changed columns / leaves a speculative traversal takes (more: no speculation)
+static void ahead_spec_body(maple_ctx *c, PlaceParams P, double bLen, int onlyIdentical, bool rv_, bool u_, bool ss_)
+{
+    PlaceAhead &A = *c->ahead;
+    PlaceAhead::Spec &S = A.spec;
+    const PlaceMeta &M = *c->place;
+    S.status = -100;
+    if (hipSetDevice(c->device) != hipSuccess) return;
+    const size_t n = S.cols.size(), nl = S.leafCols.size();
+    uint8_t *const hPatchM = (uint8_t *)(A.hSpecPatch + n), *const dPatchM = (uint8_t *)(A.dSpecPatch + n);
+    if (n) {
+        if (hipMemcpyAsync(A.dSpecLists.p, S.lists.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, A.specStream) != hipSuccess) return;
+        const int grid = (int)std::min<size_t>(1024, (n + MAPLE_BLOCK - 1) / MAPLE_BLOCK);
+#define SPEC_COLS(RV, U, SS) k_ahead_cols<RV, U, SS><<<grid, MAPLE_BLOCK, 0, A.specStream>>>(c->d_model, view(c), A.dQ.p + S.row, (int)n, A.dSpecLists.p, bLen, A.dSpecPatch)
+        if (!rv_ && !u_) SPEC_COLS(false, false, false);
+        else if (rv_ && !u_) SPEC_COLS(true, false, false);
+        else if (!rv_ && u_ && !ss_) SPEC_COLS(false, true, false);
+        else if (!rv_ && u_ && ss_) SPEC_COLS(false, true, true);
+        else if (rv_ && u_ && !ss_) SPEC_COLS(true, true, false);
+        else SPEC_COLS(true, true, true);
+#undef SPEC_COLS
+    }
+    if (nl) {
+        if (hipMemcpyAsync(A.dSpecLeaf.p, S.leafLists.data(), nl * sizeof(int32_t), hipMemcpyHostToDevice, A.specStream) != hipSuccess) return;
+        hipLaunchKernelGGL(k_place_minor, dim3((int)std::min<size_t>(1024, (nl + MAPLE_BLOCK - 1) / MAPLE_BLOCK)), dim3(MAPLE_BLOCK), 0, A.specStream, c->lRef,
+                           view(c), 1, 1, A.dQ.p + S.row, (int)nl, A.dSpecLeaf.p, (const int32_t *)nullptr, onlyIdentical, dPatchM, (long long)nl,
+                           (const int32_t *)nullptr);
+    }
+    if (hipGetLastError() != hipSuccess) return;
+    if (hipStreamSynchronize(A.specStream) != hipSuccess) return;
+    if (hipStreamSynchronize(A.copyStream) != hipSuccess) return;         // (the row itself: set off by the search before)
+    double *const row = A.hRow[S.buf];
+    for (size_t i = 0; i < n; i++) row[S.cols[i]] = A.hSpecPatch[i];
+    uint8_t *const mrow = (uint8_t *)A.hMinor + (size_t)S.row * A.ldL;
+    for (size_t i = 0; i < nl; i++) mrow[S.leafCols[i]] = hPatchM[i];
+    const size_t SL = MAPLE_PLACE_SHORTLIST;
+    S.hi.assign(6 + SL, 0); S.hf.assign(2 + SL, 0.0); S.hb.assign(1 + SL, 0);
+    PlaceOut o;
+    int32_t *ib = S.hi.data();
+    o.status = ib; o.minorNode = ib + 1; o.bestNode = ib + 2; o.nAppend = ib + 3; o.missed = ib + 4; o.nShort = ib + 5; o.slNode = ib + 6;
+    o.bestLK = S.hf.data(); o.originalLK = S.hf.data() + 1; o.slLK = S.hf.data() + 2;
+    o.bestShort = S.hb.data(); o.slShort = S.hb.data() + 1;
+    o.fromBits = nullptr;
+    place_replay_ptr(c, M, P, row, (int)(A.ld - 1), mrow, 1, o, A.sparse, A.visitEpoch.data(), S.id);
+    S.status = o.status[0] == -7 ? -7 : 0;
+}
+// main thread, at the end of a search that took a row: the traversal of the sample after it sets off
+static void ahead_spec_kick(maple_ctx *c, const PlaceParams &P, const maple_placement_params *pp)
+{
+    PlaceAhead &A = *c->ahead;
+    const PlaceMeta &M = *c->place;
+    A.join();
+    A.spec.row = -1;
+    if (!A.active || c->tuning.noAheadSpeculation || A.rootDirty || !A.specStream || !A.hSpecPatch) return;
+    const int buf = A.rowInBuf[0] == A.next ? 0 : (A.rowInBuf[1] == A.next ? 1 : -1);
+    if (buf < 0) return;                                                  // (its row is not on its way)
+    auto uniq = [](std::vector<int32_t> &v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); };
+    uniq(A.dirtyCols); uniq(A.dirtyLeaves);
+    if (A.dirtyCols.size() > MAPLE_SPEC_CAP || A.dirtyLeaves.size() > MAPLE_SPEC_CAP) return;
+    PlaceAhead::Spec &S = A.spec;
+    S.cols = A.dirtyCols; S.leafCols = A.dirtyLeaves;
+    S.lists.resize(S.cols.size()); S.leafLists.resize(S.leafCols.size());
+    for (size_t i = 0; i < S.cols.size(); i++) S.lists[i] = M.h_candList[S.cols[i]];
+    for (size_t i = 0; i < S.leafCols.size(); i++) S.leafLists[i] = M.h_leafList[S.leafCols[i]];
+    S.touched.clear(); S.rootTouched = false;
+    S.row = A.next; S.buf = buf; S.id = ++A.specSeq; S.status = -1;
+    if (A.visitEpoch.size() < M.h_pn.size()) A.visitEpoch.resize(M.h_pn.size(), 0);
+    S.th = std::thread(ahead_spec_body, c, P, pp->oneMutBLen, (int)pp->onlyFindIdentical, c->dm.useRateVariation != 0, c->dm.usingErrorRate != 0,
+                       c->dm.errorRateSiteSpecific != 0);
+}
+// ... and at the start of the next search: is the traversal made for this row good as it is?
+static bool ahead_spec_usable(maple_ctx *c)
+{
+    PlaceAhead &A = *c->ahead;
+    A.join();
+    PlaceAhead::Spec &S = A.spec;
+    if (S.row != A.next) return false;
+    bool ok = S.status == 0 && !S.rootTouched && !A.rootDirty;
+    for (size_t i = 0; ok && i < S.touched.size(); i++) {
+        const int32_t v = S.touched[i];
+        if ((size_t)v < A.visitEpoch.size() && A.visitEpoch[v] == S.id) ok = false;   // (the placement in between changed a node it had visited)
+    }
+    if (ok) A.specUsed++; else A.specDropped++;
+    return ok;
+}
+
 // The row of the sample searched NOW (A.next), current: *rowOut = that row in page-locked host memory.  The device table keeps
 // the rows as they were made (the tree of the batch's start); what changed since -- every column maple_tree_patch noted since the
 // batch began, a few per placement -- is scored for THIS sample in one launch (1 x changed columns, straight into a page-locked
 // patch buffer) and written over the host copy of its row, which the copy engine brought over during the placement before.
-static int ahead_refresh(maple_ctx *c, const double **rowOut)
+static int ahead_refresh(maple_ctx *c, const double **rowOut, bool rowIsCurrent = false)
 {
     PlaceAhead &A = *c->ahead;
     PlaceMeta &M = *c->place;
+    if (rowIsCurrent) {                                                    // (a speculative traversal has used the row already: only what follows it)
+        const int buf = A.spec.buf;
+        if (A.next + 1 < A.K) {
+            const int nb = buf ^ 1;
+            HIPCK(c, hipMemcpyAsync(A.hRow[nb], A.dTable.p + (size_t)(A.next + 1) * A.ld, (size_t)A.ld * sizeof(double), hipMemcpyDeviceToHost, A.copyStream));
+            A.rowInBuf[nb] = A.next + 1;
+        }
+        *rowOut = A.hRow[buf];
+        return MAPLE_OK;
+    }
     auto uniq = [](std::vector<int32_t> &v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); };
     uniq(A.dirtyCols); uniq(A.dirtyLeaves);
     int buf = A.rowInBuf[0] == A.next ? 0 : (A.rowInBuf[1] == A.next ? 1 : -1);
@@ -499,6 +612,8 @@ extern "C" int maple_placement_ahead(maple_ctx *c, int32_t nQ, const int32_t *qL
     TRY(need_model(c));
     if (!c->tree_set) return fail(c, MAPLE_ERR_STATE, "maple_tree_upload has not been called");
     if (c->ahead) {
+        c->ahead->join();
+        c->ahead->spec.row = -1;
         if (c->ahead->copyStream) HIPCK(c, hipStreamSynchronize(c->ahead->copyStream));
         c->ahead->active = false;
     }
@@ -542,6 +657,15 @@ extern "C" int maple_placement_ahead(maple_ctx *c, int32_t nQ, const int32_t *qL
     if (hipHostGetDevicePointer(&dp, A.hMinor, 0) != hipSuccess || !dp) { (void)hipGetLastError(); return MAPLE_OK; }   // (no zero copy: no rows ahead)
     A.dMinor = (uint8_t *)dp;
     if (!A.copyStream) HIPCK(c, hipStreamCreateWithFlags(&A.copyStream, hipStreamNonBlocking));
+    if (!A.specStream) {
+        HIPCK(c, hipStreamCreateWithFlags(&A.specStream, hipStreamNonBlocking));
+        HIPCK(c, A.dSpecLists.reserve_exact(MAPLE_SPEC_CAP)); HIPCK(c, A.dSpecLeaf.reserve_exact(MAPLE_SPEC_CAP));
+        A.capSpecPatch = (size_t)MAPLE_SPEC_CAP * (sizeof(double) + 1) + 64;
+        HIPCK(c, hipHostMalloc((void **)&A.hSpecPatch, A.capSpecPatch, hipHostMallocDefault));
+        void *dps = nullptr;
+        HIPCK(c, hipHostGetDevicePointer(&dps, A.hSpecPatch, 0));
+        A.dSpecPatch = (double *)dps;
+    }
     A.K = K; A.next = 0; A.pp = *pp;
     A.rowInBuf[0] = A.rowInBuf[1] = -1;
     A.q.assign(qLists, qLists + K);
@@ -584,7 +708,7 @@ extern "C" int maple_placement_ahead_stats(maple_ctx *c, int64_t *out5)
     for (int i = 0; i < 5; i++) out5[i] = 0;
     if (!c->ahead) return MAPLE_OK;
     const PlaceAhead &A = *c->ahead;
-    out5[0] = A.searches; out5[1] = A.fallbacks; out5[2] = A.expanded; out5[3] = A.refreshes; out5[4] = A.refreshedPairs;
+    out5[0] = A.searches; out5[1] = A.fallbacks; out5[2] = A.expanded; out5[3] = A.specUsed; out5[4] = A.specDropped;
     return MAPLE_OK;
 }
 
@@ -630,6 +754,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                                  int32_t *nAppend, int32_t *status, SupportsOut *sup)
 {
     if (nQ == 0) return MAPLE_OK;
+    if (c->ahead) c->ahead->join();                                       // (a speculative traversal reads the tables this call may rebuild)
     const auto tEntry = std::chrono::steady_clock::now();
     int32_t *const bestDiffs = bestDiffsOut;
     HIPCK(c, hipSetDevice(c->device));
@@ -720,7 +845,8 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                                 && memcmp(&c->ahead->pp, pp, sizeof(maple_placement_params)) == 0
                                 && (int64_t)nCols < c->ahead->ld - 1 && (int64_t)nL <= c->ahead->ldL) ? c->ahead : nullptr;
         const double *aheadRow = nullptr;
-        if (ah) TRY(ahead_refresh(c, &aheadRow));
+        const bool specUse = ah && ahead_spec_usable(c);                   // (the traversal was made while the sample before was being placed)
+        if (ah) TRY(ahead_refresh(c, &aheadRow, specUse));
         if (dbg) fprintf(stderr, "[maple]   %s\n", ah ? "rows made ahead: brought up to date" : "scoring launch");
         DevBuf<int32_t> &dU = c->p_i32[0];
         if (!ah) TRY(h2d(c, dU, U.data(), U.size()));
@@ -794,7 +920,8 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
             std::vector<double> stL(stackCap);
             std::vector<int16_t> stF(stackCap);
             std::vector<uint32_t> bits(words);
-            for (int q = 0; q < nq; q++) {
+            if (specUse) { hi = ah->spec.hi; hf = ah->spec.hf; hb = ah->spec.hb; }
+            for (int q = 0; q < nq && !specUse; q++) {
                 // per-query outputs are addressed [.. + q] inside, the work arrays as lane 0 of 1
                 PlaceOut oq = o;
                 oq.status += q; oq.minorNode += q; oq.bestNode += q; oq.nAppend += q; oq.missed += q; oq.nShort += q;
@@ -813,7 +940,11 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                     place_replay_ptr(c, M, P, hs, rootCol, hm, nF, oq, false);
                 }
             }
-            if (ah) { ah->searches++; ah->next++; if (ah->next >= ah->K) ah->active = false; }
+            if (ah) {
+                ah->searches++; ah->next++;
+                if (ah->next >= ah->K) ah->active = false;
+                ahead_spec_kick(c, P, pp);                                  // (the next announced sample's traversal sets off)
+            }
         } else {
             HIPCK(c, c->p_f64[0].reserve((size_t)nq * stackCap));         // per-depth lastLK
             HIPCK(c, c->p_i16.reserve((size_t)nq * stackCap));            // per-depth fails

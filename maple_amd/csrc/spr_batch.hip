@@ -394,6 +394,7 @@ extern "C" int maple_tree_upload(maple_ctx *c, int32_t n, int32_t root, const in
         || !totUp || !mutList)
         return MAPLE_ERR_ARG;
     HIPCK(c, hipSetDevice(c->device));
+    if (c->ahead) { c->ahead->join(); c->ahead->spec.row = -1; c->ahead->active = false; }
     const bool dbgU = c->tuning.verbose != 0;
     auto tU0 = std::chrono::steady_clock::now();
     auto lapU = [&](const char *what) {
@@ -601,6 +602,7 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
         return MAPLE_ERR_ARG;
     if (!c->tree_set) return fail(c, MAPLE_ERR_STATE, "maple_tree_upload has not been called");
     HIPCK(c, hipSetDevice(c->device));
+    if (c->ahead) c->ahead->join();                                       // (a speculative traversal reads the per-node records this call rewrites)
     const int32_t nOld = (int32_t)c->h_tree_up.size(), root = c->dtree.root;
     if (nTotal < nOld) return fail(c, MAPLE_ERR_ARG, "a patch cannot remove nodes (%d < %d)", nTotal, nOld);
     const int32_t nl = (int32_t)c->h_n_ent.size();
@@ -744,6 +746,8 @@ extern "C" int maple_tree_patch(maple_ctx *c, int32_t nTotal, int32_t nTouched, 
     // (score rows made ahead, maple_placement_ahead: the columns whose list changes here, and the new ones, are scored again for
     // the samples still waiting before the next of them is searched)
     PlaceAhead *const ah = (c->ahead && c->ahead->active) ? c->ahead : nullptr;
+    if (ah && ah->spec.row == ah->next)                                   // (what the traversal made ahead for the next sample must not have visited)
+        for (int i = 0; i < nTouched; i++) { ah->spec.touched.push_back(nodes[i]); if (nodes[i] == root) ah->spec.rootTouched = true; }
     auto dirty_col = [&](int col) { if (ah) { if ((int64_t)col >= ah->ld - 1) ah->active = false; else ah->dirtyCols.push_back(col); } };
     auto dirty_leaf = [&](int lc) { if (ah) { if ((int64_t)lc >= ah->ldL) ah->active = false; else ah->dirtyLeaves.push_back(lc); } };
     for (int i = 0; i < nTouched && M.valid; i++) {

@@ -50,7 +50,7 @@ class MapleSearchParams(C.Structure):
 
 class MapleTuning(C.Structure):
     _fields_ = [("structSize", C.c_uint32), ("wavePerItemMax", C.c_int32), ("placementChunkMax", C.c_int32), ("noCladeScan", C.c_int32), ("verbose", C.c_int32),
-                ("wideOutsideFrontier", C.c_int32), ("denseWideScoring", C.c_int32), ("waveAllBelow", C.c_int32), ("noOverHint", C.c_int32), ("noAheadExpansion", C.c_int32)]
+                ("wideOutsideFrontier", C.c_int32), ("denseWideScoring", C.c_int32), ("waveAllBelow", C.c_int32), ("noOverHint", C.c_int32), ("noAheadExpansion", C.c_int32), ("noAheadSpeculation", C.c_int32)]
 
 
 class MaplePlacementParams(C.Structure):
@@ -165,11 +165,11 @@ class Device:
 
     # -- model -------------------------------------------------------------------------------
     def set_tuning(self, *, wave_per_item_max=0, placement_chunk_max=0, no_clade_scan=False, verbose=0, wide_outside_frontier=False,
-                   dense_wide_scoring=False, wave_all_below=0, no_over_hint=False, no_ahead_expansion=False):
+                   dense_wide_scoring=False, wave_all_below=0, no_over_hint=False, no_ahead_expansion=False, no_ahead_speculation=False):
         """How the library schedules its work (never what it computes): see maple_tuning in include/maple_hip.h."""
         t = MapleTuning(C.sizeof(MapleTuning), int(wave_per_item_max), int(placement_chunk_max), int(bool(no_clade_scan)), int(verbose),
                         int(bool(wide_outside_frontier)), int(bool(dense_wide_scoring)), int(wave_all_below), int(bool(no_over_hint)),
-                        int(no_ahead_expansion))
+                        int(no_ahead_expansion), int(bool(no_ahead_speculation)))
         self._ck(self.lib.maple_set_tuning(self.h, C.byref(t)))
 
     def set_model(self, Q, siteRates=None, usingErrorRate=False, errorRateGlobal=0.0, errorRates=None):
@@ -500,7 +500,7 @@ class Device:
     def placement_ahead_stats(self):
         out = np.zeros(5, dtype=np.int64)
         self._ck(self.lib.maple_placement_ahead_stats(self.h, _ptr(out)))
-        return dict(zip(("searches", "fallbacks", "expanded_items", "refreshes", "refreshed_pairs"), (int(x) for x in out)))
+        return dict(zip(("searches", "fallbacks", "expanded_items", "traversals_ahead_used", "traversals_ahead_dropped"), (int(x) for x in out)))
 
     def placement_search_batch(self, q_lists, *, oneMutBLen, effectivelyNon0BLen, thresholdLogLK,
                                thresholdLogLKoptimization, thresholdLogLKconsecutivePlacement, allowedFails=5,

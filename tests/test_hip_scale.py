@@ -923,9 +923,10 @@ def test_serial_loop_with_rows_made_ahead_equals_the_plain_loop(mode):
         dl = data.diffs[int(i)] if k % 25 == 0 else perturb_diffs(data.diffs[int(i)], data.ref, prng)
         new_lists.append(tip_genome_list(dl, dev.ref_idx, **tip_kw))
     runs, stats = [], []
-    for ahead, expansion in ((0, 0), (64, 0), (64, 1), (64, 2)):             # plain loop; rows by expansion; every branch; expansion cut short
+    # plain loop; rows by expansion; every branch; expansion cut short; rows by expansion without the traversals made ahead
+    for ahead, expansion, spec in ((0, 0, True), (64, 0, True), (64, 1, True), (64, 2, True), (64, 0, False)):
         mark = dev.mark()
-        dev.set_tuning(no_ahead_expansion=expansion)
+        dev.set_tuning(no_ahead_expansion=expansion, no_ahead_speculation=not spec)
         before = dev.placement_ahead_stats()
         sp = bench.serial_phase(dev, m, new_lists, pkw, ahead=ahead)
         after = dev.placement_ahead_stats()
@@ -956,5 +957,10 @@ def test_serial_loop_with_rows_made_ahead_equals_the_plain_loop(mode):
     assert stats[2]["fallbacks"] == 0
     # ... and with the expansion cut short after six levels nearly every search has its row scored in full after all: same results
     assert stats[3]["fallbacks"] > 0.5 * len(new_lists), stats[3]
+    # the traversal of the next sample made by a host thread during the placement before it: used where the placement touched
+    # nothing it had visited, dropped (and made again) where it did -- and never made when switched off
+    assert stats[1]["traversals_ahead_used"] > 0.3 * len(new_lists), stats[1]
+    assert stats[1]["traversals_ahead_used"] + stats[1]["traversals_ahead_dropped"] <= len(new_lists)
+    assert stats[4]["traversals_ahead_used"] == 0 and stats[4]["traversals_ahead_dropped"] == 0
     print("rows made ahead:", stats)
     dev.close()
