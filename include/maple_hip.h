@@ -323,6 +323,10 @@ int maple_placement_prepare(maple_ctx *ctx, const maple_placement_params *params
  * tables; 0 on a tree with MAT reference frames, where the call changes nothing); announce the rest when those are done.
  * The rows hold the branches an expansion of all announced samples under permissive rules reaches (every branch the
  * reference's traversal can visit on the tree as it is then; maple_tuning.noAheadExpansion: every branch of the tree).
+ * While rows live, the library runs the traversal of the NEXT announced sample in a host thread of its own as soon as a search
+ * has finished its own -- on library-owned memory only, joined at the start of maple_tree_patch and of every call that could
+ * change what it reads; it is used if the patch in between touched no node it had visited (maple_tuning.noAheadSpeculation
+ * switches it off).
  * The rows are dropped by anything that renumbers the columns or changes what a score means (maple_tree_upload,
  * maple_set_model, other parameters, a release of the samples' lists), and by a search of any other sample. */
 int maple_placement_ahead(maple_ctx *ctx, int32_t nQ, const int32_t *qLists, const maple_placement_params *params, int32_t *nTaken);

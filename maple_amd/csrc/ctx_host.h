@@ -103,8 +103,11 @@ struct PlaceAhead {
     // while the sample before it is being placed (hRow: two page-locked rows, taking turns), and what the placement in between
     // changed -- a handful of columns -- is patched into it from `hPatch`
     DevBuf<double> dTable;
-    double *hRow[2] = {nullptr, nullptr}; size_t capRow = 0;    // doubles per row buffer
-    int32_t rowInBuf[2] = {-1, -1};    // which row each buffer holds (or is receiving)
+    double *hRow[3] = {nullptr, nullptr, nullptr}; size_t capRow = 0;    // doubles per row buffer (this sample's, the next one's -- a traversal
+                                       // made ahead may be reading it --, the one after that on its way)
+    int32_t rowInBuf[3] = {-1, -1, -1};    // which row each buffer holds (or is receiving)
+    int buf_of(int32_t row) const { for (int b = 0; b < 3; b++) if (rowInBuf[b] == row) return b; return -1; }
+    int free_buf(int32_t keepA, int32_t keepB) const { for (int b = 0; b < 3; b++) if (rowInBuf[b] != keepA && rowInBuf[b] != keepB) return b; return -1; }
     double *hPatch = nullptr, *dPatch = nullptr; size_t capPatch = 0;   // page-locked (bytes), written by the scoring launch of a search: the changed columns' scores, then the changed leaves' flags
     void *hMinor = nullptr; uint8_t *dMinor = nullptr; size_t capMinor = 0;   // [K][ldL] u8 minor-sequence flags, page-locked, written by the kernel (1 MB per row)
     hipStream_t copyStream = nullptr;

@@ -431,14 +431,16 @@ static void ahead_spec_body(maple_ctx *c, PlaceParams P, double bLen, int onlyId
     S.status = o.status[0] == -7 ? -7 : 0;
 }
 // main thread, at the end of a search that took a row: the traversal of the sample after it sets off
-static void ahead_spec_kick(maple_ctx *c, const PlaceParams &P, const maple_placement_params *pp)
+// (`row`: the sample after the one being searched -- the thread runs next to that search's own traversal, if it makes one, and
+// to everything the caller does until its maple_tree_patch)
+static void ahead_spec_kick(maple_ctx *c, int32_t row, const PlaceParams &P, const maple_placement_params *pp)
 {
     PlaceAhead &A = *c->ahead;
     const PlaceMeta &M = *c->place;
     A.join();
     A.spec.row = -1;
-    if (!A.active || c->tuning.noAheadSpeculation || A.rootDirty || !A.specStream || !A.hSpecPatch) return;
-    const int buf = A.rowInBuf[0] == A.next ? 0 : (A.rowInBuf[1] == A.next ? 1 : -1);
+    if (!A.active || row >= A.K || c->tuning.noAheadSpeculation || A.rootDirty || !A.specStream || !A.hSpecPatch) return;
+    const int buf = A.buf_of(row);
     if (buf < 0) return;                                                  // (its row is not on its way)
     auto uniq = [](std::vector<int32_t> &v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); };
     uniq(A.dirtyCols); uniq(A.dirtyLeaves);
@@ -449,10 +451,12 @@ static void ahead_spec_kick(maple_ctx *c, const PlaceParams &P, const maple_plac
     for (size_t i = 0; i < S.cols.size(); i++) S.lists[i] = M.h_candList[S.cols[i]];
     for (size_t i = 0; i < S.leafCols.size(); i++) S.leafLists[i] = M.h_leafList[S.leafCols[i]];
     S.touched.clear(); S.rootTouched = false;
-    S.row = A.next; S.buf = buf; S.id = ++A.specSeq; S.status = -1;
+    S.row = row; S.buf = buf; S.id = ++A.specSeq; S.status = -1;
     if (A.visitEpoch.size() < M.h_pn.size()) A.visitEpoch.resize(M.h_pn.size(), 0);
-    S.th = std::thread(ahead_spec_body, c, P, pp->oneMutBLen, (int)pp->onlyFindIdentical, c->dm.useRateVariation != 0, c->dm.usingErrorRate != 0,
-                       c->dm.errorRateSiteSpecific != 0);
+    try {
+        S.th = std::thread(ahead_spec_body, c, P, pp->oneMutBLen, (int)pp->onlyFindIdentical, c->dm.useRateVariation != 0, c->dm.usingErrorRate != 0,
+                           c->dm.errorRateSiteSpecific != 0);
+    } catch (...) { S.row = -1; }                                         // (no thread to be had: the search makes its traversal itself)
 }
 // ... and at the start of the next search: is the traversal made for this row good as it is?
 static bool ahead_spec_usable(maple_ctx *c)
@@ -478,19 +482,26 @@ static int ahead_refresh(maple_ctx *c, const double **rowOut, bool rowIsCurrent 
 {
     PlaceAhead &A = *c->ahead;
     PlaceMeta &M = *c->place;
-    if (rowIsCurrent) {                                                    // (a speculative traversal has used the row already: only what follows it)
-        const int buf = A.spec.buf;
-        if (A.next + 1 < A.K) {
-            const int nb = buf ^ 1;
-            HIPCK(c, hipMemcpyAsync(A.hRow[nb], A.dTable.p + (size_t)(A.next + 1) * A.ld, (size_t)A.ld * sizeof(double), hipMemcpyDeviceToHost, A.copyStream));
-            A.rowInBuf[nb] = A.next + 1;
+    // the rows of the two samples after this one set off (the device rows never change: no order to keep); a buffer is free if it
+    // holds neither this sample's row nor the next one's
+    auto prefetch = [&]() -> int {
+        for (int32_t r = A.next + 1; r <= A.next + 2 && r < A.K; r++) {
+            if (A.buf_of(r) >= 0) continue;
+            const int nb = A.free_buf(A.next, A.next + 1);
+            if (nb < 0) break;
+            HIPCK(c, hipMemcpyAsync(A.hRow[nb], A.dTable.p + (size_t)r * A.ld, (size_t)A.ld * sizeof(double), hipMemcpyDeviceToHost, A.copyStream));
+            A.rowInBuf[nb] = r;
         }
-        *rowOut = A.hRow[buf];
+        return MAPLE_OK;
+    };
+    if (rowIsCurrent) {                                                    // (a traversal made ahead has used the row already: only what follows it)
+        TRY(prefetch());
+        *rowOut = A.hRow[A.spec.buf];
         return MAPLE_OK;
     }
     auto uniq = [](std::vector<int32_t> &v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); };
     uniq(A.dirtyCols); uniq(A.dirtyLeaves);
-    int buf = A.rowInBuf[0] == A.next ? 0 : (A.rowInBuf[1] == A.next ? 1 : -1);
+    int buf = A.buf_of(A.next);
     const bool prefetched = buf >= 0;
     if (!prefetched) buf = 0;
     std::vector<int32_t> cols(A.dirtyCols), lists(A.dirtyCols.size());
@@ -531,12 +542,7 @@ static int ahead_refresh(maple_ctx *c, const double **rowOut, bool rowIsCurrent 
     for (size_t i = 0; i < n; i++) row[cols[i]] = A.hPatch[i];
     uint8_t *const mrow = (uint8_t *)A.hMinor + (size_t)A.next * A.ldL;
     for (size_t i = 0; i < nl; i++) mrow[A.dirtyLeaves[i]] = hPatchM[i];
-    // ... and the row of the sample after this one sets off (the device rows never change: no order to keep)
-    if (A.next + 1 < A.K) {
-        const int nb = buf ^ 1;
-        HIPCK(c, hipMemcpyAsync(A.hRow[nb], A.dTable.p + (size_t)(A.next + 1) * A.ld, (size_t)A.ld * sizeof(double), hipMemcpyDeviceToHost, A.copyStream));
-        A.rowInBuf[nb] = A.next + 1;
-    }
+    TRY(prefetch());
     *rowOut = row;
     return MAPLE_OK;
 }
@@ -667,7 +673,7 @@ extern "C" int maple_placement_ahead(maple_ctx *c, int32_t nQ, const int32_t *qL
         A.dSpecPatch = (double *)dps;
     }
     A.K = K; A.next = 0; A.pp = *pp;
-    A.rowInBuf[0] = A.rowInBuf[1] = -1;
+    A.rowInBuf[0] = A.rowInBuf[1] = A.rowInBuf[2] = -1;
     A.q.assign(qLists, qLists + K);
     A.dirtyCols.clear(); A.dirtyLeaves.clear(); A.rootDirty = false;
     TRY(h2d(c, A.dQ, A.q.data(), (size_t)K));
@@ -847,6 +853,11 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
         const double *aheadRow = nullptr;
         const bool specUse = ah && ahead_spec_usable(c);                   // (the traversal was made while the sample before was being placed)
         if (ah) TRY(ahead_refresh(c, &aheadRow, specUse));
+        // (the NEXT announced sample's traversal sets off now, next to this search's own work: it needs the columns changed up to the
+        // placement before this one -- known -- and its row, on its way since the search before)
+        std::vector<int32_t> specHi; std::vector<double> specHf; std::vector<uint8_t> specHb;
+        if (specUse) { specHi.swap(ah->spec.hi); specHf.swap(ah->spec.hf); specHb.swap(ah->spec.hb); }   // (this row's traversal, made ahead)
+        if (ah) ahead_spec_kick(c, ah->next + 1, P, pp);
         if (dbg) fprintf(stderr, "[maple]   %s\n", ah ? "rows made ahead: brought up to date" : "scoring launch");
         DevBuf<int32_t> &dU = c->p_i32[0];
         if (!ah) TRY(h2d(c, dU, U.data(), U.size()));
@@ -920,7 +931,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
             std::vector<double> stL(stackCap);
             std::vector<int16_t> stF(stackCap);
             std::vector<uint32_t> bits(words);
-            if (specUse) { hi = ah->spec.hi; hf = ah->spec.hf; hb = ah->spec.hb; }
+            if (specUse) { hi.swap(specHi); hf.swap(specHf); hb.swap(specHb); }
             for (int q = 0; q < nq && !specUse; q++) {
                 // per-query outputs are addressed [.. + q] inside, the work arrays as lane 0 of 1
                 PlaceOut oq = o;
@@ -940,11 +951,7 @@ static int placement_search_impl(maple_ctx *c, int32_t nQ, const int32_t *qLists
                     place_replay_ptr(c, M, P, hs, rootCol, hm, nF, oq, false);
                 }
             }
-            if (ah) {
-                ah->searches++; ah->next++;
-                if (ah->next >= ah->K) ah->active = false;
-                ahead_spec_kick(c, P, pp);                                  // (the next announced sample's traversal sets off)
-            }
+            if (ah) { ah->searches++; ah->next++; if (ah->next >= ah->K) ah->active = false; }
         } else {
             HIPCK(c, c->p_f64[0].reserve((size_t)nq * stackCap));         // per-depth lastLK
             HIPCK(c, c->p_i16.reserve((size_t)nq * stackCap));            // per-depth fails
