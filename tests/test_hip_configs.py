@@ -231,9 +231,19 @@ def test_config5_online_update_of_the_1M_tree(million):
     touched_all = []
     placed = checked = 0
     t_loop = time.time()
+    waiting, rest = [], []
     for k, lst in enumerate(new_lists):
         dev.placement_prepare(**pkw)
-        qid = int(dev.upload([lst])[0])
+        # (the loop as a maintainer would write it since round 6: the next 512 samples announced, maple_placement_ahead -- their
+        # rows made by expansion, the traversals made ahead; every search below is still ONE sample on the tree as it is then, and
+        # the checks against the oracle are the same)
+        if not waiting:
+            if not rest:
+                rest = [int(x) for x in dev.upload(new_lists[k: k + 512])]
+            got = dev.placement_ahead(np.asarray(rest, dtype=np.int32), **pkw)
+            got = got if got > 0 else len(rest)
+            waiting, rest = rest[:got], rest[got:]
+        qid = waiting.pop(0)
         mark = dev.mark()
         out = dev.placement_search_batch(np.asarray([qid], dtype=np.int32), **pkw)
         dev.release(mark)
@@ -291,7 +301,10 @@ def test_config5_online_update_of_the_1M_tree(million):
                 assert len(lt) == len(want_t) and all(x[0] == y[0] and x[1] == y[1] for x, y in zip(lt, want_t)), k
             checked += 1
     loop_s = time.time() - t_loop
+    ahead_stats = dev.placement_ahead_stats()
     assert placed > 0.95 * n_add and checked >= 0.85 * (n_add // every)
+    assert ahead_stats["searches"] == n_add and ahead_stats["fallbacks"] <= 0.05 * n_add, ahead_stats
+    assert ahead_stats["traversals_ahead_used"] > 0.5 * n_add, ahead_stats
     touched_all = np.unique(np.concatenate(touched_all))
     # lists that were never touched are the lists of the tree before; every node of the final tree has what it needs
     untouched = np.setdiff1d(np.arange(n0), touched_all)
@@ -317,5 +330,5 @@ def test_config5_online_update_of_the_1M_tree(million):
     n_ok, n_pl = check_sample_against_oracle(orc2, otree, nodes, gres, sel, kw)
     assert n_ok > 200
     print(f"config 5: {placed} samples added in {loop_s:.1f} s ({1e3 * loop_s / max(1, placed):.2f} ms per sample, {checked} checked against the "
-          f"oracle), {len(touched_all)} nodes touched; the round after it: {len(sel)} of {len(nodes)} searches equal the oracle's; "
+          f"oracle; rows made ahead: {ahead_stats}), {len(touched_all)} nodes touched; the round after it: {len(sel)} of {len(nodes)} searches equal the oracle's; "
           f"{time.time() - t0:.0f} s")

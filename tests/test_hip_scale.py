@@ -812,6 +812,21 @@ def test_frontier_tier_on_a_tree_with_local_references_equals_the_lane_tier(mode
             for k in ("status", "bestNode", "placement", "nAppend", "bestScore", "currentLK", "improvement", "blen"):
                 assert np.array_equal(g[k], lane[k]), (budget, k, int((g[k] != lane[k]).sum()))
     assert (g["status"] == 0).sum() > 15000 and g["nAppend"].sum() > 1e7
+    if mode == "unrest":
+        # bestRemovedPartials (M:7720: the removed list in the best branch's frame, as the reference's in-place shorten() left it):
+        # the two tiers hand back the same list, entry for entry -- also where a list was shortened on the way and re-expressed
+        # from its shortened form afterwards (k_fr_replay hands such a search to the one-lane kernel: the event item's own
+        # children included since round 6)
+        mark = dev.mark()
+        a = dev.spr_search_batch(nodes, want_removed_partials=True, **kw)
+        la = dev.download(a["removedPartials"][a["removedPartials"] >= 0])
+        have_a = a["removedPartials"] >= 0
+        dev.release(mark)
+        b = dev.spr_search_batch(nodes, search_tier=1, want_removed_partials=True, **kw)
+        assert np.array_equal(have_a, b["removedPartials"] >= 0) and have_a.sum() > 1000
+        lb = dev.download(b["removedPartials"][b["removedPartials"] >= 0])
+        assert la == lb
+        dev.release(mark)
     dev.close()
 
 
