@@ -19,6 +19,12 @@ search itself) of all ranks in the K timed steps / wall time (max over ranks).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  Everything the searches read is resident in HBM before the timed region starts.
+
+Next to the headline the default run has (rank 0, N = 1): a second leg on BASELINE configs[3]'s tree (`config_1M`: 1 000 000
+samples, full model, 131 072 searches per step), a third on configs[4] (`config_5`: 50 000 samples added to that tree one after the
+other -- the serial placement loop with its samples announced, maple_placement_ahead -- then a round), a whole round on a
+changing tree at the headline's size (`changing_tree`: search, every proposed move re-searched and applied, the next round),
+`tree_log_lk` against the oracle and `cpu_baseline`; everything else goes to bench_detail.json.
 """
 import argparse
 import glob

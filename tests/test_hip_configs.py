@@ -10,8 +10,8 @@ searches over the WHOLE downloaded tree, plus properties that do not depend on t
 * configs[3]: 1 000 000 samples, UNREST + per-site rates + per-site error rates: 16 384 evenly spread searches, every 48th
   against the oracle, the same properties;
 * configs[4]: the online update at its stated size: 50 000 new samples added one after the other to the 1 000 000-tip tree
-  (placement search, tree edit, maple_update_partials, maple_tree_patch), then a deep round over every node the additions
-  touched and 8 192 others -- see the test.
+  (placement search -- the samples announced 512 at a time, maple_placement_ahead --, tree edit, maple_update_partials,
+  maple_tree_patch), then a deep round over an even sample of the nodes the additions touched and 8 192 others -- see the test.
 """
 import math
 import os
