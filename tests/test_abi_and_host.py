@@ -318,3 +318,41 @@ def test_native_generator_and_packed_tip_lists_match_the_python_forms():
         want = pack_lists([tip_genome_list(c[i], ref_idx, **kw) for i in range(len(c))], bool(kw))
         for a in ("ent_off", "pos", "meta", "aux_off", "aux"):
             assert np.array_equal(getattr(got, a), getattr(want, a)), (kw.keys(), a)
+
+
+def test_depth_numbering_of_the_serial_loop_keeps_room_and_renumbers():
+    """bench.tree_depths / place_depths (the depths maple_update_partials compares): a node put on a branch gets a depth strictly
+    between its neighbours', a new tip one below its parent with room for a later node above it, and the tree is numbered again
+    when a branch has no depth left -- checked on a random tree with thousands of placements piled onto the same branches."""
+    import bench
+    rng = np.random.default_rng(1)
+    n_tips = 150
+    cap = 2 * n_tips - 1 + 2 * 2000
+    up, c0, c1 = (np.full(cap, -1, np.int32) for _ in range(3))
+    nodes, nxt = list(range(n_tips)), n_tips
+    while len(nodes) > 1:
+        i, j = (int(x) for x in rng.choice(len(nodes), 2, replace=False))
+        a, b = nodes[i], nodes[j]
+        up[a] = up[b] = nxt
+        c0[nxt], c1[nxt] = a, b
+        nodes = [x for k, x in enumerate(nodes) if k not in (i, j)] + [nxt]
+        nxt += 1
+    root, n = nodes[0], 2 * n_tips - 1
+    depth, step = bench.tree_depths(root, c0, c1, n, cap)
+    assert step >= bench.DEPTH_STEP and depth[root] == 0
+    renumbered = 0
+    for k in range(2000):
+        b = 0 if k % 2 == 0 else n - 1                                 # the same tip again and again / the sample added last
+        g, p, s = int(up[b]), n, n + 1
+        before = depth
+        depth, step = bench.place_depths(depth, step, g, p, b, s, root, c0, c1, n)
+        renumbered += depth is not before
+        if c0[g] == b:
+            c0[g] = p
+        else:
+            c1[g] = p
+        up[p], c0[p], c1[p], up[b], up[s] = g, b, s, p, p
+        n += 2
+        assert depth[g] < depth[p] < depth[b] and depth[p] < depth[s]
+    ch = np.nonzero(up[:n] >= 0)[0]
+    assert (depth[ch] > depth[up[ch]]).all() and renumbered > 0

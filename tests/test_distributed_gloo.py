@@ -34,6 +34,11 @@ def _worker(rank, world, port, q):
     mine = np.arange(n)[rank::world]
     rec = pack_proposals(mine, placement_all[mine], improvement_all[mine])
     moves = gather_proposals(rec)
+    # ... and with the fixed-size blocks of a round (cap = the largest shard of searched nodes: ONE collective, no count exchange)
+    moves_cap = gather_proposals(rec, cap=len(np.arange(n)[0::world]))
+    assert moves_cap == moves
+    empty = gather_proposals(np.zeros((0, 3)), cap=4)                     # (nobody proposes a move)
+    assert empty == []
     q.put((rank, moves))
     dist.destroy_process_group()
 
